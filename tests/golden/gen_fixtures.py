@@ -1,0 +1,380 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+Usage (from the repo root, in the build container where /root/reference exists):
+
+    python tests/golden/gen_fixtures.py [group ...]
+
+The reference is imported from /root/reference/src with a stand-in `loguru`
+logger (its only missing dependency on this path; the shim is written to a temp
+dir and contains no reference code).  Torch-level functions run natively on CPU;
+Triton kernels run under TRITON_INTERPRET=1 on float32 tensors that hold
+bf16-representable values (bf16 tensors are unsupported by the interpreter).
+
+Only the resulting *data* (inputs + expected outputs, .npz) is committed under
+tests/golden/.  Nothing of the reference travels to the GPU box.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+from types import SimpleNamespace
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+_SHIM = '''
+import sys
+class _L:
+    def debug(self, *a, **k): pass
+    def info(self, *a, **k): pass
+    def warning(self, m, *a, **k): pass
+    def error(self, m, *a, **k): sys.stderr.write(f"[E] {m}\\n")
+    exception = error
+    def remove(self, *a, **k): pass
+    def add(self, *a, **k): return 0
+    def bind(self, **k): return self
+    def opt(self, **k): return self
+    def log(self, *a, **k): pass
+logger = _L()
+'''
+
+
+def _bootstrap():
+    shim_dir = tempfile.mkdtemp(prefix="svk_shim_")
+    os.makedirs(os.path.join(shim_dir, "loguru"))
+    with open(os.path.join(shim_dir, "loguru", "__init__.py"), "w") as f:
+        f.write(_SHIM)
+    os.environ.setdefault("SPARSEVLLM_PLATFORM", "cpu")
+    os.environ.setdefault("TRITON_INTERPRET", "1")
+    sys.dont_write_bytecode = True
+    sys.path[:0] = ["/root/reference/src", "/root/reference", shim_dir]
+
+
+_bootstrap()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def bf16f(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    """float32 tensor holding bf16 values -> uint16 bit patterns (compact storage)."""
+    return (t.contiguous().view(torch.int32).numpy().view(np.uint32) >> 16).astype(np.uint16)
+
+
+def save(name: str, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------------
+# decode attention (Triton interpreter)
+# ----------------------------------------------------------------------------------
+
+def gen_decode():
+    from sparsevllm.kernels.triton.gqa_flash_decoding_stage1 import (
+        flash_decode_stage1, flash_decode_stage1_with_score)
+    from sparsevllm.kernels.triton.flash_decoding_stage2 import flash_decode_stage2
+
+    out = {}
+    cases = [
+        # name, B, Hq, Hkv, D, slots, lens, rows, maxlen_table, block_seq, score mode
+        ("a", 2, 28, 4, 128, 224, (150, 37), (1, 3), 160, 64, "2d"),
+        ("b", 3, 8, 2, 64, 512, (200, 129, 1), (0, 2, 1), 256, 32, "3d"),
+        ("c", 2, 28, 4, 128, 272, (97, 160), (2, 0), 160, 256, "none"),
+        ("d", 2, 14, 2, 64, 300, (64, 48), (1, 0), 128, 16, "2d"),
+    ]
+    g = torch.Generator().manual_seed(20260625)
+    for (name, B, Hq, Hkv, D, slots, lens, rows, cap, block_seq, mode) in cases:
+        q = bf16f(torch.randn(B, Hq, D, generator=g) * 0.5)
+        k = bf16f(torch.randn(slots, Hkv, D, generator=g) * 0.5)
+        v = bf16f(torch.randn(slots, Hkv, D, generator=g) * 0.5)
+        req = torch.zeros(max(rows) + 1, cap, dtype=torch.int32)
+        perm = torch.randperm(slots, generator=g).to(torch.int32)
+        off = 0
+        for b in range(B):
+            req[rows[b], : lens[b]] = perm[off: off + lens[b]]
+            off += lens[b]
+        bidx = torch.tensor(rows, dtype=torch.int32)
+        blen = torch.tensor(lens, dtype=torch.int32)
+        max_len = max(lens)
+        nblk = (max_len + block_seq - 1) // block_seq
+        mid = torch.zeros(B, Hq, nblk, D)
+        lse = torch.zeros(B, Hq, nblk)
+        if mode == "2d":
+            score = torch.full((B, max_len), -1e20)
+            flash_decode_stage1_with_score(q, k, v, req, bidx, blen, max_len, mid, lse, score, block_seq)
+        elif mode == "3d":
+            score = torch.full((B, Hq, max_len), -1e20)
+            flash_decode_stage1_with_score(q, k, v, req, bidx, blen, max_len, mid, lse, score, block_seq)
+        else:
+            score = torch.zeros(1)
+            flash_decode_stage1(q, k, v, req, bidx, blen, max_len, mid, lse, block_seq)
+        o = torch.empty_like(q)
+        flash_decode_stage2(mid, lse, blen, o, block_seq)
+        out.update({
+            f"{name}_q": bits(q), f"{name}_k": bits(k), f"{name}_v": bits(v),
+            f"{name}_req": req.numpy(), f"{name}_bidx": bidx.numpy(), f"{name}_blen": blen.numpy(),
+            f"{name}_meta": np.array([max_len, block_seq, {"none": 0, "2d": 2, "3d": 3}[mode]], dtype=np.int64),
+            f"{name}_mid_o": mid.numpy(), f"{name}_mid_lse": lse.numpy(),
+            f"{name}_score": score.numpy(), f"{name}_o": o.numpy(),
+        })
+    save("decode_attention", **out)
+
+
+# ----------------------------------------------------------------------------------
+# H2O selection / scores (torch on CPU)
+# ----------------------------------------------------------------------------------
+
+def gen_h2o_select():
+    from sparsevllm.engine.cache_manager.h2o import H2OCacheManager as M
+
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    # known answer from the reference's own unit test (tests/test_h2o_cache_manager.py:290-293)
+    ka = torch.tensor([1.0, 9.0, 2.0, 8.0, 3.0, 0.0, 0.0, 0.0])
+    out["ka_scores"] = ka.numpy()
+    out["ka_keep"] = M.select_h2o_indices(ka, budget=4, recent_ratio=0.5).numpy()
+    cases = [
+        ("u", torch.rand(6, 300, generator=g), 64, 0.5),
+        ("ties", torch.randint(0, 7, (5, 257), generator=g).float() / 4.0, 100, 0.5),
+        ("short", torch.rand(3, 40, generator=g), 64, 0.5),
+        ("ratio", torch.rand(4, 999, generator=g), 333, 0.1),
+        ("zeros", torch.cat([torch.zeros(2, 50), -torch.zeros(2, 50), torch.rand(2, 100, generator=g)], 1), 120, 0.25),
+        ("softmaxlike", torch.softmax(torch.randn(4, 4224, generator=g) * 3, -1) + torch.rand(4, 4224, generator=g), 4096, 0.5),
+        ("allrecent", torch.rand(2, 10, generator=g), 1, 0.5),
+    ]
+    for name, s, budget, ratio in cases:
+        keep = M.select_h2o_indices_batch(s, budget=budget, recent_ratio=ratio)
+        keep1 = torch.stack([M.select_h2o_indices(r, budget=budget, recent_ratio=ratio) for r in s])
+        assert torch.equal(keep, keep1)
+        out[f"{name}_scores"] = s.numpy()
+        out[f"{name}_cfg"] = np.array([budget, ratio], dtype=np.float64)
+        out[f"{name}_keep"] = keep.numpy()
+    save("h2o_select", **out)
+
+
+def gen_h2o_scores():
+    from sparsevllm.engine.cache_manager.h2o import H2OCacheManager as M
+
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # decode normalisation exactly as sparse_controller.py:766-767
+    B, W, D = 3, 200, 128
+    raw = torch.full((B, W), -1e20)
+    lens = [200, 150, 7]
+    for b, L in enumerate(lens):
+        raw[b, :L] = torch.randn(L, generator=g) * 6
+    out["norm_raw"] = raw.numpy().copy()
+    x = raw.clone()
+    x.mul_(float(D) ** -0.5)
+    torch.softmax(x, dim=-1, out=x)
+    out["norm_out"] = x.numpy()
+    out["norm_meta"] = np.array([D], dtype=np.int64)
+
+    # accumulate (h2o.py:610-626) incl. the reference unit-test numbers (:400-452 style)
+    prev = torch.rand(37, generator=g)
+    step = torch.rand(64, generator=g)
+    out["acc_prev"] = prev.numpy()
+    out["acc_step"] = step.numpy()
+    out["acc_out"] = M._accumulate_score(prev, step, new_len=50, weight=128.0).numpy()
+    out["acc_out_none"] = M._accumulate_score(None, step, new_len=20, weight=3.0).numpy()
+
+    # logits-mode normalisation (h2o.py:628-655)
+    lg = torch.randn(80, generator=g) * 4
+    lg[10:20] = float("-inf")
+    out["logit_in"] = lg.numpy()
+    out["logit_out"] = M._normalize_logit_prefill_score(lg, new_len=64).numpy()
+    save("h2o_scores", **out)
+
+
+# ----------------------------------------------------------------------------------
+# manager-level state transitions (slot table / free stack / scores)
+# ----------------------------------------------------------------------------------
+
+def _make_manager(lengths_by_layer, *, cap=96, nslots=1024, budget=8, interval=4, prefill_budget=16,
+                  heads=2, dim=4, slot_seed=3, free_ptr=None, cls_name="H2OCacheManager"):
+    """Hand-built H2OCacheManager (no engine), same attribute recipe the reference's
+    unit tests use (tests/test_h2o_cache_manager.py:49-138), with a *shared* layer-major
+    slot table / free-stack tensor so the fused batch-layers paths are exercised."""
+    from sparsevllm.engine.cache_manager.h2o import H2OCacheManager
+    from sparsevllm.engine.cache_manager.snapkv import SnapKVCacheManager
+    from sparsevllm.method_registry import PREFILL_POLICY_ALL_CHUNKED
+
+    L = len(lengths_by_layer)
+    B = len(lengths_by_layer[0])
+    m = object.__new__({"H2OCacheManager": H2OCacheManager, "SnapKVCacheManager": SnapKVCacheManager}[cls_name])
+    m.device = torch.device("cpu")
+    m.num_layers = L
+    m.num_kv_layers = L
+    m.runtime_layout = SimpleNamespace(
+        kv_idx_to_layer_idx=tuple(range(L)),
+        kv_layer_index=lambda layer: int(layer),
+        is_full_attention=lambda layer: 0 <= int(layer) < L,
+    )
+    m.config = SimpleNamespace(
+        vllm_sparse_method="h2o", h2o_decode_budget=budget, h2o_decode_eviction_interval=interval,
+        h2o_prefill_budget=prefill_budget, h2o_recent_ratio=0.5, h2o_prefill_score_window=4,
+        sparse_prefill_score_mode="probability", max_model_len=cap, snapkv_window_size=4,
+        snapkv_num_full_layers=0, pyramid_layer_ratios=None,
+        prefill_schedule_policy=PREFILL_POLICY_ALL_CHUNKED, chunk_prefill_size=4,
+        validate_runtime_invariants=False, num_kvcache_slots=nslots,
+    )
+    m.validate_runtime_invariants = False
+    m.max_model_len = cap
+    m.num_kv_heads = heads
+    m.head_dim = dim
+    m.hf_config = SimpleNamespace(torch_dtype=torch.float32)
+    m._h2o_scores = {}
+    m._h2o_active_decode_seq_ids = set()
+    m._h2o_counters = {k: 0 for k in ("intermediate_prefill_evictions", "final_prefill_evictions",
+                                      "decode_eviction_bursts", "decode_evictions", "dropped_tokens")}
+    m._h2o_final_prefill_workspace = None
+    m._uniform_decode_metadata = False
+    m.seq_id_to_row = [{i: i for i in range(B)} for _ in range(L)]
+    m.row_seq_lens = [np.asarray(x, dtype=np.int32) for x in lengths_by_layer]
+    m.buffer_req_to_token_slots_tensor = torch.zeros((L, B, cap), dtype=torch.int32)
+    m.buffer_req_to_token_slots = [m.buffer_req_to_token_slots_tensor[i] for i in range(L)]
+    g = torch.Generator().manual_seed(slot_seed)
+    m.free_slots_stack_tensor = torch.zeros((L, nslots), dtype=torch.int32)
+    m.free_slots_stack = [m.free_slots_stack_tensor[i] for i in range(L)]
+    m._num_free_slots = []
+    for li, lengths in enumerate(lengths_by_layer):
+        perm = torch.randperm(nslots, generator=g).to(torch.int32)
+        used = 0
+        for r, n in enumerate(lengths):
+            m.buffer_req_to_token_slots[li][r, :n] = perm[used: used + n]
+            used += n
+        nfree = nslots - used if free_ptr is None else free_ptr
+        m.free_slots_stack[li][:nfree] = perm[used: used + nfree]
+        m._num_free_slots.append(int(nfree))
+    m.kv_cache = torch.zeros((2, L, nslots, heads, dim), dtype=torch.float32)
+    m.attention_cache_storage = None
+    return m
+
+
+def _state(m):
+    return dict(
+        slot_table=m.buffer_req_to_token_slots_tensor.numpy().copy(),
+        free_stack=m.free_slots_stack_tensor.numpy().copy(),
+        free_ptr=np.asarray(m._num_free_slots, dtype=np.int64),
+        row_len=np.stack(m.row_seq_lens).astype(np.int32),
+    )
+
+
+def _put(out, prefix, st):
+    for k_, v_ in st.items():
+        out[f"{prefix}_{k_}"] = v_
+
+
+def gen_compaction():
+    from sparsevllm.engine.cache_manager.snapkv import SnapKVCacheManager
+    from sparsevllm.engine.cache_manager.h2o import H2OCacheManager
+
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    seqs = lambda n: [SimpleNamespace(seq_id=i, is_last_chunk_prefill=True) for i in range(n)]
+
+    # (1) fused batch-layers compaction, uniform lengths
+    L, B, cur, K = 3, 4, 40, 25
+    m = _make_manager([[cur] * B] * L)
+    keep = torch.stack([torch.stack([torch.randperm(cur, generator=g)[:K] for _ in range(B)]) for _ in range(L)])
+    _put(out, "bl_before", _state(m))
+    out["bl_keep"] = keep.numpy()
+    SnapKVCacheManager.free_part_slots_batch_layers(m, list(range(L)), seqs(B), keep, keep_indices_sorted=False)
+    _put(out, "bl_after", _state(m))
+
+    # (2) non-uniform lengths -> per-row fallback order
+    m = _make_manager([[30, 22, 30], [30, 22, 30]], cls_name="SnapKVCacheManager")
+    keep = torch.stack([torch.stack([torch.sort(torch.randperm(22, generator=g)[:10]).values for _ in range(3)]) for _ in range(2)])
+    _put(out, "nu_before", _state(m))
+    out["nu_keep"] = keep.numpy()
+    SnapKVCacheManager.free_part_slots_batch_layers(m, [0, 1], seqs(3), keep, keep_indices_sorted=True)
+    _put(out, "nu_after", _state(m))
+
+    # (3) StreamingLLM sink+recent compaction
+    m = _make_manager([[50] * 3] * 2)
+    _put(out, "sr_before", _state(m))
+    out["sr_cfg"] = np.array([50, 4, 16], dtype=np.int64)
+    SnapKVCacheManager.free_prefix_recent_slots_batch_layers(
+        m, [0, 1], seqs(3), kv_len=50, num_sink_tokens=4, num_recent_tokens=16)
+    _put(out, "sr_after", _state(m))
+
+    # (4) final-prefill dense compaction (K/V payload moves)
+    budget = 8
+    m = _make_manager([[20] * 3], budget=budget, heads=2, dim=4)
+    m.kv_cache.copy_(torch.randn(m.kv_cache.shape, generator=g))
+    keep = torch.stack([torch.sort(torch.randperm(20, generator=g)[:budget]).values for _ in range(3)])
+    _put(out, "fp_before", _state(m))
+    out["fp_keep"] = keep.numpy()
+    out["fp_kv_before"] = m.kv_cache.numpy().copy()
+    m.get_layer_kv_cache = lambda layer_idx: (m.kv_cache[0, layer_idx], m.kv_cache[1, layer_idx])
+    H2OCacheManager._compact_final_prefill_dense_batch(m, 0, seqs(3), keep)
+    _put(out, "fp_after", _state(m))
+    out["fp_kv_after"] = m.kv_cache.numpy().copy()
+    out["fp_cfg"] = np.array([budget], dtype=np.int64)
+    save("compaction", **out)
+
+
+def gen_h2o_burst():
+    """Whole decode bursts through H2OCacheManager._evict_decode_rows (h2o.py:1558-1625)
+    incl. the slot-pressure trigger and unscheduled active rows (h2o.py:1498-1538)."""
+    out = {}
+    g = torch.Generator().manual_seed(9)
+    budget, interval = 8, 4
+
+    def run(tag, lens, scheduled, active, free_ptr):
+        L = 2
+        m = _make_manager([list(lens)] * L, budget=budget, interval=interval, free_ptr=free_ptr)
+        for l in range(L):
+            for r, n in enumerate(lens):
+                # coarse values -> guaranteed ties
+                m._h2o_scores[(l, r)] = (torch.randint(0, 6, (n,), generator=g).float() / 3.0
+                                         + (torch.rand(n, generator=g) > 0.7).float() * torch.rand(n, generator=g))
+        m._h2o_active_decode_seq_ids = set(active)
+        _put(out, f"{tag}_before", _state(m))
+        for l in range(L):
+            for r, n in enumerate(lens):
+                out[f"{tag}_score_before_{l}_{r}"] = m._h2o_scores[(l, r)].numpy().copy()
+        m._evict_decode_rows([SimpleNamespace(seq_id=i) for i in scheduled])
+        _put(out, f"{tag}_after", _state(m))
+        for l in range(L):
+            for r, n in enumerate(lens):
+                out[f"{tag}_score_after_{l}_{r}"] = m._h2o_scores[(l, r)].numpy().copy()
+        out[f"{tag}_cfg"] = np.array([budget, interval, free_ptr], dtype=np.int64)
+        out[f"{tag}_scheduled"] = np.array(scheduled, dtype=np.int64)
+        out[f"{tag}_active"] = np.array(sorted(active), dtype=np.int64)
+        out[f"{tag}_counters"] = np.array([m._h2o_counters[k] for k in
+                                           ("decode_eviction_bursts", "decode_evictions", "dropped_tokens")], dtype=np.int64)
+
+    run("periodic", (12, 12, 9, 12), [0, 1, 2, 3], {0, 1, 2, 3}, 100)
+    run("pressure", (12, 9, 10, 11), [0, 1], {0, 1, 2, 3}, 0)
+    run("noop", (11, 10, 9, 8), [0, 1, 2, 3], {0, 1, 2, 3}, 50)
+    save("h2o_burst", **out)
+
+
+GROUPS = {
+    "decode": gen_decode,
+    "h2o_select": gen_h2o_select,
+    "h2o_scores": gen_h2o_scores,
+    "compaction": gen_compaction,
+    "h2o_burst": gen_h2o_burst,
+}
+
+
+def main(argv):
+    names = argv or list(GROUPS)
+    for n in names:
+        GROUPS[n]()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
