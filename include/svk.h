@@ -1,0 +1,243 @@
+/*
+ * svk.h - C ABI of the MI355X (gfx950) sparse paged-attention hot path.
+ *
+ * This is the drop-in boundary of the rebuild of CURRENTF/Sparse-vLLM's sparse
+ * decode/prefill-selection path.  The reference has no FFI of its own (its device
+ * code is Triton called from Python); every entry point below replaces one
+ * reference operator and cites it (paths relative to the reference's
+ * src/sparsevllm/).  The Python host side (sparse_vllm_amd/) binds these with
+ * ctypes and re-exposes the reference's own names and argument order; a
+ * maintainer of the reference binds them the same way.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers unless a field is documented "host".
+ *  - Every call only enqueues work on `stream` (a hipStream_t passed as void*):
+ *    no allocation, no synchronisation, no host read-back -> hipGraph-capture safe.
+ *  - Tensors are dense in their last dimension; other strides are given in
+ *    ELEMENTS where a *_stride field exists, otherwise the layout is contiguous.
+ *  - bf16 tensors are `uint16_t` bit patterns (torch.bfloat16 storage).
+ *  - Return value: SVK_OK or a negative SvkStatus; svk_last_error() returns a
+ *    thread-local message.  The host wrapper maps SVK_ERR_VALUE -> ValueError,
+ *    SVK_ERR_LAYOUT -> AssertionError, SVK_ERR_STATE/SVK_ERR_LAUNCH -> RuntimeError
+ *    (the reference's own exception classes for the same conditions).
+ */
+#ifndef SVK_H_
+#define SVK_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* svk_stream_t; /* hipStream_t */
+
+typedef enum SvkStatus {
+  SVK_OK = 0,
+  SVK_ERR_VALUE = -1,   /* bad argument value/shape            -> ValueError     */
+  SVK_ERR_LAYOUT = -2,  /* unsupported layout / head config    -> AssertionError */
+  SVK_ERR_STATE = -3,   /* invariant of the cache state broken -> RuntimeError   */
+  SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
+} SvkStatus;
+
+#define SVK_ABI_VERSION 1
+
+int svk_abi_version(void);
+const char* svk_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * KV payload
+ * ---------------------------------------------------------------------------------- */
+
+/* store_kvcache: cache[slot_mapping[i]] = kv[i], rows with slot == -1 skipped.
+ * Replaces kernels/triton/store_kvcache.py:10-71 (store_kvcache_kernel / store_kvcache),
+ * called from engine/cache_manager/base.py:674-694 (_store_layer_kv). */
+typedef struct SvkStoreKvcacheArgs {
+  const uint16_t* key;          /* [n_tokens, Hkv*D] bf16, row stride key_stride   */
+  const uint16_t* value;        /* [n_tokens, Hkv*D] bf16, row stride value_stride */
+  uint16_t* k_cache;            /* [slots, Hkv*D] bf16 contiguous                  */
+  uint16_t* v_cache;            /* [slots, Hkv*D] bf16 contiguous                  */
+  const int32_t* slot_mapping;  /* [n_tokens]                                      */
+  int64_t key_stride;
+  int64_t value_stride;
+  int32_t n_tokens;
+  int32_t row_elems;            /* Hkv*D, multiple of 8                            */
+} SvkStoreKvcacheArgs;
+int svk_store_kvcache(const SvkStoreKvcacheArgs* a, svk_stream_t stream);
+
+/* copy_slots: cache[dst[i]] = cache[src[i]] for K and V through a caller-owned
+ * workspace (gather all, then scatter all => safe when src and dst sets overlap).
+ * Replaces the K/V move of H2OCacheManager._compact_final_prefill_dense_batch,
+ * engine/cache_manager/h2o.py:1296-1329 (index_select -> workspace -> index_copy_)
+ * and ExplicitKVStorage.copy_slots, engine/cache_manager/storage/explicit_kv.py:150-203. */
+typedef struct SvkCopySlotsArgs {
+  uint16_t* k_cache;
+  uint16_t* v_cache;
+  const int64_t* src_slots;  /* [n] */
+  const int64_t* dst_slots;  /* [n] */
+  uint16_t* workspace;       /* [2, n, row_elems] bf16 */
+  int32_t n;
+  int32_t row_elems;
+} SvkCopySlotsArgs;
+int svk_copy_slots(const SvkCopySlotsArgs* a, svk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Decode attention (split-KV, GQA) with fused token scores
+ * ---------------------------------------------------------------------------------- */
+
+#define SVK_SCORE_NONE 0     /* flash_decode_stage1                                   */
+#define SVK_SCORE_HEADMAX 2  /* 2-D attn_score [B, W]: max over q heads of raw q.k    */
+#define SVK_SCORE_PERHEAD 3  /* 3-D attn_score [B, Hq, W]: raw q.k per head           */
+
+/* Stage 1.  Replaces kernels/triton/gqa_flash_decoding_stage1.py:
+ *   flash_decode_stage1            :329-394 (kernel :6-121)
+ *   flash_decode_stage1_with_score :397-445 (kernels :124-208 3-D, :211-295 2-D)
+ * Same math: per (batch, kv head, block_seq block) online-softmax partials
+ * mid_o = acc / sum_exp, mid_lse = max + log(sum_exp); empty blocks write (0, -inf);
+ * scores are raw logits (before 1/sqrt(D)), 2-D scores are max-combined with what the
+ * buffer already holds (the reference pre-fills -1e20 and uses atomic_max).
+ * P is rounded to bf16 before P.V like `exp_logic.to(v.dtype)` (:280). */
+typedef struct SvkFlashDecodeStage1Args {
+  const uint16_t* q;             /* [B, Hq, D] bf16                                      */
+  const uint16_t* k_cache;       /* [slots, Hkv, D] bf16, slot stride kv_slot_stride     */
+  const uint16_t* v_cache;       /* same layout as k_cache                               */
+  const int32_t* req_to_tokens;  /* [rows, req_stride] slot table                        */
+  const int32_t* b_req_idx;      /* [B] row of the slot table per batch lane             */
+  const int32_t* b_seqlen;       /* [B] valid tokens per lane                            */
+  float* mid_o;                  /* [B, Hq, nblk, D] f32, strides below                  */
+  float* mid_lse;                /* [B, Hq, nblk] f32                                    */
+  float* attn_score;             /* NULL, [B, W] or [B, Hq, W] f32                       */
+  int64_t q_stride_b, q_stride_h;
+  int64_t kv_slot_stride;        /* elements between consecutive slots (>= Hkv*D)        */
+  int64_t kv_head_stride;        /* elements between kv heads of one slot (>= D)         */
+  int64_t req_stride;
+  int64_t mid_o_stride_b, mid_o_stride_h, mid_o_stride_s;
+  int64_t mid_lse_stride_b, mid_lse_stride_h;
+  int64_t score_stride_b, score_stride_h;
+  int32_t batch;
+  int32_t num_q_heads;
+  int32_t num_kv_heads;
+  int32_t head_dim;              /* 64 or 128                                            */
+  int32_t max_len_in_batch;      /* grid covers ceil(max_len/block_seq) blocks           */
+  int32_t block_seq;             /* multiple of 16                                       */
+  int32_t score_mode;            /* SVK_SCORE_*                                          */
+} SvkFlashDecodeStage1Args;
+int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_stream_t stream);
+
+/* Stage 2: LSE-weighted merge of the partials into O (bf16).
+ * Replaces kernels/triton/flash_decoding_stage2.py:49-81 (kernel :8-46). */
+typedef struct SvkFlashDecodeStage2Args {
+  const float* mid_o;
+  const float* mid_lse;
+  const int32_t* b_seqlen;
+  uint16_t* o;                   /* [B, Hq, D] bf16 */
+  int64_t mid_o_stride_b, mid_o_stride_h, mid_o_stride_s;
+  int64_t mid_lse_stride_b, mid_lse_stride_h;
+  int64_t o_stride_b, o_stride_h;
+  int32_t batch, num_q_heads, head_dim, block_seq;
+} SvkFlashDecodeStage2Args;
+int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * H2O scores
+ * ---------------------------------------------------------------------------------- */
+
+/* Fill the per-step raw-score scratch with -1e20.
+ * Replaces SparseController._get_h2o_decode_score_buffer `view.fill_(-1e20)`,
+ * engine/sparse_controller.py:427-461. */
+int svk_fill_f32(float* dst, int64_t n, float value, svk_stream_t stream);
+
+/* In-place `x *= scale; softmax(x, dim=-1)` over the full row width (padding -1e20
+ * underflows to exactly 0), optionally fused with the cumulative-score update
+ *   cum[row(b), t] = cum[row(b), t] + x[b, t]   for t < len(b)  (new token: 0 + x)
+ * Replaces SparseController.on_layer_attention_end, engine/sparse_controller.py:762-767,
+ * and H2OCacheManager.update_decode_attention_scores{,_all_layers},
+ * engine/cache_manager/h2o.py:897-1038 (pad(prev,1) + normalized[:kv_len]). */
+typedef struct SvkH2oDecodeScoreArgs {
+  float* attn_score;        /* [B, width] raw head-max logits in, probabilities out      */
+  float* cum_score;         /* NULL or [rows, cum_stride] persistent cumulative scores   */
+  const int32_t* b_req_idx; /* [B] (used when cum_score != NULL)                         */
+  const int32_t* b_seqlen;  /* [B] current physical length incl. the new token          */
+  int64_t score_stride_b;
+  int64_t cum_stride;
+  float scale;              /* head_dim ** -0.5                                          */
+  int32_t batch;
+  int32_t width;
+} SvkH2oDecodeScoreArgs;
+int svk_h2o_decode_score_update(const SvkH2oDecodeScoreArgs* a, svk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * H2O selection + slot-table compaction
+ * ---------------------------------------------------------------------------------- */
+
+/* keep = sort(top-`heavy` of scores[:recent_start] by (score desc, index asc)
+ *             ++ [recent_start, kv_len)),  heavy = budget - recent_count.
+ * Bit-exact restatement of H2OCacheManager.select_h2o_indices{,_batch},
+ * engine/cache_manager/h2o.py:478-563 (stable descending argsort => ties keep the
+ * lower index).  Rows with kv_len <= budget return arange(kv_len) (keep_len = kv_len).
+ * NaN scores are not supported (the reference asserts finiteness upstream). */
+typedef struct SvkH2oSelectArgs {
+  const float* scores;   /* [rows, score_stride]                                   */
+  int64_t* keep;         /* [rows, keep_stride] int64 (torch.long), ascending     */
+  int64_t score_stride;
+  int64_t keep_stride;
+  int32_t rows;
+  int32_t kv_len;
+  int32_t budget;
+  int32_t recent_count;  /* host: min(max(1, int(budget*ratio)), budget, kv_len)  */
+} SvkH2oSelectArgs;
+int svk_h2o_select_indices(const SvkH2oSelectArgs* a, svk_stream_t stream);
+
+/* Slot-table compaction for a batch of (layer, row) pairs of one uniform length:
+ *   new_row = old_row[keep]; dropped slots (ascending position) are appended to the
+ *   layer's free stack at free_base[layer] + lane * (cur_len - keep_len);
+ *   row[keep_len:cur_len] = 0; optional per-row f32 payload (H2O cumulative scores)
+ *   is gathered with the same keep.
+ * Replaces SnapKVCacheManager.free_part_slots{,_batch,_batch_layers},
+ * engine/cache_manager/snapkv.py:1528-1803, and the `kept_scores = scores.gather(...)`
+ * of H2OCacheManager._evict_decode_rows, engine/cache_manager/h2o.py:1584-1602.
+ * `keep` must be ascending and in [0, cur_len) (reference: keep_indices_sorted=True).
+ * Host-side pointers (free_ptr bookkeeping) stay with the caller exactly as in the
+ * reference (`_num_free_slots` is a Python list there). */
+typedef struct SvkCompactRowsArgs {
+  int32_t* slot_table;        /* [L, rows, table_stride_row]                         */
+  int32_t* free_stack;        /* [L, stack_stride]                                   */
+  float* row_payload;         /* NULL or [L, rows, payload_stride_row] f32           */
+  const int64_t* keep;        /* [n_layers, n_lanes, keep_len] ascending             */
+  const int32_t* layer_ids;   /* [n_layers] kv-layer index into the tensors above    */
+  const int32_t* row_ids;     /* [n_layers, n_lanes] physical row per (layer, lane)  */
+  const int64_t* free_base;   /* [n_layers] free-stack write offset per layer        */
+  int64_t table_stride_layer, table_stride_row;
+  int64_t stack_stride;
+  int64_t payload_stride_layer, payload_stride_row;
+  int32_t n_layers, n_lanes;
+  int32_t cur_len, keep_len;
+} SvkCompactRowsArgs;
+int svk_compact_rows(const SvkCompactRowsArgs* a, svk_stream_t stream);
+
+/* Decode slot allocation for all layers at once: lane b of layer l takes
+ * free_stack[l, free_ptr - B + b], writes it at slot_table[l, row[b], cur_len[b]] and
+ * into slot_mapping[l, b]; context_lens[l, b] = cur_len[b] + 1; req_indices[l, b] = row[b].
+ * Replaces the device half of H2OCacheManager.prepare_decode_static,
+ * engine/cache_manager/h2o.py:386-437 (and SnapKVCacheManager.prepare_decode_static). */
+typedef struct SvkDecodeAllocArgs {
+  int32_t* slot_table;
+  const int32_t* free_stack;
+  const int32_t* layer_ids;   /* [n_layers]                                         */
+  const int32_t* row_ids;     /* [B]                                                */
+  const int32_t* cur_lens;    /* [B] length before the append                       */
+  int32_t* slot_mapping;      /* [n_layers, out_stride]  (lanes >= B get -1)        */
+  int32_t* context_lens;      /* [n_layers, out_stride]                             */
+  int32_t* req_indices;       /* [n_layers, out_stride]                             */
+  int64_t table_stride_layer, table_stride_row;
+  int64_t stack_stride;
+  int64_t out_stride;
+  int64_t free_ptr;           /* common stack pointer before the pop                */
+  int32_t n_layers, batch, graph_batch;
+} SvkDecodeAllocArgs;
+int svk_decode_alloc_slots(const SvkDecodeAllocArgs* a, svk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVK_H_ */

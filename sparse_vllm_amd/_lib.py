@@ -1,0 +1,152 @@
+"""ctypes binding of the C-ABI HIP library (include/svk.h -> libsvk.so).
+
+There is NO fallback: if the library is missing or a symbol is absent, importing the
+kernels fails loudly.  PyTorch is used only for device memory and streams; the
+structs below carry raw device pointers and sizes.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvk.so")
+
+SVK_OK = 0
+SVK_ERR_VALUE = -1
+SVK_ERR_LAYOUT = -2
+SVK_ERR_STATE = -3
+SVK_ERR_LAUNCH = -4
+
+SVK_SCORE_NONE = 0
+SVK_SCORE_HEADMAX = 2
+SVK_SCORE_PERHEAD = 3
+
+SVK_ABI_VERSION = 1
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_f32 = C.c_float
+
+
+class SvkStoreKvcacheArgs(C.Structure):
+    _fields_ = [("key", _p), ("value", _p), ("k_cache", _p), ("v_cache", _p), ("slot_mapping", _p),
+                ("key_stride", _i64), ("value_stride", _i64), ("n_tokens", _i32), ("row_elems", _i32)]
+
+
+class SvkCopySlotsArgs(C.Structure):
+    _fields_ = [("k_cache", _p), ("v_cache", _p), ("src_slots", _p), ("dst_slots", _p), ("workspace", _p),
+                ("n", _i32), ("row_elems", _i32)]
+
+
+class SvkFlashDecodeStage1Args(C.Structure):
+    _fields_ = [("q", _p), ("k_cache", _p), ("v_cache", _p), ("req_to_tokens", _p), ("b_req_idx", _p),
+                ("b_seqlen", _p), ("mid_o", _p), ("mid_lse", _p), ("attn_score", _p),
+                ("q_stride_b", _i64), ("q_stride_h", _i64), ("kv_slot_stride", _i64), ("kv_head_stride", _i64),
+                ("req_stride", _i64), ("mid_o_stride_b", _i64), ("mid_o_stride_h", _i64), ("mid_o_stride_s", _i64),
+                ("mid_lse_stride_b", _i64), ("mid_lse_stride_h", _i64), ("score_stride_b", _i64),
+                ("score_stride_h", _i64),
+                ("batch", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
+                ("max_len_in_batch", _i32), ("block_seq", _i32), ("score_mode", _i32)]
+
+
+class SvkFlashDecodeStage2Args(C.Structure):
+    _fields_ = [("mid_o", _p), ("mid_lse", _p), ("b_seqlen", _p), ("o", _p),
+                ("mid_o_stride_b", _i64), ("mid_o_stride_h", _i64), ("mid_o_stride_s", _i64),
+                ("mid_lse_stride_b", _i64), ("mid_lse_stride_h", _i64), ("o_stride_b", _i64), ("o_stride_h", _i64),
+                ("batch", _i32), ("num_q_heads", _i32), ("head_dim", _i32), ("block_seq", _i32)]
+
+
+class SvkH2oDecodeScoreArgs(C.Structure):
+    _fields_ = [("attn_score", _p), ("cum_score", _p), ("b_req_idx", _p), ("b_seqlen", _p),
+                ("score_stride_b", _i64), ("cum_stride", _i64), ("scale", _f32), ("batch", _i32), ("width", _i32)]
+
+
+class SvkH2oSelectArgs(C.Structure):
+    _fields_ = [("scores", _p), ("keep", _p), ("score_stride", _i64), ("keep_stride", _i64),
+                ("rows", _i32), ("kv_len", _i32), ("budget", _i32), ("recent_count", _i32)]
+
+
+class SvkCompactRowsArgs(C.Structure):
+    _fields_ = [("slot_table", _p), ("free_stack", _p), ("row_payload", _p), ("keep", _p), ("layer_ids", _p),
+                ("row_ids", _p), ("free_base", _p),
+                ("table_stride_layer", _i64), ("table_stride_row", _i64), ("stack_stride", _i64),
+                ("payload_stride_layer", _i64), ("payload_stride_row", _i64),
+                ("n_layers", _i32), ("n_lanes", _i32), ("cur_len", _i32), ("keep_len", _i32)]
+
+
+class SvkDecodeAllocArgs(C.Structure):
+    _fields_ = [("slot_table", _p), ("free_stack", _p), ("layer_ids", _p), ("row_ids", _p), ("cur_lens", _p),
+                ("slot_mapping", _p), ("context_lens", _p), ("req_indices", _p),
+                ("table_stride_layer", _i64), ("table_stride_row", _i64), ("stack_stride", _i64),
+                ("out_stride", _i64), ("free_ptr", _i64),
+                ("n_layers", _i32), ("batch", _i32), ("graph_batch", _i32)]
+
+
+# symbol -> (argtypes) ; every entry point declared in include/svk.h
+ENTRY_POINTS = {
+    "svk_abi_version": ([], C.c_int),
+    "svk_last_error": ([], C.c_char_p),
+    "svk_store_kvcache": ([C.POINTER(SvkStoreKvcacheArgs), _p], C.c_int),
+    "svk_copy_slots": ([C.POINTER(SvkCopySlotsArgs), _p], C.c_int),
+    "svk_flash_decode_stage1": ([C.POINTER(SvkFlashDecodeStage1Args), _p], C.c_int),
+    "svk_flash_decode_stage2": ([C.POINTER(SvkFlashDecodeStage2Args), _p], C.c_int),
+    "svk_fill_f32": ([_p, _i64, _f32, _p], C.c_int),
+    "svk_h2o_decode_score_update": ([C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
+    "svk_h2o_select_indices": ([C.POINTER(SvkH2oSelectArgs), _p], C.c_int),
+    "svk_compact_rows": ([C.POINTER(SvkCompactRowsArgs), _p], C.c_int),
+    "svk_decode_alloc_slots": ([C.POINTER(SvkDecodeAllocArgs), _p], C.c_int),
+}
+
+_lib = None
+
+
+class SvkLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsvk.so (once).  Raises SvkLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvkLibraryError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C sparse_vllm_amd/csrc`. There is no CPU fallback for the sparse attention hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in ENTRY_POINTS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise SvkLibraryError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.svk_abi_version() != SVK_ABI_VERSION:
+        raise SvkLibraryError(f"libsvk.so ABI {lib.svk_abi_version()} != binding {SVK_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, lib=None):
+    """Map a C status to the reference's exception classes (include/svk.h header)."""
+    if status == SVK_OK:
+        return
+    lib = lib or load()
+    msg = (lib.svk_last_error() or b"").decode("utf-8", "replace")
+    if status == SVK_ERR_VALUE:
+        raise ValueError(msg)
+    if status == SVK_ERR_LAYOUT:
+        raise AssertionError(msg)
+    raise RuntimeError(msg)
+
+
+def current_stream_handle() -> int:
+    import torch
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> int | None:
+    return None if t is None else int(t.data_ptr())

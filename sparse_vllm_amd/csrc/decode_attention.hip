@@ -1,0 +1,420 @@
+// Split-KV GQA decode attention over a token-granular paged KV cache, with the H2O /
+// SnapKV token-score fused into stage 1.  gfx950 (MI355X) only.
+//
+// Replaces (include/svk.h cites the exact lines)
+//   kernels/triton/gqa_flash_decoding_stage1.py  flash_decode_stage1{,_with_score}
+//   kernels/triton/flash_decoding_stage2.py      flash_decode_stage2
+//
+// Design (DESIGN.md "decode stage 1"):
+//   * one workgroup = (batch lane, block_seq block); one WAVE per KV head, so the four
+//     256-byte head segments of each 1 KiB token row are fetched by the four waves of one
+//     workgroup back to back (same DRAM page), every byte exactly once;
+//   * Q.K^T on the matrix cores: v_mfma_f32_16x16x32_bf16 with A = the <=16 query heads
+//     of the GQA group (rows >= G are zero) and B = 16 token rows loaded straight from
+//     HBM in the B-operand layout (lane = (token, 8-element k chunk)), fp32 accumulate
+//     like the reference's tl.dot;
+//   * per-token score = max over heads of the raw logit: lane-local max over the 4
+//     accumulator rows, then combined across the row groups and the KV-head waves
+//     through LDS by ONE owner thread per token column -> plain coalesced store, no
+//     float atomics (the reference issues 4 contended atomic_max per token);
+//   * online softmax statistics with DPP row reductions (16 tokens live in one DPP row);
+//   * P.V on the vector ALUs: P (rounded to bf16 like `exp_logic.to(v.dtype)`) is
+//     re-distributed through a 1 KiB per-wave LDS tile, V rows are read with fully
+//     coalesced 16 B/lane loads and accumulated in fp32.
+
+#include "svk_common.hpp"
+
+namespace svk {
+namespace {
+
+constexpr int kTileTokens = 32;    // 2 MFMA column groups of 16 tokens
+constexpr int kScoreChunk = 256;   // tokens between two score-combine barriers
+
+template <int D, int G>
+struct Stage1Cfg {
+  static constexpr int NC = D / 32;          // MFMA k-chunks per head row
+  static constexpr int JQ = (G + 3) / 4;     // accumulator row groups holding real heads
+  static constexpr int PH = JQ * 4;          // padded heads per token in the P tile
+  static constexpr int DC = D / 8;           // lanes per V head row (16 B each)
+  static constexpr int TQ = 64 / DC;         // tokens per V wave-load
+  static constexpr int NV = kTileTokens / TQ;
+  static constexpr int P_FLOATS = kTileTokens * PH;
+  static constexpr int WAVE_FLOATS = P_FLOATS + 16;
+};
+
+template <int D, int G>
+__global__ void __launch_bounds__(512)
+decode_stage1_kernel(const SvkFlashDecodeStage1Args a) {
+  using C = Stage1Cfg<D, G>;
+  constexpr int NC = C::NC, JQ = C::JQ, PH = C::PH, DC = C::DC, TQ = C::TQ, NV = C::NV;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // kv head of this wave
+  const int Hkv = a.num_kv_heads;
+  const int b = blockIdx.y;
+  const int blk = blockIdx.x;
+  const int n = lane & 15;       // token column inside a 16-token MFMA group
+  const int jq = lane >> 4;      // accumulator row group / k chunk
+  const int dc = lane % DC;      // V: 16-byte chunk of the head row
+  const int tq = lane / DC;      // V: token inside a wave-load
+  const int score_mode = a.score_mode;
+
+  const int len = a.b_seqlen[b];
+  const int start = blk * a.block_seq;
+  const int end = min(len, start + a.block_seq);
+
+  float* Pw = lds + w * C::WAVE_FLOATS;
+  float* bc = Pw + C::P_FLOATS;                                   // 16 floats broadcast pad
+  float* spart = lds + Hkv * C::WAVE_FLOATS;                       // [kScoreChunk][Hkv*JQ]
+  const int SP = Hkv * JQ;
+
+  float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)blk * a.mid_o_stride_s;
+  float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + blk;
+
+  if (end <= start) {
+    // empty block: neutral partial (gqa_flash_decoding_stage1.py:288-294)
+    for (int h = 0; h < G; ++h) {
+      float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h;
+      for (int d = lane; d < D; d += 64) o[d] = 0.f;
+      if (lane == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = -INFINITY;
+    }
+    return;
+  }
+
+  // ---- Q fragments (A operand): lane (m = n, k chunk jq) holds Q[head n][c*32 + jq*8 .. +8]
+  bf16x8_t qa[NC];
+  {
+    const uint16_t* qp = a.q + (int64_t)b * a.q_stride_b + (int64_t)(w * G + n) * a.q_stride_h + jq * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (n < G) t = *reinterpret_cast<const uint4*>(qp + c * 32);
+      qa[c] = __builtin_bit_cast(bf16x8_t, t);
+    }
+  }
+
+  const int32_t* row = a.req_to_tokens + (int64_t)a.b_req_idx[b] * a.req_stride;
+  const uint16_t* kbase = a.k_cache + (int64_t)w * a.kv_head_stride + jq * 8;
+  const uint16_t* vbase = a.v_cache + (int64_t)w * a.kv_head_stride + dc * 8;
+  const float sm_scale = rsqrtf((float)D);
+
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+  float acc[G][8];
+#pragma unroll
+  for (int h = 0; h < G; ++h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+
+  // slot ids of the current tile (K: two 16-token groups; V: NV wave-loads)
+  int sk[2], sv[NV];
+  auto load_slots = [&](int t0, int (&k2)[2], int (&v2)[NV]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int t = t0 + g * 16 + n;
+      k2[g] = (t < end) ? row[t] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int t = t0 + i * TQ + tq;
+      v2[i] = (t < end) ? row[t] : 0;
+    }
+  };
+  load_slots(start, sk, sv);
+
+  for (int c0 = start; c0 < end; c0 += kScoreChunk) {
+    const int c1 = min(end, c0 + kScoreChunk);
+    for (int t0 = c0; t0 < c1; t0 += kTileTokens) {
+      const bool full = (t0 + kTileTokens <= end);
+
+      // ---- issue all K and V loads of this tile
+      uint4 kr[2][NC];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint16_t* kp = kbase + (int64_t)sk[g] * a.kv_slot_stride;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) kr[g][c] = *reinterpret_cast<const uint4*>(kp + c * 32);
+      }
+      uint4 vr[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        vr[i] = *reinterpret_cast<const uint4*>(vbase + (int64_t)sv[i] * a.kv_slot_stride);
+
+      // ---- prefetch the next tile's slot ids
+      int skn[2], svn[NV];
+      if (t0 + kTileTokens < end) load_slots(t0 + kTileTokens, skn, svn);
+      else {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) skn[g] = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) svn[i] = 0;
+      }
+
+      // ---- S = Q K^T  (rows = heads jq*4+r, col = token n)
+      f32x4_t s[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        s[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          s[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, kr[g][c]), s[g], 0, 0, 0);
+      }
+      bool tv[2];
+      tv[0] = full || (t0 + n < end);
+      tv[1] = full || (t0 + 16 + n < end);
+
+      // ---- raw scores out
+      if (score_mode == SVK_SCORE_PERHEAD) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int h = jq * 4 + r;
+            if (h < G && tv[g])
+              a.attn_score[(int64_t)b * a.score_stride_b + (int64_t)(w * G + h) * a.score_stride_h + t0 + g * 16 + n] = s[g][r];
+          }
+      } else if (score_mode == SVK_SCORE_HEADMAX) {
+        if (jq < JQ) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            float pm = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (jq * 4 + r < G) pm = fmaxf(pm, s[g][r]);
+            spart[(t0 - c0 + g * 16 + n) * SP + w * JQ + jq] = tv[g] ? pm : -INFINITY;
+          }
+        }
+      }
+
+      // ---- online softmax (per head row; 16 tokens of a group live in one DPP row)
+      float p[2][4];
+      float alpha[4];
+      bool rescale = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool hv = (jq * 4 + r < G);
+        const float x0 = (hv && tv[0]) ? s[0][r] * sm_scale : -INFINITY;
+        const float x1 = (hv && tv[1]) ? s[1][r] * sm_scale : -INFINITY;
+        const float tmax = row16_allmax(fmaxf(x0, x1));
+        const float nm = fmaxf(m[r], tmax);
+        if (hv) {
+          alpha[r] = __expf(m[r] - nm);          // first tile: exp(-inf) = 0
+          p[0][r] = __expf(x0 - nm);
+          p[1][r] = __expf(x1 - nm);
+          rescale |= (nm != m[r]);
+        } else {
+          alpha[r] = 1.f; p[0][r] = 0.f; p[1][r] = 0.f;
+        }
+        l[r] = l[r] * alpha[r] + row16_allsum(p[0][r] + p[1][r]);
+        m[r] = hv ? nm : m[r];
+      }
+
+      // ---- P (bf16-rounded) -> per-wave LDS tile [token][head]
+      if (jq < JQ) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          float4 t = make_float4(bf16_round(p[g][0]), bf16_round(p[g][1]), bf16_round(p[g][2]), bf16_round(p[g][3]));
+          *reinterpret_cast<float4*>(Pw + (g * 16 + n) * PH + jq * 4) = t;
+        }
+      }
+      const bool any_rescale = __any(rescale);
+      if (any_rescale && n == 0 && jq < JQ)
+        *reinterpret_cast<float4*>(bc + jq * 4) = make_float4(alpha[0], alpha[1], alpha[2], alpha[3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      if (any_rescale) {
+        float al[PH];
+#pragma unroll
+        for (int q4 = 0; q4 < JQ; ++q4) {
+          float4 t = *reinterpret_cast<const float4*>(bc + q4 * 4);
+          al[q4 * 4 + 0] = t.x; al[q4 * 4 + 1] = t.y; al[q4 * 4 + 2] = t.z; al[q4 * 4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[h][e] *= al[h];
+      }
+
+      // ---- acc += P V
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        uint4 vv = vr[i];
+        if (!full && (t0 + i * TQ + tq >= end)) vv = make_uint4(0, 0, 0, 0);
+        float ph[PH];
+#pragma unroll
+        for (int q4 = 0; q4 < JQ; ++q4) {
+          float4 t = *reinterpret_cast<const float4*>(Pw + (i * TQ + tq) * PH + q4 * 4);
+          ph[q4 * 4 + 0] = t.x; ph[q4 * 4 + 1] = t.y; ph[q4 * 4 + 2] = t.z; ph[q4 * 4 + 3] = t.w;
+        }
+        float vf[8];
+        vf[0] = bf16_lo(vv.x); vf[1] = bf16_hi(vv.x);
+        vf[2] = bf16_lo(vv.y); vf[3] = bf16_hi(vv.y);
+        vf[4] = bf16_lo(vv.z); vf[5] = bf16_hi(vv.z);
+        vf[6] = bf16_lo(vv.w); vf[7] = bf16_hi(vv.w);
+#pragma unroll
+        for (int h = 0; h < G; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[h][e] = fmaf(ph[h], vf[e], acc[h][e]);
+      }
+      // the next tile's P stores must not overtake this tile's P reads
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+      for (int g = 0; g < 2; ++g) sk[g] = skn[g];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) sv[i] = svn[i];
+    }
+
+    if (score_mode == SVK_SCORE_HEADMAX) {
+      // one owner thread per token column: combine row groups and KV-head waves
+      __syncthreads();
+      for (int t = threadIdx.x; t < c1 - c0; t += blockDim.x) {
+        float mx = -INFINITY;
+        for (int j = 0; j < SP; ++j) mx = fmaxf(mx, spart[t * SP + j]);
+        float* dst = a.attn_score + (int64_t)b * a.score_stride_b + c0 + t;
+        *dst = fmaxf(*dst, mx);      // same combine as the reference's atomic_max
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: mid_lse = m + log(l);  mid_o = acc / l
+  if (n == 0 && jq < JQ) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = jq * 4 + r;
+      if (h < G) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = m[r] + __logf(l[r]);
+    }
+    *reinterpret_cast<float4*>(bc + jq * 4) = make_float4(l[0], l[1], l[2], l[3]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float lh[PH];
+#pragma unroll
+  for (int q4 = 0; q4 < JQ; ++q4) {
+    float4 t = *reinterpret_cast<const float4*>(bc + q4 * 4);
+    lh[q4 * 4 + 0] = t.x; lh[q4 * 4 + 1] = t.y; lh[q4 * 4 + 2] = t.z; lh[q4 * 4 + 3] = t.w;
+  }
+#pragma unroll
+  for (int h = 0; h < G; ++h) {
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = acc[h][e];
+#pragma unroll
+      for (int off = DC; off < 64; off <<= 1) x += __shfl_xor(x, off, 64);
+      o8[e] = x / lh[h];
+    }
+    if (tq == 0) {
+      float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h + dc * 8;
+      *reinterpret_cast<float4*>(o) = make_float4(o8[0], o8[1], o8[2], o8[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+    }
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(D / 2)
+decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
+  // one (batch lane, q head) per workgroup; each thread owns 2 output dims
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int d = threadIdx.x * 2;
+  const int len = a.b_seqlen[b];
+  const int nblk = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq;
+  const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h + d;
+  const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
+  float sum = 0.f, mx = -INFINITY, a0 = 0.f, a1 = 0.f;
+  for (int i = 0; i < nblk; ++i) {
+    const float2 tv = *reinterpret_cast<const float2*>(mo + (int64_t)i * a.mid_o_stride_s);
+    const float tl = ml[i];
+    const float nm = fmaxf(tl, mx);
+    const float os = __expf(mx - nm);
+    const float e = __expf(tl - nm);
+    a0 = a0 * os + e * tv.x;
+    a1 = a1 * os + e * tv.y;
+    sum = sum * os + e;
+    mx = nm;
+  }
+  const uint32_t lo = f32_to_bf16_bits(a0 / sum), hi = f32_to_bf16_bits(a1 / sum);
+  *reinterpret_cast<uint32_t*>(a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d) = lo | (hi << 16);
+}
+
+template <int D, int G>
+int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
+  using C = Stage1Cfg<D, G>;
+  const int nblk = (a.max_len_in_batch + a.block_seq - 1) / a.block_seq;
+  dim3 grid(nblk, a.batch);
+  dim3 block(64 * a.num_kv_heads);
+  size_t shm = sizeof(float) * ((size_t)a.num_kv_heads * C::WAVE_FLOATS +
+                                (a.score_mode == SVK_SCORE_HEADMAX ? (size_t)kScoreChunk * a.num_kv_heads * C::JQ : 0));
+  hipLaunchKernelGGL((decode_stage1_kernel<D, G>), grid, block, shm, stream, a);
+  return check_launch("svk_flash_decode_stage1");
+}
+
+template <int D>
+int dispatch_group(const SvkFlashDecodeStage1Args& a, int G, hipStream_t stream) {
+  switch (G) {
+    case 1: return launch_stage1<D, 1>(a, stream);
+    case 2: return launch_stage1<D, 2>(a, stream);
+    case 3: return launch_stage1<D, 3>(a, stream);
+    case 4: return launch_stage1<D, 4>(a, stream);
+    case 5: return launch_stage1<D, 5>(a, stream);
+    case 6: return launch_stage1<D, 6>(a, stream);
+    case 7: return launch_stage1<D, 7>(a, stream);
+    case 8: return launch_stage1<D, 8>(a, stream);
+    default:
+      set_error("svk_flash_decode_stage1: GQA group size %d unsupported (1..8)", G);
+      return SVK_ERR_LAYOUT;
+  }
+}
+
+}  // namespace
+}  // namespace svk
+
+extern "C" int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_flash_decode_stage1: null args");
+  SVK_REQUIRE(a->head_dim == 64 || a->head_dim == 128, SVK_ERR_LAYOUT,
+              "svk_flash_decode_stage1: head_dim %d unsupported (64, 128)", a->head_dim);
+  SVK_REQUIRE(a->block_seq > 0 && a->block_seq % 16 == 0, SVK_ERR_LAYOUT,
+              "svk_flash_decode_stage1: block_seq %d must be a positive multiple of 16 (BLOCK_SEQ %% BLOCK_N)", a->block_seq);
+  SVK_REQUIRE(a->num_kv_heads >= 1 && a->num_kv_heads <= 8, SVK_ERR_LAYOUT,
+              "svk_flash_decode_stage1: num_kv_heads %d unsupported (1..8 per rank)", a->num_kv_heads);
+  SVK_REQUIRE(a->num_q_heads % a->num_kv_heads == 0, SVK_ERR_LAYOUT,
+              "svk_flash_decode_stage1: q heads %d not divisible by kv heads %d", a->num_q_heads, a->num_kv_heads);
+  SVK_REQUIRE(a->score_mode == SVK_SCORE_NONE || a->score_mode == SVK_SCORE_HEADMAX || a->score_mode == SVK_SCORE_PERHEAD,
+              SVK_ERR_VALUE, "svk_flash_decode_stage1: bad score_mode %d", a->score_mode);
+  SVK_REQUIRE(a->score_mode == SVK_SCORE_NONE || a->attn_score != nullptr, SVK_ERR_VALUE,
+              "svk_flash_decode_stage1: score_mode %d needs attn_score", a->score_mode);
+  SVK_REQUIRE((a->kv_slot_stride % 8) == 0 && (a->kv_head_stride % 8) == 0 && (a->q_stride_h % 8) == 0 && (a->q_stride_b % 8) == 0,
+              SVK_ERR_LAYOUT, "svk_flash_decode_stage1: q/k/v strides must keep 16-byte alignment");
+  SVK_REQUIRE((a->mid_o_stride_h % 4) == 0 && (a->mid_o_stride_s % 4) == 0 && (a->mid_o_stride_b % 4) == 0, SVK_ERR_LAYOUT,
+              "svk_flash_decode_stage1: mid_o strides must keep 16-byte alignment");
+  if (a->batch <= 0 || a->max_len_in_batch <= 0) return SVK_OK;
+  const int G = a->num_q_heads / a->num_kv_heads;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return a->head_dim == 128 ? dispatch_group<128>(*a, G, s) : dispatch_group<64>(*a, G, s);
+}
+
+extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_flash_decode_stage2: null args");
+  SVK_REQUIRE(a->head_dim == 64 || a->head_dim == 128, SVK_ERR_LAYOUT,
+              "svk_flash_decode_stage2: head_dim %d unsupported (64, 128)", a->head_dim);
+  SVK_REQUIRE(a->block_seq > 0, SVK_ERR_VALUE, "svk_flash_decode_stage2: block_seq must be positive");
+  SVK_REQUIRE((a->mid_o_stride_h % 2) == 0 && (a->mid_o_stride_s % 2) == 0 && (a->mid_o_stride_b % 2) == 0 &&
+                  (a->o_stride_b % 2) == 0 && (a->o_stride_h % 2) == 0,
+              SVK_ERR_LAYOUT, "svk_flash_decode_stage2: strides must be even");
+  if (a->batch <= 0) return SVK_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid(a->batch, a->num_q_heads);
+  if (a->head_dim == 128) hipLaunchKernelGGL((decode_stage2_kernel<128>), grid, dim3(64), 0, s, *a);
+  else hipLaunchKernelGGL((decode_stage2_kernel<64>), grid, dim3(32), 0, s, *a);
+  return check_launch("svk_flash_decode_stage2");
+}

@@ -1,0 +1,342 @@
+// H2O / SnapKV-family bookkeeping kernels: score normalisation + accumulation, exact
+// top-k selection with the reference's tie rule, slot-table compaction, decode slot
+// allocation.  gfx950 only.  Integer results are bit-exact with the reference's torch
+// code (include/svk.h cites the lines); these are HBM/L2-bound index kernels.
+
+#include "svk_common.hpp"
+
+namespace svk {
+namespace {
+
+// ------------------------------------------------------------------------------------
+// block-wide helpers (blockDim.x multiple of 64, <= 1024)
+// ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float block_allmax(float x, float* red) {
+  x = wave_allmax(x);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = x;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+
+__device__ __forceinline__ float block_allsum(float x, float* red) {
+  x = wave_allsum(x);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = x;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
+  return r;
+}
+
+// exclusive prefix count of a 1-bit flag over the block, plus the block total
+__device__ __forceinline__ int block_excl_count(bool flag, int* wsum, int& total) {
+  const unsigned long long bal = __ballot(flag);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0) wsum[w] = __popcll(bal);
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < nw; ++i) {
+    const int c = wsum[i];
+    if (i < w) base += c;
+    tot += c;
+  }
+  total = tot;
+  return base + in_wave;
+}
+
+// ------------------------------------------------------------------------------------
+// fill
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) fill_f32_kernel(float* dst, int64_t n, float v) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n && ((reinterpret_cast<uintptr_t>(dst + i) & 15) == 0)) {
+      *reinterpret_cast<float4*>(dst + i) = make_float4(v, v, v, v);
+    } else {
+      for (int64_t j = i; j < n && j < i + 4; ++j) dst[j] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// decode score: x *= scale; softmax over the full width; optional cumulative update
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDecodeScoreArgs a) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  float* x = a.attn_score + (int64_t)b * a.score_stride_b;
+  const int W = a.width;
+  float mx = -INFINITY;
+  // __fmul_rn keeps `x * scale` a separately rounded product like torch's mul_ (no fma contraction)
+  for (int t = threadIdx.x; t < W; t += blockDim.x) mx = fmaxf(mx, __fmul_rn(x[t], a.scale));
+  mx = block_allmax(mx, red);
+  float sum = 0.f;
+  for (int t = threadIdx.x; t < W; t += blockDim.x) sum += expf(__fmul_rn(x[t], a.scale) - mx);
+  sum = block_allsum(sum, red);
+  float* cum = nullptr;
+  int len = 0;
+  if (a.cum_score != nullptr) {
+    cum = a.cum_score + (int64_t)a.b_req_idx[b] * a.cum_stride;
+    len = a.b_seqlen[b];
+  }
+  for (int t = threadIdx.x; t < W; t += blockDim.x) {
+    const float p = expf(__fmul_rn(x[t], a.scale) - mx) / sum;
+    x[t] = p;
+    if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : cum[t] + p;   // pad(prev, 1) + p
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// exact H2O selection
+// ------------------------------------------------------------------------------------
+
+// Descending-order key: smaller key == larger score; -0.0 and +0.0 compare equal like
+// torch's comparison-based stable sort.
+__device__ __forceinline__ uint32_t desc_key(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u << 1) == 0u) u = 0u;                                   // canonical +0
+  const uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ~asc;
+}
+
+__global__ void __launch_bounds__(256) h2o_select_kernel(const SvkH2oSelectArgs a) {
+  __shared__ int hist[256];
+  __shared__ int wsum[16];
+  __shared__ uint32_t sh_prefix;
+  __shared__ int sh_k;
+
+  const int rowi = blockIdx.x;
+  const float* sc = a.scores + (int64_t)rowi * a.score_stride;
+  int64_t* keep = a.keep + (int64_t)rowi * a.keep_stride;
+  const int kv_len = a.kv_len, budget = a.budget;
+  const int tid = threadIdx.x, nt = blockDim.x;
+
+  if (kv_len <= budget) {
+    for (int i = tid; i < kv_len; i += nt) keep[i] = i;
+    return;
+  }
+  const int recent = a.recent_count;
+  const int heavy = budget - recent;
+  const int rs = kv_len - recent;      // recent_start; heavy < rs always holds here
+  for (int i = tid; i < recent; i += nt) keep[heavy + i] = rs + i;
+  if (heavy <= 0) return;
+
+  // ---- radix select (MSB first, 8 bits per pass) of the heavy-th smallest desc_key
+  uint32_t prefix = 0;     // bits decided so far
+  int k = heavy;           // rank still to find inside the current prefix bucket (1-based)
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = tid; i < 256; i += nt) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < rs; i += nt) {
+      const uint32_t key = desc_key(sc[i]);
+      if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // wave 0: find the bin holding rank k
+      int c[4];
+      int local = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c[j] = hist[tid * 4 + j]; local += c[j]; }
+      int incl = local;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += v;
+      }
+      const int excl = incl - local;
+      if (k > excl && k <= incl) {
+        int run = excl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (k > run && k <= run + c[j]) {
+            sh_prefix = prefix | ((uint32_t)(tid * 4 + j) << shift);
+            sh_k = k - run;
+          }
+          run += c[j];
+        }
+      }
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    k = sh_k;
+    __syncthreads();
+  }
+  // prefix == threshold key T; k == how many elements equal to T are taken (lowest index first)
+  const uint32_t T = prefix;
+  const int take_eq = k;
+
+  // ---- ordered compaction: ascending index, exactly `heavy` outputs
+  int out_base = 0, eq_base = 0;
+  for (int c0 = 0; c0 < rs; c0 += nt) {
+    const int i = c0 + tid;
+    uint32_t key = 0xffffffffu;
+    bool in = i < rs;
+    if (in) key = desc_key(sc[i]);
+    const bool is_eq = in && key == T;
+    int eq_total;
+    const int eq_rank = eq_base + block_excl_count(is_eq, wsum, eq_total);
+    const bool sel = in && (key < T || (is_eq && eq_rank < take_eq));
+    int sel_total;
+    const int pos = out_base + block_excl_count(sel, wsum, sel_total);
+    if (sel) keep[pos] = i;
+    out_base += sel_total;
+    eq_base += eq_total;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// slot-table compaction
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) compact_rows_kernel(const SvkCompactRowsArgs a) {
+  const int lane_i = blockIdx.x, li = blockIdx.y;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int layer = a.layer_ids[li];
+  const int row = a.row_ids[(int64_t)li * a.n_lanes + lane_i];
+  const int K = a.keep_len, cur = a.cur_len;
+  const int64_t* keep = a.keep + ((int64_t)li * a.n_lanes + lane_i) * K;
+  int32_t* tab = a.slot_table + (int64_t)layer * a.table_stride_layer + (int64_t)row * a.table_stride_row;
+  int32_t* stack = a.free_stack + (int64_t)layer * a.stack_stride + a.free_base[li] + (int64_t)lane_i * (cur - K);
+  float* pay = a.row_payload ? a.row_payload + (int64_t)layer * a.payload_stride_layer + (int64_t)row * a.payload_stride_row
+                             : nullptr;
+
+  // (A) dropped slots -> free stack, ascending position.  Position q with j = |{keep < q}|
+  //     kept entries before it lands at out[q - j]   (snapkv.py:1754-1768 row-major mask order)
+  for (int q = tid; q < cur; q += nt) {
+    int lo = 0, hi = K;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (keep[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    if (!(lo < K && keep[lo] == q)) stack[q - lo] = tab[q];
+  }
+  __syncthreads();
+
+  // (B) in-place gather new[j] = old[keep[j]]: keep is ascending so keep[j] >= j; a chunk
+  //     reads only positions >= its own first index, hence chunk-by-chunk is hazard free.
+  for (int c0 = 0; c0 < K; c0 += nt) {
+    const int j = c0 + tid;
+    int32_t s = 0;
+    float p = 0.f;
+    if (j < K) {
+      const int64_t src = keep[j];
+      s = tab[src];
+      if (pay) p = pay[src];
+    }
+    __syncthreads();
+    if (j < K) {
+      tab[j] = s;
+      if (pay) pay[j] = p;
+    }
+    __syncthreads();
+  }
+  // (C) zero the tail (snapkv.py:1790-1799)
+  for (int q = K + tid; q < cur; q += nt) {
+    tab[q] = 0;
+    if (pay) pay[q] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// decode slot allocation (all layers)
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) decode_alloc_kernel(const SvkDecodeAllocArgs a) {
+  const int li = blockIdx.y;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.graph_batch) return;
+  const int layer = a.layer_ids[li];
+  int32_t* sm = a.slot_mapping + (int64_t)li * a.out_stride;
+  int32_t* cl = a.context_lens + (int64_t)li * a.out_stride;
+  int32_t* ri = a.req_indices + (int64_t)li * a.out_stride;
+  if (b >= a.batch) {
+    // padded graph lanes: slot -1, metadata of lane 0 (h2o.py:419-424 index_fill_)
+    sm[b] = -1;
+    cl[b] = a.cur_lens[0] + 1;
+    ri[b] = a.row_ids[0];
+    return;
+  }
+  const int32_t slot = a.free_stack[(int64_t)layer * a.stack_stride + a.free_ptr - a.batch + b];
+  const int row = a.row_ids[b];
+  const int cur = a.cur_lens[b];
+  a.slot_table[(int64_t)layer * a.table_stride_layer + (int64_t)row * a.table_stride_row + cur] = slot;
+  sm[b] = slot;
+  cl[b] = cur + 1;
+  ri[b] = row;
+}
+
+}  // namespace
+}  // namespace svk
+
+extern "C" int svk_fill_f32(float* dst, int64_t n, float value, svk_stream_t stream) {
+  using namespace svk;
+  if (n <= 0) return SVK_OK;
+  SVK_REQUIRE(dst != nullptr, SVK_ERR_VALUE, "svk_fill_f32: null dst");
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dst, n, value);
+  return check_launch("svk_fill_f32");
+}
+
+extern "C" int svk_h2o_decode_score_update(const SvkH2oDecodeScoreArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->attn_score != nullptr, SVK_ERR_VALUE, "svk_h2o_decode_score_update: null args");
+  SVK_REQUIRE(a->width > 0, SVK_ERR_VALUE, "svk_h2o_decode_score_update: width must be positive");
+  SVK_REQUIRE(a->cum_score == nullptr || (a->b_req_idx != nullptr && a->b_seqlen != nullptr), SVK_ERR_VALUE,
+              "svk_h2o_decode_score_update: cum_score needs b_req_idx and b_seqlen");
+  if (a->batch <= 0) return SVK_OK;
+  const int threads = a->width >= 4096 ? 1024 : (a->width >= 1024 ? 512 : 256);
+  hipLaunchKernelGGL(h2o_decode_score_kernel, dim3(a->batch), dim3(threads), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_h2o_decode_score_update");
+}
+
+extern "C" int svk_h2o_select_indices(const SvkH2oSelectArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_h2o_select_indices: null args");
+  SVK_REQUIRE(a->budget > 0, SVK_ERR_VALUE, "H2O budget must be positive, got %d.", a->budget);
+  SVK_REQUIRE(a->kv_len >= 0 && a->rows >= 0, SVK_ERR_VALUE, "svk_h2o_select_indices: negative shape");
+  if (a->kv_len > a->budget) {
+    SVK_REQUIRE(a->recent_count >= 1 && a->recent_count <= a->budget && a->recent_count <= a->kv_len, SVK_ERR_VALUE,
+                "svk_h2o_select_indices: recent_count %d out of range (budget %d, kv_len %d)", a->recent_count, a->budget, a->kv_len);
+  }
+  if (a->rows == 0 || a->kv_len == 0) return SVK_OK;
+  hipLaunchKernelGGL(h2o_select_kernel, dim3(a->rows), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_h2o_select_indices");
+}
+
+extern "C" int svk_compact_rows(const SvkCompactRowsArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_compact_rows: null args");
+  SVK_REQUIRE(a->keep_len > 0, SVK_ERR_STATE, "free_part_slots got empty keep_indices");
+  SVK_REQUIRE(a->keep_len <= a->cur_len, SVK_ERR_STATE, "svk_compact_rows: keep_len %d exceeds cur_len %d", a->keep_len, a->cur_len);
+  if (a->n_layers <= 0 || a->n_lanes <= 0) return SVK_OK;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(a->n_lanes, a->n_layers), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_compact_rows");
+}
+
+extern "C" int svk_decode_alloc_slots(const SvkDecodeAllocArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_decode_alloc_slots: null args");
+  SVK_REQUIRE(a->batch > 0, SVK_ERR_VALUE, "Static decode requires a non-empty real decode batch.");
+  SVK_REQUIRE(a->graph_batch >= a->batch, SVK_ERR_VALUE,
+              "Static decode graph batch is smaller than the real decode batch: graph=%d, real=%d.", a->graph_batch, a->batch);
+  SVK_REQUIRE(a->free_ptr >= a->batch, SVK_ERR_STATE, "Out of KV cache slots in static decode: need=%d free=%lld.", a->batch,
+              (long long)a->free_ptr);
+  if (a->n_layers <= 0) return SVK_OK;
+  hipLaunchKernelGGL(decode_alloc_kernel, dim3((a->graph_batch + 255) / 256, a->n_layers), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_decode_alloc_slots");
+}

@@ -1,0 +1,81 @@
+// Shared helpers for the gfx950 kernels behind include/svk.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "svk.h"
+
+namespace svk {
+
+void set_error(const char* fmt, ...);
+
+#define SVK_REQUIRE(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::svk::set_error(__VA_ARGS__);      \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return SVK_ERR_LAUNCH;
+  }
+  return SVK_OK;
+}
+
+constexpr int kWave = 64;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// round-to-nearest-even f32 -> bf16 bit pattern (finite inputs; NaN quieted)
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_round(float f) {
+  return __builtin_bit_cast(float, f32_to_bf16_bits(f) << 16);
+}
+
+// DPP row rotate inside each 16-lane row: returns x from lane (l - n) mod 16 of the row.
+template <int N>
+__device__ __forceinline__ float row_ror(float x) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_allmax(float x) {
+  x = fmaxf(x, row_ror<8>(x));
+  x = fmaxf(x, row_ror<4>(x));
+  x = fmaxf(x, row_ror<2>(x));
+  x = fmaxf(x, row_ror<1>(x));
+  return x;
+}
+__device__ __forceinline__ float row16_allsum(float x) {
+  x += row_ror<8>(x);
+  x += row_ror<4>(x);
+  x += row_ror<2>(x);
+  x += row_ror<1>(x);
+  return x;
+}
+
+__device__ __forceinline__ float wave_allmax(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+  return x;
+}
+__device__ __forceinline__ float wave_allsum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+}  // namespace svk

@@ -1,0 +1,85 @@
+"""GQA split-KV decode stage 1 (optionally with fused token scores) on gfx950.
+
+Mirror of the reference's kernels/triton/gqa_flash_decoding_stage1.py:
+`flash_decode_stage1` (:329-394) and `flash_decode_stage1_with_score` (:397-445), same
+argument order, same layout asserts (:298-326).  `num_warps`/`num_stages`/`block_n` are
+Triton launch knobs with no meaning for the HIP kernel; they are accepted and ignored so
+existing call sites (layers/attention_backend.py:284-349) keep working.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+
+def _assert_supported_layout(q, k, v, req_to_tokens, b_req_idx, b_seqlen, mid_out, mid_out_logsumexp):
+    assert q.stride(-1) == 1, f"q head_dim must be contiguous, got stride={q.stride()}."
+    assert k.stride(-1) == 1, f"k head_dim must be contiguous, got stride={k.stride()}."
+    assert v.stride(-1) == 1, f"v head_dim must be contiguous, got stride={v.stride()}."
+    assert k.stride() == v.stride(), (
+        "k and v must have identical layouts because the GQA decode kernel shares their strides, "
+        f"got k_stride={k.stride()} v_stride={v.stride()}.")
+    assert req_to_tokens.stride(-1) == 1, (
+        f"req_to_tokens sequence dimension must be contiguous, got stride={req_to_tokens.stride()}.")
+    assert b_req_idx.stride(0) == 1, f"b_req_idx must be contiguous, got stride={b_req_idx.stride()}."
+    assert b_seqlen.stride(0) == 1, f"b_seqlen must be contiguous, got stride={b_seqlen.stride()}."
+    assert mid_out.stride(-1) == 1, f"mid_out head_dim must be contiguous, got stride={mid_out.stride()}."
+    assert mid_out_logsumexp.stride(-1) == 1, (
+        f"mid_out_logsumexp block dimension must be contiguous, got stride={mid_out_logsumexp.stride()}.")
+
+
+def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
+            attn_score, block_seq):
+    Lq, Lk = q.shape[-1], k.shape[-1]
+    assert Lq == Lk
+    assert Lk in {16, 32, 64, 128, 256}
+    assert q.dtype == k.dtype and k.dtype == v.dtype
+    assert q.dtype == torch.bfloat16, f"the gfx950 decode kernel computes in bf16, got {q.dtype}"
+    assert int(block_seq) % 16 == 0
+    _assert_supported_layout(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, mid_out, mid_out_logsumexp)
+    assert Req_to_tokens.dtype == torch.int32 and B_req_idx.dtype == torch.int32 and B_Seqlen.dtype == torch.int32
+    assert mid_out.dtype == torch.float32 and mid_out_logsumexp.dtype == torch.float32
+    batch, kv_head_num = B_req_idx.shape[0], k.shape[1]
+    nblk = (int(max_len_in_batch) + int(block_seq) - 1) // int(block_seq)
+    assert mid_out.shape[2] >= nblk and mid_out_logsumexp.shape[2] >= nblk
+    mode = _lib.SVK_SCORE_NONE
+    ss_b = ss_h = 0
+    if attn_score is not None:
+        assert attn_score.dtype == torch.float32 and attn_score.stride(-1) == 1
+        if attn_score.dim() == 3:
+            mode = _lib.SVK_SCORE_PERHEAD
+            ss_b, ss_h = attn_score.stride(0), attn_score.stride(1)
+        else:
+            mode = _lib.SVK_SCORE_HEADMAX
+            ss_b = attn_score.stride(0)
+    lib = _lib.load()
+    a = _lib.SvkFlashDecodeStage1Args(
+        q=_lib.ptr(q), k_cache=_lib.ptr(k), v_cache=_lib.ptr(v), req_to_tokens=_lib.ptr(Req_to_tokens),
+        b_req_idx=_lib.ptr(B_req_idx), b_seqlen=_lib.ptr(B_Seqlen), mid_o=_lib.ptr(mid_out),
+        mid_lse=_lib.ptr(mid_out_logsumexp), attn_score=_lib.ptr(attn_score),
+        q_stride_b=q.stride(0), q_stride_h=q.stride(1), kv_slot_stride=k.stride(0), kv_head_stride=k.stride(1),
+        req_stride=Req_to_tokens.stride(0),
+        mid_o_stride_b=mid_out.stride(0), mid_o_stride_h=mid_out.stride(1), mid_o_stride_s=mid_out.stride(2),
+        mid_lse_stride_b=mid_out_logsumexp.stride(0), mid_lse_stride_h=mid_out_logsumexp.stride(1),
+        score_stride_b=ss_b, score_stride_h=ss_h,
+        batch=batch, num_q_heads=q.shape[1], num_kv_heads=kv_head_num, head_dim=Lk,
+        max_len_in_batch=int(max_len_in_batch), block_seq=int(block_seq), score_mode=mode)
+    _lib.check(lib.svk_flash_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+@torch.no_grad()
+def flash_decode_stage1(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
+                        mid_out_logsumexp, block_seq, block_n=16, num_warps=2, num_stages=2):
+    _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp, None,
+            block_seq)
+
+
+@torch.no_grad()
+def flash_decode_stage1_with_score(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
+                                   mid_out_logsumexp, attn_score, block_seq):
+    _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
+            attn_score, block_seq)
