@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: H2O scored-decode hot path, Qwen2.5-7B shapes, 128k-context rows.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): sparse_method=h2o, decode_budget=4096, interval=128,
+28 layers, 28 q heads / 4 kv heads, head_dim 128, bf16.  Every GPU hosts B sequences whose
+131072-token prompts have already been reduced by chunked prefill to 4096-token physical rows
+(per layer) scattered over a randomly permuted paged KV pool.  One "step" = one decode step of
+the hot path for the whole batch: slot allocation, then per layer {store_kvcache, scored
+split-KV decode stage 1, stage 2 merge, score normalise + accumulate}, then the eviction
+trigger; every 128th step runs the burst (exact H2O selection + slot-table compaction on all
+28 layers).  K steps are timed between barriers; `value` = tokens of all GPUs / max-over-ranks
+time.  The model's dense layers are outside this build (hot path only).
+
+One JSON line is printed by rank 0.  `roofline` times every stage-1 launch of the timed
+region with HIP events on the launch stream; `cpu_baseline` times the numpy oracle on a
+bounded sample of the same workload on the host (rank 0, N=1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK = 8.0e12   # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seed: int = 20260625):
+    """Oracle (numpy restatement of the reference) on a bounded sample: 2 sequences x 28 layers
+    x 4 decode steps at row length 4160 (the mean of the 4096..4224 cycle) + one burst
+    selection over the 56 (layer, sequence) rows amortised over the 128-step interval."""
+    from oracle import bf16_round
+    from oracle import decode_attention as oda
+    from oracle import h2o as oh
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:      # pragma: no cover
+        limiter = None
+    rng = np.random.default_rng(seed)
+    B, Hq, Hkv, D, Lrow, layers, steps = 2, 28, 4, 128, 4160, 28, 4
+    slots = B * 4224 + 64
+    k = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.3).astype(np.float32))
+    v = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.3).astype(np.float32))
+    q = bf16_round((rng.standard_normal((B, Hq, D)) * 0.3).astype(np.float32))
+    req = rng.permutation(slots)[: B * 4224].reshape(B, 4224).astype(np.int32)
+    rows = np.arange(B, dtype=np.int32)
+    lens = np.full(B, Lrow, np.int32)
+    cum = rng.random((B, Lrow - 1)).astype(np.float32)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for _l in range(layers):
+            raw = np.full((B, Lrow), -1e20, np.float32)
+            mid, lse = oda.flash_decode_stage1(q, k, v, req, rows, lens, Lrow, 256, attn_score=raw)
+            oda.flash_decode_stage2(mid, lse, lens, 256)
+            norm = oda.h2o_normalize_decode_scores(raw, D)
+            oh.update_decode_scores(cum, norm, Lrow)
+    t_steps = time.perf_counter() - t0
+    s = rng.random((layers * B, 4224)).astype(np.float32)
+    t0 = time.perf_counter()
+    oh.select_h2o_indices_batch(s, budget=4096, recent_ratio=0.5)
+    t_burst = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
+    per_step = t_steps / steps + t_burst / 128.0
+    return {
+        "value": B / per_step, "unit": "tokens/s", "cores": 1, "kind": "port",
+        "sample": f"numpy oracle, {B} seqs x {layers} layers x {steps} decode steps at row length {Lrow} "
+                  f"(+1 burst selection over {layers * B} rows / 128 steps), {t_steps + t_burst:.1f} s of CPU work, "
+                  f"{os.cpu_count()} host cores present, 1 thread used",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    n_gpus = world if use_dist else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; running {n_gpus} rank(s)", file=sys.stderr)
+    device = f"cuda:{local_rank}"
+
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    import sparse_vllm_amd.layers.attention as attn_mod
+
+    B = args.batch
+    budget, interval = 4096, 128
+    conf = Config.from_kwargs(
+        sparse_method="h2o", num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4, head_dim=128,
+        max_model_len=131072 if B <= 64 else 8192, max_num_seqs_in_gpu=B, num_kvcache_slots=B * (budget + interval) + 4096,
+        h2o_decode_budget=budget, h2o_decode_eviction_interval=interval, h2o_prefill_budget=8192,
+        engine_prefill_chunk_size=8192, device=device)
+    drv = SparseDecodeDriver(conf)
+    cm = drv.cache_manager
+    cm.permute_free_slots(20260625 + rank)
+    drv.admit_resident_rows(B, budget, logical_len=131072, seed=20260625 + rank, device_rng=True)
+    q, k, v = drv.random_step_inputs(seed=7 + rank)
+
+    # ---- per-launch HIP events around stage 1 (same stream as the launch: torch's current stream)
+    events = []
+    record = {"on": False}
+    orig = attn_mod.flash_decode_stage1_with_score
+
+    def timed_stage1(q_, k_, v_, req, bidx, blen, max_len, mid, lse, score, block_seq):
+        if not record["on"]:
+            return orig(q_, k_, v_, req, bidx, blen, max_len, mid, lse, score, block_seq)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(q_, k_, v_, req, bidx, blen, max_len, mid, lse, score, block_seq)
+        e1.record()
+        events.append((e0, e1, int(max_len)))
+
+    if not args.no_kernel_events:
+        attn_mod.flash_decode_stage1_with_score = timed_stage1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        drv.step(q, k, v)
+    barrier()
+    record["on"] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.step(q, k, v)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    record["on"] = False
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tokens = n_gpus * B * args.steps
+    out = {
+        "metric": "decode tokens/s at 128k ctx, H2O budget=4k, Qwen2.5-7B (sparse attention hot path)",
+        "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {
+            "workload": "Qwen2.5-7B h2o 128k ctx decode_budget=4096 interval=128 (BASELINE.json configs[2]); "
+                        "hot path only: alloc + 28 x {store_kvcache, scored stage1, stage2, score update} + burst "
+                        "eviction every 128 steps; dense model layers not included",
+            "seqs_per_gpu": B, "global_batch": n_gpus * B, "resident_row_len": "4096..4224", "layers": 28,
+            "heads": "28q/4kv x 128", "parallelism": f"replicas x{n_gpus} (sequence-sharded, no collective)",
+        },
+    }
+    if events:
+        torch.cuda.synchronize()
+        ms = np.array([e0.elapsed_time(e1) for e0, e1, _ in events])
+        byts = np.array([B * L * (2 * 4 * 128 * 2 + 4 + 4) for _, _, L in events], dtype=np.float64)
+        achieved = float(byts.sum() / (ms.sum() * 1e-3))
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "stage1_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "kernel": "decode_stage1_kernel<128,7> (scored GQA split-KV decode)",
+            "launches_timed": len(events), "avg_launch_us": float(ms.mean() * 1e3),
+            "algorithmic_bytes_per_launch": float(byts.mean()),
+        }
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,201 @@
+"""Operator surface of the cache managers (mirror of engine/cache_manager/base.py).
+
+Types: LayerBatchStates (:71-81), SparseSelection (:129-143), AttentionViewMeta (:146-155),
+ExplicitKVPayload (:158-165), DecodeComputeView / PrefillComputeView (:198-211);
+`CacheManager.create` factory (:329-369).  One manager per rank owns every KV / slot /
+score tensor for the life of the process; views handed to attention are borrowed.
+"""
+
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+
+from ...method_registry import NATIVE_SPARSE_METHODS, SUPPORTED_SPARSE_METHODS, normalize_sparse_method
+
+
+@dataclass
+class LayerBatchStates:
+    slot_mapping: torch.Tensor | None = None
+    context_lens: torch.Tensor | None = None
+    max_context_len: int | None = None
+    req_indices: torch.Tensor | None = None
+
+
+@dataclass
+class SparseSelection:
+    kind: str
+    req_indices: torch.Tensor
+    context_lens: torch.Tensor
+    max_context_len: int | None = None
+    attn_score: torch.Tensor | None = None
+    active_indices: torch.Tensor | None = None
+    active_slots: torch.Tensor | None = None
+    active_compressed_indices: torch.Tensor | None = None
+    global_req_indices: torch.Tensor | None = None
+    chunk_lens: torch.Tensor | None = None
+    release_temp_slots: bool = False
+
+
+@dataclass(frozen=True)
+class AttentionViewMeta:
+    active_slots: torch.Tensor
+    req_indices: torch.Tensor
+    context_lens: torch.Tensor
+    max_context_len: int | None = None
+    attn_score: torch.Tensor | None = None
+    temp_slots: torch.Tensor | None = None
+
+
+@dataclass(frozen=True)
+class ExplicitKVPayload:
+    k_cache: torch.Tensor
+    v_cache: torch.Tensor
+    backend: str = "dense"
+    metadata: dict[str, Any] | None = None
+
+
+@dataclass(frozen=True)
+class DecodeComputeView:
+    meta: AttentionViewMeta
+    payload: ExplicitKVPayload
+
+
+@dataclass(frozen=True)
+class PrefillComputeView:
+    meta: AttentionViewMeta
+    payload: ExplicitKVPayload
+
+
+class CacheManager(ABC):
+    """One per rank; owns the physical slots and KV of every layer."""
+
+    validate_runtime_invariants = False
+
+    def __init__(self, config, parallel_context=None):
+        self.config = config
+        self.validate_runtime_invariants = bool(getattr(config, "validate_runtime_invariants", False))
+        self.parallel_context = parallel_context
+        self.tp_size = int(getattr(config, "tp_size", 1))
+        self.device = torch.device(config.device)
+        self.num_layers = int(config.num_hidden_layers)
+        self.num_kv_layers = self.num_layers
+        self.num_kv_heads = int(config.num_key_value_heads) // self.tp_size
+        self.num_heads = int(config.num_attention_heads) // self.tp_size
+        self.head_dim = int(config.head_dim)
+        self.max_model_len = int(config.max_model_len)
+        self.max_buffer_rows = int(config.max_num_seqs_in_gpu)
+        self.kv_cache = None
+        self._decode_static_max_context_len: int | None = None
+        self.layer_batch_states = [LayerBatchStates() for _ in range(self.num_layers)]
+
+    # layout helpers (reference: runtime_layout; Qwen2 has a KV cache on every layer)
+    def kv_layer_index(self, layer_idx: int) -> int:
+        layer_idx = int(layer_idx)
+        if not 0 <= layer_idx < self.num_layers:
+            raise ValueError(f"layer {layer_idx} has no KV cache")
+        return layer_idx
+
+    def kv_transformer_layer_indices(self) -> tuple[int, ...]:
+        return tuple(range(self.num_layers))
+
+    def is_full_attention_layer(self, layer_idx: int) -> bool:
+        return 0 <= int(layer_idx) < self.num_layers
+
+    @staticmethod
+    def create(config, parallel_context=None) -> "CacheManager":
+        """base.py:329-369."""
+        sparse_method = normalize_sparse_method(config.vllm_sparse_method)
+        if sparse_method not in SUPPORTED_SPARSE_METHODS:
+            raise ValueError(f"Unsupported vllm_sparse_method={sparse_method!r}.")
+        if sparse_method not in NATIVE_SPARSE_METHODS:
+            raise NotImplementedError(
+                f"sparse_method={sparse_method!r} is outside the MI355X hot-path build (SURVEY.md section 8); "
+                f"native methods: {sorted(m or 'vanilla' for m in NATIVE_SPARSE_METHODS)}.")
+        if sparse_method == "streamingllm":
+            from .streamingllm import StreamingLLMCacheManager
+            return StreamingLLMCacheManager(config, parallel_context)
+        if sparse_method == "snapkv":
+            from .snapkv import SnapKVCacheManager
+            return SnapKVCacheManager(config, parallel_context)
+        if sparse_method == "h2o":
+            from .h2o import H2OCacheManager
+            return H2OCacheManager(config, parallel_context)
+        if sparse_method == "quest":
+            from .quest import QuestCacheManager
+            return QuestCacheManager(config, parallel_context)
+        if sparse_method == "deltakv":
+            from .deltakv import DeltaKVCacheManager
+            return DeltaKVCacheManager(config, parallel_context)
+        from .standard import StandardCacheManager
+        return StandardCacheManager(config, parallel_context)
+
+    # ---- abstract operator set (base.py:595-614, :981-983, :1228-1231, :1803-1817)
+    @abstractmethod
+    def allocate_kv_cache(self): ...
+
+    @abstractmethod
+    def get_layer_batch_states(self, layer_idx: int) -> LayerBatchStates: ...
+
+    @abstractmethod
+    def get_layer_kv_cache(self, layer_idx: int): ...
+
+    @abstractmethod
+    def get_layer_buffer_req_to_token_slots(self, layer_idx: int) -> torch.Tensor: ...
+
+    @property
+    @abstractmethod
+    def num_free_slots(self) -> int: ...
+
+    @abstractmethod
+    def free_seq(self, seq_id: int): ...
+
+    @abstractmethod
+    def free_part_slots(self, layer_idx: int, seq, keep_indices: torch.Tensor, *, keep_indices_sorted: bool = False): ...
+
+    @abstractmethod
+    def _prepare_prefill(self, seqs): ...
+
+    @abstractmethod
+    def _prepare_decode(self, seqs): ...
+
+    # ---- shared hooks with reference defaults
+    def get_layer_store_view(self, layer_idx: int):
+        return self.get_layer_kv_cache(layer_idx)
+
+    def get_layer_compute_tensors(self, layer_idx: int):
+        return self.get_layer_kv_cache(layer_idx)
+
+    def get_decode_block_seq(self, layer_idx: int, default: int) -> int:
+        return int(default)
+
+    def save_rope_kv_if_needed(self, layer_idx: int, k: torch.Tensor, v: torch.Tensor):
+        """base.py:629-694 (_store_layer_kv): scatter this step's K/V rows to their slots."""
+        from ...kernels import store_kvcache
+        k_cache, v_cache = self.get_layer_store_view(layer_idx)
+        store_kvcache(k, v, k_cache, v_cache, self.layer_batch_states[layer_idx].slot_mapping)
+
+    def build_decode_compute_view(self, layer_idx: int, q: torch.Tensor, selection: SparseSelection, *,
+                                  num_heads: int, num_kv_heads: int) -> DecodeComputeView:
+        """base.py:1162-1206: full physical row of every request."""
+        k_cache, v_cache = self.get_layer_compute_tensors(layer_idx)
+        meta = AttentionViewMeta(
+            active_slots=self.get_layer_buffer_req_to_token_slots(layer_idx),
+            req_indices=selection.req_indices, context_lens=selection.context_lens,
+            max_context_len=selection.max_context_len, attn_score=selection.attn_score)
+        return DecodeComputeView(meta=meta, payload=ExplicitKVPayload(k_cache=k_cache, v_cache=v_cache))
+
+    def record_decode_query(self, layer_idx: int, q: torch.Tensor):
+        return None
+
+    def on_layer_attention_end(self, layer_idx: int):
+        return None
+
+    def release_layer_temp_slots(self, layer_idx: int, temp_slots):
+        return None
+
+    def on_forward_end(self, seqs, is_prefill: bool):
+        return None

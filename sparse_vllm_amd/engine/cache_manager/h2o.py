@@ -1,0 +1,307 @@
+"""H2O physical KV eviction: one cumulative token-importance vector per (layer, row).
+
+Host mirror of `H2OCacheManager` (engine/cache_manager/h2o.py:25-1674).  Differences in
+*representation* only (results are the reference's):
+  * the reference keeps a Python dict {(layer, seq_id): 1-D tensor} and restacks 28*B
+    tensors every token (h2o.py:1009-1037); here the scores live in ONE persistent device
+    tensor `h2o_score_tensor[L, rows, max_model_len]` aligned with the slot table, updated
+    by the fused decode-score kernel and compacted by the same kernel that compacts the
+    slot table;
+  * selection, compaction and the score gather are libsvk kernels (bit-exact indices).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from ...kernels import h2o_ops
+from .snapkv import SnapKVCacheManager
+
+
+@dataclass(frozen=True)
+class _H2ORowRef:
+    """Stand-in for an unscheduled active decode row (h2o.py `_H2ORowRef`)."""
+    seq_id: int
+
+
+class H2OCacheManager(SnapKVCacheManager):
+    def __init__(self, config, parallel_context=None):
+        super().__init__(config, parallel_context)
+        self._h2o_active_decode_seq_ids: set[int] = set()
+        self._h2o_counters = {
+            "intermediate_prefill_evictions": 0,
+            "final_prefill_evictions": 0,
+            "decode_eviction_bursts": 0,
+            "decode_evictions": 0,
+            "dropped_tokens": 0,
+        }
+        self._h2o_final_prefill_workspace: torch.Tensor | None = None
+        self.h2o_score_tensor = torch.zeros(
+            (self.num_kv_layers, self.max_buffer_rows, self.max_model_len), dtype=torch.float32, device=self.device)
+
+    # ---- config views (h2o.py:55-71)
+    @property
+    def h2o_decode_budget(self) -> int:
+        return int(self.config.h2o_decode_budget)
+
+    @property
+    def h2o_decode_eviction_interval(self) -> int:
+        return int(self.config.h2o_decode_eviction_interval)
+
+    @property
+    def h2o_prefill_budget(self) -> int:
+        return int(self.config.h2o_prefill_budget)
+
+    def _h2o_budget_partition(self) -> tuple[int, int]:
+        budget = self.h2o_decode_budget
+        recent_count = max(1, int(budget * float(self.config.h2o_recent_ratio)))
+        recent_count = min(recent_count, budget)
+        return budget - recent_count, recent_count
+
+    def decode_cuda_graph_context_capacity(self, seqs=None, *, requested_context_capacity: int = 0,
+                                           current_context_capacity: int = 0) -> tuple[int, bool]:
+        """h2o.py:241-254: graph capacity = the periodic decode peak."""
+        capacity = min(self.h2o_decode_budget + self.h2o_decode_eviction_interval, int(self.config.max_model_len))
+        return max(1, capacity), False
+
+    # ---- selection (device, bit-exact with h2o.py:478-563)
+    @staticmethod
+    def select_h2o_indices_batch(scores: torch.Tensor, *, budget: int, recent_ratio: float) -> torch.Tensor:
+        return h2o_ops.select_h2o_indices_batch(scores, budget=budget, recent_ratio=recent_ratio)
+
+    @staticmethod
+    def select_h2o_indices(scores: torch.Tensor, *, budget: int, recent_ratio: float) -> torch.Tensor:
+        if scores.dim() != 1:
+            raise ValueError(f"H2O scores must be 1D, got shape={tuple(scores.shape)}.")
+        return h2o_ops.select_h2o_indices_batch(scores.unsqueeze(0), budget=budget, recent_ratio=recent_ratio)[0]
+
+    # ---- score rows
+    def _row_payload_tensor(self):
+        return self.h2o_score_tensor
+
+    def _on_row_released(self, layer_idx: int, row: int):
+        self.h2o_score_tensor[self.kv_layer_index(layer_idx), row].zero_()
+
+    def _physical_row_len(self, layer_idx: int, seq) -> int:
+        row = self.seq_id_to_row[layer_idx].get(int(seq.seq_id))
+        if row is None:
+            raise RuntimeError(f"H2O physical row is missing: layer={layer_idx} seq_id={seq.seq_id}.")
+        return int(self.row_seq_lens[layer_idx][row])
+
+    def h2o_score(self, layer_idx: int, seq_id: int) -> torch.Tensor | None:
+        row = self.seq_id_to_row[layer_idx].get(int(seq_id))
+        if row is None:
+            return None
+        return self.h2o_score_tensor[self.kv_layer_index(layer_idx), row, : int(self.row_seq_lens[layer_idx][row])]
+
+    def set_h2o_score(self, layer_idx: int, seq_id: int, score: torch.Tensor):
+        row = self.seq_id_to_row[layer_idx][int(seq_id)]
+        n = int(score.numel())
+        dst = self.h2o_score_tensor[self.kv_layer_index(layer_idx), row]
+        dst[:n].copy_(score)
+        dst[n:].zero_()
+
+    def update_decode_attention_scores_all_layers(self, layer_indices, seqs, reduced_scores: torch.Tensor) -> bool:
+        """h2o.py:957-1038 as a standalone op: cum[:, :, :kv_len] = pad(prev,1) + normalized.
+        The decode loop normally never calls this - the accumulation is fused into
+        svk_h2o_decode_score_update at `on_layer_attention_end`; kept for API parity."""
+        if reduced_scores.dim() != 3:
+            raise ValueError("H2O all-layer decode scores must have shape [layers, batch, width], "
+                             f"got {tuple(reduced_scores.shape)}.")
+        if tuple(reduced_scores.shape[:2]) != (len(layer_indices), len(seqs)):
+            raise ValueError("H2O all-layer decode score shape does not match layers and batch: "
+                             f"layers={len(layer_indices)} batch={len(seqs)} shape={tuple(reduced_scores.shape)}.")
+        uniform = True
+        for i, layer_idx in enumerate(layer_indices):
+            for b, seq in enumerate(seqs):
+                kv_len = self._physical_row_len(layer_idx, seq)
+                row = self.seq_id_to_row[layer_idx][seq.seq_id]
+                dst = self.h2o_score_tensor[self.kv_layer_index(layer_idx), row]
+                dst[kv_len - 1] = 0
+                dst[:kv_len] += reduced_scores[i, b, :kv_len]
+                uniform &= kv_len == self._physical_row_len(layer_indices[0], seqs[0])
+        return uniform
+
+    # ---- decode burst (h2o.py:1498-1630)
+    def _decode_eviction_groups(self, seqs):
+        seq_ids = [int(s.seq_id) for s in seqs]
+        if len(seq_ids) != len(set(seq_ids)):
+            raise RuntimeError(f"H2O decode eviction received duplicate sequence ids: {seq_ids}.")
+        self._h2o_active_decode_seq_ids.update(seq_ids)
+        layer_indices = [int(l) for l in self.kv_transformer_layer_indices()]
+        budget = self.h2o_decode_budget
+        periodic_trigger = budget + self.h2o_decode_eviction_interval
+        under_pressure = self.num_free_slots <= 0
+        trigger = budget + 1 if under_pressure else periodic_trigger
+        seq_by_id = {int(s.seq_id): s for s in seqs}
+        candidate_ids = list(seq_ids)
+        if under_pressure:
+            candidate_ids.extend(sorted(self._h2o_active_decode_seq_ids.difference(seq_ids)))
+        groups: dict[int, list] = {}
+        for seq_id in candidate_ids:
+            seq = seq_by_id.get(seq_id, _H2ORowRef(seq_id))
+            lens = [self._physical_row_len(l, seq) for l in layer_indices]
+            if any(x != lens[0] for x in lens[1:]):
+                raise RuntimeError("H2O decode eviction requires aligned KV-layer row lengths: "
+                                   f"seq_id={seq.seq_id} lengths={lens}.")
+            if lens[0] >= trigger:
+                groups.setdefault(int(lens[0]), []).append(seq)
+        return layer_indices, groups
+
+    def _preflight_decode_eviction_capacity(self, layer_indices, groups) -> None:
+        dropped = sum((kv_len - self.h2o_decode_budget) * len(g) for kv_len, g in groups.items())
+        for l in layer_indices:
+            end = int(self._num_free_slots[l]) + int(dropped)
+            if end > self.num_slots:
+                raise RuntimeError("H2O decode eviction would overflow the free-slot stack: "
+                                   f"layer={l} end={end} capacity={self.num_slots}.")
+
+    def _evict_decode_rows(self, seqs) -> None:
+        layer_indices, groups = self._decode_eviction_groups(seqs)
+        if not groups:
+            return
+        self._preflight_decode_eviction_capacity(layer_indices, groups)
+        budget = self.h2o_decode_budget
+        ratio = float(self.config.h2o_recent_ratio)
+        evicted_rows = dropped_tokens = burst_count = 0
+        L = len(layer_indices)
+        for kv_len, group in groups.items():
+            burst_count += len(group)
+            rows = np.array([[self.seq_id_to_row[l][int(s.seq_id)] for s in group] for l in layer_indices])
+            # scores of every (layer, lane) as one strided [L*n, kv_len] view - no restacking
+            kv_layers = torch.tensor([self.kv_layer_index(l) for l in layer_indices], device=self.device)
+            rows_gpu = torch.from_numpy(rows).to(self.device)
+            scores = self.h2o_score_tensor[kv_layers[:, None], rows_gpu, :kv_len]
+            keep = self.select_h2o_indices_batch(scores.view(-1, kv_len), budget=budget,
+                                                 recent_ratio=ratio).view(L, len(group), budget)
+            self._compact(layer_indices, rows, keep, kv_len)     # slot table + free stack + score rows
+            self._uniform_decode_metadata = False
+            n = L * len(group)
+            evicted_rows += n
+            dropped_tokens += (kv_len - budget) * n
+        self._h2o_counters["decode_eviction_bursts"] += int(burst_count)
+        self._h2o_counters["decode_evictions"] += int(evicted_rows)
+        self._h2o_counters["dropped_tokens"] += int(dropped_tokens)
+
+    def evict_after_decode(self, seqs):
+        if not seqs:
+            return
+        self._evict_decode_rows(seqs)
+
+    # ---- prefill-side eviction (h2o.py:1351-1496)
+    def _evict_prefill_uniform(self, seqs, *, final: bool):
+        budget = self.h2o_decode_budget if final else self.h2o_prefill_budget
+        ratio = float(self.config.h2o_recent_ratio)
+        for layer_idx in self.kv_transformer_layer_indices():
+            lens = [self._physical_row_len(layer_idx, s) for s in seqs]
+            groups: dict[int, list] = {}
+            for s, n in zip(seqs, lens):
+                if n > budget:
+                    groups.setdefault(n, []).append(s)
+            for kv_len, group in groups.items():
+                rows = np.array([[self.seq_id_to_row[layer_idx][int(s.seq_id)] for s in group]])
+                rows_gpu = torch.from_numpy(rows[0]).to(self.device)
+                scores = self.h2o_score_tensor[self.kv_layer_index(layer_idx), rows_gpu, :kv_len]
+                keep = self.select_h2o_indices_batch(scores, budget=budget, recent_ratio=ratio)
+                if final:
+                    self._compact_final_prefill_dense_batch(layer_idx, group, keep)
+                else:
+                    self._compact([layer_idx], rows, keep.unsqueeze(0), kv_len)
+                key = "final_prefill_evictions" if final else "intermediate_prefill_evictions"
+                self._h2o_counters[key] += len(group)
+                self._h2o_counters["dropped_tokens"] += (kv_len - budget) * len(group)
+
+    def evict_after_prefill(self, seqs):
+        finals = [s for s in seqs if bool(s.is_last_chunk_prefill)]
+        inter = [s for s in seqs if not bool(s.is_last_chunk_prefill)]
+        if inter:
+            self._evict_prefill_uniform(inter, final=False)
+        if finals:
+            self._evict_prefill_uniform(finals, final=True)
+        for layer_idx in self.kv_transformer_layer_indices():
+            for s in finals:
+                kv_len = self._physical_row_len(layer_idx, s)
+                if kv_len > self.h2o_decode_budget:
+                    raise RuntimeError("H2O final prefill did not compact to the decode budget: "
+                                       f"layer={layer_idx} seq_id={s.seq_id} kv_len={kv_len} budget={self.h2o_decode_budget}.")
+        if self.num_free_slots <= 0:
+            self._evict_decode_rows([])
+
+    def _get_final_prefill_workspace(self, batch_size: int, budget: int) -> torch.Tensor:
+        """h2o.py:1065-1113."""
+        need = (2, batch_size, budget, self.num_kv_heads, self.head_dim)
+        ws = self._h2o_final_prefill_workspace
+        if ws is None or ws.shape[1] < batch_size or tuple(ws.shape[2:]) != need[2:]:
+            ws = torch.empty(need, dtype=torch.bfloat16, device=self.device)
+            self._h2o_final_prefill_workspace = ws
+        return ws[:, :batch_size]
+
+    @torch.no_grad()
+    def _compact_final_prefill_dense_batch(self, layer_idx: int, seqs, keep_indices: torch.Tensor) -> None:
+        """h2o.py:1181-1349: the selected K/V rows MOVE into the `budget` smallest physical
+        slots of the row (ascending), the larger slots are released."""
+        if not seqs:
+            raise RuntimeError("H2O final-prefill dense compaction requires sequences.")
+        kv_idx = self.kv_layer_index(layer_idx)
+        budget = self.h2o_decode_budget
+        batch = len(seqs)
+        keep = keep_indices.to(device=self.device, dtype=torch.long).contiguous()
+        if keep.dim() != 2 or tuple(keep.shape) != (batch, budget):
+            raise RuntimeError("H2O final-prefill keep indices must have shape [batch, decode_budget]: "
+                               f"expected={(batch, budget)} got={tuple(keep.shape)}.")
+        rows = [self.seq_id_to_row[layer_idx][int(s.seq_id)] for s in seqs]
+        if len(rows) != len(set(rows)):
+            raise RuntimeError(f"H2O final-prefill dense compaction received duplicate physical rows: rows={rows}.")
+        lens = [int(self.row_seq_lens[layer_idx][r]) for r in rows]
+        kv_len = lens[0]
+        if any(x != kv_len for x in lens[1:]):
+            raise RuntimeError("H2O final-prefill dense batch requires uniform physical lengths; "
+                               f"layer={layer_idx} lengths={lens}.")
+        if kv_len <= budget:
+            raise RuntimeError("H2O final-prefill dense compaction requires an over-budget row: "
+                               f"layer={layer_idx} kv_len={kv_len} budget={budget}.")
+        free_count = (kv_len - budget) * batch
+        free_ptr = int(self._num_free_slots[layer_idx])
+        if free_ptr + free_count > self.num_slots:
+            raise RuntimeError("H2O final-prefill dense compaction would overflow the free-slot stack: "
+                               f"layer={layer_idx} ptr={free_ptr} release={free_count} capacity={self.num_slots}.")
+        rows_gpu = torch.tensor(rows, dtype=torch.long, device=self.device)
+        table = self.buffer_req_to_token_slots[layer_idx]
+        old_slots = table[rows_gpu, :kv_len].to(torch.long)
+        torch._assert_async(((keep >= 0) & (keep < kv_len)).all())
+        if budget > 1:
+            torch._assert_async((keep[:, 1:] > keep[:, :-1]).all())
+        selected = old_slots.gather(1, keep)
+        sorted_old = torch.sort(old_slots, dim=1).values
+        dest = sorted_old[:, :budget].contiguous()
+        released = sorted_old[:, budget:].reshape(-1)
+        k_cache, v_cache = self.get_layer_kv_cache(layer_idx)
+        h2o_ops.copy_slots(k_cache, v_cache, selected.reshape(-1).contiguous(), dest.reshape(-1).contiguous(),
+                           self._get_final_prefill_workspace(batch, budget))
+        self.free_slots_stack[layer_idx][free_ptr: free_ptr + free_count] = released.to(torch.int32)
+        self._num_free_slots[layer_idx] = free_ptr + free_count
+        table[rows_gpu, :budget] = dest.to(torch.int32)
+        table[rows_gpu, budget:kv_len] = 0
+        sc = self.h2o_score_tensor[kv_idx]
+        kept_scores = sc[rows_gpu, :kv_len].gather(1, keep)
+        sc[rows_gpu, :budget] = kept_scores
+        sc[rows_gpu, budget:kv_len] = 0
+        self.row_seq_lens[layer_idx][rows] = budget
+        self._uniform_decode_metadata = False
+
+    # ---- lifecycle
+    def free_seq(self, seq_id: int):
+        self._h2o_active_decode_seq_ids.discard(int(seq_id))
+        super().free_seq(int(seq_id))
+
+    def reset_after_warmup(self) -> None:
+        self.h2o_score_tensor.zero_()
+        self._h2o_active_decode_seq_ids.clear()
+        for k in self._h2o_counters:
+            self._h2o_counters[k] = 0
+
+    def debug_state_summary(self) -> dict:
+        return {"h2o": {"counters": dict(self._h2o_counters), "free_slots": self.free_slot_stats()}}

@@ -1,0 +1,333 @@
+"""SnapKV-family physical cache manager: per-layer slot tables + LIFO free-slot stacks.
+
+Host mirror of `SnapKVCacheManager` (engine/cache_manager/snapkv.py:98-3055) for the
+parts on the hot path.  Same state, same names:
+
+  kv_cache                          [2, L, slots, Hkv, D] bf16     (snapkv.py:135-200)
+  buffer_req_to_token_slots_tensor  [L, rows, max_model_len] i32   row-major slot table
+  free_slots_stack_tensor           [L, slots] i32                 LIFO stack, top = _num_free_slots[l]
+  row_seq_lens / seq_id_to_row / free_rows                          host bookkeeping
+
+Slot ids move only through libsvk kernels (decode allocation, compaction); the host
+keeps the same integers the reference keeps in Python (`_num_free_slots`, `row_seq_lens`).
+In decode, "eviction" rewrites the slot table and the free stack only - K/V payload rows
+never move (snapkv.py:1528-1803).
+"""
+
+from __future__ import annotations
+
+from collections import deque
+
+import numpy as np
+import torch
+
+from ...kernels import h2o_ops
+from .base import CacheManager, LayerBatchStates
+
+
+class SnapKVCacheManager(CacheManager):
+    def __init__(self, config, parallel_context=None):
+        super().__init__(config, parallel_context)
+        self._uniform_decode_metadata = False
+        self.allocate_kv_cache()
+
+    # ------------------------------------------------------------------ allocation
+    def _resolve_num_slots(self) -> int:
+        n = int(getattr(self.config, "num_kvcache_slots", 0) or 0)
+        if n > 0:
+            return n
+        if not torch.cuda.is_available():
+            return self.max_buffer_rows * min(self.max_model_len, 8192)
+        free, _total = torch.cuda.mem_get_info(self.device)
+        per_slot = 2 * self.num_kv_layers * self.num_kv_heads * self.head_dim * 2
+        return max(1, int(free * 0.8) // per_slot)
+
+    def allocate_kv_cache(self):
+        L, rows = self.num_kv_layers, self.max_buffer_rows
+        self.num_slots = self._resolve_num_slots()
+        self.config.num_kvcache_slots = self.num_slots
+        d = self.device
+        self.kv_cache = torch.zeros((2, L, self.num_slots, self.num_kv_heads, self.head_dim),
+                                    dtype=torch.bfloat16, device=d)
+        self.buffer_req_to_token_slots_tensor = torch.zeros((L, rows, self.max_model_len), dtype=torch.int32, device=d)
+        self.buffer_req_to_token_slots = [self.buffer_req_to_token_slots_tensor[i] for i in range(L)]
+        self.free_slots_stack_tensor = torch.arange(self.num_slots, dtype=torch.int32, device=d).repeat(L, 1)
+        self.free_slots_stack = [self.free_slots_stack_tensor[i] for i in range(L)]
+        self._num_free_slots = [self.num_slots for _ in range(L)]
+        self.row_seq_lens = [np.zeros((rows,), dtype=np.int32) for _ in range(L)]
+        self.seq_id_to_row = [dict() for _ in range(L)]
+        self.free_rows = [deque(range(rows)) for _ in range(L)]
+        self._layer_ids_all = torch.arange(L, dtype=torch.int32, device=d)
+        self._decode_static_buffers = None
+
+    def permute_free_slots(self, seed: int):
+        """Shuffle the initial free stack (benchmarks/tests: makes the KV gather genuinely
+        paged).  Only valid while every slot is free."""
+        assert all(n == self.num_slots for n in self._num_free_slots)
+        g = torch.Generator(device="cpu").manual_seed(int(seed))
+        for l in range(self.num_kv_layers):
+            self.free_slots_stack_tensor[l].copy_(torch.randperm(self.num_slots, generator=g).to(torch.int32))
+
+    # ------------------------------------------------------------------ accessors
+    def get_layer_batch_states(self, layer_idx: int) -> LayerBatchStates:
+        return self.layer_batch_states[layer_idx]
+
+    def get_layer_kv_cache(self, layer_idx: int):
+        i = self.kv_layer_index(layer_idx)
+        return self.kv_cache[0, i], self.kv_cache[1, i]
+
+    def get_layer_buffer_req_to_token_slots(self, layer_idx: int) -> torch.Tensor:
+        return self.buffer_req_to_token_slots[self.kv_layer_index(layer_idx)]
+
+    @property
+    def num_free_slots(self) -> int:
+        return int(min(self._num_free_slots))
+
+    def free_slot_stats(self) -> dict:
+        return {"min": int(min(self._num_free_slots)), "max": int(max(self._num_free_slots)), "total": self.num_slots}
+
+    def _get_free_row(self, layer_idx: int, seq_id: int) -> int:
+        row = self.seq_id_to_row[layer_idx].get(seq_id)
+        if row is None:
+            if not self.free_rows[layer_idx]:
+                raise RuntimeError(f"No free KV rows: layer={layer_idx} rows={self.max_buffer_rows}")
+            row = self.free_rows[layer_idx].popleft()
+            self.seq_id_to_row[layer_idx][seq_id] = row
+        return int(row)
+
+    def _row_of(self, layer_idx: int, seq) -> int:
+        row = self.seq_id_to_row[layer_idx].get(seq.seq_id)
+        if row is None:
+            raise ValueError(f"unknown seq_id={seq.seq_id} on layer={layer_idx}")
+        return int(row)
+
+    # ------------------------------------------------------------------ prefill-side allocation
+    def _allocate(self, layer_idx: int, seq_id: int, size: int) -> torch.Tensor:
+        """snapkv.py:1319-1340: LIFO pop of stack[ptr-size:ptr] appended to the row."""
+        assert self._num_free_slots[layer_idx] >= size, (
+            f"Out of KV cache slots: need {size}, free {self._num_free_slots[layer_idx]}")
+        row = self._get_free_row(layer_idx, seq_id)
+        cur = int(self.row_seq_lens[layer_idx][row])
+        if cur + int(size) > self.max_model_len:
+            raise RuntimeError("KV row length exceeds max_model_len in _allocate: "
+                               f"layer={layer_idx} seq_id={seq_id} row={row} cur_len={cur} size={int(size)} "
+                               f"max_model_len={self.max_model_len}")
+        ptr = self._num_free_slots[layer_idx]
+        select_index = self.free_slots_stack[layer_idx][ptr - size: ptr]
+        self._num_free_slots[layer_idx] -= size
+        self.buffer_req_to_token_slots[layer_idx][row, cur: cur + size] = select_index
+        self.row_seq_lens[layer_idx][row] += size
+        return select_index
+
+    def _prepare_prefill(self, seqs):
+        """One chunk per sequence appended on every layer (h2o.py:665-748 / snapkv)."""
+        d = self.device
+        chunk_lens = [int(s.current_chunk_size) for s in seqs]
+        total = sum(chunk_lens)
+        for layer_idx in self.kv_transformer_layer_indices():
+            parts, ctx, rows = [], [], []
+            for s, n in zip(seqs, chunk_lens):
+                parts.append(self._allocate(layer_idx, s.seq_id, n).clone())
+                row = self.seq_id_to_row[layer_idx][s.seq_id]
+                rows.append(row)
+                ctx.append(int(self.row_seq_lens[layer_idx][row]))
+            st = self.layer_batch_states[layer_idx]
+            st.slot_mapping = torch.cat(parts) if parts else torch.empty(0, dtype=torch.int32, device=d)
+            st.context_lens = torch.tensor(ctx, dtype=torch.int32, device=d)
+            st.req_indices = torch.tensor(rows, dtype=torch.int32, device=d)
+            st.max_context_len = max(ctx) if ctx else 0
+        cu = np.concatenate(([0], np.cumsum(chunk_lens))).astype(np.int32)
+        return torch.from_numpy(cu).to(d), total
+
+    # ------------------------------------------------------------------ decode-side allocation
+    def _get_decode_static_buffers(self, graph_batch_size: int):
+        """snapkv.py:2698-2750: persistent [L, B] metadata (graph-stable addresses)."""
+        buf = self._decode_static_buffers
+        if buf is None or buf[0].shape[1] < graph_batch_size:
+            d = self.device
+            L = self.num_layers
+            buf = tuple(torch.zeros((L, graph_batch_size), dtype=torch.int32, device=d) for _ in range(3))
+            self._decode_static_buffers = buf
+        return tuple(t[:, :graph_batch_size] for t in buf)
+
+    def prepare_decode_static(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,
+                              req_indices=None, *, graph_batch_size: int | None = None):
+        """Device-side decode step preparation for all layers in ONE launch
+        (h2o.py:256-476 / snapkv.py:2961): every layer pops the window
+        [ptr-B, ptr) of its free stack, lane b's slot is appended to row b."""
+        real_batch_size = len(seqs)
+        if real_batch_size <= 0:
+            raise ValueError("Static decode requires a non-empty real decode batch.")
+        graph_batch_size = int(graph_batch_size or (input_ids.numel() if input_ids is not None else real_batch_size))
+        if real_batch_size > graph_batch_size:
+            raise ValueError("Static decode graph batch is smaller than the real decode batch: "
+                             f"graph={graph_batch_size}, real={real_batch_size}.")
+        layer_ids = self.kv_transformer_layer_indices()
+        first = layer_ids[0]
+        rows = [self._row_of(first, s) for s in seqs]
+        cur_lens = self.row_seq_lens[first][rows].copy()
+        if self.validate_runtime_invariants:
+            for l in layer_ids[1:]:
+                if [self._row_of(l, s) for s in seqs] != rows or not np.array_equal(self.row_seq_lens[l][rows], cur_lens):
+                    raise RuntimeError("static decode requires uniform request rows/lengths across KV layers")
+        max_cur = int(cur_lens.max())
+        if max_cur + 1 > self.max_model_len:
+            raise RuntimeError(f"KV row length exceeds max_model_len in static decode: max_cur_len={max_cur} "
+                               f"max_model_len={self.max_model_len}.")
+        static_cap = self._decode_static_max_context_len
+        if static_cap is not None and max_cur + 1 > int(static_cap):
+            raise RuntimeError("static decode context exceeds the captured graph capacity: "
+                               f"next_len={max_cur + 1} static_cap={int(static_cap)}.")
+        free_ptrs = [int(self._num_free_slots[l]) for l in layer_ids]
+        if any(p != free_ptrs[0] for p in free_ptrs[1:]):
+            raise RuntimeError(f"static decode requires aligned per-layer free-stack pointers: ptrs={free_ptrs}.")
+        if free_ptrs[0] < real_batch_size:
+            raise RuntimeError(f"Out of KV cache slots in static decode: need={real_batch_size} free={free_ptrs[0]}.")
+        d = self.device
+        key = (tuple(s.seq_id for s in seqs), tuple(rows))
+        cached = getattr(self, "_decode_static_rows", None)
+        if cached is None or cached[0] != key:
+            cached = (key, torch.tensor(rows, dtype=torch.int32, device=d))
+            self._decode_static_rows = cached
+        rows_gpu = cached[1]
+        cur_gpu = torch.from_numpy(cur_lens.astype(np.int32)).to(d, non_blocking=True)
+        sm, cl, ri = self._get_decode_static_buffers(graph_batch_size)
+        h2o_ops.decode_alloc_slots(self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor,
+                                   self._layer_ids_all, rows_gpu, cur_gpu, sm, cl, ri,
+                                   free_ptr=free_ptrs[0], batch=real_batch_size)
+        for l in layer_ids:
+            self._num_free_slots[l] -= real_batch_size
+            self.row_seq_lens[l][rows] = cur_lens + 1
+        max_context_len = int(static_cap) if static_cap is not None else max_cur + 1
+        for l in layer_ids:
+            st = self.layer_batch_states[l]
+            st.slot_mapping, st.context_lens, st.req_indices = sm[l], cl[l], ri[l]
+            st.max_context_len = max_context_len
+        if slot_mapping is not None:
+            slot_mapping.copy_(sm[first])
+            context_lens.copy_(cl[first])
+            req_indices.copy_(ri[first])
+        return input_ids, positions, None
+
+    def _prepare_decode(self, seqs):
+        return self.prepare_decode_static(seqs)
+
+    # ------------------------------------------------------------------ release / compaction
+    def free_seq(self, seq_id: int):
+        """snapkv.py:1489-1514."""
+        for layer_idx in self.kv_transformer_layer_indices():
+            row = self.seq_id_to_row[layer_idx].pop(seq_id, None)
+            if row is None:
+                raise ValueError(f"free_seq: unknown seq_id={seq_id}")
+            cur = int(self.row_seq_lens[layer_idx][row])
+            if cur > 0:
+                ptr = self._num_free_slots[layer_idx]
+                self.free_slots_stack[layer_idx][ptr: ptr + cur] = self.buffer_req_to_token_slots[layer_idx][row, :cur]
+                self._num_free_slots[layer_idx] += cur
+            self.buffer_req_to_token_slots[layer_idx][row, :] = 0
+            self.row_seq_lens[layer_idx][row] = 0
+            self.free_rows[layer_idx].append(row)
+            self._on_row_released(layer_idx, row)
+
+    def _on_row_released(self, layer_idx: int, row: int):
+        return None
+
+    def _row_payload_tensor(self):
+        """Optional f32 rows compacted together with the slot table (H2O scores)."""
+        return None
+
+    def _compact(self, layer_indices, rows_2d: np.ndarray, keep: torch.Tensor, cur_len: int):
+        """Uniform-length fused compaction through svk_compact_rows."""
+        d = self.device
+        n_layers, n_lanes, keep_len = keep.shape
+        drop = cur_len - keep_len
+        free_base = torch.tensor([self._num_free_slots[int(l)] for l in layer_indices], dtype=torch.long, device=d)
+        for l in layer_indices:
+            if self._num_free_slots[int(l)] + drop * n_lanes > self.num_slots:
+                raise RuntimeError("compaction would overflow the free-slot stack: "
+                                   f"layer={int(l)} end={self._num_free_slots[int(l)] + drop * n_lanes} capacity={self.num_slots}.")
+        h2o_ops.compact_rows(
+            self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor, keep.contiguous(),
+            torch.tensor([self.kv_layer_index(int(l)) for l in layer_indices], dtype=torch.int32, device=d),
+            torch.from_numpy(np.ascontiguousarray(rows_2d, dtype=np.int32)).to(d),
+            free_base, cur_len=cur_len, row_payload=self._row_payload_tensor())
+        for i, l in enumerate(layer_indices):
+            self._num_free_slots[int(l)] += drop * n_lanes
+            self.row_seq_lens[int(l)][rows_2d[i]] = keep_len
+
+    def _check_keep(self, keep: torch.Tensor, cur_len: int, sorted_: bool) -> torch.Tensor:
+        keep = keep.to(device=self.device, dtype=torch.long).contiguous()
+        if keep.numel() <= 0 or keep.shape[-1] <= 0:
+            raise RuntimeError("free_part_slots got empty keep_indices")
+        bounds_ok = ((keep >= 0) & (keep < cur_len)).all()
+        torch._assert_async(bounds_ok)            # device-side check, no host sync (snapkv.py:1738-1746)
+        if not sorted_:
+            keep = torch.sort(keep, dim=-1).values
+        return keep
+
+    def free_part_slots(self, layer_idx: int, seq, keep_indices: torch.Tensor, *, keep_indices_sorted: bool = False):
+        """snapkv.py:1528-1591."""
+        if keep_indices is None:
+            return
+        self.kv_layer_index(layer_idx)
+        self._uniform_decode_metadata = False
+        row = self._row_of(layer_idx, seq)
+        cur = int(self.row_seq_lens[layer_idx][row])
+        keep = self._check_keep(keep_indices.reshape(-1), cur, keep_indices_sorted)
+        self._compact([layer_idx], np.array([[row]]), keep.view(1, 1, -1), cur)
+
+    def free_part_slots_batch(self, layer_idx: int, seqs, keep_indices: torch.Tensor, *, keep_indices_sorted: bool = False):
+        """snapkv.py:1593-1679."""
+        if keep_indices is None or not seqs:
+            return
+        self.free_part_slots_batch_layers([layer_idx], seqs, keep_indices.unsqueeze(0),
+                                          keep_indices_sorted=keep_indices_sorted)
+
+    def free_part_slots_batch_layers(self, layer_indices, seqs, keep_indices: torch.Tensor, *,
+                                     keep_indices_sorted: bool = False):
+        """snapkv.py:1681-1803: fused over layers when every (layer,row) has one length,
+        otherwise the reference's per-row fallback order."""
+        if keep_indices is None or not layer_indices or not seqs:
+            return
+        layer_indices = [int(l) for l in layer_indices]
+        for l in layer_indices:
+            self.kv_layer_index(l)
+        self._uniform_decode_metadata = False
+        n_layers, batch = len(layer_indices), len(seqs)
+        if keep_indices.dim() != 3 or tuple(keep_indices.shape[:2]) != (n_layers, batch):
+            raise RuntimeError("free_part_slots_batch_layers expected keep_indices with shape [layers, batch, keep]: "
+                               f"layers={n_layers} batch={batch} keep_shape={tuple(keep_indices.shape)}")
+        rows = np.array([[self._row_of(l, s) for s in seqs] for l in layer_indices], dtype=np.int64)
+        lens = np.array([[int(self.row_seq_lens[l][r]) for r in rows[i]] for i, l in enumerate(layer_indices)])
+        cur = int(lens[0, 0])
+        if not np.all(lens == cur):
+            for i, l in enumerate(layer_indices):
+                for j, s in enumerate(seqs):
+                    self.free_part_slots(l, s, keep_indices[i, j], keep_indices_sorted=keep_indices_sorted)
+            return
+        keep = self._check_keep(keep_indices, cur, keep_indices_sorted)
+        self._compact(layer_indices, rows, keep, cur)
+
+    def free_prefix_recent_slots_batch_layers(self, layer_indices, seqs, *, kv_len: int, num_sink_tokens: int,
+                                              num_recent_tokens: int):
+        """snapkv.py:1805-1896 (StreamingLLM sink + recent window)."""
+        if not layer_indices or not seqs:
+            return
+        layer_indices = [int(l) for l in layer_indices]
+        self._uniform_decode_metadata = False
+        kv_len = int(kv_len)
+        sink_end = min(int(num_sink_tokens), kv_len)
+        recent_start = max(sink_end, kv_len - int(num_recent_tokens))
+        new_len = sink_end + (kv_len - recent_start)
+        if new_len <= 0:
+            raise RuntimeError("prefix/recent compaction cannot keep zero tokens.")
+        if new_len >= kv_len:
+            return
+        rows = np.array([[self._row_of(l, s) for s in seqs] for l in layer_indices], dtype=np.int64)
+        lens = np.array([[int(self.row_seq_lens[l][r]) for r in rows[i]] for i, l in enumerate(layer_indices)])
+        if not np.all(lens == kv_len):
+            raise RuntimeError(f"prefix/recent compaction expected uniform row lengths: kv_len={kv_len} observed={lens.tolist()}")
+        d = self.device
+        keep1 = torch.cat((torch.arange(sink_end, device=d), torch.arange(recent_start, kv_len, device=d)))
+        keep = keep1.expand(len(layer_indices), len(seqs), -1).contiguous()
+        self._compact(layer_indices, rows, keep, kv_len)

@@ -1,0 +1,109 @@
+"""Minimal own counterpart of the reference's decode step loop for the sparse attention path.
+
+`ModelRunner.run` decode branch (engine/model_runner.py:1418-1445) drives, per step,
+    cache_manager.prepare_decode_static -> sparse_controller.prepare_forward
+    -> [per layer: save_rope_kv_if_needed, Attention.forward] -> sparse_controller.post_forward
+around the model's dense layers.  The dense layers (QKV/MLP GEMMs) are NOT part of this
+build; this driver feeds the attention path with per-layer synthetic q/k/v of the model's
+shape so the path can be exercised, parity-checked and measured exactly in the order the
+engine would run it.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..config import Config
+from ..layers.attention import Attention
+from ..operators.decode_attention import DecodeAttentionLaunchSpec, prepare_decode_launch_op
+from ..platforms import current_platform
+from ..utils.context import set_context
+from .cache_manager.base import CacheManager
+from .sequence import Sequence
+from .sparse_controller import SparseController
+
+
+class SparseDecodeDriver:
+    def __init__(self, config: Config, *, use_launch_provider: bool = True):
+        self.config = config
+        self.device = torch.device(config.device)
+        self.cache_manager = CacheManager.create(config)
+        self.sparse_controller = SparseController(config, self.cache_manager)
+        cm = self.cache_manager
+        launch_op = None
+        if use_launch_provider:
+            launch_op = prepare_decode_launch_op(
+                DecodeAttentionLaunchSpec(cm.num_heads, cm.num_kv_heads, cm.head_dim, config.vllm_sparse_method),
+                current_platform.device_caps(self.device))
+        self.attn = Attention(cm.num_heads, cm.head_dim, cm.head_dim ** -0.5, cm.num_kv_heads,
+                              decode_launch_op=launch_op)
+        self.seqs: list[Sequence] = []
+
+    # ------------------------------------------------------------------ synthetic state
+    def admit_resident_rows(self, batch: int, resident_len: int, *, logical_len: int | None = None, seed: int = 0,
+                            kv_scale: float = 0.3, fill_kv: bool = True, device_rng: bool = False):
+        """Create `batch` sequences whose physical rows already hold `resident_len` tokens
+        per layer (the state a long prompt is in after chunked prefill + final compaction),
+        with random K/V payload and, for H2O, random positive cumulative scores."""
+        cm = self.cache_manager
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        gd = torch.Generator(device=self.device).manual_seed(seed) if device_rng else None
+        self.seqs = [Sequence(num_prompt_tokens=int(logical_len or resident_len)) for _ in range(batch)]
+        for s in self.seqs:
+            s.num_prefilled_tokens = s.num_prompt_tokens
+        for layer_idx in cm.kv_transformer_layer_indices():
+            for s in self.seqs:
+                cm._allocate(layer_idx, s.seq_id, resident_len)
+        if fill_kv:
+            # fill only the slots in use, layer by layer, to bound host memory
+            for layer_idx in cm.kv_transformer_layer_indices():
+                n = cm.num_slots
+                for kv in range(2):
+                    chunk = 1 << 16
+                    for s0 in range(0, n, chunk):
+                        s1 = min(n, s0 + chunk)
+                        shape = (s1 - s0, cm.num_kv_heads, cm.head_dim)
+                        if gd is not None:
+                            blk = torch.randn(shape, generator=gd, device=self.device) * kv_scale
+                        else:
+                            blk = torch.randn(shape, generator=g) * kv_scale
+                        cm.kv_cache[kv, layer_idx, s0:s1].copy_(blk.to(torch.bfloat16))
+        if hasattr(cm, "h2o_score_tensor"):
+            for layer_idx in cm.kv_transformer_layer_indices():
+                for s in self.seqs:
+                    sc0 = (torch.rand(resident_len, generator=gd, device=self.device) if gd is not None
+                           else torch.rand(resident_len, generator=g).to(self.device))
+                    cm.set_h2o_score(layer_idx, s.seq_id, sc0)
+        return self.seqs
+
+    def random_step_inputs(self, seed: int = 1, scale: float = 0.3):
+        """Per-layer q [L,B,Hq,D] and new-token k,v [L,B,Hkv,D] (bf16)."""
+        cm = self.cache_manager
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        B, L = len(self.seqs), cm.num_layers
+        mk = lambda h: (torch.randn((L, B, h, cm.head_dim), generator=g) * scale).to(torch.bfloat16).to(self.device)
+        return mk(cm.num_heads), mk(cm.num_kv_heads), mk(cm.num_kv_heads)
+
+    # ------------------------------------------------------------------ one decode step
+    @torch.no_grad()
+    def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None):
+        cm, sc = self.cache_manager, self.sparse_controller
+        seqs = self.seqs
+        cm.prepare_decode_static(seqs)
+        ctx = set_context(False, cache_manager=cm, sparse_controller=sc)
+        sc.prepare_forward(seqs, False)
+        for layer_idx in range(cm.num_layers):
+            ctx.now_layer_idx = layer_idx
+            cm.save_rope_kv_if_needed(layer_idx, k[layer_idx], v[layer_idx])
+            o = self.attn(q[layer_idx])
+            if outputs is not None:
+                outputs[layer_idx].copy_(o)
+        sc.post_forward(seqs, False)
+        cm.on_forward_end(seqs, False)
+        for s in seqs:
+            s.append_token(0)
+
+    def row_len(self) -> np.ndarray:
+        cm = self.cache_manager
+        return np.array([cm.row_seq_lens[0][cm.seq_id_to_row[0][s.seq_id]] for s in self.seqs])

@@ -1,0 +1,115 @@
+"""Attention layer for the sparse decode path (mirror of layers/attention.py:75-257 decode
+branch and layers/attention_backend.py:217-349 `run_decode`).
+
+Per-layer call order is the reference's:
+    get_decode_selection -> build_decode_compute_view -> get_decode_block_seq -> run_decode
+    -> record_decode_query -> sparse_controller.on_layer_attention_end
+    -> cache_manager.on_layer_attention_end -> release_layer_temp_slots (finally)
+"""
+
+from __future__ import annotations
+
+import torch
+
+from ..engine.cache_manager.base import DecodeComputeView, ExplicitKVPayload
+from ..kernels import flash_decode_stage1, flash_decode_stage1_with_score, flash_decode_stage2
+from ..utils.context import get_context
+from ..utils.profiler import profiler
+
+
+def get_decode_workspace(context, batch_size: int, num_heads: int, num_blocks: int, head_dim: int,
+                         device: torch.device) -> tuple[torch.Tensor, torch.Tensor]:
+    """layers/attention.py:15-51: grow-only fp32 partial buffers kept on the context."""
+    mid_o = context.decode_mid_o
+    if (mid_o is None or mid_o.device != device or mid_o.shape[0] < batch_size or mid_o.shape[1] < num_heads
+            or mid_o.shape[2] < num_blocks or mid_o.shape[3] < head_dim):
+        mid_o = torch.empty((batch_size, num_heads, num_blocks, head_dim), dtype=torch.float32, device=device)
+        context.decode_mid_o = mid_o
+    mid_lse = context.decode_mid_o_logexpsum
+    if (mid_lse is None or mid_lse.device != device or mid_lse.shape[0] < batch_size or mid_lse.shape[1] < num_heads
+            or mid_lse.shape[2] < num_blocks):
+        mid_lse = torch.empty((batch_size, num_heads, num_blocks), dtype=torch.float32, device=device)
+        context.decode_mid_o_logexpsum = mid_lse
+    return (mid_o[:batch_size, :num_heads, :num_blocks, :head_dim], mid_lse[:batch_size, :num_heads, :num_blocks])
+
+
+class HipAttentionBackend:
+    """layers/attention_backend.py `TritonAttentionBackend.run_decode` on libsvk."""
+
+    def run_decode(self, q: torch.Tensor, view: DecodeComputeView, *, mid_o, mid_o_logexpsum, max_len_in_batch: int,
+                   block_seq: int, num_heads: int, num_kv_heads: int, gqa_block_n: int = 16,
+                   gqa_num_warps: int = 2) -> torch.Tensor:
+        payload = view.payload
+        if not isinstance(payload, ExplicitKVPayload):
+            raise TypeError(f"HIP decode requires ExplicitKVPayload, got {type(payload).__name__}.")
+        meta = view.meta
+        kind = "full" if int(max_len_in_batch) > 8192 else "sparse"
+        with profiler.record(f"decode_attention_stage1_{kind}"):
+            if meta.attn_score is not None:
+                flash_decode_stage1_with_score(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
+                                               meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum,
+                                               meta.attn_score, block_seq)
+            else:
+                flash_decode_stage1(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
+                                    meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum, block_seq,
+                                    gqa_block_n, gqa_num_warps)
+        o = torch.empty_like(q)
+        with profiler.record(f"decode_attention_stage2_{kind}"):
+            flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
+        return o
+
+
+class Attention(torch.nn.Module):
+    def __init__(self, num_heads, head_dim, scale, num_kv_heads, *, decode_launch_op=None):
+        super().__init__()
+        self.num_heads, self.head_dim, self.scale, self.num_kv_heads = num_heads, head_dim, scale, num_kv_heads
+        self.attention_backend = HipAttentionBackend()
+        self.decode_launch_op = decode_launch_op
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor | None = None, v: torch.Tensor | None = None):
+        context = get_context()
+        cache_manager = context.cache_manager
+        sparse_controller = context.sparse_controller
+        layer_idx = context.now_layer_idx
+        if context.is_prefill:
+            raise NotImplementedError("prefill attention is outside this round's scope (SURVEY.md 8(f).1)")
+        temp_slots = None
+        try:
+            batch_size = q.shape[0]
+            selection = sparse_controller.get_decode_selection(layer_idx, q)
+            decode_view = cache_manager.build_decode_compute_view(
+                layer_idx, q, selection, num_heads=self.num_heads, num_kv_heads=self.num_kv_heads)
+            decode_meta = decode_view.meta
+            temp_slots = decode_meta.temp_slots
+            max_context_len = decode_meta.max_context_len
+            static_cap = getattr(cache_manager, "_decode_static_max_context_len", None)
+            if static_cap is not None:
+                max_context_len = max(int(max_context_len) if max_context_len is not None else 0, int(static_cap))
+            if max_context_len is None:
+                raise RuntimeError(f"static decode requires max_context_len, got None at layer={layer_idx}")
+            max_len_in_batch = int(max_context_len)
+            if decode_meta.active_slots.dim() == 2:
+                max_len_in_batch = min(max_len_in_batch, int(decode_meta.active_slots.shape[1]))
+                if max_len_in_batch <= 0:
+                    raise RuntimeError(f"decode requires a positive context length, got {max_len_in_batch} at layer={layer_idx}")
+            block_seq = cache_manager.get_decode_block_seq(layer_idx, 256)
+            if self.decode_launch_op is None:
+                gqa_block_n, gqa_num_warps = 16, 2
+            else:
+                block_seq, gqa_block_n, gqa_num_warps = self.decode_launch_op.launch_config(
+                    block_seq=block_seq, max_context_len=max_len_in_batch,
+                    requires_attention_scores=decode_meta.attn_score is not None, batch_size=batch_size)
+            num_seq_blocks = (max_len_in_batch + block_seq - 1) // block_seq
+            mid_o, mid_lse = get_decode_workspace(context, batch_size, self.num_heads, num_seq_blocks, self.head_dim,
+                                                  q.device)
+            o = self.attention_backend.run_decode(
+                q, decode_view, mid_o=mid_o, mid_o_logexpsum=mid_lse, max_len_in_batch=max_len_in_batch,
+                block_seq=block_seq, num_heads=self.num_heads, num_kv_heads=self.num_kv_heads,
+                gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps)
+            cache_manager.record_decode_query(layer_idx, q)
+            sparse_controller.on_layer_attention_end(layer_idx)
+            cache_manager.on_layer_attention_end(layer_idx)
+            return o
+        finally:
+            if temp_slots is not None and temp_slots.numel() > 0:
+                cache_manager.release_layer_temp_slots(layer_idx, temp_slots)

@@ -1,0 +1,86 @@
+"""Decode-attention launch configuration providers (mirror of operators/decode_attention.py:13-158:
+DecodeAttentionLaunchSpec :13, provider base :29, default 16/2 :107-128).  The MI355X provider
+sizes BLOCK_SEQ so that one launch fills 256 CUs: the HIP stage-1 kernel runs one workgroup
+(= Hkv waves) per (batch lane, BLOCK_SEQ block), and wants >= ~1 workgroup per CU."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+from .registry import DeviceCaps, OpRegistry, OpResolver, PlatformEnum, SupportResult
+
+DECODE_LAUNCH_REGISTRY = OpRegistry("decode_attention_launch")
+
+
+@dataclass(frozen=True)
+class DecodeAttentionLaunchSpec:
+    num_heads: int
+    num_kv_heads: int
+    head_dim: int
+    sparse_method: str = ""
+
+
+class DecodeAttentionLaunchProvider:
+    name = "base"
+    priority = 0
+
+    def supports(self, spec: DecodeAttentionLaunchSpec, caps: DeviceCaps) -> SupportResult:
+        raise NotImplementedError
+
+    def launch_config(self, *, block_seq: int, max_context_len: int, requires_attention_scores: bool,
+                      batch_size: int | None = None) -> tuple[int, int, int]:
+        """-> (BLOCK_SEQ, block_n, num_warps)"""
+        raise NotImplementedError
+
+
+@DECODE_LAUNCH_REGISTRY.register
+class DefaultDecodeLaunchProvider(DecodeAttentionLaunchProvider):
+    """Reference default: keep the caller's BLOCK_SEQ, BLOCK_N=16, 2 warps."""
+    name = "default"
+    priority = 0
+
+    def supports(self, spec, caps):
+        return SupportResult.yes()
+
+    def launch_config(self, *, block_seq, max_context_len, requires_attention_scores, batch_size=None):
+        return int(block_seq), 16, 2
+
+
+@DECODE_LAUNCH_REGISTRY.register
+class Mi355xDecodeLaunchProvider(DecodeAttentionLaunchProvider):
+    name = "mi355x_hip"
+    priority = 100
+    TARGET_WORKGROUPS = 512        # 2 per CU
+    MIN_BLOCK_SEQ, MAX_BLOCK_SEQ = 64, 1024
+
+    def supports(self, spec, caps):
+        if caps.platform != PlatformEnum.ROCM:
+            return SupportResult.no("not a ROCm device")
+        if not caps.arch.startswith("gfx950"):
+            return SupportResult.no(f"arch {caps.arch!r} is not gfx950")
+        if spec.head_dim not in (64, 128):
+            return SupportResult.no(f"head_dim {spec.head_dim} unsupported")
+        if spec.num_heads % spec.num_kv_heads or not 1 <= spec.num_heads // spec.num_kv_heads <= 8:
+            return SupportResult.no("GQA group size must be 1..8")
+        if not 1 <= spec.num_kv_heads <= 8:
+            return SupportResult.no("1..8 KV heads per rank")
+        return SupportResult.yes()
+
+    def launch_config(self, *, block_seq, max_context_len, requires_attention_scores, batch_size=None):
+        b = max(1, int(batch_size or 1))
+        bs = self.MAX_BLOCK_SEQ
+        while bs > self.MIN_BLOCK_SEQ and b * ((int(max_context_len) + bs - 1) // bs) < self.TARGET_WORKGROUPS:
+            bs //= 2
+        return bs, 16, 4
+
+
+class PreparedDecodeAttentionLaunchOp:
+    def __init__(self, provider: DecodeAttentionLaunchProvider):
+        self.provider = provider
+
+    def launch_config(self, **kw):
+        return self.provider.launch_config(**kw)
+
+
+def prepare_decode_launch_op(spec: DecodeAttentionLaunchSpec, caps: DeviceCaps) -> PreparedDecodeAttentionLaunchOp:
+    return PreparedDecodeAttentionLaunchOp(OpResolver(DECODE_LAUNCH_REGISTRY).resolve(spec, caps))
