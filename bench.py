@@ -43,12 +43,14 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of hipGraph replay")
+    ap.add_argument("--event-steps", type=int, default=8, help="eager steps timed per launch for the roofline leg")
     return ap.parse_args()
 
 
 def cpu_baseline(seed: int = 20260625):
     """Oracle (numpy restatement of the reference) on a bounded sample: 2 sequences x 28 layers
-    x 4 decode steps at row length 4160 (the mean of the 4096..4224 cycle) + one burst
+    x 12 decode steps at row length 4160 (the mean of the 4096..4224 cycle) + one burst
     selection over the 56 (layer, sequence) rows amortised over the 128-step interval."""
     from oracle import bf16_round
     from oracle import decode_attention as oda
@@ -59,7 +61,7 @@ def cpu_baseline(seed: int = 20260625):
     except Exception:      # pragma: no cover
         limiter = None
     rng = np.random.default_rng(seed)
-    B, Hq, Hkv, D, Lrow, layers, steps = 2, 28, 4, 128, 4160, 28, 4
+    B, Hq, Hkv, D, Lrow, layers, steps = 2, 28, 4, 128, 4160, 28, 12
     slots = B * 4224 + 64
     k = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.3).astype(np.float32))
     v = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.3).astype(np.float32))
@@ -124,23 +126,37 @@ def main():
     drv.admit_resident_rows(B, budget, logical_len=131072, seed=20260625 + rank, device_rng=True)
     q, k, v = drv.random_step_inputs(seed=7 + rank)
 
-    # ---- per-launch HIP events around stage 1 (same stream as the launch: torch's current stream)
-    events = []
-    record = {"on": False}
+    # ---- stage-1 launch timing with HIP events on the launch stream (torch's current stream).
+    # Eager mode: the arguments of every stage-1 launch of a step are captured, and after the step
+    # the same 28 launches (same data, same state) are re-issued back to back between ONE pair of
+    # events.  (Bracketing each launch separately measures the event markers' own system-scope
+    # cache flushes and the Python launch latency, 2x the kernel time on this box; the re-issue is
+    # idempotent: identical partials, and the score max-combine sees identical values.)
+    events = []          # (total_ms, n_launches, row_len)
+    record = {"on": False, "calls": []}
     orig = attn_mod.flash_decode_stage1_with_score
 
-    def timed_stage1(q_, k_, v_, req, bidx, blen, max_len, mid, lse, score, block_seq):
-        if not record["on"]:
-            return orig(q_, k_, v_, req, bidx, blen, max_len, mid, lse, score, block_seq)
+    def capturing_stage1(*a):
+        if record["on"]:
+            record["calls"].append(a)
+        return orig(*a)
+
+    def time_captured_launches():
+        calls, record["calls"] = record["calls"], []
+        if not calls:
+            return
+        torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        orig(q_, k_, v_, req, bidx, blen, max_len, mid, lse, score, block_seq)
+        for a in calls:
+            orig(*a)
         e1.record()
-        events.append((e0, e1, int(max_len)))
+        torch.cuda.synchronize()
+        events.append((e0.elapsed_time(e1), len(calls), int(drv.row_len()[0])))
 
     if not args.no_kernel_events:
-        attn_mod.flash_decode_stage1_with_score = timed_stage1
+        attn_mod.flash_decode_stage1_with_score = capturing_stage1
 
     def barrier():
         torch.cuda.synchronize()
@@ -148,16 +164,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    if not args.no_graph:
+        drv.enable_decode_graph()
+    warmup = max(args.warmup, 2 if not args.no_graph else 0)   # graph capture happens in warm-up step 2
+    for _ in range(warmup):
         drv.step(q, k, v)
     barrier()
-    record["on"] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         drv.step(q, k, v)
     barrier()
     elapsed = time.perf_counter() - t0
-    record["on"] = False
+    if not args.no_kernel_events:
+        # roofline leg: the same workload continues for a few eagerly launched steps
+        drv.config.decode_cuda_graph = False
+        for _ in range(args.event_steps):
+            record["on"] = True
+            drv.step(q, k, v)
+            record["on"] = False
+            time_captured_launches()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -166,22 +191,22 @@ def main():
     tokens = n_gpus * B * args.steps
     out = {
         "metric": "decode tokens/s at 128k ctx, H2O budget=4k, Qwen2.5-7B (sparse attention hot path)",
-        "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {
             "workload": "Qwen2.5-7B h2o 128k ctx decode_budget=4096 interval=128 (BASELINE.json configs[2]); "
                         "hot path only: alloc + 28 x {store_kvcache, scored stage1, stage2, score update} + burst "
                         "eviction every 128 steps; dense model layers not included",
-            "seqs_per_gpu": B, "global_batch": n_gpus * B, "resident_row_len": "4096..4224", "layers": 28,
+            "seqs_per_gpu": B, "global_batch": n_gpus * B, "launch": "eager" if args.no_graph else "hipGraph replay", "resident_row_len": "4096..4224", "layers": 28,
             "heads": "28q/4kv x 128", "parallelism": f"replicas x{n_gpus} (sequence-sharded, no collective)",
         },
     }
     if events:
-        torch.cuda.synchronize()
-        ms = np.array([e0.elapsed_time(e1) for e0, e1, _ in events])
-        byts = np.array([B * L * (2 * 4 * 128 * 2 + 4 + 4) for _, _, L in events], dtype=np.float64)
-        achieved = float(byts.sum() / (ms.sum() * 1e-3))
+        ms_total = sum(e[0] for e in events)
+        n_launch = sum(e[1] for e in events)
+        bytes_total = float(sum(e[1] * B * e[2] * (2 * 4 * 128 * 2 + 4 + 4) for e in events))
+        achieved = bytes_total / (ms_total * 1e-3)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "stage1_traffic.json")
         if os.path.exists(pmc):
@@ -192,9 +217,12 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic,
-            "kernel": "decode_stage1_kernel<128,7> (scored GQA split-KV decode)",
-            "launches_timed": len(events), "avg_launch_us": float(ms.mean() * 1e3),
-            "algorithmic_bytes_per_launch": float(byts.mean()),
+            "kernel": "decode_stage1_kernel_v2<128,7,HEADMAX> (scored GQA split-KV decode)",
+            "launches_timed": n_launch, "avg_launch_us": ms_total * 1e3 / n_launch,
+            "timing": (f"{args.event_steps} eagerly launched steps continue the timed region; after each, its 28 "
+                       "stage-1 launches are re-issued back to back on the same data between one pair of HIP "
+                       "events on the launch stream"),
+            "algorithmic_bytes_per_launch": bytes_total / n_launch,
         }
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

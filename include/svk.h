@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 1
+#define SVK_ABI_VERSION 2
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -110,6 +110,8 @@ typedef struct SvkFlashDecodeStage1Args {
   int64_t q_stride_b, q_stride_h;
   int64_t kv_slot_stride;        /* elements between consecutive slots (>= Hkv*D)        */
   int64_t kv_head_stride;        /* elements between kv heads of one slot (>= D)         */
+  int64_t kv_num_slots;          /* slots in k_cache/v_cache (0 = unknown); enables the  */
+                                 /* 32-bit row-offset fast path when the tensor < 4 GiB  */
   int64_t req_stride;
   int64_t mid_o_stride_b, mid_o_stride_h, mid_o_stride_s;
   int64_t mid_lse_stride_b, mid_lse_stride_h;
@@ -165,6 +167,16 @@ typedef struct SvkH2oDecodeScoreArgs {
   int32_t width;
 } SvkH2oDecodeScoreArgs;
 int svk_h2o_decode_score_update(const SvkH2oDecodeScoreArgs* a, svk_stream_t stream);
+
+/* Fused decode epilogue of one H2O layer: svk_flash_decode_stage2 and
+ * svk_h2o_decode_score_update in ONE launch (independent workgroups of the same grid), i.e.
+ * flash_decoding_stage2.py:49-81 + sparse_controller.py:762-767 + h2o.py:957-1038.
+ * Same arguments and results as the two separate calls. */
+typedef struct SvkH2oDecodeFinishArgs {
+  SvkFlashDecodeStage2Args stage2;
+  SvkH2oDecodeScoreArgs score;
+} SvkH2oDecodeFinishArgs;
+int svk_h2o_decode_finish(const SvkH2oDecodeFinishArgs* a, svk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * H2O selection + slot-table compaction

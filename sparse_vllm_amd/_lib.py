@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 1
+SVK_ABI_VERSION = 2
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -45,7 +45,7 @@ class SvkFlashDecodeStage1Args(C.Structure):
     _fields_ = [("q", _p), ("k_cache", _p), ("v_cache", _p), ("req_to_tokens", _p), ("b_req_idx", _p),
                 ("b_seqlen", _p), ("mid_o", _p), ("mid_lse", _p), ("attn_score", _p),
                 ("q_stride_b", _i64), ("q_stride_h", _i64), ("kv_slot_stride", _i64), ("kv_head_stride", _i64),
-                ("req_stride", _i64), ("mid_o_stride_b", _i64), ("mid_o_stride_h", _i64), ("mid_o_stride_s", _i64),
+                ("kv_num_slots", _i64), ("req_stride", _i64), ("mid_o_stride_b", _i64), ("mid_o_stride_h", _i64), ("mid_o_stride_s", _i64),
                 ("mid_lse_stride_b", _i64), ("mid_lse_stride_h", _i64), ("score_stride_b", _i64),
                 ("score_stride_h", _i64),
                 ("batch", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
@@ -62,6 +62,10 @@ class SvkFlashDecodeStage2Args(C.Structure):
 class SvkH2oDecodeScoreArgs(C.Structure):
     _fields_ = [("attn_score", _p), ("cum_score", _p), ("b_req_idx", _p), ("b_seqlen", _p),
                 ("score_stride_b", _i64), ("cum_stride", _i64), ("scale", _f32), ("batch", _i32), ("width", _i32)]
+
+
+class SvkH2oDecodeFinishArgs(C.Structure):
+    _fields_ = [("stage2", SvkFlashDecodeStage2Args), ("score", SvkH2oDecodeScoreArgs)]
 
 
 class SvkH2oSelectArgs(C.Structure):
@@ -95,6 +99,7 @@ ENTRY_POINTS = {
     "svk_flash_decode_stage2": ([C.POINTER(SvkFlashDecodeStage2Args), _p], C.c_int),
     "svk_fill_f32": ([_p, _i64, _f32, _p], C.c_int),
     "svk_h2o_decode_score_update": ([C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
+    "svk_h2o_decode_finish": ([C.POINTER(SvkH2oDecodeFinishArgs), _p], C.c_int),
     "svk_h2o_select_indices": ([C.POINTER(SvkH2oSelectArgs), _p], C.c_int),
     "svk_compact_rows": ([C.POINTER(SvkCompactRowsArgs), _p], C.c_int),
     "svk_decode_alloc_slots": ([C.POINTER(SvkDecodeAllocArgs), _p], C.c_int),

@@ -22,6 +22,9 @@
 //     re-distributed through a 1 KiB per-wave LDS tile, V rows are read with fully
 //     coalesced 16 B/lane loads and accumulated in fp32.
 
+#include <stdlib.h>
+#include <type_traits>
+
 #include "svk_common.hpp"
 
 namespace svk {
@@ -44,7 +47,7 @@ struct Stage1Cfg {
 
 template <int D, int G>
 __global__ void __launch_bounds__(512)
-decode_stage1_kernel(const SvkFlashDecodeStage1Args a) {
+decode_stage1_kernel_v1(const SvkFlashDecodeStage1Args a) {
   using C = Stage1Cfg<D, G>;
   constexpr int NC = C::NC, JQ = C::JQ, PH = C::PH, DC = C::DC, TQ = C::TQ, NV = C::NV;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -319,6 +322,344 @@ decode_stage1_kernel(const SvkFlashDecodeStage1Args a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// v2: software-pipelined tile loop.  Same math and layouts as v1, but HBM requests stay in
+// flight while a wave computes:
+//   top of tile i : issue V(i) loads (non-temporal: each V byte is read once per launch),
+//                   prefetch slot ids (V slots of tile i+1, K slots of tile i+2)
+//   after QK^T(i) : the K registers are dead -> re-issue them for K(i+1)
+//   softmax(i), P.V(i) run under the K(i+1) loads; QK^T(i) ran under the V(i) loads.
+// No extra VGPRs versus v1 (K is single-buffered, re-armed right after the MFMAs).
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+template <int D, int G>
+struct Stage1V2Lds {
+  // P tile + 16-float pad + 64 slot ids + Q fragments (NC x 64 lanes x 16 B)
+  static constexpr int WAVE_FLOATS = Stage1Cfg<D, G>::P_FLOATS + 16 + 64 + Stage1Cfg<D, G>::NC * 64 * 4;
+};
+
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const char* p) {
+  if (NT) return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)));
+  return *reinterpret_cast<const uint4*>(p);
+}
+
+template <int D, int G, int MODE, bool NTV, bool OFF32>
+__global__ void __launch_bounds__(512)
+decode_stage1_kernel_v2(const SvkFlashDecodeStage1Args a) {
+  using C = Stage1Cfg<D, G>;
+  constexpr int NC = C::NC, JQ = C::JQ, PH = C::PH, DC = C::DC, TQ = C::TQ, NV = C::NV;
+  constexpr int WF = Stage1V2Lds<D, G>::WAVE_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Hkv = a.num_kv_heads;
+  const int b = blockIdx.y;
+  const int blk = blockIdx.x;
+  const int n = lane & 15;
+  const int jq = lane >> 4;
+  const int dc = lane % DC;
+  const int tq = lane / DC;
+  constexpr int score_mode = MODE;
+
+  const int len = a.b_seqlen[b];
+  const int start = blk * a.block_seq;
+  const int end = min(len, start + a.block_seq);
+
+  // per-wave LDS: P tile | 16-float broadcast pad | 2 x 32 slot ids | Q fragments (lane-linear)
+  float* Pw = lds + w * WF;
+  float* bc = Pw + C::P_FLOATS;
+  int* slot_lds = reinterpret_cast<int*>(bc + 16);
+  uint4* q_lds = reinterpret_cast<uint4*>(bc + 16 + 64);
+  float* spart = lds + Hkv * WF;
+  const int SP = Hkv * JQ;
+
+  float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)blk * a.mid_o_stride_s;
+  float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + blk;
+
+  if (end <= start) {
+    for (int h = 0; h < G; ++h) {
+      float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h;
+      for (int d = lane; d < D; d += 64) o[d] = 0.f;
+      if (lane == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = -INFINITY;
+    }
+    return;
+  }
+
+  const int32_t* row = a.req_to_tokens + (int64_t)a.b_req_idx[b] * a.req_stride;
+  // Byte addressing.  OFF32: the whole K (V) tensor spans < 4 GiB, so a row address is the
+  // wave-uniform tensor base (SGPR pair) + a 32-bit per-lane byte offset: one VGPR per address
+  // and 32-bit integer math instead of 64-bit (frees ~20 VGPRs in the pipelined loop).
+  const char* const kt = reinterpret_cast<const char*>(a.k_cache);
+  const char* const vt = reinterpret_cast<const char*>(a.v_cache);
+  const int64_t slot_bytes = a.kv_slot_stride * 2;
+  const int64_t k_lane_bytes = ((int64_t)w * a.kv_head_stride + jq * 8) * 2;
+  const int64_t v_lane_bytes = ((int64_t)w * a.kv_head_stride + dc * 8) * 2;
+  auto k_ptr = [&](int slot) -> const char* {
+    if (OFF32) return kt + (size_t)((uint32_t)slot * (uint32_t)slot_bytes + (uint32_t)k_lane_bytes);
+    return kt + (int64_t)slot * slot_bytes + k_lane_bytes;
+  };
+  auto v_ptr = [&](int slot) -> const char* {
+    if (OFF32) return vt + (size_t)((uint32_t)slot * (uint32_t)slot_bytes + (uint32_t)v_lane_bytes);
+    return vt + (int64_t)slot * slot_bytes + v_lane_bytes;
+  };
+  const float sm_scale = rsqrtf((float)D);
+
+  // slot ids of one 32-token tile: lanes 0..31 fetch row[t0 + lane] (one coalesced 128 B read)
+  // (index clamped to the last valid token: always a legal, branch-free load - a conditional
+  //  load would make the compiler's vmcnt bookkeeping conservative for the whole tile body)
+  auto fetch_slots = [&](int t0) -> int { return row[(uint32_t)min(t0 + (lane_id_fresh() & 31), end - 1)]; };
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // ---- prologue
+  {
+    const int s0 = fetch_slots(start);
+    if (lane < 32) slot_lds[lane] = s0;
+    const uint16_t* qp = a.q + (int64_t)b * a.q_stride_b + (int64_t)(w * G + n) * a.q_stride_h + jq * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (n < G) t = *reinterpret_cast<const uint4*>(qp + c * 32);
+      q_lds[c * 64 + lane] = t;
+    }
+  }
+  int s_next = fetch_slots(start + kTileTokens);     // slot ids of tile 1, parked in a register
+  wave_sync();
+  uint4 kr[2][NC];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const char* kp = k_ptr(slot_lds[g * 16 + n]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) kr[g][c] = ld16<false>(kp + c * 64);
+  }
+
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+  float acc[G][8];
+#pragma unroll
+  for (int h = 0; h < G; ++h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+
+  int c0 = start;     // first token of the current score chunk
+  int buf = 0;        // slot_lds half holding the current tile's ids
+  int t0 = start;
+  // One tile.  HAS_NEXT is a compile-time flag (the last tile is peeled) so that the K(i+1)
+  // re-arm is straight-line code: behind a run-time branch the compiler must assume the loads
+  // may not have been issued and turns every later vmcnt(N) into a wait for K(i+1) itself.
+  auto tile = [&](auto has_next_c) {
+    constexpr bool has_next = decltype(has_next_c)::value;
+    const bool full = has_next || (t0 + kTileTokens <= end);
+    const int* cur_slots = slot_lds + buf * 32;
+    int* nxt_slots = slot_lds + (buf ^ 1) * 32;
+
+    // ---- V(i) loads (slot ids from LDS)
+    uint4 vr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      vr[i] = ld16<NTV>(v_ptr(cur_slots[i * TQ + tq]));
+
+    // ---- publish tile i+1's slot ids (fetched one iteration ago), fetch tile i+2's
+    {
+      const int ln = lane_id_fresh();
+      if (ln < 32) nxt_slots[ln] = s_next;
+    }
+    s_next = fetch_slots(t0 + 2 * kTileTokens);
+
+    // ---- S = Q K^T on K(i)
+    f32x4_t s[2];
+    {
+      bf16x8_t qa[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) qa[c] = __builtin_bit_cast(bf16x8_t, q_lds[c * 64 + lane]);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        s[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          s[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, kr[g][c]), s[g], 0, 0, 0);
+      }
+    }
+    wave_sync();        // nxt_slots visible to every lane of this wave
+    // ---- K registers are dead: re-arm them with K(i+1)
+    if constexpr (has_next) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const char* kp = k_ptr(nxt_slots[g * 16 + n]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) kr[g][c] = ld16<false>(kp + c * 64);
+      }
+    }
+
+    bool tv[2];
+    tv[0] = full || (t0 + n < end);
+    tv[1] = full || (t0 + 16 + n < end);
+
+    if constexpr (score_mode == SVK_SCORE_PERHEAD) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int h = jq * 4 + r;
+          if (h < G && tv[g])
+            a.attn_score[(int64_t)b * a.score_stride_b + (int64_t)(w * G + h) * a.score_stride_h + t0 + g * 16 + n] = s[g][r];
+        }
+    } else if constexpr (score_mode == SVK_SCORE_HEADMAX) {
+      if (jq < JQ) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          float pm = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (jq * 4 + r < G) pm = fmaxf(pm, s[g][r]);
+          spart[(t0 - c0 + g * 16 + n) * SP + w * JQ + jq] = tv[g] ? pm : -INFINITY;
+        }
+      }
+    }
+
+    float p[2][4];
+    float alpha[4];
+    bool rescale = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool hv = (jq * 4 + r < G);
+      const float x0 = (hv && tv[0]) ? s[0][r] * sm_scale : -INFINITY;
+      const float x1 = (hv && tv[1]) ? s[1][r] * sm_scale : -INFINITY;
+      const float tmax = row16_allmax(fmaxf(x0, x1));
+      const float nm = fmaxf(m[r], tmax);
+      if (hv) {
+        alpha[r] = __expf(m[r] - nm);
+        p[0][r] = __expf(x0 - nm);
+        p[1][r] = __expf(x1 - nm);
+        rescale |= (nm != m[r]);
+      } else {
+        alpha[r] = 1.f; p[0][r] = 0.f; p[1][r] = 0.f;
+      }
+      l[r] = l[r] * alpha[r] + row16_allsum(p[0][r] + p[1][r]);
+      m[r] = hv ? nm : m[r];
+    }
+
+    if (jq < JQ) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float4 t = make_float4(bf16_round(p[g][0]), bf16_round(p[g][1]), bf16_round(p[g][2]), bf16_round(p[g][3]));
+        *reinterpret_cast<float4*>(Pw + (g * 16 + n) * PH + jq * 4) = t;
+      }
+    }
+    const bool any_rescale = __any(rescale);
+    if (any_rescale && n == 0 && jq < JQ)
+      *reinterpret_cast<float4*>(bc + jq * 4) = make_float4(alpha[0], alpha[1], alpha[2], alpha[3]);
+    wave_sync();
+
+    if (any_rescale) {
+      float al[PH];
+#pragma unroll
+      for (int q4 = 0; q4 < JQ; ++q4) {
+        float4 t = *reinterpret_cast<const float4*>(bc + q4 * 4);
+        al[q4 * 4 + 0] = t.x; al[q4 * 4 + 1] = t.y; al[q4 * 4 + 2] = t.z; al[q4 * 4 + 3] = t.w;
+      }
+#pragma unroll
+      for (int h = 0; h < G; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[h][e] *= al[h];
+    }
+
+    // P.V with the P rows double-buffered through registers: the next token group's P is
+    // read from LDS while the current one is multiplied.  The sched_barrier keeps the compiler
+    // from hoisting all NV P reads to the top (that costs 7*NV live VGPRs and spills).
+    float ph[2][PH];
+    auto read_p = [&](int i, float (&dst)[PH]) {
+#pragma unroll
+      for (int q4 = 0; q4 < JQ; ++q4) {
+        float4 t = *reinterpret_cast<const float4*>(Pw + (i * TQ + tq) * PH + q4 * 4);
+        dst[q4 * 4 + 0] = t.x; dst[q4 * 4 + 1] = t.y; dst[q4 * 4 + 2] = t.z; dst[q4 * 4 + 3] = t.w;
+      }
+    };
+    read_p(0, ph[0]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i + 1 < NV) read_p(i + 1, ph[(i + 1) & 1]);
+      uint4 vv = vr[i];
+      if (!full && (t0 + i * TQ + tq >= end)) vv = make_uint4(0, 0, 0, 0);
+      float vf[8];
+      vf[0] = bf16_lo(vv.x); vf[1] = bf16_hi(vv.x);
+      vf[2] = bf16_lo(vv.y); vf[3] = bf16_hi(vv.y);
+      vf[4] = bf16_lo(vv.z); vf[5] = bf16_hi(vv.z);
+      vf[6] = bf16_lo(vv.w); vf[7] = bf16_hi(vv.w);
+#pragma unroll
+      for (int h = 0; h < G; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[h][e] = fmaf(ph[i & 1][h], vf[e], acc[h][e]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_sync();
+
+    // ---- end of a score chunk (or of the block): one owner thread per token column
+    if (score_mode == SVK_SCORE_HEADMAX && (!has_next || (t0 + kTileTokens - c0) == kScoreChunk)) {
+      const int c1 = min(end, t0 + kTileTokens);
+      __syncthreads();
+      float* const dst = a.attn_score + (int64_t)b * a.score_stride_b + c0;     // wave-uniform base
+      for (uint32_t t = threadIdx.x; t < (uint32_t)(c1 - c0); t += blockDim.x) {
+        float mx = -INFINITY;
+        for (int j = 0; j < SP; ++j) mx = fmaxf(mx, spart[t * SP + j]);
+        dst[t] = fmaxf(dst[t], mx);
+      }
+      __syncthreads();
+      c0 = t0 + kTileTokens;
+    }
+    t0 += kTileTokens;
+    buf ^= 1;
+  };
+  while (t0 + kTileTokens < end) tile(std::true_type{});
+  tile(std::false_type{});
+
+  // ---- epilogue.  The lane id is laundered through an empty asm so that none of the output
+  // addresses below can be hoisted above the tile loop (they would stay live across it and
+  // push the loop over the 256-VGPR budget of 2 waves/SIMD).
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int n_e = lane_e & 15, jq_e = lane_e >> 4, dc_e = lane_e % DC, tq_e = lane_e / DC;
+  if (n_e == 0 && jq_e < JQ) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = jq_e * 4 + r;
+      if (h < G) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = m[r] + __logf(l[r]);
+    }
+    *reinterpret_cast<float4*>(bc + jq_e * 4) = make_float4(l[0], l[1], l[2], l[3]);
+  }
+  wave_sync();
+  float lh[PH];
+#pragma unroll
+  for (int q4 = 0; q4 < JQ; ++q4) {
+    float4 t = *reinterpret_cast<const float4*>(bc + q4 * 4);
+    lh[q4 * 4 + 0] = t.x; lh[q4 * 4 + 1] = t.y; lh[q4 * 4 + 2] = t.z; lh[q4 * 4 + 3] = t.w;
+  }
+#pragma unroll
+  for (int h = 0; h < G; ++h) {
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = acc[h][e];
+#pragma unroll
+      for (int off = DC; off < 64; off <<= 1) x += __shfl_xor(x, off, 64);
+      o8[e] = x / lh[h];
+    }
+    if (tq_e == 0) {
+      float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h + dc_e * 8;
+      *reinterpret_cast<float4*>(o) = make_float4(o8[0], o8[1], o8[2], o8[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+    }
+  }
+}
+
 template <int D>
 __global__ void __launch_bounds__(D / 2)
 decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
@@ -351,9 +692,28 @@ int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
   const int nblk = (a.max_len_in_batch + a.block_seq - 1) / a.block_seq;
   dim3 grid(nblk, a.batch);
   dim3 block(64 * a.num_kv_heads);
-  size_t shm = sizeof(float) * ((size_t)a.num_kv_heads * C::WAVE_FLOATS +
-                                (a.score_mode == SVK_SCORE_HEADMAX ? (size_t)kScoreChunk * a.num_kv_heads * C::JQ : 0));
-  hipLaunchKernelGGL((decode_stage1_kernel<D, G>), grid, block, shm, stream, a);
+  const size_t score_floats = a.score_mode == SVK_SCORE_HEADMAX ? (size_t)kScoreChunk * a.num_kv_heads * C::JQ : 0;
+  const size_t shm1 = sizeof(float) * ((size_t)a.num_kv_heads * C::WAVE_FLOATS + score_floats);
+  const size_t shm2 = sizeof(float) * ((size_t)a.num_kv_heads * Stage1V2Lds<D, G>::WAVE_FLOATS + score_floats);
+  if constexpr (G == 8) {
+    // 64 accumulator registers per lane do not fit the pipelined loop at 2 waves/SIMD without
+    // spilling; group size 8 keeps the un-pipelined kernel.
+    (void)shm2;
+    hipLaunchKernelGGL((decode_stage1_kernel_v1<D, G>), grid, block, shm1, stream, a);
+  } else {
+    (void)shm1;
+    // 32-bit row offsets whenever the caller tells us the KV tensors span < 4 GiB
+    const bool off32 = a.kv_num_slots > 0 && (a.kv_num_slots * a.kv_slot_stride * 2) < (int64_t)0xffffffffll;
+#define SVK_LAUNCH_V2(MODE_)                                                                                      \
+  do {                                                                                                            \
+    if (off32) hipLaunchKernelGGL((decode_stage1_kernel_v2<D, G, MODE_, true, true>), grid, block, shm2, stream, a);  \
+    else hipLaunchKernelGGL((decode_stage1_kernel_v2<D, G, MODE_, true, false>), grid, block, shm2, stream, a);       \
+  } while (0)
+    if (a.score_mode == SVK_SCORE_HEADMAX) SVK_LAUNCH_V2(SVK_SCORE_HEADMAX);
+    else if (a.score_mode == SVK_SCORE_PERHEAD) SVK_LAUNCH_V2(SVK_SCORE_PERHEAD);
+    else SVK_LAUNCH_V2(SVK_SCORE_NONE);
+#undef SVK_LAUNCH_V2
+  }
   return check_launch("svk_flash_decode_stage1");
 }
 

@@ -97,6 +97,89 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
 }
 
 // ------------------------------------------------------------------------------------
+// fused decode epilogue: [0, B) workgroups normalise + accumulate one score row each (row kept
+// in registers: one HBM/L2 read, one write), the remaining workgroups merge the split-KV
+// partials of 4 (batch lane, q head) pairs each (one wave per pair).
+// ------------------------------------------------------------------------------------
+
+template <int EPT>
+__global__ void __launch_bounds__(256) h2o_decode_finish_kernel(const SvkH2oDecodeFinishArgs f) {
+  __shared__ float red[16];
+  const int B = f.score.batch;
+  if ((int)blockIdx.x < B) {
+    const SvkH2oDecodeScoreArgs& a = f.score;
+    const int b = blockIdx.x;
+    float* x = a.attn_score + (int64_t)b * a.score_stride_b;
+    const int W = a.width;
+    float v[EPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int t = threadIdx.x + i * 256;
+      v[i] = t < W ? __fmul_rn(x[t], a.scale) : -INFINITY;
+      mx = fmaxf(mx, v[i]);
+    }
+    mx = block_allmax(mx, red);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      v[i] = expf(v[i] - mx);          // exp(-inf) = 0 for the padding lanes
+      sum += v[i];
+    }
+    sum = block_allsum(sum, red);
+    float* cum = nullptr;
+    int len = 0;
+    if (a.cum_score != nullptr) {
+      cum = a.cum_score + (int64_t)a.b_req_idx[b] * a.cum_stride;
+      len = a.b_seqlen[b];
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int t = threadIdx.x + i * 256;
+      if (t < W) {
+        const float p = v[i] / sum;
+        x[t] = p;
+        if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : cum[t] + p;
+      }
+    }
+    return;
+  }
+  // ---- stage 2 (flash_decoding_stage2.py:19-46): wave -> (b, h), lane -> 2 (D=128) or 1 (D=64) dims
+  const SvkFlashDecodeStage2Args& a = f.stage2;
+  const int pair = ((int)blockIdx.x - B) * 4 + (threadIdx.x >> 6);
+  if (pair >= a.batch * a.num_q_heads) return;
+  const int b = pair / a.num_q_heads, h = pair % a.num_q_heads;
+  const int lane = threadIdx.x & 63;
+  const int D = a.head_dim;
+  const int len = a.b_seqlen[b];
+  const int nblk = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq;
+  const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h;
+  const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
+  const int d = D == 128 ? lane * 2 : lane;
+  float sum = 0.f, mxl = -INFINITY, a0 = 0.f, a1 = 0.f;
+  for (int i = 0; i < nblk; ++i) {
+    float t0, t1 = 0.f;
+    if (D == 128) {
+      const float2 tv = *reinterpret_cast<const float2*>(mo + (int64_t)i * a.mid_o_stride_s + d);
+      t0 = tv.x; t1 = tv.y;
+    } else {
+      t0 = mo[(int64_t)i * a.mid_o_stride_s + d];
+    }
+    const float tl = ml[i];
+    const float nm = fmaxf(tl, mxl);
+    const float os = __expf(mxl - nm);
+    const float e = __expf(tl - nm);
+    a0 = a0 * os + e * t0;
+    a1 = a1 * os + e * t1;
+    sum = sum * os + e;
+    mxl = nm;
+  }
+  uint16_t* o = a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d;
+  if (D == 128) *reinterpret_cast<uint32_t*>(o) = f32_to_bf16_bits(a0 / sum) | (f32_to_bf16_bits(a1 / sum) << 16);
+  else *o = (uint16_t)f32_to_bf16_bits(a0 / sum);
+}
+
+// ------------------------------------------------------------------------------------
 // exact H2O selection
 // ------------------------------------------------------------------------------------
 
@@ -301,6 +384,34 @@ extern "C" int svk_h2o_decode_score_update(const SvkH2oDecodeScoreArgs* a, svk_s
   const int threads = a->width >= 4096 ? 1024 : (a->width >= 1024 ? 512 : 256);
   hipLaunchKernelGGL(h2o_decode_score_kernel, dim3(a->batch), dim3(threads), 0, static_cast<hipStream_t>(stream), *a);
   return check_launch("svk_h2o_decode_score_update");
+}
+
+extern "C" int svk_h2o_decode_finish(const SvkH2oDecodeFinishArgs* f, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(f != nullptr && f->score.attn_score != nullptr, SVK_ERR_VALUE, "svk_h2o_decode_finish: null args");
+  const SvkFlashDecodeStage2Args& s2 = f->stage2;
+  const SvkH2oDecodeScoreArgs& sc = f->score;
+  SVK_REQUIRE(s2.head_dim == 64 || s2.head_dim == 128, SVK_ERR_LAYOUT,
+              "svk_h2o_decode_finish: head_dim %d unsupported (64, 128)", s2.head_dim);
+  SVK_REQUIRE(s2.block_seq > 0 && sc.width > 0, SVK_ERR_VALUE, "svk_h2o_decode_finish: block_seq and width must be positive");
+  SVK_REQUIRE(s2.batch == sc.batch, SVK_ERR_VALUE, "svk_h2o_decode_finish: stage2 batch %d != score batch %d", s2.batch, sc.batch);
+  SVK_REQUIRE(sc.cum_score == nullptr || (sc.b_req_idx != nullptr && sc.b_seqlen != nullptr), SVK_ERR_VALUE,
+              "svk_h2o_decode_finish: cum_score needs b_req_idx and b_seqlen");
+  if (sc.batch <= 0) return SVK_OK;
+  if (sc.width > 256 * 64) {   // row does not fit the register-resident path: two plain launches
+    int rc = svk_flash_decode_stage2(&s2, stream);
+    if (rc != SVK_OK) return rc;
+    return svk_h2o_decode_score_update(&sc, stream);
+  }
+  const int pairs = s2.batch * s2.num_q_heads;
+  dim3 grid(sc.batch + (pairs + 3) / 4);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int ept = (sc.width + 255) / 256;
+  if (ept <= 8) hipLaunchKernelGGL((h2o_decode_finish_kernel<8>), grid, dim3(256), 0, s, *f);
+  else if (ept <= 17) hipLaunchKernelGGL((h2o_decode_finish_kernel<17>), grid, dim3(256), 0, s, *f);
+  else if (ept <= 32) hipLaunchKernelGGL((h2o_decode_finish_kernel<32>), grid, dim3(256), 0, s, *f);
+  else hipLaunchKernelGGL((h2o_decode_finish_kernel<64>), grid, dim3(256), 0, s, *f);
+  return check_launch("svk_h2o_decode_finish");
 }
 
 extern "C" int svk_h2o_select_indices(const SvkH2oSelectArgs* a, svk_stream_t stream) {

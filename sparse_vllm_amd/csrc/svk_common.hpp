@@ -46,6 +46,14 @@ __device__ __forceinline__ float bf16_round(float f) {
   return __builtin_bit_cast(float, f32_to_bf16_bits(f) << 16);
 }
 
+// Lane id recomputed on the spot (2 VALU ops).  `volatile` keeps the compiler from hoisting it
+// out of a loop and then spilling it when the loop body is at its VGPR budget.
+__device__ __forceinline__ int lane_id_fresh() {
+  int x;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+  return x;
+}
+
 // DPP row rotate inside each 16-lane row: returns x from lane (l - n) mod 16 of the row.
 template <int N>
 __device__ __forceinline__ float row_ror(float x) {

@@ -86,19 +86,57 @@ class SparseDecodeDriver:
         return mk(cm.num_heads), mk(cm.num_kv_heads), mk(cm.num_kv_heads)
 
     # ------------------------------------------------------------------ one decode step
-    @torch.no_grad()
-    def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None):
+    def _forward_layers(self, q, k, v, outputs):
         cm, sc = self.cache_manager, self.sparse_controller
-        seqs = self.seqs
-        cm.prepare_decode_static(seqs)
         ctx = set_context(False, cache_manager=cm, sparse_controller=sc)
-        sc.prepare_forward(seqs, False)
+        sc.prepare_forward(self.seqs, False)
         for layer_idx in range(cm.num_layers):
             ctx.now_layer_idx = layer_idx
             cm.save_rope_kv_if_needed(layer_idx, k[layer_idx], v[layer_idx])
             o = self.attn(q[layer_idx])
             if outputs is not None:
                 outputs[layer_idx].copy_(o)
+
+    def enable_decode_graph(self):
+        """hipGraph replay of the per-step layer loop (the reference's DecodeCudaGraphRunner,
+        engine/decode_cuda_graph.py:403-566): lengths/slots are read from device buffers with
+        stable addresses, the context capacity is pinned to the method's decode peak
+        (h2o.py:241-254), so one captured graph serves every step between bursts and after."""
+        cm = self.cache_manager
+        cap_fn = getattr(cm, "decode_cuda_graph_context_capacity", None)
+        cap = cap_fn(self.seqs)[0] if cap_fn is not None else int(cm.max_model_len)
+        cm._decode_static_max_context_len = int(cap)
+        self.config.decode_cuda_graph = True
+        self._graph = None
+        self._graph_key = None
+        self._graph_steps_seen = 0
+
+    @torch.no_grad()
+    def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None):
+        cm, sc = self.cache_manager, self.sparse_controller
+        seqs = self.seqs
+        cm.prepare_decode_static(seqs)
+        if not getattr(self.config, "decode_cuda_graph", False):
+            self._forward_layers(q, k, v, outputs)
+        else:
+            key = (q.data_ptr(), k.data_ptr(), v.data_ptr(), None if outputs is None else outputs.data_ptr(),
+                   tuple(s.seq_id for s in seqs))
+            if self._graph is None or self._graph_key != key:
+                if self._graph_steps_seen == 0 or self._graph_key != key:
+                    # first step with these buffers runs eagerly (allocates every scratch buffer)
+                    self._forward_layers(q, k, v, outputs)
+                    self._graph_key = key
+                    self._graph_steps_seen = 1
+                    self._graph = None
+                else:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._forward_layers(q, k, v, outputs)
+                    self._graph = g
+                    g.replay()
+            else:
+                self._graph.replay()
         sc.post_forward(seqs, False)
         cm.on_forward_end(seqs, False)
         for s in seqs:

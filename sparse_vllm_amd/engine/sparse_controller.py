@@ -43,6 +43,7 @@ class SparseController:
         self.layer_batch_sparse_states = [LayerBatchSparseState() for _ in range(self.num_layers)]
         self._h2o_decode_attn_score_buffers: dict[tuple, torch.Tensor] = {}
         self._fused_h2o_accumulate = True
+        self._layer_score_finished = [False] * self.num_layers
 
     def _is_kv_layer(self, layer_idx: int) -> bool:
         return self.cache_manager.is_full_attention_layer(layer_idx)
@@ -108,6 +109,22 @@ class SparseController:
         return SparseSelection(kind="full", req_indices=s.req_indices, context_lens=s.context_lens,
                                max_context_len=s.max_context_len, attn_score=s.attn_score)
 
+    def fused_decode_finish(self, layer_idx: int, mid_o, mid_lse, context_lens, o, block_seq) -> bool:
+        """MI355X fusion hook called by the attention backend instead of `flash_decode_stage2`:
+        for H2O decode, stage 2 and this layer's `on_layer_attention_end` score epilogue run as
+        one launch (svk_h2o_decode_finish).  Returns False when there is nothing to fuse."""
+        if self.sparse_method != "h2o" or get_context().is_prefill:
+            return False
+        s = self.layer_batch_sparse_states[layer_idx]
+        if s.attn_score is None or s.attn_score.dim() != 2:
+            return False
+        cm = self.cache_manager
+        cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
+        h2o_ops.h2o_decode_finish(mid_o, mid_lse, context_lens, o, block_seq, s.attn_score, self.attn_softmax_scale,
+                                  cum_score=cum, b_req_idx=s.req_indices)
+        self._layer_score_finished[layer_idx] = True
+        return True
+
     @torch.no_grad()
     def on_layer_attention_end(self, layer_idx: int):
         """sparse_controller.py:748-768.  For H2O decode: in place scale + softmax of the
@@ -119,6 +136,9 @@ class SparseController:
             return
         s = self.layer_batch_sparse_states[layer_idx]
         if s.attn_score is None:
+            return
+        if self._layer_score_finished[layer_idx]:      # already done inside the stage-2 launch
+            self._layer_score_finished[layer_idx] = False
             return
         if s.attn_score.dim() != 2:
             raise RuntimeError("SnapKV-family decode attention must write a fused head-reduced [B, L] score tensor: "

@@ -62,6 +62,7 @@ def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_o
         b_req_idx=_lib.ptr(B_req_idx), b_seqlen=_lib.ptr(B_Seqlen), mid_o=_lib.ptr(mid_out),
         mid_lse=_lib.ptr(mid_out_logsumexp), attn_score=_lib.ptr(attn_score),
         q_stride_b=q.stride(0), q_stride_h=q.stride(1), kv_slot_stride=k.stride(0), kv_head_stride=k.stride(1),
+        kv_num_slots=k.shape[0],
         req_stride=Req_to_tokens.stride(0),
         mid_o_stride_b=mid_out.stride(0), mid_o_stride_h=mid_out.stride(1), mid_o_stride_s=mid_out.stride(2),
         mid_lse_stride_b=mid_out_logsumexp.stride(0), mid_lse_stride_h=mid_out_logsumexp.stride(1),

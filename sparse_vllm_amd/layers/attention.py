@@ -38,7 +38,7 @@ class HipAttentionBackend:
 
     def run_decode(self, q: torch.Tensor, view: DecodeComputeView, *, mid_o, mid_o_logexpsum, max_len_in_batch: int,
                    block_seq: int, num_heads: int, num_kv_heads: int, gqa_block_n: int = 16,
-                   gqa_num_warps: int = 2) -> torch.Tensor:
+                   gqa_num_warps: int = 2, fused_finish=None) -> torch.Tensor:
         payload = view.payload
         if not isinstance(payload, ExplicitKVPayload):
             raise TypeError(f"HIP decode requires ExplicitKVPayload, got {type(payload).__name__}.")
@@ -55,7 +55,9 @@ class HipAttentionBackend:
                                     gqa_block_n, gqa_num_warps)
         o = torch.empty_like(q)
         with profiler.record(f"decode_attention_stage2_{kind}"):
-            flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
+            # a sparse controller may fuse its per-layer score epilogue into the stage-2 launch
+            if fused_finish is None or not fused_finish(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq):
+                flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
         return o
 
 
@@ -102,10 +104,12 @@ class Attention(torch.nn.Module):
             num_seq_blocks = (max_len_in_batch + block_seq - 1) // block_seq
             mid_o, mid_lse = get_decode_workspace(context, batch_size, self.num_heads, num_seq_blocks, self.head_dim,
                                                   q.device)
+            finish = getattr(sparse_controller, "fused_decode_finish", None)
             o = self.attention_backend.run_decode(
                 q, decode_view, mid_o=mid_o, mid_o_logexpsum=mid_lse, max_len_in_batch=max_len_in_batch,
                 block_seq=block_seq, num_heads=self.num_heads, num_kv_heads=self.num_kv_heads,
-                gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps)
+                gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps,
+                fused_finish=None if finish is None else (lambda *a, _l=layer_idx: finish(_l, *a)))
             cache_manager.record_decode_query(layer_idx, q)
             sparse_controller.on_layer_attention_end(layer_idx)
             cache_manager.on_layer_attention_end(layer_idx)

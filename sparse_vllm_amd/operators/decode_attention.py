@@ -48,10 +48,18 @@ class DefaultDecodeLaunchProvider(DecodeAttentionLaunchProvider):
 
 @DECODE_LAUNCH_REGISTRY.register
 class Mi355xDecodeLaunchProvider(DecodeAttentionLaunchProvider):
+    """BLOCK_SEQ for the HIP stage-1 kernel on MI355X.
+
+    The kernel runs one workgroup (= Hkv waves) per (batch lane, BLOCK_SEQ block) and two
+    workgroups are resident per CU (2 waves/SIMD).  Measured at B=64, L=4224 (profiles/):
+    544-token blocks (512 workgroups = exactly one resident wave of the grid) reach 6.07 TB/s,
+    272 -> 5.5, 256 -> 5.1, 128 -> 4.3: fewer, longer blocks amortise the per-block prologue /
+    epilogue and the stage-2 partials, as long as every CU still has its two workgroups.  So:
+    the largest 16-aligned BLOCK_SEQ that still yields >= RESIDENT_WORKGROUPS blocks."""
     name = "mi355x_hip"
     priority = 100
-    TARGET_WORKGROUPS = 512        # 2 per CU
-    MIN_BLOCK_SEQ, MAX_BLOCK_SEQ = 64, 1024
+    RESIDENT_WORKGROUPS = 512       # 256 CUs x 2 workgroups
+    MIN_BLOCK_SEQ = 64
 
     def supports(self, spec, caps):
         if caps.platform != PlatformEnum.ROCM:
@@ -68,9 +76,10 @@ class Mi355xDecodeLaunchProvider(DecodeAttentionLaunchProvider):
 
     def launch_config(self, *, block_seq, max_context_len, requires_attention_scores, batch_size=None):
         b = max(1, int(batch_size or 1))
-        bs = self.MAX_BLOCK_SEQ
-        while bs > self.MIN_BLOCK_SEQ and b * ((int(max_context_len) + bs - 1) // bs) < self.TARGET_WORKGROUPS:
-            bs //= 2
+        length = max(1, int(max_context_len))
+        nblk = max(1, -(-self.RESIDENT_WORKGROUPS // b))                 # blocks per sequence wanted
+        bs = -(-length // nblk)                                          # tokens per block
+        bs = max(self.MIN_BLOCK_SEQ, -(-bs // 16) * 16)
         return bs, 16, 4
 
 

@@ -380,3 +380,33 @@ def test_decode_alloc_slots_matches_oracle():
     assert (sm.cpu().numpy()[:, B:] == -1).all()
     np.testing.assert_array_equal(cl.cpu().numpy()[0], [8, 11, 34, 8, 8])
     np.testing.assert_array_equal(ri.cpu().numpy()[0], [5, 0, 2, 5, 5])
+
+
+def test_fused_decode_finish_equals_separate_calls():
+    """svk_h2o_decode_finish == svk_flash_decode_stage2 + svk_h2o_decode_score_update, bit for bit."""
+    from sparse_vllm_amd.kernels import flash_decode_stage2
+    from sparse_vllm_amd.kernels.h2o_ops import h2o_decode_finish, h2o_decode_score_update
+    d = dev()
+    g = torch.Generator(device="cpu").manual_seed(8)
+    for (B, Hq, D, nblk, block_seq, W, rows) in [(5, 28, 128, 9, 512, 4224, 7), (3, 14, 64, 4, 64, 200, 3),
+                                                 (2, 28, 128, 2, 4096, 8000, 2)]:
+        lens = torch.randint(1, min(W, nblk * block_seq) + 1, (B,), generator=g).to(torch.int32)
+        lens[0] = min(W, nblk * block_seq)
+        mid = torch.randn(B, Hq, nblk, D, generator=g).to(d)
+        lse = (torch.randn(B, Hq, nblk, generator=g) * 3).to(d)
+        raw = torch.full((B, W), -1e20)
+        for b in range(B):
+            raw[b, : lens[b]] = torch.randn(int(lens[b]), generator=g) * 5
+        cum = torch.rand(rows, W + 5, generator=g)
+        ridx = torch.randperm(rows, generator=g)[:B].to(torch.int32)
+        x1, c1 = raw.clone().to(d), cum.clone().to(d)
+        o1 = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=d)
+        flash_decode_stage2(mid, lse, lens.to(d), o1, block_seq)
+        h2o_decode_score_update(x1, D ** -0.5, cum_score=c1, b_req_idx=ridx.to(d), b_seqlen=lens.to(d))
+        x2, c2 = raw.clone().to(d), cum.clone().to(d)
+        o2 = torch.empty_like(o1)
+        h2o_decode_finish(mid, lse, lens.to(d), o2, block_seq, x2, D ** -0.5, cum_score=c2, b_req_idx=ridx.to(d))
+        assert torch.equal(o1, o2)
+        # the register-resident row sums in a different order than the 3-pass kernel: 1-2 ulp
+        torch.testing.assert_close(x2, x1, rtol=2e-6, atol=1e-12)
+        torch.testing.assert_close(c2, c1, rtol=2e-6, atol=1e-9)
