@@ -183,12 +183,8 @@ def main():
             drv.step(q, k, v)
             record["on"] = False
             time_captured_launches()
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    tokens = n_gpus * B * args.steps
+    from sparse_vllm_amd.replicas import aggregate_throughput
+    tokens, elapsed = aggregate_throughput(B * args.steps, elapsed, device=device)
     out = {
         "metric": "decode tokens/s at 128k ctx, H2O budget=4k, Qwen2.5-7B (sparse attention hot path)",
         "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": warmup,

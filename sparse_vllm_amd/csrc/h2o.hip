@@ -99,11 +99,12 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
 // ------------------------------------------------------------------------------------
 // fused decode epilogue: [0, B) workgroups normalise + accumulate one score row each (row kept
 // in registers: one HBM/L2 read, one write), the remaining workgroups merge the split-KV
-// partials of 4 (batch lane, q head) pairs each (one wave per pair).
+// partials of 16 (batch lane, q head) pairs each (one wave per pair).  1024-thread workgroups
+// keep the per-row dependency chain short (the score rows are latency-, not bandwidth-bound).
 // ------------------------------------------------------------------------------------
 
 template <int EPT>
-__global__ void __launch_bounds__(256) h2o_decode_finish_kernel(const SvkH2oDecodeFinishArgs f) {
+__global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDecodeFinishArgs f) {
   __shared__ float red[16];
   const int B = f.score.batch;
   if ((int)blockIdx.x < B) {
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(256) h2o_decode_finish_kernel(const SvkH2oDeco
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      const int t = threadIdx.x + i * 256;
+      const int t = threadIdx.x + i * 1024;
       v[i] = t < W ? __fmul_rn(x[t], a.scale) : -INFINITY;
       mx = fmaxf(mx, v[i]);
     }
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(256) h2o_decode_finish_kernel(const SvkH2oDeco
     }
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      const int t = threadIdx.x + i * 256;
+      const int t = threadIdx.x + i * 1024;
       if (t < W) {
         const float p = v[i] / sum;
         x[t] = p;
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) h2o_decode_finish_kernel(const SvkH2oDeco
   }
   // ---- stage 2 (flash_decoding_stage2.py:19-46): wave -> (b, h), lane -> 2 (D=128) or 1 (D=64) dims
   const SvkFlashDecodeStage2Args& a = f.stage2;
-  const int pair = ((int)blockIdx.x - B) * 4 + (threadIdx.x >> 6);
+  const int pair = ((int)blockIdx.x - B) * 16 + (threadIdx.x >> 6);
   if (pair >= a.batch * a.num_q_heads) return;
   const int b = pair / a.num_q_heads, h = pair % a.num_q_heads;
   const int lane = threadIdx.x & 63;
@@ -398,19 +399,19 @@ extern "C" int svk_h2o_decode_finish(const SvkH2oDecodeFinishArgs* f, svk_stream
   SVK_REQUIRE(sc.cum_score == nullptr || (sc.b_req_idx != nullptr && sc.b_seqlen != nullptr), SVK_ERR_VALUE,
               "svk_h2o_decode_finish: cum_score needs b_req_idx and b_seqlen");
   if (sc.batch <= 0) return SVK_OK;
-  if (sc.width > 256 * 64) {   // row does not fit the register-resident path: two plain launches
+  if (sc.width > 1024 * 32) {   // row does not fit the register-resident path: two plain launches
     int rc = svk_flash_decode_stage2(&s2, stream);
     if (rc != SVK_OK) return rc;
     return svk_h2o_decode_score_update(&sc, stream);
   }
   const int pairs = s2.batch * s2.num_q_heads;
-  dim3 grid(sc.batch + (pairs + 3) / 4);
+  dim3 grid(sc.batch + (pairs + 15) / 16);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int ept = (sc.width + 255) / 256;
-  if (ept <= 8) hipLaunchKernelGGL((h2o_decode_finish_kernel<8>), grid, dim3(256), 0, s, *f);
-  else if (ept <= 17) hipLaunchKernelGGL((h2o_decode_finish_kernel<17>), grid, dim3(256), 0, s, *f);
-  else if (ept <= 32) hipLaunchKernelGGL((h2o_decode_finish_kernel<32>), grid, dim3(256), 0, s, *f);
-  else hipLaunchKernelGGL((h2o_decode_finish_kernel<64>), grid, dim3(256), 0, s, *f);
+  const int ept = (sc.width + 1023) / 1024;
+  if (ept <= 2) hipLaunchKernelGGL((h2o_decode_finish_kernel<2>), grid, dim3(1024), 0, s, *f);
+  else if (ept <= 5) hipLaunchKernelGGL((h2o_decode_finish_kernel<5>), grid, dim3(1024), 0, s, *f);
+  else if (ept <= 16) hipLaunchKernelGGL((h2o_decode_finish_kernel<16>), grid, dim3(1024), 0, s, *f);
+  else hipLaunchKernelGGL((h2o_decode_finish_kernel<32>), grid, dim3(1024), 0, s, *f);
   return check_launch("svk_h2o_decode_finish");
 }
 
