@@ -249,6 +249,97 @@ typedef struct SvkDecodeAllocArgs {
 } SvkDecodeAllocArgs;
 int svk_decode_alloc_slots(const SvkDecodeAllocArgs* a, svk_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Quest: query-aware page top-k
+ * ---------------------------------------------------------------------------------- */
+
+/* Per-page, per-KV-head elementwise max / min of the page's post-RoPE keys, for whole pages:
+ *   metadata[0, l, p] = max_t K[l, p*page + t],  metadata[1, l, p] = min_t ...
+ * for every KV layer l < n_layers and every listed physical page p.  Exact (bf16 compares).
+ * Replaces QuestCacheManager.on_kv_stored / on_forward_end,
+ * engine/cache_manager/quest.py:1607-1685, :1718-1771 (aminmax + index_copy_ per layer). */
+typedef struct SvkQuestPageMinmaxArgs {
+  const uint16_t* k_cache;     /* [L, slots, row_elems] bf16 (K half of kv_cache)          */
+  uint16_t* metadata;          /* [2, L, pages, row_elems] bf16: 0 = max, 1 = min          */
+  const int64_t* page_slots;   /* [n_pages] physical page ids                              */
+  int64_t k_layer_stride;      /* elements between layers of k_cache                       */
+  int64_t meta_kind_stride;    /* elements between the max and the min tensors             */
+  int64_t meta_layer_stride;   /* elements between layers of metadata                      */
+  int32_t n_pages, n_layers;
+  int32_t page_size;           /* tokens per page (16)                                     */
+  int32_t row_elems;           /* Hkv*D, multiple of 8                                     */
+} SvkQuestPageMinmaxArgs;
+int svk_quest_page_minmax(const SvkQuestPageMinmaxArgs* a, svk_stream_t stream);
+
+/* Upper-bound page scores of the previous (complete) pages of every batch lane:
+ *   s[b,p] = max_{q head h} bf16( bf16(q_h^+ . max_p) + bf16(q_h^- . min_p) ),  -inf for p >= num_pages-1
+ * (bf16 roundings exactly where torch.bmm / `+=` on bf16 tensors round).
+ * Replaces QuestCacheManager._score_pages_batched + the metadata gather and mask of
+ * _build_decode_view_static, engine/cache_manager/quest.py:1773-1802, :1868-1885. */
+typedef struct SvkQuestScorePagesArgs {
+  const uint16_t* q;            /* [B, Hq, D] bf16                                         */
+  const uint16_t* page_max;     /* [pages, Hkv, D] bf16 (metadata[0, layer])               */
+  const uint16_t* page_min;     /* [pages, Hkv, D] bf16 (metadata[1, layer])               */
+  const int32_t* page_table;    /* [rows, page_table_stride] physical page per logical page, -1 = none */
+  const int32_t* req_indices;   /* [B]                                                     */
+  const int32_t* context_lens;  /* [B]                                                     */
+  float* page_scores;           /* [B, score_stride] f32 out (bf16-valued), first n_prev columns */
+  int64_t q_stride_b, q_stride_h;
+  int64_t page_table_stride;
+  int64_t score_stride;
+  int32_t batch, num_q_heads, num_kv_heads, head_dim;
+  int32_t page_size;
+  int32_t n_prev;               /* max_pages - 1 columns to score                          */
+} SvkQuestScorePagesArgs;
+int svk_quest_score_pages(const SvkQuestScorePagesArgs* a, svk_stream_t stream);
+
+/* Packed decode view: top-`prev_budget` previous pages by (score desc, page index asc) in
+ * ascending page order, then the last page; token slots = page_slot*page_size + [0, page_size);
+ * lens = prev_budget*page_size + last_page_len.  Rows that are short (len <= token_budget or
+ * num_pages <= page_budget_base) copy their dense prefix instead unless is_long_text.
+ * `topk(sorted=False)` leaves the order and the choice among boundary ties unspecified in the
+ * reference; this kernel makes the deterministic lowest-index choice.
+ * Replaces _build_decode_view_static, engine/cache_manager/quest.py:1886-1913. */
+typedef struct SvkQuestBuildViewArgs {
+  const float* page_scores;     /* [B, score_stride]                                       */
+  const int32_t* page_table;    /* [rows, page_table_stride]                               */
+  const int32_t* token_table;   /* [rows, token_table_stride] dense slot table             */
+  const int32_t* req_indices;   /* [B]                                                     */
+  const int32_t* context_lens;  /* [B]                                                     */
+  int32_t* packed_slots;        /* [B, packed_stride] out                                  */
+  int32_t* local_lens;          /* [B] out                                                 */
+  int32_t* local_req;           /* [B] out = arange(B)                                     */
+  int64_t score_stride, page_table_stride, token_table_stride, packed_stride;
+  int32_t batch;
+  int32_t page_size;
+  int32_t n_prev;               /* scored columns = max_pages - 1                          */
+  int32_t prev_budget;          /* previous pages kept                                     */
+  int32_t token_budget;
+  int32_t page_budget_base;
+  int32_t max_keep;             /* columns of packed_slots that are defined                */
+  int32_t is_long_text;
+} SvkQuestBuildViewArgs;
+int svk_quest_build_view(const SvkQuestBuildViewArgs* a, svk_stream_t stream);
+
+/* Quest decode slot allocation: lane b appends one token to row req_indices[b]; lanes whose
+ * cur_len % page_size == 0 take new_page_slots[b] (host-popped from the page stack) as their
+ * next page.  Writes page table, token table, slot_mapping, context_lens (= cur+1), req rows.
+ * Replaces QuestCacheManager._allocate_batch / prepare_decode_static device half,
+ * engine/cache_manager/quest.py:1279-1360, :1542-1605. */
+typedef struct SvkQuestDecodeAllocArgs {
+  int32_t* page_table;
+  int32_t* token_table;
+  const int32_t* row_ids;        /* [B]                                                    */
+  const int32_t* cur_lens;       /* [B]                                                    */
+  const int32_t* new_page_slots; /* [B] page for lanes starting a new page, else ignored   */
+  int32_t* slot_mapping;         /* [graph_batch] (lanes >= B get -1)                      */
+  int32_t* context_lens;         /* [graph_batch]                                          */
+  int32_t* req_indices;          /* [graph_batch]                                          */
+  int64_t page_table_stride, token_table_stride;
+  int32_t batch, graph_batch, page_size;
+} SvkQuestDecodeAllocArgs;
+int svk_quest_decode_alloc(const SvkQuestDecodeAllocArgs* a, svk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,36 @@ class SvkDecodeAllocArgs(C.Structure):
                 ("n_layers", _i32), ("batch", _i32), ("graph_batch", _i32)]
 
 
+class SvkQuestPageMinmaxArgs(C.Structure):
+    _fields_ = [("k_cache", _p), ("metadata", _p), ("page_slots", _p),
+                ("k_layer_stride", _i64), ("meta_kind_stride", _i64), ("meta_layer_stride", _i64),
+                ("n_pages", _i32), ("n_layers", _i32), ("page_size", _i32), ("row_elems", _i32)]
+
+
+class SvkQuestScorePagesArgs(C.Structure):
+    _fields_ = [("q", _p), ("page_max", _p), ("page_min", _p), ("page_table", _p), ("req_indices", _p),
+                ("context_lens", _p), ("page_scores", _p),
+                ("q_stride_b", _i64), ("q_stride_h", _i64), ("page_table_stride", _i64), ("score_stride", _i64),
+                ("batch", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
+                ("page_size", _i32), ("n_prev", _i32)]
+
+
+class SvkQuestBuildViewArgs(C.Structure):
+    _fields_ = [("page_scores", _p), ("page_table", _p), ("token_table", _p), ("req_indices", _p),
+                ("context_lens", _p), ("packed_slots", _p), ("local_lens", _p), ("local_req", _p),
+                ("score_stride", _i64), ("page_table_stride", _i64), ("token_table_stride", _i64),
+                ("packed_stride", _i64),
+                ("batch", _i32), ("page_size", _i32), ("n_prev", _i32), ("prev_budget", _i32),
+                ("token_budget", _i32), ("page_budget_base", _i32), ("max_keep", _i32), ("is_long_text", _i32)]
+
+
+class SvkQuestDecodeAllocArgs(C.Structure):
+    _fields_ = [("page_table", _p), ("token_table", _p), ("row_ids", _p), ("cur_lens", _p), ("new_page_slots", _p),
+                ("slot_mapping", _p), ("context_lens", _p), ("req_indices", _p),
+                ("page_table_stride", _i64), ("token_table_stride", _i64),
+                ("batch", _i32), ("graph_batch", _i32), ("page_size", _i32)]
+
+
 # symbol -> (argtypes) ; every entry point declared in include/svk.h
 ENTRY_POINTS = {
     "svk_abi_version": ([], C.c_int),
@@ -103,6 +133,10 @@ ENTRY_POINTS = {
     "svk_h2o_select_indices": ([C.POINTER(SvkH2oSelectArgs), _p], C.c_int),
     "svk_compact_rows": ([C.POINTER(SvkCompactRowsArgs), _p], C.c_int),
     "svk_decode_alloc_slots": ([C.POINTER(SvkDecodeAllocArgs), _p], C.c_int),
+    "svk_quest_page_minmax": ([C.POINTER(SvkQuestPageMinmaxArgs), _p], C.c_int),
+    "svk_quest_score_pages": ([C.POINTER(SvkQuestScorePagesArgs), _p], C.c_int),
+    "svk_quest_build_view": ([C.POINTER(SvkQuestBuildViewArgs), _p], C.c_int),
+    "svk_quest_decode_alloc": ([C.POINTER(SvkQuestDecodeAllocArgs), _p], C.c_int),
 }
 
 _lib = None

@@ -4,53 +4,10 @@
 // code (include/svk.h cites the lines); these are HBM/L2-bound index kernels.
 
 #include "svk_common.hpp"
+#include "svk_select.hpp"
 
 namespace svk {
 namespace {
-
-// ------------------------------------------------------------------------------------
-// block-wide helpers (blockDim.x multiple of 64, <= 1024)
-// ------------------------------------------------------------------------------------
-
-__device__ __forceinline__ float block_allmax(float x, float* red) {
-  x = wave_allmax(x);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[w] = x;
-  __syncthreads();
-  float r = red[0];
-  for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
-  return r;
-}
-
-__device__ __forceinline__ float block_allsum(float x, float* red) {
-  x = wave_allsum(x);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[w] = x;
-  __syncthreads();
-  float r = red[0];
-  for (int i = 1; i < nw; ++i) r += red[i];
-  return r;
-}
-
-// exclusive prefix count of a 1-bit flag over the block, plus the block total
-__device__ __forceinline__ int block_excl_count(bool flag, int* wsum, int& total) {
-  const unsigned long long bal = __ballot(flag);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
-  __syncthreads();
-  if (lane == 0) wsum[w] = __popcll(bal);
-  __syncthreads();
-  int base = 0, tot = 0;
-  for (int i = 0; i < nw; ++i) {
-    const int c = wsum[i];
-    if (i < w) base += c;
-    tot += c;
-  }
-  total = tot;
-  return base + in_wave;
-}
 
 // ------------------------------------------------------------------------------------
 // fill
@@ -184,21 +141,8 @@ __global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDec
 // exact H2O selection
 // ------------------------------------------------------------------------------------
 
-// Descending-order key: smaller key == larger score; -0.0 and +0.0 compare equal like
-// torch's comparison-based stable sort.
-__device__ __forceinline__ uint32_t desc_key(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u << 1) == 0u) u = 0u;                                   // canonical +0
-  const uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-  return ~asc;
-}
-
 __global__ void __launch_bounds__(256) h2o_select_kernel(const SvkH2oSelectArgs a) {
-  __shared__ int hist[256];
-  __shared__ int wsum[16];
-  __shared__ uint32_t sh_prefix;
-  __shared__ int sh_k;
-
+  __shared__ SelectScratch scratch;
   const int rowi = blockIdx.x;
   const float* sc = a.scores + (int64_t)rowi * a.score_stride;
   int64_t* keep = a.keep + (int64_t)rowi * a.keep_stride;
@@ -214,71 +158,8 @@ __global__ void __launch_bounds__(256) h2o_select_kernel(const SvkH2oSelectArgs 
   const int rs = kv_len - recent;      // recent_start; heavy < rs always holds here
   for (int i = tid; i < recent; i += nt) keep[heavy + i] = rs + i;
   if (heavy <= 0) return;
-
-  // ---- radix select (MSB first, 8 bits per pass) of the heavy-th smallest desc_key
-  uint32_t prefix = 0;     // bits decided so far
-  int k = heavy;           // rank still to find inside the current prefix bucket (1-based)
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-    for (int i = tid; i < 256; i += nt) hist[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < rs; i += nt) {
-      const uint32_t key = desc_key(sc[i]);
-      if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
-    }
-    __syncthreads();
-    if (tid < 64) {
-      // wave 0: find the bin holding rank k
-      int c[4];
-      int local = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { c[j] = hist[tid * 4 + j]; local += c[j]; }
-      int incl = local;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (tid >= o) incl += v;
-      }
-      const int excl = incl - local;
-      if (k > excl && k <= incl) {
-        int run = excl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (k > run && k <= run + c[j]) {
-            sh_prefix = prefix | ((uint32_t)(tid * 4 + j) << shift);
-            sh_k = k - run;
-          }
-          run += c[j];
-        }
-      }
-    }
-    __syncthreads();
-    prefix = sh_prefix;
-    k = sh_k;
-    __syncthreads();
-  }
-  // prefix == threshold key T; k == how many elements equal to T are taken (lowest index first)
-  const uint32_t T = prefix;
-  const int take_eq = k;
-
-  // ---- ordered compaction: ascending index, exactly `heavy` outputs
-  int out_base = 0, eq_base = 0;
-  for (int c0 = 0; c0 < rs; c0 += nt) {
-    const int i = c0 + tid;
-    uint32_t key = 0xffffffffu;
-    bool in = i < rs;
-    if (in) key = desc_key(sc[i]);
-    const bool is_eq = in && key == T;
-    int eq_total;
-    const int eq_rank = eq_base + block_excl_count(is_eq, wsum, eq_total);
-    const bool sel = in && (key < T || (is_eq && eq_rank < take_eq));
-    int sel_total;
-    const int pos = out_base + block_excl_count(sel, wsum, sel_total);
-    if (sel) keep[pos] = i;
-    out_base += sel_total;
-    eq_base += eq_total;
-  }
+  // top-`heavy` of sc[0:rs] by (score desc, index asc), emitted in ascending index order
+  block_select_topk_ordered(sc, rs, heavy, scratch, [&](int pos, int idx) { keep[pos] = idx; });
 }
 
 // ------------------------------------------------------------------------------------

@@ -1,0 +1,251 @@
+// Quest (query-aware page top-k) kernels for gfx950: page min/max metadata, page scoring on the
+// matrix cores with the reference's bf16 rounding points, exact top-k + packed view, paging.
+// HBM-bound scans of the [pages, Hkv, D] min/max metadata (1/16 of the K bytes each).
+
+#include "svk_common.hpp"
+#include "svk_select.hpp"
+
+namespace svk {
+namespace {
+
+// ------------------------------------------------------------------------------------
+// page min / max
+// ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t bf16x2_max(uint32_t a, uint32_t b) {
+  const float al = bf16_lo(a), ah = bf16_hi(a), bl = bf16_lo(b), bh = bf16_hi(b);
+  return (al >= bl ? (a & 0xffffu) : (b & 0xffffu)) | (ah >= bh ? (a & 0xffff0000u) : (b & 0xffff0000u));
+}
+__device__ __forceinline__ uint32_t bf16x2_min(uint32_t a, uint32_t b) {
+  const float al = bf16_lo(a), ah = bf16_hi(a), bl = bf16_lo(b), bh = bf16_hi(b);
+  return (al <= bl ? (a & 0xffffu) : (b & 0xffffu)) | (ah <= bh ? (a & 0xffff0000u) : (b & 0xffff0000u));
+}
+
+__global__ void __launch_bounds__(128) quest_page_minmax_kernel(const SvkQuestPageMinmaxArgs a, int chunks_per_row) {
+  const int page_i = blockIdx.x, layer = blockIdx.y;
+  const int64_t page = a.page_slots[page_i];
+  const uint16_t* k = a.k_cache + (int64_t)layer * a.k_layer_stride + page * a.page_size * (int64_t)a.row_elems;
+  uint16_t* mx = a.metadata + (int64_t)layer * a.meta_layer_stride + page * (int64_t)a.row_elems;
+  uint16_t* mn = mx + a.meta_kind_stride;
+  for (int ch = threadIdx.x; ch < chunks_per_row; ch += blockDim.x) {
+    uint4 hi = *reinterpret_cast<const uint4*>(k + ch * 8);
+    uint4 lo = hi;
+    for (int t = 1; t < a.page_size; ++t) {
+      const uint4 v = *reinterpret_cast<const uint4*>(k + (int64_t)t * a.row_elems + ch * 8);
+      hi.x = bf16x2_max(hi.x, v.x); hi.y = bf16x2_max(hi.y, v.y); hi.z = bf16x2_max(hi.z, v.z); hi.w = bf16x2_max(hi.w, v.w);
+      lo.x = bf16x2_min(lo.x, v.x); lo.y = bf16x2_min(lo.y, v.y); lo.z = bf16x2_min(lo.z, v.z); lo.w = bf16x2_min(lo.w, v.w);
+    }
+    *reinterpret_cast<uint4*>(mx + ch * 8) = hi;
+    *reinterpret_cast<uint4*>(mn + ch * 8) = lo;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// page scoring: one wave per KV head, 16 pages per MFMA group
+//   S+ = Q+ . Max^T, S- = Q- . Min^T (fp32 accumulate), s = bf16(bf16(S+) + bf16(S-)), max over heads
+// ------------------------------------------------------------------------------------
+
+constexpr int kPagesPerBlock = 128;
+
+template <int D, int G>
+__global__ void __launch_bounds__(512) quest_score_pages_kernel(const SvkQuestScorePagesArgs a) {
+  constexpr int NC = D / 32, JQ = (G + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [kPagesPerBlock][Hkv*JQ]
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Hkv = a.num_kv_heads;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * kPagesPerBlock;
+  const int n = lane & 15, jq = lane >> 4;
+  const int SP = Hkv * JQ;
+  const int len = a.context_lens[b];
+  const int num_pages = max(1, (len + a.page_size - 1) / a.page_size);
+  const int n_valid = min(a.n_prev, num_pages - 1);        // previous pages that exist
+  const int p1 = min(p0 + kPagesPerBlock, a.n_prev);
+  float* out = a.page_scores + (int64_t)b * a.score_stride;
+  if (p0 >= n_valid) {                                       // nothing valid in this block
+    for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) out[p] = -INFINITY;
+    return;
+  }
+  // Q+ / Q- fragments (A operand rows = heads of this KV group)
+  bf16x8_t qp[NC], qn[NC];
+  {
+    const uint16_t* qptr = a.q + (int64_t)b * a.q_stride_b + (int64_t)(w * G + n) * a.q_stride_h + jq * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (n < G) t = *reinterpret_cast<const uint4*>(qptr + c * 32);
+      uint32_t v[4] = {t.x, t.y, t.z, t.w}, pp[4], nn[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // clamp_min(0) / clamp_max(0) per bf16 element: keep the element iff its sign bit says so
+        const uint32_t lo = v[i] & 0xffffu, hi = v[i] & 0xffff0000u;
+        const bool lo_neg = (lo & 0x8000u) != 0, hi_neg = (hi & 0x80000000u) != 0;
+        pp[i] = (lo_neg ? 0u : lo) | (hi_neg ? 0u : hi);
+        nn[i] = (lo_neg ? lo : 0u) | (hi_neg ? hi : 0u);
+      }
+      qp[c] = __builtin_bit_cast(bf16x8_t, make_uint4(pp[0], pp[1], pp[2], pp[3]));
+      qn[c] = __builtin_bit_cast(bf16x8_t, make_uint4(nn[0], nn[1], nn[2], nn[3]));
+    }
+  }
+  const int32_t* ptab = a.page_table + (int64_t)a.req_indices[b] * a.page_table_stride;
+  const int64_t head_off = (int64_t)w * D + jq * 8;
+  const int64_t row_elems = (int64_t)Hkv * D;
+  for (int g0 = p0; g0 < p1; g0 += 16) {
+    const int p = g0 + n;
+    int slot = 0;
+    if (p < n_valid) slot = max(ptab[p], 0);
+    const uint16_t* pm = a.page_max + (int64_t)slot * row_elems + head_off;
+    const uint16_t* pn = a.page_min + (int64_t)slot * row_elems + head_off;
+    f32x4_t sp = {0.f, 0.f, 0.f, 0.f}, sn = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const uint4 vmax = *reinterpret_cast<const uint4*>(pm + c * 32);
+      const uint4 vmin = *reinterpret_cast<const uint4*>(pn + c * 32);
+      sp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qp[c], __builtin_bit_cast(bf16x8_t, vmax), sp, 0, 0, 0);
+      sn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qn[c], __builtin_bit_cast(bf16x8_t, vmin), sn, 0, 0, 0);
+    }
+    if (jq < JQ) {
+      float best = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (jq * 4 + r < G) best = fmaxf(best, bf16_round(bf16_round(sp[r]) + bf16_round(sn[r])));
+      lds[(g0 - p0 + n) * SP + w * JQ + jq] = best;
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < p1 - p0; t += blockDim.x) {
+    float mx = -INFINITY;
+    for (int j = 0; j < SP; ++j) mx = fmaxf(mx, lds[t * SP + j]);
+    out[p0 + t] = (p0 + t < n_valid) ? mx : -INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// top-k + packed view, one workgroup per batch lane
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) quest_build_view_kernel(const SvkQuestBuildViewArgs a) {
+  __shared__ SelectScratch scratch;
+  extern __shared__ int sel_pages[];          // [prev_budget] selected logical pages, ascending
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int len = a.context_lens[b];
+  const int row = a.req_indices[b];
+  const int ps = a.page_size;
+  const int num_pages = max(1, (len + ps - 1) / ps);
+  int32_t* packed = a.packed_slots + (int64_t)b * a.packed_stride;
+  const int32_t* ttab = a.token_table + (int64_t)row * a.token_table_stride;
+  const int32_t* ptab = a.page_table + (int64_t)row * a.page_table_stride;
+  if (tid == 0) a.local_req[b] = b;
+  const bool dense = !a.is_long_text && (len <= a.token_budget || num_pages <= a.page_budget_base);
+  if (dense) {
+    for (int i = tid; i < a.max_keep; i += nt) packed[i] = ttab[i];
+    if (tid == 0) a.local_lens[b] = len;
+    return;
+  }
+  const float* sc = a.page_scores + (int64_t)b * a.score_stride;
+  block_select_topk_ordered(sc, a.n_prev, a.prev_budget, scratch, [&](int pos, int idx) { sel_pages[pos] = idx; });
+  __syncthreads();
+  const int sparse_keep = (a.prev_budget + 1) * ps;
+  for (int i = tid; i < sparse_keep; i += nt) {
+    const int j = i / ps, o = i - j * ps;
+    const int page = j < a.prev_budget ? sel_pages[j] : num_pages - 1;
+    packed[i] = max(ptab[page], 0) * ps + o;
+  }
+  if (!a.is_long_text)
+    for (int i = sparse_keep + tid; i < a.max_keep; i += nt) packed[i] = ttab[i];
+  if (tid == 0) a.local_lens[b] = a.prev_budget * ps + (len - (num_pages - 1) * ps);
+}
+
+__global__ void __launch_bounds__(256) quest_decode_alloc_kernel(const SvkQuestDecodeAllocArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.graph_batch) return;
+  if (b >= a.batch) {
+    a.slot_mapping[b] = -1;
+    a.context_lens[b] = a.cur_lens[0] + 1;
+    a.req_indices[b] = a.row_ids[0];
+    return;
+  }
+  const int row = a.row_ids[b], cur = a.cur_lens[b];
+  const int page = cur / a.page_size, off = cur - page * a.page_size;
+  int32_t* ptab = a.page_table + (int64_t)row * a.page_table_stride;
+  int page_slot;
+  if (off == 0) {
+    page_slot = a.new_page_slots[b];
+    ptab[page] = page_slot;
+  } else {
+    page_slot = ptab[page];
+  }
+  const int slot = page_slot * a.page_size + off;
+  a.token_table[(int64_t)row * a.token_table_stride + cur] = slot;
+  a.slot_mapping[b] = slot;
+  a.context_lens[b] = cur + 1;
+  a.req_indices[b] = row;
+}
+
+template <int D>
+int dispatch_score(const SvkQuestScorePagesArgs& a, hipStream_t s) {
+  const int G = a.num_q_heads / a.num_kv_heads;
+  dim3 grid((a.n_prev + kPagesPerBlock - 1) / kPagesPerBlock, a.batch), block(64 * a.num_kv_heads);
+  const size_t shm = sizeof(float) * kPagesPerBlock * a.num_kv_heads * ((G + 3) / 4);
+  switch (G) {
+#define SVK_CASE(G_) case G_: hipLaunchKernelGGL((quest_score_pages_kernel<D, G_>), grid, block, shm, s, a); break;
+    SVK_CASE(1) SVK_CASE(2) SVK_CASE(3) SVK_CASE(4) SVK_CASE(5) SVK_CASE(6) SVK_CASE(7) SVK_CASE(8)
+#undef SVK_CASE
+    default:
+      set_error("svk_quest_score_pages: GQA group size %d unsupported (1..8)", G);
+      return SVK_ERR_LAYOUT;
+  }
+  return check_launch("svk_quest_score_pages");
+}
+
+}  // namespace
+}  // namespace svk
+
+extern "C" int svk_quest_page_minmax(const SvkQuestPageMinmaxArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_quest_page_minmax: null args");
+  SVK_REQUIRE(a->row_elems > 0 && a->row_elems % 8 == 0, SVK_ERR_LAYOUT, "svk_quest_page_minmax: row_elems %d must be a multiple of 8", a->row_elems);
+  SVK_REQUIRE(a->page_size > 0, SVK_ERR_VALUE, "quest_chunk_size must be > 0");
+  if (a->n_pages <= 0 || a->n_layers <= 0) return SVK_OK;
+  const int cpr = a->row_elems / 8;
+  hipLaunchKernelGGL(quest_page_minmax_kernel, dim3(a->n_pages, a->n_layers), dim3(cpr >= 128 ? 128 : 64), 0,
+                     static_cast<hipStream_t>(stream), *a, cpr);
+  return check_launch("svk_quest_page_minmax");
+}
+
+extern "C" int svk_quest_score_pages(const SvkQuestScorePagesArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_quest_score_pages: null args");
+  SVK_REQUIRE(a->head_dim == 64 || a->head_dim == 128, SVK_ERR_LAYOUT, "svk_quest_score_pages: head_dim %d unsupported (64, 128)", a->head_dim);
+  SVK_REQUIRE(a->num_kv_heads >= 1 && a->num_kv_heads <= 8 && a->num_q_heads % a->num_kv_heads == 0, SVK_ERR_LAYOUT,
+              "svk_quest_score_pages: unsupported head configuration %d/%d", a->num_q_heads, a->num_kv_heads);
+  SVK_REQUIRE(a->page_size > 0, SVK_ERR_VALUE, "quest_chunk_size must be > 0");
+  if (a->batch <= 0 || a->n_prev <= 0) return SVK_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return a->head_dim == 128 ? dispatch_score<128>(*a, s) : dispatch_score<64>(*a, s);
+}
+
+extern "C" int svk_quest_build_view(const SvkQuestBuildViewArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_quest_build_view: null args");
+  SVK_REQUIRE(a->prev_budget >= 1 && a->prev_budget <= a->n_prev, SVK_ERR_VALUE,
+              "svk_quest_build_view: prev_budget %d must be in [1, n_prev=%d]", a->prev_budget, a->n_prev);
+  SVK_REQUIRE(a->max_keep >= (a->prev_budget + 1) * a->page_size || a->is_long_text, SVK_ERR_VALUE,
+              "svk_quest_build_view: max_keep %d smaller than the sparse view", a->max_keep);
+  if (a->batch <= 0) return SVK_OK;
+  hipLaunchKernelGGL(quest_build_view_kernel, dim3(a->batch), dim3(256), sizeof(int) * a->prev_budget,
+                     static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_quest_build_view");
+}
+
+extern "C" int svk_quest_decode_alloc(const SvkQuestDecodeAllocArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_quest_decode_alloc: null args");
+  SVK_REQUIRE(a->batch > 0, SVK_ERR_VALUE, "Static decode requires a non-empty real decode batch.");
+  SVK_REQUIRE(a->graph_batch >= a->batch, SVK_ERR_VALUE,
+              "Static decode graph batch is smaller than the real decode batch: graph=%d, real=%d.", a->graph_batch, a->batch);
+  hipLaunchKernelGGL(quest_decode_alloc_kernel, dim3((a->graph_batch + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_quest_decode_alloc");
+}

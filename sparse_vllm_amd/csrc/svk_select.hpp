@@ -1,0 +1,140 @@
+// Block-wide primitives shared by the selection kernels (H2O heavy hitters, Quest page top-k,
+// SnapKV / DeltaKV top-k): reductions, 1-bit prefix counts and an exact radix select.
+#pragma once
+
+#include "svk_common.hpp"
+
+namespace svk {
+
+// ------------------------------------------------------------------------------------
+// block-wide helpers (blockDim.x multiple of 64, <= 1024)
+// ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float block_allmax(float x, float* red) {
+  x = wave_allmax(x);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = x;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+
+__device__ __forceinline__ float block_allsum(float x, float* red) {
+  x = wave_allsum(x);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = x;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
+  return r;
+}
+
+// exclusive prefix count of a 1-bit flag over the block, plus the block total
+__device__ __forceinline__ int block_excl_count(bool flag, int* wsum, int& total) {
+  const unsigned long long bal = __ballot(flag);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0) wsum[w] = __popcll(bal);
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < nw; ++i) {
+    const int c = wsum[i];
+    if (i < w) base += c;
+    tot += c;
+  }
+  total = tot;
+  return base + in_wave;
+}
+
+// Descending-order key: smaller key == larger score; -0.0 and +0.0 compare equal like
+// torch's comparison-based stable sort.
+__device__ __forceinline__ uint32_t desc_key(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u << 1) == 0u) u = 0u;                                   // canonical +0
+  const uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ~asc;
+}
+
+
+struct SelectScratch {
+  int hist[256];
+  int wsum[16];
+  uint32_t prefix;
+  int k;
+};
+
+// Exact top-k of sc[0:n) under the order (score descending, index ascending) -- the order of a
+// stable descending argsort, i.e. ties keep the LOWER index.  Requires 1 <= k <= n and a block of
+// 64..1024 threads, all of which must call.  `emit(pos, idx)` is called exactly k times with
+// pos = rank of idx among the selected indices in ASCENDING index order.
+// Method: 4-pass MSB radix select (8 bits per pass) of the k-th smallest desc_key gives the
+// threshold key T and how many elements equal to T are taken; one ordered pass then emits.
+template <typename Emit>
+__device__ __forceinline__ void block_select_topk_ordered(const float* sc, int n, int k, SelectScratch& S, Emit emit) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  uint32_t prefix = 0;
+  int kk = k;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = tid; i < 256; i += nt) S.hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+      const uint32_t key = desc_key(sc[i]);
+      if ((key & himask) == prefix) atomicAdd(&S.hist[(key >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      int c[4];
+      int local = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c[j] = S.hist[tid * 4 + j]; local += c[j]; }
+      int incl = local;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += v;
+      }
+      const int excl = incl - local;
+      if (kk > excl && kk <= incl) {
+        int run = excl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (kk > run && kk <= run + c[j]) {
+            S.prefix = prefix | ((uint32_t)(tid * 4 + j) << shift);
+            S.k = kk - run;
+          }
+          run += c[j];
+        }
+      }
+    }
+    __syncthreads();
+    prefix = S.prefix;
+    kk = S.k;
+    __syncthreads();
+  }
+  const uint32_t T = prefix;   // threshold key
+  const int take_eq = kk;      // elements equal to T that are taken, lowest index first
+  int out_base = 0, eq_base = 0;
+  for (int c0 = 0; c0 < n; c0 += nt) {
+    const int i = c0 + tid;
+    uint32_t key = 0xffffffffu;
+    const bool in = i < n;
+    if (in) key = desc_key(sc[i]);
+    const bool is_eq = in && key == T;
+    int eq_total;
+    const int eq_rank = eq_base + block_excl_count(is_eq, S.wsum, eq_total);
+    const bool sel = in && (key < T || (is_eq && eq_rank < take_eq));
+    int sel_total;
+    const int pos = out_base + block_excl_count(sel, S.wsum, sel_total);
+    if (sel) emit(pos, i);
+    out_base += sel_total;
+    eq_base += eq_total;
+  }
+}
+
+}  // namespace svk

@@ -176,7 +176,7 @@ class CacheManager(ABC):
         """base.py:629-694 (_store_layer_kv): scatter this step's K/V rows to their slots."""
         from ...kernels import store_kvcache
         k_cache, v_cache = self.get_layer_store_view(layer_idx)
-        store_kvcache(k, v, k_cache, v_cache, self.layer_batch_states[layer_idx].slot_mapping)
+        store_kvcache(k, v, k_cache, v_cache, self.get_layer_batch_states(layer_idx).slot_mapping)
 
     def build_decode_compute_view(self, layer_idx: int, q: torch.Tensor, selection: SparseSelection, *,
                                   num_heads: int, num_kv_heads: int) -> DecodeComputeView:

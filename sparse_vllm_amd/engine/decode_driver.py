@@ -52,9 +52,14 @@ class SparseDecodeDriver:
         self.seqs = [Sequence(num_prompt_tokens=int(logical_len or resident_len)) for _ in range(batch)]
         for s in self.seqs:
             s.num_prefilled_tokens = s.num_prompt_tokens
-        for layer_idx in cm.kv_transformer_layer_indices():
+        paged = hasattr(cm, "page_size")          # Quest: one page table for all layers
+        if paged:
             for s in self.seqs:
-                cm._allocate(layer_idx, s.seq_id, resident_len)
+                cm._allocate(s.seq_id, resident_len)
+        else:
+            for layer_idx in cm.kv_transformer_layer_indices():
+                for s in self.seqs:
+                    cm._allocate(layer_idx, s.seq_id, resident_len)
         if fill_kv:
             # fill only the slots in use, layer by layer, to bound host memory
             for layer_idx in cm.kv_transformer_layer_indices():
@@ -69,6 +74,16 @@ class SparseDecodeDriver:
                         else:
                             blk = torch.randn(shape, generator=g) * kv_scale
                         cm.kv_cache[kv, layer_idx, s0:s1].copy_(blk.to(torch.bfloat16))
+        if paged and fill_kv:
+            # min/max metadata of every complete page, as prefill would have left it
+            from ..kernels import quest_ops
+            pages = []
+            for s in self.seqs:
+                row = cm.seq_id_to_row[s.seq_id]
+                pages.extend(int(x) for x in cm.buffer_req_to_page_slots_cpu[row, : resident_len // cm.page_size])
+            if pages:
+                quest_ops.page_minmax(cm.kv_cache, cm.metadata_cache,
+                                      torch.tensor(pages, dtype=torch.long, device=self.device), page_size=cm.page_size)
         if hasattr(cm, "h2o_score_tensor"):
             for layer_idx in cm.kv_transformer_layer_indices():
                 for s in self.seqs:
@@ -144,4 +159,6 @@ class SparseDecodeDriver:
 
     def row_len(self) -> np.ndarray:
         cm = self.cache_manager
+        if hasattr(cm, "page_size"):
+            return np.array([cm.row_seq_lens[cm.seq_id_to_row[s.seq_id]] for s in self.seqs])
         return np.array([cm.row_seq_lens[0][cm.seq_id_to_row[0][s.seq_id]] for s in self.seqs])

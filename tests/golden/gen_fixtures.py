@@ -361,12 +361,113 @@ def gen_h2o_burst():
     save("h2o_burst", **out)
 
 
+def gen_quest():
+    """QuestCacheManager (hand-built, SURVEY.md appendix A recipe): page metadata after a decode
+    step completes pages (on_forward_end), page scores (_score_pages_batched) and the packed decode
+    view (build_decode_view) in bf16 on CPU."""
+    from collections import deque
+    from sparsevllm.engine.cache_manager.base import LayerBatchStates
+    from sparsevllm.engine.cache_manager.quest import QuestCacheManager
+    from sparsevllm.utils.context import set_context, reset_context
+
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    page, Hkv, D, Hq, L = 16, 2, 64, 14, 1
+    rows, max_model_len = 3, 512
+    num_pages = 100
+    m = object.__new__(QuestCacheManager)
+    m.device = torch.device("cpu")
+    m.page_size = page
+    m.max_model_len = max_model_len
+    m.max_pages_per_row = max_model_len // page
+    m.head_dim, m.num_kv_heads, m.num_kv_layers, m.num_layers = D, Hkv, L, L
+    m.runtime_layout = SimpleNamespace(kv_layer_index=lambda l: int(l), kv_idx_to_layer_idx=tuple(range(L)))
+    m.page_offsets_i32 = torch.arange(page, dtype=torch.int32)
+    m.page_offsets_i64 = m.page_offsets_i32.to(torch.int64)
+    m.num_pages = num_pages
+    m.kv_cache = (torch.randn(2, L, num_pages * page, Hkv, D, generator=g) * 0.5).to(torch.bfloat16)
+    m.metadata_cache = torch.zeros(2, L, num_pages, Hkv, D, dtype=torch.bfloat16)
+    m.buffer_req_to_token_slots = torch.zeros(rows, max_model_len, dtype=torch.int32)
+    m.buffer_req_to_page_slots = torch.full((rows, m.max_pages_per_row), -1, dtype=torch.int32)
+    m.buffer_req_to_page_slots_cpu = np.full((rows, m.max_pages_per_row), -1, dtype=np.int32)
+    m.enable_prefix_caching = False
+    m.prefix_offload_controller = None
+    m.seq_id_to_row = {}
+    m.row_seq_lens = np.zeros((rows,), dtype=np.int32)
+    m.layer_batch_state = LayerBatchStates()
+    m.config = SimpleNamespace(quest_skip_layers=0, quest_token_budget=160)
+    # rows: lengths 480 (full pages), 331 (partial last page), 96 (short -> dense in mixed mode)
+    lens = [480, 331, 96]
+    perm = torch.randperm(num_pages, generator=g).tolist()
+    used = 0
+    for r, n in enumerate(lens):
+        m.seq_id_to_row[r] = r
+        npg = (n + page - 1) // page
+        ps = perm[used: used + npg]
+        used += npg
+        m.buffer_req_to_page_slots[r, :npg] = torch.tensor(ps, dtype=torch.int32)
+        m.buffer_req_to_page_slots_cpu[r, :npg] = np.asarray(ps, dtype=np.int32)
+        pos = torch.arange(n)
+        m.buffer_req_to_token_slots[r, :n] = (torch.tensor(ps)[pos // page] * page + pos % page).to(torch.int32)
+        m.row_seq_lens[r] = n
+    out["kv_k"] = bits(m.kv_cache[0].float())
+    out["page_table"] = m.buffer_req_to_page_slots.numpy().copy()
+    out["token_table"] = m.buffer_req_to_token_slots.numpy().copy()
+    out["lens"] = np.asarray(lens, dtype=np.int32)
+    # metadata of every complete page through the reference's own decode-completion hook: pretend each
+    # row just completed each of its full pages in turn
+    class _Base:  # CacheManager.on_forward_end default is a no-op for this purpose
+        pass
+    seqs = [SimpleNamespace(seq_id=r) for r in range(rows)]
+    real_lens = m.row_seq_lens.copy()
+    import sparsevllm.engine.cache_manager.quest as qmod
+    orig_super = qmod.CacheManager.on_forward_end
+    qmod.CacheManager.on_forward_end = lambda self, seqs, is_prefill: None
+    m._poll_prefix_offload = lambda: None
+    try:
+        max_full = max(n // page for n in lens)
+        for pg in range(1, max_full + 1):
+            for r, n in enumerate(lens):
+                m.row_seq_lens[r] = pg * page if pg * page <= n else 1   # len%16==0 -> page pg-1 "completed"
+            QuestCacheManager.on_forward_end(m, seqs, False)
+    finally:
+        qmod.CacheManager.on_forward_end = orig_super
+    m.row_seq_lens[:] = real_lens
+    out["metadata"] = np.stack([bits(m.metadata_cache[0].float()), bits(m.metadata_cache[1].float())])
+
+    q = (torch.randn(rows, Hq, D, generator=g) * 0.5).to(torch.bfloat16)
+    out["q"] = bits(q.float())
+    ctx_lens = torch.tensor(lens, dtype=torch.int32)
+    req = torch.arange(rows, dtype=torch.int32)
+    for tag, long_text in (("long", True), ("mixed", False)):
+        reset_context()
+        set_context(False, is_long_text=long_text)
+        m.layer_batch_state.max_context_len = max(lens)
+        active = m.buffer_req_to_token_slots
+        packed, ridx, clens = QuestCacheManager.build_decode_view(
+            m, 0, q, active, req, ctx_lens, num_heads=Hq, num_kv_heads=Hkv)
+        out[f"{tag}_packed"] = packed.numpy()
+        out[f"{tag}_req"] = ridx.numpy()
+        out[f"{tag}_lens"] = clens.numpy()
+    reset_context()
+    # raw page scores of layer 2 for all previous pages of each row
+    max_pages = (max(lens) + page - 1) // page
+    prev = m.buffer_req_to_page_slots[:, : max_pages - 1].long().clamp_min(0)
+    pmax = m.metadata_cache[0, 0].index_select(0, prev.reshape(-1)).view(rows, max_pages - 1, Hkv, D).permute(0, 2, 1, 3)
+    pmin = m.metadata_cache[1, 0].index_select(0, prev.reshape(-1)).view(rows, max_pages - 1, Hkv, D).permute(0, 2, 1, 3)
+    sc = QuestCacheManager._score_pages_batched(q, pmax, pmin, Hkv)
+    out["page_scores"] = sc.float().numpy()
+    out["cfg"] = np.array([page, 160, 0, max(lens), m.max_pages_per_row, Hkv, 0], dtype=np.int64)
+    save("quest", **out)
+
+
 GROUPS = {
     "decode": gen_decode,
     "h2o_select": gen_h2o_select,
     "h2o_scores": gen_h2o_scores,
     "compaction": gen_compaction,
     "h2o_burst": gen_h2o_burst,
+    "quest": gen_quest,
 }
 
 

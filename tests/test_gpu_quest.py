@@ -1,0 +1,191 @@
+"""GPU parity tests for the Quest path (page metadata, page scores, top-k view, paged decode)."""
+
+import numpy as np
+import pytest
+
+from oracle import bf16_bits_to_f32, bf16_round, f32_to_bf16_bits
+from oracle import decode_attention as oda
+from oracle import quest as oq
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_bf16(x):
+    return torch.from_numpy(f32_to_bf16_bits(x).view(np.int16).copy()).to(dev()).view(torch.bfloat16)
+
+
+def _fixture(golden):
+    g = golden("quest")
+    page, budget, layer, max_ctx, mppr, Hkv, _ = (int(x) for x in g["cfg"])
+    k = bf16_bits_to_f32(g["kv_k"])
+    meta = bf16_bits_to_f32(g["metadata"])
+    q = bf16_bits_to_f32(g["q"])
+    return g, page, budget, layer, max_ctx, mppr, Hkv, k, meta, q
+
+
+def test_page_minmax_golden(golden):
+    from sparse_vllm_amd.kernels.quest_ops import page_minmax
+    g, page, budget, layer, max_ctx, mppr, Hkv, k, meta, q = _fixture(golden)
+    L, slots, H, D = k.shape
+    kv = torch.zeros((2, L, slots, H, D), dtype=torch.bfloat16, device=dev())
+    kv[0] = to_bf16(k)
+    md = torch.zeros((2, L, slots // page, H, D), dtype=torch.bfloat16, device=dev())
+    pages = np.concatenate([g["page_table"][r, : n // page] for r, n in enumerate(g["lens"])]).astype(np.int64)
+    page_minmax(kv, md, torch.from_numpy(pages).to(dev()), page_size=page)
+    got = md.float().cpu().numpy()
+    np.testing.assert_array_equal(got[:, :, pages], meta[:, :, pages])
+    untouched = np.setdiff1d(np.arange(slots // page), pages)
+    assert (got[:, :, untouched] == 0).all()
+
+
+def test_score_pages_and_view_golden(golden):
+    from sparse_vllm_amd.kernels.quest_ops import build_view, score_pages
+    g, page, budget, layer, max_ctx, mppr, Hkv, k, meta, q = _fixture(golden)
+    lens = g["lens"]
+    B = len(lens)
+    d = dev()
+    max_pages = (max_ctx + page - 1) // page
+    n_prev = max_pages - 1
+    ptab = torch.from_numpy(g["page_table"].copy()).to(d)
+    ttab = torch.from_numpy(g["token_table"].copy()).to(d)
+    req = torch.arange(B, dtype=torch.int32, device=d)
+    cl = torch.from_numpy(lens.copy()).to(d)
+    scores = torch.zeros((B, n_prev), dtype=torch.float32, device=d)
+    score_pages(to_bf16(q), to_bf16(meta[0, layer]), to_bf16(meta[1, layer]), ptab, req, cl, scores, page_size=page,
+                n_prev=n_prev)
+    got = scores.cpu().numpy()
+    ref = g["page_scores"]
+    num_pages = (lens + page - 1) // page
+    valid = np.arange(n_prev)[None, :] < (num_pages - 1)[:, None]
+    assert np.isneginf(got[~valid]).all()
+    # bf16-valued scores; the MFMA's fp32 summation order may flip a rounding: <= 1 bf16 ulp, rarely
+    np.testing.assert_allclose(got[valid], ref[valid], rtol=2 ** -7, atol=1e-6)
+    assert (got[valid] != ref[valid]).mean() < 0.05
+    # the view kernel on the REFERENCE's scores must make the oracle's deterministic choice exactly
+    page_budget_base = max(3, budget // page)
+    prev_budget = min(page_budget_base - 1, max_pages - 1)
+    for long_text in (True, False):
+        keep = (prev_budget + 1) * page if long_text else max(budget, page_budget_base * page, page)
+        packed = torch.zeros((B, keep), dtype=torch.int32, device=d)
+        ll = torch.zeros((B,), dtype=torch.int32, device=d)
+        lr = torch.zeros((B,), dtype=torch.int32, device=d)
+        sc_in = torch.from_numpy(np.where(valid, ref, -np.inf).astype(np.float32)).to(d)
+        build_view(sc_in, ptab, ttab, req, cl, packed, ll, lr, page_size=page, n_prev=n_prev, prev_budget=prev_budget,
+                   token_budget=budget, page_budget_base=page_budget_base, max_keep=keep, is_long_text=long_text)
+        exp_packed, exp_req, exp_lens, info = oq.build_decode_view(
+            q, meta[0, layer], meta[1, layer], g["token_table"], g["page_table"], np.arange(B, dtype=np.int32), lens,
+            page_size=page, token_budget=budget, max_context_len=max_ctx, max_pages_per_row=mppr, num_kv_heads=Hkv,
+            is_long_text=long_text)
+        np.testing.assert_array_equal(ll.cpu().numpy(), exp_lens)
+        np.testing.assert_array_equal(lr.cpu().numpy(), exp_req)
+        gp = packed.cpu().numpy()
+        for b in range(B):
+            if valid[b].sum() < prev_budget and long_text:
+                continue      # undefined in the reference too (-inf pages)
+            np.testing.assert_array_equal(gp[b, : exp_lens[b]], exp_packed[b, : exp_lens[b]])
+        # and the reference's own choice differs only by boundary ties
+        tag = "long" if long_text else "mixed"
+        np.testing.assert_array_equal(ll.cpu().numpy(), g[f"{tag}_lens"])
+
+
+def test_quest_scores_qwen7b_shape_vs_oracle():
+    from sparse_vllm_amd.kernels.quest_ops import page_minmax, score_pages
+    rng = np.random.default_rng(4)
+    page, Hq, Hkv, D, B = 16, 28, 4, 128, 3
+    lens = np.array([4096 + 160, 2000, 333], dtype=np.int32)
+    n_pages_tot = int(((lens + page - 1) // page).sum()) + 8
+    k = bf16_round((rng.standard_normal((n_pages_tot * page, Hkv, D)) * 0.5).astype(np.float32))
+    q = bf16_round((rng.standard_normal((B, Hq, D)) * 0.5).astype(np.float32))
+    perm = rng.permutation(n_pages_tot)
+    max_pages = int((lens.max() + page - 1) // page)
+    ptab = np.full((B, max_pages + 3), -1, dtype=np.int32)
+    off = 0
+    for b, n in enumerate(lens):
+        npg = (n + page - 1) // page
+        ptab[b, :npg] = perm[off: off + npg]
+        off += npg
+    d = dev()
+    kv = torch.zeros((2, 1, n_pages_tot * page, Hkv, D), dtype=torch.bfloat16, device=d)
+    kv[0, 0] = to_bf16(k)
+    md = torch.zeros((2, 1, n_pages_tot, Hkv, D), dtype=torch.bfloat16, device=d)
+    full = np.concatenate([ptab[b, : n // page] for b, n in enumerate(lens)]).astype(np.int64)
+    page_minmax(kv, md, torch.from_numpy(full).to(d), page_size=page)
+    pmax, pmin = oq.page_minmax(k, full, page)
+    np.testing.assert_array_equal(md[0, 0].float().cpu().numpy()[full], pmax)
+    np.testing.assert_array_equal(md[1, 0].float().cpu().numpy()[full], pmin)
+    n_prev = max_pages - 1
+    scores = torch.zeros((B, n_prev), dtype=torch.float32, device=d)
+    score_pages(to_bf16(q), md[0, 0], md[1, 0], torch.from_numpy(ptab).to(d), torch.arange(B, dtype=torch.int32, device=d),
+                torch.from_numpy(lens).to(d), scores, page_size=page, n_prev=n_prev)
+    mmax = md[0, 0].float().cpu().numpy()
+    mmin = md[1, 0].float().cpu().numpy()
+    prev = np.maximum(ptab[:, :n_prev], 0).astype(np.int64)
+    ref = oq.score_pages_batched(q, mmax[prev].transpose(0, 2, 1, 3), mmin[prev].transpose(0, 2, 1, 3), Hkv)
+    valid = np.arange(n_prev)[None, :] < ((lens + page - 1) // page - 1)[:, None]
+    got = scores.cpu().numpy()
+    np.testing.assert_allclose(got[valid], ref[valid], rtol=2 ** -7, atol=1e-6)
+    assert (got[valid] != ref[valid]).mean() < 0.05
+    assert np.isneginf(got[~valid]).all()
+
+
+def test_quest_decode_steps_match_oracle():
+    """Quest through the operator surface: paged allocation, metadata refresh when a page completes,
+    query-aware view, unscored decode over the packed table."""
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from sparse_vllm_amd.utils.context import get_context
+    B, L, page = 2, 3, 16
+    conf = Config.from_kwargs(sparse_method="quest", num_hidden_layers=L, max_model_len=1024, max_num_seqs_in_gpu=B,
+                              num_kvcache_slots=B * 1024 + 64, sink_keep_tokens=16, recent_keep_tokens=16,
+                              decode_keep_tokens=96, quest_skip_layers=1)
+    assert conf.quest_token_budget == 128
+    drv = SparseDecodeDriver(conf)
+    cm = drv.cache_manager
+    cm.permute_free_pages(5)
+    start = 500
+    seqs = drv.admit_resident_rows(B, start, seed=9)
+    rows = [cm.seq_id_to_row[s.seq_id] for s in seqs]
+    outs = torch.zeros((L, B, 28, 128), dtype=torch.bfloat16, device=drv.device)
+    budget = 128
+    for step in range(20):       # crosses a page boundary at len 512
+        q, k, v = drv.random_step_inputs(seed=300 + step)
+        import sparse_vllm_amd.utils.context as ctxmod
+        drv.step(q, k, v, outputs=outs)
+        torch.cuda.synchronize()
+        lens = cm.row_seq_lens[rows].astype(np.int32)
+        assert (lens == start + step + 1).all()
+        ttab = cm.buffer_req_to_token_slots.cpu().numpy()
+        ptab = cm.buffer_req_to_page_slots.cpu().numpy()
+        # paging invariant: slot = page_slot*16 + offset
+        for b, r in enumerate(rows):
+            pos = np.arange(lens[b])
+            np.testing.assert_array_equal(ttab[r, : lens[b]], ptab[r, pos // page] * page + pos % page)
+        kc = cm.kv_cache[0].float().cpu().numpy()
+        vc = cm.kv_cache[1].float().cpu().numpy()
+        md = cm.metadata_cache.float().cpu().numpy()
+        qn = q.float().cpu().numpy()
+        for l in range(L):
+            if l < conf.quest_skip_layers:
+                mid, lse = oda.flash_decode_stage1(qn[l], kc[l], vc[l], ttab, np.array(rows, np.int32), lens,
+                                                   int(lens.max()), 64)
+                o = oda.flash_decode_stage2(mid, lse, lens, 64)
+            else:
+                # metadata of complete pages must be exact
+                for b, r in enumerate(rows):
+                    full = ptab[r, : lens[b] // page].astype(np.int64)
+                    # the page completed by THIS step is refreshed after the forward (quest.py:1718-1771)
+                    pmax, pmin = oq.page_minmax(kc[l], full, page)
+                    np.testing.assert_array_equal(md[0, l][full], pmax)
+                    np.testing.assert_array_equal(md[1, l][full], pmin)
+                res = oq.build_decode_view(qn[l], md[0, l], md[1, l], ttab, ptab, np.array(rows, np.int32), lens,
+                                           page_size=page, token_budget=budget, max_context_len=int(lens.max()),
+                                           max_pages_per_row=cm.max_pages_per_row, num_kv_heads=4, is_long_text=False)
+                packed, lreq, llens, info = res
+                mid, lse = oda.flash_decode_stage1(qn[l], kc[l], vc[l], packed, lreq, llens, int(packed.shape[1]), 64)
+                o = oda.flash_decode_stage2(mid, lse, llens, 64)
+            np.testing.assert_allclose(outs[l].float().cpu().numpy(), bf16_round(o), rtol=3e-2, atol=3e-2)
