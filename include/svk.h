@@ -250,6 +250,48 @@ typedef struct SvkDecodeAllocArgs {
 int svk_decode_alloc_slots(const SvkDecodeAllocArgs* a, svk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Prefill token scores (H2O accumulation / SnapKV selection)
+ * ---------------------------------------------------------------------------------- */
+
+#define SVK_PREFILL_SCORE_PROBABILITY 0
+#define SVK_PREFILL_SCORE_LOGITS 1
+
+/* attn_score[i, t] for score range i over the candidate keys t of its sequence:
+ *   probability: max_h (1/max(q_end-q_start,1)) * sum_{p in window} softmax_t(q_{p,h}.k_t / sqrt(D))
+ *                (softmax over the valid = candidate & causal keys of each query), others 0
+ *   logits:      max_{p,h} q_{p,h}.k_t (raw), others -inf
+ * The whole [n_ranges, score_cols] buffer is overwritten (fill + scores), like the reference wrapper.
+ * Replaces kernels/triton/prefill_score.py: prefill_score_fwd :432-670 (kernels :70-429),
+ * PrefillScoreWorkspace :6-67.  Q.K^T runs on the matrix cores (v_mfma_f32_16x16x32_bf16). */
+typedef struct SvkPrefillScoreArgs {
+  const uint16_t* q;                  /* [tokens, Hq, D] bf16 (this step's chunk queries)          */
+  const uint16_t* k_cache;            /* [slots, Hkv, D] bf16                                      */
+  float* attn_score;                  /* [n_ranges, score_stride] f32 out                          */
+  const int32_t* b_req_idx;           /* [batch] slot-table row per sequence                       */
+  const int32_t* b_start_loc;         /* [batch] first row of the sequence's chunk in q            */
+  const int32_t* b_seq_len;           /* [batch] context length incl. the chunk                    */
+  const int32_t* b_prompt_cache_len;  /* [batch] tokens before the chunk                           */
+  const int32_t* req_to_tokens;       /* [rows, req_stride]                                        */
+  const int32_t* score_q_start;       /* [n_ranges] absolute query window start                    */
+  const int32_t* score_q_end;         /* [n_ranges]                                                */
+  const int32_t* batch_indices;       /* NULL (range i <-> sequence i) or [n_ranges]               */
+  float* workspace;                   /* probability mode: svk_prefill_score_workspace_bytes()     */
+  int64_t q_stride_t, q_stride_h;
+  int64_t kv_slot_stride, kv_head_stride;
+  int64_t req_stride;
+  int64_t score_stride;
+  int32_t n_ranges;
+  int32_t num_q_heads, num_kv_heads, head_dim;
+  int32_t max_query_len;              /* longest window; probability mode: <= 128                  */
+  int32_t score_cols;                 /* columns of attn_score = longest candidate range           */
+  int32_t candidate_start, num_recent_tokens;
+  int32_t score_mode;                 /* SVK_PREFILL_SCORE_*                                       */
+} SvkPrefillScoreArgs;
+int64_t svk_prefill_score_workspace_bytes(int32_t n_ranges, int32_t num_q_heads, int32_t num_kv_heads,
+                                          int32_t max_query_len, int32_t score_cols);
+int svk_prefill_score(const SvkPrefillScoreArgs* a, svk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Quest: query-aware page top-k
  * ---------------------------------------------------------------------------------- */
 

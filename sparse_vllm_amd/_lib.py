@@ -25,6 +25,9 @@ SVK_SCORE_PERHEAD = 3
 
 SVK_ABI_VERSION = 2
 
+SVK_PREFILL_SCORE_PROBABILITY = 0
+SVK_PREFILL_SCORE_LOGITS = 1
+
 _p = C.c_void_p
 _i64 = C.c_int64
 _i32 = C.c_int32
@@ -119,6 +122,17 @@ class SvkQuestDecodeAllocArgs(C.Structure):
                 ("batch", _i32), ("graph_batch", _i32), ("page_size", _i32)]
 
 
+class SvkPrefillScoreArgs(C.Structure):
+    _fields_ = [("q", _p), ("k_cache", _p), ("attn_score", _p), ("b_req_idx", _p), ("b_start_loc", _p),
+                ("b_seq_len", _p), ("b_prompt_cache_len", _p), ("req_to_tokens", _p), ("score_q_start", _p),
+                ("score_q_end", _p), ("batch_indices", _p), ("workspace", _p),
+                ("q_stride_t", _i64), ("q_stride_h", _i64), ("kv_slot_stride", _i64), ("kv_head_stride", _i64),
+                ("req_stride", _i64), ("score_stride", _i64),
+                ("n_ranges", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
+                ("max_query_len", _i32), ("score_cols", _i32), ("candidate_start", _i32),
+                ("num_recent_tokens", _i32), ("score_mode", _i32)]
+
+
 # symbol -> (argtypes) ; every entry point declared in include/svk.h
 ENTRY_POINTS = {
     "svk_abi_version": ([], C.c_int),
@@ -133,6 +147,8 @@ ENTRY_POINTS = {
     "svk_h2o_select_indices": ([C.POINTER(SvkH2oSelectArgs), _p], C.c_int),
     "svk_compact_rows": ([C.POINTER(SvkCompactRowsArgs), _p], C.c_int),
     "svk_decode_alloc_slots": ([C.POINTER(SvkDecodeAllocArgs), _p], C.c_int),
+    "svk_prefill_score_workspace_bytes": ([_i32, _i32, _i32, _i32, _i32], C.c_int64),
+    "svk_prefill_score": ([C.POINTER(SvkPrefillScoreArgs), _p], C.c_int),
     "svk_quest_page_minmax": ([C.POINTER(SvkQuestPageMinmaxArgs), _p], C.c_int),
     "svk_quest_score_pages": ([C.POINTER(SvkQuestScorePagesArgs), _p], C.c_int),
     "svk_quest_build_view": ([C.POINTER(SvkQuestBuildViewArgs), _p], C.c_int),

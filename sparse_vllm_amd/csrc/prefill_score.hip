@@ -1,0 +1,326 @@
+// Prefill token scores on the matrix cores (gfx950).  Replaces kernels/triton/prefill_score.py.
+//
+// Row space of one (score range, KV head): row = g * Wpad + qi, g = head of the GQA group,
+// qi = query inside the window, Wpad = window padded to 16 -> every 16-row MFMA tile belongs to one
+// head.  A workgroup = 4 waves x 64 rows; it walks a 256-key range 16 keys at a time with
+// register double-buffered B fragments (keys are loaded straight from the paged cache in the
+// B-operand layout, as in decode stage 1).
+//   probability: pass 1 keeps per-lane online (max, sum) for its 16 rows, reduces across the
+//                16 key lanes once per range and writes partial stats; a tiny reduce kernel merges
+//                the partials; pass 2 recomputes Q.K^T (cheaper than spilling 58 MB of logits),
+//                forms probabilities, sums them over each head's queries and max-combines heads.
+//   logits:      one pass, per-token max over rows.
+// The only atomics are the final per-token max across workgroups (float max as integer max).
+
+#include <algorithm>
+
+#include "svk_common.hpp"
+
+namespace svk {
+namespace {
+
+constexpr int kRowsPerWg = 256;
+constexpr int kKeysPerWg = 256;
+constexpr float kMasked = -1.0e20f;
+
+__device__ __forceinline__ void atomic_max_nonneg(float* p, float v) {
+  atomicMax(reinterpret_cast<int*>(p), __builtin_bit_cast(int, v));      // valid for v >= 0, *p >= 0
+}
+__device__ __forceinline__ void atomic_max_any(float* p, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(p), __builtin_bit_cast(int, v));
+  else atomicMin(reinterpret_cast<unsigned int*>(p), __builtin_bit_cast(unsigned int, v));
+}
+
+struct RangeInfo {
+  int start_loc, cache_len, ctx_len, chunk_len, q_start, q_end, cand_end;
+  const int32_t* row;
+};
+
+__device__ __forceinline__ RangeInfo load_range(const SvkPrefillScoreArgs& a, int i) {
+  RangeInfo r;
+  const int s = a.batch_indices ? a.batch_indices[i] : i;
+  r.start_loc = a.b_start_loc[s];
+  r.cache_len = a.b_prompt_cache_len[s];
+  r.ctx_len = a.b_seq_len[s];
+  r.chunk_len = r.ctx_len - r.cache_len;
+  r.q_start = a.score_q_start[i];
+  r.q_end = a.score_q_end[i];
+  r.cand_end = min(max(a.candidate_start, r.ctx_len - a.num_recent_tokens), a.score_cols);
+  r.row = a.req_to_tokens + (int64_t)a.b_req_idx[s] * a.req_stride;
+  return r;
+}
+
+// PASS: 0 = partial stats, 1 = final probabilities, 2 = logits
+template <int D, int PASS>
+__global__ void __launch_bounds__(256) prefill_score_kernel(const SvkPrefillScoreArgs a, int G, int Wpad, int q_limit,
+                                                            int RB, int NKB, float* part_m, float* part_l,
+                                                            const float* glob_m, const float* glob_l) {
+  constexpr int NC = D / 32;
+  __shared__ float tsum[16][kKeysPerWg];       // per row tile column sums / maxima
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = lane & 15, jq = lane >> 4;
+  const int kb = blockIdx.x;
+  int grp = blockIdx.y;
+  const int rb = grp % RB; grp /= RB;
+  const int h = grp % a.num_kv_heads;
+  const int i = grp / a.num_kv_heads;
+  const RangeInfo R = load_range(a, i);
+  const int k0 = kb * kKeysPerWg;
+  const int key_lo = max(k0, a.candidate_start), key_hi = min(k0 + kKeysPerWg, R.cand_end);
+  const int rows_total = G * Wpad;
+  const int wrow0 = rb * kRowsPerWg + w * 64;          // first row of this wave
+  const float sm_scale = rsqrtf((float)D);
+
+  // absolute query position of the 16 rows this lane sees in the C layout (-1 = masked row)
+  int rowpos[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wrow0 + rt * 16 + jq * 4 + r;
+      const int qi = row % Wpad;
+      const int qa = R.q_start + qi;
+      const int rel = qa - R.cache_len;
+      const bool ok = row < rows_total && qi < q_limit && qa < R.q_end && rel >= 0 && rel < R.chunk_len;
+      rowpos[rt][r] = ok ? qa : -1;
+    }
+  // A fragments: lane (m = n, k chunk jq) holds Q[row wrow0 + rt*16 + n][c*32 + jq*8 ..]
+  bf16x8_t qa_frag[4][NC];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int row = wrow0 + rt * 16 + n;
+    const int g = row / Wpad, qi = row % Wpad;
+    const int qabs = R.q_start + qi;
+    const int rel = qabs - R.cache_len;
+    const bool ok = row < rows_total && qi < q_limit && qabs < R.q_end && rel >= 0 && rel < R.chunk_len;
+    const uint16_t* qp = a.q + (int64_t)(R.start_loc + rel) * a.q_stride_t + (int64_t)(h * G + g) * a.q_stride_h + jq * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (ok) t = *reinterpret_cast<const uint4*>(qp + c * 32);
+      qa_frag[rt][c] = __builtin_bit_cast(bf16x8_t, t);
+    }
+  }
+  float gm[4][4], gl[4][4];      // pass 1: running stats; pass 2: global stats of the row
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (PASS == 1) {
+        const int row = rb * kRowsPerWg + w * 64 + rt * 16 + jq * 4 + r;
+        const int64_t o = ((int64_t)(i * a.num_kv_heads + h) * RB + rb) * kRowsPerWg + (row - rb * kRowsPerWg);
+        gm[rt][r] = glob_m[o];
+        const float l = glob_l[o];
+        gl[rt][r] = l > 0.f ? l : 1.f;
+      } else {
+        gm[rt][r] = kMasked;
+        gl[rt][r] = 0.f;
+      }
+    }
+  if (PASS != 0) {
+    for (int t = threadIdx.x; t < 16 * kKeysPerWg; t += blockDim.x) (&tsum[0][0])[t] = PASS == 2 ? -INFINITY : 0.f;
+    __syncthreads();
+  }
+
+  const uint16_t* kbase = a.k_cache + (int64_t)h * a.kv_head_stride + jq * 8;
+  auto load_keys = [&](int t0, uint4 (&kr)[NC]) {
+    const int t = t0 + n;
+    const bool in = t >= key_lo && t < key_hi;
+    const int slot = in ? R.row[t] : 0;
+    const uint16_t* kp = kbase + (int64_t)slot * a.kv_slot_stride;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) kr[c] = *reinterpret_cast<const uint4*>(kp + c * 32);
+  };
+  if (key_lo < key_hi) {
+    const int t_first = (key_lo / 16) * 16;
+    uint4 kcur[NC], knxt[NC];
+    load_keys(t_first, kcur);
+    for (int t0 = t_first; t0 < key_hi; t0 += 16) {
+      if (t0 + 16 < key_hi) load_keys(t0 + 16, knxt);
+      const int t = t0 + n;
+      const bool kin = t >= key_lo && t < key_hi;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa_frag[rt][c], __builtin_bit_cast(bf16x8_t, kcur[c]), s, 0, 0, 0);
+        if (PASS == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool valid = kin && rowpos[rt][r] >= t;
+            const float x = valid ? s[r] * sm_scale : kMasked;
+            const float nm = fmaxf(gm[rt][r], x);
+            gl[rt][r] = gl[rt][r] * __expf(gm[rt][r] - nm) + (valid ? __expf(x - nm) : 0.f);
+            gm[rt][r] = nm;
+          }
+        } else if (PASS == 1) {
+          float colsum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool valid = kin && rowpos[rt][r] >= t;
+            colsum += valid ? __expf(s[r] * sm_scale - gm[rt][r]) / gl[rt][r] : 0.f;
+          }
+          colsum += __shfl_xor(colsum, 16, 64);
+          colsum += __shfl_xor(colsum, 32, 64);
+          if (jq == 0 && kin) tsum[w * 4 + rt][t - k0] = colsum;
+        } else {
+          float colmax = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool valid = kin && rowpos[rt][r] >= t;
+            colmax = fmaxf(colmax, valid ? s[r] : kMasked);
+          }
+          colmax = fmaxf(colmax, __shfl_xor(colmax, 16, 64));
+          colmax = fmaxf(colmax, __shfl_xor(colmax, 32, 64));
+          if (jq == 0 && kin) tsum[w * 4 + rt][t - k0] = colmax;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) kcur[c] = knxt[c];
+    }
+  }
+
+  if (PASS == 0) {
+    // merge the 16 key lanes of every row: (m, l) pairs combine as M = max m, L = sum l*exp(m-M)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float M = row16_allmax(gm[rt][r]);
+        const float L = row16_allsum(gl[rt][r] * __expf(gm[rt][r] - M));
+        if (n == 0) {
+          const int row_in_wg = w * 64 + rt * 16 + jq * 4 + r;
+          const int64_t o = (((int64_t)(i * a.num_kv_heads + h) * RB + rb) * NKB + kb) * kRowsPerWg + row_in_wg;
+          part_m[o] = M;
+          part_l[o] = L;
+        }
+      }
+    return;
+  }
+  __syncthreads();
+  // one thread per key column: combine the row tiles of each head, then heads, then publish
+  const int tiles_per_head = Wpad / 16;
+  for (int c = threadIdx.x; c < kKeysPerWg; c += blockDim.x) {
+    const int t = k0 + c;
+    if (t < key_lo || t >= key_hi) continue;
+    float* dst = a.attn_score + (int64_t)i * a.score_stride + t;
+    if (PASS == 2) {
+      float mx = -INFINITY;
+      for (int tl = 0; tl < 16; ++tl)
+        if (rb * kRowsPerWg + tl * 16 < rows_total) mx = fmaxf(mx, tsum[tl][c]);
+      atomic_max_any(dst, mx);
+    } else {
+      const float inv_len = 1.f / (float)max(R.q_end - R.q_start, 1);
+      // tiles of this workgroup that belong to head g: global tile index in [g*tph, (g+1)*tph)
+      const int tile0 = rb * 16;
+      float best = 0.f;
+      for (int tl = 0; tl < 16;) {
+        const int gt = tile0 + tl;
+        if (gt * 16 >= rows_total) break;
+        const int g = gt / tiles_per_head;
+        float hs = 0.f;
+        while (tl < 16 && (tile0 + tl) / tiles_per_head == g && (tile0 + tl) * 16 < rows_total) hs += tsum[tl++][c];
+        // NOTE: a head whose tiles straddle two workgroups (Wpad = 128 with an odd row-block
+        // boundary never happens: 256 % Wpad == 0) is always complete here
+        best = fmaxf(best, hs * inv_len);
+      }
+      atomic_max_nonneg(dst, best);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) prefill_score_reduce_kernel(const float* part_m, const float* part_l, float* glob_m,
+                                                                    float* glob_l, int NKB) {
+  // one thread per (group, row): merge the NKB partial (m, l) pairs
+  const int64_t o = (int64_t)blockIdx.x * kRowsPerWg + threadIdx.x;
+  const float* pm = part_m + (int64_t)blockIdx.x * NKB * kRowsPerWg + threadIdx.x;
+  const float* pl = part_l + (int64_t)blockIdx.x * NKB * kRowsPerWg + threadIdx.x;
+  float M = kMasked;
+  for (int b = 0; b < NKB; ++b) M = fmaxf(M, pm[(int64_t)b * kRowsPerWg]);
+  float L = 0.f;
+  for (int b = 0; b < NKB; ++b) L += pl[(int64_t)b * kRowsPerWg] * __expf(pm[(int64_t)b * kRowsPerWg] - M);
+  glob_m[o] = M;
+  glob_l[o] = L;
+}
+
+__global__ void __launch_bounds__(256) fill_rows_kernel(float* dst, int64_t stride, int cols, float v) {
+  float* row = dst + (int64_t)blockIdx.y * stride;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) row[c] = v;
+}
+
+struct Tiling { int G, Wpad, q_limit, RB, NKB; int64_t groups; };
+
+inline int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+inline Tiling make_tiling(int n_ranges, int Hq, int Hkv, int max_q, int cols, int mode) {
+  Tiling t;
+  t.G = Hq / Hkv;
+  if (mode == SVK_PREFILL_SCORE_LOGITS) {
+    const int block_m = std::min(32, std::max(16, next_pow2(max_q)));     // prefill_score.py:493-495
+    t.q_limit = ((max_q + block_m - 1) / block_m) * block_m;
+  } else {
+    t.q_limit = std::max(16, next_pow2(max_q));                          // :497
+  }
+  t.Wpad = ((std::min(t.q_limit, std::max(max_q, 1)) + 15) / 16) * 16;
+  if (kRowsPerWg % t.Wpad != 0 && t.Wpad < kRowsPerWg) t.Wpad = next_pow2(t.Wpad);   // keep heads inside one workgroup
+  t.RB = (t.G * t.Wpad + kRowsPerWg - 1) / kRowsPerWg;
+  t.NKB = (cols + kKeysPerWg - 1) / kKeysPerWg;
+  t.groups = (int64_t)n_ranges * Hkv * t.RB;
+  return t;
+}
+
+}  // namespace
+}  // namespace svk
+
+extern "C" int64_t svk_prefill_score_workspace_bytes(int32_t n_ranges, int32_t num_q_heads, int32_t num_kv_heads,
+                                                     int32_t max_query_len, int32_t score_cols) {
+  using namespace svk;
+  if (n_ranges <= 0 || num_kv_heads <= 0 || max_query_len <= 0 || score_cols <= 0) return 0;
+  const Tiling t = make_tiling(n_ranges, num_q_heads, num_kv_heads, max_query_len, score_cols, SVK_PREFILL_SCORE_PROBABILITY);
+  return (int64_t)sizeof(float) * 2 * t.groups * kRowsPerWg * ((int64_t)t.NKB + 1);
+}
+
+extern "C" int svk_prefill_score(const SvkPrefillScoreArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_prefill_score: null args");
+  SVK_REQUIRE(a->score_mode == SVK_PREFILL_SCORE_PROBABILITY || a->score_mode == SVK_PREFILL_SCORE_LOGITS, SVK_ERR_VALUE,
+              "prefill score_mode must be 'probability' or 'logits', got %d.", a->score_mode);
+  SVK_REQUIRE(a->head_dim == 64 || a->head_dim == 128, SVK_ERR_LAYOUT, "svk_prefill_score: head_dim %d unsupported (64, 128)", a->head_dim);
+  SVK_REQUIRE(a->num_kv_heads > 0 && a->num_q_heads % a->num_kv_heads == 0, SVK_ERR_VALUE,
+              "num query heads must be divisible by num kv heads: q=%d k=%d", a->num_q_heads, a->num_kv_heads);
+  if (a->max_query_len <= 0 || a->score_cols <= 0 || a->n_ranges <= 0) return SVK_OK;
+  if (a->score_mode == SVK_PREFILL_SCORE_PROBABILITY) {
+    SVK_REQUIRE(std::max(16, next_pow2(a->max_query_len)) <= 128, SVK_ERR_VALUE,
+                "probability prefill score query range is too large for this kernel: %d > 128", a->max_query_len);
+    SVK_REQUIRE(a->workspace != nullptr, SVK_ERR_VALUE, "svk_prefill_score: probability mode needs a workspace");
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Tiling t = make_tiling(a->n_ranges, a->num_q_heads, a->num_kv_heads, a->max_query_len, a->score_cols, a->score_mode);
+  const bool logits = a->score_mode == SVK_PREFILL_SCORE_LOGITS;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3(std::min(64, (a->score_cols + 255) / 256), a->n_ranges), dim3(256), 0, s,
+                     a->attn_score, a->score_stride, a->score_cols, logits ? -INFINITY : 0.f);
+  dim3 grid(t.NKB, (unsigned)t.groups), block(256);
+  const int64_t part = t.groups * t.NKB * kRowsPerWg, glob = t.groups * kRowsPerWg;
+  float* pm = a->workspace;
+  float* pl = pm ? pm + part : nullptr;
+  float* gmx = pl ? pl + part : nullptr;
+  float* glx = gmx ? gmx + glob : nullptr;
+#define SVK_PS(D_)                                                                                                         \
+  do {                                                                                                                     \
+    if (logits) {                                                                                                          \
+      hipLaunchKernelGGL((prefill_score_kernel<D_, 2>), grid, block, 0, s, *a, t.G, t.Wpad, t.q_limit, t.RB, t.NKB, nullptr, \
+                         nullptr, nullptr, nullptr);                                                                       \
+    } else {                                                                                                               \
+      hipLaunchKernelGGL((prefill_score_kernel<D_, 0>), grid, block, 0, s, *a, t.G, t.Wpad, t.q_limit, t.RB, t.NKB, pm, pl,  \
+                         nullptr, nullptr);                                                                                \
+      hipLaunchKernelGGL(prefill_score_reduce_kernel, dim3((unsigned)t.groups), dim3(kRowsPerWg), 0, s, pm, pl, gmx, glx,  \
+                         t.NKB);                                                                                           \
+      hipLaunchKernelGGL((prefill_score_kernel<D_, 1>), grid, block, 0, s, *a, t.G, t.Wpad, t.q_limit, t.RB, t.NKB, nullptr, \
+                         nullptr, gmx, glx);                                                                               \
+    }                                                                                                                      \
+  } while (0)
+  if (a->head_dim == 128) SVK_PS(128); else SVK_PS(64);
+#undef SVK_PS
+  return check_launch("svk_prefill_score");
+}

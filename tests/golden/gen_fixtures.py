@@ -461,6 +461,53 @@ def gen_quest():
     save("quest", **out)
 
 
+def gen_prefill_score():
+    """prefill_score_fwd (both modes) under the Triton interpreter, fp32 tensors holding bf16 values."""
+    from sparsevllm.kernels.triton.prefill_score import prefill_score_fwd
+
+    out = {}
+    g = torch.Generator().manual_seed(33)
+    cases = [
+        # name, Hq, Hkv, D, [(cache_len, chunk_len)], window, candidate_start, num_recent, mode
+        ("p1", 8, 2, 64, [(96, 40), (0, 57)], 32, 0, 0, "probability"),
+        ("p2", 28, 4, 128, [(70, 50)], 32, 4, 16, "probability"),       # SnapKV-style sink/recent carve-out
+        ("l1", 8, 2, 64, [(96, 40), (10, 30)], 40, 0, 0, "logits"),
+        ("p3", 14, 2, 64, [(0, 20)], 128, 0, 0, "probability"),          # window longer than the chunk
+    ]
+    for name, Hq, Hkv, D, seqs_cfg, window, cstart, nrecent, mode in cases:
+        nb = len(seqs_cfg)
+        ctx = [c + n for c, n in seqs_cfg]
+        slots = sum(ctx) + 32
+        k = bf16f(torch.randn(slots, Hkv, D, generator=g) * 0.5)
+        total_q = sum(n for _, n in seqs_cfg)
+        q = bf16f(torch.randn(total_q, Hq, D, generator=g) * 0.5)
+        cap = max(ctx) + 9
+        req = torch.zeros(nb + 1, cap, dtype=torch.int32)
+        perm = torch.randperm(slots, generator=g).to(torch.int32)
+        rows = list(range(nb, 0, -1))           # rows nb..1 (not identity)
+        off = 0
+        for i, L in enumerate(ctx):
+            req[rows[i], :L] = perm[off: off + L]
+            off += L
+        b_req = torch.tensor(rows, dtype=torch.int32)
+        b_start = torch.tensor(np.concatenate(([0], np.cumsum([n for _, n in seqs_cfg])[:-1])), dtype=torch.int32)
+        b_seq = torch.tensor(ctx, dtype=torch.int32)
+        b_cache = torch.tensor([c for c, _ in seqs_cfg], dtype=torch.int32)
+        q_end = torch.tensor(ctx, dtype=torch.int32)
+        q_start = torch.tensor([max(L - window, c) for L, (c, n) in zip(ctx, seqs_cfg)], dtype=torch.int32)
+        max_q = int((q_end - q_start).max())
+        Lc = max(ctx)
+        score = torch.empty(nb, Lc)
+        prefill_score_fwd(q, k, score, b_req, b_start, b_seq, b_cache, max_q, req, q_start, q_end,
+                          candidate_start=cstart, num_recent_tokens=nrecent, score_mode=mode)
+        out.update({f"{name}_q": bits(q), f"{name}_k": bits(k), f"{name}_req": req.numpy(),
+                    f"{name}_b_req": b_req.numpy(), f"{name}_b_start": b_start.numpy(), f"{name}_b_seq": b_seq.numpy(),
+                    f"{name}_b_cache": b_cache.numpy(), f"{name}_q_start": q_start.numpy(), f"{name}_q_end": q_end.numpy(),
+                    f"{name}_cfg": np.array([max_q, cstart, nrecent, 1 if mode == "logits" else 0], dtype=np.int64),
+                    f"{name}_score": score.numpy()})
+    save("prefill_score", **out)
+
+
 GROUPS = {
     "decode": gen_decode,
     "h2o_select": gen_h2o_select,
@@ -468,6 +515,7 @@ GROUPS = {
     "compaction": gen_compaction,
     "h2o_burst": gen_h2o_burst,
     "quest": gen_quest,
+    "prefill_score": gen_prefill_score,
 }
 
 

@@ -1,0 +1,114 @@
+"""GPU parity of svk_prefill_score (MFMA Q.K^T) vs the reference-generated fixtures and the oracle.
+Tolerance: rtol 2e-2 / atol 2e-4 on probabilities (the reference's kernel-test bar is rtol=atol=2e-2,
+tests/test_prefill_score_kernel.py:282-284); logits: atol 2e-3 (fp32 accumulate of bf16 products)."""
+
+import numpy as np
+import pytest
+
+from oracle import bf16_bits_to_f32, bf16_round, f32_to_bf16_bits
+from oracle import prefill_score as ops
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_bf16(x):
+    return torch.from_numpy(f32_to_bf16_bits(x).view(np.int16).copy()).to(dev()).view(torch.bfloat16)
+
+
+def run(q, k, shape, b_req, b_start, b_seq, b_cache, max_q, req, qs, qe, cstart, nrecent, mode, batch_indices=None):
+    from sparse_vllm_amd.kernels.prefill_score import prefill_score_fwd
+    d = dev()
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(d)
+    out = torch.full(shape, 777.0, dtype=torch.float32, device=d)
+    prefill_score_fwd(to_bf16(q), to_bf16(k), out, t(b_req), t(b_start), t(b_seq), t(b_cache), max_q, t(req), t(qs), t(qe),
+                      candidate_start=cstart, num_recent_tokens=nrecent, score_mode=mode,
+                      batch_indices=None if batch_indices is None else t(batch_indices))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def compare(out, ref, logits):
+    if logits:
+        assert np.array_equal(np.isneginf(out), np.isneginf(ref))
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(out[fin], ref[fin], rtol=1e-4, atol=2e-3)
+    else:
+        np.testing.assert_allclose(out, ref, rtol=2e-2, atol=2e-4)
+        assert np.abs(out - ref).max() < 1e-3
+
+
+@pytest.mark.parametrize("case", ["p1", "p2", "l1", "p3"])
+def test_prefill_score_golden(golden, case):
+    g = golden("prefill_score")
+    q, k = bf16_bits_to_f32(g[f"{case}_q"]), bf16_bits_to_f32(g[f"{case}_k"])
+    max_q, cstart, nrecent, is_logits = (int(x) for x in g[f"{case}_cfg"])
+    ref = g[f"{case}_score"]
+    out = run(q, k, ref.shape, g[f"{case}_b_req"], g[f"{case}_b_start"], g[f"{case}_b_seq"], g[f"{case}_b_cache"], max_q,
+              g[f"{case}_req"], g[f"{case}_q_start"], g[f"{case}_q_end"], cstart, nrecent,
+              "logits" if is_logits else "probability")
+    compare(out, ref, bool(is_logits))
+
+
+@pytest.mark.parametrize("cfg", [
+    # Hq, Hkv, D, [(cache, chunk)], window, cstart, nrecent, mode
+    (28, 4, 128, [(3000, 1096)], 128, 0, 0, "probability"),            # H2O chunk: window 128, GQA 7
+    (28, 4, 128, [(500, 700), (0, 333)], 32, 64, 512, "probability"),  # SnapKV: window 32, sink 64, recent 512
+    (28, 4, 128, [(1000, 600)], 128, 0, 0, "logits"),
+    (14, 2, 64, [(300, 300), (10, 100), (0, 50)], 100, 0, 0, "probability"),
+    (8, 8, 64, [(100, 200)], 200, 0, 0, "logits"),                      # logits window > 128
+])
+def test_prefill_score_vs_oracle(cfg):
+    Hq, Hkv, D, seqs, window, cstart, nrecent, mode = cfg
+    rng = np.random.default_rng(Hq + len(seqs) + window)
+    ctx = [c + n for c, n in seqs]
+    nb = len(seqs)
+    slots = sum(ctx) + 64
+    k = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.4).astype(np.float32))
+    q = bf16_round((rng.standard_normal((sum(n for _, n in seqs), Hq, D)) * 0.4).astype(np.float32))
+    req = np.zeros((nb + 2, max(ctx) + 5), dtype=np.int32)
+    perm = rng.permutation(slots).astype(np.int32)
+    rows = rng.permutation(nb + 2)[:nb].astype(np.int32)
+    off = 0
+    for i, L in enumerate(ctx):
+        req[rows[i], :L] = perm[off: off + L]
+        off += L
+    b_start = np.concatenate(([0], np.cumsum([n for _, n in seqs])[:-1])).astype(np.int32)
+    b_seq = np.array(ctx, dtype=np.int32)
+    b_cache = np.array([c for c, _ in seqs], dtype=np.int32)
+    qe = b_seq.copy()
+    qs = np.array([max(L - window, c) for L, (c, n) in zip(ctx, seqs)], dtype=np.int32)
+    max_q = int((qe - qs).max())
+    ref = np.empty((nb, max(ctx)), dtype=np.float32)
+    ops.prefill_score_fwd(q, k, ref, rows, b_start, b_seq, b_cache, max_q, req, qs, qe, candidate_start=cstart,
+                          num_recent_tokens=nrecent, score_mode=mode)
+    out = run(q, k, ref.shape, rows, b_start, b_seq, b_cache, max_q, req, qs, qe, cstart, nrecent, mode)
+    compare(out, ref, mode == "logits")
+    # with batch_indices: ranges in reverse order of the sequences
+    if nb > 1:
+        bi = np.arange(nb - 1, -1, -1).astype(np.int32)
+        ref2 = np.empty_like(ref)
+        ops.prefill_score_fwd(q, k, ref2, rows, b_start, b_seq, b_cache, max_q, req, qs[bi], qe[bi], candidate_start=cstart,
+                              num_recent_tokens=nrecent, score_mode=mode, batch_indices=bi)
+        out2 = run(q, k, ref.shape, rows, b_start, b_seq, b_cache, max_q, req, qs[bi], qe[bi], cstart, nrecent, mode, bi)
+        compare(out2, ref2, mode == "logits")
+
+
+def test_prefill_score_validation():
+    from sparse_vllm_amd.kernels.prefill_score import prefill_score_fwd
+    d = dev()
+    q = torch.zeros(4, 8, 64, dtype=torch.bfloat16, device=d)
+    k = torch.zeros(16, 2, 64, dtype=torch.bfloat16, device=d)
+    z = torch.zeros(1, dtype=torch.int32, device=d)
+    sc = torch.zeros(1, 8, device=d)
+    req = torch.zeros(1, 8, dtype=torch.int32, device=d)
+    with pytest.raises(ValueError, match="score_mode"):
+        prefill_score_fwd(q, k, sc, z, z, z, z, 4, req, z, z, score_mode="softmax")
+    with pytest.raises(ValueError, match="too large"):
+        prefill_score_fwd(q, k, sc, z, z, z, z, 200, req, z, z)
+    with pytest.raises(ValueError, match="one row per score range"):
+        prefill_score_fwd(q, k, torch.zeros(2, 8, device=d), z, z, z, z, 4, req, z, z)
