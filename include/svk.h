@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 2
+#define SVK_ABI_VERSION 3
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -199,6 +199,22 @@ typedef struct SvkH2oSelectArgs {
   int32_t recent_count;  /* host: min(max(1, int(budget*ratio)), budget, kv_len)  */
 } SvkH2oSelectArgs;
 int svk_h2o_select_indices(const SvkH2oSelectArgs* a, svk_stream_t stream);
+
+/* keep = [0, prefix) ++ (prefix + top-`topk` of scores[prefix : kv_len - suffix] by (score desc,
+ * index asc)) ++ [kv_len - suffix, kv_len), ascending, int64; exactly prefix + topk + suffix entries
+ * (requires topk <= kv_len - suffix - prefix).
+ * Replaces SparseController._snapkv_select_indices{,_batch}, engine/sparse_controller.py:1670-1747
+ * (sink ++ topk(middle) ++ recent; the reference's `topk` order/tie choice is unspecified and
+ * free_part_slots sorts the indices, so parity is on the index SET with lowest-index tie-break),
+ * and the DeltaKV compressed-position top-k, sparse_controller.py:1813-1822. */
+typedef struct SvkSelectTopkArgs {
+  const float* scores;
+  int64_t* keep;
+  int64_t score_stride, keep_stride;
+  int32_t rows, kv_len;
+  int32_t prefix, topk, suffix;
+} SvkSelectTopkArgs;
+int svk_select_prefix_topk_suffix(const SvkSelectTopkArgs* a, svk_stream_t stream);
 
 /* Slot-table compaction for a batch of (layer, row) pairs of one uniform length:
  *   new_row = old_row[keep]; dropped slots (ascending position) are appended to the

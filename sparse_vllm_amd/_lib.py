@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 2
+SVK_ABI_VERSION = 3
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -74,6 +74,11 @@ class SvkH2oDecodeFinishArgs(C.Structure):
 class SvkH2oSelectArgs(C.Structure):
     _fields_ = [("scores", _p), ("keep", _p), ("score_stride", _i64), ("keep_stride", _i64),
                 ("rows", _i32), ("kv_len", _i32), ("budget", _i32), ("recent_count", _i32)]
+
+
+class SvkSelectTopkArgs(C.Structure):
+    _fields_ = [("scores", _p), ("keep", _p), ("score_stride", _i64), ("keep_stride", _i64),
+                ("rows", _i32), ("kv_len", _i32), ("prefix", _i32), ("topk", _i32), ("suffix", _i32)]
 
 
 class SvkCompactRowsArgs(C.Structure):
@@ -145,6 +150,7 @@ ENTRY_POINTS = {
     "svk_h2o_decode_score_update": ([C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
     "svk_h2o_decode_finish": ([C.POINTER(SvkH2oDecodeFinishArgs), _p], C.c_int),
     "svk_h2o_select_indices": ([C.POINTER(SvkH2oSelectArgs), _p], C.c_int),
+    "svk_select_prefix_topk_suffix": ([C.POINTER(SvkSelectTopkArgs), _p], C.c_int),
     "svk_compact_rows": ([C.POINTER(SvkCompactRowsArgs), _p], C.c_int),
     "svk_decode_alloc_slots": ([C.POINTER(SvkDecodeAllocArgs), _p], C.c_int),
     "svk_prefill_score_workspace_bytes": ([_i32, _i32, _i32, _i32, _i32], C.c_int64),

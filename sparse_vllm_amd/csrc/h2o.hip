@@ -162,6 +162,23 @@ __global__ void __launch_bounds__(256) h2o_select_kernel(const SvkH2oSelectArgs 
   block_select_topk_ordered(sc, rs, heavy, scratch, [&](int pos, int idx) { keep[pos] = idx; });
 }
 
+__global__ void __launch_bounds__(256) select_topk_kernel(const SvkSelectTopkArgs a) {
+  __shared__ SelectScratch scratch;
+  const float* sc = a.scores + (int64_t)blockIdx.x * a.score_stride;
+  int64_t* keep = a.keep + (int64_t)blockIdx.x * a.keep_stride;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int mid = a.kv_len - a.suffix - a.prefix;
+  for (int i = tid; i < a.prefix; i += nt) keep[i] = i;
+  for (int i = tid; i < a.suffix; i += nt) keep[a.prefix + a.topk + i] = a.kv_len - a.suffix + i;
+  if (a.topk <= 0) return;
+  if (a.topk >= mid) {
+    for (int i = tid; i < mid; i += nt) keep[a.prefix + i] = a.prefix + i;
+    return;
+  }
+  block_select_topk_ordered(sc + a.prefix, mid, a.topk, scratch,
+                            [&](int pos, int idx) { keep[a.prefix + pos] = a.prefix + idx; });
+}
+
 // ------------------------------------------------------------------------------------
 // slot-table compaction
 // ------------------------------------------------------------------------------------
@@ -308,6 +325,17 @@ extern "C" int svk_h2o_select_indices(const SvkH2oSelectArgs* a, svk_stream_t st
   if (a->rows == 0 || a->kv_len == 0) return SVK_OK;
   hipLaunchKernelGGL(h2o_select_kernel, dim3(a->rows), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   return check_launch("svk_h2o_select_indices");
+}
+
+extern "C" int svk_select_prefix_topk_suffix(const SvkSelectTopkArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_select_prefix_topk_suffix: null args");
+  SVK_REQUIRE(a->prefix >= 0 && a->topk >= 0 && a->suffix >= 0, SVK_ERR_VALUE, "svk_select_prefix_topk_suffix: negative counts");
+  SVK_REQUIRE(a->prefix + a->suffix <= a->kv_len && a->topk <= a->kv_len - a->prefix - a->suffix, SVK_ERR_VALUE,
+              "svk_select_prefix_topk_suffix: prefix %d + topk %d + suffix %d exceeds kv_len %d", a->prefix, a->topk, a->suffix, a->kv_len);
+  if (a->rows <= 0 || a->prefix + a->topk + a->suffix == 0) return SVK_OK;
+  hipLaunchKernelGGL(select_topk_kernel, dim3(a->rows), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_select_prefix_topk_suffix");
 }
 
 extern "C" int svk_compact_rows(const SvkCompactRowsArgs* a, svk_stream_t stream) {

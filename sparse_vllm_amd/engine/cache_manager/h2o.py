@@ -125,6 +125,46 @@ class H2OCacheManager(SnapKVCacheManager):
                 uniform &= kv_len == self._physical_row_len(layer_indices[0], seqs[0])
         return uniform
 
+    # ---- prefill score accumulation (h2o.py:750-894)
+    def prefill_score_ranges(self, layer_idx: int, seqs):
+        """-> [(batch, seq, prompt_cache_len, score_start, score_end)] in compressed physical coordinates."""
+        window = int(self.config.h2o_prefill_score_window)
+        ranges = []
+        for b, seq in enumerate(seqs):
+            chunk_len = int(seq.current_chunk_size)
+            context_len = self._physical_row_len(layer_idx, seq)
+            cache_len = context_len - chunk_len
+            if cache_len < 0:
+                raise RuntimeError("H2O current chunk exceeds its physical row: "
+                                   f"layer={layer_idx} seq_id={seq.seq_id} context={context_len} chunk={chunk_len}.")
+            start = max(cache_len, context_len - window) if window > 0 else cache_len
+            ranges.append((b, seq, cache_len, start, context_len))
+        return ranges
+
+    @torch.no_grad()
+    def collect_prefill_attention_score(self, layer_idx: int, q: torch.Tensor, seqs, *, b_start_loc: torch.Tensor):
+        """cum[:len] = expand(prev, len) + W_eff * step_score (logits mode: softmax of the vector first)."""
+        ranges = self.prefill_score_ranges(layer_idx, seqs)
+        if not ranges:
+            return None
+        d = q.device
+        cache_lens = torch.tensor([r[2] for r in ranges], dtype=torch.int32, device=d)
+        starts = torch.tensor([r[3] for r in ranges], dtype=torch.int32, device=d)
+        ends = torch.tensor([r[4] for r in ranges], dtype=torch.int32, device=d)
+        max_ctx = max(r[4] for r in ranges)
+        step = torch.empty((len(seqs), max_ctx), dtype=torch.float32, device=d)
+        k_cache, _ = self.get_layer_kv_cache(layer_idx)
+        self._run_prefill_score(q, k_cache, step, layer_idx, b_start_loc, cache_lens, max(r[4] - r[3] for r in ranges),
+                                starts, ends, candidate_start=0, num_recent_tokens=0)
+        kv = self.kv_layer_index(layer_idx)
+        for b, seq, cache_len, start, end in ranges:
+            row = self.seq_id_to_row[layer_idx][int(seq.seq_id)]
+            score_row = step[b, :end]
+            if self.config.sparse_prefill_score_mode == "logits":
+                score_row = torch.softmax(score_row.float(), dim=0)          # h2o.py:628-655
+            self.h2o_score_tensor[kv, row, :end].add_(score_row, alpha=float(end - start))
+        return None
+
     # ---- decode burst (h2o.py:1498-1630)
     def _decode_eviction_groups(self, seqs):
         seq_ids = [int(s.seq_id) for s in seqs]
@@ -192,16 +232,25 @@ class H2OCacheManager(SnapKVCacheManager):
         self._evict_decode_rows(seqs)
 
     # ---- prefill-side eviction (h2o.py:1351-1496)
-    def _evict_prefill_uniform(self, seqs, *, final: bool):
-        budget = self.h2o_decode_budget if final else self.h2o_prefill_budget
+    def _evict_prefill(self, seqs):
+        """h2o.py:1351-1480.  Per layer, sequences are visited in batch order (that order fixes the
+        free-stack contents); maximal runs of consecutive sequences with the same finality and the
+        same physical length are selected/compacted in one launch."""
         ratio = float(self.config.h2o_recent_ratio)
         for layer_idx in self.kv_transformer_layer_indices():
-            lens = [self._physical_row_len(layer_idx, s) for s in seqs]
-            groups: dict[int, list] = {}
-            for s, n in zip(seqs, lens):
-                if n > budget:
-                    groups.setdefault(n, []).append(s)
-            for kv_len, group in groups.items():
+            i = 0
+            while i < len(seqs):
+                final = bool(seqs[i].is_last_chunk_prefill)
+                kv_len = self._physical_row_len(layer_idx, seqs[i])
+                j = i + 1
+                while (j < len(seqs) and bool(seqs[j].is_last_chunk_prefill) == final
+                       and self._physical_row_len(layer_idx, seqs[j]) == kv_len):
+                    j += 1
+                group = seqs[i:j]
+                i = j
+                budget = self.h2o_decode_budget if final else self.h2o_prefill_budget
+                if kv_len <= budget:
+                    continue
                 rows = np.array([[self.seq_id_to_row[layer_idx][int(s.seq_id)] for s in group]])
                 rows_gpu = torch.from_numpy(rows[0]).to(self.device)
                 scores = self.h2o_score_tensor[self.kv_layer_index(layer_idx), rows_gpu, :kv_len]
@@ -215,12 +264,8 @@ class H2OCacheManager(SnapKVCacheManager):
                 self._h2o_counters["dropped_tokens"] += (kv_len - budget) * len(group)
 
     def evict_after_prefill(self, seqs):
+        self._evict_prefill(seqs)
         finals = [s for s in seqs if bool(s.is_last_chunk_prefill)]
-        inter = [s for s in seqs if not bool(s.is_last_chunk_prefill)]
-        if inter:
-            self._evict_prefill_uniform(inter, final=False)
-        if finals:
-            self._evict_prefill_uniform(finals, final=True)
         for layer_idx in self.kv_transformer_layer_indices():
             for s in finals:
                 kv_len = self._physical_row_len(layer_idx, s)

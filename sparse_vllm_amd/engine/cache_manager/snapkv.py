@@ -29,6 +29,8 @@ class SnapKVCacheManager(CacheManager):
     def __init__(self, config, parallel_context=None):
         super().__init__(config, parallel_context)
         self._uniform_decode_metadata = False
+        self._prefill_attn_score_accumulators: dict[tuple[int, int], torch.Tensor] = {}
+        self._prefill_score_workspace = None
         self.allocate_kv_cache()
 
     # ------------------------------------------------------------------ allocation
@@ -138,6 +140,98 @@ class SnapKVCacheManager(CacheManager):
             st.max_context_len = max(ctx) if ctx else 0
         cu = np.concatenate(([0], np.cumsum(chunk_lens))).astype(np.int32)
         return torch.from_numpy(cu).to(d), total
+
+    # ------------------------------------------------------------------ prefill token scores (SnapKV)
+    def _prefill_score_layer_budget(self, layer_idx: int) -> int | None:
+        """snapkv.py:920-933."""
+        if self.kv_layer_index(layer_idx) < int(getattr(self.config, "snapkv_num_full_layers", 0) or 0):
+            return None
+        if self.config.vllm_sparse_method == "snapkv":
+            return int(self.config.num_sink_tokens) + int(self.config.decode_keep_tokens) + int(self.config.num_recent_tokens)
+        return None
+
+    def _prefill_score_rows(self, layer_idx: int, seqs) -> list[tuple[int, object, int, int]]:
+        """snapkv.py:935-1009 (without chain-resume): the window = last `snapkv_window_size` prompt
+        tokens must sit inside the current chunk; rows whose prompt fits the budget are skipped."""
+        budget = self._prefill_score_layer_budget(layer_idx)
+        if budget is None:
+            return []
+        window = int(getattr(self.config, "snapkv_window_size", 0) or 0)
+        if window <= 0:
+            return []
+        rows = []
+        for b_idx, seq in enumerate(seqs):
+            prompt_len = int(seq.num_prompt_tokens)
+            if prompt_len <= budget:
+                continue
+            score_end = prompt_len
+            score_start = max(0, score_end - min(window, prompt_len))
+            chunk_start = int(seq.num_prefilled_tokens)
+            chunk_end = chunk_start + int(seq.current_chunk_size)
+            if chunk_start <= score_start and chunk_end >= score_end:
+                rows.append((b_idx, seq, score_start, score_end))
+            elif seq.is_last_chunk_prefill and chunk_start < score_end and chunk_end > score_start:
+                raise RuntimeError("SnapKV/PyramidKV prefill score requires the score query window to fit in the final "
+                                   f"prefill chunk. layer={layer_idx} seq_id={seq.seq_id} score_range=[{score_start}, {score_end}) "
+                                   f"chunk_range=[{chunk_start}, {chunk_end}).")
+        return rows
+
+    def _prefill_score_initial_value(self) -> float:
+        return float("-inf") if getattr(self.config, "sparse_prefill_score_mode", "probability") == "logits" else 0.0
+
+    def _run_prefill_score(self, q, k_cache, step_score, layer_idx, b_start_loc, b_prompt_cache_len, max_score_len,
+                           score_starts, score_ends, *, candidate_start: int, num_recent_tokens: int, batch_indices=None):
+        """snapkv.py:1050-1085 -> svk_prefill_score."""
+        from ...kernels.prefill_score import PrefillScoreWorkspace, prefill_score_fwd
+        if self._prefill_score_workspace is None:
+            self._prefill_score_workspace = PrefillScoreWorkspace()
+        st = self.layer_batch_states[layer_idx]
+        prefill_score_fwd(q, k_cache, step_score, st.req_indices, b_start_loc, st.context_lens, b_prompt_cache_len,
+                          int(max_score_len), self.get_layer_buffer_req_to_token_slots(layer_idx), score_starts, score_ends,
+                          candidate_start=candidate_start, num_recent_tokens=num_recent_tokens,
+                          score_mode=self.config.sparse_prefill_score_mode, workspace=self._prefill_score_workspace,
+                          batch_indices=batch_indices)
+
+    @torch.no_grad()
+    def collect_prefill_attention_score(self, layer_idx: int, q: torch.Tensor, seqs, *, b_start_loc: torch.Tensor):
+        """snapkv.py:1216-1304: score the row with the last-window queries of the final chunk
+        (candidates [sink, len - recent)), max-accumulate per (layer, sequence)."""
+        if self.config.vllm_sparse_method != "snapkv":
+            return None
+        rows = self._prefill_score_rows(layer_idx, seqs)
+        if not rows:
+            return None
+        d = q.device
+        st = self.layer_batch_states[layer_idx]
+        ctx = [int(self.row_seq_lens[layer_idx][self.seq_id_to_row[layer_idx][s.seq_id]]) for s in seqs]
+        cache_lens = torch.tensor([c - int(s.current_chunk_size) for c, s in zip(ctx, seqs)], dtype=torch.int32, device=d)
+        bi = torch.tensor([r[0] for r in rows], dtype=torch.int32, device=d)
+        starts = torch.tensor([r[2] for r in rows], dtype=torch.int32, device=d)
+        ends = torch.tensor([r[3] for r in rows], dtype=torch.int32, device=d)
+        max_ctx = max(ctx[r[0]] for r in rows)
+        step = torch.empty((len(rows), max_ctx), dtype=torch.float32, device=d)
+        k_cache, _ = self.get_layer_kv_cache(layer_idx)
+        self._run_prefill_score(q, k_cache, step, layer_idx, b_start_loc, cache_lens, max(r[3] - r[2] for r in rows),
+                                starts, ends, candidate_start=int(self.config.num_sink_tokens),
+                                num_recent_tokens=int(self.config.num_recent_tokens), batch_indices=bi)
+        for i, (b_idx, seq, _s, _e) in enumerate(rows):
+            n = ctx[b_idx]
+            key = (int(layer_idx), int(seq.seq_id))
+            if int(seq.num_prefilled_tokens) == 0:
+                self._prefill_attn_score_accumulators.pop(key, None)
+            acc = self._prefill_attn_score_accumulators.get(key)
+            if acc is None:
+                acc = torch.full((n,), self._prefill_score_initial_value(), dtype=torch.float32, device=d)
+                self._prefill_attn_score_accumulators[key] = acc
+            torch.maximum(acc[:n], step[i, :n], out=acc[:n])
+        return None
+
+    def pop_prefill_attention_score(self, layer_idx: int, seq):
+        return self._prefill_attn_score_accumulators.pop((int(layer_idx), int(seq.seq_id)), None)
+
+    def decode_kv_lens_for_layer(self, layer_idx: int, seqs) -> list[int]:
+        """snapkv.py:1516-1527."""
+        return [int(self.row_seq_lens[layer_idx][self._row_of(layer_idx, s)]) for s in seqs]
 
     # ------------------------------------------------------------------ decode-side allocation
     def _get_decode_static_buffers(self, graph_batch_size: int):

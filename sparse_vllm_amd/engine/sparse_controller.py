@@ -37,7 +37,9 @@ class SparseController:
         self.device = cache_manager.device
         self.num_sink = int(config.num_sink_tokens)
         self.num_recent = int(config.num_recent_tokens)
+        self.decode_keep_tokens = int(config.decode_keep_tokens)
         self.attn_softmax_scale = float(config.head_dim) ** -0.5          # sparse_controller.py:98
+        self._snapkv_decode_reduced_attn_score_buffers: dict[int, torch.Tensor] = {}
         self.snapkv_decode_score_dtype = torch.float32
         self.validate_runtime_invariants = bool(getattr(config, "validate_runtime_invariants", False))
         self.layer_batch_sparse_states = [LayerBatchSparseState() for _ in range(self.num_layers)]
@@ -55,7 +57,63 @@ class SparseController:
         """sparse_controller.py:1963-2034 (h2o: every KV layer in decode, none in prefill)."""
         if self.sparse_method == "h2o":
             return (not is_prefill) and self._is_kv_layer(layer_idx)
+        if self.sparse_method == "snapkv":
+            if is_prefill:
+                return False
+            budget = self._get_layer_budget(layer_idx, is_prefill=False)
+            if budget is None:
+                return False
+            trigger_len = self._snapkv_decode_trigger_len(budget)
+            # eager decode only collects scores on the step that is about to evict (:2003-2007)
+            kv_lens = self.cache_manager.decode_kv_lens_for_layer(layer_idx, seqs)
+            return any(int(n) >= trigger_len and int(n) > budget for n in kv_lens)
         return False
+
+    def _get_layer_budget(self, layer_idx: int, is_prefill: bool) -> int | None:
+        """sparse_controller.py:2036-2048 (snapkv branch)."""
+        if self.cache_manager.kv_layer_index(layer_idx) < int(getattr(self.config, "snapkv_num_full_layers", 0) or 0):
+            return None
+        if self.sparse_method == "snapkv":
+            return self.num_sink + self.decode_keep_tokens + self.num_recent
+        return None
+
+    def _snapkv_decode_trigger_len(self, budget: int) -> int:
+        """sparse_controller.py:2050-2054."""
+        return int(2.0 * (int(budget) - self.num_sink - self.num_recent))
+
+    def _get_snapkv_decode_score_buffer(self, layer_idx: int, batch_size: int, max_len: int, *, fill_value: float):
+        """sparse_controller.py:691-721."""
+        buf = self._snapkv_decode_reduced_attn_score_buffers.get(int(layer_idx))
+        if buf is None or buf.shape[0] < batch_size or buf.shape[1] < max_len:
+            buf = torch.empty((batch_size, max_len), dtype=torch.float32, device=self.device)
+            self._snapkv_decode_reduced_attn_score_buffers[int(layer_idx)] = buf
+        view = buf[:batch_size, :max_len]
+        view.fill_(fill_value)
+        return view
+
+    def _snapkv_select_indices_batch(self, scores: torch.Tensor, kv_len: int, budget: int, *, pool_kernel_size: int = 1):
+        """sparse_controller.py:1707-1747 on device: sink ++ topk(middle) ++ recent (ascending; the
+        reference's order is unspecified and free_part_slots sorts)."""
+        if scores.dim() != 2:
+            raise ValueError(f"Expected batched SnapKV scores with shape [B, L], got {tuple(scores.shape)}.")
+        assert kv_len > budget
+        if int(scores.shape[1]) < int(kv_len):
+            raise ValueError(f"SnapKV batched scores are shorter than kv_len: scores={tuple(scores.shape)} kv_len={kv_len}.")
+        recent_start = kv_len - self.num_recent
+        num_topk = budget - self.num_sink - self.num_recent
+        if not (num_topk > 0 and recent_start > self.num_sink):
+            num_topk = 0
+        if int(pool_kernel_size) > 1 and num_topk > 0:
+            mid = torch.nn.functional.max_pool1d(scores[:, None, self.num_sink:recent_start], kernel_size=int(pool_kernel_size),
+                                                 padding=int(pool_kernel_size) // 2, stride=1).squeeze(1)
+            scores = torch.cat((scores[:, : self.num_sink], mid[:, : recent_start - self.num_sink], scores[:, recent_start:kv_len]), 1)
+        scores = scores.float().contiguous() if scores.stride(1) != 1 or scores.dtype != torch.float32 else scores
+        return h2o_ops.select_prefix_topk_suffix(scores, kv_len=kv_len, prefix=self.num_sink,
+                                                 topk=min(num_topk, max(0, recent_start - self.num_sink)),
+                                                 suffix=self.num_recent)
+
+    def _snapkv_select_indices(self, scores: torch.Tensor, kv_len: int, budget: int, *, pool_kernel_size: int = 1):
+        return self._snapkv_select_indices_batch(scores[None, :kv_len], kv_len, budget, pool_kernel_size=pool_kernel_size)[0]
 
     # ------------------------------------------------------------------ prepare
     def prepare_forward(self, seqs, is_prefill: bool):
@@ -67,6 +125,12 @@ class SparseController:
             s.attn_score = None
         if not is_prefill and self.sparse_method == "h2o":
             self._prepare_h2o_decode_attn_score_buffer(seqs)
+        if not is_prefill and self.sparse_method == "snapkv":
+            for layer_idx in range(self.num_layers):
+                if self._needs_attn_score(layer_idx, False, seqs):
+                    s = self.layer_batch_sparse_states[layer_idx]
+                    s.attn_score = self._get_snapkv_decode_score_buffer(
+                        layer_idx, int(s.context_lens.numel()), int(s.max_context_len), fill_value=-1e20)
 
     def _h2o_decode_score_width(self, layer_indices) -> int:
         """sparse_controller.py:401-425."""
@@ -157,11 +221,79 @@ class SparseController:
                 self.cache_manager.evict_after_prefill(seqs)
             elif self.sparse_method == "streamingllm":
                 self._streamingllm_prefill_eviction(seqs)
+            elif self.sparse_method == "snapkv":
+                self._snapkv_prefill_eviction(seqs)
             return
         if self.sparse_method == "h2o":
             self._h2o_decode_eviction(seqs)
         elif self.sparse_method == "streamingllm":
             self._streamingllm_decode_eviction(seqs)
+        elif self.sparse_method == "snapkv":
+            self._snapkv_decode_eviction(seqs)
+
+    # ------------------------------------------------------------------ SnapKV
+    @torch.no_grad()
+    def _snapkv_prefill_eviction(self, seqs):
+        """sparse_controller.py:1059-1102: at the final chunk keep sink ++ topk ++ recent."""
+        cm = self.cache_manager
+        for layer_idx in range(self.num_layers):
+            if not self._is_kv_layer(layer_idx):
+                continue
+            budget = self._get_layer_budget(layer_idx, is_prefill=True)
+            if budget is None:
+                continue
+            for seq in seqs:
+                if not seq.is_last_chunk_prefill:
+                    continue
+                kv_len = int(seq.num_prefilled_tokens) + int(seq.current_chunk_size)
+                if kv_len <= budget:
+                    continue
+                seq_scores = cm.pop_prefill_attention_score(layer_idx, seq)
+                if seq_scores is None:
+                    raise RuntimeError("SnapKV/PyramidKV prefill eviction requires prefill attention scores. "
+                                       f"method={self.sparse_method} layer={layer_idx} seq_id={seq.seq_id}")
+                keep = self._snapkv_select_indices(seq_scores[:kv_len], kv_len, budget,
+                                                   pool_kernel_size=int(getattr(self.config, "snapkv_pooling_kernel_size", 1) or 1))
+                cm.free_part_slots(layer_idx, seq, keep, keep_indices_sorted=True)
+
+    @torch.no_grad()
+    def _snapkv_decode_eviction(self, seqs):
+        """sparse_controller.py:1104-1223: when a row reaches 2 x top budget, re-select on this step's
+        head-max raw decode scores; equal-length rows are compacted across layers in one launch."""
+        cm = self.cache_manager
+        with profiler.record("snapkv_decode_eviction"):
+            pending: dict[tuple, list] = {}
+            for layer_idx in range(self.num_layers):
+                if not self._is_kv_layer(layer_idx):
+                    continue
+                scores = self.layer_batch_sparse_states[layer_idx].attn_score
+                if scores is None:
+                    continue
+                budget = self._get_layer_budget(layer_idx, is_prefill=False)
+                if budget is None:
+                    continue
+                trigger_len = self._snapkv_decode_trigger_len(budget)
+                kv_lens = cm.decode_kv_lens_for_layer(layer_idx, seqs)
+                by_len: dict[int, list] = {}
+                for b, (seq, n) in enumerate(zip(seqs, kv_lens)):
+                    if n <= budget or n < trigger_len:
+                        continue
+                    by_len.setdefault(int(n), []).append((b, seq))
+                if by_len and scores.dim() != 2:
+                    raise RuntimeError("SnapKV/PyramidKV post-forward eviction requires head-reduced [B, L] scores: "
+                                       f"layer={layer_idx} shape={tuple(scores.shape)}.")
+                for kv_len, group in by_len.items():
+                    idx = torch.tensor([b for b, _ in group], dtype=torch.long, device=scores.device)
+                    with profiler.record("snapkv_decode_select"):
+                        keep = self._snapkv_select_indices_batch(scores.index_select(0, idx)[:, :kv_len].contiguous(),
+                                                                 kv_len, budget)
+                    key = (tuple(int(s.seq_id) for _, s in group), tuple(keep.shape))
+                    pending.setdefault(key, []).append((layer_idx, [s for _, s in group], keep))
+            for entries in pending.values():
+                layers = [e[0] for e in entries]
+                with profiler.record("snapkv_decode_compact_layers"):
+                    cm.free_part_slots_batch_layers(layers, entries[0][1], torch.stack([e[2] for e in entries]),
+                                                    keep_indices_sorted=True)
 
     def _h2o_decode_eviction(self, seqs):
         """sparse_controller.py:1226-1282: scores are already accumulated (fused), evict."""

@@ -94,6 +94,23 @@ def select_h2o_indices_batch(scores: torch.Tensor, *, budget: int, recent_ratio:
     return out
 
 
+def select_prefix_topk_suffix(scores: torch.Tensor, *, kv_len: int, prefix: int, topk: int, suffix: int,
+                              out: torch.Tensor | None = None) -> torch.Tensor:
+    """[0,prefix) ++ top-`topk` of scores[:, prefix:kv_len-suffix] ++ [kv_len-suffix, kv_len), ascending int64."""
+    assert scores.dim() == 2 and scores.dtype == torch.float32 and scores.stride(1) == 1 and scores.shape[1] >= kv_len
+    rows = scores.shape[0]
+    n = prefix + topk + suffix
+    if out is None:
+        out = torch.empty((rows, n), dtype=torch.long, device=scores.device)
+    assert out.dtype == torch.long and tuple(out.shape) == (rows, n) and out.stride(1) == 1
+    lib = _lib.load()
+    a = _lib.SvkSelectTopkArgs(scores=_lib.ptr(scores), keep=_lib.ptr(out), score_stride=scores.stride(0),
+                               keep_stride=out.stride(0), rows=rows, kv_len=int(kv_len), prefix=int(prefix),
+                               topk=int(topk), suffix=int(suffix))
+    _lib.check(lib.svk_select_prefix_topk_suffix(C.byref(a), _lib.current_stream_handle()), lib)
+    return out
+
+
 def compact_rows(slot_table: torch.Tensor, free_stack: torch.Tensor, keep: torch.Tensor, layer_ids: torch.Tensor,
                  row_ids: torch.Tensor, free_base: torch.Tensor, *, cur_len: int,
                  row_payload: torch.Tensor | None = None):
