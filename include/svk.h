@@ -398,6 +398,113 @@ typedef struct SvkQuestDecodeAllocArgs {
 } SvkQuestDecodeAllocArgs;
 int svk_quest_decode_alloc(const SvkQuestDecodeAllocArgs* a, svk_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * DeltaKV: compressed-KV decode
+ * ---------------------------------------------------------------------------------- */
+
+#define SVK_DTYPE_F32 0
+#define SVK_DTYPE_BF16 1
+#define SVK_DTYPE_F16 2
+
+/* Sparse-layer view + reconstruct work list of one decode step:
+ *   row b = [sink raw slots | for j < min(clen,K): temp slot if the selected compressed position has a
+ *            latent else its raw slot | up to max_buffer recent raw slots], padding = first sink slot;
+ *   recon_{pos,latent,out_slot}[b*K + j] = work item or -1;  new_context_lens = sink + min(clen,K) + buf.
+ * Bit-exact restatement of deltakv_static_decode_plan, kernels/triton/deltakv_kernels.py:3854-3942
+ * (kernel :3695-3851). */
+typedef struct SvkDeltakvPlanArgs {
+  const int32_t* raw_slots_map;      /* [rows, max_positions]                     */
+  const int32_t* latent_slots_map;   /* [rows, max_positions]                     */
+  const int32_t* active_compressed;  /* [B, K] relative compressed positions      */
+  const int32_t* req_indices;        /* [B]                                       */
+  const int32_t* context_lens;       /* [B]                                       */
+  const int32_t* compressed_lens;    /* [B]                                       */
+  const int32_t* temp_slots;         /* [B, K]                                    */
+  int32_t* active_slots_out;         /* [B, sink+K+max_buffer]                    */
+  int32_t* active_pos_out;           /* [B, sink+K+max_buffer]                    */
+  int32_t* new_context_lens_out;     /* [B]                                       */
+  int32_t* recon_pos_out;            /* [B*K]                                     */
+  int32_t* recon_latent_out;         /* [B*K]                                     */
+  int32_t* recon_out_slot_out;       /* [B*K]                                     */
+  int64_t raw_stride, latent_stride, active_stride, temp_stride, out_stride, pos_stride;
+  int32_t batch, k_max, sink, max_buffer, max_positions;
+} SvkDeltakvPlanArgs;
+int svk_deltakv_static_decode_plan(const SvkDeltakvPlanArgs* a, svk_stream_t stream);
+
+/* Reconstruct compressed tokens into temp slots:
+ *   K = delta_K + mean_f(de-RoPE(father K)), optional RMS k-norm, RoPE(out_pos);  V = delta_V + mean_f(father V)
+ * delta is either dense [N, 2*Hkv*D] (delta_bits = 0; entry valid iff out_slot >= 0 and out_pos >= 0) or a
+ * packed int2/int4/int8 residual + per-group scale/min looked up by latent_slots (entry valid iff latent >= 0).
+ * Replaces deltakv_reconstruct_writeback_grouped_heads, deltakv_kernels.py:2909-3012 (kernel :2732-2907) and
+ * deltakv_less_memory_reconstruct_writeback_quantized / _int4, :3344-3485 (kernel :3173-3341). */
+typedef struct SvkDeltakvReconstructArgs {
+  const void* delta;               /* dense: [N, 2*Hkv*D] (delta_dtype); packed: int32 [latents, 2*Hkv*D*bits/32] */
+  const void* scale;               /* packed: [latents, groups] (scale_dtype)                                    */
+  const void* mn;                  /* packed: [latents, groups]                                                  */
+  const int32_t* latent_slots;     /* packed: [N]                                                                */
+  const int32_t* father_slots;     /* [N, K]                                                                     */
+  const int32_t* slot_to_pos;      /* [slots]                                                                    */
+  const int32_t* out_slots;        /* [N]                                                                        */
+  const int32_t* out_pos;          /* [N]                                                                        */
+  const void* cos_sin;             /* [max_pos, D]: cos | sin halves (cos_dtype)                                 */
+  uint16_t* k_cache;               /* [slots, Hkv, D] bf16, read (fathers) and written (out slots)               */
+  uint16_t* v_cache;
+  const float* k_norm_weight;      /* NULL or [D] f32                                                            */
+  int64_t delta_stride, scale_stride, father_stride, cos_stride, kv_slot_stride, kv_head_stride;
+  float k_norm_eps;
+  int32_t n, k_fathers, num_kv_heads, head_dim;
+  int32_t delta_bits;              /* 0 dense, else 2 / 4 / 8                                                    */
+  int32_t group_size;              /* packed: features per scale/min group                                       */
+  int32_t delta_dtype, scale_dtype, cos_dtype;   /* SVK_DTYPE_*                                                  */
+  int32_t raw_k_cache;             /* fathers hold un-rotated K                                                  */
+  int32_t store_raw_k;             /* write un-rotated K                                                         */
+} SvkDeltakvReconstructArgs;
+int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs* a, svk_stream_t stream);
+
+/* out[r, f] = code(r, f) * scale[r, f/group] + mn[r, f/group]; codes are `bits`-wide fields packed
+ * LSB-first into int32.  Replaces triton_dequantize_2d_int4_grouped (kernels/triton/quant.py:160-216) and
+ * unpack_tensor + unpack_quantized_to_16bit (:304-349). */
+typedef struct SvkDequantGroupedArgs {
+  const int32_t* packed;  /* [rows, features*bits/32] */
+  const void* scale;      /* [rows, features/group]   */
+  const void* mn;
+  void* out;              /* [rows, features]         */
+  int64_t packed_stride, scale_stride, out_stride;
+  int32_t rows, features, bits, group_size;
+  int32_t scale_dtype, out_dtype;
+} SvkDequantGroupedArgs;
+int svk_dequantize_grouped(const SvkDequantGroupedArgs* a, svk_stream_t stream);
+
+/* Observation-layer token scores for the query-aware top-k:
+ *   s[b, t] = max_h softmax_{t in [start, start+len_b)} (raw[b,h,t] * scale), cast to `round_dtype`,
+ *   everything outside the candidate range = fill_value.
+ * Replaces SparseController._decode_softmax_token_scores, engine/sparse_controller.py:255-299. */
+typedef struct SvkDeltakvTokenScoresArgs {
+  const float* raw_scores;        /* [B, H, L] f32 (3-D output of stage 1)        */
+  const int32_t* candidate_lens;  /* [B]                                          */
+  float* token_scores;            /* [B, L] f32 out                               */
+  float* workspace;               /* [B, H, 2] f32 (per-head max / sum)           */
+  int64_t raw_stride_b, raw_stride_h, out_stride;
+  float scale, fill_value;
+  int32_t batch, num_heads, length, candidate_start;
+  int32_t round_dtype;            /* SVK_DTYPE_*: F32 = no rounding               */
+} SvkDeltakvTokenScoresArgs;
+int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_stream_t stream);
+
+/* idx[r, :k] = indices of the k largest of scores[r, :n] ordered by (score desc, index asc) -
+ * `topk(k, sorted=True)` with a deterministic tie rule (the reference adds a position key to get one,
+ * sparse_controller.py:1797-1811).  Entries at index >= valid_len[r] compare as `masked_value`.
+ * Replaces the DeltaKV branch of _update_dynamic_omnikv_indices, sparse_controller.py:1790-1822. k <= 4096. */
+typedef struct SvkTopkSortedArgs {
+  const float* scores;        /* [rows, score_stride]            */
+  const int32_t* valid_len;   /* NULL or [rows]                  */
+  int32_t* indices;           /* [rows, index_stride] int32 out  */
+  int64_t score_stride, index_stride;
+  float masked_value;
+  int32_t rows, n, k;
+} SvkTopkSortedArgs;
+int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, svk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

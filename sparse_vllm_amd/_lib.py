@@ -28,6 +28,8 @@ SVK_ABI_VERSION = 3
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
 
+SVK_DTYPE_F32, SVK_DTYPE_BF16, SVK_DTYPE_F16 = 0, 1, 2
+
 _p = C.c_void_p
 _i64 = C.c_int64
 _i32 = C.c_int32
@@ -138,6 +140,47 @@ class SvkPrefillScoreArgs(C.Structure):
                 ("num_recent_tokens", _i32), ("score_mode", _i32)]
 
 
+class SvkDeltakvPlanArgs(C.Structure):
+    _fields_ = [("raw_slots_map", _p), ("latent_slots_map", _p), ("active_compressed", _p), ("req_indices", _p),
+                ("context_lens", _p), ("compressed_lens", _p), ("temp_slots", _p), ("active_slots_out", _p),
+                ("active_pos_out", _p), ("new_context_lens_out", _p), ("recon_pos_out", _p), ("recon_latent_out", _p),
+                ("recon_out_slot_out", _p),
+                ("raw_stride", _i64), ("latent_stride", _i64), ("active_stride", _i64), ("temp_stride", _i64),
+                ("out_stride", _i64), ("pos_stride", _i64),
+                ("batch", _i32), ("k_max", _i32), ("sink", _i32), ("max_buffer", _i32), ("max_positions", _i32)]
+
+
+class SvkDeltakvReconstructArgs(C.Structure):
+    _fields_ = [("delta", _p), ("scale", _p), ("mn", _p), ("latent_slots", _p), ("father_slots", _p),
+                ("slot_to_pos", _p), ("out_slots", _p), ("out_pos", _p), ("cos_sin", _p), ("k_cache", _p),
+                ("v_cache", _p), ("k_norm_weight", _p),
+                ("delta_stride", _i64), ("scale_stride", _i64), ("father_stride", _i64), ("cos_stride", _i64),
+                ("kv_slot_stride", _i64), ("kv_head_stride", _i64),
+                ("k_norm_eps", _f32), ("n", _i32), ("k_fathers", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
+                ("delta_bits", _i32), ("group_size", _i32), ("delta_dtype", _i32), ("scale_dtype", _i32),
+                ("cos_dtype", _i32), ("raw_k_cache", _i32), ("store_raw_k", _i32)]
+
+
+class SvkDequantGroupedArgs(C.Structure):
+    _fields_ = [("packed", _p), ("scale", _p), ("mn", _p), ("out", _p),
+                ("packed_stride", _i64), ("scale_stride", _i64), ("out_stride", _i64),
+                ("rows", _i32), ("features", _i32), ("bits", _i32), ("group_size", _i32),
+                ("scale_dtype", _i32), ("out_dtype", _i32)]
+
+
+class SvkDeltakvTokenScoresArgs(C.Structure):
+    _fields_ = [("raw_scores", _p), ("candidate_lens", _p), ("token_scores", _p), ("workspace", _p),
+                ("raw_stride_b", _i64), ("raw_stride_h", _i64), ("out_stride", _i64),
+                ("scale", _f32), ("fill_value", _f32),
+                ("batch", _i32), ("num_heads", _i32), ("length", _i32), ("candidate_start", _i32),
+                ("round_dtype", _i32)]
+
+
+class SvkTopkSortedArgs(C.Structure):
+    _fields_ = [("scores", _p), ("valid_len", _p), ("indices", _p), ("score_stride", _i64), ("index_stride", _i64),
+                ("masked_value", _f32), ("rows", _i32), ("n", _i32), ("k", _i32)]
+
+
 # symbol -> (argtypes) ; every entry point declared in include/svk.h
 ENTRY_POINTS = {
     "svk_abi_version": ([], C.c_int),
@@ -155,6 +198,11 @@ ENTRY_POINTS = {
     "svk_decode_alloc_slots": ([C.POINTER(SvkDecodeAllocArgs), _p], C.c_int),
     "svk_prefill_score_workspace_bytes": ([_i32, _i32, _i32, _i32, _i32], C.c_int64),
     "svk_prefill_score": ([C.POINTER(SvkPrefillScoreArgs), _p], C.c_int),
+    "svk_deltakv_static_decode_plan": ([C.POINTER(SvkDeltakvPlanArgs), _p], C.c_int),
+    "svk_deltakv_reconstruct_writeback": ([C.POINTER(SvkDeltakvReconstructArgs), _p], C.c_int),
+    "svk_dequantize_grouped": ([C.POINTER(SvkDequantGroupedArgs), _p], C.c_int),
+    "svk_deltakv_token_scores": ([C.POINTER(SvkDeltakvTokenScoresArgs), _p], C.c_int),
+    "svk_topk_sorted_desc": ([C.POINTER(SvkTopkSortedArgs), _p], C.c_int),
     "svk_quest_page_minmax": ([C.POINTER(SvkQuestPageMinmaxArgs), _p], C.c_int),
     "svk_quest_score_pages": ([C.POINTER(SvkQuestScorePagesArgs), _p], C.c_int),
     "svk_quest_build_view": ([C.POINTER(SvkQuestBuildViewArgs), _p], C.c_int),

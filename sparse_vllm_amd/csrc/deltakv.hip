@@ -1,0 +1,395 @@
+// DeltaKV decode-side kernels for gfx950: static decode plan, residual (de)quantisation, father-mean
+// reconstruct with RoPE write-back, observation-layer token scores and sorted top-k.
+// All HBM/L2-bound integer / byte / elementwise work; no matrix cores.
+
+#include "svk_common.hpp"
+#include "svk_select.hpp"
+
+namespace svk {
+namespace {
+
+__device__ __forceinline__ float load_scalar(const void* p, int64_t i, int dtype) {
+  if (dtype == SVK_DTYPE_F32) return reinterpret_cast<const float*>(p)[i];
+  const uint16_t h = reinterpret_cast<const uint16_t*>(p)[i];
+  if (dtype == SVK_DTYPE_BF16) return __builtin_bit_cast(float, (uint32_t)h << 16);
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+
+// ------------------------------------------------------------------------------------
+// static decode plan (one workgroup per batch lane)
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) deltakv_plan_kernel(const SvkDeltakvPlanArgs a) {
+  const int b = blockIdx.x;
+  const int K = a.k_max, SINK = a.sink;
+  const int S = SINK + K + a.max_buffer;
+  const int max_pos = a.max_positions - 1;
+  const int row = a.req_indices[b];
+  const int ctx = a.context_lens[b];
+  const int clen = a.compressed_lens[b];
+  const int top_len = min(max(clen, 0), K);
+  const int32_t* raw = a.raw_slots_map + (int64_t)row * a.raw_stride;
+  const int32_t* lat = a.latent_slots_map + (int64_t)row * a.latent_stride;
+  const int safe = SINK > 0 ? max(raw[0], 0) : 0;
+  const int buf_start = SINK + clen;
+  const int buf_len = min(max(ctx - buf_start, 0), a.max_buffer);
+  const int start_out = SINK + top_len;
+  for (int c = threadIdx.x; c < S; c += blockDim.x) {
+    int o_slot = safe, o_pos = 0;
+    if (c < SINK) {
+      const int sp = min(c, max_pos);
+      o_slot = raw[sp];
+      o_pos = sp;
+    }
+    if (c >= SINK && c < SINK + K) {
+      const int j = c - SINK;
+      const bool in_top = j < top_len;
+      int rel = -1;
+      if (true) rel = a.active_compressed[(int64_t)b * a.active_stride + j];
+      const int top_pos = rel + SINK;
+      const bool valid = in_top && rel >= 0 && rel < clen && top_pos < ctx;
+      const int sp = min(max(top_pos, 0), max_pos);
+      const int r = in_top ? raw[sp] : 0;
+      const int l = in_top ? lat[sp] : -1;
+      const int t = in_top ? a.temp_slots[(int64_t)b * a.temp_stride + j] : 0;
+      const bool need = valid && l >= 0;
+      if (in_top) {
+        o_slot = need ? t : (valid ? max(r, 0) : safe);
+        o_pos = valid ? top_pos : 0;
+      }
+      a.recon_pos_out[b * K + j] = need ? top_pos : -1;
+      a.recon_latent_out[b * K + j] = need ? l : -1;
+      a.recon_out_slot_out[b * K + j] = need ? t : -1;
+    }
+    if (c >= start_out) {           // recent buffer, compacted right after the visible top slots
+      const int j = c - start_out;
+      const int pos = min(max(buf_start + j, 0), max_pos);
+      const bool ok = j < buf_len;
+      o_slot = ok ? max(raw[pos], 0) : safe;
+      o_pos = ok ? pos : 0;
+    }
+    a.active_slots_out[(int64_t)b * a.out_stride + c] = o_slot;
+    a.active_pos_out[(int64_t)b * a.pos_stride + c] = o_pos;
+  }
+  if (threadIdx.x == 0) a.new_context_lens_out[b] = SINK + top_len + buf_len;
+}
+
+// ------------------------------------------------------------------------------------
+// grouped dequantisation
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) dequant_grouped_kernel(const SvkDequantGroupedArgs a) {
+  const int r = blockIdx.y;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= a.features) return;
+  const int fpi = 32 / a.bits;
+  const uint32_t word = (uint32_t)a.packed[(int64_t)r * a.packed_stride + f / fpi];
+  const float q = (float)((word >> ((f % fpi) * a.bits)) & ((1u << a.bits) - 1u));
+  const int g = f / a.group_size;
+  // two roundings (q*scale, then +min) like the un-fused reference arithmetic the fixtures pin
+  const float v = add_rn(mul_rn(q, load_scalar(a.scale, (int64_t)r * a.scale_stride + g, a.scale_dtype)),
+                            load_scalar(a.mn, (int64_t)r * a.scale_stride + g, a.scale_dtype));
+  if (a.out_dtype == SVK_DTYPE_F32) reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + f] = v;
+  else if (a.out_dtype == SVK_DTYPE_BF16) reinterpret_cast<uint16_t*>(a.out)[(int64_t)r * a.out_stride + f] = (uint16_t)f32_to_bf16_bits(v);
+  else reinterpret_cast<_Float16*>(a.out)[(int64_t)r * a.out_stride + f] = (_Float16)v;
+}
+
+// ------------------------------------------------------------------------------------
+// reconstruct + RoPE write-back.  One thread = (entry, kv head, pair p) -> elements p and p + D/2
+// (the rotate-half partner); the D/2 threads of a head are consecutive lanes, so every father row
+// segment is read as two fully coalesced D-byte runs.
+// ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float delta_at(const SvkDeltakvReconstructArgs& a, int n, int latent, int feat) {
+  if (a.delta_bits == 0) return load_scalar(a.delta, (int64_t)n * a.delta_stride + feat, a.delta_dtype);
+  const int fpi = 32 / a.delta_bits;
+  const uint32_t word = (uint32_t)reinterpret_cast<const int32_t*>(a.delta)[(int64_t)latent * a.delta_stride + feat / fpi];
+  const float q = (float)((word >> ((feat % fpi) * a.delta_bits)) & ((1u << a.delta_bits) - 1u));
+  const int g = feat / a.group_size;
+  return q * load_scalar(a.scale, (int64_t)latent * a.scale_stride + g, a.scale_dtype) +
+         load_scalar(a.mn, (int64_t)latent * a.scale_stride + g, a.scale_dtype);
+}
+
+__global__ void __launch_bounds__(256) deltakv_reconstruct_kernel(const SvkDeltakvReconstructArgs a) {
+  extern __shared__ float red[];       // [blockDim.x] sum of squares for the k-norm
+  const int D = a.head_dim, HD2 = D / 2, H = a.num_kv_heads;
+  const int per_entry = H * HD2;
+  const int entries_per_block = blockDim.x / per_entry;
+  const int e = threadIdx.x / per_entry;
+  const int n = blockIdx.x * entries_per_block + e;
+  const int t = threadIdx.x % per_entry;
+  const int h = t / HD2, p = t % HD2;
+  bool active = e < entries_per_block && n < a.n;
+  int latent = -1, out_slot = 0, out_pos = 0;
+  if (active) {
+    out_slot = a.out_slots[n];
+    out_pos = a.out_pos[n];
+    if (a.delta_bits == 0) active = out_slot >= 0 && out_pos >= 0;
+    else { latent = a.latent_slots[n]; active = latent >= 0; }
+  }
+  float k1 = 0.f, k2 = 0.f, v1 = 0.f, v2 = 0.f;
+  if (active) {
+    float ak1 = 0.f, ak2 = 0.f, av1 = 0.f, av2 = 0.f;
+    for (int kk = 0; kk < a.k_fathers; ++kk) {
+      const int fs = a.father_slots[(int64_t)n * a.father_stride + kk];
+      const int64_t base = (int64_t)fs * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
+      const float y1 = __builtin_bit_cast(float, (uint32_t)a.k_cache[base] << 16);
+      const float y2 = __builtin_bit_cast(float, (uint32_t)a.k_cache[base + HD2] << 16);
+      if (a.raw_k_cache) {
+        ak1 += y1; ak2 += y2;
+      } else {
+        const int fp = a.slot_to_pos[fs];
+        const float c = load_scalar(a.cos_sin, (int64_t)fp * a.cos_stride + p, a.cos_dtype);
+        const float s = load_scalar(a.cos_sin, (int64_t)fp * a.cos_stride + p + HD2, a.cos_dtype);
+        ak1 += y1 * c + y2 * s;
+        ak2 += y2 * c - y1 * s;
+      }
+      av1 += __builtin_bit_cast(float, (uint32_t)a.v_cache[base] << 16);
+      av2 += __builtin_bit_cast(float, (uint32_t)a.v_cache[base + HD2] << 16);
+    }
+    const float inv = 1.0f / (float)a.k_fathers;
+    const int Dtot = H * D;
+    const int fk1 = h * D + p;
+    k1 = delta_at(a, n, latent, fk1) + ak1 * inv;
+    k2 = delta_at(a, n, latent, fk1 + HD2) + ak2 * inv;
+    v1 = delta_at(a, n, latent, Dtot + fk1) + av1 * inv;
+    v2 = delta_at(a, n, latent, Dtot + fk1 + HD2) + av2 * inv;
+  }
+  if (a.k_norm_weight != nullptr && !a.store_raw_k) {
+    // RMS norm over the head's D elements = the HD2 consecutive threads of this head
+    red[threadIdx.x] = active ? k1 * k1 + k2 * k2 : 0.f;
+    __syncthreads();
+    if (active) {
+      const int h0 = threadIdx.x - p;
+      float ss = 0.f;
+      for (int i = 0; i < HD2; ++i) ss += red[h0 + i];
+      const float rstd = rsqrtf(ss / (float)D + a.k_norm_eps);
+      k1 = k1 * rstd * a.k_norm_weight[p];
+      k2 = k2 * rstd * a.k_norm_weight[p + HD2];
+    }
+  }
+  if (!active) return;
+  float o1 = k1, o2 = k2;
+  if (!a.store_raw_k) {
+    const float c = load_scalar(a.cos_sin, (int64_t)out_pos * a.cos_stride + p, a.cos_dtype);
+    const float s = load_scalar(a.cos_sin, (int64_t)out_pos * a.cos_stride + p + HD2, a.cos_dtype);
+    o1 = k1 * c - k2 * s;
+    o2 = k2 * c + k1 * s;
+  }
+  const int64_t ob = (int64_t)out_slot * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
+  a.k_cache[ob] = (uint16_t)f32_to_bf16_bits(o1);
+  a.k_cache[ob + HD2] = (uint16_t)f32_to_bf16_bits(o2);
+  a.v_cache[ob] = (uint16_t)f32_to_bf16_bits(v1);
+  a.v_cache[ob + HD2] = (uint16_t)f32_to_bf16_bits(v2);
+}
+
+// ------------------------------------------------------------------------------------
+// observation-layer token scores
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) token_score_stats_kernel(const SvkDeltakvTokenScoresArgs a) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int len = min(max(a.candidate_lens[b], 0), a.length - a.candidate_start);
+  const float* x = a.raw_scores + (int64_t)b * a.raw_stride_b + (int64_t)h * a.raw_stride_h + a.candidate_start;
+  float mx = -INFINITY;
+  for (int t = threadIdx.x; t < len; t += blockDim.x) mx = fmaxf(mx, mul_rn(x[t], a.scale));
+  mx = block_allmax(mx, red);
+  float sum = 0.f;
+  for (int t = threadIdx.x; t < len; t += blockDim.x) sum += expf(mul_rn(x[t], a.scale) - mx);
+  sum = block_allsum(sum, red);
+  if (threadIdx.x == 0) {
+    float* ws = a.workspace + ((int64_t)b * a.num_heads + h) * 2;
+    ws[0] = mx;
+    ws[1] = sum;
+  }
+}
+
+__global__ void __launch_bounds__(256) token_score_final_kernel(const SvkDeltakvTokenScoresArgs a) {
+  extern __shared__ float stats[];      // [H][2]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < a.num_heads * 2; i += blockDim.x) stats[i] = a.workspace[(int64_t)b * a.num_heads * 2 + i];
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.length) return;
+  const int len = min(max(a.candidate_lens[b], 0), a.length - a.candidate_start);
+  float out = a.fill_value;
+  const int rel = t - a.candidate_start;
+  if (rel >= 0 && rel < len) {
+    float best = 0.f;
+    const float* x = a.raw_scores + (int64_t)b * a.raw_stride_b + t;
+    for (int h = 0; h < a.num_heads; ++h)
+      best = fmaxf(best, expf(mul_rn(x[(int64_t)h * a.raw_stride_h], a.scale) - stats[2 * h]) / stats[2 * h + 1]);
+    if (a.round_dtype == SVK_DTYPE_BF16) best = bf16_round(best);
+    else if (a.round_dtype == SVK_DTYPE_F16) best = (float)(_Float16)best;
+    out = best;
+  }
+  a.token_scores[(int64_t)b * a.out_stride + t] = out;
+}
+
+// ------------------------------------------------------------------------------------
+// sorted top-k: radix select, then a bitonic sort of the k winners in LDS
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(1024) topk_sorted_kernel(const SvkTopkSortedArgs a, int kpad) {
+  __shared__ SelectScratch scratch;
+  extern __shared__ unsigned long long keys[];     // [kpad]
+  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const float* sc = a.scores + (int64_t)r * a.score_stride;
+  const int vlen = a.valid_len ? min(max(a.valid_len[r], 0), a.n) : a.n;
+  const float masked = a.masked_value;
+  auto score_at = [&](int i) { return i < vlen ? sc[i] : masked; };
+  for (int i = tid; i < kpad; i += nt) keys[i] = ~0ull;
+  __syncthreads();
+  // selection on the (masked) scores: block_select works on a pointer, so mask through a functor copy
+  {
+    // radix select over score_at(i)
+    uint32_t prefix = 0;
+    int kk = a.k;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+      for (int i = tid; i < 256; i += nt) scratch.hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < a.n; i += nt) {
+        const uint32_t key = desc_key(score_at(i));
+        if ((key & himask) == prefix) atomicAdd(&scratch.hist[(key >> shift) & 255u], 1);
+      }
+      __syncthreads();
+      if (tid < 64) {
+        int c[4], local = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = scratch.hist[tid * 4 + j]; local += c[j]; }
+        int incl = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o, 64);
+          if (tid >= o) incl += v;
+        }
+        const int excl = incl - local;
+        if (kk > excl && kk <= incl) {
+          int run = excl;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (kk > run && kk <= run + c[j]) { scratch.prefix = prefix | ((uint32_t)(tid * 4 + j) << shift); scratch.k = kk - run; }
+            run += c[j];
+          }
+        }
+      }
+      __syncthreads();
+      prefix = scratch.prefix;
+      kk = scratch.k;
+      __syncthreads();
+    }
+    const uint32_t T = prefix;
+    const int take_eq = kk;
+    int out_base = 0, eq_base = 0;
+    for (int c0 = 0; c0 < a.n; c0 += nt) {
+      const int i = c0 + tid;
+      uint32_t key = 0xffffffffu;
+      const bool in = i < a.n;
+      if (in) key = desc_key(score_at(i));
+      const bool is_eq = in && key == T;
+      int eq_total;
+      const int eq_rank = eq_base + block_excl_count(is_eq, scratch.wsum, eq_total);
+      const bool sel = in && (key < T || (is_eq && eq_rank < take_eq));
+      int sel_total;
+      const int pos = out_base + block_excl_count(sel, scratch.wsum, sel_total);
+      if (sel) keys[pos] = ((unsigned long long)key << 32) | (unsigned)i;
+      out_base += sel_total;
+      eq_base += eq_total;
+    }
+  }
+  __syncthreads();
+  // bitonic sort ascending on (desc_key, index) == (score desc, index asc)
+  for (int size = 2; size <= kpad; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < kpad / 2; i += nt) {
+        const int lo = 2 * i - (i & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long x = keys[lo], y = keys[hi];
+        if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(keys[i] & 0xffffffffull);
+}
+
+}  // namespace
+}  // namespace svk
+
+extern "C" int svk_deltakv_static_decode_plan(const SvkDeltakvPlanArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_deltakv_static_decode_plan: null args");
+  SVK_REQUIRE(a->k_max >= 0 && a->sink >= 0 && a->max_buffer >= 0 && a->max_positions > 0, SVK_ERR_VALUE,
+              "svk_deltakv_static_decode_plan: bad shape parameters");
+  if (a->batch <= 0) return SVK_OK;
+  hipLaunchKernelGGL(deltakv_plan_kernel, dim3(a->batch), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_deltakv_static_decode_plan");
+}
+
+extern "C" int svk_dequantize_grouped(const SvkDequantGroupedArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_dequantize_grouped: null args");
+  SVK_REQUIRE(a->bits == 2 || a->bits == 4 || a->bits == 8, SVK_ERR_VALUE,
+              "Packed quantization supports bits=(2, 4, 8), got %d.", a->bits);
+  SVK_REQUIRE(a->group_size > 0 && a->features % a->group_size == 0, SVK_ERR_VALUE,
+              "dequantization requires output_dim divisible by group_size, got output_dim=%d, group_size=%d.", a->features, a->group_size);
+  SVK_REQUIRE(a->features % (32 / a->bits) == 0, SVK_ERR_VALUE, "features %d not divisible by %d", a->features, 32 / a->bits);
+  if (a->rows <= 0) return SVK_OK;
+  hipLaunchKernelGGL(dequant_grouped_kernel, dim3((a->features + 255) / 256, a->rows), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_dequantize_grouped");
+}
+
+extern "C" int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_deltakv_reconstruct_writeback: null args");
+  SVK_REQUIRE(a->head_dim % 2 == 0 && a->head_dim > 0, SVK_ERR_LAYOUT, "head_dim must be even");
+  SVK_REQUIRE(a->delta_bits == 0 || a->delta_bits == 2 || a->delta_bits == 4 || a->delta_bits == 8, SVK_ERR_VALUE,
+              "DeltaKV fused residual reconstruction supports quant_bits=2, 4 or 8, got %d.", a->delta_bits);
+  SVK_REQUIRE(a->k_fathers > 0, SVK_ERR_VALUE, "svk_deltakv_reconstruct_writeback: k_fathers must be positive");
+  const int per_entry = a->num_kv_heads * (a->head_dim / 2);
+  SVK_REQUIRE(per_entry <= 1024, SVK_ERR_LAYOUT, "svk_deltakv_reconstruct_writeback: Hkv*D/2 = %d exceeds 1024", per_entry);
+  if (a->delta_bits != 0) {
+    const int feats = 2 * a->num_kv_heads * a->head_dim;
+    SVK_REQUIRE(a->group_size > 0 && feats % a->group_size == 0, SVK_ERR_VALUE,
+                "DeltaKV fused residual reconstruction requires 2*D divisible by group_size; 2*D=%d, group_size=%d.", feats, a->group_size);
+    SVK_REQUIRE(a->latent_slots != nullptr && a->scale != nullptr && a->mn != nullptr, SVK_ERR_VALUE,
+                "svk_deltakv_reconstruct_writeback: packed residuals need latent_slots, scale and mn");
+  }
+  if (a->n <= 0) return SVK_OK;
+  int threads = per_entry;
+  if (threads < 256) threads = (256 / per_entry) * per_entry;
+  const int epb = threads / per_entry;
+  hipLaunchKernelGGL(deltakv_reconstruct_kernel, dim3((a->n + epb - 1) / epb), dim3(threads), sizeof(float) * threads,
+                     static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_deltakv_reconstruct_writeback");
+}
+
+extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->workspace != nullptr, SVK_ERR_VALUE, "svk_deltakv_token_scores: null args/workspace");
+  SVK_REQUIRE(a->candidate_start >= 0 && a->candidate_start <= a->length, SVK_ERR_VALUE,
+              "candidate_start must be within score length; got %d for L=%d.", a->candidate_start, a->length);
+  if (a->batch <= 0 || a->length <= 0) return SVK_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(token_score_stats_kernel, dim3(a->batch, a->num_heads), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(token_score_final_kernel, dim3((a->length + 255) / 256, a->batch), dim3(256),
+                     sizeof(float) * 2 * a->num_heads, s, *a);
+  return check_launch("svk_deltakv_token_scores");
+}
+
+extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_topk_sorted_desc: null args");
+  SVK_REQUIRE(a->k >= 0 && a->k <= a->n, SVK_ERR_VALUE, "svk_topk_sorted_desc: k %d out of range (n=%d)", a->k, a->n);
+  SVK_REQUIRE(a->k <= 4096, SVK_ERR_VALUE, "svk_topk_sorted_desc: k %d > 4096 unsupported", a->k);
+  if (a->rows <= 0 || a->k == 0) return SVK_OK;
+  int kpad = 2;
+  while (kpad < a->k) kpad <<= 1;
+  hipLaunchKernelGGL(topk_sorted_kernel, dim3(a->rows), dim3(kpad >= 2048 ? 1024 : 256), sizeof(unsigned long long) * kpad,
+                     static_cast<hipStream_t>(stream), *a, kpad);
+  return check_launch("svk_topk_sorted_desc");
+}

@@ -35,10 +35,10 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
   const int W = a.width;
   float mx = -INFINITY;
   // __fmul_rn keeps `x * scale` a separately rounded product like torch's mul_ (no fma contraction)
-  for (int t = threadIdx.x; t < W; t += blockDim.x) mx = fmaxf(mx, __fmul_rn(x[t], a.scale));
+  for (int t = threadIdx.x; t < W; t += blockDim.x) mx = fmaxf(mx, mul_rn(x[t], a.scale));
   mx = block_allmax(mx, red);
   float sum = 0.f;
-  for (int t = threadIdx.x; t < W; t += blockDim.x) sum += expf(__fmul_rn(x[t], a.scale) - mx);
+  for (int t = threadIdx.x; t < W; t += blockDim.x) sum += expf(mul_rn(x[t], a.scale) - mx);
   sum = block_allsum(sum, red);
   float* cum = nullptr;
   int len = 0;
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
     len = a.b_seqlen[b];
   }
   for (int t = threadIdx.x; t < W; t += blockDim.x) {
-    const float p = expf(__fmul_rn(x[t], a.scale) - mx) / sum;
+    const float p = expf(mul_rn(x[t], a.scale) - mx) / sum;
     x[t] = p;
     if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : cum[t] + p;   // pad(prev, 1) + p
   }
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDec
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int t = threadIdx.x + i * 1024;
-      v[i] = t < W ? __fmul_rn(x[t], a.scale) : -INFINITY;
+      v[i] = t < W ? mul_rn(x[t], a.scale) : -INFINITY;
       mx = fmaxf(mx, v[i]);
     }
     mx = block_allmax(mx, red);

@@ -46,6 +46,17 @@ __device__ __forceinline__ float bf16_round(float f) {
   return __builtin_bit_cast(float, f32_to_bf16_bits(f) << 16);
 }
 
+// x*y rounded on its own (never contracted into an fma with a following add): ROCm's __fmul_rn is a
+// plain `x * y` and still fuses under -ffp-contract=fast, so the contraction is switched off locally.
+__device__ __forceinline__ float mul_rn(float x, float y) {
+#pragma clang fp contract(off)
+  return x * y;
+}
+__device__ __forceinline__ float add_rn(float x, float y) {
+#pragma clang fp contract(off)
+  return x + y;
+}
+
 // Lane id recomputed on the spot (2 VALU ops).  `volatile` keeps the compiler from hoisting it
 // out of a loop and then spilling it when the loop body is at its VGPR budget.
 __device__ __forceinline__ int lane_id_fresh() {

@@ -1,0 +1,220 @@
+"""DeltaKV decode-side ops on gfx950.  Mirrors (names, keyword arguments, validation) of
+kernels/triton/deltakv_kernels.py `deltakv_static_decode_plan` (:3854-3942),
+`deltakv_reconstruct_writeback_grouped_heads` (:2909-3012),
+`deltakv_less_memory_reconstruct_writeback_quantized` / `_int4` (:3344-3485) and of
+kernels/triton/quant.py `triton_dequantize_2d_int4_grouped` (:160-216), `unpack_quantized_to_16bit` (:326-349)."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+_DT = {torch.float32: _lib.SVK_DTYPE_F32, torch.bfloat16: _lib.SVK_DTYPE_BF16, torch.float16: _lib.SVK_DTYPE_F16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError as e:
+        raise TypeError(f"unsupported dtype {t.dtype}") from e
+
+
+@torch.no_grad()
+def deltakv_static_decode_plan(*, raw_slots_map, latent_slots_map, active_compressed_indices, req_indices, context_lens,
+                               compressed_lens, temp_slots, active_slots_out, active_pos_out, new_context_lens_out,
+                               recon_pos_out, recon_latent_out, recon_out_slot_out, sink: int, max_buffer: int):
+    assert raw_slots_map.dim() == 2 and latent_slots_map.dim() == 2
+    assert active_compressed_indices.dim() == 2 and temp_slots.dim() == 2
+    assert req_indices.dim() == 1 and context_lens.dim() == 1 and compressed_lens.dim() == 1
+    assert active_slots_out.dim() == 2 and active_pos_out.dim() == 2
+    for t in (raw_slots_map, latent_slots_map, active_compressed_indices, req_indices, context_lens, compressed_lens,
+              temp_slots, active_slots_out, active_pos_out, new_context_lens_out, recon_pos_out, recon_latent_out,
+              recon_out_slot_out):
+        assert t.dtype == torch.int32 and t.stride(-1) == 1
+    batch_size = int(req_indices.shape[0])
+    k_max = int(active_compressed_indices.shape[1])
+    sink, max_buffer = int(sink), int(max_buffer)
+    max_s = sink + k_max + max_buffer
+    if active_slots_out.shape != (batch_size, max_s):
+        raise ValueError("DeltaKV static decode plan active_slots_out shape mismatch: "
+                         f"got={tuple(active_slots_out.shape)}, expected=({batch_size}, {max_s}).")
+    if active_pos_out.shape != (batch_size, max_s):
+        raise ValueError("DeltaKV static decode plan active_pos_out shape mismatch: "
+                         f"got={tuple(active_pos_out.shape)}, expected=({batch_size}, {max_s}).")
+    if temp_slots.shape != (batch_size, k_max):
+        raise ValueError("DeltaKV static decode plan temp_slots shape mismatch: "
+                         f"got={tuple(temp_slots.shape)}, expected=({batch_size}, {k_max}).")
+    if recon_pos_out.numel() != batch_size * k_max:
+        raise ValueError("DeltaKV static decode plan recon outputs must have B*K elements.")
+    if batch_size == 0:
+        return
+    lib = _lib.load()
+    a = _lib.SvkDeltakvPlanArgs(
+        raw_slots_map=_lib.ptr(raw_slots_map), latent_slots_map=_lib.ptr(latent_slots_map),
+        active_compressed=_lib.ptr(active_compressed_indices), req_indices=_lib.ptr(req_indices),
+        context_lens=_lib.ptr(context_lens), compressed_lens=_lib.ptr(compressed_lens), temp_slots=_lib.ptr(temp_slots),
+        active_slots_out=_lib.ptr(active_slots_out), active_pos_out=_lib.ptr(active_pos_out),
+        new_context_lens_out=_lib.ptr(new_context_lens_out), recon_pos_out=_lib.ptr(recon_pos_out),
+        recon_latent_out=_lib.ptr(recon_latent_out), recon_out_slot_out=_lib.ptr(recon_out_slot_out),
+        raw_stride=raw_slots_map.stride(0), latent_stride=latent_slots_map.stride(0),
+        active_stride=active_compressed_indices.stride(0), temp_stride=temp_slots.stride(0),
+        out_stride=active_slots_out.stride(0), pos_stride=active_pos_out.stride(0), batch=batch_size, k_max=k_max,
+        sink=sink, max_buffer=max_buffer, max_positions=int(raw_slots_map.shape[1]))
+    _lib.check(lib.svk_deltakv_static_decode_plan(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
+                 v_cache, bits, group_size, k_norm_weight, k_norm_eps, raw_k_cache, store_raw_k):
+    assert k_cache.dtype == torch.bfloat16 and k_cache.stride() == v_cache.stride() and k_cache.stride(-1) == 1
+    assert father_slots.dim() == 2 and father_slots.dtype == torch.int32 and father_slots.stride(1) == 1
+    assert cos_sin.stride(1) == 1
+    if k_norm_weight is not None:
+        assert k_norm_weight.dim() == 1 and k_norm_weight.shape[0] == k_cache.shape[2]
+        k_norm_weight = k_norm_weight.float().contiguous()
+    lib = _lib.load()
+    a = _lib.SvkDeltakvReconstructArgs(
+        delta=_lib.ptr(delta), scale=_lib.ptr(scale), mn=_lib.ptr(mn), latent_slots=_lib.ptr(latent_slots),
+        father_slots=_lib.ptr(father_slots), slot_to_pos=_lib.ptr(slot_to_pos), out_slots=_lib.ptr(out_slots),
+        out_pos=_lib.ptr(out_pos), cos_sin=_lib.ptr(cos_sin), k_cache=_lib.ptr(k_cache), v_cache=_lib.ptr(v_cache),
+        k_norm_weight=_lib.ptr(k_norm_weight), delta_stride=delta.stride(0),
+        scale_stride=0 if scale is None else scale.stride(0), father_stride=father_slots.stride(0),
+        cos_stride=cos_sin.stride(0), kv_slot_stride=k_cache.stride(0), kv_head_stride=k_cache.stride(1),
+        k_norm_eps=float(k_norm_eps), n=int(father_slots.shape[0]), k_fathers=int(father_slots.shape[1]),
+        num_kv_heads=int(k_cache.shape[1]), head_dim=int(k_cache.shape[2]), delta_bits=int(bits),
+        group_size=int(group_size), delta_dtype=_dt(delta) if bits == 0 else 0,
+        scale_dtype=0 if scale is None else _dt(scale), cos_dtype=_dt(cos_sin), raw_k_cache=int(bool(raw_k_cache)),
+        store_raw_k=int(bool(store_raw_k)))
+    _lib.check(lib.svk_deltakv_reconstruct_writeback(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+@torch.no_grad()
+def deltakv_reconstruct_writeback_grouped_heads(kv_delta, father_slots, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
+                                                v_cache, *, heads_per_program: int = 4, pre_rope_k_cache=None,
+                                                ref_v_cache=None, k_norm_weight=None, k_norm_eps: float = 1e-6,
+                                                raw_k_cache: bool = False, store_raw_k: bool = False):
+    if int(heads_per_program) <= 0:
+        raise ValueError("heads_per_program must be a positive integer.")
+    if pre_rope_k_cache is not None or ref_v_cache is not None:
+        raise NotImplementedError("separate pre-RoPE K / reference V caches are not part of this build")
+    assert kv_delta.dim() == 2 and kv_delta.stride(1) == 1
+    _reconstruct(delta=kv_delta, scale=None, mn=None, latent_slots=None, father_slots=father_slots,
+                 slot_to_pos=slot_to_pos, out_slots=out_slots, out_pos=out_pos, cos_sin=cos_sin, k_cache=k_cache,
+                 v_cache=v_cache, bits=0, group_size=0, k_norm_weight=k_norm_weight, k_norm_eps=k_norm_eps,
+                 raw_k_cache=raw_k_cache, store_raw_k=store_raw_k)
+
+
+@torch.no_grad()
+def deltakv_less_memory_reconstruct_writeback_quantized(packed_delta_cache, scale_cache, min_cache, latent_slots,
+                                                        father_slots, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
+                                                        v_cache, *, quant_bits: int, group_size: int | None = None,
+                                                        heads_per_program: int = 4, k_norm_weight=None,
+                                                        k_norm_eps: float = 1e-6, raw_k_cache: bool = False,
+                                                        store_raw_k: bool = False):
+    assert packed_delta_cache.dim() == 2 and packed_delta_cache.dtype == torch.int32
+    assert scale_cache.dim() == 2 and min_cache.dim() == 2 and scale_cache.dtype == min_cache.dtype
+    assert latent_slots.dim() == 1 and father_slots.dim() == 2
+    num_kv_heads, head_dim = k_cache.shape[1], k_cache.shape[2]
+    assert head_dim % 2 == 0
+    D = num_kv_heads * head_dim
+    quant_bits = int(quant_bits)
+    if quant_bits not in (2, 4):
+        raise ValueError(f"DeltaKV fused residual reconstruction supports quant_bits=2 or 4, got {quant_bits}.")
+    feat_per_int = 32 // quant_bits
+    if (2 * D) % feat_per_int != 0:
+        raise ValueError(f"int{quant_bits} residual packing requires 2*D={2 * D} divisible by {feat_per_int}.")
+    assert packed_delta_cache.shape[1] == (2 * D) // feat_per_int
+    group_size = int(group_size or (2 * D))
+    if group_size <= 0 or (2 * D) % group_size != 0:
+        raise ValueError("DeltaKV fused residual reconstruction requires 2*D divisible by group_size; "
+                         f"2*D={2 * D}, group_size={group_size}.")
+    num_groups = (2 * D) // group_size
+    if scale_cache.shape[1] != num_groups or min_cache.shape[1] != num_groups:
+        raise ValueError("DeltaKV fused residual reconstruction scale/min group count mismatch: "
+                         f"expected={num_groups}, scale={tuple(scale_cache.shape)}, min={tuple(min_cache.shape)}.")
+    if int(heads_per_program) <= 0:
+        raise ValueError("heads_per_program must be a positive integer.")
+    assert scale_cache.stride() == min_cache.stride() and scale_cache.stride(1) == 1
+    _reconstruct(delta=packed_delta_cache, scale=scale_cache, mn=min_cache, latent_slots=latent_slots,
+                 father_slots=father_slots, slot_to_pos=slot_to_pos, out_slots=out_slots, out_pos=out_pos,
+                 cos_sin=cos_sin, k_cache=k_cache, v_cache=v_cache, bits=quant_bits, group_size=group_size,
+                 k_norm_weight=k_norm_weight, k_norm_eps=k_norm_eps, raw_k_cache=raw_k_cache, store_raw_k=store_raw_k)
+
+
+def deltakv_less_memory_reconstruct_writeback_int4(*args, **kwargs):
+    return deltakv_less_memory_reconstruct_writeback_quantized(*args, quant_bits=4, **kwargs)
+
+
+def dequantize_grouped(packed, scale, mn, group_size: int, output_dim: int, bits: int, out_dtype=None):
+    """q * scale + mn for LSB-first `bits`-wide codes (quant.py:120-157, :304-349)."""
+    if packed.dim() != 2 or scale.dim() != 2 or mn.dim() != 2:
+        raise ValueError("2D dequantization expects rank-2 packed/scale/min tensors, "
+                         f"got packed={tuple(packed.shape)}, scale={tuple(scale.shape)}, mn={tuple(mn.shape)}.")
+    n, output_dim, group_size, bits = int(packed.shape[0]), int(output_dim), int(group_size), int(bits)
+    if bits not in (2, 4, 8):
+        raise ValueError(f"Packed quantization supports bits=(2, 4, 8), got {bits}.")
+    fpi = 32 // bits
+    if output_dim <= 0 or output_dim % fpi != 0:
+        raise ValueError(f"dequantization requires output_dim divisible by {fpi}, got {output_dim}.")
+    if group_size <= 0 or output_dim % group_size != 0:
+        raise ValueError("dequantization requires output_dim divisible by group_size, "
+                         f"got output_dim={output_dim}, group_size={group_size}.")
+    if int(packed.shape[1]) != output_dim // fpi:
+        raise ValueError(f"dequantization packed width mismatch: packed={packed.shape[1]}, expected={output_dim // fpi}.")
+    if tuple(scale.shape) != (n, output_dim // group_size) or tuple(mn.shape) != tuple(scale.shape):
+        raise ValueError("dequantization scale/min shape mismatch: "
+                         f"scale={tuple(scale.shape)}, mn={tuple(mn.shape)}, expected={(n, output_dim // group_size)}.")
+    packed, scale, mn = packed.contiguous(), scale.contiguous(), mn.contiguous()
+    out = torch.empty((n, output_dim), device=packed.device, dtype=out_dtype or scale.dtype)
+    lib = _lib.load()
+    a = _lib.SvkDequantGroupedArgs(packed=_lib.ptr(packed), scale=_lib.ptr(scale), mn=_lib.ptr(mn), out=_lib.ptr(out),
+                                   packed_stride=packed.stride(0), scale_stride=scale.stride(0), out_stride=out.stride(0),
+                                   rows=n, features=output_dim, bits=bits, group_size=group_size, scale_dtype=_dt(scale),
+                                   out_dtype=_dt(out))
+    _lib.check(lib.svk_dequantize_grouped(C.byref(a), _lib.current_stream_handle()), lib)
+    return out
+
+
+def triton_dequantize_2d_int4_grouped(packed, scale, mn, group_size: int, output_dim: int):
+    """Reference name kept for call-site compatibility (quant.py:160-216)."""
+    return dequantize_grouped(packed, scale, mn, group_size, output_dim, 4)
+
+
+def decode_softmax_token_scores(scores, *, candidate_start: int, candidate_lens, scale: float, round_dtype=None,
+                                fill_value: float | None = None):
+    """SparseController._decode_softmax_token_scores (sparse_controller.py:255-299)."""
+    if scores.dim() != 3:
+        raise ValueError(f"Expected decode scores with shape [B, H, L], got {tuple(scores.shape)}.")
+    candidate_start = int(candidate_start)
+    if candidate_start < 0 or candidate_start > scores.shape[-1]:
+        raise ValueError(f"candidate_start must be within score length; got {candidate_start} for L={scores.shape[-1]}.")
+    assert scores.dtype == torch.float32 and scores.stride(2) == 1
+    B, H, L = scores.shape
+    rd = torch.float32 if round_dtype is None else round_dtype
+    if fill_value is None:
+        fill_value = torch.finfo(rd).min
+    out = torch.empty((B, L), dtype=torch.float32, device=scores.device)
+    ws = torch.empty((B, H, 2), dtype=torch.float32, device=scores.device)
+    lib = _lib.load()
+    a = _lib.SvkDeltakvTokenScoresArgs(
+        raw_scores=_lib.ptr(scores), candidate_lens=_lib.ptr(candidate_lens.to(torch.int32)), token_scores=_lib.ptr(out),
+        workspace=_lib.ptr(ws), raw_stride_b=scores.stride(0), raw_stride_h=scores.stride(1), out_stride=out.stride(0),
+        scale=float(scale), fill_value=float(fill_value), batch=B, num_heads=H, length=L, candidate_start=candidate_start,
+        round_dtype=_DT[rd])
+    _lib.check(lib.svk_deltakv_token_scores(C.byref(a), _lib.current_stream_handle()), lib)
+    return out
+
+
+def topk_sorted_desc(scores, k: int, *, valid_len=None, masked_value: float = -1e10):
+    """`scores.topk(k, sorted=True).indices` (int32) with ties broken by the lower index."""
+    assert scores.dim() == 2 and scores.dtype == torch.float32 and scores.stride(1) == 1
+    rows, n = scores.shape
+    out = torch.empty((rows, int(k)), dtype=torch.int32, device=scores.device)
+    lib = _lib.load()
+    a = _lib.SvkTopkSortedArgs(scores=_lib.ptr(scores), valid_len=_lib.ptr(valid_len), indices=_lib.ptr(out),
+                               score_stride=scores.stride(0), index_stride=out.stride(0), masked_value=float(masked_value),
+                               rows=rows, n=n, k=int(k))
+    _lib.check(lib.svk_topk_sorted_desc(C.byref(a), _lib.current_stream_handle()), lib)
+    return out

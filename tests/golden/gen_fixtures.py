@@ -508,6 +508,106 @@ def gen_prefill_score():
     save("prefill_score", **out)
 
 
+def gen_deltakv():
+    """DeltaKV decode-side Triton kernels under the interpreter.  Their Python wrappers assert
+    `.is_cuda`, so the @triton.jit kernels are launched directly with the wrapper's grid / constexprs
+    (deltakv_kernels.py:3854-3942, :2909-3012, :3344-3450; quant.py:160-216)."""
+    from sparsevllm.kernels.triton import deltakv_kernels as dk
+    from sparsevllm.kernels.triton import quant as qk
+
+    out = {}
+    g = torch.Generator().manual_seed(44)
+    # ---- static decode plan
+    B, K, sink, max_buffer, rows, max_pos = 4, 12, 3, 6, 6, 64
+    S = sink + K + max_buffer
+    raw = torch.randint(-1, 500, (rows, max_pos), generator=g, dtype=torch.int32)
+    raw[:, :sink] = torch.randint(0, 500, (rows, sink), generator=g, dtype=torch.int32)
+    lat = torch.randint(-1, 300, (rows, max_pos), generator=g, dtype=torch.int32)
+    lat[lat % 3 == 0] = -1
+    active = torch.randint(-2, 40, (B, K), generator=g, dtype=torch.int32)
+    req = torch.tensor([4, 0, 2, 5], dtype=torch.int32)
+    ctx = torch.tensor([50, 30, 9, 64], dtype=torch.int32)
+    clen = torch.tensor([40, 5, 0, 55], dtype=torch.int32)
+    temp = torch.randint(600, 700, (B, K), generator=g, dtype=torch.int32)
+    a_slots = torch.zeros(B, S, dtype=torch.int32); a_pos = torch.zeros(B, S, dtype=torch.int32)
+    new_len = torch.zeros(B, dtype=torch.int32)
+    r_pos = torch.zeros(B * K, dtype=torch.int32); r_lat = torch.zeros(B * K, dtype=torch.int32); r_out = torch.zeros(B * K, dtype=torch.int32)
+    block_m = 1 << max(0, (S - 1).bit_length())
+    dk._deltakv_static_decode_plan_kernel[(B,)](
+        raw, lat, active, req, ctx, clen, temp, a_slots, a_pos, new_len, r_pos, r_lat, r_out,
+        raw.stride(0), raw.stride(1), lat.stride(0), lat.stride(1), active.stride(0), active.stride(1),
+        temp.stride(0), temp.stride(1), a_slots.stride(0), a_slots.stride(1), a_pos.stride(0), a_pos.stride(1),
+        SINK=sink, K_MAX=K, MAX_BUFFER=max_buffer, MAX_S=S, MAX_POS=max_pos - 1, BLOCK_M=block_m)
+    out.update(plan_raw=raw.numpy(), plan_lat=lat.numpy(), plan_active=active.numpy(), plan_req=req.numpy(),
+               plan_ctx=ctx.numpy(), plan_clen=clen.numpy(), plan_temp=temp.numpy(),
+               plan_cfg=np.array([sink, max_buffer], dtype=np.int64), plan_slots=a_slots.numpy(), plan_pos=a_pos.numpy(),
+               plan_new_len=new_len.numpy(), plan_rpos=r_pos.numpy(), plan_rlat=r_lat.numpy(), plan_rout=r_out.numpy())
+
+    # ---- reconstruct + RoPE write-back: dense delta and packed int2 / int4 residuals
+    Hkv, D, slots, N, Kf, max_p = 2, 64, 96, 10, 4, 128
+    Dtot = Hkv * D
+    kc0 = bf16f(torch.randn(slots, Hkv, D, generator=g) * 0.5)
+    vc0 = bf16f(torch.randn(slots, Hkv, D, generator=g) * 0.5)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, D // 2).float() / (D // 2)))
+    ang = torch.arange(max_p).float()[:, None] * inv_freq[None, :]
+    cos_sin = torch.cat((ang.cos(), ang.sin()), dim=1).contiguous()
+    fathers = torch.randint(0, 64, (N, Kf), generator=g, dtype=torch.int32)
+    slot_to_pos = torch.randint(0, max_p, (slots,), generator=g, dtype=torch.int32)
+    out_slots = torch.arange(70, 70 + N, dtype=torch.int32)
+    out_pos = torch.randint(0, max_p, (N,), generator=g, dtype=torch.int32)
+    out_slots_d = out_slots.clone(); out_slots_d[3] = -1          # dense form: entry 3 skipped
+    knorm = torch.rand(D, generator=g) + 0.5
+    delta = bf16f(torch.randn(N, 2 * Dtot, generator=g) * 0.3)
+    out.update(rc_k=bits(kc0), rc_v=bits(vc0), rc_cos_sin=cos_sin.numpy(), rc_fathers=fathers.numpy(),
+               rc_slot_to_pos=slot_to_pos.numpy(), rc_out_slots=out_slots.numpy(), rc_out_slots_dense=out_slots_d.numpy(),
+               rc_out_pos=out_pos.numpy(), rc_delta=bits(delta), rc_knorm=knorm.numpy())
+    for tag, raw_k, use_norm in (("dense", False, False), ("dense_norm_raw", True, True)):
+        kc, vc = kc0.clone(), vc0.clone()
+        dk._deltakv_reconstruct_writeback_grouped_heads_kernel[(N, 1)](
+            delta, fathers, slot_to_pos, out_slots_d, out_pos, cos_sin, kc, vc, kc, vc, knorm if use_norm else cos_sin,
+            delta.stride(0), delta.stride(1), fathers.stride(0), fathers.stride(1), cos_sin.stride(0), cos_sin.stride(1),
+            kc.stride(0), kc.stride(1), kc.stride(2), vc.stride(0), vc.stride(1), vc.stride(2),
+            kc.stride(0), kc.stride(1), kc.stride(2), vc.stride(0), vc.stride(1), vc.stride(2),
+            (knorm if use_norm else cos_sin).stride(0),
+            D=Dtot, HEAD_DIM=D, HD2=D // 2, NUM_KV_HEADS=Hkv, K=Kf, HEADS_PER_PROG=2, USE_PRE_ROPE_K=False,
+            USE_REF_V=False, APPLY_K_NORM=use_norm, K_NORM_EPS=1e-6, RAW_K_CACHE=raw_k, STORE_RAW_K=False)
+        out[f"rc_{tag}_k"] = kc.numpy(); out[f"rc_{tag}_v"] = vc.numpy()
+    n_lat = 24
+    latent_slots = torch.randint(0, n_lat, (N,), generator=g, dtype=torch.int32)
+    latent_slots[5] = -1                                           # quantised form: entry 5 skipped
+    out["rc_latent_slots"] = latent_slots.numpy()
+    for qbits, group in ((4, 32), (2, 32), (2, 2 * Dtot)):
+        fpi = 32 // qbits
+        codes = torch.randint(0, 2 ** 31 - 1, (n_lat, 2 * Dtot // fpi), generator=g, dtype=torch.int32)
+        codes = codes ^ (torch.randint(0, 2, codes.shape, generator=g, dtype=torch.int32) << 31)
+        ngroups = 2 * Dtot // group
+        scale = torch.rand(n_lat, ngroups, generator=g) * 0.05
+        mn = -torch.rand(n_lat, ngroups, generator=g) * 0.3
+        kc, vc = kc0.clone(), vc0.clone()
+        dk._deltakv_less_memory_reconstruct_writeback_kernel[(N, 1)](
+            codes, scale, mn, latent_slots, fathers, slot_to_pos, out_slots, out_pos, cos_sin, kc, vc, cos_sin,
+            codes.stride(0), codes.stride(1), scale.stride(0), scale.stride(1), mn.stride(0), mn.stride(1),
+            fathers.stride(0), fathers.stride(1), cos_sin.stride(0), cos_sin.stride(1),
+            kc.stride(0), kc.stride(1), kc.stride(2), vc.stride(0), vc.stride(1), vc.stride(2), cos_sin.stride(0),
+            D=Dtot, HEAD_DIM=D, HD2=D // 2, NUM_KV_HEADS=Hkv, K=Kf, HEADS_PER_PROG=2, BITS=qbits, FEAT_PER_INT=fpi,
+            QUANT_MASK=(1 << qbits) - 1, GROUP_SIZE=group, RAW_K_CACHE=False, STORE_RAW_K=False, APPLY_K_NORM=False,
+            K_NORM_EPS=1e-6)
+        t = f"q{qbits}g{group}"
+        out.update({f"rc_{t}_codes": codes.numpy(), f"rc_{t}_scale": scale.numpy(), f"rc_{t}_mn": mn.numpy(),
+                    f"rc_{t}_k": kc.numpy(), f"rc_{t}_v": vc.numpy()})
+    # ---- 2-D int4 grouped quantise + dequantise (quant.py:28-216), fp32 data
+    data = torch.randn(6, 64, generator=g)
+    code = torch.empty((6, 8), dtype=torch.int32); sc = torch.empty((6, 2)); mnq = torch.empty((6, 2))
+    qk._quantize_pack_2d_int4_grouped_kernel[(6, 2)](data, code, sc, mnq, data.stride(0), data.stride(1), code.stride(0),
+                                                     code.stride(1), sc.stride(0), sc.stride(1), D=64, GROUP_SIZE=32,
+                                                     PACKS_PER_GROUP=4, BLOCK_G=32)
+    deq = torch.empty((6, 64))
+    qk._dequantize_2d_int4_grouped_kernel[(6,)](code, sc, mnq, deq, code.stride(0), code.stride(1), sc.stride(0),
+                                                sc.stride(1), deq.stride(0), deq.stride(1), D=64, GROUP_SIZE=32, BLOCK_D=64)
+    out.update(q4_data=data.numpy(), q4_code=code.numpy(), q4_scale=sc.numpy(), q4_mn=mnq.numpy(), q4_deq=deq.numpy())
+    save("deltakv", **out)
+
+
 GROUPS = {
     "decode": gen_decode,
     "h2o_select": gen_h2o_select,
@@ -516,6 +616,7 @@ GROUPS = {
     "h2o_burst": gen_h2o_burst,
     "quest": gen_quest,
     "prefill_score": gen_prefill_score,
+    "deltakv": gen_deltakv,
 }
 
 

@@ -1,0 +1,186 @@
+"""GPU parity of the DeltaKV decode-side kernels vs reference-generated fixtures and the oracle.
+Reconstruct tolerance: the reference's own (tests/test_deltakv_less_memory_kernel.py:408-503: atol 2e-3 int4 /
+4e-3 int2 against unpack-then-reconstruct) plus bf16 output rounding -> atol 8e-3, rtol 1e-2."""
+
+import numpy as np
+import pytest
+
+from oracle import bf16_bits_to_f32, bf16_round, f32_to_bf16_bits
+from oracle import deltakv as od
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev())
+
+
+def to_bf16(x):
+    return torch.from_numpy(f32_to_bf16_bits(x).view(np.int16).copy()).to(dev()).view(torch.bfloat16)
+
+
+def test_static_plan_golden_and_random(golden):
+    from sparse_vllm_amd.kernels.deltakv_kernels import deltakv_static_decode_plan
+    g = golden("deltakv")
+    sink, max_buffer = (int(x) for x in g["plan_cfg"])
+
+    def run(raw, lat, active, req, ctx, clen, temp, sink, max_buffer):
+        B, K = active.shape
+        S = sink + K + max_buffer
+        z = lambda *s: torch.full(s, 99, dtype=torch.int32, device=dev())
+        outs = dict(active_slots_out=z(B, S), active_pos_out=z(B, S), new_context_lens_out=z(B), recon_pos_out=z(B * K),
+                    recon_latent_out=z(B * K), recon_out_slot_out=z(B * K))
+        deltakv_static_decode_plan(raw_slots_map=t(raw), latent_slots_map=t(lat), active_compressed_indices=t(active),
+                                   req_indices=t(req), context_lens=t(ctx), compressed_lens=t(clen), temp_slots=t(temp),
+                                   sink=sink, max_buffer=max_buffer, **outs)
+        return {k: v.cpu().numpy() for k, v in outs.items()}
+
+    o = run(g["plan_raw"], g["plan_lat"], g["plan_active"], g["plan_req"], g["plan_ctx"], g["plan_clen"], g["plan_temp"],
+            sink, max_buffer)
+    np.testing.assert_array_equal(o["active_slots_out"], g["plan_slots"])
+    np.testing.assert_array_equal(o["active_pos_out"], g["plan_pos"])
+    np.testing.assert_array_equal(o["new_context_lens_out"], g["plan_new_len"])
+    np.testing.assert_array_equal(o["recon_pos_out"], g["plan_rpos"])
+    np.testing.assert_array_equal(o["recon_latent_out"], g["plan_rlat"])
+    np.testing.assert_array_equal(o["recon_out_slot_out"], g["plan_rout"])
+    # paper-config shape: sink 8, K 2048, buffer 128
+    rng = np.random.default_rng(2)
+    B, K, sink, mb, rows, mp = 5, 2048, 8, 128, 7, 6000
+    raw = rng.integers(-1, 100000, (rows, mp)).astype(np.int32)
+    lat = rng.integers(-1, 50000, (rows, mp)).astype(np.int32)
+    lat[rng.random((rows, mp)) < 0.3] = -1
+    active = rng.integers(-1, 5800, (B, K)).astype(np.int32)
+    req = rng.permutation(rows)[:B].astype(np.int32)
+    ctx = np.array([5990, 3000, 9, 2056, 2200], np.int32)
+    clen = np.array([5800, 2900, 0, 2040, 2049], np.int32)
+    temp = rng.integers(200000, 300000, (B, K)).astype(np.int32)
+    o = run(raw, lat, active, req, ctx, clen, temp, sink, mb)
+    e = od.static_decode_plan(raw, lat, active, req, ctx, clen, temp, sink=sink, max_buffer=mb)
+    np.testing.assert_array_equal(o["active_slots_out"], e["active_slots"])
+    np.testing.assert_array_equal(o["active_pos_out"], e["active_pos"])
+    np.testing.assert_array_equal(o["new_context_lens_out"], e["new_context_lens"])
+    np.testing.assert_array_equal(o["recon_pos_out"], e["recon_pos"])
+    np.testing.assert_array_equal(o["recon_latent_out"], e["recon_latent"])
+    np.testing.assert_array_equal(o["recon_out_slot_out"], e["recon_out_slot"])
+
+
+def _close(got, ref):
+    np.testing.assert_allclose(got, bf16_round(ref), rtol=1e-2, atol=8e-3)
+
+
+@pytest.mark.parametrize("tag,raw_k,use_norm", [("dense", False, False), ("dense_norm_raw", True, True)])
+def test_reconstruct_dense_golden(golden, tag, raw_k, use_norm):
+    from sparse_vllm_amd.kernels.deltakv_kernels import deltakv_reconstruct_writeback_grouped_heads
+    g = golden("deltakv")
+    kc, vc = to_bf16(bf16_bits_to_f32(g["rc_k"])), to_bf16(bf16_bits_to_f32(g["rc_v"]))
+    deltakv_reconstruct_writeback_grouped_heads(
+        to_bf16(bf16_bits_to_f32(g["rc_delta"])), t(g["rc_fathers"]), t(g["rc_slot_to_pos"]), t(g["rc_out_slots_dense"]),
+        t(g["rc_out_pos"]), t(g["rc_cos_sin"]), kc, vc, k_norm_weight=t(g["rc_knorm"]) if use_norm else None,
+        raw_k_cache=raw_k)
+    _close(kc.float().cpu().numpy(), g[f"rc_{tag}_k"])
+    _close(vc.float().cpu().numpy(), g[f"rc_{tag}_v"])
+    # the skipped entry's slot is untouched
+    np.testing.assert_array_equal(kc.float().cpu().numpy()[73], bf16_bits_to_f32(g["rc_k"])[73])
+
+
+@pytest.mark.parametrize("bits,group", [(4, 32), (2, 32), (2, 256)])
+@pytest.mark.parametrize("sdtype", ["f32", "bf16"])
+def test_reconstruct_quantized_golden(golden, bits, group, sdtype):
+    from sparse_vllm_amd.kernels.deltakv_kernels import deltakv_less_memory_reconstruct_writeback_quantized
+    g = golden("deltakv")
+    tg = f"q{bits}g{group}"
+    kc, vc = to_bf16(bf16_bits_to_f32(g["rc_k"])), to_bf16(bf16_bits_to_f32(g["rc_v"]))
+    scale, mn = g[f"rc_{tg}_scale"], g[f"rc_{tg}_mn"]
+    if sdtype == "bf16":
+        sc_t, mn_t = to_bf16(scale), to_bf16(mn)
+        scale, mn = bf16_round(scale), bf16_round(mn)
+    else:
+        sc_t, mn_t = t(scale), t(mn)
+    deltakv_less_memory_reconstruct_writeback_quantized(
+        t(g[f"rc_{tg}_codes"]), sc_t, mn_t, t(g["rc_latent_slots"]), t(g["rc_fathers"]), t(g["rc_slot_to_pos"]),
+        t(g["rc_out_slots"]), t(g["rc_out_pos"]), t(g["rc_cos_sin"]), kc, vc, quant_bits=bits, group_size=group)
+    if sdtype == "f32":
+        _close(kc.float().cpu().numpy(), g[f"rc_{tg}_k"])
+        _close(vc.float().cpu().numpy(), g[f"rc_{tg}_v"])
+    ek, ev = bf16_bits_to_f32(g["rc_k"]), bf16_bits_to_f32(g["rc_v"])
+    od.reconstruct_writeback(ek, ev, packed=g[f"rc_{tg}_codes"], scale=scale, mn=mn, latent_slots=g["rc_latent_slots"],
+                             bits=bits, group_size=group, father_slots=g["rc_fathers"], slot_to_pos=g["rc_slot_to_pos"],
+                             out_slots=g["rc_out_slots"], out_pos=g["rc_out_pos"], cos_sin=g["rc_cos_sin"])
+    np.testing.assert_allclose(kc.float().cpu().numpy(), ek, rtol=1e-2, atol=8e-3)
+    np.testing.assert_allclose(vc.float().cpu().numpy(), ev, rtol=1e-2, atol=8e-3)
+
+
+def test_reconstruct_qwen7b_shape_vs_oracle():
+    from sparse_vllm_amd.kernels.deltakv_kernels import deltakv_less_memory_reconstruct_writeback_quantized
+    rng = np.random.default_rng(9)
+    Hkv, D, slots, N, Kf, max_p, n_lat, bits, group = 4, 128, 4096, 300, 4, 4096, 512, 2, 32
+    Dtot = Hkv * D
+    k0 = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.5).astype(np.float32))
+    v0 = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.5).astype(np.float32))
+    inv = 1.0 / (10000 ** (np.arange(D // 2) / (D // 2)))
+    ang = np.arange(max_p)[:, None] * inv[None, :]
+    cs = np.concatenate((np.cos(ang), np.sin(ang)), 1).astype(np.float32)
+    fathers = rng.integers(0, 3000, (N, Kf)).astype(np.int32)
+    s2p = rng.integers(0, max_p, slots).astype(np.int32)
+    out_slots = (3500 + np.arange(N)).astype(np.int32)
+    out_pos = rng.integers(0, max_p, N).astype(np.int32)
+    lat = rng.integers(0, n_lat, N).astype(np.int32)
+    lat[::17] = -1
+    resid = (rng.standard_normal((n_lat, 2 * Dtot)) * 0.2).astype(np.float32)
+    codes, scale, mn = od.quantize_pack_grouped(resid, group, bits)
+    kc, vc = to_bf16(k0), to_bf16(v0)
+    deltakv_less_memory_reconstruct_writeback_quantized(t(codes), t(scale), t(mn), t(lat), t(fathers), t(s2p), t(out_slots),
+                                                        t(out_pos), t(cs), kc, vc, quant_bits=bits, group_size=group)
+    ek, ev = k0.copy(), v0.copy()
+    od.reconstruct_writeback(ek, ev, packed=codes, scale=scale, mn=mn, latent_slots=lat, bits=bits, group_size=group,
+                             father_slots=fathers, slot_to_pos=s2p, out_slots=out_slots, out_pos=out_pos, cos_sin=cs)
+    np.testing.assert_allclose(kc.float().cpu().numpy(), ek, rtol=1e-2, atol=8e-3)
+    np.testing.assert_allclose(vc.float().cpu().numpy(), ev, rtol=1e-2, atol=8e-3)
+
+
+@pytest.mark.parametrize("bits", [2, 4, 8])
+def test_dequantize_grouped(golden, bits):
+    from sparse_vllm_amd.kernels.deltakv_kernels import dequantize_grouped
+    g = golden("deltakv")
+    if bits == 4:
+        out = dequantize_grouped(t(g["q4_code"]), t(g["q4_scale"]), t(g["q4_mn"]), 32, 64, 4)
+        np.testing.assert_allclose(out.cpu().numpy(), g["q4_deq"], rtol=1e-6, atol=1e-7)
+    rng = np.random.default_rng(bits)
+    x = rng.standard_normal((37, 512)).astype(np.float32)
+    code, scale, mn = od.quantize_pack_grouped(x, 32, bits)
+    out = dequantize_grouped(t(code), t(scale), t(mn), 32, 512, bits)
+    np.testing.assert_allclose(out.cpu().numpy(), od.dequantize_grouped(code, scale, mn, 32, bits), rtol=1e-6, atol=1e-7)
+    outb = dequantize_grouped(t(code), to_bf16(scale), to_bf16(mn), 32, 512, bits)
+    assert outb.dtype == torch.bfloat16
+    np.testing.assert_allclose(outb.float().cpu().numpy(),
+                               bf16_round(od.dequantize_grouped(code, bf16_round(scale), bf16_round(mn), 32, bits)),
+                               rtol=1e-2, atol=1e-6)
+
+
+def test_token_scores_and_sorted_topk():
+    from sparse_vllm_amd.kernels.deltakv_kernels import decode_softmax_token_scores, topk_sorted_desc
+    rng = np.random.default_rng(1)
+    B, H, L, sink, K = 3, 28, 5000, 8, 2048
+    raw = (rng.standard_normal((B, H, L)) * 4).astype(np.float32)
+    clens = np.array([4800, 2050, 100], np.int32)
+    ts = decode_softmax_token_scores(t(raw), candidate_start=sink, candidate_lens=t(clens), scale=128 ** -0.5,
+                                     round_dtype=torch.bfloat16)
+    ref = od.decode_softmax_token_scores(raw, sink=sink, compressed_lens=clens, scale=128 ** -0.5)
+    got = ts.cpu().numpy()
+    fill = float(torch.finfo(torch.bfloat16).min)
+    for b in range(B):
+        c = clens[b]
+        np.testing.assert_allclose(got[b, sink:sink + c], bf16_round(ref[b, :c]), rtol=2 ** -7, atol=1e-9)
+        assert (got[b, :sink] == fill).all() and (got[b, sink + c:] == fill).all()
+    # sorted top-k on the bf16-valued scores (many exact ties): order = score desc, index asc
+    search = np.ascontiguousarray(got[:, sink:])
+    idx = topk_sorted_desc(t(search), K, valid_len=t(clens), masked_value=-1e10).cpu().numpy()
+    for b in range(B):
+        s = np.where(np.arange(L - sink) < clens[b], search[b], np.float32(-1e10))
+        exp = np.argsort(-s, kind="stable")[:K]
+        np.testing.assert_array_equal(idx[b], exp)
