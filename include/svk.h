@@ -475,6 +475,38 @@ typedef struct SvkDequantGroupedArgs {
 } SvkDequantGroupedArgs;
 int svk_dequantize_grouped(const SvkDequantGroupedArgs* a, svk_stream_t stream);
 
+/* Decode stage 1 over a full-attention layer whose older tokens are KIVI-int4 blocks and whose newest
+ * tokens are raw bf16 rows; optional 3-D raw scores (observation layers).  Same partial format as
+ * svk_flash_decode_stage1.  Per token t of row r: raw_slots_map[r,t] >= 0 -> raw row, else block
+ * b = kivi_block_slots_map[r,t], local = t - kivi_block_start_pos[b] in [0, group_size):
+ *   K = code_K[b,h,d,local]*key_scales[b,h,d] + key_mins[b,h,d];  V = code_V[b,h,local,d]*vs[b,h,local,d/G] + vm
+ * (4-bit codes, 8 per int32, LSB first), both rounded to bf16 like `.to(q.dtype)`.
+ * Replaces full_layer_kivi_flash_decode_stage1, kernels/triton/deltakv_kernels.py:973-1142 (kernel :675-929). */
+typedef struct SvkKiviDecodeStage1Args {
+  const uint16_t* q;                 /* [B, Hq, D] bf16                                  */
+  const uint16_t* raw_k;             /* [slots, Hkv, D] bf16                             */
+  const uint16_t* raw_v;
+  const int32_t* raw_slots_map;      /* [rows, map_stride]                               */
+  const int32_t* kivi_block_slots_map; /* [rows, map_stride]                             */
+  const int32_t* kivi_block_start_pos; /* [blocks]                                       */
+  const int32_t* key_packed;         /* [blocks, Hkv, D, G/8]                            */
+  const uint16_t* key_scales;        /* [blocks, Hkv, D] bf16                            */
+  const uint16_t* key_mins;
+  const int32_t* value_packed;       /* [blocks, Hkv, G, D/8]                            */
+  const uint16_t* value_scales;      /* [blocks, Hkv, G, D/G] bf16                       */
+  const uint16_t* value_mins;
+  const int32_t* req_indices;        /* [B]                                              */
+  const int32_t* context_lens;       /* [B]                                              */
+  float* mid_o;                      /* [B, Hq, nblk, D]                                 */
+  float* mid_lse;                    /* [B, Hq, nblk]                                    */
+  float* attn_score;                 /* NULL or [B, Hq, W] raw logits                    */
+  int64_t q_stride_b, q_stride_h, raw_slot_stride, raw_head_stride, map_stride;
+  int64_t mid_o_stride_b, mid_o_stride_h, mid_o_stride_s, mid_lse_stride_b, mid_lse_stride_h;
+  int64_t score_stride_b, score_stride_h;
+  int32_t batch, num_q_heads, num_kv_heads, head_dim, max_len_in_batch, block_seq, group_size;
+} SvkKiviDecodeStage1Args;
+int svk_kivi_decode_stage1(const SvkKiviDecodeStage1Args* a, svk_stream_t stream);
+
 /* Observation-layer token scores for the query-aware top-k:
  *   s[b, t] = max_h softmax_{t in [start, start+len_b)} (raw[b,h,t] * scale), cast to `round_dtype`,
  *   everything outside the candidate range = fill_value.

@@ -218,3 +218,91 @@ def topk_sorted_desc(scores, k: int, *, valid_len=None, masked_value: float = -1
                                rows=rows, n=n, k=int(k))
     _lib.check(lib.svk_topk_sorted_desc(C.byref(a), _lib.current_stream_handle()), lib)
     return out
+
+
+def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_block_slots_map, kivi_block_start_pos,
+                                        key_packed, key_scales, key_mins, value_packed, value_scales, value_mins,
+                                        req_indices, context_lens, max_len_in_batch: int, mid_out, mid_out_logsumexp,
+                                        group_size: int, block_seq: int, block_n: int = 16, num_warps: int = 2,
+                                        num_stages: int = 3, attn_score=None):
+    """Decode stage 1 over KIVI-int4 blocks + raw tail (reference wrapper deltakv_kernels.py:973-1142; same
+    argument names and ValueErrors).  block_n / num_warps / num_stages are Triton launch knobs: validated,
+    otherwise unused (the HIP kernel tiles 32 tokens per wave)."""
+    for t in (q, raw_k, raw_v, raw_slots_map, kivi_block_slots_map, kivi_block_start_pos, key_packed, key_scales,
+              key_mins, value_packed, value_scales, value_mins, req_indices, context_lens, mid_out, mid_out_logsumexp):
+        assert t.is_cuda
+    if attn_score is not None:
+        assert attn_score.is_cuda
+        if attn_score.dim() != 3:
+            raise ValueError("Full-layer KIVI fused decode currently supports rank-3 attention scores only.")
+    if q.dim() != 3 or raw_k.dim() != 3 or raw_v.dim() != 3:
+        raise ValueError(f"Expected q/raw_k/raw_v rank-3 tensors, got {q.dim()}, {raw_k.dim()}, {raw_v.dim()}.")
+    if raw_slots_map.dim() != 2 or kivi_block_slots_map.dim() != 2:
+        raise ValueError("Full-layer KIVI decode maps must be rank-2 tensors.")
+    if tuple(raw_slots_map.shape) != tuple(kivi_block_slots_map.shape):
+        raise ValueError("Full-layer KIVI raw and block slot maps must have identical shapes, "
+                         f"got raw={tuple(raw_slots_map.shape)} block={tuple(kivi_block_slots_map.shape)}.")
+    batch = int(q.shape[0])
+    if int(req_indices.numel()) != batch or int(context_lens.numel()) != batch:
+        raise ValueError("Full-layer KIVI decode expects one req index/context length per batch item.")
+    head_dim = int(q.shape[-1])
+    if head_dim != int(raw_k.shape[-1]) or head_dim != int(raw_v.shape[-1]):
+        raise ValueError("Full-layer KIVI decode head_dim mismatch.")
+    if head_dim not in {64, 128}:
+        raise ValueError(f"Unsupported decode head_dim={head_dim}.")
+    group_size = int(group_size)
+    if group_size <= 0 or head_dim % group_size != 0:
+        raise ValueError(f"Invalid KIVI group_size={group_size} for head_dim={head_dim}.")
+    if group_size % 8 != 0 or head_dim % 8 != 0:
+        raise ValueError(f"int4 KIVI requires group_size/head_dim divisible by 8, got {group_size}/{head_dim}.")
+    block_seq, block_n = int(block_seq), int(block_n)
+    if block_seq <= 0 or block_seq % 16 != 0:
+        raise ValueError(f"block_seq must be a positive multiple of 16, got {block_seq}.")
+    if block_n <= 0 or block_n % 16 != 0 or block_seq % block_n != 0:
+        raise ValueError("block_n must be a positive multiple of 16 and divide block_seq, "
+                         f"got block_n={block_n}, block_seq={block_seq}.")
+    max_len_in_batch = int(max_len_in_batch)
+    if max_len_in_batch <= 0:
+        return
+    if max_len_in_batch > int(raw_slots_map.shape[1]):
+        raise ValueError("Full-layer KIVI max_len_in_batch exceeds map width: "
+                         f"max_len={max_len_in_batch} width={int(raw_slots_map.shape[1])}.")
+    num_kv_heads = int(raw_k.shape[1])
+    if int(raw_v.shape[1]) != num_kv_heads:
+        raise ValueError("Full-layer KIVI decode raw K/V head count mismatch.")
+    if int(key_packed.shape[1]) != num_kv_heads or int(value_packed.shape[1]) != num_kv_heads:
+        raise ValueError("Full-layer KIVI packed K/V head count mismatch.")
+    if int(q.shape[1]) % num_kv_heads != 0:
+        raise ValueError(f"Q heads must be divisible by KV heads, got {q.shape[1]}/{num_kv_heads}.")
+    assert q.dtype == torch.bfloat16 and raw_k.dtype == torch.bfloat16 and raw_v.dtype == torch.bfloat16
+    assert q.stride(2) == 1 and raw_k.stride(2) == 1 and raw_k.stride() == raw_v.stride()
+    assert raw_slots_map.dtype == torch.int32 and kivi_block_slots_map.dtype == torch.int32
+    assert raw_slots_map.stride(1) == 1 and raw_slots_map.stride() == kivi_block_slots_map.stride()
+    assert kivi_block_start_pos.dtype == torch.int32 and kivi_block_start_pos.is_contiguous()
+    for t in (key_packed, value_packed):
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    for t in (key_scales, key_mins, value_scales, value_mins):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    assert tuple(key_packed.shape[2:]) == (head_dim, group_size // 8)
+    assert tuple(value_packed.shape[2:]) == (group_size, head_dim // 8)
+    assert mid_out.dtype == torch.float32 and mid_out.stride(3) == 1 and mid_out_logsumexp.stride(2) == 1
+    if attn_score is not None:
+        assert attn_score.dtype == torch.float32 and attn_score.stride(2) == 1
+    lib = _lib.load()
+    a = _lib.SvkKiviDecodeStage1Args(
+        q=_lib.ptr(q), raw_k=_lib.ptr(raw_k), raw_v=_lib.ptr(raw_v), raw_slots_map=_lib.ptr(raw_slots_map),
+        kivi_block_slots_map=_lib.ptr(kivi_block_slots_map), kivi_block_start_pos=_lib.ptr(kivi_block_start_pos),
+        key_packed=_lib.ptr(key_packed), key_scales=_lib.ptr(key_scales), key_mins=_lib.ptr(key_mins),
+        value_packed=_lib.ptr(value_packed), value_scales=_lib.ptr(value_scales), value_mins=_lib.ptr(value_mins),
+        req_indices=_lib.ptr(req_indices.to(torch.int32).contiguous()),
+        context_lens=_lib.ptr(context_lens.to(torch.int32).contiguous()),
+        mid_o=_lib.ptr(mid_out), mid_lse=_lib.ptr(mid_out_logsumexp), attn_score=_lib.ptr(attn_score),
+        q_stride_b=q.stride(0), q_stride_h=q.stride(1), raw_slot_stride=raw_k.stride(0), raw_head_stride=raw_k.stride(1),
+        map_stride=raw_slots_map.stride(0), mid_o_stride_b=mid_out.stride(0), mid_o_stride_h=mid_out.stride(1),
+        mid_o_stride_s=mid_out.stride(2), mid_lse_stride_b=mid_out_logsumexp.stride(0),
+        mid_lse_stride_h=mid_out_logsumexp.stride(1),
+        score_stride_b=attn_score.stride(0) if attn_score is not None else 0,
+        score_stride_h=attn_score.stride(1) if attn_score is not None else 0,
+        batch=batch, num_q_heads=int(q.shape[1]), num_kv_heads=num_kv_heads, head_dim=head_dim,
+        max_len_in_batch=max_len_in_batch, block_seq=block_seq, group_size=group_size)
+    _lib.check(lib.svk_kivi_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)

@@ -608,6 +608,74 @@ def gen_deltakv():
     save("deltakv", **out)
 
 
+def gen_kivi():
+    """_full_layer_kivi_flash_decode_stage1_kernel under the interpreter (fp32 tensors holding bf16 values)."""
+    from sparsevllm.kernels.triton import deltakv_kernels as dk
+
+    out = {}
+    g = torch.Generator().manual_seed(55)
+    B, Hq, Hkv, D, G = 2, 8, 2, 64, 32
+    rows, max_len = 3, 160
+    lens = [150, 70]
+    req = torch.tensor([2, 0], dtype=torch.int32)
+    n_blocks, n_raw = 8, 96
+    raw_k = bf16f(torch.randn(n_raw, Hkv, D, generator=g) * 0.5)
+    raw_v = bf16f(torch.randn(n_raw, Hkv, D, generator=g) * 0.5)
+    key_packed = torch.randint(-2 ** 31, 2 ** 31 - 1, (n_blocks, Hkv, D, G // 8), generator=g, dtype=torch.int64).to(torch.int32)
+    value_packed = torch.randint(-2 ** 31, 2 ** 31 - 1, (n_blocks, Hkv, G, D // 8), generator=g, dtype=torch.int64).to(torch.int32)
+    key_scales = bf16f(torch.rand(n_blocks, Hkv, D, generator=g) * 0.08)
+    key_mins = bf16f(-torch.rand(n_blocks, Hkv, D, generator=g) * 0.6)
+    value_scales = bf16f(torch.rand(n_blocks, Hkv, G, D // G, generator=g) * 0.08)
+    value_mins = bf16f(-torch.rand(n_blocks, Hkv, G, D // G, generator=g) * 0.6)
+    raw_map = torch.full((rows, max_len), -1, dtype=torch.int32)
+    blk_map = torch.full((rows, max_len), -1, dtype=torch.int32)
+    blk_start = torch.zeros(n_blocks, dtype=torch.int32)
+    # row 2 (lane 0): sink 8 raw, 4 KIVI blocks (tokens 8..135), raw tail; row 0 (lane 1): sink 8 raw, 1 block, raw tail
+    perm = torch.randperm(n_raw, generator=g).to(torch.int32)
+    used = 0
+    def put_raw(r, a, b_):
+        nonlocal used
+        raw_map[r, a:b_] = perm[used: used + (b_ - a)]
+        used += b_ - a
+    put_raw(2, 0, 8)
+    for i, bslot in enumerate([5, 1, 6, 2]):
+        blk_map[2, 8 + 32 * i: 8 + 32 * (i + 1)] = bslot
+        blk_start[bslot] = 8 + 32 * i
+    put_raw(2, 136, 150)
+    put_raw(0, 0, 8)
+    blk_map[0, 8:40] = 4
+    blk_start[4] = 8
+    put_raw(0, 40, 70)
+    q = bf16f(torch.randn(B, Hq, D, generator=g) * 0.5)
+    clens = torch.tensor(lens, dtype=torch.int32)
+    block_seq = 64
+    nblk = (max(lens) + block_seq - 1) // block_seq
+    mid = torch.zeros(B, Hq, nblk, D); lse = torch.zeros(B, Hq, nblk)
+    score = torch.full((B, Hq, max(lens)), -1e20)
+    grid = (B, Hkv, nblk)
+    dk._full_layer_kivi_flash_decode_stage1_kernel[grid](
+        q, raw_k, raw_v, raw_map, blk_map, blk_start, key_packed, key_scales, key_mins, value_packed, value_scales,
+        value_mins, req, clens, mid, lse, score,
+        q.stride(0), q.stride(1), q.stride(2), raw_k.stride(0), raw_k.stride(1), raw_k.stride(2),
+        raw_v.stride(0), raw_v.stride(1), raw_v.stride(2), raw_map.stride(0), raw_map.stride(1),
+        blk_map.stride(0), blk_map.stride(1),
+        key_packed.stride(0), key_packed.stride(1), key_packed.stride(2), key_packed.stride(3),
+        key_scales.stride(0), key_scales.stride(1), key_scales.stride(2),
+        value_packed.stride(0), value_packed.stride(1), value_packed.stride(2), value_packed.stride(3),
+        value_scales.stride(0), value_scales.stride(1), value_scales.stride(2), value_scales.stride(3),
+        mid.stride(0), mid.stride(1), mid.stride(2), mid.stride(3), lse.stride(0), lse.stride(1), lse.stride(2),
+        score.stride(0), score.stride(1), score.stride(2),
+        sm_scale=1.0 / (D ** 0.5), gqa_group_size=Hq // Hkv, Q_HEAD_NUM=16, BLOCK_SEQ=block_seq, BLOCK_DMODEL=D,
+        BLOCK_N=16, GROUP_SIZE=G, FEAT_PER_INT=8, QUANT_MASK=15, STORE_SCORE=True)
+    out.update(q=bits(q), raw_k=bits(raw_k), raw_v=bits(raw_v), raw_map=raw_map.numpy(), blk_map=blk_map.numpy(),
+               blk_start=blk_start.numpy(), key_packed=key_packed.numpy(), key_scales=bits(key_scales),
+               key_mins=bits(key_mins), value_packed=value_packed.numpy(), value_scales=bits(value_scales),
+               value_mins=bits(value_mins), req=req.numpy(), lens=clens.numpy(),
+               cfg=np.array([G, block_seq, max(lens)], dtype=np.int64), mid_o=mid.numpy(), mid_lse=lse.numpy(),
+               score=score.numpy())
+    save("kivi", **out)
+
+
 GROUPS = {
     "decode": gen_decode,
     "h2o_select": gen_h2o_select,
@@ -617,6 +685,7 @@ GROUPS = {
     "quest": gen_quest,
     "prefill_score": gen_prefill_score,
     "deltakv": gen_deltakv,
+    "kivi": gen_kivi,
 }
 
 

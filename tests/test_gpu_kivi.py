@@ -1,0 +1,192 @@
+"""GPU parity of the KIVI-int4 full-layer decode stage 1 through the C ABI.
+
+Tolerances: vs the oracle with bf16-rounded dequantised K/V (the real-model data flow, `.to(q.dtype)`):
+partials rtol = atol = 2e-2 (the reference's own bar for decode partials), raw scores atol 1e-4 + rtol 1e-5
+(fp32 accumulation of exact bf16 products).  The committed fixture was produced by the reference kernel
+under the Triton interpreter on fp32 tensors, where dequantised K/V are NOT rounded to bf16, so against it
+scores get the bf16 rounding slack of K (2^-8 relative per element)."""
+
+import numpy as np
+import pytest
+
+from oracle import bf16_bits_to_f32, bf16_round, f32_to_bf16_bits
+from oracle import deltakv as od
+from oracle import kivi as ok
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ATTN_TOL = 2e-2
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev())
+
+
+def bf(x_bits):
+    return torch.from_numpy(np.ascontiguousarray(x_bits).view(np.int16).copy()).to(dev()).view(torch.bfloat16)
+
+
+def run_gpu(inp_bits, maps, *, max_len, G, block_seq, score_shape=None):
+    from sparse_vllm_amd.kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1
+    q = bf(inp_bits["q"])
+    B, Hq, D = q.shape
+    nblk = (max_len + block_seq - 1) // block_seq
+    mid = torch.full((B, Hq, nblk, D), 7.0, dtype=torch.float32, device=dev())
+    lse = torch.full((B, Hq, nblk), 7.0, dtype=torch.float32, device=dev())
+    score = None if score_shape is None else torch.full(score_shape, -1e20, dtype=torch.float32, device=dev())
+    full_layer_kivi_flash_decode_stage1(
+        q=q, raw_k=bf(inp_bits["raw_k"]), raw_v=bf(inp_bits["raw_v"]), raw_slots_map=t(maps["raw_map"]),
+        kivi_block_slots_map=t(maps["blk_map"]), kivi_block_start_pos=t(maps["blk_start"]),
+        key_packed=t(inp_bits["key_packed"]), key_scales=bf(inp_bits["key_scales"]), key_mins=bf(inp_bits["key_mins"]),
+        value_packed=t(inp_bits["value_packed"]), value_scales=bf(inp_bits["value_scales"]),
+        value_mins=bf(inp_bits["value_mins"]), req_indices=t(maps["req"]), context_lens=t(maps["lens"]),
+        max_len_in_batch=max_len, mid_out=mid, mid_out_logsumexp=lse, group_size=G, block_seq=block_seq,
+        attn_score=score)
+    torch.cuda.synchronize()
+    return mid.cpu().numpy(), lse.cpu().numpy(), None if score is None else score.cpu().numpy()
+
+
+def run_oracle(inp_bits, maps, *, max_len, G, block_seq, score_shape=None):
+    f = bf16_bits_to_f32
+    score = None if score_shape is None else np.full(score_shape, -1e20, np.float32)
+    mid, lse = ok.full_layer_kivi_flash_decode_stage1(
+        q=f(inp_bits["q"]), raw_k=f(inp_bits["raw_k"]), raw_v=f(inp_bits["raw_v"]), raw_slots_map=maps["raw_map"],
+        kivi_block_slots_map=maps["blk_map"], kivi_block_start_pos=maps["blk_start"], key_packed=inp_bits["key_packed"],
+        key_scales=f(inp_bits["key_scales"]), key_mins=f(inp_bits["key_mins"]), value_packed=inp_bits["value_packed"],
+        value_scales=f(inp_bits["value_scales"]), value_mins=f(inp_bits["value_mins"]), req_indices=maps["req"],
+        context_lens=maps["lens"], max_len_in_batch=max_len, group_size=G, block_seq=block_seq, attn_score=score)
+    return mid, lse, score
+
+
+def valid_blocks(lens, block_seq, nblk):
+    return (np.arange(nblk)[None, :] * block_seq) < np.asarray(lens)[:, None]
+
+
+def compare(got, ref, lens, block_seq, score_tol=(1e-5, 1e-4)):
+    mid, lse, score = got
+    mid_r, lse_r, score_r = ref
+    vb = valid_blocks(lens, block_seq, mid.shape[2])
+    for b in range(mid.shape[0]):
+        np.testing.assert_allclose(lse[b][:, vb[b]], lse_r[b][:, vb[b]], rtol=ATTN_TOL, atol=ATTN_TOL)
+        np.testing.assert_allclose(mid[b][:, vb[b]], mid_r[b][:, vb[b]], rtol=ATTN_TOL, atol=ATTN_TOL)
+        assert np.all(np.isneginf(lse[b][:, ~vb[b]])) and not mid[b][:, ~vb[b]].any()
+    if score is not None:
+        np.testing.assert_allclose(score, score_r, rtol=score_tol[0], atol=score_tol[1])
+
+
+def test_kivi_stage1_golden(golden):
+    g = golden("kivi")
+    G, block_seq, max_len = (int(x) for x in g["cfg"])
+    maps = dict(raw_map=g["raw_map"], blk_map=g["blk_map"], blk_start=g["blk_start"], req=g["req"], lens=g["lens"])
+    got = run_gpu(g, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=g["score"].shape)
+    # reference fixture (no bf16 rounding of dequantised K/V inside the interpreter run)
+    compare(got, (g["mid_o"], g["mid_lse"], g["score"]), g["lens"], block_seq, score_tol=(2e-2, 5e-2))
+    # oracle with the real bf16 data flow: tight
+    compare(got, run_oracle(g, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=g["score"].shape),
+            g["lens"], block_seq)
+
+
+def make_case(rng, *, B, Hq, Hkv, D, G, lens, rows, raw_tail, sink):
+    """Rows = [sink raw tokens | KIVI blocks of G tokens | raw tail]; block slots and raw slots scattered."""
+    f2b = f32_to_bf16_bits
+    max_len = int(max(lens))
+    width = max_len + 5
+    n_blocks_row = [max(0, (int(n) - sink - raw_tail)) // G for n in lens]
+    n_blocks = sum(n_blocks_row) + 3
+    n_raw = sum(int(n) - nb * G for n, nb in zip(lens, n_blocks_row)) + 7
+    raw_map = np.full((rows, width), -1, np.int32)
+    blk_map = np.full((rows, width), -1, np.int32)
+    blk_start = np.zeros(n_blocks, np.int32)
+    req = rng.permutation(rows)[:B].astype(np.int32)
+    raw_perm = rng.permutation(n_raw).astype(np.int32)
+    blk_perm = rng.permutation(n_blocks).astype(np.int32)
+    ru = bu = 0
+    for b in range(B):
+        r, n, nb = int(req[b]), int(lens[b]), n_blocks_row[b]
+        s = min(sink, n)
+        raw_map[r, :s] = raw_perm[ru: ru + s]; ru += s
+        for i in range(nb):
+            bs = int(blk_perm[bu]); bu += 1
+            blk_map[r, s + i * G: s + (i + 1) * G] = bs
+            blk_start[bs] = s + i * G
+        tail0 = s + nb * G
+        raw_map[r, tail0:n] = raw_perm[ru: ru + n - tail0]; ru += n - tail0
+    kdata = rng.standard_normal((n_blocks, Hkv, D, G)).astype(np.float32)
+    vdata = rng.standard_normal((n_blocks, Hkv, G, D)).astype(np.float32)
+    kc, ks, km = od.quantize_pack_grouped(kdata.reshape(-1, G), G, 4)
+    vc, vs, vm = od.quantize_pack_grouped(vdata.reshape(-1, D), G, 4)
+    bits = dict(
+        q=f2b(rng.standard_normal((B, Hq, D)).astype(np.float32)),
+        raw_k=f2b(rng.standard_normal((n_raw, Hkv, D)).astype(np.float32)),
+        raw_v=f2b(rng.standard_normal((n_raw, Hkv, D)).astype(np.float32)),
+        key_packed=kc.reshape(n_blocks, Hkv, D, G // 8).astype(np.int32),
+        key_scales=f2b(ks.reshape(n_blocks, Hkv, D)), key_mins=f2b(km.reshape(n_blocks, Hkv, D)),
+        value_packed=vc.reshape(n_blocks, Hkv, G, D // 8).astype(np.int32),
+        value_scales=f2b(vs.reshape(n_blocks, Hkv, G, D // G)), value_mins=f2b(vm.reshape(n_blocks, Hkv, G, D // G)))
+    maps = dict(raw_map=raw_map, blk_map=blk_map, blk_start=blk_start, req=req, lens=np.asarray(lens, np.int32))
+    return bits, maps, max_len
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,G,block_seq,with_score", [
+    (28, 4, 128, 32, 128, True),       # Qwen2.5-7B heads (paper config), observation layer
+    (28, 4, 128, 32, 64, False),
+    (32, 8, 128, 32, 96, True),        # Llama-3.1-8B heads
+    (16, 2, 64, 32, 48, True),
+    (8, 8, 64, 64, 32, False),         # MHA, one group per head
+])
+def test_kivi_stage1_random(Hq, Hkv, D, G, block_seq, with_score):
+    rng = np.random.default_rng(Hq * 131 + block_seq)
+    lens = [517, 64, 9, 300]
+    bits, maps, max_len = make_case(rng, B=4, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=lens, rows=6, raw_tail=40, sink=8)
+    shape = (4, Hq, max_len) if with_score else None
+    got = run_gpu(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
+    ref = run_oracle(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
+    compare(got, ref, lens, block_seq)
+
+
+def test_kivi_stage1_all_raw_matches_plain_stage1():
+    """With no KIVI block the kernel is the ordinary slot-table decode: compare with svk_flash_decode_stage1."""
+    from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import flash_decode_stage1
+    rng = np.random.default_rng(5)
+    B, Hq, Hkv, D, G, block_seq = 3, 28, 4, 128, 32, 64
+    lens = [200, 33, 128]
+    bits, maps, max_len = make_case(rng, B=B, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=lens, rows=3, raw_tail=10**6, sink=0)
+    assert (maps["blk_map"] < 0).all()
+    mid, lse, _ = run_gpu(bits, maps, max_len=max_len, G=G, block_seq=block_seq)
+    nblk = (max_len + block_seq - 1) // block_seq
+    mid2 = torch.zeros((B, Hq, nblk, D), dtype=torch.float32, device=dev())
+    lse2 = torch.zeros((B, Hq, nblk), dtype=torch.float32, device=dev())
+    flash_decode_stage1(bf(bits["q"]), bf(bits["raw_k"]), bf(bits["raw_v"]), t(maps["raw_map"]), t(maps["req"]),
+                        t(maps["lens"]), max_len, mid2, lse2, block_seq)
+    torch.cuda.synchronize()
+    vb = valid_blocks(lens, block_seq, nblk)
+    for b in range(B):
+        np.testing.assert_allclose(mid[b][:, vb[b]], mid2.cpu().numpy()[b][:, vb[b]], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(lse[b][:, vb[b]], lse2.cpu().numpy()[b][:, vb[b]], rtol=1e-6, atol=1e-6)
+
+
+def test_kivi_stage1_validation():
+    from sparse_vllm_amd.kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1
+    rng = np.random.default_rng(1)
+    bits, maps, max_len = make_case(rng, B=1, Hq=8, Hkv=2, D=64, G=32, lens=[80], rows=1, raw_tail=8, sink=8)
+    kw = dict(q=bf(bits["q"]), raw_k=bf(bits["raw_k"]), raw_v=bf(bits["raw_v"]), raw_slots_map=t(maps["raw_map"]),
+              kivi_block_slots_map=t(maps["blk_map"]), kivi_block_start_pos=t(maps["blk_start"]),
+              key_packed=t(bits["key_packed"]), key_scales=bf(bits["key_scales"]), key_mins=bf(bits["key_mins"]),
+              value_packed=t(bits["value_packed"]), value_scales=bf(bits["value_scales"]), value_mins=bf(bits["value_mins"]),
+              req_indices=t(maps["req"]), context_lens=t(maps["lens"]), max_len_in_batch=max_len,
+              mid_out=torch.zeros((1, 8, 2, 64), device=dev()), mid_out_logsumexp=torch.zeros((1, 8, 2), device=dev()),
+              group_size=32, block_seq=64)
+    with pytest.raises(ValueError, match="block_seq must be a positive multiple of 16"):
+        full_layer_kivi_flash_decode_stage1(**{**kw, "block_seq": 40})
+    with pytest.raises(ValueError, match="Invalid KIVI group_size"):
+        full_layer_kivi_flash_decode_stage1(**{**kw, "group_size": 48})
+    with pytest.raises(ValueError, match="exceeds map width"):
+        full_layer_kivi_flash_decode_stage1(**{**kw, "max_len_in_batch": 4096})
+    with pytest.raises(ValueError, match="rank-3 attention scores only"):
+        full_layer_kivi_flash_decode_stage1(**{**kw, "attn_score": torch.zeros((1, 80), device=dev())})
+    full_layer_kivi_flash_decode_stage1(**{**kw, "max_len_in_batch": 0})      # no-op like the reference
