@@ -475,6 +475,27 @@ typedef struct SvkDequantGroupedArgs {
 } SvkDequantGroupedArgs;
 int svk_dequantize_grouped(const SvkDequantGroupedArgs* a, svk_stream_t stream);
 
+/* Attention-facing contiguous copy of a DeltaKV sparse layer's active slots: entry n = b*width + w takes slot
+ * active_slots[b, w] (clamped into [0, num_slots)); V is copied; K is copied when postrope_mask[slot] != 0,
+ * otherwise (optional RMS k-norm, then) rotated at slot_to_pos[slot] (clamped at 0).  Every entry is written.
+ * Replaces deltakv_materialize_sparse_view, kernels/triton/deltakv_kernels.py:3489-3585 (kernel :3588-3693);
+ * caller get_layer_compute_view, engine/cache_manager/deltakv_less_memory.py:1344-1402. */
+typedef struct SvkDeltakvMaterializeArgs {
+  const int32_t* active_slots;     /* [batch, width] (active_stride)                          */
+  const int32_t* slot_to_pos;      /* [num_slots]                                             */
+  const uint8_t* postrope_mask;    /* NULL or [num_slots] bool                                */
+  const uint16_t* k_cache;         /* [num_slots, Hkv, D] bf16 (kv_slot_stride/kv_head_stride) */
+  const uint16_t* v_cache;
+  uint16_t* out_k;                 /* [>= batch*width, Hkv, D] bf16 (out_slot_stride/out_head_stride) */
+  uint16_t* out_v;
+  const void* cos_sin;             /* [max_pos, D]: cos | sin halves (cos_dtype)              */
+  const float* k_norm_weight;      /* NULL or [D] f32                                         */
+  int64_t active_stride, kv_slot_stride, kv_head_stride, out_slot_stride, out_head_stride, cos_stride;
+  float k_norm_eps;
+  int32_t batch, width, num_slots, num_kv_heads, head_dim, cos_dtype;
+} SvkDeltakvMaterializeArgs;
+int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeArgs* a, svk_stream_t stream);
+
 /* Decode stage 1 over a full-attention layer whose older tokens are KIVI-int4 blocks and whose newest
  * tokens are raw bf16 rows; optional 3-D raw scores (observation layers).  Same partial format as
  * svk_flash_decode_stage1.  Per token t of row r: raw_slots_map[r,t] >= 0 -> raw row, else block
@@ -490,8 +511,8 @@ typedef struct SvkKiviDecodeStage1Args {
   const int32_t* kivi_block_slots_map; /* [rows, map_stride]                             */
   const int32_t* kivi_block_start_pos; /* [blocks]                                       */
   const int32_t* key_packed;         /* [blocks, Hkv, D, G/8]                            */
-  const uint16_t* key_scales;        /* [blocks, Hkv, D] bf16                            */
-  const uint16_t* key_mins;
+  const void* key_scales;            /* [blocks, Hkv, D] f32 or bf16 (key_param_dtype)   */
+  const void* key_mins;
   const int32_t* value_packed;       /* [blocks, Hkv, G, D/8]                            */
   const uint16_t* value_scales;      /* [blocks, Hkv, G, D/G] bf16                       */
   const uint16_t* value_mins;
@@ -504,6 +525,7 @@ typedef struct SvkKiviDecodeStage1Args {
   int64_t mid_o_stride_b, mid_o_stride_h, mid_o_stride_s, mid_lse_stride_b, mid_lse_stride_h;
   int64_t score_stride_b, score_stride_h;
   int32_t batch, num_q_heads, num_kv_heads, head_dim, max_len_in_batch, block_seq, group_size;
+  int32_t key_param_dtype;           /* SVK_DTYPE_F32 (reference manager) or SVK_DTYPE_BF16 */
 } SvkKiviDecodeStage1Args;
 int svk_kivi_decode_stage1(const SvkKiviDecodeStage1Args* a, svk_stream_t stream);
 

@@ -192,6 +192,44 @@ def reconstruct_writeback(k_cache, v_cache, *, father_slots, slot_to_pos, out_sl
 
 
 # ------------------------------------------------------------------------------------------------
+# attention-facing copy of a sparse layer's active slots (deltakv_kernels.py:3489-3693)
+# ------------------------------------------------------------------------------------------------
+
+def materialize_sparse_view(active_slots, slot_to_pos, k_cache, v_cache, cos_sin, *, postrope_mask=None,
+                            k_norm_weight=None, k_norm_eps=1e-6, out_bf16=True):
+    """-> (out_k, out_v) [B*W, Hkv, D]: entry n = b*W + w copies slot active_slots[b, w] (clamped into range);
+    K is k-normed (optional) and rotated at slot_to_pos[slot] (clamped at 0) unless the slot is flagged
+    post-RoPE, in which case it is copied verbatim (kernel :3636-3681).  Every entry is written (no length mask)."""
+    B, W = active_slots.shape
+    S, Hkv, D = k_cache.shape
+    HD2 = D // 2
+    flat = np.clip(active_slots.reshape(-1).astype(np.int64), 0, S - 1)
+    valid = (active_slots.reshape(-1) >= 0) & (active_slots.reshape(-1) < S)
+    pos = np.maximum(slot_to_pos[flat].astype(np.int64), 0)
+    k = k_cache[flat].astype(np.float32)
+    k1, k2 = k[..., :HD2], k[..., HD2:]
+    if k_norm_weight is not None:
+        w = k_norm_weight.astype(np.float32)
+        var = (k1 * k1 + k2 * k2).sum(axis=-1) / np.float32(D)
+        rstd = (1.0 / np.sqrt(var + np.float32(k_norm_eps))).astype(np.float32)
+        n1 = k1 * rstd[..., None] * w[None, None, :HD2]
+        n2 = k2 * rstd[..., None] * w[None, None, HD2:]
+    else:
+        n1, n2 = k1, k2
+    cs = cos_sin.astype(np.float32)[pos]
+    c, s_ = cs[:, None, :HD2], cs[:, None, HD2:]
+    r1 = n1 * c - n2 * s_
+    r2 = n2 * c + n1 * s_
+    if postrope_mask is not None:
+        already = (postrope_mask[flat].astype(bool) & valid)[:, None, None]
+        r1 = np.where(already, k1, r1)
+        r2 = np.where(already, k2, r2)
+    out_k = np.concatenate((r1, r2), axis=-1).astype(np.float32)
+    out_v = v_cache[flat].astype(np.float32)
+    return (bf16_round(out_k) if out_bf16 else out_k), out_v
+
+
+# ------------------------------------------------------------------------------------------------
 # query-aware top-k over the compressed range (sparse_controller.py:255-299, :1813-1822)
 # ------------------------------------------------------------------------------------------------
 

@@ -181,6 +181,15 @@ class SvkTopkSortedArgs(C.Structure):
                 ("masked_value", _f32), ("rows", _i32), ("n", _i32), ("k", _i32)]
 
 
+class SvkDeltakvMaterializeArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("active_slots", "slot_to_pos", "postrope_mask", "k_cache", "v_cache", "out_k", "out_v",
+                                  "cos_sin", "k_norm_weight")] + \
+               [(n, _i64) for n in ("active_stride", "kv_slot_stride", "kv_head_stride", "out_slot_stride",
+                                    "out_head_stride", "cos_stride")] + \
+               [("k_norm_eps", _f32)] + \
+               [(n, _i32) for n in ("batch", "width", "num_slots", "num_kv_heads", "head_dim", "cos_dtype")]
+
+
 class SvkKiviDecodeStage1Args(C.Structure):
     _fields_ = [(n, _p) for n in ("q", "raw_k", "raw_v", "raw_slots_map", "kivi_block_slots_map", "kivi_block_start_pos",
                                   "key_packed", "key_scales", "key_mins", "value_packed", "value_scales", "value_mins",
@@ -189,7 +198,7 @@ class SvkKiviDecodeStage1Args(C.Structure):
                                     "mid_o_stride_b", "mid_o_stride_h", "mid_o_stride_s", "mid_lse_stride_b",
                                     "mid_lse_stride_h", "score_stride_b", "score_stride_h")] + \
                [(n, _i32) for n in ("batch", "num_q_heads", "num_kv_heads", "head_dim", "max_len_in_batch", "block_seq",
-                                    "group_size")]
+                                    "group_size", "key_param_dtype")]
 
 
 # symbol -> (argtypes) ; every entry point declared in include/svk.h
@@ -214,6 +223,7 @@ ENTRY_POINTS = {
     "svk_dequantize_grouped": ([C.POINTER(SvkDequantGroupedArgs), _p], C.c_int),
     "svk_deltakv_token_scores": ([C.POINTER(SvkDeltakvTokenScoresArgs), _p], C.c_int),
     "svk_topk_sorted_desc": ([C.POINTER(SvkTopkSortedArgs), _p], C.c_int),
+    "svk_deltakv_materialize_sparse_view": ([C.POINTER(SvkDeltakvMaterializeArgs), _p], C.c_int),
     "svk_kivi_decode_stage1": ([C.POINTER(SvkKiviDecodeStage1Args), _p], C.c_int),
     "svk_quest_page_minmax": ([C.POINTER(SvkQuestPageMinmaxArgs), _p], C.c_int),
     "svk_quest_score_pages": ([C.POINTER(SvkQuestScorePagesArgs), _p], C.c_int),

@@ -124,6 +124,38 @@ class Config:
     h2o_prefill_budget: int = 8192
     h2o_recent_ratio: float = 0.5
     h2o_prefill_score_window: int = 128
+    # DeltaKV (configs/groups.py:50-52,104-148; configs/delta.py)
+    full_attn_layers: str | list[int] = "0"
+    obs_layer_ids: list[int] = field(default=None, init=False)
+    rope_theta: float = 1000000.0
+    deltakv_path: str | None = None
+    allow_missing_deltakv_path: bool = False
+    deltakv_k_neighbors: int = 4
+    cluster_ratio: float = 0.1
+    kv_compressed_size: int = 128
+    kv_quant_bits: int = 4
+    kv_quant_group_size: int = 0
+    full_layer_kv_quant_bits: int = 0
+    full_layer_kivi_group_size: int = 32
+    full_layer_kivi_residual_length: int = 32
+    full_layer_kivi_decode_block_seq: int = 256
+    full_layer_kivi_decode_block_n: int = 16
+    full_layer_kivi_decode_num_warps: int = 2
+    full_layer_kivi_decode_num_stages: int = 3
+    enable_full_layer_kivi_quant: bool = True
+    use_compression: bool = True
+    use_nonlinear_compressor: bool = True
+    compressor_intermediate_size: int = 2048
+    compressor_linear_bias: bool = True
+    compressor_down_type: str = "auto"
+    compressor_up_type: str = "auto"
+    compressor_down_intermediate_size: int = -1
+    compressor_up_intermediate_size: int = -1
+    deltakv_full_pool_reserve_ratio: float = 0.1
+    deltakv_sparse_decode_backend: str = "custom"
+    deltakv_num_latent_slots: int = 0          # 0 -> derived by the cache manager
+    deltakv_num_full_layer_slots: int = 0
+    deltakv_num_kivi_blocks: int = 0
 
     def __post_init__(self):
         self.vllm_sparse_method = normalize_sparse_method(self.vllm_sparse_method)
@@ -137,6 +169,9 @@ class Config:
         self._normalize_sparse_prefill_score()
         if self.vllm_sparse_method == "h2o":
             self._normalize_h2o()
+        self._normalize_sparse_layout()
+        if self.vllm_sparse_method == "deltakv":
+            self._normalize_deltakv()
         if self.num_attention_heads % self.num_key_value_heads:
             raise ValueError("num_attention_heads must be divisible by num_key_value_heads")
         if self.num_key_value_heads % self.tp_size or self.num_attention_heads % self.tp_size:
@@ -188,6 +223,68 @@ class Config:
             raise ValueError("h2o_prefill_score_window must be in [1, 128] because the prefill score kernel supports "
                              f"at most 128 query tokens, got {self.h2o_prefill_score_window}.")
 
+    # configs/sparse.py:33-37, :240-257 (every layer of this build's models has a KV cache)
+    def _normalize_sparse_layout(self):
+        if isinstance(self.full_attn_layers, str):
+            layers = self.full_attn_layers.strip()
+            self.full_attn_layers = [] if not layers else [int(x) for x in layers.split(",")]
+        self.full_attn_layers = [int(x) for x in self.full_attn_layers]
+        unknown = sorted(l for l in self.full_attn_layers if not 0 <= l < self.num_hidden_layers)
+        if unknown and self.vllm_sparse_method in {"omnikv", "deltakv"}:
+            raise ValueError("full_attn_layers must contain KV/full-attention layer indices for "
+                             f"{self.vllm_sparse_method}; non-KV layers={unknown}.")
+        configured = set(self.full_attn_layers)
+        self.obs_layer_ids = [l for l in self.full_attn_layers
+                              if 0 <= l and l + 1 < self.num_hidden_layers and (l + 1) not in configured]
+
+    # configs/delta.py:43-160 (normalize_deltakv_storage + validate_deltakv_runtime, slim runtime rules)
+    def _normalize_deltakv(self):
+        for attr in ("compressor_down_type", "compressor_up_type"):
+            v = getattr(self, attr)
+            v = "auto" if v is None else str(v).strip().lower()
+            setattr(self, attr, v or "auto")
+        if not self.use_compression:
+            raise ValueError("DeltaKV runtime is compressor-only; set use_compression=True.")
+        if self.deltakv_path is None and not self.allow_missing_deltakv_path:
+            raise ValueError("DeltaKV requires deltakv_path for compressor sparse layers. "
+                             "Set allow_missing_deltakv_path=True only for construction-only tests.")
+        self.kv_quant_bits = int(self.kv_quant_bits or 0)
+        if self.kv_quant_bits not in (0, 4):
+            raise ValueError("DeltaKV slim runtime supports sparse compressor residual bits 0 or 4 only, "
+                             f"got kv_quant_bits={self.kv_quant_bits}.")
+        self.full_layer_kv_quant_bits = int(self.full_layer_kv_quant_bits or 0)
+        if self.full_layer_kv_quant_bits not in (0, 4):
+            raise ValueError("DeltaKV slim runtime supports full-layer storage bits 0 or 4 only, "
+                             f"got full_layer_kv_quant_bits={self.full_layer_kv_quant_bits}.")
+        self.kv_quant_group_size = int(self.kv_quant_group_size or 0)
+        if self.kv_quant_group_size < 0:
+            raise ValueError(f"kv_quant_group_size must be >= 0, got {self.kv_quant_group_size}.")
+        self.full_layer_kivi_group_size = int(self.full_layer_kivi_group_size or 32)
+        if self.full_layer_kivi_group_size <= 0:
+            raise ValueError(f"full_layer_kivi_group_size must be > 0, got {self.full_layer_kivi_group_size}.")
+        self.full_layer_kivi_residual_length = int(self.full_layer_kivi_residual_length or self.full_layer_kivi_group_size)
+        if self.full_layer_kivi_residual_length <= 0:
+            raise ValueError(f"full_layer_kivi_residual_length must be > 0, got {self.full_layer_kivi_residual_length}.")
+        bs = int(self.full_layer_kivi_decode_block_seq or 256)
+        if bs <= 0 or bs % 16:
+            raise ValueError(f"full_layer_kivi_decode_block_seq must be a positive multiple of 16, got {bs}.")
+        self.full_layer_kivi_decode_block_seq = bs
+        if not 0.0 <= float(self.deltakv_full_pool_reserve_ratio) < 1.0:
+            raise ValueError("deltakv_full_pool_reserve_ratio must be in [0, 1), "
+                             f"got {self.deltakv_full_pool_reserve_ratio}.")
+        if int(self.deltakv_k_neighbors) <= 0:
+            raise ValueError(f"deltakv_k_neighbors must be > 0, got {self.deltakv_k_neighbors}.")
+        backend = str(self.deltakv_sparse_decode_backend or "auto").strip().lower()
+        if backend not in {"auto", "custom", "fa2"}:
+            raise ValueError("deltakv_sparse_decode_backend must be one of 'auto', 'custom', or 'fa2', "
+                             f"got {self.deltakv_sparse_decode_backend!r}.")
+        if backend == "fa2":
+            raise ValueError("deltakv_sparse_decode_backend='fa2' requires the flash_attn package; "
+                             "use 'custom' or leave it as 'auto' when flash_attn is not installed.")
+        self.deltakv_sparse_decode_backend = "custom"
+        if not self.full_attn_layers:
+            raise ValueError("DeltaKV needs at least one full-attention (observation) layer in full_attn_layers.")
+
     # configs/sparse.py:101-127
     def _normalize_sparse_prefill_score(self):
         mode = str(self.sparse_prefill_score_mode).strip().lower()
@@ -206,7 +303,8 @@ class Config:
     @property
     def hf_config(self):
         return SimpleNamespace(num_hidden_layers=self.num_hidden_layers, num_attention_heads=self.num_attention_heads,
-                               num_key_value_heads=self.num_key_value_heads, head_dim=self.head_dim)
+                               num_key_value_heads=self.num_key_value_heads, head_dim=self.head_dim,
+                               rope_theta=self.rope_theta, torch_dtype="bfloat16")
 
     @classmethod
     def from_kwargs(cls, **kwargs) -> "Config":

@@ -11,7 +11,7 @@ namespace {
 
 constexpr int kTile = 32;
 
-template <int D, int G>
+template <int D, int G, bool KF32>
 __global__ void __launch_bounds__(512) kivi_stage1_kernel(const SvkKiviDecodeStage1Args a) {
   constexpr int NC = D / 32, JQ = (G + 3) / 4, PH = JQ * 4, DC = D / 8, TQ = 64 / DC, NV = kTile / TQ;
   constexpr int WAVE_FLOATS = kTile * PH + 16;
@@ -80,16 +80,31 @@ __global__ void __launch_bounds__(512) kivi_stage1_kernel(const SvkKiviDecodeSta
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int d0 = c * 32 + jq * 8;
-      const uint4 sc = *reinterpret_cast<const uint4*>(a.key_scales + hb * D + d0);
-      const uint4 mn = *reinterpret_cast<const uint4*>(a.key_mins + hb * D + d0);
-      const uint32_t scw[4] = {sc.x, sc.y, sc.z, sc.w}, mnw[4] = {mn.x, mn.y, mn.z, mn.w};
+      float scf[8], mnf[8];
+      if constexpr (KF32) {     // the reference manager keeps per-channel key scale/min in fp32 (deltakv_less_memory.py:1122-1130)
+        const float* sp = reinterpret_cast<const float*>(a.key_scales) + hb * D + d0;
+        const float* mp = reinterpret_cast<const float*>(a.key_mins) + hb * D + d0;
+        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+        const float4 m0 = *reinterpret_cast<const float4*>(mp), m1 = *reinterpret_cast<const float4*>(mp + 4);
+        scf[0] = s0.x; scf[1] = s0.y; scf[2] = s0.z; scf[3] = s0.w; scf[4] = s1.x; scf[5] = s1.y; scf[6] = s1.z; scf[7] = s1.w;
+        mnf[0] = m0.x; mnf[1] = m0.y; mnf[2] = m0.z; mnf[3] = m0.w; mnf[4] = m1.x; mnf[5] = m1.y; mnf[6] = m1.z; mnf[7] = m1.w;
+      } else {
+        const uint4 sc = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.key_scales) + hb * D + d0);
+        const uint4 mn = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.key_mins) + hb * D + d0);
+        const uint32_t scw[4] = {sc.x, sc.y, sc.z, sc.w}, mnw[4] = {mn.x, mn.y, mn.z, mn.w};
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          scf[2 * e2] = bf16_lo(scw[e2]); scf[2 * e2 + 1] = bf16_hi(scw[e2]);
+          mnf[2 * e2] = bf16_lo(mnw[e2]); mnf[2 * e2 + 1] = bf16_hi(mnw[e2]);
+        }
+      }
       uint32_t outw[4];
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
         const int32_t* cw = a.key_packed + (hb * D + d0 + e2 * 2) * wpd + widx;
         const float q0 = (float)(((uint32_t)cw[0] >> shift) & 15u), q1 = (float)(((uint32_t)cw[wpd] >> shift) & 15u);
-        const float v0 = q0 * bf16_lo(scw[e2]) + bf16_lo(mnw[e2]);
-        const float v1 = q1 * bf16_hi(scw[e2]) + bf16_hi(mnw[e2]);
+        const float v0 = add_rn(mul_rn(q0, scf[2 * e2]), mnf[2 * e2]);
+        const float v1 = add_rn(mul_rn(q1, scf[2 * e2 + 1]), mnf[2 * e2 + 1]);
         outw[e2] = f32_to_bf16_bits(v0) | (f32_to_bf16_bits(v1) << 16);
       }
       kr[c] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
@@ -118,7 +133,7 @@ __global__ void __launch_bounds__(512) kivi_stage1_kernel(const SvkKiviDecodeSta
     const float sc = __builtin_bit_cast(float, (uint32_t)a.value_scales[tb * (D / GS) + g] << 16);
     const float mn = __builtin_bit_cast(float, (uint32_t)a.value_mins[tb * (D / GS) + g] << 16);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) vf[e] = bf16_round((float)((word >> (e * 4)) & 15u) * sc + mn);
+    for (int e = 0; e < 8; ++e) vf[e] = bf16_round(add_rn(mul_rn((float)((word >> (e * 4)) & 15u), sc), mn));
   };
 
   for (int t0 = start; t0 < end; t0 += kTile) {
@@ -238,7 +253,11 @@ int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
   dim3 grid(nblk, a.batch), block(64 * a.num_kv_heads);
   const size_t shm = sizeof(float) * a.num_kv_heads * (kTile * (((G + 3) / 4) * 4) + 16);
   switch (G) {
-#define SVK_CASE(G_) case G_: hipLaunchKernelGGL((kivi_stage1_kernel<D, G_>), grid, block, shm, s, a); break;
+#define SVK_CASE(G_)                                                                                     \
+  case G_:                                                                                               \
+    if (a.key_param_dtype == SVK_DTYPE_F32) hipLaunchKernelGGL((kivi_stage1_kernel<D, G_, true>), grid, block, shm, s, a); \
+    else hipLaunchKernelGGL((kivi_stage1_kernel<D, G_, false>), grid, block, shm, s, a);                  \
+    break;
     SVK_CASE(1) SVK_CASE(2) SVK_CASE(3) SVK_CASE(4) SVK_CASE(5) SVK_CASE(6) SVK_CASE(7) SVK_CASE(8)
 #undef SVK_CASE
     default:
@@ -259,6 +278,8 @@ extern "C" int svk_kivi_decode_stage1(const SvkKiviDecodeStage1Args* a, svk_stre
               "Invalid KIVI group_size=%d for head_dim=%d.", a->group_size, a->head_dim);
   SVK_REQUIRE(a->group_size % 8 == 0, SVK_ERR_VALUE, "int4 KIVI requires group_size/head_dim divisible by 8, got %d/%d.",
               a->group_size, a->head_dim);
+  SVK_REQUIRE(a->key_param_dtype == SVK_DTYPE_F32 || a->key_param_dtype == SVK_DTYPE_BF16, SVK_ERR_VALUE,
+              "svk_kivi_decode_stage1: key scale/min dtype must be f32 or bf16, got %d", a->key_param_dtype);
   SVK_REQUIRE(a->block_seq > 0 && a->block_seq % 16 == 0, SVK_ERR_VALUE,
               "block_seq must be a positive multiple of 16, got %d.", a->block_seq);
   SVK_REQUIRE(a->num_kv_heads >= 1 && a->num_kv_heads <= 8 && a->num_q_heads % a->num_kv_heads == 0, SVK_ERR_LAYOUT,

@@ -1,0 +1,723 @@
+"""DeltaKV: full-attention layers (raw bf16 or KIVI-int4 blocks) + compressed sparse layers.
+
+Host mirror of the reference's slim DeltaKV runtime for the decode side of the hot path
+(SURVEY.md section 8 a20-a25):
+  engine/cache_manager/deltakv_base.py        slot pools / maps (:114-200, :1247-1483), prepare_decode_static (:2038-2154),
+                                              get_compressed_lens (:2156-2165), build_decode_compute_view (:975-1018)
+  engine/cache_manager/deltakv_less_memory.py allocate_kv_cache (:940-1190), _load_residual (:2841-2848),
+                                              _deltakv_build_view_and_plan_reconstruct{,_static} (:2850-2934),
+                                              KIVI decode view (:2942-2982), get_layer_compute_view (:1344-1402),
+                                              deltakv_reconstruct (:4032-4143)
+  engine/cache_manager/deltakv_less_memory_cuda_graph.py  _set_postrope_slots (:476-500), get_decode_block_seq (:502-505)
+
+Data model (one pool per layer *kind*, shared slot ids across the layers of a kind):
+  full layers    full_kv_cache [2, Lf, full_slots, Hkv, D] bf16, row map `full_layer_slots_map`; with
+                 full_layer_kv_quant_bits=4 older tokens live in KIVI blocks (per-channel int4 K with fp32 scale/min,
+                 per-token int4 V with bf16 scale/min) addressed by `full_layer_kivi_block_slots_map`.
+  sparse layers  deltakv_full_kv_cache [2, Ls, slots, Hkv, D] holds *pre-RoPE* K (sink, cluster centres, raw tail)
+                 and per-step post-RoPE reconstructions in temp slots (flagged in `_deltakv_postrope_slot_mask`);
+                 every other token is a latent residual (int4 + group scale/min, or bf16) with K father slots.
+Sparse-layer decode: static plan -> residual load (dequant + compress_up) -> reconstruct + RoPE write-back into
+temp slots -> contiguous attention view (raw K rotated on the way) -> ordinary stage 1 / stage 2.
+
+The compression side (deltakv_evict, KIVI block store) is SURVEY section 8(f).3; until it lands compressed rows are
+ingested through `admit_compressed_row` (synthetic or externally produced state).
+"""
+
+from __future__ import annotations
+
+from collections import deque
+
+import numpy as np
+import torch
+
+from ...kernels import deltakv_kernels as dk
+from ...utils.context import get_context
+from ...utils.profiler import profiler
+from .base import (AttentionViewMeta, CacheManager, DecodeComputeView, ExplicitKVPayload, LayerBatchStates,
+                   SparseSelection)
+
+
+def build_compressor(input_size: int, output_size: int, kind: str, intermediate_size: int, bias: bool) -> torch.nn.Module:
+    """utils/compressor.py:36-86: linear | mlp_gelu | mlp_swiglu."""
+    if kind == "linear":
+        return torch.nn.Linear(input_size, output_size, bias=bias)
+    if kind == "mlp_gelu":
+        return torch.nn.Sequential(torch.nn.Linear(input_size, intermediate_size, bias=bias), torch.nn.GELU(),
+                                   torch.nn.Linear(intermediate_size, output_size, bias=bias))
+    if kind == "mlp_swiglu":
+        class SwiGLU(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.w12 = torch.nn.Linear(input_size, intermediate_size * 2, bias=bias)
+                self.w3 = torch.nn.Linear(intermediate_size, output_size, bias=bias)
+
+            def forward(self, x):
+                a, b = self.w12(x).chunk(2, dim=-1)
+                return self.w3(torch.nn.functional.silu(a) * b)
+        return SwiGLU()
+    raise ValueError(f"Unhandled compressor type after normalization: {kind}")
+
+
+_COMPRESSOR_KINDS = {"": "auto", "auto": "auto", "linear": "linear", "mlp": "mlp_gelu", "gelu": "mlp_gelu",
+                     "mlp_gelu": "mlp_gelu", "swiglu": "mlp_swiglu", "mlp_swiglu": "mlp_swiglu"}
+
+
+def create_compressor(is_down: bool, config) -> torch.nn.Module:
+    head_dim, hkv = int(config.head_dim), int(config.num_key_value_heads)
+    kv_dim = 2 * head_dim * hkv
+    input_size = kv_dim if is_down else int(config.kv_compressed_size)
+    output_size = int(config.kv_compressed_size) if is_down else kv_dim
+    raw = getattr(config, "compressor_down_type" if is_down else "compressor_up_type", "auto")
+    if raw not in _COMPRESSOR_KINDS:
+        raise ValueError(f"Unknown compressor type: {raw}. Use auto|linear|mlp_gelu|mlp_swiglu.")
+    kind = _COMPRESSOR_KINDS[raw]
+    if kind == "auto":
+        kind = "mlp_gelu" if bool(config.use_nonlinear_compressor) else "linear"
+    inter = int(getattr(config, "compressor_down_intermediate_size" if is_down else "compressor_up_intermediate_size", -1))
+    if inter <= 0:
+        inter = int(config.compressor_intermediate_size)
+    if inter <= 0:
+        inter = (input_size + output_size) // 2
+    return build_compressor(input_size, output_size, kind, inter, bool(config.compressor_linear_bias))
+
+
+def rope_cos_sin_cache(max_pos: int, head_dim: int, theta: float, device) -> torch.Tensor:
+    """[max_pos, D] f32: cos | sin halves (layers/rotary_embedding.py neox layout)."""
+    inv_freq = 1.0 / (float(theta) ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    ang = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv_freq[None, :]
+    return torch.cat((ang.cos(), ang.sin()), dim=1).contiguous().to(device)
+
+
+class _Pool:
+    """LIFO free stack of slot ids, mirrored on the host (`free_slots_stack_* [ptr-n:ptr]`)."""
+
+    def __init__(self, n: int, name: str):
+        self.stack = np.arange(n, dtype=np.int32)
+        self.free = int(n)
+        self.size = int(n)
+        self.name = name
+
+    def pop(self, n: int) -> np.ndarray:
+        n = int(n)
+        if self.free < n:
+            raise RuntimeError(f"Out of {self.name} slots: need={n} free={self.free}.")
+        out = self.stack[self.free - n: self.free].copy()
+        self.free -= n
+        return out
+
+    def push(self, slots: np.ndarray):
+        slots = np.asarray(slots, dtype=np.int32).reshape(-1)
+        self.stack[self.free: self.free + slots.size] = slots
+        self.free += int(slots.size)
+
+    def permute(self, seed: int):
+        assert self.free == self.size
+        self.stack = np.random.default_rng(seed).permutation(self.size).astype(np.int32)
+
+
+class DeltaKVCacheManager(CacheManager):
+    def __init__(self, config, parallel_context=None):
+        super().__init__(config, parallel_context)
+        self.full_attn_layers = sorted(int(x) for x in config.full_attn_layers)
+        self.full_layer_ids = [l for l in range(self.num_layers) if l in set(self.full_attn_layers)]
+        self.deltakv_layer_ids = [l for l in range(self.num_layers) if l not in set(self.full_attn_layers)]
+        self.full_layer_to_idx = {l: i for i, l in enumerate(self.full_layer_ids)}
+        self.deltakv_layer_to_idx = {l: i for i, l in enumerate(self.deltakv_layer_ids)}
+        self.full_layer_batch_states = LayerBatchStates()
+        self.deltakv_layer_batch_states = LayerBatchStates()
+        d = self.device
+        rows, L = self.max_buffer_rows, self.max_model_len
+        self.full_layer_slots_map = torch.zeros((rows, L), dtype=torch.int32, device=d)
+        self.sparse_layer_raw_slots_map = torch.full((rows, L), -1, dtype=torch.int32, device=d)
+        self.sparse_layer_latent_slots_map = torch.full((rows, L), -1, dtype=torch.int32, device=d)
+        self.seq_id_to_row: dict[int, int] = {}
+        self.free_rows = deque(range(rows))
+        self.row_seq_lens = np.zeros((rows,), dtype=np.int32)
+        self.row_deltakv_compressed_lens = np.zeros((rows,), dtype=np.int32)
+        self.row_deltakv_compressed_lens_gpu = torch.zeros((rows,), dtype=torch.int32, device=d)
+        self.cos_sin_cache = rope_cos_sin_cache(L, self.head_dim, float(config.rope_theta), d)
+        self.deltakv_k_norm_weight = None            # Qwen2 has no k_norm; set_model_layers would fill it
+        self.deltakv_k_norm_eps = 1e-6
+        self.allocate_kv_cache()
+        self._init_compressor_modules(config)
+        self._deltakv_reset_view_cache()
+        self._static: dict[tuple, tuple] = {}
+        self._temp_slots_by_shape: dict[tuple, torch.Tensor] = {}
+        self._plan_buffers: dict[tuple, tuple] = {}
+        self._materialized_view: dict[tuple, tuple] = {}
+        self._deltakv_decode_static_compressed_lens = None
+        self._deltakv_decode_static_slot_mapping = None
+        self._deltakv_decode_static_active_pos = None
+
+    # ------------------------------------------------------------------ configuration helpers
+    def _full_layer_kivi_enabled(self) -> bool:
+        return bool(self.config.enable_full_layer_kivi_quant) and int(self.config.full_layer_kv_quant_bits or 0) == 4
+
+    def _full_layer_kivi_group_size(self) -> int:
+        g = int(self.config.full_layer_kivi_group_size or 32)
+        if g % 8 != 0:
+            raise ValueError("Full-layer KIVI int4 packing requires group_size divisible by 8; "
+                             f"got full_layer_kivi_group_size={g}.")
+        if self.head_dim % g != 0:
+            raise ValueError("Full-layer KIVI value quantization requires head_dim divisible by group_size; "
+                             f"head_dim={self.head_dim}, group_size={g}.")
+        return g
+
+    def _sparse_payload_dim(self) -> int:
+        return int(self.config.kv_compressed_size)
+
+    def _quant_group_size(self) -> int:
+        g = int(self.config.kv_quant_group_size or 0)
+        return g if g > 0 else self._sparse_payload_dim()
+
+    def _deltakv_decode_static_max_buffer(self) -> int:
+        """deltakv_base.py:2718-2723: decode runs before post-forward compression, so the raw tail can hold one
+        recent window plus the next remainder."""
+        recent = int(self.config.num_recent_tokens)
+        return max(recent + 1, 2 * recent)
+
+    # ------------------------------------------------------------------ storage
+    def allocate_kv_cache(self):
+        """deltakv_less_memory.py:940-1190 (explicit sizes; 0 = derive a synthetic-workload default)."""
+        cfg, d = self.config, self.device
+        rows, L = self.max_buffer_rows, self.max_model_len
+        sink, recent, keep = int(cfg.num_sink_tokens), int(cfg.num_recent_tokens), int(cfg.decode_keep_tokens)
+        kivi = self._full_layer_kivi_enabled()
+        G = self._full_layer_kivi_group_size() if kivi else 0
+        n_sparse = int(cfg.num_kvcache_slots or 0)
+        if n_sparse <= 0:
+            centers = int(np.ceil(L * float(cfg.cluster_ratio))) + 1
+            n_sparse = rows * (sink + 2 * recent + 1 + centers + keep) + 64
+        n_latent = int(cfg.deltakv_num_latent_slots or 0) or rows * L
+        n_full = int(cfg.deltakv_num_full_layer_slots or 0)
+        if n_full <= 0:
+            n_full = rows * ((sink + int(cfg.full_layer_kivi_residual_length) + 2 * G + 1) if kivi else L) + 64
+        n_blocks = int(cfg.deltakv_num_kivi_blocks or 0) or (rows * (L // G + 1) if kivi else 0)
+        self.deltakv_full_num_slots, self.deltakv_latent_num_slots = n_sparse, n_latent
+        self.full_num_slots, self.full_layer_kivi_num_blocks = n_full, n_blocks
+        Lf, Ls, H, D = len(self.full_layer_ids), len(self.deltakv_layer_ids), self.num_kv_heads, self.head_dim
+        bf = torch.bfloat16
+        self.full_kv_cache = torch.zeros((2, Lf, n_full, H, D), dtype=bf, device=d)
+        self.deltakv_full_kv_cache = torch.zeros((2, Ls, n_sparse, H, D), dtype=bf, device=d)
+        self.kv_cache = self.deltakv_full_kv_cache
+        width = sink + keep + self._deltakv_decode_static_max_buffer()
+        self.deltakv_materialized_compute_num_slots = rows * width
+        self.deltakv_materialized_kv_cache = torch.zeros((2, rows * width, H, D), dtype=bf, device=d)
+        self._deltakv_postrope_slot_mask = torch.zeros((Ls, n_sparse), dtype=torch.bool, device=d)
+        bits = int(cfg.kv_quant_bits or 0)
+        payload = self._sparse_payload_dim()
+        if bits:
+            gs = self._quant_group_size()
+            if payload % gs or payload % (32 // bits):
+                raise ValueError(f"kv_compressed_size={payload} must be divisible by the quant group size {gs} and {32 // bits}.")
+            self.deltakv_latent_cache = torch.zeros((Ls, n_latent, payload // (32 // bits)), dtype=torch.int32, device=d)
+            self.deltakv_latent_scales = torch.zeros((Ls, n_latent, payload // gs), dtype=bf, device=d)
+            self.deltakv_latent_mins = torch.zeros_like(self.deltakv_latent_scales)
+        else:
+            self.deltakv_latent_cache = torch.zeros((Ls, n_latent, payload), dtype=bf, device=d)
+            self.deltakv_latent_scales = self.deltakv_latent_mins = None
+        self.deltakv_latent_to_full_slots = torch.full((Ls, n_latent, int(cfg.deltakv_k_neighbors)), -1, dtype=torch.int32, device=d)
+        self.deltakv_slot_to_pos = torch.full((n_sparse,), -1, dtype=torch.int32, device=d)
+        self.full_layer_slot_to_pos = torch.full((n_full,), -1, dtype=torch.int32, device=d)
+        self._pool_sparse = _Pool(n_sparse, "DeltaKV full cache")
+        self._pool_latent = _Pool(n_latent, "DeltaKV latent")
+        self._pool_full = _Pool(n_full, "full KV cache")
+        if kivi:
+            self.full_layer_kivi_key_packed = torch.zeros((Lf, n_blocks, H, D, G // 8), dtype=torch.int32, device=d)
+            self.full_layer_kivi_key_scales = torch.zeros((Lf, n_blocks, H, D), dtype=torch.float32, device=d)
+            self.full_layer_kivi_key_mins = torch.zeros_like(self.full_layer_kivi_key_scales)
+            self.full_layer_kivi_value_packed = torch.zeros((Lf, n_blocks, H, G, D // 8), dtype=torch.int32, device=d)
+            self.full_layer_kivi_value_scales = torch.zeros((Lf, n_blocks, H, G, D // G), dtype=bf, device=d)
+            self.full_layer_kivi_value_mins = torch.zeros_like(self.full_layer_kivi_value_scales)
+            self.full_layer_kivi_block_slots_map = torch.full((rows, L), -1, dtype=torch.int32, device=d)
+            self.full_layer_kivi_block_start_pos = torch.full((n_blocks,), -1, dtype=torch.int32, device=d)
+            self._pool_kivi = _Pool(n_blocks, "full-layer KIVI block")
+            self.row_full_layer_kivi_quantized_lens = np.zeros((rows,), dtype=np.int32)
+        else:
+            self.full_layer_kivi_key_packed = self.full_layer_kivi_value_packed = None
+            self.full_layer_kivi_block_slots_map = self.full_layer_kivi_block_start_pos = None
+            self._pool_kivi = None
+            self.row_full_layer_kivi_quantized_lens = None
+        self.row_kivi_blocks: dict[int, list[int]] = {}
+        self.row_latent_slots: dict[int, np.ndarray] = {}
+
+    def _init_compressor_modules(self, config):
+        """deltakv_less_memory.py:1190-1199; weights come from `deltakv_path` in the reference (external
+        checkpoint, absent here) -> seeded random init, overridable through `load_compressor_state`."""
+        self.compress_down, self.compress_up = [], []
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(20260625)
+        for _ in self.deltakv_layer_ids:
+            self.compress_down.append(create_compressor(True, config).to(device=self.device, dtype=torch.bfloat16))
+            self.compress_up.append(create_compressor(False, config).to(device=self.device, dtype=torch.bfloat16))
+        torch.random.set_rng_state(gen_state)
+        for m in self.compress_down + self.compress_up:
+            m.requires_grad_(False)
+
+    def load_compressor_state(self, l_idx: int, *, up: dict | None = None, down: dict | None = None):
+        if up is not None:
+            self.compress_up[l_idx].load_state_dict(up)
+        if down is not None:
+            self.compress_down[l_idx].load_state_dict(down)
+
+    def permute_free_slots(self, seed: int):
+        """Scatter the slot pools (benchmarks / tests: a genuinely paged gather)."""
+        self._pool_sparse.permute(seed)
+        self._pool_latent.permute(seed + 1)
+        self._pool_full.permute(seed + 2)
+        if self._pool_kivi is not None:
+            self._pool_kivi.permute(seed + 3)
+
+    # ------------------------------------------------------------------ operator surface
+    def get_layer_batch_states(self, layer_idx: int) -> LayerBatchStates:
+        return self.full_layer_batch_states if layer_idx in self.full_layer_to_idx else self.deltakv_layer_batch_states
+
+    def get_layer_kv_cache(self, layer_idx: int):
+        if layer_idx in self.full_layer_to_idx:
+            i = self.full_layer_to_idx[layer_idx]
+            return self.full_kv_cache[0, i], self.full_kv_cache[1, i]
+        i = self.deltakv_layer_to_idx[layer_idx]
+        return self.deltakv_full_kv_cache[0, i], self.deltakv_full_kv_cache[1, i]
+
+    def get_layer_buffer_req_to_token_slots(self, layer_idx: int) -> torch.Tensor:
+        return self.full_layer_slots_map if layer_idx in self.full_layer_to_idx else self.sparse_layer_raw_slots_map
+
+    @property
+    def num_free_slots(self) -> int:
+        return min(self._pool_full.free, self._pool_sparse.free)
+
+    def free_slot_stats(self) -> dict:
+        out = {"full": self._pool_full.free, "deltakv_full": self._pool_sparse.free, "latent": self._pool_latent.free}
+        if self._pool_kivi is not None:
+            out["kivi_blocks"] = self._pool_kivi.free
+        return out
+
+    def _stores_sparse_raw_kv(self, layer_idx: int) -> bool:
+        return layer_idx in self.deltakv_layer_to_idx
+
+    def save_raw_kv_if_needed(self, layer_idx: int, k: torch.Tensor, v: torch.Tensor):
+        """deltakv_less_memory.py:1269-1281: sparse layers keep the *pre-RoPE* key."""
+        if self._stores_sparse_raw_kv(layer_idx):
+            super().save_rope_kv_if_needed(layer_idx, k, v)
+
+    def save_rope_kv_if_needed(self, layer_idx: int, k: torch.Tensor, v: torch.Tensor):
+        if self._stores_sparse_raw_kv(layer_idx):
+            return None
+        return super().save_rope_kv_if_needed(layer_idx, k, v)
+
+    def get_decode_block_seq(self, layer_idx: int, default: int) -> int:
+        if self._full_layer_kivi_enabled() and layer_idx in self.full_layer_to_idx:
+            return int(self.config.full_layer_kivi_decode_block_seq or default)
+        return super().get_decode_block_seq(layer_idx, default)
+
+    def free_part_slots(self, layer_idx: int, seq, keep_indices, *, keep_indices_sorted: bool = False):
+        raise ValueError("DeltaKV does not evict through free_part_slots; it compresses the raw tail (deltakv_evict).")
+
+    def _prepare_prefill(self, seqs):
+        raise NotImplementedError("DeltaKV prefill + compression is SURVEY section 8(f).3; ingest rows with "
+                                  "admit_compressed_row().")
+
+    def _prepare_decode(self, seqs):
+        return self.prepare_decode_static(seqs)
+
+    def _get_free_row(self, seq_id: int) -> int:
+        row = self.seq_id_to_row.get(seq_id)
+        if row is None:
+            if not self.free_rows:
+                raise RuntimeError("No free DeltaKV rows")
+            row = self.free_rows.popleft()
+            self.seq_id_to_row[seq_id] = row
+        return int(row)
+
+    def _deltakv_reset_view_cache(self):
+        self._deltakv_view_cache_key = None
+        self._deltakv_view_cache_value = None
+
+    # ------------------------------------------------------------------ ingest of an already-compressed row
+    @torch.no_grad()
+    def admit_compressed_row(self, seq, *, total_len: int, compressed_len: int, center_positions, father_center_index,
+                             sparse_k_raw, sparse_v, latent, full_k=None, full_v=None, kivi_quantized_end: int = 0,
+                             kivi_blocks=None):
+        """Install one sequence whose prompt has already been prefilled and compressed.
+
+        positions [0, sink) and [sink+compressed_len, total_len) are raw on the sparse layers; positions
+        `center_positions` (inside the compressed range) additionally keep their raw K/V (cluster centres);
+        every compressed position p has a latent residual and `K` fathers `father_center_index[p - sink]`
+        (indices into sink ++ centres, -1 padded like the reference pads with the first father).
+          sparse_k_raw / sparse_v : [Ls, n_raw, Hkv, D] bf16 for the raw positions in ascending position order
+          latent : dict(code=[Ls, clen, W] int32, scale=[Ls, clen, g] bf16, mn=...) or dict(dense=[Ls, clen, payload] bf16)
+          full_k / full_v : [Lf, n_full_raw, Hkv, D] bf16 post-RoPE rows of the raw full-layer positions
+          kivi_blocks : dict(key_packed, key_scales, key_mins, value_packed, value_scales, value_mins) with a
+                        leading [Lf, n_blocks] for positions [sink, kivi_quantized_end) when KIVI is enabled."""
+        cfg, d = self.config, self.device
+        sink = int(cfg.num_sink_tokens)
+        row = self._get_free_row(seq.seq_id)
+        assert int(self.row_seq_lens[row]) == 0, "row already populated"
+        total_len, clen = int(total_len), int(compressed_len)
+        if total_len > self.max_model_len:
+            raise RuntimeError(f"DeltaKV row length exceeds max_model_len: {total_len} > {self.max_model_len}")
+        centers = np.asarray(center_positions, dtype=np.int64)
+        raw_pos = np.concatenate((np.arange(min(sink, total_len)), centers, np.arange(sink + clen, total_len))).astype(np.int64)
+        assert np.all(np.diff(raw_pos) > 0), "raw positions must be strictly ascending (sink < centres < tail)"
+        n_raw = raw_pos.size
+        slots = self._pool_sparse.pop(n_raw)
+        slots_gpu = torch.from_numpy(slots).to(d)
+        pos_gpu = torch.from_numpy(raw_pos).to(d)
+        self.sparse_layer_raw_slots_map[row, pos_gpu] = slots_gpu
+        self.deltakv_slot_to_pos[slots_gpu.long()] = pos_gpu.to(torch.int32)
+        self.deltakv_full_kv_cache[0][:, slots_gpu.long()] = sparse_k_raw.to(d)
+        self.deltakv_full_kv_cache[1][:, slots_gpu.long()] = sparse_v.to(d)
+        if clen > 0:
+            lat = self._pool_latent.pop(clen)
+            lat_gpu = torch.from_numpy(lat).to(d)
+            self.sparse_layer_latent_slots_map[row, sink: sink + clen] = lat_gpu
+            if "dense" in latent:
+                self.deltakv_latent_cache[:, lat_gpu.long()] = latent["dense"].to(d)
+            else:
+                self.deltakv_latent_cache[:, lat_gpu.long()] = latent["code"].to(d)
+                self.deltakv_latent_scales[:, lat_gpu.long()] = latent["scale"].to(d)
+                self.deltakv_latent_mins[:, lat_gpu.long()] = latent["mn"].to(d)
+            # fathers: indices into (sink ++ centres) -> slot ids
+            center_slots = np.concatenate((slots[: min(sink, total_len)], slots[min(sink, total_len): min(sink, total_len) + centers.size]))
+            fidx = np.asarray(father_center_index, dtype=np.int64)
+            fslots = center_slots[np.maximum(fidx, 0)]
+            fslots = np.where(fidx >= 0, fslots, fslots[..., :1])
+            self.deltakv_latent_to_full_slots[:, lat_gpu.long()] = torch.from_numpy(fslots.astype(np.int32)).to(d)
+            self.row_latent_slots[row] = lat
+        # full layers: KIVI blocks cover [sink, quant_end) (deltakv_less_memory.py:3495-3558); the rest stays raw
+        qend = int(kivi_quantized_end) if self._full_layer_kivi_enabled() else 0
+        qstart = min(sink, total_len)
+        if qend <= qstart:
+            qend = qstart
+        full_pos = np.concatenate((np.arange(qstart), np.arange(qend, total_len))).astype(np.int64)
+        fs = self._pool_full.pop(full_pos.size)
+        fs_gpu = torch.from_numpy(fs).to(d)
+        fpos_gpu = torch.from_numpy(full_pos).to(d)
+        if qend > qstart:
+            self.full_layer_slots_map[row, qstart:qend] = -1      # the kernel picks the KIVI block for these
+        self.full_layer_slots_map[row, fpos_gpu] = fs_gpu
+        self.full_layer_slot_to_pos[fs_gpu.long()] = fpos_gpu.to(torch.int32)
+        if full_k is not None:
+            self.full_kv_cache[0][:, fs_gpu.long()] = full_k.to(d)
+            self.full_kv_cache[1][:, fs_gpu.long()] = full_v.to(d)
+        if qend > qstart:
+            G = self._full_layer_kivi_group_size()
+            assert (qend - qstart) % G == 0
+            nb = (qend - qstart) // G
+            blocks = self._pool_kivi.pop(nb)
+            b_gpu = torch.from_numpy(blocks).to(d)
+            self.full_layer_kivi_block_slots_map[row, qstart:qend] = b_gpu.repeat_interleave(G)
+            self.full_layer_kivi_block_start_pos[b_gpu.long()] = torch.arange(qstart, qend, G, dtype=torch.int32, device=d)
+            if kivi_blocks is not None:
+                for name in ("key_packed", "key_scales", "key_mins", "value_packed", "value_scales", "value_mins"):
+                    getattr(self, f"full_layer_kivi_{name}")[:, b_gpu.long()] = kivi_blocks[name].to(d)
+            self.row_kivi_blocks[row] = [int(x) for x in blocks]
+            self.row_full_layer_kivi_quantized_lens[row] = qend
+        self.row_seq_lens[row] = total_len
+        self.row_deltakv_compressed_lens[row] = clen
+        self.row_deltakv_compressed_lens_gpu[row] = clen
+        return row
+
+    # ------------------------------------------------------------------ decode preparation
+    @torch.no_grad()
+    def prepare_decode_static(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,
+                              req_indices=None, *, graph_batch_size: int | None = None):
+        """deltakv_base.py:2038-2154: one new raw slot per row in each pool, graph-stable metadata buffers."""
+        with profiler.record("cache_prepare_decode"):
+            self._deltakv_reset_view_cache()
+            B = len(seqs)
+            if B <= 0:
+                raise ValueError("Static DeltaKV decode requires a non-empty real decode batch.")
+            GB = int(graph_batch_size or (slot_mapping.numel() if slot_mapping is not None else B))
+            if B > GB:
+                raise ValueError("Static DeltaKV decode graph batch is smaller than the real decode batch: "
+                                 f"graph={GB}, real={B}.")
+            d = self.device
+            rows = np.asarray([self._get_free_row(s.seq_id) for s in seqs], dtype=np.int64)
+            cur = self.row_seq_lens[rows].copy()
+            if int(cur.max()) + 1 > self.max_model_len:
+                raise RuntimeError(f"KV row length exceeds max_model_len in DeltaKV decode: max_cur_len={int(cur.max())}")
+            buf = cur - int(self.config.num_sink_tokens) - self.row_deltakv_compressed_lens[rows]
+            if int(buf.max()) + 1 > self._deltakv_decode_static_max_buffer():
+                raise RuntimeError("DeltaKV raw tail exceeds the static decode buffer; the compression side "
+                                   "(deltakv_evict, SURVEY 8(f).3) must run before more tokens are decoded: "
+                                   f"tail={int(buf.max()) + 1} max_buffer={self._deltakv_decode_static_max_buffer()}.")
+            full_slots = self._pool_full.pop(B)
+            sparse_slots = self._pool_sparse.pop(B)
+            key = (GB,)
+            st = self._static.get(key)
+            if st is None:
+                st = tuple(torch.zeros((GB,), dtype=torch.int32, device=d) for _ in range(5))
+                self._static[key] = st
+            own_slot_mapping, own_ctx, own_req, sparse_mapping, compressed = st
+            slot_mapping = own_slot_mapping if slot_mapping is None else slot_mapping
+            context_lens = own_ctx if context_lens is None else context_lens
+            req_indices = own_req if req_indices is None else req_indices
+            rows_gpu = torch.from_numpy(rows).to(d)
+            cols_gpu = torch.from_numpy(cur.astype(np.int64)).to(d)
+            fs_gpu, ss_gpu = torch.from_numpy(full_slots).to(d), torch.from_numpy(sparse_slots).to(d)
+            self.full_layer_slots_map[rows_gpu, cols_gpu] = fs_gpu
+            self.full_layer_slot_to_pos[fs_gpu.long()] = cols_gpu.to(torch.int32)
+            self.sparse_layer_raw_slots_map[rows_gpu, cols_gpu] = ss_gpu
+            self.deltakv_slot_to_pos[ss_gpu.long()] = cols_gpu.to(torch.int32)
+            self.row_seq_lens[rows] += 1
+            real_lens = self.row_seq_lens[rows]
+            clens = self.row_deltakv_compressed_lens[rows]
+
+            def fill(dst, vals, pad):
+                dst[:B].copy_(torch.from_numpy(np.asarray(vals, dtype=np.int32)).to(d))
+                if GB > B:
+                    dst[B:].fill_(int(pad))
+
+            fill(context_lens, real_lens, real_lens[0])
+            fill(req_indices, rows, rows[0])
+            fill(slot_mapping, full_slots, -1)
+            fill(sparse_mapping, sparse_slots, -1)
+            fill(compressed, clens, clens[0])
+            self._deltakv_decode_static_slot_mapping = sparse_mapping
+            self._deltakv_decode_static_compressed_lens = compressed
+            cap = self._decode_static_max_context_len
+            max_ctx = int(cap) if cap is not None else int(real_lens.max())
+            for state, mapping in ((self.full_layer_batch_states, slot_mapping), (self.deltakv_layer_batch_states, sparse_mapping)):
+                state.slot_mapping, state.context_lens, state.req_indices = mapping, context_lens, req_indices
+                state.max_context_len = max_ctx
+            return input_ids, positions, None
+
+    def get_compressed_lens(self, req_indices: torch.Tensor) -> torch.Tensor:
+        """deltakv_base.py:2156-2165."""
+        c = self._deltakv_decode_static_compressed_lens
+        if c is not None and not get_context().is_prefill:
+            return c[: req_indices.numel()]
+        return self.row_deltakv_compressed_lens_gpu[req_indices.to(torch.long)].to(torch.int32)
+
+    def free_seq(self, seq_id: int):
+        """deltakv_base.py:1534-1575."""
+        row = self.seq_id_to_row.pop(seq_id, None)
+        if row is None:
+            raise ValueError(f"free_seq: unknown seq_id={seq_id}")
+        n = int(self.row_seq_lens[row])
+        if n > 0:
+            raw = self.sparse_layer_raw_slots_map[row, :n].cpu().numpy()
+            raw = raw[raw >= 0]
+            self._pool_sparse.push(raw)
+            self.deltakv_slot_to_pos[torch.from_numpy(raw.astype(np.int64)).to(self.device)] = -1
+            full = self.full_layer_slots_map[row, :n].cpu().numpy()
+            full = full[full >= 0] if self._full_layer_kivi_enabled() else full
+            self._pool_full.push(full)
+            self.full_layer_slot_to_pos[torch.from_numpy(full.astype(np.int64)).to(self.device)] = -1
+        lat = self.row_latent_slots.pop(row, None)
+        if lat is not None:
+            self._pool_latent.push(lat)
+        blocks = self.row_kivi_blocks.pop(row, None)
+        if blocks:
+            self._pool_kivi.push(np.asarray(blocks, dtype=np.int32))
+            self.full_layer_kivi_block_start_pos[torch.tensor(blocks, dtype=torch.long, device=self.device)] = -1
+            self.full_layer_kivi_block_slots_map[row, :] = -1
+            self.row_full_layer_kivi_quantized_lens[row] = 0
+        self.full_layer_slots_map[row, :] = 0
+        self.sparse_layer_raw_slots_map[row, :] = -1
+        self.sparse_layer_latent_slots_map[row, :] = -1
+        self.row_seq_lens[row] = 0
+        self.row_deltakv_compressed_lens[row] = 0
+        self.row_deltakv_compressed_lens_gpu[row] = 0
+        self.free_rows.append(row)
+        self._deltakv_reset_view_cache()
+
+    # ------------------------------------------------------------------ sparse-layer decode view
+    def _ensure_decode_static_temp_slots(self, batch_size: int, k_max: int) -> torch.Tensor:
+        """deltakv_less_memory.py:449-470: a persistent [B, K] scratch block reused by every sparse layer."""
+        key = (int(batch_size), int(k_max))
+        slots = self._temp_slots_by_shape.get(key)
+        if slots is None:
+            if key[0] == 0 or key[1] == 0:
+                slots = torch.empty(key, dtype=torch.int32, device=self.device)
+            else:
+                slots = torch.from_numpy(self._pool_sparse.pop(key[0] * key[1])).to(self.device).view(*key)
+            self._temp_slots_by_shape[key] = slots
+        return slots
+
+    def _ensure_decode_static_plan_buffers(self, batch_size: int, k_max: int, max_s: int):
+        key = (int(batch_size), int(k_max), int(max_s))
+        bufs = self._plan_buffers.get(key)
+        if bufs is None:
+            d, i32 = self.device, torch.int32
+            B, K, S = key
+            bufs = (torch.zeros((B, S), dtype=i32, device=d), torch.zeros((B, S), dtype=i32, device=d),
+                    torch.arange(B, dtype=i32, device=d), torch.zeros((B,), dtype=i32, device=d),
+                    torch.empty((0,), dtype=i32, device=d), torch.zeros((B * K,), dtype=i32, device=d),
+                    torch.zeros((B * K,), dtype=i32, device=d), torch.zeros((B * K,), dtype=i32, device=d))
+            self._plan_buffers[key] = bufs
+        return bufs
+
+    def _deltakv_build_view_and_plan_reconstruct(self, layer_idx: int, active_compressed_indices, req_indices):
+        """deltakv_less_memory.py:2850-2882: one plan per observation group (the slot maps are shared by all
+        sparse layers), keyed on the stable input addresses."""
+        act = active_compressed_indices
+        key = (int(req_indices.data_ptr()), int(req_indices.numel()), 0 if act is None else int(act.data_ptr()),
+               int(req_indices.numel()) if act is None else int(act.shape[0]), 0 if act is None else int(act.shape[1]))
+        if self._deltakv_view_cache_key == key and self._deltakv_view_cache_value is not None:
+            return self._deltakv_view_cache_value
+        with profiler.record("deltakv_build_view_total"):
+            out = self._deltakv_build_view_and_plan_reconstruct_static(layer_idx, act, req_indices)
+        self._deltakv_view_cache_key, self._deltakv_view_cache_value = key, out
+        return out
+
+    def _deltakv_build_view_and_plan_reconstruct_static(self, layer_idx: int, active_compressed_indices, req_indices):
+        """deltakv_less_memory.py:2884-2934."""
+        if layer_idx in self.full_layer_to_idx:
+            raise ValueError("deltakv_reconstruct should only be called for sparse layers.")
+        bsz = int(req_indices.shape[0])
+        if active_compressed_indices is None:
+            active_compressed_indices = torch.empty((bsz, 0), device=req_indices.device, dtype=torch.int32)
+        k_max = int(active_compressed_indices.shape[1])
+        context_lens = self.deltakv_layer_batch_states.context_lens
+        if context_lens is None:
+            raise RuntimeError("DeltaKV static decode context_lens buffer was not initialized.")
+        context_lens = context_lens[:bsz]
+        compressed_lens = self.get_compressed_lens(req_indices)
+        sink = int(self.config.num_sink_tokens)
+        max_buffer = self._deltakv_decode_static_max_buffer()
+        max_s = sink + k_max + max_buffer
+        temp_slots = self._ensure_decode_static_temp_slots(bsz, k_max)
+        active_slots, active_pos, local_req, new_context_lens, no_free, recon_pos, recon_latent, recon_out_slot = \
+            self._ensure_decode_static_plan_buffers(bsz, k_max, max_s)
+        dk.deltakv_static_decode_plan(
+            raw_slots_map=self.sparse_layer_raw_slots_map, latent_slots_map=self.sparse_layer_latent_slots_map,
+            active_compressed_indices=active_compressed_indices, req_indices=req_indices, context_lens=context_lens,
+            compressed_lens=compressed_lens, temp_slots=temp_slots, active_slots_out=active_slots,
+            active_pos_out=active_pos, new_context_lens_out=new_context_lens, recon_pos_out=recon_pos,
+            recon_latent_out=recon_latent, recon_out_slot_out=recon_out_slot, sink=sink, max_buffer=max_buffer)
+        self._deltakv_decode_static_active_pos = active_pos
+        return active_slots, local_req, new_context_lens, no_free, recon_pos, recon_latent, recon_out_slot
+
+    def _load_residual(self, l_idx: int, recon_latent: torch.Tensor) -> torch.Tensor:
+        """deltakv_less_memory.py:2841-2848: latent gather -> (int4 dequant) -> compress_up (library GEMMs)."""
+        residual = self.deltakv_latent_cache[l_idx, recon_latent.long()]
+        if int(self.config.kv_quant_bits or 0) == 4:
+            scales = self.deltakv_latent_scales[l_idx, recon_latent.long()]
+            mins = self.deltakv_latent_mins[l_idx, recon_latent.long()]
+            residual = dk.triton_dequantize_2d_int4_grouped(residual, scales, mins, self._quant_group_size(),
+                                                            int(residual.shape[-1]) * 8)
+        return self.compress_up[l_idx](residual)
+
+    def _set_postrope_slots(self, layer_idx: int, slots: torch.Tensor):
+        """deltakv_less_memory_cuda_graph.py:476-500 (-1 entries fall on a dummy slot that no row owns)."""
+        mask = self._deltakv_postrope_slot_mask[self.deltakv_layer_to_idx[int(layer_idx)]]
+        mask.zero_()
+        if slots.numel():
+            dummy = self._postrope_dummy_slot()
+            safe = torch.where(slots >= 0, slots, dummy.expand_as(slots)).long()
+            mask.index_fill_(0, safe, True)
+
+    def _postrope_dummy_slot(self) -> torch.Tensor:
+        s = getattr(self, "_deltakv_postrope_dummy_slot", None)
+        if s is None:
+            s = torch.from_numpy(self._pool_sparse.pop(1)).to(self.device)
+            self._deltakv_postrope_dummy_slot = s
+        return s
+
+    @torch.no_grad()
+    def deltakv_reconstruct(self, layer_idx: int, active_compressed_indices, context_lens, req_indices, chunk_lens=None,
+                            return_reconstruct_temp_slots: bool = True):
+        """deltakv_less_memory.py:4032-4143 (static decode branch)."""
+        del context_lens, chunk_lens, return_reconstruct_temp_slots
+        with profiler.record("deltakv_less_memory_reconstruct_total"):
+            active_slots, local_req, new_context_lens, temp_slots, recon_pos, recon_latent, recon_out_slot = \
+                self._deltakv_build_view_and_plan_reconstruct(layer_idx, active_compressed_indices, req_indices)
+            l_idx = self.deltakv_layer_to_idx[layer_idx]
+            k_cache, v_cache = self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx]
+            if recon_latent.numel() > 0:
+                safe_latent = recon_latent.clamp_min(0)
+                father_slots = self.deltakv_latent_to_full_slots[l_idx, safe_latent.long()].clamp_min(0)
+                with profiler.record("deltakv_less_memory_reconstruct_load_residual"):
+                    kv_delta = self._load_residual(l_idx, safe_latent)
+                with profiler.record("deltakv_less_memory_reconstruct_writeback"):
+                    dk.deltakv_reconstruct_writeback_grouped_heads(
+                        kv_delta=kv_delta, father_slots=father_slots, slot_to_pos=self.deltakv_slot_to_pos,
+                        out_slots=recon_out_slot, out_pos=recon_pos, cos_sin=self.cos_sin_cache, k_cache=k_cache,
+                        v_cache=v_cache, k_norm_weight=None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx],
+                        k_norm_eps=float(self.deltakv_k_norm_eps), raw_k_cache=True, store_raw_k=False)
+            with profiler.record("deltakv_less_memory_reconstruct_mark_postrope"):
+                self._set_postrope_slots(layer_idx, recon_out_slot)
+            return active_slots, local_req, new_context_lens, torch.empty((0,), device=self.device, dtype=torch.int32)
+
+    def _ensure_materialized_sparse_view(self, batch_size: int, width: int):
+        """deltakv_less_memory.py:1309-1342: the attention view addresses the compact copy as arange(B*W)."""
+        total = int(batch_size) * int(width)
+        if total > int(self.deltakv_materialized_compute_num_slots):
+            raise RuntimeError("DeltaKV materialized sparse workspace is too small: "
+                               f"need={total} capacity={int(self.deltakv_materialized_compute_num_slots)} "
+                               f"batch={batch_size} width={width}. Increase max_num_batched_tokens or reduce decode keep tokens.")
+        key = (int(batch_size), int(width))
+        bufs = self._materialized_view.get(key)
+        if bufs is None:
+            d = self.device
+            bufs = (torch.arange(max(1, total), dtype=torch.int32, device=d).view(max(1, batch_size), max(1, width)),
+                    torch.arange(max(1, batch_size), dtype=torch.int32, device=d))
+            self._materialized_view[key] = bufs
+        return bufs[0][:batch_size, :width], bufs[1][:batch_size]
+
+    def get_layer_compute_view(self, layer_idx: int, active_slots, req_indices, context_lens, selection=None):
+        """deltakv_less_memory.py:1344-1402."""
+        if active_slots.dim() != 2:
+            raise RuntimeError("DeltaKV sparse materialization expects a 2D active slot table, "
+                               f"got shape={tuple(active_slots.shape)}.")
+        B, W = int(active_slots.shape[0]), int(active_slots.shape[1])
+        total = B * W
+        local_active, local_req = self._ensure_materialized_sparse_view(B, W)
+        k_out, v_out = self.deltakv_materialized_kv_cache[0, :total], self.deltakv_materialized_kv_cache[1, :total]
+        if total == 0:
+            return k_out, v_out, local_active, local_req, context_lens
+        l_idx = self.deltakv_layer_to_idx[layer_idx]
+        with profiler.record("deltakv_materialize_sparse_view"):
+            dk.deltakv_materialize_sparse_view(
+                active_slots, context_lens, self.deltakv_slot_to_pos, self._deltakv_postrope_slot_mask[l_idx],
+                self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx], k_out, v_out,
+                self.cos_sin_cache,
+                k_norm_weight=None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx],
+                k_norm_eps=float(self.deltakv_k_norm_eps))
+        return k_out, v_out, local_active, local_req, context_lens
+
+    def build_decode_compute_view(self, layer_idx: int, q: torch.Tensor, selection: SparseSelection, *, num_heads: int,
+                                  num_kv_heads: int) -> DecodeComputeView:
+        """deltakv_less_memory.py:2942-2995 (KIVI full layers) + deltakv_base.py:975-1018 (sparse layers)."""
+        if layer_idx in self.full_layer_to_idx:
+            l_idx = self.full_layer_to_idx[layer_idx]
+            meta = AttentionViewMeta(active_slots=self.full_layer_slots_map, req_indices=selection.req_indices,
+                                     context_lens=selection.context_lens, attn_score=selection.attn_score,
+                                     max_context_len=selection.max_context_len)
+            if self._full_layer_kivi_enabled():
+                return DecodeComputeView(meta=meta, payload=ExplicitKVPayload(
+                    k_cache=self.full_kv_cache[0, l_idx], v_cache=self.full_kv_cache[1, l_idx], backend="full_layer_kivi",
+                    metadata={"kivi_block_slots_map": self.full_layer_kivi_block_slots_map,
+                              "kivi_block_start_pos": self.full_layer_kivi_block_start_pos,
+                              "key_packed": self.full_layer_kivi_key_packed[l_idx],
+                              "key_scales": self.full_layer_kivi_key_scales[l_idx],
+                              "key_mins": self.full_layer_kivi_key_mins[l_idx],
+                              "value_packed": self.full_layer_kivi_value_packed[l_idx],
+                              "value_scales": self.full_layer_kivi_value_scales[l_idx],
+                              "value_mins": self.full_layer_kivi_value_mins[l_idx],
+                              "group_size": self._full_layer_kivi_group_size(),
+                              "block_n": int(self.config.full_layer_kivi_decode_block_n or 16),
+                              "num_warps": int(self.config.full_layer_kivi_decode_num_warps or 2),
+                              "num_stages": int(self.config.full_layer_kivi_decode_num_stages or 3)}))
+            return DecodeComputeView(meta=meta, payload=ExplicitKVPayload(k_cache=self.full_kv_cache[0, l_idx],
+                                                                          v_cache=self.full_kv_cache[1, l_idx]))
+        if selection.kind != "deltakv":
+            raise RuntimeError(f"sparse DeltaKV layer {layer_idx} needs a 'deltakv' selection, got {selection.kind!r}")
+        active_slots, local_req, context_lens, temp_slots = self.deltakv_reconstruct(
+            layer_idx=layer_idx, active_compressed_indices=selection.active_compressed_indices,
+            context_lens=selection.context_lens, req_indices=selection.req_indices, chunk_lens=selection.chunk_lens,
+            return_reconstruct_temp_slots=selection.release_temp_slots)
+        k_cache, v_cache, active_slots, req_indices, context_lens = self.get_layer_compute_view(
+            layer_idx, active_slots, local_req, context_lens, selection)
+        return DecodeComputeView(
+            meta=AttentionViewMeta(active_slots=active_slots, req_indices=req_indices, context_lens=context_lens,
+                                   attn_score=selection.attn_score, max_context_len=selection.max_context_len,
+                                   temp_slots=temp_slots),
+            payload=ExplicitKVPayload(k_cache=k_cache, v_cache=v_cache))
+
+    def release_layer_temp_slots(self, layer_idx: int, temp_slots):
+        """Static decode keeps its reconstruct scratch for the life of the graph (deltakv_less_memory.py:449-470)."""
+        return None

@@ -92,6 +92,64 @@ class SparseDecodeDriver:
                     cm.set_h2o_score(layer_idx, s.seq_id, sc0)
         return self.seqs
 
+    def admit_compressed_rows(self, batch: int, total_len: int, *, seed: int = 0, kv_scale: float = 0.3):
+        """DeltaKV: create `batch` sequences in the state a `total_len`-token prompt is in after prefill +
+        compression (the reference's deltakv_evict / KIVI store) with synthetic payload:
+        centres every int(1/cluster_ratio) tokens of each `recent`-sized evicted block
+        (deltakv_base.py:255-275), K causal fathers per compressed token, random int4 / bf16 latents, and on
+        KIVI full layers int4 blocks over [sink, quant_end) (deltakv_less_memory.py:3495-3520)."""
+        cm, cfg, d = self.cache_manager, self.config, self.device
+        lens = [int(total_len)] * batch if np.ndim(total_len) == 0 else [int(x) for x in total_len]
+        assert len(lens) == batch
+        gd = torch.Generator(device=d).manual_seed(seed)
+        self.seqs = [Sequence(num_prompt_tokens=n) for n in lens]
+        for s, n in zip(self.seqs, lens):
+            s.num_prefilled_tokens = s.num_prompt_tokens
+            self._admit_one_compressed_row(s, n, gd, kv_scale)
+        return self.seqs
+
+    def _admit_one_compressed_row(self, seq, total_len: int, gd, kv_scale: float):
+        cm, cfg, d = self.cache_manager, self.config, self.device
+        sink, recent = int(cfg.num_sink_tokens), int(cfg.num_recent_tokens)
+        step = max(1, int(1.0 / max(1e-6, float(cfg.cluster_ratio))))
+        buf = max(0, total_len - sink)
+        clen = ((buf - recent) // recent) * recent if buf > recent else 0
+        centers = np.concatenate([np.arange(s, min(s + recent, sink + clen), step)
+                                  for s in range(sink, sink + clen, recent)] or [np.empty(0, np.int64)]).astype(np.int64)
+        n_sink = min(sink, total_len)
+        n_raw = n_sink + centers.size + (total_len - n_sink - clen)
+        Ls, Lf, H, D = len(cm.deltakv_layer_ids), len(cm.full_layer_ids), cm.num_kv_heads, cm.head_dim
+        K = int(cfg.deltakv_k_neighbors)
+        rn = lambda *shape: (torch.randn(shape, generator=gd, device=d) * kv_scale).to(torch.bfloat16)
+        ri = lambda *shape: torch.randint(-2 ** 31, 2 ** 31 - 1, shape, generator=gd, device=d, dtype=torch.int64).to(torch.int32)
+        # causal father candidates of a compressed position: the sink tokens + the centres at positions <= it
+        avail = n_sink + np.searchsorted(centers, np.arange(sink, sink + clen), side="right")
+        avail_gpu = torch.from_numpy(np.maximum(avail, 1).astype(np.float32)).to(d)
+        fidx = (torch.rand((clen, K), generator=gd, device=d) * avail_gpu[:, None]).long().clamp_max_(
+            torch.from_numpy(np.maximum(avail, 1) - 1).to(d)[:, None]) if clen > 0 else torch.empty((0, K), dtype=torch.long, device=d)
+        if int(cfg.kv_quant_bits or 0) == 4:
+            W, g = cm.deltakv_latent_cache.shape[-1], cm.deltakv_latent_scales.shape[-1]
+            sc = (torch.rand((Ls, clen, g), generator=gd, device=d) * 0.05 + 0.01).to(torch.bfloat16)
+            latent = dict(code=ri(Ls, clen, W), scale=sc, mn=(sc.float() * -7.5).to(torch.bfloat16))
+        else:
+            latent = dict(dense=rn(Ls, clen, cm.deltakv_latent_cache.shape[-1]))
+        qend, blocks = 0, None
+        if cm._full_layer_kivi_enabled():
+            G = cm._full_layer_kivi_group_size()
+            qend = sink + (max(0, buf - int(cfg.full_layer_kivi_residual_length)) // G) * G
+            if qend > n_sink:
+                nb = (qend - n_sink) // G
+                ks = torch.rand((Lf, nb, H, D), generator=gd, device=d) * 0.1 + 0.02
+                vs = (torch.rand((Lf, nb, H, G, D // G), generator=gd, device=d) * 0.1 + 0.02).to(torch.bfloat16)
+                blocks = dict(key_packed=ri(Lf, nb, H, D, G // 8), key_scales=ks, key_mins=ks * -7.5,
+                              value_packed=ri(Lf, nb, H, G, D // 8), value_scales=vs,
+                              value_mins=(vs.float() * -7.5).to(torch.bfloat16))
+        n_full_raw = total_len - max(0, qend - n_sink)
+        cm.admit_compressed_row(seq, total_len=total_len, compressed_len=clen, center_positions=centers,
+                                father_center_index=fidx.cpu().numpy(), sparse_k_raw=rn(Ls, n_raw, H, D),
+                                sparse_v=rn(Ls, n_raw, H, D), latent=latent, full_k=rn(Lf, n_full_raw, H, D),
+                                full_v=rn(Lf, n_full_raw, H, D), kivi_quantized_end=qend, kivi_blocks=blocks)
+
     def random_step_inputs(self, seed: int = 1, scale: float = 0.3):
         """Per-layer q [L,B,Hq,D] and new-token k,v [L,B,Hkv,D] (bf16)."""
         cm = self.cache_manager
@@ -107,8 +165,14 @@ class SparseDecodeDriver:
         sc.prepare_forward(self.seqs, False)
         for layer_idx in range(cm.num_layers):
             ctx.now_layer_idx = layer_idx
+            save_raw = getattr(cm, "save_raw_kv_if_needed", None)
+            if save_raw is not None:          # DeltaKV sparse layers keep the pre-RoPE key (models/qwen2.py attention)
+                save_raw(layer_idx, k[layer_idx], v[layer_idx])
             cm.save_rope_kv_if_needed(layer_idx, k[layer_idx], v[layer_idx])
             o = self.attn(q[layer_idx])
+            on_layer_end = getattr(sc, "on_layer_end", None)
+            if on_layer_end is not None:
+                on_layer_end(layer_idx, ctx)
             if outputs is not None:
                 outputs[layer_idx].copy_(o)
 
@@ -187,6 +251,6 @@ class SparseDecodeDriver:
 
     def row_len(self) -> np.ndarray:
         cm = self.cache_manager
-        if hasattr(cm, "page_size"):
+        if hasattr(cm, "page_size") or isinstance(cm.seq_id_to_row, dict) and np.ndim(cm.row_seq_lens) == 1:
             return np.array([cm.row_seq_lens[cm.seq_id_to_row[s.seq_id]] for s in self.seqs])
         return np.array([cm.row_seq_lens[0][cm.seq_id_to_row[0][s.seq_id]] for s in self.seqs])

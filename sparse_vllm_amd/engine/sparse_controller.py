@@ -12,7 +12,7 @@ from dataclasses import dataclass
 
 import torch
 
-from ..kernels import h2o_ops
+from ..kernels import deltakv_kernels, h2o_ops
 from ..method_registry import normalize_sparse_method
 from ..utils.context import get_context
 from ..utils.profiler import profiler
@@ -26,6 +26,9 @@ class LayerBatchSparseState:
     req_indices: torch.Tensor | None = None
     max_context_len: int | None = None
     attn_score: torch.Tensor | None = None
+    active_compressed_indices: torch.Tensor | None = None
+    global_req_indices: torch.Tensor | None = None
+    deltakv_free_temp_slots: bool = False
 
 
 class SparseController:
@@ -46,6 +49,10 @@ class SparseController:
         self._h2o_decode_attn_score_buffers: dict[tuple, torch.Tensor] = {}
         self._fused_h2o_accumulate = True
         self._layer_score_finished = [False] * self.num_layers
+        self.is_deltakv_family = self.sparse_method == "deltakv"
+        self.obs_layer_ids = list(getattr(config, "obs_layer_ids", None) or [])
+        self.full_attn_layers = list(getattr(config, "full_attn_layers", None) or [])
+        self._decode_attn_score_buffers: dict[int, torch.Tensor] = {}
 
     def _is_kv_layer(self, layer_idx: int) -> bool:
         return self.cache_manager.is_full_attention_layer(layer_idx)
@@ -57,6 +64,8 @@ class SparseController:
         """sparse_controller.py:1963-2034 (h2o: every KV layer in decode, none in prefill)."""
         if self.sparse_method == "h2o":
             return (not is_prefill) and self._is_kv_layer(layer_idx)
+        if self.is_deltakv_family and layer_idx in self.obs_layer_ids:
+            return not is_prefill
         if self.sparse_method == "snapkv":
             if is_prefill:
                 return False
@@ -123,6 +132,15 @@ class SparseController:
             s = self.layer_batch_sparse_states[layer_idx]
             s.context_lens, s.req_indices, s.max_context_len = st.context_lens, st.req_indices, st.max_context_len
             s.attn_score = None
+            s.active_compressed_indices = None
+            s.global_req_indices = st.req_indices
+            s.deltakv_free_temp_slots = False
+        if not is_prefill and self.is_deltakv_family:
+            for layer_idx in self.obs_layer_ids:
+                s = self.layer_batch_sparse_states[layer_idx]
+                s.attn_score = self._get_decode_attn_score_buffer(
+                    layer_idx, int(s.context_lens.numel()), self.cache_manager.num_heads, int(s.max_context_len),
+                    fill_value=-1e20)
         if not is_prefill and self.sparse_method == "h2o":
             self._prepare_h2o_decode_attn_score_buffer(seqs)
         if not is_prefill and self.sparse_method == "snapkv":
@@ -131,6 +149,20 @@ class SparseController:
                     s = self.layer_batch_sparse_states[layer_idx]
                     s.attn_score = self._get_snapkv_decode_score_buffer(
                         layer_idx, int(s.context_lens.numel()), int(s.max_context_len), fill_value=-1e20)
+
+    def _get_decode_attn_score_buffer(self, layer_idx: int, batch_size: int, num_heads: int, max_len: int, *,
+                                      fill_value: float) -> torch.Tensor:
+        """sparse_controller.py:656-689: stable per-layer [B, H, L] raw-logit buffer, refilled every step."""
+        if batch_size <= 0 or num_heads <= 0 or max_len <= 0:
+            raise RuntimeError("Decode attention score buffer requires positive shape: "
+                               f"layer={layer_idx} batch={batch_size} heads={num_heads} max_len={max_len}.")
+        buf = self._decode_attn_score_buffers.get(int(layer_idx))
+        if buf is None or buf.shape[0] < batch_size or buf.shape[1] < num_heads or buf.shape[2] < max_len:
+            buf = torch.empty((batch_size, num_heads, max_len), dtype=torch.float32, device=self.device)
+            self._decode_attn_score_buffers[int(layer_idx)] = buf
+        view = buf[:batch_size, :num_heads, :max_len]
+        h2o_ops.fill_f32(view, fill_value) if view.is_contiguous() else view.fill_(fill_value)
+        return view
 
     def _h2o_decode_score_width(self, layer_indices) -> int:
         """sparse_controller.py:401-425."""
@@ -170,8 +202,17 @@ class SparseController:
     def get_decode_selection(self, layer_idx: int, q: torch.Tensor) -> SparseSelection:
         """sparse_controller.py:881-910 (kind="full": attend the whole physical row)."""
         s = self.layer_batch_sparse_states[layer_idx]
-        return SparseSelection(kind="full", req_indices=s.req_indices, context_lens=s.context_lens,
-                               max_context_len=s.max_context_len, attn_score=s.attn_score)
+        if self.is_deltakv_family and layer_idx not in self.full_attn_layers:
+            # sparse_controller.py:912-935: batch-major view, K selected compressed positions (-1 padded / None = 0)
+            return SparseSelection(kind="deltakv", req_indices=s.global_req_indices, context_lens=s.context_lens,
+                                   max_context_len=s.max_context_len, attn_score=s.attn_score,
+                                   active_compressed_indices=s.active_compressed_indices,
+                                   global_req_indices=s.global_req_indices, chunk_lens=None,
+                                   release_temp_slots=s.deltakv_free_temp_slots)
+        req = s.global_req_indices if self.is_deltakv_family else s.req_indices
+        return SparseSelection(kind="full", req_indices=req, context_lens=s.context_lens,
+                               max_context_len=s.max_context_len, attn_score=s.attn_score,
+                               global_req_indices=s.global_req_indices)
 
     def fused_decode_finish(self, layer_idx: int, mid_o, mid_lse, context_lens, o, block_seq) -> bool:
         """MI355X fusion hook called by the attention backend instead of `flash_decode_stage2`:
@@ -212,6 +253,65 @@ class SparseController:
         h2o_ops.h2o_decode_score_update(s.attn_score, self.attn_softmax_scale, cum_score=cum,
                                         b_req_idx=s.req_indices, b_seqlen=s.context_lens)
 
+    # ------------------------------------------------------------------ DeltaKV query-aware top-k
+    @torch.no_grad()
+    def on_layer_end(self, layer_idx: int, context=None):
+        """sparse_controller.py:971-1052 (DeltaKV decode branch): observation-layer raw logits -> per-head softmax over
+        the compressed range -> max over heads (bf16-rounded like the model dtype cast) -> sorted top-k, shared by
+        the sparse layers up to the next full-attention layer."""
+        context = context or get_context()
+        if not self._is_kv_layer(layer_idx) or not self.is_deltakv_family or context.is_prefill:
+            return
+        if layer_idx not in self.obs_layer_ids:
+            return
+        with profiler.record("sparse_on_layer_end"):
+            state = self.layer_batch_sparse_states[layer_idx]
+            if state.attn_score is None:
+                raise ValueError("Attn Score hasn't been initialized")
+            if state.attn_score.dim() == 3:
+                compressed_lens = self.cache_manager.get_compressed_lens(state.req_indices)
+                state.attn_score = self._decode_softmax_token_scores(state.attn_score, candidate_start=self.num_sink,
+                                                                     candidate_lens=compressed_lens)
+            target_layers = []
+            for j in range(layer_idx + 1, self.num_layers):
+                if j in self.full_attn_layers:
+                    break
+                target_layers.append(j)
+            if not target_layers:
+                raise RuntimeError("Dynamic sparse observation layer has no target KV layers: "
+                                   f"method={self.sparse_method} observation_layer={layer_idx} "
+                                   f"full_attn_layers={self.full_attn_layers}.")
+            self._update_dynamic_omnikv_indices(layer_idx, target_layers)
+
+    def _decode_softmax_token_scores(self, scores: torch.Tensor, *, candidate_start: int, candidate_lens: torch.Tensor):
+        """sparse_controller.py:255-299 as one fused pass (svk_deltakv_token_scores); values are bf16-representable
+        floats (the reference casts to the model dtype), masked entries = finfo(bf16).min."""
+        return deltakv_kernels.decode_softmax_token_scores(scores, candidate_start=candidate_start,
+                                                           candidate_lens=candidate_lens, scale=self.attn_softmax_scale,
+                                                           round_dtype=torch.bfloat16)
+
+    def _update_dynamic_omnikv_indices(self, obs_layer_idx: int, target_layers):
+        """sparse_controller.py:1755-1822, :1951-1959 (DeltaKV decode): mask beyond the compressed length with -1e10,
+        `topk(k_max, sorted=True)`; ties resolve to the lower position (the reference's optional deterministic
+        tie-break :1797-1811 has the same order)."""
+        obs = self.layer_batch_sparse_states[obs_layer_idx]
+        token_scores = obs.attn_score
+        search_scores = token_scores[:, self.num_sink:]
+        rel_hist_lens = self.cache_manager.get_compressed_lens(obs.req_indices)
+        k_max = min(int(self.decode_keep_tokens), int(search_scores.size(1)))
+        if k_max > 0:
+            topk_indices = deltakv_kernels.topk_sorted_desc(search_scores, k_max, valid_len=rel_hist_lens,
+                                                            masked_value=-1e10)
+        else:
+            topk_indices = torch.empty((token_scores.shape[0], 0), device=self.device, dtype=torch.int32)
+        for l_idx in target_layers:
+            t = self.layer_batch_sparse_states[l_idx]
+            t.active_compressed_indices = topk_indices
+            t.context_lens = obs.context_lens
+            t.req_indices = obs.req_indices
+            t.global_req_indices = obs.req_indices
+            t.deltakv_free_temp_slots = (l_idx == target_layers[-1])
+
     # ------------------------------------------------------------------ post
     @torch.no_grad()
     def post_forward(self, seqs, is_prefill: bool):
@@ -226,6 +326,10 @@ class SparseController:
             return
         if self.sparse_method == "h2o":
             self._h2o_decode_eviction(seqs)
+        elif self.is_deltakv_family:
+            evict = getattr(self.cache_manager, "deltakv_evict", None)
+            if evict is not None:
+                evict(seqs)
         elif self.sparse_method == "streamingllm":
             self._streamingllm_decode_eviction(seqs)
         elif self.sparse_method == "snapkv":

@@ -220,6 +220,52 @@ def topk_sorted_desc(scores, k: int, *, valid_len=None, masked_value: float = -1
     return out
 
 
+@torch.no_grad()
+def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, postrope_mask, k_cache, v_cache, out_k, out_v,
+                                    cos_sin, *, k_norm_weight=None, k_norm_eps: float = 1e-6, block_tokens: int = 16):
+    """Reference wrapper deltakv_kernels.py:3489-3585 (same arguments; `block_tokens` is a Triton tile knob)."""
+    for t in (active_slots, context_lens, slot_to_pos, k_cache, v_cache, out_k, out_v, cos_sin):
+        assert t.is_cuda
+    assert active_slots.dim() == 2
+    assert context_lens.dim() == 1 and context_lens.shape[0] == active_slots.shape[0]
+    assert k_cache.dim() == 3 and v_cache.shape == k_cache.shape
+    assert out_k.dim() == 3 and out_v.shape == out_k.shape
+    batch, width = active_slots.shape
+    total = int(batch) * int(width)
+    if total == 0:
+        return
+    if out_k.shape[0] < total or out_v.shape[0] < total:
+        raise RuntimeError("DeltaKV materialize sparse view output is too small: "
+                           f"out={tuple(out_k.shape)}/{tuple(out_v.shape)} need={total}.")
+    num_kv_heads, head_dim = int(k_cache.shape[1]), int(k_cache.shape[2])
+    if head_dim % 2 != 0:
+        raise RuntimeError(f"DeltaKV materialize sparse view requires an even head_dim, got {head_dim}.")
+    if cos_sin.dim() == 3:
+        cos_sin = cos_sin[:, 0, :]
+    assert cos_sin.dim() == 2 and cos_sin.shape[1] == head_dim and cos_sin.stride(1) == 1
+    if k_norm_weight is not None:
+        assert k_norm_weight.is_cuda and k_norm_weight.dim() == 1 and k_norm_weight.shape[0] == head_dim
+        k_norm_weight = k_norm_weight.to(torch.float32).contiguous()
+    if postrope_mask is not None:
+        assert postrope_mask.is_cuda and postrope_mask.dim() == 1 and postrope_mask.shape[0] >= k_cache.shape[0]
+        assert postrope_mask.dtype in (torch.bool, torch.uint8) and postrope_mask.is_contiguous()
+    assert active_slots.dtype == torch.int32 and active_slots.stride(1) == 1
+    assert slot_to_pos.dtype == torch.int32 and slot_to_pos.is_contiguous()
+    for t in (k_cache, v_cache, out_k, out_v):
+        assert t.dtype == torch.bfloat16 and t.stride(2) == 1
+    assert k_cache.stride() == v_cache.stride() and out_k.stride() == out_v.stride()
+    lib = _lib.load()
+    a = _lib.SvkDeltakvMaterializeArgs(
+        active_slots=_lib.ptr(active_slots), slot_to_pos=_lib.ptr(slot_to_pos), postrope_mask=_lib.ptr(postrope_mask),
+        k_cache=_lib.ptr(k_cache), v_cache=_lib.ptr(v_cache), out_k=_lib.ptr(out_k), out_v=_lib.ptr(out_v),
+        cos_sin=_lib.ptr(cos_sin), k_norm_weight=_lib.ptr(k_norm_weight),
+        active_stride=active_slots.stride(0), kv_slot_stride=k_cache.stride(0), kv_head_stride=k_cache.stride(1),
+        out_slot_stride=out_k.stride(0), out_head_stride=out_k.stride(1), cos_stride=cos_sin.stride(0),
+        k_norm_eps=float(k_norm_eps), batch=int(batch), width=int(width), num_slots=int(k_cache.shape[0]),
+        num_kv_heads=num_kv_heads, head_dim=head_dim, cos_dtype=_dt(cos_sin))
+    _lib.check(lib.svk_deltakv_materialize_sparse_view(C.byref(a), _lib.current_stream_handle()), lib)
+
+
 def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_block_slots_map, kivi_block_start_pos,
                                         key_packed, key_scales, key_mins, value_packed, value_scales, value_mins,
                                         req_indices, context_lens, max_len_in_batch: int, mid_out, mid_out_logsumexp,
@@ -281,8 +327,10 @@ def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_
     assert kivi_block_start_pos.dtype == torch.int32 and kivi_block_start_pos.is_contiguous()
     for t in (key_packed, value_packed):
         assert t.dtype == torch.int32 and t.is_contiguous()
-    for t in (key_scales, key_mins, value_scales, value_mins):
+    for t in (value_scales, value_mins):
         assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    assert key_scales.dtype in (torch.float32, torch.bfloat16) and key_mins.dtype == key_scales.dtype
+    assert key_scales.is_contiguous() and key_mins.is_contiguous()
     assert tuple(key_packed.shape[2:]) == (head_dim, group_size // 8)
     assert tuple(value_packed.shape[2:]) == (group_size, head_dim // 8)
     assert mid_out.dtype == torch.float32 and mid_out.stride(3) == 1 and mid_out_logsumexp.stride(2) == 1
@@ -304,5 +352,6 @@ def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_
         score_stride_b=attn_score.stride(0) if attn_score is not None else 0,
         score_stride_h=attn_score.stride(1) if attn_score is not None else 0,
         batch=batch, num_q_heads=int(q.shape[1]), num_kv_heads=num_kv_heads, head_dim=head_dim,
-        max_len_in_batch=max_len_in_batch, block_seq=block_seq, group_size=group_size)
+        max_len_in_batch=max_len_in_batch, block_seq=block_seq, group_size=group_size,
+        key_param_dtype=_dt(key_scales))
     _lib.check(lib.svk_kivi_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)

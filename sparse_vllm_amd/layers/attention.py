@@ -13,6 +13,7 @@ import torch
 
 from ..engine.cache_manager.base import DecodeComputeView, ExplicitKVPayload
 from ..kernels import flash_decode_stage1, flash_decode_stage1_with_score, flash_decode_stage2
+from ..kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1
 from ..utils.context import get_context
 from ..utils.profiler import profiler
 
@@ -44,6 +45,24 @@ class HipAttentionBackend:
             raise TypeError(f"HIP decode requires ExplicitKVPayload, got {type(payload).__name__}.")
         meta = view.meta
         kind = "full" if int(max_len_in_batch) > 8192 else "sparse"
+        if payload.backend == "full_layer_kivi":
+            # layers/attention_backend.py:236-247, :351-395
+            md = payload.metadata
+            if md is None:
+                raise RuntimeError("full_layer_kivi decode view is missing metadata.")
+            with profiler.record("decode_attention_stage1_kivi"):
+                full_layer_kivi_flash_decode_stage1(
+                    q=q, raw_k=payload.k_cache, raw_v=payload.v_cache, raw_slots_map=meta.active_slots,
+                    kivi_block_slots_map=md["kivi_block_slots_map"], kivi_block_start_pos=md["kivi_block_start_pos"],
+                    key_packed=md["key_packed"], key_scales=md["key_scales"], key_mins=md["key_mins"],
+                    value_packed=md["value_packed"], value_scales=md["value_scales"], value_mins=md["value_mins"],
+                    req_indices=meta.req_indices, context_lens=meta.context_lens, max_len_in_batch=max_len_in_batch,
+                    mid_out=mid_o, mid_out_logsumexp=mid_o_logexpsum, group_size=int(md["group_size"]),
+                    block_seq=block_seq, block_n=int(md.get("block_n", 16)), num_warps=int(md.get("num_warps", 2)),
+                    num_stages=int(md.get("num_stages", 3)), attn_score=meta.attn_score)
+            o = torch.empty_like(q)
+            flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
+            return o
         with profiler.record(f"decode_attention_stage1_{kind}"):
             if meta.attn_score is not None:
                 flash_decode_stage1_with_score(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,

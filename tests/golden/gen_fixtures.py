@@ -676,6 +676,44 @@ def gen_kivi():
     save("kivi", **out)
 
 
+def gen_deltakv_view():
+    """`deltakv_materialize_sparse_view` (deltakv_kernels.py:3489-3585, kernel :3588-3693): the attention-facing
+    contiguous copy of a sparse layer's active slots (raw pre-RoPE K -> optional k-norm -> RoPE at slot_to_pos;
+    slots flagged post-RoPE are copied).  The wrapper asserts `.is_cuda`, so the jit kernel is launched directly."""
+    from sparsevllm.kernels.triton import deltakv_kernels as dk
+
+    g = torch.Generator().manual_seed(45)
+    Hkv, D, slots, B, W, max_p, BN = 2, 64, 80, 3, 11, 96, 16
+    kc = bf16f(torch.randn(slots, Hkv, D, generator=g) * 0.5)
+    vc = bf16f(torch.randn(slots, Hkv, D, generator=g) * 0.5)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, D // 2).float() / (D // 2)))
+    ang = torch.arange(max_p).float()[:, None] * inv_freq[None, :]
+    cos_sin = torch.cat((ang.cos(), ang.sin()), dim=1).contiguous()
+    active = torch.randint(0, slots, (B, W), generator=g, dtype=torch.int32)
+    active[1, 7:] = -1                                   # padding beyond a short row
+    lens = torch.tensor([W, 7, W - 2], dtype=torch.int32)
+    slot_to_pos = torch.randint(0, max_p, (slots,), generator=g, dtype=torch.int32)
+    slot_to_pos[5] = -1                                  # unknown position -> clamped to 0
+    post = torch.rand(slots, generator=g) < 0.3
+    knorm = torch.rand(D, generator=g) + 0.5
+    out = dict(k=bits(kc), v=bits(vc), cos_sin=cos_sin.numpy(), active=active.numpy(), lens=lens.numpy(),
+               slot_to_pos=slot_to_pos.numpy(), post=post.numpy(), knorm=knorm.numpy())
+    total = B * W
+    for tag, use_norm, use_mask in (("plain", False, False), ("norm_mask", True, True)):
+        ok = torch.zeros(total, Hkv, D); ov = torch.zeros(total, Hkv, D)
+        nw = knorm if use_norm else cos_sin
+        pm = post if use_mask else slot_to_pos
+        dk._deltakv_materialize_sparse_view_block_kernel[((total + BN - 1) // BN, Hkv)](
+            active, lens, slot_to_pos, pm, kc, vc, ok, ov, cos_sin, nw,
+            active.stride(0), active.stride(1), kc.stride(0), kc.stride(1), kc.stride(2),
+            vc.stride(0), vc.stride(1), vc.stride(2), ok.stride(0), ok.stride(1), ok.stride(2),
+            ov.stride(0), ov.stride(1), ov.stride(2), cos_sin.stride(0), cos_sin.stride(1), nw.stride(0),
+            TOTAL=total, WIDTH=W, BLOCK_N=BN, NUM_SLOTS=slots, HEAD_DIM=D, HD2=D // 2, NUM_KV_HEADS=Hkv,
+            APPLY_K_NORM=use_norm, HAS_POSTROPE_MASK=use_mask, K_NORM_EPS=1e-6)
+        out[f"{tag}_k"] = ok.numpy(); out[f"{tag}_v"] = ov.numpy()
+    save("deltakv_view", **out)
+
+
 GROUPS = {
     "decode": gen_decode,
     "h2o_select": gen_h2o_select,
@@ -686,6 +724,7 @@ GROUPS = {
     "prefill_score": gen_prefill_score,
     "deltakv": gen_deltakv,
     "kivi": gen_kivi,
+    "deltakv_view": gen_deltakv_view,
 }
 
 

@@ -184,3 +184,45 @@ def test_token_scores_and_sorted_topk():
         s = np.where(np.arange(L - sink) < clens[b], search[b], np.float32(-1e10))
         exp = np.argsort(-s, kind="stable")[:K]
         np.testing.assert_array_equal(idx[b], exp)
+
+
+def test_materialize_sparse_view_golden_and_random(golden):
+    """Tolerance: one bf16 rounding of the rotated key (|x| <~ 4 -> atol 2^-7 * ... use rtol 2^-7, atol 1e-6);
+    V and post-RoPE K are copies -> bit-exact."""
+    from sparse_vllm_amd.kernels.deltakv_kernels import deltakv_materialize_sparse_view
+    g = golden("deltakv_view")
+
+    def run(active, lens, s2p, post, k_bits, v_bits, cos_sin, knorm):
+        B, W = active.shape
+        kc = torch.from_numpy(k_bits.view(np.int16).copy()).to(dev()).view(torch.bfloat16)
+        vc = torch.from_numpy(v_bits.view(np.int16).copy()).to(dev()).view(torch.bfloat16)
+        ok = torch.zeros((B * W + 3,) + tuple(kc.shape[1:]), dtype=torch.bfloat16, device=dev())
+        ov = torch.zeros_like(ok)
+        deltakv_materialize_sparse_view(t(active), t(lens), t(s2p), None if post is None else t(post), kc, vc, ok, ov,
+                                        t(cos_sin), k_norm_weight=None if knorm is None else t(knorm))
+        torch.cuda.synchronize()
+        return ok[:B * W].float().cpu().numpy(), ov[:B * W].float().cpu().numpy(), ok[B * W:].float().cpu().numpy()
+
+    for tag, norm, mask in (("plain", None, None), ("norm_mask", g["knorm"], g["post"])):
+        ok, ov, tail = run(g["active"], g["lens"], g["slot_to_pos"], mask, g["k"], g["v"], g["cos_sin"], norm)
+        np.testing.assert_allclose(ok, g[f"{tag}_k"], rtol=2 ** -7, atol=1e-6)
+        np.testing.assert_array_equal(ov, g[f"{tag}_v"])
+        assert not tail.any()
+    # paper-config shape: 4 KV heads x 128, view width 8 + 2048 + 256
+    rng = np.random.default_rng(3)
+    S, Hkv, D, B, W, P = 9000, 4, 128, 3, 2312, 5000
+    k = f32_to_bf16_bits(rng.standard_normal((S, Hkv, D)).astype(np.float32))
+    v = f32_to_bf16_bits(rng.standard_normal((S, Hkv, D)).astype(np.float32))
+    inv = 1.0 / (1e6 ** (np.arange(D // 2) / (D // 2)))
+    ang = np.arange(P)[:, None] * inv[None, :]
+    cos_sin = np.concatenate((np.cos(ang), np.sin(ang)), axis=1).astype(np.float32)
+    active = rng.integers(0, S, (B, W)).astype(np.int32)
+    s2p = rng.integers(0, P, (S,)).astype(np.int32)
+    post = rng.random(S) < 0.5
+    lens = np.full((B,), W, np.int32)
+    ok, ov, _ = run(active, lens, s2p, post, k, v, cos_sin, None)
+    rk, rv = od.materialize_sparse_view(active, s2p, bf16_bits_to_f32(k), bf16_bits_to_f32(v), cos_sin, postrope_mask=post)
+    np.testing.assert_allclose(ok, rk, rtol=2 ** -7, atol=1e-6)
+    np.testing.assert_array_equal(ov, rv)
+    copied = post[active.reshape(-1)]
+    np.testing.assert_array_equal(ok[copied], bf16_bits_to_f32(k)[active.reshape(-1)[copied]])

@@ -1,0 +1,209 @@
+"""End-to-end DeltaKV decode on the GPU through the reference's operator surface (CacheManager.create ->
+prepare_decode_static -> Attention.forward per layer -> SparseController.on_layer_end) against the numpy oracle
+chained step by step on a mirror of the device state:
+
+  full (observation) layers : KIVI-int4 or raw decode stage 1 with raw 3-D scores -> stage 2
+  query-aware top-k         : per-head softmax over the compressed range, max over heads, bf16, sorted top-k
+  sparse layers             : static plan (bit-exact) -> latent dequant -> compress_up -> reconstruct + RoPE ->
+                              attention view (RoPE on the fly) -> decode attention
+
+Tolerances: attention outputs rtol = atol = 2e-2 (the reference's bar for decode partials); token scores 1 bf16 ulp;
+the GPU's top-k must be a valid top-k set of the oracle's scores up to that ulp (ties are order-free)."""
+
+import numpy as np
+import pytest
+
+from oracle import bf16_bits_to_f32, bf16_round
+from oracle import decode_attention as oda
+from oracle import deltakv as od
+from oracle import kivi as ok
+from oracle.quest import check_topk_set
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL = 2e-2
+
+
+def f32(t):
+    return t.float().cpu().numpy()
+
+
+def linear_up(mod, x):
+    """compress_up on bf16-valued fp32 arrays (fp32 accumulation, bf16 outputs like the torch bf16 modules)."""
+    def lin(layer, v):
+        y = v @ f32(layer.weight).T
+        if layer.bias is not None:
+            y = y + f32(layer.bias)
+        return bf16_round(y.astype(np.float32))
+    if isinstance(mod, torch.nn.Linear):
+        return lin(mod, x)
+    h = lin(mod[0], x)
+    h = bf16_round((0.5 * h * (1.0 + np.vectorize(__import__("math").erf)(h / np.sqrt(2.0)))).astype(np.float32))
+    return lin(mod[2], h)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(layers=5, full="0,3", kivi=True, up="linear", bits=4, lens=[148, 92, 61], Hq=8, Hkv=2, D=64),
+    dict(layers=6, full="0,1,4", kivi=False, up="mlp_gelu", bits=0, lens=[116, 44], Hq=28, Hkv=4, D=128),
+])
+def test_deltakv_decode_steps_match_oracle(cfg):
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    B, L = len(cfg["lens"]), cfg["layers"]
+    sink, recent, keep, Kf = 4, 8, 12, 2
+    conf = Config.from_kwargs(
+        sparse_method="deltakv", num_hidden_layers=L, full_attention_layers=cfg["full"], num_attention_heads=cfg["Hq"],
+        num_key_value_heads=cfg["Hkv"], head_dim=cfg["D"], max_model_len=256, max_num_seqs_in_gpu=B + 1,
+        sink_keep_tokens=sink, recent_keep_tokens=recent, decode_keep_tokens=keep, deltakv_neighbor_count=Kf,
+        deltakv_latent_dim=32, deltakv_latent_quant_bits=cfg["bits"], deltakv_latent_quant_group_size=16,
+        deltakv_center_ratio=0.25, allow_missing_deltakv_path=True, compressor_up_type=cfg["up"],
+        compressor_intermediate_size=48, full_layer_kv_quant_bits=4 if cfg["kivi"] else 0,
+        full_layer_kivi_decode_block_seq=64, rope_theta=10000.0)
+    drv = SparseDecodeDriver(conf)
+    cm, sc = drv.cache_manager, drv.sparse_controller
+    cm.permute_free_slots(7)
+    seqs = drv.admit_compressed_rows(B, cfg["lens"], seed=3)
+    rows = np.array([cm.seq_id_to_row[s.seq_id] for s in seqs])
+    Hq, Hkv, D = cfg["Hq"], cfg["Hkv"], cfg["D"]
+    scale = D ** -0.5
+    max_buffer = cm._deltakv_decode_static_max_buffer()
+    assert max_buffer == 2 * recent
+
+    # ---- mirror of the device caches
+    full_k, full_v = f32(cm.full_kv_cache[0]).copy(), f32(cm.full_kv_cache[1]).copy()
+    sp_k, sp_v = f32(cm.deltakv_full_kv_cache[0]).copy(), f32(cm.deltakv_full_kv_cache[1]).copy()
+    cos_sin = cm.cos_sin_cache.cpu().numpy()
+    lat_map = cm.sparse_layer_latent_slots_map.cpu().numpy()
+    fathers = cm.deltakv_latent_to_full_slots.cpu().numpy()
+    if cfg["bits"]:
+        lat_code = cm.deltakv_latent_cache.cpu().numpy()
+        lat_scale, lat_mn = f32(cm.deltakv_latent_scales), f32(cm.deltakv_latent_mins)
+    else:
+        lat_dense = f32(cm.deltakv_latent_cache)
+    clens = cm.row_deltakv_compressed_lens[rows].copy()
+    if cfg["kivi"]:
+        kv = {n: getattr(cm, f"full_layer_kivi_{n}") for n in ("key_packed", "key_scales", "key_mins", "value_packed",
+                                                                "value_scales", "value_mins")}
+        kv = {n: (t.cpu().numpy() if t.dtype in (torch.int32, torch.float32) else f32(t)) for n, t in kv.items()}
+        blk_map = cm.full_layer_kivi_block_slots_map.cpu().numpy()
+        blk_start = cm.full_layer_kivi_block_start_pos.cpu().numpy()
+
+    outs = torch.zeros((L, B, Hq, D), dtype=torch.bfloat16, device=drv.device)
+    for step in range(6):                       # the raw tail grows from `recent` towards 2*recent (no compression yet)
+        q, k, v = drv.random_step_inputs(seed=50 + step)
+        drv.step(q, k, v, outputs=outs)
+        torch.cuda.synchronize()
+        got = f32(outs)
+        qf, kf, vf = f32(q), f32(k), f32(v)
+        lens = cm.row_seq_lens[rows].copy()
+        full_map = cm.full_layer_slots_map.cpu().numpy()
+        raw_map = cm.sparse_layer_raw_slots_map.cpu().numpy()
+        slot_to_pos = cm.deltakv_slot_to_pos.cpu().numpy()
+        new_full = full_map[rows, lens - 1]
+        new_sparse = raw_map[rows, lens - 1]
+        assert (new_full >= 0).all() and (new_sparse >= 0).all()
+        np.testing.assert_array_equal(slot_to_pos[new_sparse], lens - 1)
+        active = None
+        for l in range(L):
+            if l in cm.full_layer_to_idx:
+                i = cm.full_layer_to_idx[l]
+                full_k[i][new_full], full_v[i][new_full] = kf[l], vf[l]
+                max_len = int(lens.max())
+                score = np.full((B, Hq, max_len), -1e20, np.float32)
+                if cfg["kivi"]:
+                    mid, lse = ok.full_layer_kivi_flash_decode_stage1(
+                        q=qf[l], raw_k=full_k[i], raw_v=full_v[i], raw_slots_map=full_map, kivi_block_slots_map=blk_map,
+                        kivi_block_start_pos=blk_start, key_packed=kv["key_packed"][i], key_scales=kv["key_scales"][i],
+                        key_mins=kv["key_mins"][i], value_packed=kv["value_packed"][i], value_scales=kv["value_scales"][i],
+                        value_mins=kv["value_mins"][i], req_indices=rows, context_lens=lens, max_len_in_batch=max_len,
+                        group_size=32, block_seq=64, attn_score=score)
+                else:
+                    mid, lse = oda.flash_decode_stage1(qf[l], full_k[i], full_v[i], full_map, rows.astype(np.int32),
+                                                       lens.astype(np.int32), max_len, 64, attn_score=score)
+                ref = oda.flash_decode_stage2(mid, lse, lens.astype(np.int32), 64)
+                np.testing.assert_allclose(got[l], bf16_round(ref), rtol=TOL, atol=TOL, err_msg=f"full layer {l} step {step}")
+                if l in sc.obs_layer_ids:
+                    tok = bf16_round(od.decode_softmax_token_scores(score, sink=sink, compressed_lens=clens, scale=scale))
+                    st = sc.layer_batch_sparse_states[l + 1]
+                    active = st.active_compressed_indices.cpu().numpy()
+                    k_max = min(keep, int(lens.max()) - sink)
+                    assert active.shape == (B, k_max)
+                    gpu_tok = f32(sc.layer_batch_sparse_states[l].attn_score)[:, sink:]
+                    for b in range(B):
+                        c = int(clens[b])
+                        np.testing.assert_allclose(gpu_tok[b, :c], tok[b, :c], rtol=2 ** -7, atol=1e-30)
+                        n_valid = min(c, k_max)
+                        if n_valid:
+                            # a valid top-k of the GPU's own (bf16) scores; sorted descending, ties by position
+                            check_topk_set(gpu_tok[b, :c], active[b, :n_valid], n_valid)
+                            vals = gpu_tok[b, active[b, :n_valid]]
+                            assert np.all(np.diff(vals) <= 0)
+                continue
+            # ---- sparse layer
+            i = cm.deltakv_layer_to_idx[l]
+            sp_k[i][new_sparse], sp_v[i][new_sparse] = kf[l], vf[l]
+            assert active is not None
+            temp = cm._temp_slots_by_shape[(B, active.shape[1])].cpu().numpy()
+            plan = od.static_decode_plan(raw_map, lat_map, active, rows, lens, clens, temp, sink=sink, max_buffer=max_buffer)
+            rl, ro, rp = plan["recon_latent"], plan["recon_out_slot"], plan["recon_pos"]
+            need = rl >= 0
+            safe_l = np.maximum(rl, 0)
+            if cfg["bits"]:
+                x = bf16_round(od.dequantize_grouped(lat_code[i][safe_l], lat_scale[i][safe_l], lat_mn[i][safe_l], 16, 4))
+            else:
+                x = lat_dense[i][safe_l]
+            delta = linear_up(cm.compress_up[i], x)
+            od.reconstruct_writeback(sp_k[i], sp_v[i], father_slots=np.maximum(fathers[i][safe_l], 0), slot_to_pos=slot_to_pos,
+                                     out_slots=ro, out_pos=rp, cos_sin=cos_sin, delta=delta, raw_k_cache=True)
+            post = np.zeros(sp_k[i].shape[0], bool)
+            post[ro[need]] = True
+            vk, vv = od.materialize_sparse_view(plan["active_slots"], slot_to_pos, sp_k[i], sp_v[i], cos_sin, postrope_mask=post)
+            W = plan["active_slots"].shape[1]
+            table = np.arange(B * W, dtype=np.int32).reshape(B, W)
+            ref, _ = oda.decode_attention_dense(qf[l], vk, vv, table, np.arange(B, dtype=np.int32), plan["new_context_lens"])
+            np.testing.assert_allclose(got[l], bf16_round(ref), rtol=TOL, atol=TOL, err_msg=f"sparse layer {l} step {step}")
+        # ---- the last observation group's plan is still in the device buffers: bit-exact
+        S = sink + active.shape[1] + max_buffer
+        a_slots, a_pos, _, new_len, _, r_pos, r_lat, r_out = (t.cpu().numpy() for t in cm._plan_buffers[(B, active.shape[1], S)])
+        np.testing.assert_array_equal(a_slots, plan["active_slots"])
+        np.testing.assert_array_equal(a_pos, plan["active_pos"])
+        np.testing.assert_array_equal(new_len, plan["new_context_lens"])
+        np.testing.assert_array_equal(r_pos, plan["recon_pos"])
+        np.testing.assert_array_equal(r_lat, plan["recon_latent"])
+        np.testing.assert_array_equal(r_out, plan["recon_out_slot"])
+
+    # ---- the static tail is bounded: decoding past 2*recent raw tokens needs the compression side
+    with pytest.raises(RuntimeError, match="compression side"):
+        for step in range(2 * recent + 2):
+            q, k, v = drv.random_step_inputs(seed=500 + step)
+            drv.step(q, k, v)
+
+
+def test_deltakv_free_seq_returns_every_slot():
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    conf = Config.from_kwargs(
+        sparse_method="deltakv", num_hidden_layers=3, full_attention_layers="0", num_attention_heads=8,
+        num_key_value_heads=2, head_dim=64, max_model_len=256, max_num_seqs_in_gpu=3, sink_keep_tokens=4,
+        recent_keep_tokens=8, decode_keep_tokens=12, deltakv_neighbor_count=2, deltakv_latent_dim=32,
+        deltakv_latent_quant_group_size=16, deltakv_center_ratio=0.25, allow_missing_deltakv_path=True,
+        compressor_up_type="linear", full_layer_kv_quant_bits=4)
+    drv = SparseDecodeDriver(conf)
+    cm = drv.cache_manager
+    before = cm.free_slot_stats()
+    seqs = drv.admit_compressed_rows(2, [150, 80], seed=1)
+    q, k, v = drv.random_step_inputs(seed=9)
+    drv.step(q, k, v)
+    torch.cuda.synchronize()
+    held = cm.free_slot_stats()
+    assert held["latent"] < before["latent"] and held["kivi_blocks"] < before["kivi_blocks"]
+    for s in seqs:
+        cm.free_seq(s.seq_id)
+    after = cm.free_slot_stats()
+    scratch = sum(t.numel() for t in cm._temp_slots_by_shape.values()) + 1          # reconstruct scratch + dummy slot
+    assert after["full"] == before["full"] and after["latent"] == before["latent"]
+    assert after["kivi_blocks"] == before["kivi_blocks"]
+    assert after["deltakv_full"] == before["deltakv_full"] - scratch
+    with pytest.raises(ValueError, match="unknown seq_id"):
+        cm.free_seq(seqs[0].seq_id)

@@ -31,6 +31,15 @@ def bf(x_bits):
     return torch.from_numpy(np.ascontiguousarray(x_bits).view(np.int16).copy()).to(dev()).view(torch.bfloat16)
 
 
+def kparam(x):
+    """per-channel key scale/min: fp32 (what the reference manager stores) or bf16 bit patterns"""
+    return t(x) if x.dtype == np.float32 else bf(x)
+
+
+def kparam_f32(x):
+    return x if x.dtype == np.float32 else bf16_bits_to_f32(x)
+
+
 def run_gpu(inp_bits, maps, *, max_len, G, block_seq, score_shape=None):
     from sparse_vllm_amd.kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1
     q = bf(inp_bits["q"])
@@ -42,7 +51,7 @@ def run_gpu(inp_bits, maps, *, max_len, G, block_seq, score_shape=None):
     full_layer_kivi_flash_decode_stage1(
         q=q, raw_k=bf(inp_bits["raw_k"]), raw_v=bf(inp_bits["raw_v"]), raw_slots_map=t(maps["raw_map"]),
         kivi_block_slots_map=t(maps["blk_map"]), kivi_block_start_pos=t(maps["blk_start"]),
-        key_packed=t(inp_bits["key_packed"]), key_scales=bf(inp_bits["key_scales"]), key_mins=bf(inp_bits["key_mins"]),
+        key_packed=t(inp_bits["key_packed"]), key_scales=kparam(inp_bits["key_scales"]), key_mins=kparam(inp_bits["key_mins"]),
         value_packed=t(inp_bits["value_packed"]), value_scales=bf(inp_bits["value_scales"]),
         value_mins=bf(inp_bits["value_mins"]), req_indices=t(maps["req"]), context_lens=t(maps["lens"]),
         max_len_in_batch=max_len, mid_out=mid, mid_out_logsumexp=lse, group_size=G, block_seq=block_seq,
@@ -57,8 +66,8 @@ def run_oracle(inp_bits, maps, *, max_len, G, block_seq, score_shape=None):
     mid, lse = ok.full_layer_kivi_flash_decode_stage1(
         q=f(inp_bits["q"]), raw_k=f(inp_bits["raw_k"]), raw_v=f(inp_bits["raw_v"]), raw_slots_map=maps["raw_map"],
         kivi_block_slots_map=maps["blk_map"], kivi_block_start_pos=maps["blk_start"], key_packed=inp_bits["key_packed"],
-        key_scales=f(inp_bits["key_scales"]), key_mins=f(inp_bits["key_mins"]), value_packed=inp_bits["value_packed"],
-        value_scales=f(inp_bits["value_scales"]), value_mins=f(inp_bits["value_mins"]), req_indices=maps["req"],
+        key_scales=kparam_f32(inp_bits["key_scales"]), key_mins=kparam_f32(inp_bits["key_mins"]),
+        value_packed=inp_bits["value_packed"], value_scales=f(inp_bits["value_scales"]), value_mins=f(inp_bits["value_mins"]), req_indices=maps["req"],
         context_lens=maps["lens"], max_len_in_batch=max_len, group_size=G, block_seq=block_seq, attn_score=score)
     return mid, lse, score
 
@@ -91,7 +100,7 @@ def test_kivi_stage1_golden(golden):
             g["lens"], block_seq)
 
 
-def make_case(rng, *, B, Hq, Hkv, D, G, lens, rows, raw_tail, sink):
+def make_case(rng, *, B, Hq, Hkv, D, G, lens, rows, raw_tail, sink, key_f32=False):
     """Rows = [sink raw tokens | KIVI blocks of G tokens | raw tail]; block slots and raw slots scattered."""
     f2b = f32_to_bf16_bits
     max_len = int(max(lens))
@@ -125,24 +134,26 @@ def make_case(rng, *, B, Hq, Hkv, D, G, lens, rows, raw_tail, sink):
         raw_k=f2b(rng.standard_normal((n_raw, Hkv, D)).astype(np.float32)),
         raw_v=f2b(rng.standard_normal((n_raw, Hkv, D)).astype(np.float32)),
         key_packed=kc.reshape(n_blocks, Hkv, D, G // 8).astype(np.int32),
-        key_scales=f2b(ks.reshape(n_blocks, Hkv, D)), key_mins=f2b(km.reshape(n_blocks, Hkv, D)),
+        key_scales=ks.reshape(n_blocks, Hkv, D).astype(np.float32) if key_f32 else f2b(ks.reshape(n_blocks, Hkv, D)),
+        key_mins=km.reshape(n_blocks, Hkv, D).astype(np.float32) if key_f32 else f2b(km.reshape(n_blocks, Hkv, D)),
         value_packed=vc.reshape(n_blocks, Hkv, G, D // 8).astype(np.int32),
         value_scales=f2b(vs.reshape(n_blocks, Hkv, G, D // G)), value_mins=f2b(vm.reshape(n_blocks, Hkv, G, D // G)))
     maps = dict(raw_map=raw_map, blk_map=blk_map, blk_start=blk_start, req=req, lens=np.asarray(lens, np.int32))
     return bits, maps, max_len
 
 
-@pytest.mark.parametrize("Hq,Hkv,D,G,block_seq,with_score", [
-    (28, 4, 128, 32, 128, True),       # Qwen2.5-7B heads (paper config), observation layer
-    (28, 4, 128, 32, 64, False),
-    (32, 8, 128, 32, 96, True),        # Llama-3.1-8B heads
-    (16, 2, 64, 32, 48, True),
-    (8, 8, 64, 64, 32, False),         # MHA, one group per head
+@pytest.mark.parametrize("Hq,Hkv,D,G,block_seq,with_score,key_f32", [
+    (28, 4, 128, 32, 128, True, True),       # Qwen2.5-7B heads (paper config), observation layer, fp32 key params
+    (28, 4, 128, 32, 64, False, False),
+    (32, 8, 128, 32, 96, True, True),        # Llama-3.1-8B heads
+    (16, 2, 64, 32, 48, True, False),
+    (8, 8, 64, 64, 32, False, True),         # MHA, one group per head
 ])
-def test_kivi_stage1_random(Hq, Hkv, D, G, block_seq, with_score):
+def test_kivi_stage1_random(Hq, Hkv, D, G, block_seq, with_score, key_f32):
     rng = np.random.default_rng(Hq * 131 + block_seq)
     lens = [517, 64, 9, 300]
-    bits, maps, max_len = make_case(rng, B=4, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=lens, rows=6, raw_tail=40, sink=8)
+    bits, maps, max_len = make_case(rng, B=4, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=lens, rows=6, raw_tail=40, sink=8,
+                                     key_f32=key_f32)
     shape = (4, Hq, max_len) if with_score else None
     got = run_gpu(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
     ref = run_oracle(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
