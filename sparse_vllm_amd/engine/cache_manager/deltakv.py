@@ -187,7 +187,8 @@ class DeltaKVCacheManager(CacheManager):
         G = self._full_layer_kivi_group_size() if kivi else 0
         n_sparse = int(cfg.num_kvcache_slots or 0)
         if n_sparse <= 0:
-            centers = int(np.ceil(L * float(cfg.cluster_ratio))) + 1
+            step = max(1, int(1.0 / max(1e-6, float(cfg.cluster_ratio))))
+            centers = -(-L // max(1, recent)) * -(-max(1, recent) // step)      # range(start, end, step) per evicted block
             n_sparse = rows * (sink + 2 * recent + 1 + centers + keep) + 64
         n_latent = int(cfg.deltakv_num_latent_slots or 0) or rows * L
         n_full = int(cfg.deltakv_num_full_layer_slots or 0)

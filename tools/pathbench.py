@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Decode-path timings of the non-headline configurations (development / profiling tool, GPU only).
+
+    python tools/pathbench.py [--configs streamingllm,quest,deltakv,deltakv_raw,vanilla] [--steps 32] [--graph]
+
+BASELINE.json "other configs" (SURVEY section 8(d)), Qwen2.5-7B shapes, synthetic resident state:
+  streamingllm  32k prompt reduced to sink 64 + recent 512, rows 576..1151, B=64
+  quest         128k context, page 16, token budget 4672 (skip_layers 2 -> dense), B=4
+  deltakv       256k context, sink 8 / recent 128 / keep 2048, K=4, latent 256 int4, 6 KIVI-int4 full layers, B=1
+  deltakv_raw   same with raw bf16 full layers at 64k context
+  vanilla       8k context dense decode, B=16
+One JSON line per configuration: ms per decode step of the sparse path (all layers, no dense model).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from sparse_vllm_amd.config import Config
+from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+
+QWEN = dict(num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4, head_dim=128)
+
+
+def build(name: str):
+    if name == "streamingllm":
+        cfg = Config.from_kwargs(sparse_method="streamingllm", sink_keep_tokens=64, recent_keep_tokens=512,
+                                 max_model_len=2048, max_num_seqs_in_gpu=64, num_kvcache_slots=64 * 1160 + 64, **QWEN)
+        drv = SparseDecodeDriver(cfg)
+        drv.cache_manager.permute_free_slots(1)
+        drv.admit_resident_rows(64, 576, logical_len=32768, seed=0, device_rng=True)
+        return drv, dict(batch=64, context=32768, resident=576)
+    if name == "quest":
+        B, ctx = 4, 131072
+        cfg = Config.from_kwargs(sparse_method="quest", sink_keep_tokens=64, decode_keep_tokens=4096, recent_keep_tokens=512,
+                                 max_model_len=ctx + 256, max_num_seqs_in_gpu=B, num_kvcache_slots=B * (ctx + 256), **QWEN)
+        drv = SparseDecodeDriver(cfg)
+        drv.cache_manager.permute_free_pages(1)
+        drv.admit_resident_rows(B, ctx, seed=0, device_rng=True)
+        return drv, dict(batch=B, context=ctx, token_budget=cfg.quest_token_budget)
+    if name in ("deltakv", "deltakv_raw"):
+        kivi = name == "deltakv"
+        B, ctx = 1, 8 + 128 * (2048 if kivi else 512)     # tail == recent: room for `recent` decode steps
+        cfg = Config.from_kwargs(sparse_method="deltakv", full_attention_layers="0,1,2,8,18,27" if kivi else "0,1,2,8,18",
+                                 sink_keep_tokens=8, recent_keep_tokens=128, decode_keep_tokens=2048, deltakv_neighbor_count=4,
+                                 deltakv_latent_dim=256, deltakv_latent_quant_bits=4, deltakv_latent_quant_group_size=32,
+                                 deltakv_center_ratio=0.03, allow_missing_deltakv_path=True, compressor_intermediate_size=2048,
+                                 full_layer_kv_quant_bits=4 if kivi else 0, max_model_len=ctx + 512, max_num_seqs_in_gpu=B,
+                                 **QWEN)
+        drv = SparseDecodeDriver(cfg)
+        drv.cache_manager.permute_free_slots(1)
+        drv.admit_compressed_rows(B, ctx, seed=0)
+        return drv, dict(batch=B, context=ctx, full_layers=len(drv.cache_manager.full_layer_ids), kivi=kivi)
+    if name == "vanilla":
+        B, ctx = 16, 8192
+        cfg = Config.from_kwargs(sparse_method="", max_model_len=ctx + 256, max_num_seqs_in_gpu=B,
+                                 num_kvcache_slots=B * (ctx + 256), **QWEN)
+        drv = SparseDecodeDriver(cfg)
+        drv.cache_manager.permute_free_slots(1)
+        drv.admit_resident_rows(B, ctx, seed=0, device_rng=True)
+        return drv, dict(batch=B, context=ctx)
+    raise SystemExit(f"unknown config {name}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="streamingllm,quest,deltakv_raw,deltakv,vanilla")
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--graph", action="store_true")
+    args = ap.parse_args()
+    for name in args.configs.split(","):
+        t0 = time.perf_counter()
+        drv, info = build(name)
+        q, k, v = drv.random_step_inputs(seed=1)
+        if args.graph:
+            drv.enable_decode_graph()
+        torch.cuda.synchronize()
+        setup = time.perf_counter() - t0
+        for _ in range(args.warmup):
+            drv.step(q, k, v)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            drv.step(q, k, v)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) * 1e3 / args.steps
+        print(json.dumps(dict(config=name, ms_per_step=round(ms, 4), tokens_per_s=round(info["batch"] / ms * 1e3, 1),
+                              graph=bool(args.graph), steps=args.steps, setup_s=round(setup, 1), **info)), flush=True)
+        del drv, q, k, v
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
