@@ -537,13 +537,15 @@ typedef struct SvkDeltakvTokenScoresArgs {
   const float* raw_scores;        /* [B, H, L] f32 (3-D output of stage 1)        */
   const int32_t* candidate_lens;  /* [B]                                          */
   float* token_scores;            /* [B, L] f32 out                               */
-  float* workspace;               /* [B, H, 2] f32 (per-head max / sum)           */
+  float* workspace;               /* [B, H, svk_deltakv_token_scores_chunks(L), 2] f32 partial max / sum */
   int64_t raw_stride_b, raw_stride_h, out_stride;
   float scale, fill_value;
   int32_t batch, num_heads, length, candidate_start;
   int32_t round_dtype;            /* SVK_DTYPE_*: F32 = no rounding               */
 } SvkDeltakvTokenScoresArgs;
 int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_stream_t stream);
+/* number of statistics chunks the workspace must hold for score rows of `length` elements */
+int svk_deltakv_token_scores_chunks(int32_t length);
 
 /* idx[r, :k] = indices of the k largest of scores[r, :n] ordered by (score desc, index asc) -
  * `topk(k, sorted=True)` with a deterministic tie rule (the reference adds a position key to get one,

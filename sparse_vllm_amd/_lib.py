@@ -222,6 +222,7 @@ ENTRY_POINTS = {
     "svk_deltakv_reconstruct_writeback": ([C.POINTER(SvkDeltakvReconstructArgs), _p], C.c_int),
     "svk_dequantize_grouped": ([C.POINTER(SvkDequantGroupedArgs), _p], C.c_int),
     "svk_deltakv_token_scores": ([C.POINTER(SvkDeltakvTokenScoresArgs), _p], C.c_int),
+    "svk_deltakv_token_scores_chunks": ([_i32], C.c_int),
     "svk_topk_sorted_desc": ([C.POINTER(SvkTopkSortedArgs), _p], C.c_int),
     "svk_deltakv_materialize_sparse_view": ([C.POINTER(SvkDeltakvMaterializeArgs), _p], C.c_int),
     "svk_kivi_decode_stage1": ([C.POINTER(SvkKiviDecodeStage1Args), _p], C.c_int),

@@ -661,29 +661,55 @@ decode_stage1_kernel_v2(const SvkFlashDecodeStage1Args a) {
 }
 
 template <int D>
-__global__ void __launch_bounds__(D / 2)
+__global__ void __launch_bounds__(256)
 decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
-  // one (batch lane, q head) per workgroup; each thread owns 2 output dims
+  // one (batch lane, q head) per workgroup.  D/4 lanes cover one partial row with 16-byte loads; the 256/(D/4)
+  // lane groups walk the split-KV partials interleaved (long contexts have ~1000 of them), each with its own
+  // running (max, sum, acc); the groups are merged through LDS at the end.
+  constexpr int LPR = D / 4, GROUPS = 256 / LPR;
+  __shared__ float s_m[GROUPS], s_l[GROUPS];
+  __shared__ __attribute__((aligned(16))) float s_acc[GROUPS][D];
   const int b = blockIdx.x, h = blockIdx.y;
-  const int d = threadIdx.x * 2;
+  const int g = threadIdx.x / LPR, d = (threadIdx.x % LPR) * 4;
   const int len = a.b_seqlen[b];
   const int nblk = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq;
   const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h + d;
   const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
-  float sum = 0.f, mx = -INFINITY, a0 = 0.f, a1 = 0.f;
-  for (int i = 0; i < nblk; ++i) {
-    const float2 tv = *reinterpret_cast<const float2*>(mo + (int64_t)i * a.mid_o_stride_s);
+  float sum = 0.f, mx = -INFINITY;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = g; i < nblk; i += GROUPS) {
+    const float4 tv = *reinterpret_cast<const float4*>(mo + (int64_t)i * a.mid_o_stride_s);
     const float tl = ml[i];
     const float nm = fmaxf(tl, mx);
     const float os = __expf(mx - nm);
     const float e = __expf(tl - nm);
-    a0 = a0 * os + e * tv.x;
-    a1 = a1 * os + e * tv.y;
+    acc.x = acc.x * os + e * tv.x; acc.y = acc.y * os + e * tv.y;
+    acc.z = acc.z * os + e * tv.z; acc.w = acc.w * os + e * tv.w;
     sum = sum * os + e;
     mx = nm;
   }
-  const uint32_t lo = f32_to_bf16_bits(a0 / sum), hi = f32_to_bf16_bits(a1 / sum);
-  *reinterpret_cast<uint32_t*>(a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d) = lo | (hi << 16);
+  if (nblk > 1) {
+    if (d == 0) { s_m[g] = mx; s_l[g] = sum; }
+    *reinterpret_cast<float4*>(&s_acc[g][d]) = acc;
+    __syncthreads();
+    if (g != 0) return;
+    const int used = min(nblk, GROUPS);
+    for (int j = 1; j < used; ++j) {
+      const float tm = s_m[j];
+      const float nm = fmaxf(tm, mx);
+      const float os = __expf(mx - nm), e = __expf(tm - nm);
+      const float4 tv = *reinterpret_cast<const float4*>(&s_acc[j][d]);
+      acc.x = acc.x * os + e * tv.x; acc.y = acc.y * os + e * tv.y;
+      acc.z = acc.z * os + e * tv.z; acc.w = acc.w * os + e * tv.w;
+      sum = sum * os + e * s_l[j];
+      mx = nm;
+    }
+  } else if (g != 0) {
+    return;
+  }
+  const uint32_t w0 = f32_to_bf16_bits(acc.x / sum) | (f32_to_bf16_bits(acc.y / sum) << 16);
+  const uint32_t w1 = f32_to_bf16_bits(acc.z / sum) | (f32_to_bf16_bits(acc.w / sum) << 16);
+  *reinterpret_cast<uint2*>(a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d) = make_uint2(w0, w1);
 }
 
 template <int D, int G>
@@ -768,13 +794,13 @@ extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_st
   SVK_REQUIRE(a->head_dim == 64 || a->head_dim == 128, SVK_ERR_LAYOUT,
               "svk_flash_decode_stage2: head_dim %d unsupported (64, 128)", a->head_dim);
   SVK_REQUIRE(a->block_seq > 0, SVK_ERR_VALUE, "svk_flash_decode_stage2: block_seq must be positive");
-  SVK_REQUIRE((a->mid_o_stride_h % 2) == 0 && (a->mid_o_stride_s % 2) == 0 && (a->mid_o_stride_b % 2) == 0 &&
-                  (a->o_stride_b % 2) == 0 && (a->o_stride_h % 2) == 0,
-              SVK_ERR_LAYOUT, "svk_flash_decode_stage2: strides must be even");
+  SVK_REQUIRE((a->mid_o_stride_h % 4) == 0 && (a->mid_o_stride_s % 4) == 0 && (a->mid_o_stride_b % 4) == 0 &&
+                  (a->o_stride_b % 4) == 0 && (a->o_stride_h % 4) == 0,
+              SVK_ERR_LAYOUT, "svk_flash_decode_stage2: strides must be multiples of 4 elements (16-byte partial rows)");
   if (a->batch <= 0) return SVK_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(a->batch, a->num_q_heads);
-  if (a->head_dim == 128) hipLaunchKernelGGL((decode_stage2_kernel<128>), grid, dim3(64), 0, s, *a);
-  else hipLaunchKernelGGL((decode_stage2_kernel<64>), grid, dim3(32), 0, s, *a);
+  if (a->head_dim == 128) hipLaunchKernelGGL((decode_stage2_kernel<128>), grid, dim3(256), 0, s, *a);
+  else hipLaunchKernelGGL((decode_stage2_kernel<64>), grid, dim3(256), 0, s, *a);
   return check_launch("svk_flash_decode_stage2");
 }

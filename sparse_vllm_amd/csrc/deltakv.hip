@@ -187,28 +187,50 @@ __global__ void __launch_bounds__(256) deltakv_reconstruct_kernel(const SvkDelta
 // observation-layer token scores
 // ------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) token_score_stats_kernel(const SvkDeltakvTokenScoresArgs a) {
+constexpr int kTokenScoreChunk = 4096;       // score elements per statistics workgroup
+
+// partial (max, sum exp(x - max)) of one chunk of one head's candidate range -> workspace[b][h][chunk][2]
+__global__ void __launch_bounds__(256) token_score_stats_kernel(const SvkDeltakvTokenScoresArgs a, int nchunk) {
   __shared__ float red[16];
-  const int b = blockIdx.x, h = blockIdx.y;
+  const int b = blockIdx.x, h = blockIdx.y, c = blockIdx.z;
   const int len = min(max(a.candidate_lens[b], 0), a.length - a.candidate_start);
+  const int t0 = c * kTokenScoreChunk, t1 = min(len, t0 + kTokenScoreChunk);
   const float* x = a.raw_scores + (int64_t)b * a.raw_stride_b + (int64_t)h * a.raw_stride_h + a.candidate_start;
+  float v[kTokenScoreChunk / 256];
   float mx = -INFINITY;
-  for (int t = threadIdx.x; t < len; t += blockDim.x) mx = fmaxf(mx, mul_rn(x[t], a.scale));
+#pragma unroll
+  for (int j = 0; j < kTokenScoreChunk / 256; ++j) {
+    const int t = t0 + j * 256 + threadIdx.x;
+    v[j] = t < t1 ? mul_rn(x[t], a.scale) : -INFINITY;
+    mx = fmaxf(mx, v[j]);
+  }
   mx = block_allmax(mx, red);
   float sum = 0.f;
-  for (int t = threadIdx.x; t < len; t += blockDim.x) sum += expf(mul_rn(x[t], a.scale) - mx);
+  if (mx > -INFINITY) {
+#pragma unroll
+    for (int j = 0; j < kTokenScoreChunk / 256; ++j) sum += expf(v[j] - mx);     // exp(-inf) == 0 for the padding
+  }
   sum = block_allsum(sum, red);
   if (threadIdx.x == 0) {
-    float* ws = a.workspace + ((int64_t)b * a.num_heads + h) * 2;
+    float* ws = a.workspace + (((int64_t)b * a.num_heads + h) * nchunk + c) * 2;
     ws[0] = mx;
     ws[1] = sum;
   }
 }
 
-__global__ void __launch_bounds__(256) token_score_final_kernel(const SvkDeltakvTokenScoresArgs a) {
-  extern __shared__ float stats[];      // [H][2]
+__global__ void __launch_bounds__(256) token_score_final_kernel(const SvkDeltakvTokenScoresArgs a, int nchunk) {
+  extern __shared__ float stats[];      // [H][2]: global max / sum per head
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < a.num_heads * 2; i += blockDim.x) stats[i] = a.workspace[(int64_t)b * a.num_heads * 2 + i];
+  for (int h = threadIdx.x; h < a.num_heads; h += blockDim.x) {
+    const float* ws = a.workspace + ((int64_t)b * a.num_heads + h) * nchunk * 2;
+    float mx = -INFINITY;
+    for (int c = 0; c < nchunk; ++c) mx = fmaxf(mx, ws[2 * c]);
+    float sum = 0.f;
+    for (int c = 0; c < nchunk; ++c)
+      if (ws[2 * c] > -INFINITY) sum += ws[2 * c + 1] * expf(ws[2 * c] - mx);
+    stats[2 * h] = mx;
+    stats[2 * h + 1] = sum;
+  }
   __syncthreads();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.length) return;
@@ -241,65 +263,9 @@ __global__ void __launch_bounds__(1024) topk_sorted_kernel(const SvkTopkSortedAr
   auto score_at = [&](int i) { return i < vlen ? sc[i] : masked; };
   for (int i = tid; i < kpad; i += nt) keys[i] = ~0ull;
   __syncthreads();
-  // selection on the (masked) scores: block_select works on a pointer, so mask through a functor copy
-  {
-    // radix select over score_at(i)
-    uint32_t prefix = 0;
-    int kk = a.k;
-    for (int pass = 0; pass < 4; ++pass) {
-      const int shift = 24 - 8 * pass;
-      const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-      for (int i = tid; i < 256; i += nt) scratch.hist[i] = 0;
-      __syncthreads();
-      for (int i = tid; i < a.n; i += nt) {
-        const uint32_t key = desc_key(score_at(i));
-        if ((key & himask) == prefix) atomicAdd(&scratch.hist[(key >> shift) & 255u], 1);
-      }
-      __syncthreads();
-      if (tid < 64) {
-        int c[4], local = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { c[j] = scratch.hist[tid * 4 + j]; local += c[j]; }
-        int incl = local;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int v = __shfl_up(incl, o, 64);
-          if (tid >= o) incl += v;
-        }
-        const int excl = incl - local;
-        if (kk > excl && kk <= incl) {
-          int run = excl;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (kk > run && kk <= run + c[j]) { scratch.prefix = prefix | ((uint32_t)(tid * 4 + j) << shift); scratch.k = kk - run; }
-            run += c[j];
-          }
-        }
-      }
-      __syncthreads();
-      prefix = scratch.prefix;
-      kk = scratch.k;
-      __syncthreads();
-    }
-    const uint32_t T = prefix;
-    const int take_eq = kk;
-    int out_base = 0, eq_base = 0;
-    for (int c0 = 0; c0 < a.n; c0 += nt) {
-      const int i = c0 + tid;
-      uint32_t key = 0xffffffffu;
-      const bool in = i < a.n;
-      if (in) key = desc_key(score_at(i));
-      const bool is_eq = in && key == T;
-      int eq_total;
-      const int eq_rank = eq_base + block_excl_count(is_eq, scratch.wsum, eq_total);
-      const bool sel = in && (key < T || (is_eq && eq_rank < take_eq));
-      int sel_total;
-      const int pos = out_base + block_excl_count(sel, scratch.wsum, sel_total);
-      if (sel) keys[pos] = ((unsigned long long)key << 32) | (unsigned)i;
-      out_base += sel_total;
-      eq_base += eq_total;
-    }
-  }
+  block_select_topk_ordered_fn(score_at, a.n, a.k, scratch, [&](int pos, int i) {
+    keys[pos] = ((unsigned long long)desc_key(score_at(i)) << 32) | (unsigned)i;
+  });
   __syncthreads();
   // bitonic sort ascending on (desc_key, index) == (score desc, index asc)
   for (int size = 2; size <= kpad; size <<= 1)
@@ -368,6 +334,10 @@ extern "C" int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs
   return check_launch("svk_deltakv_reconstruct_writeback");
 }
 
+extern "C" int svk_deltakv_token_scores_chunks(int32_t length) {
+  return length <= 0 ? 1 : (length + svk::kTokenScoreChunk - 1) / svk::kTokenScoreChunk;
+}
+
 extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_stream_t stream) {
   using namespace svk;
   SVK_REQUIRE(a != nullptr && a->workspace != nullptr, SVK_ERR_VALUE, "svk_deltakv_token_scores: null args/workspace");
@@ -375,9 +345,10 @@ extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_
               "candidate_start must be within score length; got %d for L=%d.", a->candidate_start, a->length);
   if (a->batch <= 0 || a->length <= 0) return SVK_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(token_score_stats_kernel, dim3(a->batch, a->num_heads), dim3(256), 0, s, *a);
+  const int nchunk = svk_deltakv_token_scores_chunks(a->length);
+  hipLaunchKernelGGL(token_score_stats_kernel, dim3(a->batch, a->num_heads, nchunk), dim3(256), 0, s, *a, nchunk);
   hipLaunchKernelGGL(token_score_final_kernel, dim3((a->length + 255) / 256, a->batch), dim3(256),
-                     sizeof(float) * 2 * a->num_heads, s, *a);
+                     sizeof(float) * 2 * a->num_heads, s, *a, nchunk);
   return check_launch("svk_deltakv_token_scores");
 }
 
@@ -389,7 +360,7 @@ extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, svk_stream_t str
   if (a->rows <= 0 || a->k == 0) return SVK_OK;
   int kpad = 2;
   while (kpad < a->k) kpad <<= 1;
-  hipLaunchKernelGGL(topk_sorted_kernel, dim3(a->rows), dim3(kpad >= 2048 ? 1024 : 256), sizeof(unsigned long long) * kpad,
+  hipLaunchKernelGGL(topk_sorted_kernel, dim3(a->rows), dim3((kpad >= 2048 || a->n > 8192) ? 1024 : 256), sizeof(unsigned long long) * kpad,
                      static_cast<hipStream_t>(stream), *a, kpad);
   return check_launch("svk_topk_sorted_desc");
 }

@@ -73,8 +73,29 @@ struct SelectScratch {
 // pos = rank of idx among the selected indices in ASCENDING index order.
 // Method: 4-pass MSB radix select (8 bits per pass) of the k-th smallest desc_key gives the
 // threshold key T and how many elements equal to T are taken; one ordered pass then emits.
-template <typename Emit>
-__device__ __forceinline__ void block_select_topk_ordered(const float* sc, int n, int k, SelectScratch& S, Emit emit) {
+// histogram add with wave-level aggregation: scores that cluster into a few radix bins (probabilities, bf16-valued
+// scores whose low key bytes are all equal) would otherwise serialise ~n LDS atomics on one address.  Two leader
+// rounds fold the dominant bins into one atomic per wave each; the remaining lanes add individually.
+__device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, bool active) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(active);
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if (todo == 0ull) break;
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t lb = (uint32_t)__shfl((int)bin, leader, 64);
+    const unsigned long long same = __ballot(active && bin == lb) & todo;
+    if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+    todo &= ~same;
+  }
+  if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1);
+}
+
+// `score_at(i)` form (callers that mask or remap scores on the fly).  Each thread works on strips of kStrip
+// consecutive elements so the ordered emit needs one block scan per kStrip * blockDim elements.
+template <typename ScoreAt, typename Emit>
+__device__ __forceinline__ void block_select_topk_ordered_fn(ScoreAt score_at, int n, int k, SelectScratch& S, Emit emit) {
+  constexpr int kStrip = 4;
   const int tid = threadIdx.x, nt = blockDim.x;
   uint32_t prefix = 0;
   int kk = k;
@@ -83,9 +104,15 @@ __device__ __forceinline__ void block_select_topk_ordered(const float* sc, int n
     const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
     for (int i = tid; i < 256; i += nt) S.hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += nt) {
-      const uint32_t key = desc_key(sc[i]);
-      if ((key & himask) == prefix) atomicAdd(&S.hist[(key >> shift) & 255u], 1);
+    for (int c0 = 0; c0 < n; c0 += nt * kStrip) {
+#pragma unroll
+      for (int e = 0; e < kStrip; ++e) {
+        const int i = c0 + tid * kStrip + e;
+        uint32_t key = 0u;
+        const bool in = i < n;
+        if (in) key = desc_key(score_at(i));
+        hist_add_aggregated(S.hist, (key >> shift) & 255u, in && (key & himask) == prefix);
+      }
     }
     __syncthreads();
     if (tid < 64) {
@@ -120,21 +147,58 @@ __device__ __forceinline__ void block_select_topk_ordered(const float* sc, int n
   const uint32_t T = prefix;   // threshold key
   const int take_eq = kk;      // elements equal to T that are taken, lowest index first
   int out_base = 0, eq_base = 0;
-  for (int c0 = 0; c0 < n; c0 += nt) {
-    const int i = c0 + tid;
-    uint32_t key = 0xffffffffu;
-    const bool in = i < n;
-    if (in) key = desc_key(sc[i]);
-    const bool is_eq = in && key == T;
-    int eq_total;
-    const int eq_rank = eq_base + block_excl_count(is_eq, S.wsum, eq_total);
-    const bool sel = in && (key < T || (is_eq && eq_rank < take_eq));
-    int sel_total;
-    const int pos = out_base + block_excl_count(sel, S.wsum, sel_total);
-    if (sel) emit(pos, i);
-    out_base += sel_total;
-    eq_base += eq_total;
+  const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
+  for (int c0 = 0; c0 < n; c0 += nt * kStrip) {
+    uint32_t key[kStrip];
+    int n_lt = 0, n_eq = 0;
+#pragma unroll
+    for (int e = 0; e < kStrip; ++e) {
+      const int i = c0 + tid * kStrip + e;
+      key[e] = 0xffffffffu;
+      if (i < n) {
+        key[e] = desc_key(score_at(i));
+        n_lt += key[e] < T;
+        n_eq += key[e] == T;
+      }
+    }
+    // block-wide exclusive prefix of (n_lt, n_eq) packed in one int (each < 2^15 per block of <= 4096 elements)
+    const int packed = (n_lt << 16) | n_eq;
+    int incl = packed;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    __syncthreads();
+    if (lane == 63) S.wsum[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int j = 0; j < nw; ++j) {
+      const int c = S.wsum[j];
+      if (j < w) base += c;
+      tot += c;
+    }
+    const int excl = base + incl - packed;
+    int lt_before = excl >> 16, eq_before = eq_base + (excl & 0xffff);
+    // selected-before = (all < T before) + (equal-to-T before that are taken)
+#pragma unroll
+    for (int e = 0; e < kStrip; ++e) {
+      const int i = c0 + tid * kStrip + e;
+      if (i < n) {
+        const bool lt = key[e] < T, eq = key[e] == T;
+        if (lt || (eq && eq_before < take_eq)) emit(out_base + lt_before + min(eq_before, take_eq) - min(eq_base, take_eq), i);
+        lt_before += lt;
+        eq_before += eq;
+      }
+    }
+    out_base += (tot >> 16) + (min(eq_base + (tot & 0xffff), take_eq) - min(eq_base, take_eq));
+    eq_base += tot & 0xffff;
   }
+}
+
+template <typename Emit>
+__device__ __forceinline__ void block_select_topk_ordered(const float* sc, int n, int k, SelectScratch& S, Emit emit) {
+  block_select_topk_ordered_fn([sc](int i) { return sc[i]; }, n, k, S, emit);
 }
 
 }  // namespace svk

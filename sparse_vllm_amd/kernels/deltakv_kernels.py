@@ -196,8 +196,8 @@ def decode_softmax_token_scores(scores, *, candidate_start: int, candidate_lens,
     if fill_value is None:
         fill_value = torch.finfo(rd).min
     out = torch.empty((B, L), dtype=torch.float32, device=scores.device)
-    ws = torch.empty((B, H, 2), dtype=torch.float32, device=scores.device)
     lib = _lib.load()
+    ws = torch.empty((B, H, int(lib.svk_deltakv_token_scores_chunks(L)), 2), dtype=torch.float32, device=scores.device)
     a = _lib.SvkDeltakvTokenScoresArgs(
         raw_scores=_lib.ptr(scores), candidate_lens=_lib.ptr(candidate_lens.to(torch.int32)), token_scores=_lib.ptr(out),
         workspace=_lib.ptr(ws), raw_stride_b=scores.stride(0), raw_stride_h=scores.stride(1), out_stride=out.stride(0),
