@@ -458,6 +458,12 @@ typedef struct SvkDeltakvReconstructArgs {
   int32_t delta_dtype, scale_dtype, cos_dtype;   /* SVK_DTYPE_*                                                  */
   int32_t raw_k_cache;             /* fathers hold un-rotated K                                                  */
   int32_t store_raw_k;             /* write un-rotated K                                                         */
+  /* fused father lookup (static decode): when father_table != NULL, father_slots is ignored and the fathers of
+   * entry n are max(father_table[max(father_index[n], 0), :], 0) - the reference's
+   * `deltakv_latent_to_full_slots[l, recon_latent.clamp_min(0)].clamp_min(0)` (deltakv_less_memory.py:4054-4058). */
+  const int32_t* father_table;     /* NULL or [latents, K]                                                       */
+  const int32_t* father_index;     /* [N] latent slot per entry (may be -1)                                      */
+  int64_t father_table_stride;
 } SvkDeltakvReconstructArgs;
 int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs* a, svk_stream_t stream);
 
@@ -472,6 +478,8 @@ typedef struct SvkDequantGroupedArgs {
   int64_t packed_stride, scale_stride, out_stride;
   int32_t rows, features, bits, group_size;
   int32_t scale_dtype, out_dtype;
+  const int32_t* row_index; /* NULL or [rows]: output row r reads source row max(row_index[r], 0) - the fused
+                               `cache[l, recon_latent.clamp_min(0)]` gather of _load_residual */
 } SvkDequantGroupedArgs;
 int svk_dequantize_grouped(const SvkDequantGroupedArgs* a, svk_stream_t stream);
 
@@ -493,6 +501,11 @@ typedef struct SvkDeltakvMaterializeArgs {
   int64_t active_stride, kv_slot_stride, kv_head_stride, out_slot_stride, out_head_stride, cos_stride;
   float k_norm_eps;
   int32_t batch, width, num_slots, num_kv_heads, head_dim, cos_dtype;
+  /* static-decode alternative to postrope_mask: entry (b, w) with temp_offset <= w < temp_offset + temp_count is
+   * post-RoPE iff its slot equals temp_slots[b, w - temp_offset] (the reconstruct scratch of this step) */
+  const int32_t* temp_slots;       /* NULL or [batch, temp_count] (temp_stride)               */
+  int64_t temp_stride;
+  int32_t temp_offset, temp_count;
 } SvkDeltakvMaterializeArgs;
 int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeArgs* a, svk_stream_t stream);
 
@@ -550,7 +563,9 @@ int svk_deltakv_token_scores_chunks(int32_t length);
 /* idx[r, :k] = indices of the k largest of scores[r, :n] ordered by (score desc, index asc) -
  * `topk(k, sorted=True)` with a deterministic tie rule (the reference adds a position key to get one,
  * sparse_controller.py:1797-1811).  Entries at index >= valid_len[r] compare as `masked_value`.
- * Replaces the DeltaKV branch of _update_dynamic_omnikv_indices, sparse_controller.py:1790-1822. k <= 4096. */
+ * Replaces the DeltaKV branch of _update_dynamic_omnikv_indices, sparse_controller.py:1790-1822. k <= 4096.
+ * Long rows are split over several workgroups through `workspace` (svk_topk_sorted_workspace_bytes(); may be NULL
+ * when that returns 0, and a NULL workspace always selects the single-workgroup path). */
 typedef struct SvkTopkSortedArgs {
   const float* scores;        /* [rows, score_stride]            */
   const int32_t* valid_len;   /* NULL or [rows]                  */
@@ -559,7 +574,8 @@ typedef struct SvkTopkSortedArgs {
   float masked_value;
   int32_t rows, n, k;
 } SvkTopkSortedArgs;
-int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, svk_stream_t stream);
+int64_t svk_topk_sorted_workspace_bytes(int32_t rows, int32_t n, int32_t k);
+int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, void* workspace, svk_stream_t stream);
 
 #ifdef __cplusplus
 }

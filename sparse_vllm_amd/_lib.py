@@ -158,14 +158,15 @@ class SvkDeltakvReconstructArgs(C.Structure):
                 ("kv_slot_stride", _i64), ("kv_head_stride", _i64),
                 ("k_norm_eps", _f32), ("n", _i32), ("k_fathers", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
                 ("delta_bits", _i32), ("group_size", _i32), ("delta_dtype", _i32), ("scale_dtype", _i32),
-                ("cos_dtype", _i32), ("raw_k_cache", _i32), ("store_raw_k", _i32)]
+                ("cos_dtype", _i32), ("raw_k_cache", _i32), ("store_raw_k", _i32),
+                ("father_table", _p), ("father_index", _p), ("father_table_stride", _i64)]
 
 
 class SvkDequantGroupedArgs(C.Structure):
     _fields_ = [("packed", _p), ("scale", _p), ("mn", _p), ("out", _p),
                 ("packed_stride", _i64), ("scale_stride", _i64), ("out_stride", _i64),
                 ("rows", _i32), ("features", _i32), ("bits", _i32), ("group_size", _i32),
-                ("scale_dtype", _i32), ("out_dtype", _i32)]
+                ("scale_dtype", _i32), ("out_dtype", _i32), ("row_index", _p)]
 
 
 class SvkDeltakvTokenScoresArgs(C.Structure):
@@ -187,7 +188,8 @@ class SvkDeltakvMaterializeArgs(C.Structure):
                [(n, _i64) for n in ("active_stride", "kv_slot_stride", "kv_head_stride", "out_slot_stride",
                                     "out_head_stride", "cos_stride")] + \
                [("k_norm_eps", _f32)] + \
-               [(n, _i32) for n in ("batch", "width", "num_slots", "num_kv_heads", "head_dim", "cos_dtype")]
+               [(n, _i32) for n in ("batch", "width", "num_slots", "num_kv_heads", "head_dim", "cos_dtype")] + \
+               [("temp_slots", _p), ("temp_stride", _i64), ("temp_offset", _i32), ("temp_count", _i32)]
 
 
 class SvkKiviDecodeStage1Args(C.Structure):
@@ -223,7 +225,8 @@ ENTRY_POINTS = {
     "svk_dequantize_grouped": ([C.POINTER(SvkDequantGroupedArgs), _p], C.c_int),
     "svk_deltakv_token_scores": ([C.POINTER(SvkDeltakvTokenScoresArgs), _p], C.c_int),
     "svk_deltakv_token_scores_chunks": ([_i32], C.c_int),
-    "svk_topk_sorted_desc": ([C.POINTER(SvkTopkSortedArgs), _p], C.c_int),
+    "svk_topk_sorted_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),
+    "svk_topk_sorted_desc": ([C.POINTER(SvkTopkSortedArgs), _p, _p], C.c_int),
     "svk_deltakv_materialize_sparse_view": ([C.POINTER(SvkDeltakvMaterializeArgs), _p], C.c_int),
     "svk_kivi_decode_stage1": ([C.POINTER(SvkKiviDecodeStage1Args), _p], C.c_int),
     "svk_quest_page_minmax": ([C.POINTER(SvkQuestPageMinmaxArgs), _p], C.c_int),

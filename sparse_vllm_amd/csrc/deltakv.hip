@@ -83,12 +83,13 @@ __global__ void __launch_bounds__(256) dequant_grouped_kernel(const SvkDequantGr
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= a.features) return;
   const int fpi = 32 / a.bits;
-  const uint32_t word = (uint32_t)a.packed[(int64_t)r * a.packed_stride + f / fpi];
+  const int64_t src = a.row_index ? max(a.row_index[r], 0) : r;
+  const uint32_t word = (uint32_t)a.packed[src * a.packed_stride + f / fpi];
   const float q = (float)((word >> ((f % fpi) * a.bits)) & ((1u << a.bits) - 1u));
   const int g = f / a.group_size;
   // two roundings (q*scale, then +min) like the un-fused reference arithmetic the fixtures pin
-  const float v = add_rn(mul_rn(q, load_scalar(a.scale, (int64_t)r * a.scale_stride + g, a.scale_dtype)),
-                            load_scalar(a.mn, (int64_t)r * a.scale_stride + g, a.scale_dtype));
+  const float v = add_rn(mul_rn(q, load_scalar(a.scale, src * a.scale_stride + g, a.scale_dtype)),
+                            load_scalar(a.mn, src * a.scale_stride + g, a.scale_dtype));
   if (a.out_dtype == SVK_DTYPE_F32) reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + f] = v;
   else if (a.out_dtype == SVK_DTYPE_BF16) reinterpret_cast<uint16_t*>(a.out)[(int64_t)r * a.out_stride + f] = (uint16_t)f32_to_bf16_bits(v);
   else reinterpret_cast<_Float16*>(a.out)[(int64_t)r * a.out_stride + f] = (_Float16)v;
@@ -130,8 +131,10 @@ __global__ void __launch_bounds__(256) deltakv_reconstruct_kernel(const SvkDelta
   float k1 = 0.f, k2 = 0.f, v1 = 0.f, v2 = 0.f;
   if (active) {
     float ak1 = 0.f, ak2 = 0.f, av1 = 0.f, av2 = 0.f;
+    const int32_t* fathers = a.father_table ? a.father_table + (int64_t)max(a.father_index[n], 0) * a.father_table_stride
+                                            : a.father_slots + (int64_t)n * a.father_stride;
     for (int kk = 0; kk < a.k_fathers; ++kk) {
-      const int fs = a.father_slots[(int64_t)n * a.father_stride + kk];
+      const int fs = a.father_table ? max(fathers[kk], 0) : fathers[kk];
       const int64_t base = (int64_t)fs * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
       const float y1 = __builtin_bit_cast(float, (uint32_t)a.k_cache[base] << 16);
       const float y2 = __builtin_bit_cast(float, (uint32_t)a.k_cache[base + HD2] << 16);
@@ -250,9 +253,88 @@ __global__ void __launch_bounds__(256) token_score_final_kernel(const SvkDeltakv
 }
 
 // ------------------------------------------------------------------------------------
-// sorted top-k: radix select, then a bitonic sort of the k winners in LDS
+// sorted top-k: radix select on LDS-staged keys, then a bitonic sort of the k winners in LDS.
+// Rows longer than one LDS stage are split over several workgroups: every chunk emits its own top-k
+// candidates (ascending index), one workgroup per row then selects among the chunks' candidates - the
+// global top-k under (score desc, index asc) is a subset of the union of the chunk top-k's.
 // ------------------------------------------------------------------------------------
 
+constexpr int kTopkStage = 24576;     // keys staged in LDS by one workgroup (96 KiB) next to a <= 32 KiB sort buffer
+
+__device__ __forceinline__ void bitonic_sort_keys(unsigned long long* keys, int kpad) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int size = 2; size <= kpad; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < kpad / 2; i += nt) {
+        const int lo = 2 * i - (i & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long x = keys[lo], y = keys[hi];
+        if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+}
+
+// grid (chunks, rows).  chunks == 1: final indices; else candidates[(row * chunks + c) * k ..] = (key << 32 | index)
+__global__ void __launch_bounds__(1024) topk_stage_kernel(const SvkTopkSortedArgs a, int kpad, int chunk, int chunks,
+                                                          unsigned long long* cand) {
+  __shared__ SelectScratch scratch;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  unsigned long long* sorted = reinterpret_cast<unsigned long long*>(dyn);                  // [kpad] (chunks == 1)
+  uint32_t* keys = reinterpret_cast<uint32_t*>(dyn + (chunks == 1 ? sizeof(unsigned long long) * kpad : 0));
+  const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+  const float* sc = a.scores + (int64_t)r * a.score_stride;
+  const int vlen = a.valid_len ? min(max(a.valid_len[r], 0), a.n) : a.n;
+  const int i0 = c * chunk, m = min(a.n, i0 + chunk) - i0;
+  const float masked = a.masked_value;
+  for (int i = tid; i < m; i += nt) keys[i] = desc_key(i0 + i < vlen ? sc[i0 + i] : masked);
+  if (chunks == 1)
+    for (int i = tid; i < kpad; i += nt) sorted[i] = ~0ull;
+  __syncthreads();
+  if (chunks == 1) {
+    block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, m, a.k, scratch, [&](int pos, int i) {
+      sorted[pos] = ((unsigned long long)keys[i] << 32) | (unsigned)i;
+    });
+    __syncthreads();
+    bitonic_sort_keys(sorted, kpad);
+    for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(sorted[i] & 0xffffffffull);
+    return;
+  }
+  unsigned long long* out = cand + ((int64_t)r * chunks + c) * a.k;
+  if (m <= a.k) {                       // the whole chunk survives; pad with "worst" entries
+    for (int i = tid; i < a.k; i += nt) out[i] = i < m ? (((unsigned long long)keys[i] << 32) | (unsigned)(i0 + i)) : ~0ull;
+    return;
+  }
+  block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, m, a.k, scratch, [&](int pos, int i) {
+    out[pos] = ((unsigned long long)keys[i] << 32) | (unsigned)(i0 + i);
+  });
+}
+
+// one workgroup per row over the chunks * k candidates (ascending index by construction)
+__global__ void __launch_bounds__(1024) topk_merge_kernel(const SvkTopkSortedArgs a, int kpad, int chunks,
+                                                          const unsigned long long* cand) {
+  __shared__ SelectScratch scratch;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  unsigned long long* sorted = reinterpret_cast<unsigned long long*>(dyn);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(dyn + sizeof(unsigned long long) * kpad);
+  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int total = chunks * a.k;
+  const unsigned long long* in = cand + (int64_t)r * total;
+  for (int i = tid; i < total; i += nt) keys[i] = (uint32_t)(in[i] >> 32);
+  for (int i = tid; i < kpad; i += nt) sorted[i] = ~0ull;
+  __syncthreads();
+  // padding entries carry key 0xffffffff with index 0xffffffff: they lose every tie against real entries because
+  // real entries of equal key (there are none unless a score is the all-ones NaN pattern) come first in a chunk
+  block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, total, a.k, scratch, [&](int pos, int i) {
+    sorted[pos] = in[i];
+  });
+  __syncthreads();
+  bitonic_sort_keys(sorted, kpad);
+  for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(sorted[i] & 0xffffffffull);
+}
+
+// fallback for shapes whose candidates do not fit one LDS stage: single workgroup, keys re-read from memory
 __global__ void __launch_bounds__(1024) topk_sorted_kernel(const SvkTopkSortedArgs a, int kpad) {
   __shared__ SelectScratch scratch;
   extern __shared__ unsigned long long keys[];     // [kpad]
@@ -267,19 +349,19 @@ __global__ void __launch_bounds__(1024) topk_sorted_kernel(const SvkTopkSortedAr
     keys[pos] = ((unsigned long long)desc_key(score_at(i)) << 32) | (unsigned)i;
   });
   __syncthreads();
-  // bitonic sort ascending on (desc_key, index) == (score desc, index asc)
-  for (int size = 2; size <= kpad; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = tid; i < kpad / 2; i += nt) {
-        const int lo = 2 * i - (i & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const unsigned long long x = keys[lo], y = keys[hi];
-        if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
-      }
-      __syncthreads();
-    }
+  bitonic_sort_keys(keys, kpad);
   for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(keys[i] & 0xffffffffull);
+}
+
+// chunks a row of n scores is split into (1 = single launch), or 0 when the two-level scheme does not fit
+int topk_plan_chunks(int n, int k) {
+  if (n <= kTopkStage) return 1;
+  const int max_chunks = kTopkStage / (k > 0 ? k : 1);          // merge stage: chunks * k keys in LDS
+  if (max_chunks < 2) return 0;
+  int chunks = (n + 16383) / 16384;
+  if (chunks > max_chunks) chunks = max_chunks;
+  const int chunk = (n + chunks - 1) / chunks;
+  return chunk <= 32768 ? chunks : 0;                            // chunk stage: 128 KiB of keys, no sort buffer
 }
 
 }  // namespace
@@ -352,7 +434,12 @@ extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_
   return check_launch("svk_deltakv_token_scores");
 }
 
-extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, svk_stream_t stream) {
+extern "C" int64_t svk_topk_sorted_workspace_bytes(int32_t rows, int32_t n, int32_t k) {
+  const int chunks = svk::topk_plan_chunks(n, k);
+  return chunks > 1 ? (int64_t)sizeof(unsigned long long) * rows * chunks * k : 0;
+}
+
+extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, void* workspace, svk_stream_t stream) {
   using namespace svk;
   SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_topk_sorted_desc: null args");
   SVK_REQUIRE(a->k >= 0 && a->k <= a->n, SVK_ERR_VALUE, "svk_topk_sorted_desc: k %d out of range (n=%d)", a->k, a->n);
@@ -360,7 +447,28 @@ extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, svk_stream_t str
   if (a->rows <= 0 || a->k == 0) return SVK_OK;
   int kpad = 2;
   while (kpad < a->k) kpad <<= 1;
-  hipLaunchKernelGGL(topk_sorted_kernel, dim3(a->rows), dim3((kpad >= 2048 || a->n > 8192) ? 1024 : 256), sizeof(unsigned long long) * kpad,
-                     static_cast<hipStream_t>(stream), *a, kpad);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    attr_set = true;
+  }
+  const int chunks = topk_plan_chunks(a->n, a->k);
+  if (chunks == 1) {
+    hipLaunchKernelGGL(topk_stage_kernel, dim3(1, a->rows), dim3(a->n > 2048 ? 1024 : 256),
+                       sizeof(unsigned long long) * kpad + sizeof(uint32_t) * (size_t)a->n, s, *a, kpad, a->n, 1,
+                       static_cast<unsigned long long*>(nullptr));
+  } else if (chunks > 1 && workspace != nullptr) {
+    const int chunk = (a->n + chunks - 1) / chunks;
+    unsigned long long* cand = static_cast<unsigned long long*>(workspace);
+    hipLaunchKernelGGL(topk_stage_kernel, dim3(chunks, a->rows), dim3(1024), sizeof(uint32_t) * (size_t)chunk, s, *a, kpad,
+                       chunk, chunks, cand);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(a->rows), dim3(1024),
+                       sizeof(unsigned long long) * kpad + sizeof(uint32_t) * (size_t)chunks * a->k, s, *a, kpad, chunks, cand);
+  } else {
+    hipLaunchKernelGGL(topk_sorted_kernel, dim3(a->rows), dim3((kpad >= 2048 || a->n > 8192) ? 1024 : 256),
+                       sizeof(unsigned long long) * kpad, s, *a, kpad);
+  }
   return check_launch("svk_topk_sorted_desc");
 }

@@ -54,6 +54,10 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
     const int safe = min(max(slot, 0), a.num_slots - 1);
     pos = max(a.slot_to_pos[safe], 0);
     copy = valid && a.postrope_mask != nullptr && a.postrope_mask[safe] != 0;
+    if (a.temp_slots != nullptr) {
+      const int j = w - a.temp_offset;
+      copy = valid && j >= 0 && j < a.temp_count && a.temp_slots[(int64_t)b * a.temp_stride + j] == slot;
+    }
     const int64_t base = (int64_t)safe * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
     rk1 = *reinterpret_cast<const uint4*>(a.k_cache + base);
     rk2 = *reinterpret_cast<const uint4*>(a.k_cache + base + HD2);

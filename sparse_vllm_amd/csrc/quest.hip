@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(512) quest_score_pages_kernel(const SvkQuestSc
 // top-k + packed view, one workgroup per batch lane
 // ------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) quest_build_view_kernel(const SvkQuestBuildViewArgs a) {
+__global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBuildViewArgs a, int lds_keys) {
   __shared__ SelectScratch scratch;
   extern __shared__ int sel_pages[];          // [prev_budget] selected logical pages, ascending
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -144,7 +144,15 @@ __global__ void __launch_bounds__(256) quest_build_view_kernel(const SvkQuestBui
     return;
   }
   const float* sc = a.page_scores + (int64_t)b * a.score_stride;
-  block_select_topk_ordered(sc, a.n_prev, a.prev_budget, scratch, [&](int pos, int idx) { sel_pages[pos] = idx; });
+  if (lds_keys) {
+    uint32_t* keys = reinterpret_cast<uint32_t*>(sel_pages + a.prev_budget);
+    for (int i = tid; i < a.n_prev; i += nt) keys[i] = desc_key(sc[i]);
+    __syncthreads();
+    block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, a.n_prev, a.prev_budget, scratch,
+                                   [&](int pos, int idx) { sel_pages[pos] = idx; });
+  } else {
+    block_select_topk_ordered(sc, a.n_prev, a.prev_budget, scratch, [&](int pos, int idx) { sel_pages[pos] = idx; });
+  }
   __syncthreads();
   const int sparse_keep = (a.prev_budget + 1) * ps;
   for (int i = tid; i < sparse_keep; i += nt) {
@@ -234,8 +242,17 @@ extern "C" int svk_quest_build_view(const SvkQuestBuildViewArgs* a, svk_stream_t
   SVK_REQUIRE(a->max_keep >= (a->prev_budget + 1) * a->page_size || a->is_long_text, SVK_ERR_VALUE,
               "svk_quest_build_view: max_keep %d smaller than the sparse view", a->max_keep);
   if (a->batch <= 0) return SVK_OK;
-  hipLaunchKernelGGL(quest_build_view_kernel, dim3(a->batch), dim3(256), sizeof(int) * a->prev_budget,
-                     static_cast<hipStream_t>(stream), *a);
+  // page-score keys are staged in LDS (one coalesced read, five LDS sweeps) whenever the row fits
+  size_t shm = sizeof(int) * a->prev_budget;
+  const int lds_keys = (shm + sizeof(uint32_t) * (size_t)a->n_prev) <= 128 * 1024;
+  if (lds_keys) shm += sizeof(uint32_t) * (size_t)a->n_prev;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quest_build_view_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(quest_build_view_kernel, dim3(a->batch), dim3(a->n_prev > 2048 ? 1024 : 256), shm,
+                     static_cast<hipStream_t>(stream), *a, lds_keys);
   return check_launch("svk_quest_build_view");
 }
 

@@ -91,10 +91,11 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, boo
   if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1);
 }
 
-// `score_at(i)` form (callers that mask or remap scores on the fly).  Each thread works on strips of kStrip
-// consecutive elements so the ordered emit needs one block scan per kStrip * blockDim elements.
-template <typename ScoreAt, typename Emit>
-__device__ __forceinline__ void block_select_topk_ordered_fn(ScoreAt score_at, int n, int k, SelectScratch& S, Emit emit) {
+// Core on descending-order keys `key_at(i)` (smaller key = better; callers stage keys in LDS when the row fits, so the
+// five sweeps do not pay a dependent global-load latency each).  Each thread works on strips of kStrip consecutive
+// elements so the ordered emit needs one block scan per kStrip * blockDim elements.
+template <typename KeyAt, typename Emit>
+__device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int n, int k, SelectScratch& S, Emit emit) {
   constexpr int kStrip = 4;
   const int tid = threadIdx.x, nt = blockDim.x;
   uint32_t prefix = 0;
@@ -110,7 +111,7 @@ __device__ __forceinline__ void block_select_topk_ordered_fn(ScoreAt score_at, i
         const int i = c0 + tid * kStrip + e;
         uint32_t key = 0u;
         const bool in = i < n;
-        if (in) key = desc_key(score_at(i));
+        if (in) key = key_at(i);
         hist_add_aggregated(S.hist, (key >> shift) & 255u, in && (key & himask) == prefix);
       }
     }
@@ -156,7 +157,7 @@ __device__ __forceinline__ void block_select_topk_ordered_fn(ScoreAt score_at, i
       const int i = c0 + tid * kStrip + e;
       key[e] = 0xffffffffu;
       if (i < n) {
-        key[e] = desc_key(score_at(i));
+        key[e] = key_at(i);
         n_lt += key[e] < T;
         n_eq += key[e] == T;
       }
@@ -196,9 +197,15 @@ __device__ __forceinline__ void block_select_topk_ordered_fn(ScoreAt score_at, i
   }
 }
 
+// `score_at(i)` form (callers that mask or remap scores on the fly)
+template <typename ScoreAt, typename Emit>
+__device__ __forceinline__ void block_select_topk_ordered_fn(ScoreAt score_at, int n, int k, SelectScratch& S, Emit emit) {
+  block_select_topk_ordered_keys([&](int i) { return desc_key(score_at(i)); }, n, k, S, emit);
+}
+
 template <typename Emit>
 __device__ __forceinline__ void block_select_topk_ordered(const float* sc, int n, int k, SelectScratch& S, Emit emit) {
-  block_select_topk_ordered_fn([sc](int i) { return sc[i]; }, n, k, S, emit);
+  block_select_topk_ordered_keys([sc](int i) { return desc_key(sc[i]); }, n, k, S, emit);
 }
 
 }  // namespace svk

@@ -594,12 +594,13 @@ class DeltaKVCacheManager(CacheManager):
 
     def _load_residual(self, l_idx: int, recon_latent: torch.Tensor) -> torch.Tensor:
         """deltakv_less_memory.py:2841-2848: latent gather -> (int4 dequant) -> compress_up (library GEMMs)."""
-        residual = self.deltakv_latent_cache[l_idx, recon_latent.long()]
         if int(self.config.kv_quant_bits or 0) == 4:
-            scales = self.deltakv_latent_scales[l_idx, recon_latent.long()]
-            mins = self.deltakv_latent_mins[l_idx, recon_latent.long()]
-            residual = dk.triton_dequantize_2d_int4_grouped(residual, scales, mins, self._quant_group_size(),
-                                                            int(residual.shape[-1]) * 8)
+            # gather + dequant in one launch (row_index = recon_latent, -1 entries read latent 0 and are never written back)
+            cache = self.deltakv_latent_cache[l_idx]
+            residual = dk.dequantize_grouped(cache, self.deltakv_latent_scales[l_idx], self.deltakv_latent_mins[l_idx],
+                                             self._quant_group_size(), int(cache.shape[-1]) * 8, 4, row_index=recon_latent)
+        else:
+            residual = self.deltakv_latent_cache[l_idx, recon_latent.clamp_min(0).long()]
         return self.compress_up[l_idx](residual)
 
     def _set_postrope_slots(self, layer_idx: int, slots: torch.Tensor):
@@ -629,18 +630,19 @@ class DeltaKVCacheManager(CacheManager):
             l_idx = self.deltakv_layer_to_idx[layer_idx]
             k_cache, v_cache = self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx]
             if recon_latent.numel() > 0:
-                safe_latent = recon_latent.clamp_min(0)
-                father_slots = self.deltakv_latent_to_full_slots[l_idx, safe_latent.long()].clamp_min(0)
                 with profiler.record("deltakv_less_memory_reconstruct_load_residual"):
-                    kv_delta = self._load_residual(l_idx, safe_latent)
+                    kv_delta = self._load_residual(l_idx, recon_latent)
                 with profiler.record("deltakv_less_memory_reconstruct_writeback"):
+                    # fathers = latent_to_full_slots[l, recon_latent.clamp_min(0)].clamp_min(0), resolved in-kernel
                     dk.deltakv_reconstruct_writeback_grouped_heads(
-                        kv_delta=kv_delta, father_slots=father_slots, slot_to_pos=self.deltakv_slot_to_pos,
+                        kv_delta=kv_delta, father_slots=self.deltakv_latent_to_full_slots[l_idx], father_index=recon_latent,
+                        slot_to_pos=self.deltakv_slot_to_pos,
                         out_slots=recon_out_slot, out_pos=recon_pos, cos_sin=self.cos_sin_cache, k_cache=k_cache,
                         v_cache=v_cache, k_norm_weight=None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx],
                         k_norm_eps=float(self.deltakv_k_norm_eps), raw_k_cache=True, store_raw_k=False)
-            with profiler.record("deltakv_less_memory_reconstruct_mark_postrope"):
-                self._set_postrope_slots(layer_idx, recon_out_slot)
+            # static decode: the post-RoPE slots of this layer are exactly the reconstruct scratch slots the plan put
+            # into the view, so the attention view identifies them positionally (no per-layer mask maintenance;
+            # `_set_postrope_slots` remains for callers that want the reference's mask)
             return active_slots, local_req, new_context_lens, torch.empty((0,), device=self.device, dtype=torch.int32)
 
     def _ensure_materialized_sparse_view(self, batch_size: int, width: int):
@@ -672,12 +674,14 @@ class DeltaKVCacheManager(CacheManager):
             return k_out, v_out, local_active, local_req, context_lens
         l_idx = self.deltakv_layer_to_idx[layer_idx]
         with profiler.record("deltakv_materialize_sparse_view"):
+            k_max = W - int(self.config.num_sink_tokens) - self._deltakv_decode_static_max_buffer()
             dk.deltakv_materialize_sparse_view(
-                active_slots, context_lens, self.deltakv_slot_to_pos, self._deltakv_postrope_slot_mask[l_idx],
+                active_slots, context_lens, self.deltakv_slot_to_pos, None,
                 self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx], k_out, v_out,
                 self.cos_sin_cache,
                 k_norm_weight=None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx],
-                k_norm_eps=float(self.deltakv_k_norm_eps))
+                k_norm_eps=float(self.deltakv_k_norm_eps),
+                temp_slots=self._ensure_decode_static_temp_slots(B, k_max), temp_offset=int(self.config.num_sink_tokens))
         return k_out, v_out, local_active, local_req, context_lens
 
     def build_decode_compute_view(self, layer_idx: int, q: torch.Tensor, selection: SparseSelection, *, num_heads: int,

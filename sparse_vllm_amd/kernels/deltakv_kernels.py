@@ -67,9 +67,11 @@ def deltakv_static_decode_plan(*, raw_slots_map, latent_slots_map, active_compre
 
 
 def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
-                 v_cache, bits, group_size, k_norm_weight, k_norm_eps, raw_k_cache, store_raw_k):
+                 v_cache, bits, group_size, k_norm_weight, k_norm_eps, raw_k_cache, store_raw_k, father_index=None):
     assert k_cache.dtype == torch.bfloat16 and k_cache.stride() == v_cache.stride() and k_cache.stride(-1) == 1
     assert father_slots.dim() == 2 and father_slots.dtype == torch.int32 and father_slots.stride(1) == 1
+    if father_index is not None:      # father_slots is the [latents, K] table, indexed in-kernel
+        assert father_index.dtype == torch.int32 and father_index.is_contiguous()
     assert cos_sin.stride(1) == 1
     if k_norm_weight is not None:
         assert k_norm_weight.dim() == 1 and k_norm_weight.shape[0] == k_cache.shape[2]
@@ -82,11 +84,13 @@ def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, o
         k_norm_weight=_lib.ptr(k_norm_weight), delta_stride=delta.stride(0),
         scale_stride=0 if scale is None else scale.stride(0), father_stride=father_slots.stride(0),
         cos_stride=cos_sin.stride(0), kv_slot_stride=k_cache.stride(0), kv_head_stride=k_cache.stride(1),
-        k_norm_eps=float(k_norm_eps), n=int(father_slots.shape[0]), k_fathers=int(father_slots.shape[1]),
+        k_norm_eps=float(k_norm_eps), n=int(father_slots.shape[0] if father_index is None else father_index.numel()),
+        k_fathers=int(father_slots.shape[1]),
         num_kv_heads=int(k_cache.shape[1]), head_dim=int(k_cache.shape[2]), delta_bits=int(bits),
         group_size=int(group_size), delta_dtype=_dt(delta) if bits == 0 else 0,
         scale_dtype=0 if scale is None else _dt(scale), cos_dtype=_dt(cos_sin), raw_k_cache=int(bool(raw_k_cache)),
-        store_raw_k=int(bool(store_raw_k)))
+        store_raw_k=int(bool(store_raw_k)), father_table=_lib.ptr(father_slots) if father_index is not None else None,
+        father_index=_lib.ptr(father_index), father_table_stride=father_slots.stride(0))
     _lib.check(lib.svk_deltakv_reconstruct_writeback(C.byref(a), _lib.current_stream_handle()), lib)
 
 
@@ -94,7 +98,9 @@ def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, o
 def deltakv_reconstruct_writeback_grouped_heads(kv_delta, father_slots, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
                                                 v_cache, *, heads_per_program: int = 4, pre_rope_k_cache=None,
                                                 ref_v_cache=None, k_norm_weight=None, k_norm_eps: float = 1e-6,
-                                                raw_k_cache: bool = False, store_raw_k: bool = False):
+                                                raw_k_cache: bool = False, store_raw_k: bool = False, father_index=None):
+    """`father_index` (extension): `father_slots` is then the whole `[latents, K]` father table and entry n uses row
+    max(father_index[n], 0) with negative fathers clamped to 0 (the static-decode gather fused into the kernel)."""
     if int(heads_per_program) <= 0:
         raise ValueError("heads_per_program must be a positive integer.")
     if pre_rope_k_cache is not None or ref_v_cache is not None:
@@ -103,7 +109,7 @@ def deltakv_reconstruct_writeback_grouped_heads(kv_delta, father_slots, slot_to_
     _reconstruct(delta=kv_delta, scale=None, mn=None, latent_slots=None, father_slots=father_slots,
                  slot_to_pos=slot_to_pos, out_slots=out_slots, out_pos=out_pos, cos_sin=cos_sin, k_cache=k_cache,
                  v_cache=v_cache, bits=0, group_size=0, k_norm_weight=k_norm_weight, k_norm_eps=k_norm_eps,
-                 raw_k_cache=raw_k_cache, store_raw_k=store_raw_k)
+                 raw_k_cache=raw_k_cache, store_raw_k=store_raw_k, father_index=father_index)
 
 
 @torch.no_grad()
@@ -147,12 +153,15 @@ def deltakv_less_memory_reconstruct_writeback_int4(*args, **kwargs):
     return deltakv_less_memory_reconstruct_writeback_quantized(*args, quant_bits=4, **kwargs)
 
 
-def dequantize_grouped(packed, scale, mn, group_size: int, output_dim: int, bits: int, out_dtype=None):
-    """q * scale + mn for LSB-first `bits`-wide codes (quant.py:120-157, :304-349)."""
+def dequantize_grouped(packed, scale, mn, group_size: int, output_dim: int, bits: int, out_dtype=None, *, row_index=None):
+    """q * scale + mn for LSB-first `bits`-wide codes (quant.py:120-157, :304-349).  With `row_index` (int32 [n]) the
+    output row r is decoded from source row max(row_index[r], 0): the latent gather of `_load_residual` fused in."""
     if packed.dim() != 2 or scale.dim() != 2 or mn.dim() != 2:
         raise ValueError("2D dequantization expects rank-2 packed/scale/min tensors, "
                          f"got packed={tuple(packed.shape)}, scale={tuple(scale.shape)}, mn={tuple(mn.shape)}.")
-    n, output_dim, group_size, bits = int(packed.shape[0]), int(output_dim), int(group_size), int(bits)
+    src_rows = int(packed.shape[0])
+    n = src_rows if row_index is None else int(row_index.numel())
+    output_dim, group_size, bits = int(output_dim), int(group_size), int(bits)
     if bits not in (2, 4, 8):
         raise ValueError(f"Packed quantization supports bits=(2, 4, 8), got {bits}.")
     fpi = 32 // bits
@@ -163,16 +172,20 @@ def dequantize_grouped(packed, scale, mn, group_size: int, output_dim: int, bits
                          f"got output_dim={output_dim}, group_size={group_size}.")
     if int(packed.shape[1]) != output_dim // fpi:
         raise ValueError(f"dequantization packed width mismatch: packed={packed.shape[1]}, expected={output_dim // fpi}.")
-    if tuple(scale.shape) != (n, output_dim // group_size) or tuple(mn.shape) != tuple(scale.shape):
+    if tuple(scale.shape) != (src_rows, output_dim // group_size) or tuple(mn.shape) != tuple(scale.shape):
         raise ValueError("dequantization scale/min shape mismatch: "
-                         f"scale={tuple(scale.shape)}, mn={tuple(mn.shape)}, expected={(n, output_dim // group_size)}.")
-    packed, scale, mn = packed.contiguous(), scale.contiguous(), mn.contiguous()
+                         f"scale={tuple(scale.shape)}, mn={tuple(mn.shape)}, expected={(src_rows, output_dim // group_size)}.")
+    if row_index is not None:
+        assert row_index.dtype == torch.int32 and row_index.is_contiguous()
+        assert packed.stride(1) == 1 and scale.stride(1) == 1 and scale.stride() == mn.stride()
+    else:
+        packed, scale, mn = packed.contiguous(), scale.contiguous(), mn.contiguous()
     out = torch.empty((n, output_dim), device=packed.device, dtype=out_dtype or scale.dtype)
     lib = _lib.load()
     a = _lib.SvkDequantGroupedArgs(packed=_lib.ptr(packed), scale=_lib.ptr(scale), mn=_lib.ptr(mn), out=_lib.ptr(out),
                                    packed_stride=packed.stride(0), scale_stride=scale.stride(0), out_stride=out.stride(0),
                                    rows=n, features=output_dim, bits=bits, group_size=group_size, scale_dtype=_dt(scale),
-                                   out_dtype=_dt(out))
+                                   out_dtype=_dt(out), row_index=_lib.ptr(row_index))
     _lib.check(lib.svk_dequantize_grouped(C.byref(a), _lib.current_stream_handle()), lib)
     return out
 
@@ -213,17 +226,22 @@ def topk_sorted_desc(scores, k: int, *, valid_len=None, masked_value: float = -1
     rows, n = scores.shape
     out = torch.empty((rows, int(k)), dtype=torch.int32, device=scores.device)
     lib = _lib.load()
+    ws_bytes = int(lib.svk_topk_sorted_workspace_bytes(rows, n, int(k)))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=scores.device) if ws_bytes > 0 else None
     a = _lib.SvkTopkSortedArgs(scores=_lib.ptr(scores), valid_len=_lib.ptr(valid_len), indices=_lib.ptr(out),
                                score_stride=scores.stride(0), index_stride=out.stride(0), masked_value=float(masked_value),
                                rows=rows, n=n, k=int(k))
-    _lib.check(lib.svk_topk_sorted_desc(C.byref(a), _lib.current_stream_handle()), lib)
+    _lib.check(lib.svk_topk_sorted_desc(C.byref(a), _lib.ptr(ws), _lib.current_stream_handle()), lib)
     return out
 
 
 @torch.no_grad()
 def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, postrope_mask, k_cache, v_cache, out_k, out_v,
-                                    cos_sin, *, k_norm_weight=None, k_norm_eps: float = 1e-6, block_tokens: int = 16):
-    """Reference wrapper deltakv_kernels.py:3489-3585 (same arguments; `block_tokens` is a Triton tile knob)."""
+                                    cos_sin, *, k_norm_weight=None, k_norm_eps: float = 1e-6, block_tokens: int = 16,
+                                    temp_slots=None, temp_offset: int = 0):
+    """Reference wrapper deltakv_kernels.py:3489-3585 (same arguments; `block_tokens` is a Triton tile knob).
+    Extension: `temp_slots` [B, K] + `temp_offset` replace the mask in static decode (an entry in columns
+    [temp_offset, temp_offset + K) is post-RoPE iff its slot is this step's reconstruct scratch slot)."""
     for t in (active_slots, context_lens, slot_to_pos, k_cache, v_cache, out_k, out_v, cos_sin):
         assert t.is_cuda
     assert active_slots.dim() == 2
@@ -249,6 +267,9 @@ def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, pos
     if postrope_mask is not None:
         assert postrope_mask.is_cuda and postrope_mask.dim() == 1 and postrope_mask.shape[0] >= k_cache.shape[0]
         assert postrope_mask.dtype in (torch.bool, torch.uint8) and postrope_mask.is_contiguous()
+    if temp_slots is not None:
+        assert temp_slots.dtype == torch.int32 and temp_slots.dim() == 2 and temp_slots.stride(1) == 1
+        assert temp_slots.shape[0] == batch
     assert active_slots.dtype == torch.int32 and active_slots.stride(1) == 1
     assert slot_to_pos.dtype == torch.int32 and slot_to_pos.is_contiguous()
     for t in (k_cache, v_cache, out_k, out_v):
@@ -262,7 +283,9 @@ def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, pos
         active_stride=active_slots.stride(0), kv_slot_stride=k_cache.stride(0), kv_head_stride=k_cache.stride(1),
         out_slot_stride=out_k.stride(0), out_head_stride=out_k.stride(1), cos_stride=cos_sin.stride(0),
         k_norm_eps=float(k_norm_eps), batch=int(batch), width=int(width), num_slots=int(k_cache.shape[0]),
-        num_kv_heads=num_kv_heads, head_dim=head_dim, cos_dtype=_dt(cos_sin))
+        num_kv_heads=num_kv_heads, head_dim=head_dim, cos_dtype=_dt(cos_sin), temp_slots=_lib.ptr(temp_slots),
+        temp_stride=0 if temp_slots is None else temp_slots.stride(0), temp_offset=int(temp_offset),
+        temp_count=0 if temp_slots is None else int(temp_slots.shape[1]))
     _lib.check(lib.svk_deltakv_materialize_sparse_view(C.byref(a), _lib.current_stream_handle()), lib)
 
 

@@ -186,6 +186,23 @@ def test_token_scores_and_sorted_topk():
         np.testing.assert_array_equal(idx[b], exp)
 
 
+@pytest.mark.parametrize("n,k,rows", [(262144, 2048, 2), (70000, 4096, 1), (40000, 300, 3), (24576, 4096, 2),
+                                       (9000, 291, 4), (1_100_000, 2048, 1), (50, 50, 2)])
+def test_sorted_topk_long_rows(n, k, rows):
+    """Rows longer than one LDS stage take the chunked path (per-chunk candidates + merge); shapes that fit neither
+    take the single-workgroup fallback.  bf16-valued probabilities => massive ties; result must equal the stable
+    descending argsort (score desc, index asc) bit for bit, including masked tails shorter than k."""
+    from sparse_vllm_amd.kernels.deltakv_kernels import topk_sorted_desc
+    rng = np.random.default_rng(n + k)
+    x = bf16_round((rng.random((rows, n)) ** 8).astype(np.float32))
+    x[0, : min(n, 5000)] = 0.25                                   # one huge tie group
+    vlen = np.array([n, max(1, k // 2), max(1, n - 7)][:rows] + [n] * max(0, rows - 3), np.int32)
+    idx = topk_sorted_desc(t(x), k, valid_len=t(vlen), masked_value=-1e10).cpu().numpy()
+    for r in range(rows):
+        s = np.where(np.arange(n) < vlen[r], x[r], np.float32(-1e10))
+        np.testing.assert_array_equal(idx[r], np.argsort(-s, kind="stable")[:k])
+
+
 def test_materialize_sparse_view_golden_and_random(golden):
     """Tolerance: one bf16 rounding of the rotated key (|x| <~ 4 -> atol 2^-7 * ... use rtol 2^-7, atol 1e-6);
     V and post-RoPE K are copies -> bit-exact."""
@@ -226,3 +243,60 @@ def test_materialize_sparse_view_golden_and_random(golden):
     np.testing.assert_array_equal(ov, rv)
     copied = post[active.reshape(-1)]
     np.testing.assert_array_equal(ok[copied], bf16_bits_to_f32(k)[active.reshape(-1)[copied]])
+
+
+def test_fused_static_decode_variants_match_unfused():
+    """The static-decode fusions (row-indexed dequant, in-kernel father lookup, positional post-RoPE test) must be
+    bit-identical to the reference-shaped call sequences they replace (deltakv_less_memory.py:2841-2848, :4054-4058,
+    deltakv_less_memory_cuda_graph.py:476-500)."""
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    rng = np.random.default_rng(11)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n_lat, feat, grp, N, Kf, S, Hkv, D, P = 300, 256, 32, 70, 4, 500, 4, 128, 900
+    code = torch.randint(-2 ** 31, 2 ** 31 - 1, (n_lat, feat // 8), generator=g, dtype=torch.int64).to(torch.int32).to(dev())
+    scale = (torch.rand((n_lat, feat // grp), generator=g) * 0.05 + 0.01).to(torch.bfloat16).to(dev())
+    mn = (scale.float() * -7.5).to(torch.bfloat16)
+    idx = torch.from_numpy(rng.integers(-1, n_lat, N).astype(np.int32)).to(dev())
+    safe = idx.clamp_min(0).long()
+    a = dk.dequantize_grouped(code, scale, mn, grp, feat, 4, row_index=idx)
+    b = dk.triton_dequantize_2d_int4_grouped(code[safe], scale[safe], mn[safe], grp, feat)
+    assert torch.equal(a, b)
+
+    kc = (torch.randn((S, Hkv, D), generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    vc = (torch.randn((S, Hkv, D), generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    table = torch.from_numpy(rng.integers(-1, 400, (n_lat, Kf)).astype(np.int32)).to(dev())
+    s2p = torch.from_numpy(rng.integers(0, P, S).astype(np.int32)).to(dev())
+    out_slots = torch.arange(400, 400 + N, dtype=torch.int32, device=dev())
+    out_slots[idx < 0] = -1
+    out_pos = torch.from_numpy(rng.integers(0, P, N).astype(np.int32)).to(dev())
+    out_pos[idx < 0] = -1
+    inv = 1.0 / (1e6 ** (np.arange(D // 2) / (D // 2)))
+    ang = np.arange(P)[:, None] * inv[None, :]
+    cos_sin = t(np.concatenate((np.cos(ang), np.sin(ang)), axis=1).astype(np.float32))
+    delta = (torch.randn((N, 2 * Hkv * D), generator=g) * 0.3).to(torch.bfloat16).to(dev())
+    k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    dk.deltakv_reconstruct_writeback_grouped_heads(delta, table[safe].clamp_min(0).contiguous(), s2p, out_slots, out_pos,
+                                                   cos_sin, k1, v1, raw_k_cache=True)
+    dk.deltakv_reconstruct_writeback_grouped_heads(delta, table, s2p, out_slots, out_pos, cos_sin, k2, v2, raw_k_cache=True,
+                                                   father_index=idx)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+
+    B, sink, K, buf = 2, 8, 35, 16
+    W = sink + K + buf
+    temp = out_slots.clone().view(B, K)
+    temp[temp < 0] = 499                       # scratch ids of entries that were not reconstructed
+    active = torch.from_numpy(rng.integers(0, 400, (B, W)).astype(np.int32)).to(dev())
+    use_temp = torch.from_numpy(rng.random((B, K)) < 0.6).to(dev())
+    active[:, sink:sink + K] = torch.where(use_temp, temp, active[:, sink:sink + K])
+    mask = torch.zeros(S, dtype=torch.bool, device=dev())
+    mask[temp[use_temp].long()] = True
+    lens = torch.full((B,), W, dtype=torch.int32, device=dev())
+    outs = []
+    for kw in (dict(postrope_mask=mask), dict(postrope_mask=None, temp_slots=temp, temp_offset=sink)):
+        ok = torch.zeros((B * W, Hkv, D), dtype=torch.bfloat16, device=dev())
+        ov = torch.zeros_like(ok)
+        pm = kw.pop("postrope_mask")
+        dk.deltakv_materialize_sparse_view(active, lens, s2p, pm, k2, v2, ok, ov, cos_sin, **kw)
+        outs.append((ok, ov))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
