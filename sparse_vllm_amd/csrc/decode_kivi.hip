@@ -246,12 +246,415 @@ __global__ void __launch_bounds__(512) kivi_stage1_kernel(const SvkKiviDecodeSta
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 128-token-tile kernel (group_size 32): both products on the matrix cores, K/V dequantised straight
+// into MFMA operand registers.
+//
+//   Q.K^T  tile = 128 tokens = 16 "groups" of 8 consecutive tokens.  MFMA i (0..7) of d-chunk c takes as
+//          column n the token 8n+i, so lane (n, kc) needs nibble i of the 8 words
+//          Key_Packed[block(n)][h][c*32 + kc*8 + e][word(n)], e = 0..7 - one 4-byte load per word serves all 8
+//          MFMAs (the 8 tokens of a word), 32 loads per lane per tile instead of 256.
+//   P.V    MFMA i of 32-token block j takes as column n the head dim n*8+i, so lane (n, kc) needs nibble i of
+//          Value_Packed[block j][h][kc*8 + e][n], e = 0..7: again one word per token serves all 8 MFMAs, and the
+//          accumulator of lane (n, rows g) ends up holding 8 consecutive head dims -> 32-byte output stores.
+//   The S accumulators already hold, per lane, 8 consecutive tokens of 4 heads, which is what the P tile in
+//   LDS ([head][token] bf16) wants as 16-byte writes; the A operand of P.V reads it back as 16-byte rows.
+//   Tiles that contain raw tokens (sink, tail), a ragged end or blocks not aligned to 8 tokens take the same data
+//   flow with per-token loads.
+// ------------------------------------------------------------------------------------------------
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));      // v_cvt_pk_bf16_f32 (RNE)
+}
+
+template <int N>
+__device__ __forceinline__ float cvt_ubyte(uint32_t x) {
+  float f;
+  if constexpr (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(x));
+  else if constexpr (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(x));
+  else if constexpr (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(x));
+  else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(x));
+  return f;
+}
+
+// nibble I of `w` as a float: even nibbles come out of (w & 0x0f0f0f0f) as q, odd ones out of (w & 0xf0f0f0f0) as
+// 16*q - callers multiply those by scale/16, which rounds exactly like q*scale (power-of-two scaling).
+template <int I>
+__device__ __forceinline__ float nibble_f32(uint32_t lo, uint32_t hi) {
+  return (I & 1) ? cvt_ubyte<I / 2>(hi) : cvt_ubyte<I / 2>(lo);
+}
+
+template <int D, int G, bool KF32>
+__global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviDecodeStage1Args a) {
+  constexpr int NC = D / 32, JQ = (G + 3) / 4, DW = D / 8, NG = D / 32;
+  constexpr int kT = 128, GS = 32;
+  // per-wave LDS: P tile [16][128] bf16 (4 KiB) | V scales [NG][128] bf16 | V mins [NG][128] bf16
+  constexpr int P_BYTES = 16 * kT * 2, VS_BYTES = NG * kT * 2, WAVE_BYTES = P_BYTES + 2 * VS_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Hkv = a.num_kv_heads;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int n = lane & 15, kc = lane >> 4;          // MFMA column / k chunk; kc doubles as accumulator row group
+  const int dg = n % DW;                            // V word (8 head dims) of this lane
+  unsigned char* wl = lds_raw + w * WAVE_BYTES;
+  uint16_t* Pl = reinterpret_cast<uint16_t*>(wl);
+  uint16_t* Vs = reinterpret_cast<uint16_t*>(wl + P_BYTES);
+  uint16_t* Vm = reinterpret_cast<uint16_t*>(wl + P_BYTES + VS_BYTES);
+  const int len = a.context_lens[b];
+  const int start = blk * a.block_seq;
+  const int end = min(len, start + a.block_seq);
+  float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)blk * a.mid_o_stride_s;
+  float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + blk;
+  if (end <= start) {
+    for (int h = 0; h < G; ++h) {
+      float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h;
+      for (int d = lane; d < D; d += 64) o[d] = 0.f;
+      if (lane == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = -INFINITY;
+    }
+    return;
+  }
+  for (int i = lane; i < P_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(Pl)[i] = 0u;     // rows >= G stay zero
+  // Q fragments (A operand of Q.K^T): lane (m = n, kc) holds Q[head n][c*32 + kc*8 .. +8]
+  bf16x8_t qa[NC];
+  {
+    const uint16_t* qp = a.q + (int64_t)b * a.q_stride_b + (int64_t)(w * G + n) * a.q_stride_h + kc * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (n < G) t = *reinterpret_cast<const uint4*>(qp + c * 32);
+      qa[c] = __builtin_bit_cast(bf16x8_t, t);
+    }
+  }
+  const int row = a.req_indices[b];
+  const int32_t* raw_map = a.raw_slots_map + (int64_t)row * a.map_stride;
+  const int32_t* blk_map = a.kivi_block_slots_map + (int64_t)row * a.map_stride;
+  const float sm_scale = rsqrtf((float)D);
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+  f32x4_t acc[8];                                    // acc[i][r]: head kc*4+r, head dim dg*8+i
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // K fragment of one token (generic path): 8 channels c*32 + kc*8.. of token t, raw or dequantised
+  auto token_k = [&](int t, uint4 (&kr)[NC]) -> bool {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) kr[c] = make_uint4(0, 0, 0, 0);
+    if (t >= end) return false;
+    const int rs = raw_map[t];
+    if (rs >= 0) {
+      const uint16_t* kp = a.raw_k + (int64_t)rs * a.raw_slot_stride + (int64_t)w * a.raw_head_stride + kc * 8;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) kr[c] = *reinterpret_cast<const uint4*>(kp + c * 32);
+      return true;
+    }
+    const int bs = blk_map[t];
+    if (bs < 0) return false;
+    const int lt = t - a.kivi_block_start_pos[bs];
+    if (lt < 0 || lt >= GS) return false;
+    const int64_t hb = (int64_t)bs * Hkv + w;
+    const int shift = (lt & 7) * 4, widx = lt >> 3;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int d0 = c * 32 + kc * 8;
+      uint32_t ow[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        float s0, s1, m0, m1;
+        if constexpr (KF32) {
+          const float* sp = reinterpret_cast<const float*>(a.key_scales) + hb * D + d0 + e2 * 2;
+          const float* mp = reinterpret_cast<const float*>(a.key_mins) + hb * D + d0 + e2 * 2;
+          s0 = sp[0]; s1 = sp[1]; m0 = mp[0]; m1 = mp[1];
+        } else {
+          const uint32_t sw = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.key_scales) + hb * D + d0 + e2 * 2);
+          const uint32_t mw = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.key_mins) + hb * D + d0 + e2 * 2);
+          s0 = bf16_lo(sw); s1 = bf16_hi(sw); m0 = bf16_lo(mw); m1 = bf16_hi(mw);
+        }
+        const int32_t* cw = a.key_packed + (hb * D + d0 + e2 * 2) * (GS / 8) + widx;
+        const float q0 = (float)(((uint32_t)cw[0] >> shift) & 15u), q1 = (float)(((uint32_t)cw[GS / 8] >> shift) & 15u);
+        ow[e2] = pack_bf16(add_rn(mul_rn(q0, s0), m0), add_rn(mul_rn(q1, s1), m1));
+      }
+      kr[c] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+    return true;
+  };
+  // V row segment of one token (generic path): 8 head dims dg*8.. as packed bf16; zero when invalid
+  auto token_v = [&](int t) -> uint4 {
+    if (t >= end) return make_uint4(0, 0, 0, 0);
+    const int rs = raw_map[t];
+    if (rs >= 0) return *reinterpret_cast<const uint4*>(a.raw_v + (int64_t)rs * a.raw_slot_stride + (int64_t)w * a.raw_head_stride + dg * 8);
+    const int bs = blk_map[t];
+    if (bs < 0) return make_uint4(0, 0, 0, 0);
+    const int lt = t - a.kivi_block_start_pos[bs];
+    if (lt < 0 || lt >= GS) return make_uint4(0, 0, 0, 0);
+    const int64_t tb = ((int64_t)bs * Hkv + w) * GS + lt;
+    const uint32_t word = (uint32_t)a.value_packed[tb * DW + dg];
+    const float sc = __builtin_bit_cast(float, (uint32_t)a.value_scales[tb * NG + dg / 4] << 16);
+    const float mn = __builtin_bit_cast(float, (uint32_t)a.value_mins[tb * NG + dg / 4] << 16);
+    uint32_t o[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2)
+      o[e2] = pack_bf16(add_rn(mul_rn((float)((word >> (e2 * 8)) & 15u), sc), mn),
+                        add_rn(mul_rn((float)((word >> (e2 * 8 + 4)) & 15u), sc), mn));
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
+
+  for (int t0 = start; t0 < end; t0 += kT) {
+    // ---- classify the 16 groups of 8 tokens (lanes 0..15, one group each)
+    int gb = 0, glt = 0;
+    bool gfast = true;
+    if (lane < 16) {
+      const int tg = t0 + lane * 8;
+      gfast = false;
+      if (tg + 8 <= end) {
+        const int b0 = blk_map[tg];
+        bool ok = b0 >= 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ok = ok && raw_map[tg + e] < 0 && blk_map[tg + e] == b0;
+        if (ok) {
+          const int lt0 = tg - a.kivi_block_start_pos[b0];
+          gfast = lt0 >= 0 && (lt0 & 7) == 0 && lt0 + 8 <= GS;
+          gb = b0;
+          glt = lt0;
+        }
+      }
+    }
+    const bool fast = __all(gfast);
+    f32x4_t s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    unsigned tvmask = 0xffu;                          // bit i: token 8n+i of this lane's column is valid
+    if (fast) {
+      const int kb = __shfl(gb, n, 64), klt = __shfl(glt, n, 64);
+      const int64_t hb = (int64_t)kb * Hkv + w;
+      const int32_t* kw = a.key_packed + (hb * D + kc * 8) * (GS / 8) + (klt >> 3);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        uint32_t wd[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wd[e] = (uint32_t)kw[(c * 32 + e) * (GS / 8)];
+        float sc[8], mn[8];
+        if constexpr (KF32) {
+          const float* sp = reinterpret_cast<const float*>(a.key_scales) + hb * D + c * 32 + kc * 8;
+          const float* mp = reinterpret_cast<const float*>(a.key_mins) + hb * D + c * 32 + kc * 8;
+          const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+          const float4 m0 = *reinterpret_cast<const float4*>(mp), m1 = *reinterpret_cast<const float4*>(mp + 4);
+          sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+          mn[0] = m0.x; mn[1] = m0.y; mn[2] = m0.z; mn[3] = m0.w; mn[4] = m1.x; mn[5] = m1.y; mn[6] = m1.z; mn[7] = m1.w;
+        } else {
+          const uint4 sv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.key_scales) + hb * D + c * 32 + kc * 8);
+          const uint4 mv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.key_mins) + hb * D + c * 32 + kc * 8);
+          sc[0] = bf16_lo(sv.x); sc[1] = bf16_hi(sv.x); sc[2] = bf16_lo(sv.y); sc[3] = bf16_hi(sv.y);
+          sc[4] = bf16_lo(sv.z); sc[5] = bf16_hi(sv.z); sc[6] = bf16_lo(sv.w); sc[7] = bf16_hi(sv.w);
+          mn[0] = bf16_lo(mv.x); mn[1] = bf16_hi(mv.x); mn[2] = bf16_lo(mv.y); mn[3] = bf16_hi(mv.y);
+          mn[4] = bf16_lo(mv.z); mn[5] = bf16_hi(mv.z); mn[6] = bf16_lo(mv.w); mn[7] = bf16_hi(mv.w);
+        }
+        uint32_t lo[8], hi[8];
+        float sc16[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lo[e] = wd[e] & 0x0f0f0f0fu; hi[e] = wd[e] & 0xf0f0f0f0u; sc16[e] = sc[e] * 0.0625f; }
+#define SVK_K_MFMA(I_)                                                                                         \
+        {                                                                                                      \
+          uint32_t kf[4];                                                                                      \
+          _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                                   \
+            const float x0 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2], hi[2 * e2]), ((I_) & 1) ? sc16[2 * e2] : sc[2 * e2]), mn[2 * e2]);             \
+            const float x1 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2 + 1], hi[2 * e2 + 1]), ((I_) & 1) ? sc16[2 * e2 + 1] : sc[2 * e2 + 1]), mn[2 * e2 + 1]); \
+            kf[e2] = pack_bf16(x0, x1);                                                                        \
+          }                                                                                                    \
+          s[I_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, make_uint4(kf[0], kf[1], kf[2], kf[3])), s[I_], 0, 0, 0); \
+        }
+        SVK_K_MFMA(0) SVK_K_MFMA(1) SVK_K_MFMA(2) SVK_K_MFMA(3) SVK_K_MFMA(4) SVK_K_MFMA(5) SVK_K_MFMA(6) SVK_K_MFMA(7)
+#undef SVK_K_MFMA
+      }
+    } else {
+      tvmask = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        uint4 kr[NC];
+        if (token_k(t0 + 8 * n + i, kr)) tvmask |= 1u << i;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, kr[c]), s[i], 0, 0, 0);
+      }
+    }
+    // ---- raw scores (observation layers): 8 consecutive tokens per head per lane
+    if (a.attn_score != nullptr && kc < JQ) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int h = kc * 4 + r;
+        if (h < G) {
+          float* dst = a.attn_score + (int64_t)b * a.score_stride_b + (int64_t)(w * G + h) * a.score_stride_h + t0 + 8 * n;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if ((tvmask >> i) & 1u) dst[i] = s[i][r];
+        }
+      }
+    }
+    // ---- online softmax over the tile; P (bf16) -> LDS [head][token]
+    float alpha[4];
+    bool rescale = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool hv = (kc * 4 + r < G);
+      float x[8], tmax = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[i] = (hv && ((tvmask >> i) & 1u)) ? s[i][r] * sm_scale : -INFINITY;
+        tmax = fmaxf(tmax, x[i]);
+      }
+      tmax = row16_allmax(tmax);
+      const float nm = fmaxf(m[r], tmax);
+      float psum = 0.f;
+      uint32_t pw[4] = {0u, 0u, 0u, 0u};
+      alpha[r] = 1.f;
+      if (hv && nm > -INFINITY) {
+        alpha[r] = __expf(m[r] - nm);
+        float p[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { p[i] = __expf(x[i] - nm); psum += p[i]; }
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) pw[e2] = pack_bf16(p[2 * e2], p[2 * e2 + 1]);
+        rescale |= (nm != m[r]);
+        m[r] = nm;
+      }
+      l[r] = l[r] * alpha[r] + row16_allsum(psum);
+      if (kc < JQ) *reinterpret_cast<uint4*>(Pl + (kc * 4 + r) * kT + 8 * n) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+    }
+    if (__any(rescale)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] *= alpha[r];
+    }
+    // ---- V scales / mins of the tile -> LDS [group][token] (fast tiles): lane l covers tokens 2l, 2l+1
+    if (fast) {
+      const int gsrc = lane >> 2;                    // group of 8 tokens that holds tokens 2*lane, 2*lane+1
+      const int vb = __shfl(gb, gsrc, 64), vlt = __shfl(glt, gsrc, 64) + ((2 * lane) & 7);
+      const int64_t tb = (((int64_t)vb * Hkv + w) * GS + vlt) * NG;
+      uint32_t sw[NG], mw[NG];                       // [token pair][group] bf16: NG words per tensor (2 tokens x NG groups)
+      if constexpr (NG == 4) {
+        const uint4 s4 = *reinterpret_cast<const uint4*>(a.value_scales + tb), m4 = *reinterpret_cast<const uint4*>(a.value_mins + tb);
+        sw[0] = s4.x; sw[1] = s4.y; sw[2] = s4.z; sw[3] = s4.w; mw[0] = m4.x; mw[1] = m4.y; mw[2] = m4.z; mw[3] = m4.w;
+      } else {
+        const uint2 s2 = *reinterpret_cast<const uint2*>(a.value_scales + tb), m2 = *reinterpret_cast<const uint2*>(a.value_mins + tb);
+        sw[0] = s2.x; sw[1] = s2.y; mw[0] = m2.x; mw[1] = m2.y;
+      }
+      // memory order: token 2l: groups 0..NG-1, token 2l+1: groups 0..NG-1 (2 bf16 per word)
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int flat = tk * NG + g;
+          const uint32_t sword = sw[flat >> 1], mword = mw[flat >> 1];
+          Vs[g * kT + 2 * lane + tk] = (uint16_t)((flat & 1) ? (sword >> 16) : (sword & 0xffffu));
+          Vm[g * kT + 2 * lane + tk] = (uint16_t)((flat & 1) ? (mword >> 16) : (mword & 0xffffu));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- P.V: 4 blocks of 32 tokens, 8 MFMAs each (head dims dg*8 + i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint4 pa = *reinterpret_cast<const uint4*>(Pl + n * kT + 32 * j + kc * 8);       // A: head n, tokens 32j + kc*8..
+      const bf16x8_t pfrag = __builtin_bit_cast(bf16x8_t, pa);
+      if (fast) {
+        const int vb = __shfl(gb, 4 * j + kc, 64), vlt = __shfl(glt, 4 * j + kc, 64);
+        const int32_t* vw = a.value_packed + ((((int64_t)vb * Hkv + w) * GS + vlt) * DW + dg);
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t wd = (uint32_t)vw[e * DW];
+          lo[e] = wd & 0x0f0f0f0fu;
+          hi[e] = wd & 0xf0f0f0f0u;
+        }
+        const uint4 s8 = *reinterpret_cast<const uint4*>(Vs + (dg / 4) * kT + 32 * j + kc * 8);
+        const uint4 m8 = *reinterpret_cast<const uint4*>(Vm + (dg / 4) * kT + 32 * j + kc * 8);
+        float sc[8], sc16[8], mn[8];
+        sc[0] = bf16_lo(s8.x); sc[1] = bf16_hi(s8.x); sc[2] = bf16_lo(s8.y); sc[3] = bf16_hi(s8.y);
+        sc[4] = bf16_lo(s8.z); sc[5] = bf16_hi(s8.z); sc[6] = bf16_lo(s8.w); sc[7] = bf16_hi(s8.w);
+        mn[0] = bf16_lo(m8.x); mn[1] = bf16_hi(m8.x); mn[2] = bf16_lo(m8.y); mn[3] = bf16_hi(m8.y);
+        mn[4] = bf16_lo(m8.z); mn[5] = bf16_hi(m8.z); mn[6] = bf16_lo(m8.w); mn[7] = bf16_hi(m8.w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sc16[e] = sc[e] * 0.0625f;
+#define SVK_V_MFMA(I_)                                                                                         \
+        {                                                                                                      \
+          uint32_t vf[4];                                                                                      \
+          _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                                   \
+            const float x0 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2], hi[2 * e2]), ((I_) & 1) ? sc16[2 * e2] : sc[2 * e2]), mn[2 * e2]);             \
+            const float x1 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2 + 1], hi[2 * e2 + 1]), ((I_) & 1) ? sc16[2 * e2 + 1] : sc[2 * e2 + 1]), mn[2 * e2 + 1]); \
+            vf[e2] = pack_bf16(x0, x1);                                                                        \
+          }                                                                                                    \
+          acc[I_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag, __builtin_bit_cast(bf16x8_t, make_uint4(vf[0], vf[1], vf[2], vf[3])), acc[I_], 0, 0, 0); \
+        }
+        SVK_V_MFMA(0) SVK_V_MFMA(1) SVK_V_MFMA(2) SVK_V_MFMA(3) SVK_V_MFMA(4) SVK_V_MFMA(5) SVK_V_MFMA(6) SVK_V_MFMA(7)
+#undef SVK_V_MFMA
+      } else {
+        uint4 vr[8];                                  // vr[e] = 8 head dims (i = 0..7) of token 32j + kc*8 + e
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vr[e] = token_v(t0 + 32 * j + kc * 8 + e);
+        const uint32_t* vv = reinterpret_cast<const uint32_t*>(vr);        // vv[e*4 + i/2], half i&1
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          uint32_t vf[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const uint32_t w0 = vv[(2 * e2) * 4 + i / 2], w1 = vv[(2 * e2 + 1) * 4 + i / 2];
+            vf[e2] = (i & 1) ? ((w0 >> 16) | (w1 & 0xffff0000u)) : ((w0 & 0xffffu) | (w1 << 16));
+          }
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag, __builtin_bit_cast(bf16x8_t, make_uint4(vf[0], vf[1], vf[2], vf[3])), acc[i], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- epilogue: lane (n, kc) owns heads kc*4+r and head dims dg*8 .. +8
+  if (kc < JQ) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = kc * 4 + r;
+      if (h < G) {
+        if (n == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = m[r] + __logf(l[r]);
+        if (n < DW) {
+          float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h + dg * 8;
+          const float inv = 1.0f / l[r];
+          *reinterpret_cast<float4*>(o) = make_float4(acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4][r] * inv, acc[5][r] * inv, acc[6][r] * inv, acc[7][r] * inv);
+        }
+      }
+    }
+  }
+}
+
 template <int D>
 int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
   const int G = a.num_q_heads / a.num_kv_heads;
   const int nblk = (a.max_len_in_batch + a.block_seq - 1) / a.block_seq;
   dim3 grid(nblk, a.batch), block(64 * a.num_kv_heads);
   const size_t shm = sizeof(float) * a.num_kv_heads * (kTile * (((G + 3) / 4) * 4) + 16);
+  if (a.group_size == 32) {
+    // 128-token tiles, both products on the matrix cores
+    const size_t shm_t = (size_t)a.num_kv_heads * (16 * 128 * 2 + 2 * (D / 32) * 128 * 2);
+    switch (G) {
+#define SVK_CASE(G_)                                                                                          \
+  case G_:                                                                                                    \
+    if (a.key_param_dtype == SVK_DTYPE_F32) hipLaunchKernelGGL((kivi_stage1_tile128_kernel<D, G_, true>), grid, block, shm_t, s, a); \
+    else hipLaunchKernelGGL((kivi_stage1_tile128_kernel<D, G_, false>), grid, block, shm_t, s, a);            \
+    break;
+      SVK_CASE(1) SVK_CASE(2) SVK_CASE(3) SVK_CASE(4) SVK_CASE(5) SVK_CASE(6) SVK_CASE(7) SVK_CASE(8)
+#undef SVK_CASE
+      default:
+        set_error("svk_kivi_decode_stage1: GQA group size %d unsupported (1..8)", G);
+        return SVK_ERR_LAYOUT;
+    }
+    return check_launch("svk_kivi_decode_stage1");
+  }
   switch (G) {
 #define SVK_CASE(G_)                                                                                     \
   case G_:                                                                                               \

@@ -161,7 +161,9 @@ def test_kivi_stage1_random(Hq, Hkv, D, G, block_seq, with_score, key_f32):
 
 
 def test_kivi_stage1_all_raw_matches_plain_stage1():
-    """With no KIVI block the kernel is the ordinary slot-table decode: compare with svk_flash_decode_stage1."""
+    """With no KIVI block the kernel is the ordinary slot-table decode: compare with svk_flash_decode_stage1.
+    The two kernels tile the row differently (128 vs 32 tokens per online-softmax step), so P is rounded to bf16
+    against different running maxima: partials agree to bf16 precision of P (2^-9 relative per term), not bitwise."""
     from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import flash_decode_stage1
     rng = np.random.default_rng(5)
     B, Hq, Hkv, D, G, block_seq = 3, 28, 4, 128, 32, 64
@@ -177,7 +179,7 @@ def test_kivi_stage1_all_raw_matches_plain_stage1():
     torch.cuda.synchronize()
     vb = valid_blocks(lens, block_seq, nblk)
     for b in range(B):
-        np.testing.assert_allclose(mid[b][:, vb[b]], mid2.cpu().numpy()[b][:, vb[b]], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(mid[b][:, vb[b]], mid2.cpu().numpy()[b][:, vb[b]], rtol=5e-3, atol=5e-3)
         np.testing.assert_allclose(lse[b][:, vb[b]], lse2.cpu().numpy()[b][:, vb[b]], rtol=1e-6, atol=1e-6)
 
 
