@@ -429,16 +429,25 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     unsigned tvmask = 0xffu;                          // bit i: token 8n+i of this lane's column is valid
+    uint32_t vsw[NG], vmw[NG];                        // V scale / min words of tokens 2*lane, 2*lane+1 (fast tiles)
+    uint32_t vq[2][8];                                // V words of block j (double buffered)
+    auto issue_v = [&](int j, uint32_t (&vw8)[8]) {
+      const int vb = __shfl(gb, 4 * j + kc, 64), vlt = __shfl(glt, 4 * j + kc, 64);
+      const int32_t* vw = a.value_packed + ((((int64_t)vb * Hkv + w) * GS + vlt) * DW + dg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vw8[e] = (uint32_t)vw[e * DW];
+    };
     if (fast) {
       const int kb = __shfl(gb, n, 64), klt = __shfl(glt, n, 64);
       const int64_t hb = (int64_t)kb * Hkv + w;
       const int32_t* kw = a.key_packed + (hb * D + kc * 8) * (GS / 8) + (klt >> 3);
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        uint32_t wd[8];
+      // software pipeline: chunk c+1's words / scales are in flight while chunk c is dequantised and multiplied;
+      // the V scale rows and the first V block are requested under the last chunk
+      uint32_t wq[2][8];
+      float scq[2][8], mnq[2][8];
+      auto issue_k = [&](int c, uint32_t (&wd)[8], float (&sc)[8], float (&mn)[8]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) wd[e] = (uint32_t)kw[(c * 32 + e) * (GS / 8)];
-        float sc[8], mn[8];
         if constexpr (KF32) {
           const float* sp = reinterpret_cast<const float*>(a.key_scales) + hb * D + c * 32 + kc * 8;
           const float* mp = reinterpret_cast<const float*>(a.key_mins) + hb * D + c * 32 + kc * 8;
@@ -454,6 +463,29 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
           mn[0] = bf16_lo(mv.x); mn[1] = bf16_hi(mv.x); mn[2] = bf16_lo(mv.y); mn[3] = bf16_hi(mv.y);
           mn[4] = bf16_lo(mv.z); mn[5] = bf16_hi(mv.z); mn[6] = bf16_lo(mv.w); mn[7] = bf16_hi(mv.w);
         }
+      };
+      issue_k(0, wq[0], scq[0], mnq[0]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) {
+          issue_k(c + 1, wq[(c + 1) & 1], scq[(c + 1) & 1], mnq[(c + 1) & 1]);
+        } else {
+          // V scale / min rows of the tile (lane l: tokens 2l, 2l+1) and the first V block
+          const int gsrc = lane >> 2;
+          const int vb = __shfl(gb, gsrc, 64), vlt = __shfl(glt, gsrc, 64) + ((2 * lane) & 7);
+          const int64_t tb = (((int64_t)vb * Hkv + w) * GS + vlt) * NG;
+          if constexpr (NG == 4) {
+            const uint4 s4 = *reinterpret_cast<const uint4*>(a.value_scales + tb), m4 = *reinterpret_cast<const uint4*>(a.value_mins + tb);
+            vsw[0] = s4.x; vsw[1] = s4.y; vsw[2] = s4.z; vsw[3] = s4.w; vmw[0] = m4.x; vmw[1] = m4.y; vmw[2] = m4.z; vmw[3] = m4.w;
+          } else {
+            const uint2 s2 = *reinterpret_cast<const uint2*>(a.value_scales + tb), m2 = *reinterpret_cast<const uint2*>(a.value_mins + tb);
+            vsw[0] = s2.x; vsw[1] = s2.y; vmw[0] = m2.x; vmw[1] = m2.y;
+          }
+          issue_v(0, vq[0]);
+        }
+        const uint32_t (&wd)[8] = wq[c & 1];
+        const float (&sc)[8] = scq[c & 1];
+        const float (&mn)[8] = mnq[c & 1];
         uint32_t lo[8], hi[8];
         float sc16[8];
 #pragma unroll
@@ -533,24 +565,13 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     }
     // ---- V scales / mins of the tile -> LDS [group][token] (fast tiles): lane l covers tokens 2l, 2l+1
     if (fast) {
-      const int gsrc = lane >> 2;                    // group of 8 tokens that holds tokens 2*lane, 2*lane+1
-      const int vb = __shfl(gb, gsrc, 64), vlt = __shfl(glt, gsrc, 64) + ((2 * lane) & 7);
-      const int64_t tb = (((int64_t)vb * Hkv + w) * GS + vlt) * NG;
-      uint32_t sw[NG], mw[NG];                       // [token pair][group] bf16: NG words per tensor (2 tokens x NG groups)
-      if constexpr (NG == 4) {
-        const uint4 s4 = *reinterpret_cast<const uint4*>(a.value_scales + tb), m4 = *reinterpret_cast<const uint4*>(a.value_mins + tb);
-        sw[0] = s4.x; sw[1] = s4.y; sw[2] = s4.z; sw[3] = s4.w; mw[0] = m4.x; mw[1] = m4.y; mw[2] = m4.z; mw[3] = m4.w;
-      } else {
-        const uint2 s2 = *reinterpret_cast<const uint2*>(a.value_scales + tb), m2 = *reinterpret_cast<const uint2*>(a.value_mins + tb);
-        sw[0] = s2.x; sw[1] = s2.y; mw[0] = m2.x; mw[1] = m2.y;
-      }
       // memory order: token 2l: groups 0..NG-1, token 2l+1: groups 0..NG-1 (2 bf16 per word)
 #pragma unroll
       for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const int flat = tk * NG + g;
-          const uint32_t sword = sw[flat >> 1], mword = mw[flat >> 1];
+          const uint32_t sword = vsw[flat >> 1], mword = vmw[flat >> 1];
           Vs[g * kT + 2 * lane + tk] = (uint16_t)((flat & 1) ? (sword >> 16) : (sword & 0xffffu));
           Vm[g * kT + 2 * lane + tk] = (uint16_t)((flat & 1) ? (mword >> 16) : (mword & 0xffffu));
         }
@@ -564,12 +585,11 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       const uint4 pa = *reinterpret_cast<const uint4*>(Pl + n * kT + 32 * j + kc * 8);       // A: head n, tokens 32j + kc*8..
       const bf16x8_t pfrag = __builtin_bit_cast(bf16x8_t, pa);
       if (fast) {
-        const int vb = __shfl(gb, 4 * j + kc, 64), vlt = __shfl(glt, 4 * j + kc, 64);
-        const int32_t* vw = a.value_packed + ((((int64_t)vb * Hkv + w) * GS + vlt) * DW + dg);
+        if (j + 1 < 4) issue_v(j + 1, vq[(j + 1) & 1]);
         uint32_t lo[8], hi[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const uint32_t wd = (uint32_t)vw[e * DW];
+          const uint32_t wd = vq[j & 1][e];
           lo[e] = wd & 0x0f0f0f0fu;
           hi[e] = wd & 0xf0f0f0f0u;
         }
