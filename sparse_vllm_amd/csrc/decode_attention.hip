@@ -660,6 +660,292 @@ decode_stage1_kernel_v2(const SvkFlashDecodeStage1Args a) {
   }
 }
 
+constexpr int kPRow = 40;                          // P tile row stride in bf16 (32 tokens + pad, 16-byte aligned rows)
+constexpr int kPFloats = 16 * kPRow / 2;           // P tile [16][kPRow] bf16 expressed in floats
+
+template <int D, int G>
+struct Stage1V3Lds {
+  // P tile (bf16) + 64 slot ids + Q fragments (NC x 64 lanes x 16 B)
+  static constexpr int WAVE_FLOATS = kPFloats + 64 + Stage1Cfg<D, G>::NC * 64 * 4;
+};
+
+// ---------------------------------------------------------------------------------------
+// v3 = v2's pipeline with P.V on the matrix cores as well: V rows are loaded as 16-byte segments in the B-operand
+// token order (lane (n, jq): 8 head dims n*8.. of tokens jq*8+e) and the 8 MFMAs of a tile pick column
+// "head dim n*8+i" with a byte permute, so the accumulator of a lane is 8 consecutive head dims of 4 heads
+// (32 registers for any GQA group size, no cross-lane reduction in the epilogue).  The vector ALUs are left with
+// the softmax only (v2 spent ~75 % of its VALU issue slots on the P.V FMAs).
+// ---------------------------------------------------------------------------------------
+template <int D, int G, int MODE, bool NTV, bool OFF32>
+__global__ void __launch_bounds__(512)
+decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
+  using C = Stage1Cfg<D, G>;
+  constexpr int NC = C::NC, JQ = C::JQ;
+  constexpr int WF = Stage1V3Lds<D, G>::WAVE_FLOATS;
+  constexpr int DW = D / 8;                       // 16-byte segments per head row
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Hkv = a.num_kv_heads;
+  const int b = blockIdx.y;
+  const int blk = blockIdx.x;
+  const int n = lane & 15;
+  const int jq = lane >> 4;
+  const int dg = n % DW;                           // V: 16-byte segment (8 head dims) of this lane's MFMA column
+  constexpr int score_mode = MODE;
+
+  const int len = a.b_seqlen[b];
+  const int start = blk * a.block_seq;
+  const int end = min(len, start + a.block_seq);
+
+  // per-wave LDS: P tile | 16-float broadcast pad | 2 x 32 slot ids | Q fragments (lane-linear)
+  float* Pw = lds + w * WF;
+  uint16_t* Pl = reinterpret_cast<uint16_t*>(Pw);                 // [16 heads][kPRow] bf16, rows >= G stay zero
+  int* slot_lds = reinterpret_cast<int*>(Pw + kPFloats);
+  uint4* q_lds = reinterpret_cast<uint4*>(Pw + kPFloats + 64);
+  float* spart = lds + Hkv * WF;
+  const int SP = Hkv * JQ;
+
+  float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)blk * a.mid_o_stride_s;
+  float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + blk;
+
+  if (end <= start) {
+    for (int h = 0; h < G; ++h) {
+      float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h;
+      for (int d = lane; d < D; d += 64) o[d] = 0.f;
+      if (lane == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = -INFINITY;
+    }
+    return;
+  }
+
+  const int32_t* row = a.req_to_tokens + (int64_t)a.b_req_idx[b] * a.req_stride;
+  // Byte addressing.  OFF32: the whole K (V) tensor spans < 4 GiB, so a row address is the
+  // wave-uniform tensor base (SGPR pair) + a 32-bit per-lane byte offset: one VGPR per address
+  // and 32-bit integer math instead of 64-bit (frees ~20 VGPRs in the pipelined loop).
+  const char* const kt = reinterpret_cast<const char*>(a.k_cache);
+  const char* const vt = reinterpret_cast<const char*>(a.v_cache);
+  const int64_t slot_bytes = a.kv_slot_stride * 2;
+  const int64_t k_lane_bytes = ((int64_t)w * a.kv_head_stride + jq * 8) * 2;
+  const int64_t v_lane_bytes = ((int64_t)w * a.kv_head_stride + dg * 8) * 2;
+  auto k_ptr = [&](int slot) -> const char* {
+    if (OFF32) return kt + (size_t)((uint32_t)slot * (uint32_t)slot_bytes + (uint32_t)k_lane_bytes);
+    return kt + (int64_t)slot * slot_bytes + k_lane_bytes;
+  };
+  auto v_ptr = [&](int slot) -> const char* {
+    if (OFF32) return vt + (size_t)((uint32_t)slot * (uint32_t)slot_bytes + (uint32_t)v_lane_bytes);
+    return vt + (int64_t)slot * slot_bytes + v_lane_bytes;
+  };
+  const float sm_scale = rsqrtf((float)D);
+
+  // slot ids of one 32-token tile: lanes 0..31 fetch row[t0 + lane] (one coalesced 128 B read)
+  // (index clamped to the last valid token: always a legal, branch-free load - a conditional
+  //  load would make the compiler's vmcnt bookkeeping conservative for the whole tile body)
+  auto fetch_slots = [&](int t0) -> int { return row[(uint32_t)min(t0 + (lane_id_fresh() & 31), end - 1)]; };
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // ---- prologue
+  for (int i = lane; i < kPFloats; i += 64) Pw[i] = 0.f;
+  {
+    const int s0 = fetch_slots(start);
+    if (lane < 32) slot_lds[lane] = s0;
+    const uint16_t* qp = a.q + (int64_t)b * a.q_stride_b + (int64_t)(w * G + n) * a.q_stride_h + jq * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (n < G) t = *reinterpret_cast<const uint4*>(qp + c * 32);
+      q_lds[c * 64 + lane] = t;
+    }
+  }
+  int s_next = fetch_slots(start + kTileTokens);     // slot ids of tile 1, parked in a register
+  wave_sync();
+  uint4 kr[2][NC];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const char* kp = k_ptr(slot_lds[g * 16 + n]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) kr[g][c] = ld16<false>(kp + c * 64);
+  }
+
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+  f32x4_t acc[8];                                  // acc[i][r]: head jq*4+r, head dim dg*8+i
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int c0 = start;     // first token of the current score chunk
+  int buf = 0;        // slot_lds half holding the current tile's ids
+  int t0 = start;
+  // One tile.  HAS_NEXT is a compile-time flag (the last tile is peeled) so that the K(i+1)
+  // re-arm is straight-line code: behind a run-time branch the compiler must assume the loads
+  // may not have been issued and turns every later vmcnt(N) into a wait for K(i+1) itself.
+  auto tile = [&](auto has_next_c) {
+    constexpr bool has_next = decltype(has_next_c)::value;
+    const bool full = has_next || (t0 + kTileTokens <= end);
+    const int* cur_slots = slot_lds + buf * 32;
+    int* nxt_slots = slot_lds + (buf ^ 1) * 32;
+
+    // ---- V(i) loads (slot ids from LDS)
+    uint4 vr[8];                                   // vr[e] = dims dg*8.. of token jq*8+e (the k index of P.V)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      vr[e] = ld16<NTV>(v_ptr(cur_slots[jq * 8 + e]));
+
+    // ---- publish tile i+1's slot ids (fetched one iteration ago), fetch tile i+2's
+    {
+      const int ln = lane_id_fresh();
+      if (ln < 32) nxt_slots[ln] = s_next;
+    }
+    s_next = fetch_slots(t0 + 2 * kTileTokens);
+
+    // ---- S = Q K^T on K(i)
+    f32x4_t s[2];
+    {
+      bf16x8_t qa[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) qa[c] = __builtin_bit_cast(bf16x8_t, q_lds[c * 64 + lane]);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        s[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          s[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, kr[g][c]), s[g], 0, 0, 0);
+      }
+    }
+    wave_sync();        // nxt_slots visible to every lane of this wave
+    // ---- K registers are dead: re-arm them with K(i+1)
+    if constexpr (has_next) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const char* kp = k_ptr(nxt_slots[g * 16 + n]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) kr[g][c] = ld16<false>(kp + c * 64);
+      }
+    }
+
+    bool tv[2];
+    tv[0] = full || (t0 + n < end);
+    tv[1] = full || (t0 + 16 + n < end);
+
+    if constexpr (score_mode == SVK_SCORE_PERHEAD) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int h = jq * 4 + r;
+          if (h < G && tv[g])
+            a.attn_score[(int64_t)b * a.score_stride_b + (int64_t)(w * G + h) * a.score_stride_h + t0 + g * 16 + n] = s[g][r];
+        }
+    } else if constexpr (score_mode == SVK_SCORE_HEADMAX) {
+      if (jq < JQ) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          float pm = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (jq * 4 + r < G) pm = fmaxf(pm, s[g][r]);
+          spart[(t0 - c0 + g * 16 + n) * SP + w * JQ + jq] = tv[g] ? pm : -INFINITY;
+        }
+      }
+    }
+
+    float p[2][4];
+    float alpha[4];
+    bool rescale = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool hv = (jq * 4 + r < G);
+      const float x0 = (hv && tv[0]) ? s[0][r] * sm_scale : -INFINITY;
+      const float x1 = (hv && tv[1]) ? s[1][r] * sm_scale : -INFINITY;
+      const float tmax = row16_allmax(fmaxf(x0, x1));
+      const float nm = fmaxf(m[r], tmax);
+      if (hv) {
+        alpha[r] = __expf(m[r] - nm);
+        p[0][r] = __expf(x0 - nm);
+        p[1][r] = __expf(x1 - nm);
+        rescale |= (nm != m[r]);
+      } else {
+        alpha[r] = 1.f; p[0][r] = 0.f; p[1][r] = 0.f;
+      }
+      l[r] = l[r] * alpha[r] + row16_allsum(p[0][r] + p[1][r]);
+      m[r] = hv ? nm : m[r];
+    }
+
+    if (jq < JQ) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pl[(jq * 4 + r) * kPRow + g * 16 + n] = (uint16_t)f32_to_bf16_bits(p[g][r]);
+    }
+    if (__any(rescale)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] *= alpha[r];
+    }
+    wave_sync();
+
+    // P.V on the matrix cores: A = P [head n][tokens jq*8 .. +8] (one 16-byte LDS row read), B column n of MFMA i
+    // = head dim dg*8+i, whose 8 k-values are the i-th halves of the 8 loaded 16-byte V segments.
+    {
+      const bf16x8_t pfrag = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Pl + n * kPRow + jq * 8));
+      const uint32_t* vv = reinterpret_cast<const uint32_t*>(vr);            // vv[e * 4 + i / 2]
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        uint32_t vf[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2)
+          vf[e2] = __builtin_amdgcn_perm(vv[(2 * e2 + 1) * 4 + i / 2], vv[(2 * e2) * 4 + i / 2], (i & 1) ? 0x07060302u : 0x05040100u);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag, __builtin_bit_cast(bf16x8_t, make_uint4(vf[0], vf[1], vf[2], vf[3])), acc[i], 0, 0, 0);
+      }
+    }
+    wave_sync();
+
+    // ---- end of a score chunk (or of the block): one owner thread per token column
+    if (score_mode == SVK_SCORE_HEADMAX && (!has_next || (t0 + kTileTokens - c0) == kScoreChunk)) {
+      const int c1 = min(end, t0 + kTileTokens);
+      __syncthreads();
+      float* const dst = a.attn_score + (int64_t)b * a.score_stride_b + c0;     // wave-uniform base
+      for (uint32_t t = threadIdx.x; t < (uint32_t)(c1 - c0); t += blockDim.x) {
+        float mx = -INFINITY;
+        for (int j = 0; j < SP; ++j) mx = fmaxf(mx, spart[t * SP + j]);
+        dst[t] = fmaxf(dst[t], mx);
+      }
+      __syncthreads();
+      c0 = t0 + kTileTokens;
+    }
+    t0 += kTileTokens;
+    buf ^= 1;
+  };
+  while (t0 + kTileTokens < end) tile(std::true_type{});
+  tile(std::false_type{});
+
+  // ---- epilogue: lane (n, jq) owns heads jq*4+r and head dims dg*8 .. +8.  The lane id is laundered through an
+  // empty asm so that none of the output addresses can be hoisted above the tile loop.
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int n_e = lane_e & 15, jq_e = lane_e >> 4;
+  if (jq_e < JQ) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = jq_e * 4 + r;
+      if (h < G) {
+        if (n_e == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = m[r] + __logf(l[r]);
+        if (n_e < DW) {
+          float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h + (n_e % DW) * 8;
+          *reinterpret_cast<float4*>(o) = make_float4(acc[0][r] / l[r], acc[1][r] / l[r], acc[2][r] / l[r], acc[3][r] / l[r]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4][r] / l[r], acc[5][r] / l[r], acc[6][r] / l[r], acc[7][r] / l[r]);
+        }
+      }
+    }
+  }
+}
+
 template <int D>
 __global__ void __launch_bounds__(256)
 decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
@@ -719,27 +1005,39 @@ int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
   dim3 grid(nblk, a.batch);
   dim3 block(64 * a.num_kv_heads);
   const size_t score_floats = a.score_mode == SVK_SCORE_HEADMAX ? (size_t)kScoreChunk * a.num_kv_heads * C::JQ : 0;
-  const size_t shm1 = sizeof(float) * ((size_t)a.num_kv_heads * C::WAVE_FLOATS + score_floats);
-  const size_t shm2 = sizeof(float) * ((size_t)a.num_kv_heads * Stage1V2Lds<D, G>::WAVE_FLOATS + score_floats);
-  if constexpr (G == 8) {
-    // 64 accumulator registers per lane do not fit the pipelined loop at 2 waves/SIMD without
-    // spilling; group size 8 keeps the un-pipelined kernel.
-    (void)shm2;
+  const size_t shm3 = sizeof(float) * ((size_t)a.num_kv_heads * Stage1V3Lds<D, G>::WAVE_FLOATS + score_floats);
+  // 32-bit row offsets whenever the caller tells us the KV tensors span < 4 GiB
+  const bool off32 = a.kv_num_slots > 0 && (a.kv_num_slots * a.kv_slot_stride * 2) < (int64_t)0xffffffffll;
+  static const int variant = getenv("SVK_STAGE1_VARIANT") ? atoi(getenv("SVK_STAGE1_VARIANT")) : 3;   // 1/2: earlier kernels (A/B runs)
+  if (variant == 1 || (variant == 2 && G == 8)) {
+    const size_t shm1 = sizeof(float) * ((size_t)a.num_kv_heads * C::WAVE_FLOATS + score_floats);
     hipLaunchKernelGGL((decode_stage1_kernel_v1<D, G>), grid, block, shm1, stream, a);
-  } else {
-    (void)shm1;
-    // 32-bit row offsets whenever the caller tells us the KV tensors span < 4 GiB
-    const bool off32 = a.kv_num_slots > 0 && (a.kv_num_slots * a.kv_slot_stride * 2) < (int64_t)0xffffffffll;
+    return check_launch("svk_flash_decode_stage1");
+  }
+  if (variant == 2) {
+    if constexpr (G != 8) {
+      const size_t shm2 = sizeof(float) * ((size_t)a.num_kv_heads * Stage1V2Lds<D, G>::WAVE_FLOATS + score_floats);
 #define SVK_LAUNCH_V2(MODE_)                                                                                      \
   do {                                                                                                            \
     if (off32) hipLaunchKernelGGL((decode_stage1_kernel_v2<D, G, MODE_, true, true>), grid, block, shm2, stream, a);  \
     else hipLaunchKernelGGL((decode_stage1_kernel_v2<D, G, MODE_, true, false>), grid, block, shm2, stream, a);       \
   } while (0)
-    if (a.score_mode == SVK_SCORE_HEADMAX) SVK_LAUNCH_V2(SVK_SCORE_HEADMAX);
-    else if (a.score_mode == SVK_SCORE_PERHEAD) SVK_LAUNCH_V2(SVK_SCORE_PERHEAD);
-    else SVK_LAUNCH_V2(SVK_SCORE_NONE);
+      if (a.score_mode == SVK_SCORE_HEADMAX) SVK_LAUNCH_V2(SVK_SCORE_HEADMAX);
+      else if (a.score_mode == SVK_SCORE_PERHEAD) SVK_LAUNCH_V2(SVK_SCORE_PERHEAD);
+      else SVK_LAUNCH_V2(SVK_SCORE_NONE);
 #undef SVK_LAUNCH_V2
+    }
+    return check_launch("svk_flash_decode_stage1");
   }
+#define SVK_LAUNCH_V3(MODE_)                                                                                      \
+  do {                                                                                                            \
+    if (off32) hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, true>), grid, block, shm3, stream, a);  \
+    else hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, false>), grid, block, shm3, stream, a);       \
+  } while (0)
+  if (a.score_mode == SVK_SCORE_HEADMAX) SVK_LAUNCH_V3(SVK_SCORE_HEADMAX);
+  else if (a.score_mode == SVK_SCORE_PERHEAD) SVK_LAUNCH_V3(SVK_SCORE_PERHEAD);
+  else SVK_LAUNCH_V3(SVK_SCORE_NONE);
+#undef SVK_LAUNCH_V3
   return check_launch("svk_flash_decode_stage1");
 }
 
