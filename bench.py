@@ -166,7 +166,12 @@ def main():
 
     if not args.no_graph:
         drv.enable_decode_graph()
-    warmup = max(args.warmup, 2 if not args.no_graph else 0)   # graph capture happens in warm-up step 2
+    # priming (part of setup, untimed): one full eviction interval, so that the first burst's one-time costs (code
+    # object load of the selection / compaction kernels, first-use allocations: ~45 ms) are not billed to the K timed
+    # steps.  The timed region still contains its bursts (one per 128 steps per sequence) at steady-state cost.
+    for _ in range(int(conf.h2o_decode_eviction_interval) + 2):
+        drv.step(q, k, v)
+    warmup = max(args.warmup, 2 if not args.no_graph else 0)   # graph capture happens in the first steps
     for _ in range(warmup):
         drv.step(q, k, v)
     barrier()
@@ -213,7 +218,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic,
-            "kernel": "decode_stage1_kernel_v2<128,7,HEADMAX> (scored GQA split-KV decode)",
+            "kernel": "decode_stage1_kernel_v3<128,7,HEADMAX> (scored GQA split-KV decode)",
             "launches_timed": n_launch, "avg_launch_us": ms_total * 1e3 / n_launch,
             "timing": (f"{args.event_steps} eagerly launched steps continue the timed region; after each, its 28 "
                        "stage-1 launches are re-issued back to back on the same data between one pair of HIP "

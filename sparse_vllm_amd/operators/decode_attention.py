@@ -50,15 +50,15 @@ class DefaultDecodeLaunchProvider(DecodeAttentionLaunchProvider):
 class Mi355xDecodeLaunchProvider(DecodeAttentionLaunchProvider):
     """BLOCK_SEQ for the HIP stage-1 kernel on MI355X.
 
-    The kernel runs one workgroup (= Hkv waves) per (batch lane, BLOCK_SEQ block) and two
-    workgroups are resident per CU (2 waves/SIMD).  Measured at B=64, L=4224 (profiles/):
-    544-token blocks (512 workgroups = exactly one resident wave of the grid) reach 6.07 TB/s,
-    272 -> 5.5, 256 -> 5.1, 128 -> 4.3: fewer, longer blocks amortise the per-block prologue /
-    epilogue and the stage-2 partials, as long as every CU still has its two workgroups.  So:
-    the largest 16-aligned BLOCK_SEQ that still yields >= RESIDENT_WORKGROUPS blocks."""
+    The kernel runs one workgroup (= Hkv waves) per (batch lane, BLOCK_SEQ block); up to three workgroups are
+    resident per CU (154 VGPRs -> 3 waves/SIMD).  Measured at L=4224 (tools/kbench.py, stage-1 v3):
+      B=64: 1056 -> 83.8 us, 528 -> 85.5, 352 -> 86.4, 272 -> 92.7, 192 -> 101.2, 2112 -> 118.8
+      B=32:  528 -> 45.7 us, 272 -> 47.6, 176 -> 46.6        B=16: 352 -> 26.8 us, 272 -> 27.2, 528 -> 33.1
+    Fewer, longer blocks amortise the per-block prologue / epilogue and the stage-2 partials as long as every CU
+    still owns a workgroup.  So: the largest 16-aligned BLOCK_SEQ that still yields >= one block per CU."""
     name = "mi355x_hip"
     priority = 100
-    RESIDENT_WORKGROUPS = 512       # 256 CUs x 2 workgroups
+    RESIDENT_WORKGROUPS = 256       # one workgroup per CU
     MIN_BLOCK_SEQ = 64
 
     def supports(self, spec, caps):

@@ -21,14 +21,16 @@ def main():
     ap.add_argument("--len", type=int, default=4224)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--modes", default="2,0")
+    ap.add_argument("--layers", type=int, default=6, help="distinct K/V sets cycled through (defeats the 256 MB MALL)")
     args = ap.parse_args()
     d = torch.device("cuda:0")
     Hq, Hkv, D, L = 28, 4, 128, args.len
     torch.manual_seed(20260625)
     for B in [int(x) for x in args.batches.split(",")]:
         slots = B * L + 4096
-        kc = (torch.randn(slots, Hkv, D, device=d) * 0.3).bfloat16()
-        vc = (torch.randn(slots, Hkv, D, device=d) * 0.3).bfloat16()
+        kcs = [(torch.randn(slots, Hkv, D, device=d) * 0.3).bfloat16() for _ in range(args.layers)]
+        vcs = [(torch.randn(slots, Hkv, D, device=d) * 0.3).bfloat16() for _ in range(args.layers)]
+        it = [0]
         q = (torch.randn(B, Hq, D, device=d) * 0.3).bfloat16()
         perm = torch.randperm(slots, device=d)[: B * L].to(torch.int32).view(B, L)
         req = torch.zeros(B, L + 128, dtype=torch.int32, device=d)
@@ -43,6 +45,8 @@ def main():
             o = torch.empty_like(q)
             for mode in [int(x) for x in args.modes.split(",")]:
                 def run():
+                    kc, vc = kcs[it[0] % args.layers], vcs[it[0] % args.layers]
+                    it[0] += 1
                     if mode == 2:
                         flash_decode_stage1_with_score(q, kc, vc, req, bidx, blen, L, mid, lse, score, bs)
                     else:
