@@ -509,6 +509,75 @@ typedef struct SvkDeltakvMaterializeArgs {
 } SvkDeltakvMaterializeArgs;
 int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeArgs* a, svk_stream_t stream);
 
+/* ---- DeltaKV compression side -------------------------------------------------------------- */
+
+/* Grouped quantise + pack of residual rows: per group scale = (max - min) / (2^bits - 1) stored in the data dtype,
+ * q = round_half_even(clamp((x - min) / (scale + 1e-6), 0, 2^bits - 1)) with the reference kernel's rounding points
+ * (max/min/scale in fp32, `x - min` in the data dtype, quotient in fp32), codes LSB-first in int32.  Output row r goes
+ * to row dst_rows[r] (or r when NULL) of code / scale / mn - the `cache[l, latent_slots] = ...` stores fused in.
+ * Replaces triton_quantize_and_pack_2d_int4_grouped, kernels/triton/quant.py:29-117 (caller _store_residual,
+ * engine/cache_manager/deltakv_less_memory.py:2157-2179). */
+typedef struct SvkQuantPackArgs {
+  const void* data;           /* [rows, features] (data_dtype, data_stride)      */
+  const int32_t* dst_rows;    /* NULL or [rows]                                  */
+  int32_t* code;              /* [*, features*bits/32] (code_stride)             */
+  void* scale;                /* [*, features/group] (data_dtype, scale_stride)  */
+  void* mn;
+  int64_t data_stride, code_stride, scale_stride;
+  int32_t rows, features, bits, group_size, data_dtype;
+} SvkQuantPackArgs;
+int svk_quantize_pack_grouped(const SvkQuantPackArgs* a, svk_stream_t stream);
+
+/* KIVI-int4 block store: for block j the G = group_size tokens at cache rows raw_slots[j, 0..G) are quantised
+ * per channel (K: one scale/min per (head, dim) over the block's tokens) and per token (V: one scale/min per
+ * (token, group of G dims)) with torch's bf16 arithmetic (every op rounds), and written to block block_slots[j].
+ * Replaces _store_full_layer_kivi_blocks, engine/cache_manager/deltakv_less_memory.py:1741-1780
+ * (triton_quantize_and_pack_along_last_dim, kernels/triton/quant.py:264-301) including the gather at :3544-3545. */
+typedef struct SvkKiviStoreArgs {
+  const uint16_t* k_cache;      /* [slots, Hkv, D] bf16 (kv_slot_stride / kv_head_stride) */
+  const uint16_t* v_cache;
+  const int32_t* raw_slots;     /* [blocks, G]                                        */
+  const int32_t* block_slots;   /* [blocks]                                           */
+  int32_t* key_packed;          /* [*, Hkv, D, G/8]                                   */
+  void* key_scales;             /* [*, Hkv, D] f32 or bf16 (key_param_dtype)          */
+  void* key_mins;
+  int32_t* value_packed;        /* [*, Hkv, G, D/8]                                   */
+  uint16_t* value_scales;       /* [*, Hkv, G, D/G] bf16                              */
+  uint16_t* value_mins;
+  int64_t kv_slot_stride, kv_head_stride;
+  int32_t blocks, num_kv_heads, head_dim, group_size, key_param_dtype;
+} SvkKiviStoreArgs;
+int svk_kivi_store_blocks(const SvkKiviStoreArgs* a, svk_stream_t stream);
+
+/* Father assignment: per row r the k best columns of scores[r, :m] (best first, lower column on ties), where column
+ * c >= m0 is admissible only if new_center_rel[c - m0] <= row_offset + r (a token only sees the centres of its own
+ * block at or before itself).  Replaces the mask + `scores.topk(k_eff, sorted=False)` of _cluster_compress,
+ * engine/cache_manager/deltakv_less_memory.py:2780-2787.  k <= 8. */
+typedef struct SvkClusterTopkArgs {
+  const void* scores;             /* [rows, m] (score_dtype, score_stride)   */
+  const int32_t* new_center_rel;  /* [m - m0]                                */
+  int32_t* topk;                  /* [rows, k] (topk_stride)                 */
+  int64_t score_stride, topk_stride;
+  int32_t rows, m, m0, k, row_offset, score_dtype;
+} SvkClusterTopkArgs;
+int svk_cluster_topk(const SvkClusterTopkArgs* a, svk_stream_t stream);
+
+/* base[r] = mean over the k father rows of concat(K[slot], V[slot]) (fp32 accumulate, bf16 out): the
+ * `all_centers.gather(...).mean(dim=2)` of _cluster_compress (:2788-2789) / batch_gather_mean
+ * (kernels/triton/deltakv_kernels.py:2268-2301), reading the centre rows straight from the layer's cache.
+ * father = center_slots[topk[r, j]]. */
+typedef struct SvkGatherMeanArgs {
+  const uint16_t* k_cache;        /* [slots, Hkv, D] bf16 */
+  const uint16_t* v_cache;
+  const int32_t* center_slots;    /* [m] slot of every centre column          */
+  const int32_t* topk;            /* [rows, k] column indices (topk_stride)   */
+  uint16_t* base;                 /* [rows, 2*Hkv*D] bf16 (base_stride)       */
+  int32_t* father_slots;          /* NULL or [rows, k_out]: center_slots[topk], padded with the first father */
+  int64_t kv_slot_stride, kv_head_stride, topk_stride, base_stride, father_stride;
+  int32_t rows, k, k_out, num_kv_heads, head_dim;
+} SvkGatherMeanArgs;
+int svk_gather_mean_fathers(const SvkGatherMeanArgs* a, svk_stream_t stream);
+
 /* Decode stage 1 over a full-attention layer whose older tokens are KIVI-int4 blocks and whose newest
  * tokens are raw bf16 rows; optional 3-D raw scores (observation layers).  Same partial format as
  * svk_flash_decode_stage1.  Per token t of row r: raw_slots_map[r,t] >= 0 -> raw row, else block

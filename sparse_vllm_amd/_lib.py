@@ -192,6 +192,30 @@ class SvkDeltakvMaterializeArgs(C.Structure):
                [("temp_slots", _p), ("temp_stride", _i64), ("temp_offset", _i32), ("temp_count", _i32)]
 
 
+class SvkQuantPackArgs(C.Structure):
+    _fields_ = [("data", _p), ("dst_rows", _p), ("code", _p), ("scale", _p), ("mn", _p),
+                ("data_stride", _i64), ("code_stride", _i64), ("scale_stride", _i64),
+                ("rows", _i32), ("features", _i32), ("bits", _i32), ("group_size", _i32), ("data_dtype", _i32)]
+
+
+class SvkKiviStoreArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("k_cache", "v_cache", "raw_slots", "block_slots", "key_packed", "key_scales", "key_mins",
+                                  "value_packed", "value_scales", "value_mins")] + \
+               [("kv_slot_stride", _i64), ("kv_head_stride", _i64)] + \
+               [(n, _i32) for n in ("blocks", "num_kv_heads", "head_dim", "group_size", "key_param_dtype")]
+
+
+class SvkClusterTopkArgs(C.Structure):
+    _fields_ = [("scores", _p), ("new_center_rel", _p), ("topk", _p), ("score_stride", _i64), ("topk_stride", _i64)] + \
+               [(n, _i32) for n in ("rows", "m", "m0", "k", "row_offset", "score_dtype")]
+
+
+class SvkGatherMeanArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("k_cache", "v_cache", "center_slots", "topk", "base", "father_slots")] + \
+               [(n, _i64) for n in ("kv_slot_stride", "kv_head_stride", "topk_stride", "base_stride", "father_stride")] + \
+               [(n, _i32) for n in ("rows", "k", "k_out", "num_kv_heads", "head_dim")]
+
+
 class SvkKiviDecodeStage1Args(C.Structure):
     _fields_ = [(n, _p) for n in ("q", "raw_k", "raw_v", "raw_slots_map", "kivi_block_slots_map", "kivi_block_start_pos",
                                   "key_packed", "key_scales", "key_mins", "value_packed", "value_scales", "value_mins",
@@ -228,6 +252,10 @@ ENTRY_POINTS = {
     "svk_topk_sorted_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),
     "svk_topk_sorted_desc": ([C.POINTER(SvkTopkSortedArgs), _p, _p], C.c_int),
     "svk_deltakv_materialize_sparse_view": ([C.POINTER(SvkDeltakvMaterializeArgs), _p], C.c_int),
+    "svk_quantize_pack_grouped": ([C.POINTER(SvkQuantPackArgs), _p], C.c_int),
+    "svk_kivi_store_blocks": ([C.POINTER(SvkKiviStoreArgs), _p], C.c_int),
+    "svk_cluster_topk": ([C.POINTER(SvkClusterTopkArgs), _p], C.c_int),
+    "svk_gather_mean_fathers": ([C.POINTER(SvkGatherMeanArgs), _p], C.c_int),
     "svk_kivi_decode_stage1": ([C.POINTER(SvkKiviDecodeStage1Args), _p], C.c_int),
     "svk_quest_page_minmax": ([C.POINTER(SvkQuestPageMinmaxArgs), _p], C.c_int),
     "svk_quest_score_pages": ([C.POINTER(SvkQuestScorePagesArgs), _p], C.c_int),

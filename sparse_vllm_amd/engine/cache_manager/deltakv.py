@@ -242,6 +242,9 @@ class DeltaKVCacheManager(CacheManager):
             self.row_full_layer_kivi_quantized_lens = None
         self.row_kivi_blocks: dict[int, list[int]] = {}
         self.row_latent_slots: dict[int, np.ndarray] = {}
+        # sink ++ every centre slot chosen so far, per row (row_deltakv_center_slots, identical for all sparse layers
+        # because slot ids are shared between them; deltakv_less_memory.py:3660-3667, :3750-3753)
+        self.row_deltakv_center_slots: dict[int, torch.Tensor] = {}
 
     def _init_compressor_modules(self, config):
         """deltakv_less_memory.py:1190-1199; weights come from `deltakv_path` in the reference (external
@@ -386,6 +389,7 @@ class DeltaKVCacheManager(CacheManager):
             fslots = np.where(fidx >= 0, fslots, fslots[..., :1])
             self.deltakv_latent_to_full_slots[:, lat_gpu.long()] = torch.from_numpy(fslots.astype(np.int32)).to(d)
             self.row_latent_slots[row] = lat
+            self.row_deltakv_center_slots[row] = torch.from_numpy(center_slots.astype(np.int32)).to(d)
         # full layers: KIVI blocks cover [sink, quant_end) (deltakv_less_memory.py:3495-3558); the rest stays raw
         qend = int(kivi_quantized_end) if self._full_layer_kivi_enabled() else 0
         qstart = min(sink, total_len)
@@ -441,8 +445,8 @@ class DeltaKVCacheManager(CacheManager):
                 raise RuntimeError(f"KV row length exceeds max_model_len in DeltaKV decode: max_cur_len={int(cur.max())}")
             buf = cur - int(self.config.num_sink_tokens) - self.row_deltakv_compressed_lens[rows]
             if int(buf.max()) + 1 > self._deltakv_decode_static_max_buffer():
-                raise RuntimeError("DeltaKV raw tail exceeds the static decode buffer; the compression side "
-                                   "(deltakv_evict, SURVEY 8(f).3) must run before more tokens are decoded: "
+                raise RuntimeError("DeltaKV raw tail exceeds the static decode buffer; deltakv_evict (the compression "
+                                   "side) must run after every forward (SparseController.post_forward): "
                                    f"tail={int(buf.max()) + 1} max_buffer={self._deltakv_decode_static_max_buffer()}.")
             full_slots = self._pool_full.pop(B)
             sparse_slots = self._pool_sparse.pop(B)
@@ -510,6 +514,7 @@ class DeltaKVCacheManager(CacheManager):
         lat = self.row_latent_slots.pop(row, None)
         if lat is not None:
             self._pool_latent.push(lat)
+        self.row_deltakv_center_slots.pop(row, None)
         blocks = self.row_kivi_blocks.pop(row, None)
         if blocks:
             self._pool_kivi.push(np.asarray(blocks, dtype=np.int32))
@@ -726,3 +731,175 @@ class DeltaKVCacheManager(CacheManager):
     def release_layer_temp_slots(self, layer_idx: int, temp_slots):
         """Static decode keeps its reconstruct scratch for the life of the graph (deltakv_less_memory.py:449-470)."""
         return None
+
+    # ------------------------------------------------------------------ compression side (SURVEY section 8 a26)
+    def _deltakv_base_cluster_step(self) -> int:
+        """deltakv_base.py:255-260."""
+        ratio = float(self.config.cluster_ratio or 0.0)
+        if ratio <= 0.0:
+            raise ValueError(f"DeltaKV cluster_ratio must be > 0, got {ratio}.")
+        return max(1, int(1.0 / max(1e-6, ratio)))
+
+    @staticmethod
+    def _metric_l2(kv_states: torch.Tensor, all_centers: torch.Tensor) -> torch.Tensor:
+        """deltakv_base.py:2168-2190: ranking score 2*dot(a, b) - ||b||^2, the [N, M] matrix kept in bf16 (library GEMM)."""
+        dot = torch.matmul(kv_states, all_centers.transpose(0, 1))
+        b_norm = (all_centers * all_centers).sum(dim=1, dtype=torch.float32).to(dot.dtype)
+        return dot.mul(2.0).sub_(b_norm.unsqueeze(0))
+
+    def _gather_raw_kv_rows(self, l_idx: int, slots: torch.Tensor) -> torch.Tensor:
+        """[n] slots -> [n, 2*Hkv*D] concat(K_raw, V) rows of sparse layer l_idx (deltakv_less_memory.py:2708-2717)."""
+        half = self.num_kv_heads * self.head_dim
+        idx = slots.long()
+        return torch.cat((self.deltakv_full_kv_cache[0, l_idx, idx].reshape(-1, half),
+                          self.deltakv_full_kv_cache[1, l_idx, idx].reshape(-1, half)), dim=-1)
+
+    def _cluster_compress(self, l_idx: int, kv_block: torch.Tensor, all_center_slots: torch.Tensor, m0: int,
+                          new_center_rel: torch.Tensor):
+        """deltakv_less_memory.py:2719-2802: -> (father slots [n, K] int32, base_kv [n, kv_dim] bf16).  The centre rows
+        are gathered once for the ranking GEMM; top-k with the causal mask over the block's own centres and the mean of
+        the father rows are HIP kernels that read the layer cache directly."""
+        k_neighbors = int(self.config.deltakv_k_neighbors)
+        m = int(all_center_slots.numel())
+        if m == 0:
+            raise RuntimeError("DeltaKV less-memory: no available reference centers.")
+        k_eff = min(k_neighbors, m)
+        centers = self._gather_raw_kv_rows(l_idx, all_center_slots)
+        scores = self._metric_l2(kv_block, centers)
+        topk = dk.cluster_topk(scores, m0=m0, new_center_rel=new_center_rel, k=k_eff)
+        base, fathers = dk.gather_mean_fathers(self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx],
+                                               all_center_slots, topk, k_out=k_neighbors)
+        return fathers, base
+
+    def _store_residual(self, l_idx: int, latent_slots: torch.Tensor, residual: torch.Tensor):
+        """deltakv_less_memory.py:2157-2179: int4 group quantise + pack straight into the latent caches."""
+        if latent_slots.numel() != residual.shape[0]:
+            raise RuntimeError("DeltaKV less-memory latent residual store shape mismatch: "
+                               f"slots={int(latent_slots.numel())}, residual_rows={int(residual.shape[0])}.")
+        if int(self.config.kv_quant_bits or 0) == 4:
+            dk.triton_quantize_and_pack_2d_int4_grouped(
+                residual, self._quant_group_size(),
+                out=(self.deltakv_latent_cache[l_idx], self.deltakv_latent_scales[l_idx], self.deltakv_latent_mins[l_idx]),
+                dst_rows=latent_slots)
+        else:
+            self.deltakv_latent_cache[l_idx, latent_slots.long()] = residual.to(self.deltakv_latent_cache.dtype)
+
+    def _deltakv_store_layer_latent(self, *, l_idx: int, latent_slots: torch.Tensor, kv_block: torch.Tensor, base_kv: torch.Tensor):
+        """deltakv_less_memory.py:2181-2240 (store_all): residual = down(kv) - down(base), both through one library GEMM
+        batch when the block is small (:2232-2235)."""
+        down = self.compress_down[l_idx]
+        n = int(kv_block.shape[0])
+        if n <= 1024:
+            enc = down(torch.cat((kv_block, base_kv), dim=0))
+            residual = enc[:n]
+            residual.sub_(enc[n:])
+        else:
+            residual = down(kv_block)
+            residual.sub_(down(base_kv))
+        self._store_residual(l_idx, latent_slots, residual)
+
+    @torch.no_grad()
+    def deltakv_evict(self, seqs):
+        """deltakv_less_memory.py:3602-3780: when a row's raw tail exceeds `recent`, compress whole multiples of `recent`:
+        centres every int(1/cluster_ratio) tokens of the evicted block keep their raw K/V, every evicted token gets a
+        latent residual against the mean of its K nearest (L2) causal centres, non-centre raw slots are released."""
+        with profiler.record("deltakv_less_memory_evict_total"):
+            if not self.deltakv_layer_ids:
+                return
+            d = self.device
+            sink, recent = int(self.config.num_sink_tokens), int(self.config.num_recent_tokens)
+            step = self._deltakv_base_cluster_step()
+            for seq in seqs:
+                row = self.seq_id_to_row.get(seq.seq_id)
+                if row is None:
+                    continue
+                total_len = int(self.row_seq_lens[row])
+                clen = int(self.row_deltakv_compressed_lens[row])
+                start = sink + clen
+                buffer_len = total_len - start
+                if buffer_len <= recent:
+                    continue
+                evict_len = ((buffer_len - recent) // recent) * recent
+                if evict_len <= 0:
+                    continue
+                end = start + evict_len
+                raw_block = self.sparse_layer_raw_slots_map[row, start:end].clone()
+                center_rel_np = np.arange(0, evict_len, step, dtype=np.int32)          # range(start, end, step) - start
+                center_rel = torch.from_numpy(center_rel_np).to(d)
+                new_center_slots = raw_block[center_rel.long()].contiguous()
+                existing = self.row_deltakv_center_slots.get(row)
+                if existing is None:
+                    existing = self.sparse_layer_raw_slots_map[row, :sink].clone()
+                all_centers = torch.cat((existing, new_center_slots)).contiguous()
+                latent_np = self._pool_latent.pop(evict_len)
+                latent_slots = torch.from_numpy(latent_np).to(d)
+                self.sparse_layer_latent_slots_map[row, start:end] = latent_slots
+                prev = self.row_latent_slots.get(row)
+                self.row_latent_slots[row] = latent_np if prev is None else np.concatenate((prev, latent_np))
+                for l_idx in range(len(self.deltakv_layer_ids)):
+                    kv_block = self._gather_raw_kv_rows(l_idx, raw_block)
+                    fathers, base = self._cluster_compress(l_idx, kv_block, all_centers, int(existing.numel()), center_rel)
+                    self.deltakv_latent_to_full_slots[l_idx, latent_slots.long()] = fathers
+                    self._deltakv_store_layer_latent(l_idx=l_idx, latent_slots=latent_slots, kv_block=kv_block, base_kv=base)
+                self.row_deltakv_center_slots[row] = all_centers
+                is_center = np.zeros((evict_len,), dtype=bool)
+                is_center[center_rel_np] = True
+                raw_np = raw_block.cpu().numpy()
+                free_np = raw_np[~is_center]
+                self._pool_sparse.push(free_np)
+                free_gpu = torch.from_numpy(free_np.astype(np.int64)).to(d)
+                self.deltakv_slot_to_pos[free_gpu] = -1
+                pos_free = torch.from_numpy((np.arange(start, end)[~is_center]).astype(np.int64)).to(d)
+                self.sparse_layer_raw_slots_map[row, pos_free] = -1
+                self.row_deltakv_compressed_lens[row] += evict_len
+                self.row_deltakv_compressed_lens_gpu[row] += evict_len
+            self._full_layer_kivi_evict(seqs)
+            self._deltakv_reset_view_cache()
+
+    @torch.no_grad()
+    def _full_layer_kivi_evict(self, seqs):
+        """deltakv_less_memory.py:3495-3558: quantise whole groups of the full layers' raw rows that fell out of the
+        residual window into KIVI blocks and release their raw slots."""
+        if not self._full_layer_kivi_enabled() or not self.full_layer_ids:
+            return
+        d = self.device
+        G = self._full_layer_kivi_group_size()
+        residual_length = int(self.config.full_layer_kivi_residual_length or G)
+        sink = int(self.config.num_sink_tokens)
+        for seq in seqs:
+            row = self.seq_id_to_row.get(seq.seq_id)
+            if row is None:
+                continue
+            total_len = int(self.row_seq_lens[row])
+            quant_rel_end = ((max(0, total_len - sink) - residual_length) // G) * G
+            if quant_rel_end <= 0:
+                continue
+            quant_end = sink + quant_rel_end
+            quant_start = max(sink, int(self.row_full_layer_kivi_quantized_lens[row] or sink))
+            quant_start = sink + (((quant_start - sink) + G - 1) // G) * G
+            if quant_end <= quant_start:
+                continue
+            slots = self.full_layer_slots_map[row, quant_start:quant_end].contiguous()
+            num_blocks = (quant_end - quant_start) // G
+            blocks_np = self._pool_kivi.pop(num_blocks)
+            block_slots = torch.from_numpy(blocks_np).to(d)
+            raw = slots.view(num_blocks, G)
+            for l_idx in range(len(self.full_layer_ids)):
+                dk.kivi_store_blocks(k_cache=self.full_kv_cache[0, l_idx], v_cache=self.full_kv_cache[1, l_idx], raw_slots=raw,
+                                     block_slots=block_slots, key_packed=self.full_layer_kivi_key_packed[l_idx],
+                                     key_scales=self.full_layer_kivi_key_scales[l_idx],
+                                     key_mins=self.full_layer_kivi_key_mins[l_idx],
+                                     value_packed=self.full_layer_kivi_value_packed[l_idx],
+                                     value_scales=self.full_layer_kivi_value_scales[l_idx],
+                                     value_mins=self.full_layer_kivi_value_mins[l_idx], group_size=G)
+            self.full_layer_kivi_block_slots_map[row, quant_start:quant_end] = block_slots.repeat_interleave(G)
+            self.full_layer_kivi_block_start_pos[block_slots.long()] = torch.arange(quant_start, quant_end, G, dtype=torch.int32, device=d)
+            slots_np = slots.cpu().numpy()
+            if (slots_np < 0).any():
+                raise RuntimeError("Full-layer KIVI expects raw full-layer slots for the quantized block.")
+            self._pool_full.push(slots_np)
+            self.full_layer_slot_to_pos[slots.long()] = -1
+            self.full_layer_slots_map[row, quant_start:quant_end] = -1
+            self.row_kivi_blocks.setdefault(row, []).extend(int(x) for x in blocks_np)
+            self.row_full_layer_kivi_quantized_lens[row] = quant_end
+

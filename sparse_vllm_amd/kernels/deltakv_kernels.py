@@ -378,3 +378,116 @@ def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_
         max_len_in_batch=max_len_in_batch, block_seq=block_seq, group_size=group_size,
         key_param_dtype=_dt(key_scales))
     _lib.check(lib.svk_kivi_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# compression side
+# ------------------------------------------------------------------------------------------------------------------
+
+@torch.no_grad()
+def triton_quantize_and_pack_2d_int4_grouped(data, group_size: int, *, out=None, dst_rows=None, bits: int = 4):
+    """kernels/triton/quant.py:79-117 (same ValueErrors).  Extension: `out=(code, scale, mn)` + `dst_rows` write row r of
+    the result to row dst_rows[r] of caller-owned caches (the latent-cache stores of _store_residual fused in)."""
+    if data.dim() != 2:
+        raise ValueError(f"2D int4 quantization expects rank-2 input, got shape={tuple(data.shape)}.")
+    if not data.is_cuda:
+        raise ValueError("2D int4 quantization expects a CUDA tensor.")
+    group_size = int(group_size)
+    if group_size <= 0 or group_size % 8 != 0:
+        raise ValueError(f"2D int4 quantization requires group_size to be a positive multiple of 8, got {group_size}.")
+    n, d = data.shape
+    if d % group_size != 0:
+        raise ValueError(f"2D int4 quantization requires D divisible by group_size, got D={d}, group={group_size}.")
+    if d % 8 != 0:
+        raise ValueError(f"2D int4 quantization requires D divisible by 8, got D={d}.")
+    data = data.contiguous()
+    fpi = 32 // int(bits)
+    if out is None:
+        code = torch.empty((n, d // fpi), device=data.device, dtype=torch.int32)
+        scale = torch.empty((n, d // group_size), device=data.device, dtype=data.dtype)
+        mn = torch.empty_like(scale)
+    else:
+        code, scale, mn = out
+        assert code.dtype == torch.int32 and code.stride(1) == 1 and scale.dtype == data.dtype and mn.dtype == data.dtype
+        assert scale.stride() == mn.stride() and scale.stride(1) == 1
+    if dst_rows is not None:
+        assert dst_rows.dtype == torch.int32 and dst_rows.is_contiguous() and dst_rows.numel() == n
+    lib = _lib.load()
+    a = _lib.SvkQuantPackArgs(data=_lib.ptr(data), dst_rows=_lib.ptr(dst_rows), code=_lib.ptr(code), scale=_lib.ptr(scale),
+                              mn=_lib.ptr(mn), data_stride=data.stride(0), code_stride=code.stride(0),
+                              scale_stride=scale.stride(0), rows=n, features=d, bits=int(bits), group_size=group_size,
+                              data_dtype=_dt(data))
+    _lib.check(lib.svk_quantize_pack_grouped(C.byref(a), _lib.current_stream_handle()), lib)
+    return code, scale, mn
+
+
+@torch.no_grad()
+def kivi_store_blocks(*, k_cache, v_cache, raw_slots, block_slots, key_packed, key_scales, key_mins, value_packed,
+                      value_scales, value_mins, group_size: int):
+    """_store_full_layer_kivi_blocks (deltakv_less_memory.py:1741-1780) with the gather of the block's raw rows
+    (:3544-3545) and the six indexed stores fused: raw_slots [blocks, G] cache rows -> KIVI block block_slots[j]."""
+    assert k_cache.dtype == torch.bfloat16 and k_cache.stride() == v_cache.stride() and k_cache.stride(2) == 1
+    assert raw_slots.dtype == torch.int32 and raw_slots.dim() == 2 and raw_slots.is_contiguous()
+    assert block_slots.dtype == torch.int32 and block_slots.is_contiguous() and block_slots.numel() == raw_slots.shape[0]
+    G = int(group_size)
+    if int(raw_slots.shape[1]) != G:
+        raise ValueError(f"Full-layer KIVI key blocks shape mismatch: got={tuple(raw_slots.shape)} expected=(*, {G}).")
+    H, D = int(k_cache.shape[1]), int(k_cache.shape[2])
+    for t_ in (key_packed, value_packed):
+        assert t_.dtype == torch.int32 and t_.is_contiguous()
+    assert tuple(key_packed.shape[1:]) == (H, D, G // 8) and tuple(value_packed.shape[1:]) == (H, G, D // 8)
+    assert key_scales.dtype in (torch.float32, torch.bfloat16) and key_mins.dtype == key_scales.dtype
+    assert key_scales.is_contiguous() and key_mins.is_contiguous()
+    for t_ in (value_scales, value_mins):
+        assert t_.dtype == torch.bfloat16 and t_.is_contiguous()
+    lib = _lib.load()
+    a = _lib.SvkKiviStoreArgs(k_cache=_lib.ptr(k_cache), v_cache=_lib.ptr(v_cache), raw_slots=_lib.ptr(raw_slots),
+                              block_slots=_lib.ptr(block_slots), key_packed=_lib.ptr(key_packed),
+                              key_scales=_lib.ptr(key_scales), key_mins=_lib.ptr(key_mins),
+                              value_packed=_lib.ptr(value_packed), value_scales=_lib.ptr(value_scales),
+                              value_mins=_lib.ptr(value_mins), kv_slot_stride=k_cache.stride(0),
+                              kv_head_stride=k_cache.stride(1), blocks=int(raw_slots.shape[0]), num_kv_heads=H, head_dim=D,
+                              group_size=G, key_param_dtype=_dt(key_scales))
+    _lib.check(lib.svk_kivi_store_blocks(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+@torch.no_grad()
+def cluster_topk(scores, *, m0: int, new_center_rel, k: int, row_offset: int = 0):
+    """Causal mask over the block's own centres + `topk(k, sorted=False)` of _cluster_compress
+    (deltakv_less_memory.py:2780-2787); returns int32 [rows, k] column indices, best first."""
+    assert scores.dim() == 2 and scores.stride(1) == 1
+    rows, m = scores.shape
+    out = torch.empty((rows, int(k)), dtype=torch.int32, device=scores.device)
+    if new_center_rel is not None:
+        assert new_center_rel.dtype == torch.int32 and new_center_rel.is_contiguous() and new_center_rel.numel() == m - int(m0)
+    else:
+        assert int(m0) == m
+    lib = _lib.load()
+    a = _lib.SvkClusterTopkArgs(scores=_lib.ptr(scores), new_center_rel=_lib.ptr(new_center_rel), topk=_lib.ptr(out),
+                                score_stride=scores.stride(0), topk_stride=out.stride(0), rows=rows, m=m, m0=int(m0),
+                                k=int(k), row_offset=int(row_offset), score_dtype=_dt(scores))
+    _lib.check(lib.svk_cluster_topk(C.byref(a), _lib.current_stream_handle()), lib)
+    return out
+
+
+@torch.no_grad()
+def gather_mean_fathers(k_cache, v_cache, center_slots, topk, *, k_out: int | None = None):
+    """base = mean over fathers of concat(K[slot], V[slot]) (deltakv_less_memory.py:2788-2789, batch_gather_mean
+    deltakv_kernels.py:2268-2301) read from the layer cache; also returns father slots [rows, k_out] padded with
+    the first father (deltakv_less_memory.py:3721-3727)."""
+    assert k_cache.dtype == torch.bfloat16 and k_cache.stride() == v_cache.stride() and k_cache.stride(2) == 1
+    assert center_slots.dtype == torch.int32 and center_slots.is_contiguous()
+    assert topk.dtype == torch.int32 and topk.stride(1) == 1
+    rows, k = topk.shape
+    H, D = int(k_cache.shape[1]), int(k_cache.shape[2])
+    k_out = int(k_out or k)
+    base = torch.empty((rows, 2 * H * D), dtype=torch.bfloat16, device=k_cache.device)
+    fathers = torch.empty((rows, k_out), dtype=torch.int32, device=k_cache.device)
+    lib = _lib.load()
+    a = _lib.SvkGatherMeanArgs(k_cache=_lib.ptr(k_cache), v_cache=_lib.ptr(v_cache), center_slots=_lib.ptr(center_slots),
+                               topk=_lib.ptr(topk), base=_lib.ptr(base), father_slots=_lib.ptr(fathers),
+                               kv_slot_stride=k_cache.stride(0), kv_head_stride=k_cache.stride(1), topk_stride=topk.stride(0),
+                               base_stride=base.stride(0), father_stride=fathers.stride(0), rows=rows, k=k,
+                               k_out=k_out, num_kv_heads=H, head_dim=D)
+    _lib.check(lib.svk_gather_mean_fathers(C.byref(a), _lib.current_stream_handle()), lib)
+    return base, fathers

@@ -714,6 +714,71 @@ def gen_deltakv_view():
     save("deltakv_view", **out)
 
 
+def gen_deltakv_compress():
+    """DeltaKV compression side: residual quantiser (quant.py:29-117), KIVI block quantiser
+    (quant.py:243-301 as used by _store_full_layer_kivi_blocks, deltakv_less_memory.py:1741-1780) and the
+    L2 top-k father assignment `_cluster_compress` (deltakv_less_memory.py:2719-2802).  Low-precision inputs are
+    fp16 (the interpreter cannot do bf16): they pin the per-operation rounding structure, which the oracle / HIP
+    path then apply with bf16 rounding."""
+    import contextlib
+    from sparsevllm.kernels.triton import quant as qk
+    from sparsevllm.engine.cache_manager.deltakv_less_memory import DeltaKVLessMemoryCacheManager as M
+
+    g = torch.Generator().manual_seed(46)
+    out = {}
+    # ---- 2-D grouped int4 residual quantiser, fp32 and fp16 data
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16)):
+        n, d, group = 9, 64, 16
+        data = (torch.randn(n, d, generator=g) * 0.7).to(dt)
+        data[2] = 0.25                                            # constant row: scale 0
+        code = torch.zeros(n, d // 8, dtype=torch.int32)
+        scale = torch.zeros(n, d // group, dtype=dt); mn = torch.zeros(n, d // group, dtype=dt)
+        qk._quantize_pack_2d_int4_grouped_kernel[(n, d // group)](
+            data, code, scale, mn, data.stride(0), data.stride(1), code.stride(0), code.stride(1), scale.stride(0),
+            scale.stride(1), D=d, GROUP_SIZE=group, PACKS_PER_GROUP=group // 8, BLOCK_G=16)
+        out.update({f"q2d_{tag}_data": data.float().numpy(), f"q2d_{tag}_code": code.numpy(),
+                    f"q2d_{tag}_scale": scale.float().numpy(), f"q2d_{tag}_mn": mn.float().numpy()})
+    # ---- KIVI quantiser along the last dim (torch arithmetic + Triton min/max and pack), fp16 data
+    saved = torch.cuda.device
+    torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()
+    try:
+        for tag, dt in (("f16", torch.float16), ("f32", torch.float32)):
+            blocks, H, D, G = 3, 2, 16, 32
+            k = (torch.randn(blocks, G, H, D, generator=g) * 0.6).to(dt)
+            v = (torch.randn(blocks, G, H, D, generator=g) * 0.6).to(dt)
+            ks = k.permute(0, 2, 3, 1).contiguous()
+            pk, sk, mk = qk.triton_quantize_and_pack_along_last_dim(ks, G, 4)
+            vs = v.permute(0, 2, 1, 3).contiguous()
+            pv, sv, mv = qk.triton_quantize_and_pack_along_last_dim(vs, 16, 4)
+            out.update({f"kivi_{tag}_k": k.float().numpy(), f"kivi_{tag}_v": v.float().numpy(),
+                        f"kivi_{tag}_kcode": pk.numpy(), f"kivi_{tag}_kscale": sk.squeeze(-1).float().numpy(),
+                        f"kivi_{tag}_kmn": mk.squeeze(-1).float().numpy(), f"kivi_{tag}_vcode": pv.numpy(),
+                        f"kivi_{tag}_vscale": sv.float().numpy(), f"kivi_{tag}_vmn": mv.float().numpy()})
+    finally:
+        torch.cuda.device = saved
+    # ---- father assignment: L2 ranking score in the storage dtype, causal over the block's own centres, top-k, mean
+    m = object.__new__(M)
+    Hkv, D, slots = 2, 16, 64
+    m.num_kv_heads, m.head_dim, m.device = Hkv, D, torch.device("cpu")
+    m.hf_config = SimpleNamespace(torch_dtype=torch.bfloat16)
+    m.config = SimpleNamespace(deltakv_k_neighbors=3, cluster_metric="l2", deltakv_cluster_gather_chunk_size=16384)
+    m.deltakv_layer_to_idx = {1: 0}
+    m.deltakv_full_kv_cache = (torch.randn(2, 1, slots, Hkv, D, generator=g) * 0.5).to(torch.bfloat16)
+    m.deltakv_slot_to_pos = torch.arange(slots, dtype=torch.int32)
+    m._is_stream_capturing = lambda: False
+    m._prefill_pre_rope_stage_active = lambda: False
+    n = 24
+    kv = (torch.randn(1, n, 2 * Hkv * D, generator=g) * 0.5).to(torch.bfloat16)
+    existing = torch.tensor([3, 9, 17, 40, 41], dtype=torch.int32)
+    rel = torch.tensor([0, 6, 12, 18], dtype=torch.long)
+    topk, base = m._cluster_compress(layer_idx=1, kv_states=kv, existing_center_slots=existing, cluster_step=6,
+                                     new_center_rel=rel, validate_centers=False)
+    out.update(cc_cache_k=bits(m.deltakv_full_kv_cache[0, 0].float()), cc_cache_v=bits(m.deltakv_full_kv_cache[1, 0].float()),
+               cc_kv=bits(kv[0].float()), cc_existing=existing.numpy(), cc_rel=rel.numpy().astype(np.int32),
+               cc_topk=topk.numpy(), cc_base=bits(base[0].float()), cc_k=np.array([3], dtype=np.int64))
+    save("deltakv_compress", **out)
+
+
 GROUPS = {
     "decode": gen_decode,
     "h2o_select": gen_h2o_select,
@@ -725,6 +790,7 @@ GROUPS = {
     "deltakv": gen_deltakv,
     "kivi": gen_kivi,
     "deltakv_view": gen_deltakv_view,
+    "deltakv_compress": gen_deltakv_compress,
 }
 
 

@@ -70,40 +70,46 @@ def test_deltakv_decode_steps_match_oracle(cfg):
     max_buffer = cm._deltakv_decode_static_max_buffer()
     assert max_buffer == 2 * recent
 
-    # ---- mirror of the device caches
-    full_k, full_v = f32(cm.full_kv_cache[0]).copy(), f32(cm.full_kv_cache[1]).copy()
-    sp_k, sp_v = f32(cm.deltakv_full_kv_cache[0]).copy(), f32(cm.deltakv_full_kv_cache[1]).copy()
-    cos_sin = cm.cos_sin_cache.cpu().numpy()
-    lat_map = cm.sparse_layer_latent_slots_map.cpu().numpy()
-    fathers = cm.deltakv_latent_to_full_slots.cpu().numpy()
-    if cfg["bits"]:
-        lat_code = cm.deltakv_latent_cache.cpu().numpy()
-        lat_scale, lat_mn = f32(cm.deltakv_latent_scales), f32(cm.deltakv_latent_mins)
-    else:
-        lat_dense = f32(cm.deltakv_latent_cache)
-    clens = cm.row_deltakv_compressed_lens[rows].copy()
-    if cfg["kivi"]:
-        kv = {n: getattr(cm, f"full_layer_kivi_{n}") for n in ("key_packed", "key_scales", "key_mins", "value_packed",
-                                                                "value_scales", "value_mins")}
-        kv = {n: (t.cpu().numpy() if t.dtype in (torch.int32, torch.float32) else f32(t)) for n, t in kv.items()}
-        blk_map = cm.full_layer_kivi_block_slots_map.cpu().numpy()
-        blk_start = cm.full_layer_kivi_block_start_pos.cpu().numpy()
-
     outs = torch.zeros((L, B, Hq, D), dtype=torch.bfloat16, device=drv.device)
-    for step in range(6):                       # the raw tail grows from `recent` towards 2*recent (no compression yet)
+    n_evictions = 0
+    for step in range(cfg.get("steps", 28)):    # the raw tail cycles recent .. 2*recent: a compression every `recent` steps
+        # ---- mirror of the device state before the step (compression at the end of the previous step changed it)
+        full_k, full_v = f32(cm.full_kv_cache[0]).copy(), f32(cm.full_kv_cache[1]).copy()
+        sp_k, sp_v = f32(cm.deltakv_full_kv_cache[0]).copy(), f32(cm.deltakv_full_kv_cache[1]).copy()
+        cos_sin = cm.cos_sin_cache.cpu().numpy()
+        lat_map = cm.sparse_layer_latent_slots_map.cpu().numpy()
+        fathers = cm.deltakv_latent_to_full_slots.cpu().numpy()
+        if cfg["bits"]:
+            lat_code = cm.deltakv_latent_cache.cpu().numpy()
+            lat_scale, lat_mn = f32(cm.deltakv_latent_scales), f32(cm.deltakv_latent_mins)
+        else:
+            lat_dense = f32(cm.deltakv_latent_cache)
+        clens = cm.row_deltakv_compressed_lens[rows].copy()
+        if cfg["kivi"]:
+            kv = {n: getattr(cm, f"full_layer_kivi_{n}") for n in ("key_packed", "key_scales", "key_mins", "value_packed",
+                                                                    "value_scales", "value_mins")}
+            kv = {n: (t.cpu().numpy() if t.dtype in (torch.int32, torch.float32) else f32(t)) for n, t in kv.items()}
+            blk_map = cm.full_layer_kivi_block_slots_map.cpu().numpy()
+            blk_start = cm.full_layer_kivi_block_start_pos.cpu().numpy()
+        clens_before = clens.copy()
+        full_map = cm.full_layer_slots_map.cpu().numpy()
+        raw_map = cm.sparse_layer_raw_slots_map.cpu().numpy()
+        slot_to_pos = cm.deltakv_slot_to_pos.cpu().numpy()
         q, k, v = drv.random_step_inputs(seed=50 + step)
         drv.step(q, k, v, outputs=outs)
         torch.cuda.synchronize()
         got = f32(outs)
         qf, kf, vf = f32(q), f32(k), f32(v)
         lens = cm.row_seq_lens[rows].copy()
-        full_map = cm.full_layer_slots_map.cpu().numpy()
-        raw_map = cm.sparse_layer_raw_slots_map.cpu().numpy()
-        slot_to_pos = cm.deltakv_slot_to_pos.cpu().numpy()
-        new_full = full_map[rows, lens - 1]
-        new_sparse = raw_map[rows, lens - 1]
+        # maps as the attention saw them = the pre-step maps + this step's new token (the newest token is never
+        # compressed in the same step, so its slots are still in the post-step maps)
+        new_full = cm.full_layer_slots_map.cpu().numpy()[rows, lens - 1]
+        new_sparse = cm.sparse_layer_raw_slots_map.cpu().numpy()[rows, lens - 1]
         assert (new_full >= 0).all() and (new_sparse >= 0).all()
-        np.testing.assert_array_equal(slot_to_pos[new_sparse], lens - 1)
+        np.testing.assert_array_equal(cm.deltakv_slot_to_pos.cpu().numpy()[new_sparse], lens - 1)
+        full_map[rows, lens - 1] = new_full
+        raw_map[rows, lens - 1] = new_sparse
+        slot_to_pos[new_sparse] = lens - 1
         active = None
         for l in range(L):
             if l in cm.full_layer_to_idx:
@@ -173,11 +179,20 @@ def test_deltakv_decode_steps_match_oracle(cfg):
         np.testing.assert_array_equal(r_lat, plan["recon_latent"])
         np.testing.assert_array_equal(r_out, plan["recon_out_slot"])
 
-    # ---- the static tail is bounded: decoding past 2*recent raw tokens needs the compression side
-    with pytest.raises(RuntimeError, match="compression side"):
-        for step in range(2 * recent + 2):
-            q, k, v = drv.random_step_inputs(seed=500 + step)
-            drv.step(q, k, v)
+        # ---- compression side bookkeeping after the step (deltakv_evict / KIVI evict ran in post_forward)
+        after = cm.row_deltakv_compressed_lens[rows]
+        n_evictions += int((after != clens_before).sum())
+        tails = cm.row_seq_lens[rows] - sink - after
+        assert ((tails >= min(recent, int(tails.max()))) | (after == 0)).all() and (tails < 2 * recent).all()
+        raw_after = cm.sparse_layer_raw_slots_map.cpu().numpy()
+        lat_after = cm.sparse_layer_latent_slots_map.cpu().numpy()
+        for bi, r in enumerate(rows):
+            n_tot, c = int(cm.row_seq_lens[r]), int(after[bi])
+            assert (lat_after[r, sink:sink + c] >= 0).all() and (lat_after[r, sink + c:n_tot] < 0).all()
+            assert (raw_after[r, :sink] >= 0).all() and (raw_after[r, sink + c:n_tot] >= 0).all()
+            centres = raw_after[r, sink:sink + c] >= 0
+            assert centres.sum() == len(cm.row_deltakv_center_slots.get(int(r), [0] * sink)) - sink or c == 0
+    assert n_evictions >= 2 * B - 1
 
 
 def test_deltakv_free_seq_returns_every_slot():
