@@ -183,6 +183,7 @@ def main():
     if not args.no_kernel_events:
         # roofline leg: the same workload continues for a few eagerly launched steps
         drv.config.decode_cuda_graph = False
+        drv.sparse_controller._fused_h2o_layer = False
         for _ in range(args.event_steps):
             record["on"] = True
             drv.step(q, k, v)
@@ -197,7 +198,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {
             "workload": "Qwen2.5-7B h2o 128k ctx decode_budget=4096 interval=128 (BASELINE.json configs[2]); "
-                        "hot path only: alloc + 28 x {store_kvcache, scored stage1, stage2, score update} + burst "
+                        "hot path only: alloc + 28 x {store_kvcache, scored stage1, stage2 + score update} + burst "
                         "eviction every 128 steps; dense model layers not included",
             "seqs_per_gpu": B, "global_batch": n_gpus * B, "launch": "eager" if args.no_graph else "hipGraph replay", "resident_row_len": "4096..4224", "layers": 28,
             "heads": "28q/4kv x 128", "parallelism": f"replicas x{n_gpus} (sequence-sharded, no collective)",
@@ -218,7 +219,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic,
-            "kernel": "decode_stage1_kernel_v3<128,7,HEADMAX> (scored GQA split-KV decode)",
+            "kernel": "decode_stage1_kernel_v3<128,7,HEADMAX,nt,off32> (scored GQA split-KV decode)",
             "launches_timed": n_launch, "avg_launch_us": ms_total * 1e3 / n_launch,
             "timing": (f"{args.event_steps} eagerly launched steps continue the timed region; after each, its 28 "
                        "stage-1 launches are re-issued back to back on the same data between one pair of HIP "

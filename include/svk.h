@@ -178,6 +178,20 @@ typedef struct SvkH2oDecodeFinishArgs {
 } SvkH2oDecodeFinishArgs;
 int svk_h2o_decode_finish(const SvkH2oDecodeFinishArgs* a, svk_stream_t stream);
 
+/* One launch for a whole H2O decode layer: svk_flash_decode_stage1 (score_mode HEADMAX) + svk_h2o_decode_finish.  Every
+ * workgroup of a batch lane takes a ticket after publishing its partials / token scores; the last one merges the lane's
+ * split-KV partials into `o` and normalises + accumulates its token scores.  `tickets` is a caller-owned int32 [B]
+ * zeroed once (the kernel resets it).  Same results as the two calls (layers/attention_backend.py:284-349 +
+ * sparse_controller.py:762-767 + h2o.py:957-1038). */
+typedef struct SvkH2oDecodeFusedArgs {
+  SvkFlashDecodeStage1Args stage1;   /* score_mode must be SVK_SCORE_HEADMAX                      */
+  SvkH2oDecodeScoreArgs score;       /* attn_score / stride identical to stage1's                 */
+  uint16_t* o;                       /* [B, Hq, D] bf16                                           */
+  int64_t o_stride_b, o_stride_h;
+  int32_t* tickets;                  /* [B] int32, zero before the first launch                   */
+} SvkH2oDecodeFusedArgs;
+int svk_h2o_decode_fused(const SvkH2oDecodeFusedArgs* a, svk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * H2O selection + slot-table compaction
  * ---------------------------------------------------------------------------------- */

@@ -73,6 +73,11 @@ class SvkH2oDecodeFinishArgs(C.Structure):
     _fields_ = [("stage2", SvkFlashDecodeStage2Args), ("score", SvkH2oDecodeScoreArgs)]
 
 
+class SvkH2oDecodeFusedArgs(C.Structure):
+    _fields_ = [("stage1", SvkFlashDecodeStage1Args), ("score", SvkH2oDecodeScoreArgs), ("o", _p), ("o_stride_b", _i64),
+                ("o_stride_h", _i64), ("tickets", _p)]
+
+
 class SvkH2oSelectArgs(C.Structure):
     _fields_ = [("scores", _p), ("keep", _p), ("score_stride", _i64), ("keep_stride", _i64),
                 ("rows", _i32), ("kv_len", _i32), ("budget", _i32), ("recent_count", _i32)]
@@ -237,6 +242,7 @@ ENTRY_POINTS = {
     "svk_flash_decode_stage2": ([C.POINTER(SvkFlashDecodeStage2Args), _p], C.c_int),
     "svk_fill_f32": ([_p, _i64, _f32, _p], C.c_int),
     "svk_h2o_decode_score_update": ([C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
+    "svk_h2o_decode_fused": ([C.POINTER(SvkH2oDecodeFusedArgs), _p], C.c_int),
     "svk_h2o_decode_finish": ([C.POINTER(SvkH2oDecodeFinishArgs), _p], C.c_int),
     "svk_h2o_select_indices": ([C.POINTER(SvkH2oSelectArgs), _p], C.c_int),
     "svk_select_prefix_topk_suffix": ([C.POINTER(SvkSelectTopkArgs), _p], C.c_int),

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "svk_common.hpp"
+#include "svk_select.hpp"
 
 namespace svk {
 namespace {
@@ -676,9 +677,121 @@ struct Stage1V3Lds {
 // (32 registers for any GQA group size, no cross-lane reduction in the epilogue).  The vector ALUs are left with
 // the softmax only (v2 spent ~75 % of its VALU issue slots on the P.V FMAs).
 // ---------------------------------------------------------------------------------------
-template <int D, int G, int MODE, bool NTV, bool OFF32>
+// ---------------------------------------------------------------------------------------
+// Single-launch H2O decode layer: every workgroup of a row takes a ticket after publishing its partials and token
+// scores; the last one to arrive merges the split-KV partials of the row's heads (stage 2) and normalises /
+// accumulates the row's token scores (the `h2o_decode_finish` work) - no second launch, no grid barrier.
+// Release: each thread fences its stores at agent scope before the ticket; acquire: the finishing workgroup
+// invalidates its vector L1 after the ticket, so the other CUs' partials are read from L2.
+// ---------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void fused_row_finish(const SvkFlashDecodeStage1Args& a, const SvkH2oDecodeScoreArgs& fs, uint16_t* fo,
+                                                 int64_t fo_stride_b, int64_t fo_stride_h, int32_t* tickets, int b, float* lds) {
+  __shared__ int s_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = atomicAdd(&tickets[b], 1);
+    s_last = (t == (int)gridDim.x - 1);
+    if (s_last) tickets[b] = 0;                       // self-cleaning for the next launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int len = a.b_seqlen[b];
+  // ---- stage 2 (flash_decoding_stage2.py:19-46): one wave per q head, lane -> 2 (D=128) or 1 (D=64) dims; partials are
+  //      fetched 8 at a time so the L2 round trips overlap instead of chaining
+  const int nblk = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq;
+  for (int h = w; h < a.num_q_heads; h += nw) {
+    const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h;
+    const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
+    const int d = D == 128 ? lane * 2 : lane;
+    float sum = 0.f, mxl = -INFINITY, a0 = 0.f, a1 = 0.f;
+    for (int i0 = 0; i0 < nblk; i0 += 8) {
+      float t0[8], t1[8], tl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = min(i0 + j, nblk - 1);
+        tl[j] = ml[i];
+        if (D == 128) {
+          const float2 tv = *reinterpret_cast<const float2*>(mo + (int64_t)i * a.mid_o_stride_s + d);
+          t0[j] = tv.x; t1[j] = tv.y;
+        } else {
+          t0[j] = mo[(int64_t)i * a.mid_o_stride_s + d];
+          t1[j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (i0 + j < nblk) {
+          const float nm = fmaxf(tl[j], mxl);
+          const float os = __expf(mxl - nm);
+          const float e = __expf(tl[j] - nm);
+          a0 = a0 * os + e * t0[j];
+          a1 = a1 * os + e * t1[j];
+          sum = sum * os + e;
+          mxl = nm;
+        }
+      }
+    }
+    uint16_t* o = fo + (int64_t)b * fo_stride_b + (int64_t)h * fo_stride_h + d;
+    if (D == 128) *reinterpret_cast<uint32_t*>(o) = f32_to_bf16_bits(a0 / sum) | (f32_to_bf16_bits(a1 / sum) << 16);
+    else *o = (uint16_t)f32_to_bf16_bits(a0 / sum);
+  }
+  // ---- token scores: x *= scale; softmax over the full width; cum = pad(prev, 1) + p  (sparse_controller.py:762-767,
+  //      h2o.py:957-1038).  The row is held in registers when it fits (<= 32 elements per thread).
+  float* red = lds;                                   // the tile loop is over: reuse the dynamic LDS
+  float* x = fs.attn_score + (int64_t)b * fs.score_stride_b;
+  const int W = fs.width;
+  float* cum = fs.cum_score != nullptr ? fs.cum_score + (int64_t)fs.b_req_idx[b] * fs.cum_stride : nullptr;
+  const int nt = blockDim.x;
+  if (W <= 32 * nt) {
+    float v[32], c[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int t = threadIdx.x + i * nt;
+      v[i] = t < W ? mul_rn(x[t], fs.scale) : -INFINITY;
+      c[i] = (cum != nullptr && t < len - 1) ? cum[t] : 0.f;
+      mx = fmaxf(mx, v[i]);
+    }
+    mx = block_allmax(mx, red);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      v[i] = expf(v[i] - mx);
+      sum += v[i];
+    }
+    sum = block_allsum(sum, red);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int t = threadIdx.x + i * nt;
+      if (t < W) {
+        const float p = v[i] / sum;
+        x[t] = p;
+        if (cum != nullptr && t < len) cum[t] = c[i] + p;         // pad(prev, 1): the newest position starts from 0
+      }
+    }
+    return;
+  }
+  float mx = -INFINITY;
+  for (int t = threadIdx.x; t < W; t += nt) mx = fmaxf(mx, mul_rn(x[t], fs.scale));
+  mx = block_allmax(mx, red);
+  float sum = 0.f;
+  for (int t = threadIdx.x; t < W; t += nt) sum += expf(mul_rn(x[t], fs.scale) - mx);
+  sum = block_allsum(sum, red);
+  for (int t = threadIdx.x; t < W; t += nt) {
+    const float p = expf(mul_rn(x[t], fs.scale) - mx) / sum;
+    x[t] = p;
+    if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : cum[t] + p;
+  }
+}
+
+template <int D, int G, int MODE, bool NTV, bool OFF32, bool FUSED>
 __global__ void __launch_bounds__(512)
-decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
+decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a, const SvkH2oDecodeScoreArgs fs, uint16_t* fo, int64_t fo_stride_b,
+                        int64_t fo_stride_h, int32_t* tickets) {
   using C = Stage1Cfg<D, G>;
   constexpr int NC = C::NC, JQ = C::JQ;
   constexpr int WF = Stage1V3Lds<D, G>::WAVE_FLOATS;
@@ -716,6 +829,7 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
       for (int d = lane; d < D; d += 64) o[d] = 0.f;
       if (lane == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = -INFINITY;
     }
+    if constexpr (FUSED) fused_row_finish<D>(a, fs, fo, fo_stride_b, fo_stride_h, tickets, b, lds);
     return;
   }
 
@@ -944,6 +1058,7 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
       }
     }
   }
+  if constexpr (FUSED) fused_row_finish<D>(a, fs, fo, fo_stride_b, fo_stride_h, tickets, b, lds);
 }
 
 template <int D>
@@ -1031,14 +1146,44 @@ int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
   }
 #define SVK_LAUNCH_V3(MODE_)                                                                                      \
   do {                                                                                                            \
-    if (off32) hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, true>), grid, block, shm3, stream, a);  \
-    else hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, false>), grid, block, shm3, stream, a);       \
+    if (off32) hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, true, false>), grid, block, shm3, stream, a, SvkH2oDecodeScoreArgs{}, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int32_t*)nullptr);  \
+    else hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, false, false>), grid, block, shm3, stream, a, SvkH2oDecodeScoreArgs{}, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int32_t*)nullptr);       \
   } while (0)
   if (a.score_mode == SVK_SCORE_HEADMAX) SVK_LAUNCH_V3(SVK_SCORE_HEADMAX);
   else if (a.score_mode == SVK_SCORE_PERHEAD) SVK_LAUNCH_V3(SVK_SCORE_PERHEAD);
   else SVK_LAUNCH_V3(SVK_SCORE_NONE);
 #undef SVK_LAUNCH_V3
   return check_launch("svk_flash_decode_stage1");
+}
+
+template <int D, int G>
+int launch_fused(const SvkH2oDecodeFusedArgs& f, hipStream_t stream) {
+  using C = Stage1Cfg<D, G>;
+  const SvkFlashDecodeStage1Args& a = f.stage1;
+  const int nblk = (a.max_len_in_batch + a.block_seq - 1) / a.block_seq;
+  dim3 grid(nblk, a.batch), block(64 * a.num_kv_heads);
+  const size_t shm3 = sizeof(float) * ((size_t)a.num_kv_heads * Stage1V3Lds<D, G>::WAVE_FLOATS + (size_t)kScoreChunk * a.num_kv_heads * C::JQ);
+  const bool off32 = a.kv_num_slots > 0 && (a.kv_num_slots * a.kv_slot_stride * 2) < (int64_t)0xffffffffll;
+  if (off32) hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, SVK_SCORE_HEADMAX, true, true, true>), grid, block, shm3, stream, a, f.score, f.o, f.o_stride_b, f.o_stride_h, f.tickets);
+  else hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, SVK_SCORE_HEADMAX, true, false, true>), grid, block, shm3, stream, a, f.score, f.o, f.o_stride_b, f.o_stride_h, f.tickets);
+  return check_launch("svk_h2o_decode_fused");
+}
+
+template <int D>
+int dispatch_fused(const SvkH2oDecodeFusedArgs& f, int G, hipStream_t stream) {
+  switch (G) {
+    case 1: return launch_fused<D, 1>(f, stream);
+    case 2: return launch_fused<D, 2>(f, stream);
+    case 3: return launch_fused<D, 3>(f, stream);
+    case 4: return launch_fused<D, 4>(f, stream);
+    case 5: return launch_fused<D, 5>(f, stream);
+    case 6: return launch_fused<D, 6>(f, stream);
+    case 7: return launch_fused<D, 7>(f, stream);
+    case 8: return launch_fused<D, 8>(f, stream);
+    default:
+      set_error("svk_h2o_decode_fused: GQA group size %d unsupported (1..8)", G);
+      return SVK_ERR_LAYOUT;
+  }
 }
 
 template <int D>
@@ -1061,29 +1206,53 @@ int dispatch_group(const SvkFlashDecodeStage1Args& a, int G, hipStream_t stream)
 }  // namespace
 }  // namespace svk
 
+static int validate_stage1(const SvkFlashDecodeStage1Args* a, const char* who) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "%s: null args", who);
+  SVK_REQUIRE(a->head_dim == 64 || a->head_dim == 128, SVK_ERR_LAYOUT, "%s: head_dim %d unsupported (64, 128)", who, a->head_dim);
+  SVK_REQUIRE(a->block_seq > 0 && a->block_seq % 16 == 0, SVK_ERR_LAYOUT,
+              "%s: block_seq %d must be a positive multiple of 16 (BLOCK_SEQ %% BLOCK_N)", who, a->block_seq);
+  SVK_REQUIRE(a->num_kv_heads >= 1 && a->num_kv_heads <= 8, SVK_ERR_LAYOUT, "%s: num_kv_heads %d unsupported (1..8 per rank)", who,
+              a->num_kv_heads);
+  SVK_REQUIRE(a->num_q_heads % a->num_kv_heads == 0, SVK_ERR_LAYOUT, "%s: q heads %d not divisible by kv heads %d", who,
+              a->num_q_heads, a->num_kv_heads);
+  SVK_REQUIRE(a->score_mode == SVK_SCORE_NONE || a->score_mode == SVK_SCORE_HEADMAX || a->score_mode == SVK_SCORE_PERHEAD,
+              SVK_ERR_VALUE, "%s: bad score_mode %d", who, a->score_mode);
+  SVK_REQUIRE(a->score_mode == SVK_SCORE_NONE || a->attn_score != nullptr, SVK_ERR_VALUE, "%s: score_mode %d needs attn_score", who,
+              a->score_mode);
+  SVK_REQUIRE((a->kv_slot_stride % 8) == 0 && (a->kv_head_stride % 8) == 0 && (a->q_stride_h % 8) == 0 && (a->q_stride_b % 8) == 0,
+              SVK_ERR_LAYOUT, "%s: q/k/v strides must keep 16-byte alignment", who);
+  SVK_REQUIRE((a->mid_o_stride_h % 4) == 0 && (a->mid_o_stride_s % 4) == 0 && (a->mid_o_stride_b % 4) == 0, SVK_ERR_LAYOUT,
+              "%s: mid_o strides must keep 16-byte alignment", who);
+  return SVK_OK;
+}
+
 extern "C" int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_stream_t stream) {
   using namespace svk;
-  SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_flash_decode_stage1: null args");
-  SVK_REQUIRE(a->head_dim == 64 || a->head_dim == 128, SVK_ERR_LAYOUT,
-              "svk_flash_decode_stage1: head_dim %d unsupported (64, 128)", a->head_dim);
-  SVK_REQUIRE(a->block_seq > 0 && a->block_seq % 16 == 0, SVK_ERR_LAYOUT,
-              "svk_flash_decode_stage1: block_seq %d must be a positive multiple of 16 (BLOCK_SEQ %% BLOCK_N)", a->block_seq);
-  SVK_REQUIRE(a->num_kv_heads >= 1 && a->num_kv_heads <= 8, SVK_ERR_LAYOUT,
-              "svk_flash_decode_stage1: num_kv_heads %d unsupported (1..8 per rank)", a->num_kv_heads);
-  SVK_REQUIRE(a->num_q_heads % a->num_kv_heads == 0, SVK_ERR_LAYOUT,
-              "svk_flash_decode_stage1: q heads %d not divisible by kv heads %d", a->num_q_heads, a->num_kv_heads);
-  SVK_REQUIRE(a->score_mode == SVK_SCORE_NONE || a->score_mode == SVK_SCORE_HEADMAX || a->score_mode == SVK_SCORE_PERHEAD,
-              SVK_ERR_VALUE, "svk_flash_decode_stage1: bad score_mode %d", a->score_mode);
-  SVK_REQUIRE(a->score_mode == SVK_SCORE_NONE || a->attn_score != nullptr, SVK_ERR_VALUE,
-              "svk_flash_decode_stage1: score_mode %d needs attn_score", a->score_mode);
-  SVK_REQUIRE((a->kv_slot_stride % 8) == 0 && (a->kv_head_stride % 8) == 0 && (a->q_stride_h % 8) == 0 && (a->q_stride_b % 8) == 0,
-              SVK_ERR_LAYOUT, "svk_flash_decode_stage1: q/k/v strides must keep 16-byte alignment");
-  SVK_REQUIRE((a->mid_o_stride_h % 4) == 0 && (a->mid_o_stride_s % 4) == 0 && (a->mid_o_stride_b % 4) == 0, SVK_ERR_LAYOUT,
-              "svk_flash_decode_stage1: mid_o strides must keep 16-byte alignment");
+  const int rc = validate_stage1(a, "svk_flash_decode_stage1");
+  if (rc != SVK_OK) return rc;
   if (a->batch <= 0 || a->max_len_in_batch <= 0) return SVK_OK;
   const int G = a->num_q_heads / a->num_kv_heads;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return a->head_dim == 128 ? dispatch_group<128>(*a, G, s) : dispatch_group<64>(*a, G, s);
+}
+
+extern "C" int svk_h2o_decode_fused(const SvkH2oDecodeFusedArgs* f, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(f != nullptr && f->o != nullptr && f->tickets != nullptr && f->score.attn_score != nullptr, SVK_ERR_VALUE,
+              "svk_h2o_decode_fused: null args");
+  const SvkFlashDecodeStage1Args* a = &f->stage1;
+  int rc = validate_stage1(a, "svk_h2o_decode_fused");
+  if (rc != SVK_OK) return rc;
+  SVK_REQUIRE(a->score_mode == SVK_SCORE_HEADMAX && a->attn_score == f->score.attn_score && a->score_stride_b == f->score.score_stride_b,
+              SVK_ERR_VALUE, "svk_h2o_decode_fused: stage 1 must write the head-max scores the finish step normalises");
+  SVK_REQUIRE(f->score.batch == a->batch && f->score.width > 0, SVK_ERR_VALUE, "svk_h2o_decode_fused: score batch/width mismatch");
+  SVK_REQUIRE(f->score.cum_score == nullptr || f->score.b_req_idx != nullptr, SVK_ERR_VALUE, "svk_h2o_decode_fused: cum_score needs b_req_idx");
+  SVK_REQUIRE((f->o_stride_b % 2) == 0 && (f->o_stride_h % 2) == 0, SVK_ERR_LAYOUT, "svk_h2o_decode_fused: output strides must be even");
+  if (a->batch <= 0 || a->max_len_in_batch <= 0) return SVK_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int G = a->num_q_heads / a->num_kv_heads;
+  return a->head_dim == 128 ? dispatch_fused<128>(*f, G, s) : dispatch_fused<64>(*f, G, s);
 }
 
 extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_stream_t stream) {

@@ -8,6 +8,7 @@ kernels).  Call order (fixed by ModelRunner.run, model_runner.py:1447-1481):
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -48,6 +49,10 @@ class SparseController:
         self.layer_batch_sparse_states = [LayerBatchSparseState() for _ in range(self.num_layers)]
         self._h2o_decode_attn_score_buffers: dict[tuple, torch.Tensor] = {}
         self._fused_h2o_accumulate = True
+        # single-launch layer (svk_h2o_decode_fused).  Measured slower than stage 1 + the 1024-thread finish kernel
+        # (139.7 us vs 93.5 + 9.3 us at B=64: one workgroup per row cannot hide the finish step's L2 round trips), so it
+        # is opt-in; kept because it halves the launches for callers that are launch-bound.
+        self._fused_h2o_layer = os.environ.get("SVK_H2O_FUSED_LAYER", "0") == "1"
         self._layer_score_finished = [False] * self.num_layers
         self.is_deltakv_family = self.sparse_method == "deltakv"
         self.obs_layer_ids = list(getattr(config, "obs_layer_ids", None) or [])
@@ -213,6 +218,23 @@ class SparseController:
         return SparseSelection(kind="full", req_indices=req, context_lens=s.context_lens,
                                max_context_len=s.max_context_len, attn_score=s.attn_score,
                                global_req_indices=s.global_req_indices)
+
+    def fused_decode_layer(self, layer_idx: int, q, k_cache, v_cache, active_slots, req_indices, context_lens, max_len_in_batch,
+                           mid_o, mid_lse, attn_score, block_seq, o) -> bool:
+        """MI355X fusion hook: the whole H2O decode layer (scored stage 1, stage 2, score normalise + cumulative
+        update) in one launch (svk_h2o_decode_fused).  Returns False when the layer is not an H2O decode layer."""
+        if self.sparse_method != "h2o" or get_context().is_prefill or not self._fused_h2o_layer:
+            return False
+        s = self.layer_batch_sparse_states[layer_idx]
+        if s.attn_score is None or s.attn_score.dim() != 2 or attn_score.data_ptr() != s.attn_score.data_ptr():
+            return False
+        cm = self.cache_manager
+        cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
+        from ..kernels.gqa_flash_decoding_stage1 import h2o_decode_fused
+        h2o_decode_fused(q, k_cache, v_cache, active_slots, req_indices, context_lens, max_len_in_batch, mid_o, mid_lse,
+                         attn_score, block_seq, o, self.attn_softmax_scale, cum_score=cum)
+        self._layer_score_finished[layer_idx] = True
+        return True
 
     def fused_decode_finish(self, layer_idx: int, mid_o, mid_lse, context_lens, o, block_seq) -> bool:
         """MI355X fusion hook called by the attention backend instead of `flash_decode_stage2`:

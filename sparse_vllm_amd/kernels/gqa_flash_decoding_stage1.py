@@ -32,8 +32,8 @@ def _assert_supported_layout(q, k, v, req_to_tokens, b_req_idx, b_seqlen, mid_ou
         f"mid_out_logsumexp block dimension must be contiguous, got stride={mid_out_logsumexp.stride()}.")
 
 
-def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq):
+def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
+                 attn_score, block_seq):
     Lq, Lk = q.shape[-1], k.shape[-1]
     assert Lq == Lk
     assert Lk in {16, 32, 64, 128, 256}
@@ -56,8 +56,7 @@ def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_o
         else:
             mode = _lib.SVK_SCORE_HEADMAX
             ss_b = attn_score.stride(0)
-    lib = _lib.load()
-    a = _lib.SvkFlashDecodeStage1Args(
+    return _lib.SvkFlashDecodeStage1Args(
         q=_lib.ptr(q), k_cache=_lib.ptr(k), v_cache=_lib.ptr(v), req_to_tokens=_lib.ptr(Req_to_tokens),
         b_req_idx=_lib.ptr(B_req_idx), b_seqlen=_lib.ptr(B_Seqlen), mid_o=_lib.ptr(mid_out),
         mid_lse=_lib.ptr(mid_out_logsumexp), attn_score=_lib.ptr(attn_score),
@@ -69,7 +68,45 @@ def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_o
         score_stride_b=ss_b, score_stride_h=ss_h,
         batch=batch, num_q_heads=q.shape[1], num_kv_heads=kv_head_num, head_dim=Lk,
         max_len_in_batch=int(max_len_in_batch), block_seq=int(block_seq), score_mode=mode)
+
+
+def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
+            attn_score, block_seq):
+    a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
+                     attn_score, block_seq)
+    lib = _lib.load()
     _lib.check(lib.svk_flash_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+_TICKETS: dict = {}
+
+
+@torch.no_grad()
+def h2o_decode_fused(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp, attn_score,
+                     block_seq, O, scale, *, cum_score=None):
+    """One launch = flash_decode_stage1_with_score (2-D head-max scores) + flash_decode_stage2 + the H2O score
+    normalise / accumulate of `h2o_decode_finish` (ticketed last-workgroup epilogue).  Same results."""
+    assert attn_score is not None and attn_score.dim() == 2
+    assert O.dtype == torch.bfloat16 and O.stride(-1) == 1
+    if cum_score is not None:
+        assert cum_score.dim() == 2 and cum_score.dtype == torch.float32 and cum_score.stride(1) == 1
+    a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
+                     attn_score, block_seq)
+    key = (q.device, int(B_req_idx.shape[0]))
+    tickets = _TICKETS.get(key)
+    if tickets is None:
+        tickets = torch.zeros((int(B_req_idx.shape[0]),), dtype=torch.int32, device=q.device)
+        _TICKETS[key] = tickets
+    lib = _lib.load()
+    f = _lib.SvkH2oDecodeFusedArgs(
+        stage1=a,
+        score=_lib.SvkH2oDecodeScoreArgs(
+            attn_score=_lib.ptr(attn_score), cum_score=_lib.ptr(cum_score), b_req_idx=_lib.ptr(B_req_idx),
+            b_seqlen=_lib.ptr(B_Seqlen), score_stride_b=attn_score.stride(0),
+            cum_stride=0 if cum_score is None else cum_score.stride(0), scale=float(scale),
+            batch=attn_score.shape[0], width=attn_score.shape[1]),
+        o=_lib.ptr(O), o_stride_b=O.stride(0), o_stride_h=O.stride(1), tickets=_lib.ptr(tickets))
+    _lib.check(lib.svk_h2o_decode_fused(C.byref(f), _lib.current_stream_handle()), lib)
 
 
 @torch.no_grad()

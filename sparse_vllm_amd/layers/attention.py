@@ -39,7 +39,7 @@ class HipAttentionBackend:
 
     def run_decode(self, q: torch.Tensor, view: DecodeComputeView, *, mid_o, mid_o_logexpsum, max_len_in_batch: int,
                    block_seq: int, num_heads: int, num_kv_heads: int, gqa_block_n: int = 16,
-                   gqa_num_warps: int = 2, fused_finish=None) -> torch.Tensor:
+                   gqa_num_warps: int = 2, fused_finish=None, fused_layer=None) -> torch.Tensor:
         payload = view.payload
         if not isinstance(payload, ExplicitKVPayload):
             raise TypeError(f"HIP decode requires ExplicitKVPayload, got {type(payload).__name__}.")
@@ -63,6 +63,13 @@ class HipAttentionBackend:
             o = torch.empty_like(q)
             flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
             return o
+        if fused_layer is not None and payload.backend == "dense" and meta.attn_score is not None and meta.attn_score.dim() == 2:
+            # MI355X: stage 1 + stage 2 + the controller's per-layer score epilogue as ONE launch
+            o = torch.empty_like(q)
+            with profiler.record(f"decode_attention_fused_{kind}"):
+                if fused_layer(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices, meta.context_lens,
+                               max_len_in_batch, mid_o, mid_o_logexpsum, meta.attn_score, block_seq, o):
+                    return o
         with profiler.record(f"decode_attention_stage1_{kind}"):
             if meta.attn_score is not None:
                 flash_decode_stage1_with_score(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
@@ -124,11 +131,13 @@ class Attention(torch.nn.Module):
             mid_o, mid_lse = get_decode_workspace(context, batch_size, self.num_heads, num_seq_blocks, self.head_dim,
                                                   q.device)
             finish = getattr(sparse_controller, "fused_decode_finish", None)
+            layer_fn = getattr(sparse_controller, "fused_decode_layer", None)
             o = self.attention_backend.run_decode(
                 q, decode_view, mid_o=mid_o, mid_o_logexpsum=mid_lse, max_len_in_batch=max_len_in_batch,
                 block_seq=block_seq, num_heads=self.num_heads, num_kv_heads=self.num_kv_heads,
                 gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps,
-                fused_finish=None if finish is None else (lambda *a, _l=layer_idx: finish(_l, *a)))
+                fused_finish=None if finish is None else (lambda *a, _l=layer_idx: finish(_l, *a)),
+                fused_layer=None if layer_fn is None else (lambda *a, _l=layer_idx: layer_fn(_l, *a)))
             cache_manager.record_decode_query(layer_idx, q)
             sparse_controller.on_layer_attention_end(layer_idx)
             cache_manager.on_layer_attention_end(layer_idx)

@@ -410,3 +410,40 @@ def test_fused_decode_finish_equals_separate_calls():
         # the register-resident row sums in a different order than the 3-pass kernel: 1-2 ulp
         torch.testing.assert_close(x2, x1, rtol=2e-6, atol=1e-12)
         torch.testing.assert_close(c2, c1, rtol=2e-6, atol=1e-9)
+
+
+def test_single_launch_layer_matches_two_launches():
+    """svk_h2o_decode_fused (stage 1 + ticketed finish in one launch) == stage 1 followed by h2o_decode_finish, bit for bit
+    (same kernels bodies, same merge order), over ragged rows and repeated launches (ticket self-reset)."""
+    from sparse_vllm_amd.kernels import flash_decode_stage1_with_score
+    from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import h2o_decode_fused
+    from sparse_vllm_amd.kernels.h2o_ops import h2o_decode_finish
+    d = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(9)
+    B, Hq, Hkv, D, W, bs, rows = 5, 28, 4, 128, 700, 128, 7
+    slots = 6000
+    kc = (torch.randn(slots, Hkv, D, generator=g) * 0.3).bfloat16().to(d)
+    vc = (torch.randn(slots, Hkv, D, generator=g) * 0.3).bfloat16().to(d)
+    q = (torch.randn(B, Hq, D, generator=g) * 0.3).bfloat16().to(d)
+    table = torch.randperm(slots, generator=g)[: rows * W].to(torch.int32).view(rows, W).to(d)
+    req = torch.tensor([3, 0, 6, 2, 5], dtype=torch.int32, device=d)
+    lens = torch.tensor([700, 1, 129, 640, 257], dtype=torch.int32, device=d)
+    nblk = (W + bs - 1) // bs
+    outs = []
+    for fused in (False, True):
+        for rep in range(2):
+            mid = torch.zeros(B, Hq, nblk, D, device=d)
+            lse = torch.zeros(B, Hq, nblk, device=d)
+            score = torch.full((B, W), -1e20, device=d)
+            cum = torch.arange(rows * W, dtype=torch.float32, device=d).view(rows, W) * 1e-3
+            o = torch.zeros(B, Hq, D, dtype=torch.bfloat16, device=d)
+            if fused:
+                h2o_decode_fused(q, kc, vc, table, req, lens, W, mid, lse, score, bs, o, D ** -0.5, cum_score=cum)
+            else:
+                flash_decode_stage1_with_score(q, kc, vc, table, req, lens, W, mid, lse, score, bs)
+                h2o_decode_finish(mid, lse, lens, o, bs, score, D ** -0.5, cum_score=cum, b_req_idx=req)
+            torch.cuda.synchronize()
+        outs.append((o.clone(), score.clone(), cum.clone()))
+    torch.testing.assert_close(outs[1][0].float(), outs[0][0].float(), rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(outs[1][2], outs[0][2], rtol=1e-6, atol=1e-7)
