@@ -334,6 +334,8 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
   const int32_t* raw_map = a.raw_slots_map + (int64_t)row * a.map_stride;
   const int32_t* blk_map = a.kivi_block_slots_map + (int64_t)row * a.map_stride;
   const float sm_scale = rsqrtf((float)D);
+  const bool score_vec = a.attn_score != nullptr && (a.score_stride_b % 4) == 0 && (a.score_stride_h % 4) == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.attn_score) % 16) == 0 && (start % 8) == 0;
   float m[4], l[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
@@ -514,16 +516,23 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
           s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, kr[c]), s[i], 0, 0, 0);
       }
     }
-    // ---- raw scores (observation layers): 8 consecutive tokens per head per lane
+    // ---- raw scores (observation layers): 8 consecutive tokens per head per lane -> two 16-byte stores when the
+    //      score rows keep 16-byte alignment (t0 and 8n are multiples of 8)
     if (a.attn_score != nullptr && kc < JQ) {
+      const bool vec = score_vec && tvmask == 0xffu;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int h = kc * 4 + r;
         if (h < G) {
           float* dst = a.attn_score + (int64_t)b * a.score_stride_b + (int64_t)(w * G + h) * a.score_stride_h + t0 + 8 * n;
+          if (vec) {
+            *reinterpret_cast<float4*>(dst) = make_float4(s[0][r], s[1][r], s[2][r], s[3][r]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(s[4][r], s[5][r], s[6][r], s[7][r]);
+          } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if ((tvmask >> i) & 1u) dst[i] = s[i][r];
+            for (int i = 0; i < 8; ++i)
+              if ((tvmask >> i) & 1u) dst[i] = s[i][r];
+          }
         }
       }
     }

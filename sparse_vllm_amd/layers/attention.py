@@ -121,7 +121,8 @@ class Attention(torch.nn.Module):
                 if max_len_in_batch <= 0:
                     raise RuntimeError(f"decode requires a positive context length, got {max_len_in_batch} at layer={layer_idx}")
             block_seq = cache_manager.get_decode_block_seq(layer_idx, 256)
-            if self.decode_launch_op is None:
+            if self.decode_launch_op is None or decode_view.payload.backend == "full_layer_kivi":
+                # KIVI layers keep the manager's full_layer_kivi_decode_block_seq (128-token tiles, >= 2 workgroups per CU)
                 gqa_block_n, gqa_num_warps = 16, 2
             else:
                 block_seq, gqa_block_n, gqa_num_warps = self.decode_launch_op.launch_config(
