@@ -523,6 +523,31 @@ typedef struct SvkDeltakvMaterializeArgs {
 } SvkDeltakvMaterializeArgs;
 int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeArgs* a, svk_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Chunked-prefill causal attention over the paged slot table
+ * ---------------------------------------------------------------------------------- */
+
+/* o[t, h, :] = softmax_j(q[t, h] . k[j] * D^-0.5) v[j] over the keys j <= prompt_cache_len[b] + (t - start_loc[b]) of
+ * sequence b, keys / values read through req_to_tokens[b_req_idx[b], j] (the chunk's own K/V are already stored).
+ * base-2 online softmax with the reference's constants (sm_scale = D^-0.5 * log2(e), masked logits = -1e8), P rounded
+ * to bf16 before P.V, fp32 accumulation.
+ * Replaces context_attention_fwd (attn_score=None), kernels/triton/context_flashattention_nopad.py:10-78, 242-276
+ * (call sites layers/attention_backend.py:140, operators/prefill_attention.py:621-625). */
+typedef struct SvkContextAttentionArgs {
+  const uint16_t* q;             /* [tokens, Hq, D] bf16 (q_stride_t / q_stride_h)        */
+  const uint16_t* k_cache;       /* [slots, Hkv, D] bf16 (kv_slot_stride / kv_head_stride) */
+  const uint16_t* v_cache;
+  uint16_t* o;                   /* [tokens, Hq, D] bf16 (o_stride_t / o_stride_h)        */
+  const int32_t* b_req_idx;      /* [B]                                                   */
+  const int32_t* b_start_loc;    /* [B] first query token of the sequence in q            */
+  const int32_t* b_seq_len;      /* [B] total length incl. the cached prefix              */
+  const int32_t* b_prompt_cache_len; /* [B]                                               */
+  const int32_t* req_to_tokens;  /* [rows, req_stride]                                    */
+  int64_t q_stride_t, q_stride_h, kv_slot_stride, kv_head_stride, o_stride_t, o_stride_h, req_stride;
+  int32_t batch, num_q_heads, num_kv_heads, head_dim, max_input_len;
+} SvkContextAttentionArgs;
+int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_stream_t stream);
+
 /* ---- DeltaKV compression side -------------------------------------------------------------- */
 
 /* Grouped quantise + pack of residual rows: per group scale = (max - min) / (2^bits - 1) stored in the data dtype,

@@ -197,6 +197,14 @@ class SvkDeltakvMaterializeArgs(C.Structure):
                [("temp_slots", _p), ("temp_stride", _i64), ("temp_offset", _i32), ("temp_count", _i32)]
 
 
+class SvkContextAttentionArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("q", "k_cache", "v_cache", "o", "b_req_idx", "b_start_loc", "b_seq_len",
+                                  "b_prompt_cache_len", "req_to_tokens")] + \
+               [(n, _i64) for n in ("q_stride_t", "q_stride_h", "kv_slot_stride", "kv_head_stride", "o_stride_t", "o_stride_h",
+                                    "req_stride")] + \
+               [(n, _i32) for n in ("batch", "num_q_heads", "num_kv_heads", "head_dim", "max_input_len")]
+
+
 class SvkQuantPackArgs(C.Structure):
     _fields_ = [("data", _p), ("dst_rows", _p), ("code", _p), ("scale", _p), ("mn", _p),
                 ("data_stride", _i64), ("code_stride", _i64), ("scale_stride", _i64),
@@ -258,6 +266,7 @@ ENTRY_POINTS = {
     "svk_topk_sorted_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),
     "svk_topk_sorted_desc": ([C.POINTER(SvkTopkSortedArgs), _p, _p], C.c_int),
     "svk_deltakv_materialize_sparse_view": ([C.POINTER(SvkDeltakvMaterializeArgs), _p], C.c_int),
+    "svk_context_attention_fwd": ([C.POINTER(SvkContextAttentionArgs), _p], C.c_int),
     "svk_quantize_pack_grouped": ([C.POINTER(SvkQuantPackArgs), _p], C.c_int),
     "svk_kivi_store_blocks": ([C.POINTER(SvkKiviStoreArgs), _p], C.c_int),
     "svk_cluster_topk": ([C.POINTER(SvkClusterTopkArgs), _p], C.c_int),

@@ -1,0 +1,41 @@
+"""Chunked-prefill causal attention over the paged slot table on gfx950.
+
+Mirror of the reference's kernels/triton/context_flashattention_nopad.py `context_attention_fwd` (:242-302): same
+argument order and layout asserts.  The score-collecting variants (`attn_score` 2-D / 3-D, used by the reference's
+OmniKV / DeltaKV prefill observation layers) are not part of this build; H2O / SnapKV prefill scores come from
+`prefill_score_fwd`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+
+@torch.no_grad()
+def context_attention_fwd(q, k, v, o, b_req_idx, b_start_loc, b_seq_len, b_prompt_cache_len, max_input_len,
+                          req_to_token_indexs, attn_score=None):
+    if attn_score is not None:
+        raise NotImplementedError("prefill attention with fused score collection is outside this build (SURVEY 8(f).1)")
+    Lq, Lk, Lv = q.shape[-1], k.shape[-1], v.shape[-1]
+    assert Lq == Lk and Lk == Lv
+    assert Lk in {16, 32, 64, 128, 256}
+    assert q.dtype == k.dtype and k.dtype == v.dtype
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1 and o.stride(-1) == 1
+    assert q.dtype == torch.bfloat16 and o.dtype == torch.bfloat16, f"the gfx950 prefill kernel computes in bf16, got {q.dtype}"
+    assert k.stride() == v.stride()
+    for t in (b_req_idx, b_start_loc, b_seq_len, b_prompt_cache_len, req_to_token_indexs):
+        assert t.dtype == torch.int32
+    assert req_to_token_indexs.stride(-1) == 1
+    lib = _lib.load()
+    a = _lib.SvkContextAttentionArgs(
+        q=_lib.ptr(q), k_cache=_lib.ptr(k), v_cache=_lib.ptr(v), o=_lib.ptr(o), b_req_idx=_lib.ptr(b_req_idx),
+        b_start_loc=_lib.ptr(b_start_loc), b_seq_len=_lib.ptr(b_seq_len), b_prompt_cache_len=_lib.ptr(b_prompt_cache_len),
+        req_to_tokens=_lib.ptr(req_to_token_indexs), q_stride_t=q.stride(0), q_stride_h=q.stride(1),
+        kv_slot_stride=k.stride(0), kv_head_stride=k.stride(1), o_stride_t=o.stride(0), o_stride_h=o.stride(1),
+        req_stride=req_to_token_indexs.stride(0), batch=int(b_seq_len.shape[0]), num_q_heads=int(q.shape[1]),
+        num_kv_heads=int(k.shape[1]), head_dim=int(Lk), max_input_len=int(max_input_len))
+    _lib.check(lib.svk_context_attention_fwd(C.byref(a), _lib.current_stream_handle()), lib)

@@ -779,6 +779,29 @@ def gen_deltakv_compress():
     save("deltakv_compress", **out)
 
 
+def gen_prefill_attention():
+    """`context_attention_fwd(attn_score=None)` (context_flashattention_nopad.py:242-276) under the interpreter on fp32
+    tensors holding bf16 values; two sequences of one chunked-prefill step, one with a cached prefix."""
+    from sparsevllm.kernels.triton.context_flashattention_nopad import context_attention_fwd
+
+    g = torch.Generator().manual_seed(47)
+    Hq, Hkv, D, slots = 4, 2, 64, 160
+    chunk, pc = [37, 20], [11, 0]
+    T = sum(chunk)
+    q = bf16f(torch.randn(T, Hq, D, generator=g) * 0.5)
+    kc = bf16f(torch.randn(slots, Hkv, D, generator=g) * 0.5)
+    vc = bf16f(torch.randn(slots, Hkv, D, generator=g) * 0.5)
+    table = torch.randperm(slots, generator=g)[: 3 * 50].to(torch.int32).view(3, 50)
+    req = torch.tensor([2, 0], dtype=torch.int32)
+    start = torch.tensor([0, chunk[0]], dtype=torch.int32)
+    seq_len = torch.tensor([chunk[0] + pc[0], chunk[1] + pc[1]], dtype=torch.int32)
+    pcl = torch.tensor(pc, dtype=torch.int32)
+    o = torch.zeros(T, Hq, D)
+    context_attention_fwd(q, kc, vc, o, req, start, seq_len, pcl, max(chunk), table)
+    save("prefill_attention", q=bits(q), k=bits(kc), v=bits(vc), table=table.numpy(), req=req.numpy(), start=start.numpy(),
+         seq_len=seq_len.numpy(), pcl=pcl.numpy(), o=o.numpy())
+
+
 GROUPS = {
     "decode": gen_decode,
     "h2o_select": gen_h2o_select,
@@ -791,6 +814,7 @@ GROUPS = {
     "kivi": gen_kivi,
     "deltakv_view": gen_deltakv_view,
     "deltakv_compress": gen_deltakv_compress,
+    "prefill_attention": gen_prefill_attention,
 }
 
 
