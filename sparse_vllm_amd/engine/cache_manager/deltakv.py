@@ -20,8 +20,10 @@ Data model (one pool per layer *kind*, shared slot ids across the layers of a ki
 Sparse-layer decode: static plan -> residual load (dequant + compress_up) -> reconstruct + RoPE write-back into
 temp slots -> contiguous attention view (raw K rotated on the way) -> ordinary stage 1 / stage 2.
 
-The compression side (deltakv_evict, KIVI block store) is SURVEY section 8(f).3; until it lands compressed rows are
-ingested through `admit_compressed_row` (synthetic or externally produced state).
+Compression side: `deltakv_evict` compresses `recent` tokens of a row's raw tail every `recent`
+decode steps (centres, causal L2 top-k fathers, compress_down residual, int4 pack) and `_full_layer_kivi_evict` moves
+full-layer rows that left the residual window into KIVI blocks.  Prompts are still ingested already compressed
+(`admit_compressed_row`): the prefill-time bulk compression is SURVEY section 8(f).3.
 """
 
 from __future__ import annotations
