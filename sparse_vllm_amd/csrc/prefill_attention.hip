@@ -11,6 +11,8 @@
 //           B-operand token order and MFMA i takes head dim n*8+i as its column (byte permutes), so a lane's
 //           accumulator is 8 consecutive head dims of 4 query rows -> 16-byte bf16 output stores.
 
+#include <type_traits>
+
 #include "svk_common.hpp"
 
 namespace svk {
@@ -19,6 +21,13 @@ namespace {
 constexpr int kQTile = 32;      // query tokens per wave
 constexpr int kKTile = 32;      // keys per iteration
 constexpr int kPRowP = 40;      // P tile row stride (bf16), 16-byte aligned rows
+
+typedef __attribute__((ext_vector_type(2))) __bf16 pa_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float pa_f32x2_t;
+__device__ __forceinline__ uint32_t pack_bf16_pair(float lo, float hi) {
+  const pa_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pa_bf16x2_t));      // v_cvt_pk_bf16_f32 (RNE)
+}
 
 template <int D>
 __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContextAttentionArgs a) {
@@ -38,7 +47,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
   const int start_loc = a.b_start_loc[b];
   const int kv_end = min(m0 + kQTile + pc, q_len + pc);       // keys visible to the last query of the block
   // per-wave LDS: P tile [32][kPRowP] bf16 | 32 slot ids
-  uint16_t* Pl = reinterpret_cast<uint16_t*>(lds_raw + (size_t)w * (kQTile * kPRowP * 2 + 128));
+  uint16_t* Pl = reinterpret_cast<uint16_t*>(lds_raw + (size_t)w * (kQTile * kPRowP * 2 + 256));
   int* slot_lds = reinterpret_cast<int*>(Pl + kQTile * kPRowP);
   const int32_t* row = a.req_to_tokens + (int64_t)a.b_req_idx[b] * a.req_stride;
 
@@ -63,59 +72,94 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
   }
   const uint16_t* kbase = a.k_cache + (int64_t)kvh * a.kv_head_stride + kc * 8;
   const uint16_t* vbase = a.v_cache + (int64_t)kvh * a.kv_head_stride + dg * 8;
-
-  for (int k0 = 0; k0 < kv_end; k0 += kKTile) {
-    // slot ids of the tile (clamped: masked keys still read a legal row)
-    if (lane < kKTile) slot_lds[lane] = row[min(k0 + lane, kv_end - 1)];
+  uint32_t* Pl32 = reinterpret_cast<uint32_t*>(Pl);
+  auto wave_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint4 kr[2][NC], vr[8];
+  };
+  // slot ids of one key tile: lanes 0..31 read row[k0 + lane], clamped to the last visible key (always a legal row)
+  auto fetch_slots = [&](int k0) -> int { return row[min(k0 + (lane & 31), kv_end - 1)]; };
+  // The k index j of the second product maps to key column (j & 1) * 16 + (j >> 1), so the two probabilities a lane
+  // holds for one query row (columns n and 16 + n) are neighbours in the P tile: one packed 32-bit LDS store per row.
+  const int vcol0 = kc * 4;                          // V row of k index kc*8 + e: column (e & 1) * 16 + kc*4 + (e >> 1)
+
+  // ---- prologue: tile 0 slot ids -> LDS, tile 1 ids parked in a register, K(0) in flight
+  if (lane < kKTile) slot_lds[lane] = fetch_slots(0);
+  int s_next = fetch_slots(kKTile);
+  wave_sync();
+  uint4 kr[2][NC];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const uint16_t* kp = kbase + (int64_t)slot_lds[g * 16 + n] * a.kv_slot_stride;
+  for (int g = 0; g < 2; ++g) {
+    const uint16_t* kp = kbase + (int64_t)slot_lds[g * 16 + n] * a.kv_slot_stride;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) kr[g][c] = *reinterpret_cast<const uint4*>(kp + c * 32);
-    }
+    for (int c = 0; c < NC; ++c) kr[g][c] = *reinterpret_cast<const uint4*>(kp + c * 32);
+  }
+  int k0 = 0, buf = 0;
+  // one key tile; the last one is peeled (compile-time flag) so the K(i+1) re-arm is straight-line code
+  auto tile = [&](auto has_next_c) {
+    constexpr bool has_next = decltype(has_next_c)::value;
+    const int* cur = slot_lds + buf * 32;
+    int* nxt = slot_lds + (buf ^ 1) * 32;
+    // ---- V(i) loads; publish tile i+1's ids, fetch tile i+2's
+    uint4 vr[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) vr[e] = *reinterpret_cast<const uint4*>(vbase + (int64_t)slot_lds[kc * 8 + e] * a.kv_slot_stride);
-    // ---- S = Q K^T, mask, online softmax (rows = queries m0 + t*16 + kc*4 + r, columns = keys k0 + g*16 + n)
+    for (int e = 0; e < 8; ++e)
+      vr[e] = *reinterpret_cast<const uint4*>(vbase + (int64_t)cur[(e & 1) * 16 + vcol0 + (e >> 1)] * a.kv_slot_stride);
+    if (lane < kKTile) nxt[lane] = s_next;
+    s_next = fetch_slots(k0 + 2 * kKTile);
+    // ---- S = Q K^T for both query tiles, then the K registers are dead: re-arm them with K(i+1)
+    f32x4_t s[2][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f32x4_t s[2];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        s[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        s[t][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-          s[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t][c], __builtin_bit_cast(bf16x8_t, kr[g][c]), s[g], 0, 0, 0);
+          s[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t][c], __builtin_bit_cast(bf16x8_t, kr[g][c]), s[t][g], 0, 0, 0);
       }
-      float alpha[4];
+    wave_sync();
+    if constexpr (has_next) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint16_t* kp = kbase + (int64_t)nxt[g * 16 + n] * a.kv_slot_stride;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) kr[g][c] = *reinterpret_cast<const uint4*>(kp + c * 32);
+      }
+    }
+    // ---- mask + base-2 online softmax (rows = queries m0 + t*16 + kc*4 + r, columns = keys k0 + g*16 + n)
+    const bool diag = k0 + kKTile > m0 + pc;          // only tiles touching the diagonal / the end need the mask
+    bool rescale = false;
+    float alpha[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qrow = m0 + t * 16 + kc * 4 + r;
-        float x[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int key = k0 + g * 16 + n;
-          x[g] = (key <= qrow + pc && key < kv_end) ? s[g][r] * sm_scale : -1.0e8f;
+        float x0 = s[t][0][r] * sm_scale, x1 = s[t][1][r] * sm_scale;
+        if (diag) {
+          const int key = k0 + n;
+          if (!(key <= qrow + pc && key < kv_end)) x0 = -1.0e8f;
+          if (!(key + 16 <= qrow + pc && key + 16 < kv_end)) x1 = -1.0e8f;
         }
-        const float nm = fmaxf(m[t][r], row16_allmax(fmaxf(x[0], x[1])));
-        const float p0 = __builtin_amdgcn_exp2f(x[0] - nm), p1 = __builtin_amdgcn_exp2f(x[1] - nm);
-        alpha[r] = __builtin_amdgcn_exp2f(m[t][r] - nm);
-        l[t][r] = l[t][r] * alpha[r] + row16_allsum(p0 + p1);
+        const float nm = fmaxf(m[t][r], row16_allmax(fmaxf(x0, x1)));
+        const float p0 = __builtin_amdgcn_exp2f(x0 - nm), p1 = __builtin_amdgcn_exp2f(x1 - nm);
+        alpha[t][r] = __builtin_amdgcn_exp2f(m[t][r] - nm);
+        rescale |= (nm != m[t][r]);
+        l[t][r] = l[t][r] * alpha[t][r] + row16_allsum(p0 + p1);
         m[t][r] = nm;
-        Pl[(t * 16 + kc * 4 + r) * kPRowP + n] = (uint16_t)f32_to_bf16_bits(p0);
-        Pl[(t * 16 + kc * 4 + r) * kPRowP + 16 + n] = (uint16_t)f32_to_bf16_bits(p1);
+        Pl32[(t * 16 + kc * 4 + r) * (kPRowP / 2) + n] = pack_bf16_pair(p0, p1);
       }
+    if (__any(rescale)) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][i][r] *= alpha[r];
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][i][r] *= alpha[t][r];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_sync();
     // ---- O += P V
     {
       bf16x8_t pf[2];
@@ -134,9 +178,12 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
         acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[1], vb, acc[1][i], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
+    wave_sync();
+    k0 += kKTile;
+    buf ^= 1;
+  };
+  while (k0 + kKTile < kv_end) tile(std::true_type{});
+  tile(std::false_type{});
   // ---- epilogue: lane (n, kc) owns query rows t*16 + kc*4 + r and head dims dg*8 .. +8
   if (n < DW) {
 #pragma unroll
@@ -173,7 +220,7 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
               SVK_ERR_LAYOUT, "svk_context_attention_fwd: q/k/v/o strides must keep 16-byte alignment");
   if (a->batch <= 0 || a->max_input_len <= 0) return SVK_OK;
   dim3 grid((a->max_input_len + kQTile - 1) / kQTile, a->num_kv_heads, a->batch), block(64 * G);
-  const size_t shm = (size_t)G * (kQTile * kPRowP * 2 + 128);
+  const size_t shm = (size_t)G * (kQTile * kPRowP * 2 + 256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (a->head_dim == 128) hipLaunchKernelGGL(context_attention_kernel<128>, grid, block, shm, s, *a);
   else hipLaunchKernelGGL(context_attention_kernel<64>, grid, block, shm, s, *a);
