@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
         const float p0 = __builtin_amdgcn_exp2f(x0 - nm), p1 = __builtin_amdgcn_exp2f(x1 - nm);
         alpha[t][r] = __builtin_amdgcn_exp2f(m[t][r] - nm);
         rescale |= (nm != m[t][r]);
-        l[t][r] = l[t][r] * alpha[t][r] + row16_allsum(p0 + p1);
+        l[t][r] = l[t][r] * alpha[t][r] + (p0 + p1);      // lane-partial row sum: reduced across the 16 columns once, in the epilogue
         m[t][r] = nm;
         Pl32[(t * 16 + kc * 4 + r) * (kPRowP / 2) + n] = pack_bf16_pair(p0, p1);
       }
@@ -185,6 +185,10 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
   while (k0 + kKTile < kv_end) tile(std::true_type{});
   tile(std::false_type{});
   // ---- epilogue: lane (n, kc) owns query rows t*16 + kc*4 + r and head dims dg*8 .. +8
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) l[t][r] = row16_allsum(l[t][r]);       // all 64 lanes take part in the DPP reduction
   if (n < DW) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
