@@ -223,11 +223,11 @@ class SparseDecodeDriver:
 
     # ------------------------------------------------------------------ one prefill chunk
     @torch.no_grad()
-    def prefill_chunk(self, seqs, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
+    def prefill_chunk(self, seqs, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None):
         """The sparse side of one chunked-prefill step (ModelRunner.run prefill branch,
         model_runner.py:1447-1481): allocate the chunk, store its K/V, collect the method's prefill
-        token scores with the chunk's queries, then the post-forward eviction.  The prefill
-        attention output itself (context_attention_fwd) is outside this round's scope.
+        token scores with the chunk's queries, then the post-forward eviction.  With `outputs`
+        [L, tokens, Hq, D] the chunk's causal attention (context_attention_fwd) is computed too.
         q [L, tokens, Hq, D], k/v [L, tokens, Hkv, D]; every seq needs `current_chunk_size`."""
         cm, sc = self.cache_manager, self.sparse_controller
         out = cm._prepare_prefill(seqs)
@@ -236,11 +236,14 @@ class SparseDecodeDriver:
             lens = [int(s.current_chunk_size) for s in seqs]
             cu = torch.tensor(np.concatenate(([0], np.cumsum(lens))).astype(np.int32), device=self.device)
         ctx = set_context(True, cu_seqlens_q=cu, cache_manager=cm, sparse_controller=sc)
+        ctx.max_chunk_len = max(int(s.current_chunk_size) for s in seqs)
         sc.prepare_forward(seqs, True)
         collect = getattr(cm, "collect_prefill_attention_score", None)
         for layer_idx in range(cm.num_layers):
             ctx.now_layer_idx = layer_idx
             cm.save_rope_kv_if_needed(layer_idx, k[layer_idx], v[layer_idx])
+            if outputs is not None:
+                outputs[layer_idx].copy_(self.attn(q[layer_idx]))
             if collect is not None:
                 collect(layer_idx, q[layer_idx], seqs, b_start_loc=cu[:-1])
         sc.post_forward(seqs, True)

@@ -13,6 +13,7 @@ import torch
 
 from ..engine.cache_manager.base import DecodeComputeView, ExplicitKVPayload
 from ..kernels import flash_decode_stage1, flash_decode_stage1_with_score, flash_decode_stage2
+from ..kernels.context_flashattention_nopad import context_attention_fwd
 from ..kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1
 from ..utils.context import get_context
 from ..utils.profiler import profiler
@@ -100,7 +101,25 @@ class Attention(torch.nn.Module):
         sparse_controller = context.sparse_controller
         layer_idx = context.now_layer_idx
         if context.is_prefill:
-            raise NotImplementedError("prefill attention is outside this round's scope (SURVEY.md 8(f).1)")
+            # layers/attention.py:88-140 + attention_backend.py:113-155 (`run_prefill`): causal attention of the chunk's
+            # queries over the sequence's physical row (cached prefix + the chunk just stored)
+            if context.cu_seqlens_q is None or context.cu_seqlens_q.numel() <= 1:
+                return torch.empty_like(q)
+            st = cache_manager.get_layer_batch_states(layer_idx)
+            k_cache, v_cache = cache_manager.get_layer_kv_cache(layer_idx)
+            b_start_loc = context.cu_seqlens_q[:-1].to(torch.int32)
+            chunk_lens = (context.cu_seqlens_q[1:] - context.cu_seqlens_q[:-1]).to(torch.int32)
+            b_seq_len = st.context_lens
+            if b_seq_len.numel() != chunk_lens.numel():
+                raise RuntimeError("prefill context_lens/chunk_lens batch mismatch: "
+                                   f"layer={layer_idx} context_lens_shape={tuple(b_seq_len.shape)} "
+                                   f"chunk_lens_shape={tuple(chunk_lens.shape)} q_shape={tuple(q.shape)}")
+            o = torch.empty_like(q)
+            with profiler.record("prefill_attention"):
+                context_attention_fwd(q, k_cache, v_cache, o, st.req_indices, b_start_loc, b_seq_len, b_seq_len - chunk_lens,
+                                      int(context.max_chunk_len or q.shape[0]),
+                                      cache_manager.get_layer_buffer_req_to_token_slots(layer_idx))
+            return o
         temp_slots = None
         try:
             batch_size = q.shape[0]

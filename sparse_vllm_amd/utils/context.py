@@ -18,6 +18,7 @@ class Context:
     decode_mid_o: torch.Tensor | None = None
     decode_mid_o_logexpsum: torch.Tensor | None = None
     is_long_text: bool = False
+    max_chunk_len: int | None = None       # host-known longest chunk of a prefill step (avoids a device sync)
 
 
 _CONTEXT = Context()

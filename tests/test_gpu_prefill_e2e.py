@@ -4,7 +4,9 @@ eviction; SnapKV final-chunk selection) against the oracle driven chunk by chunk
 import numpy as np
 import pytest
 
+from oracle import bf16_round
 from oracle import h2o as oh
+from oracle import prefill_attention as opa
 from oracle import prefill_score as ops
 
 pytestmark = pytest.mark.gpu
@@ -67,8 +69,10 @@ def test_h2o_chunked_prefill_matches_oracle(prompts, mode):
         v = (torch.randn(L, tot, Hkv, D, generator=g) * 0.4).to(torch.bfloat16).to(drv.device)
         finals = [bool(s.is_last_chunk_prefill) for s in active]
         chunk_lens = [s.current_chunk_size for s in active]
-        drv.prefill_chunk(active, q, k, v)
+        outs = torch.zeros_like(q)
+        drv.prefill_chunk(active, q, k, v, outputs=outs)
         torch.cuda.synchronize()
+        got_o = _f(outs)
         rows_all = {s.seq_id: cm.seq_id_to_row[0][s.seq_id] for s in seqs if s.seq_id in cm.seq_id_to_row[0]}
         arows = [rows_all[s.seq_id] for s in active]
         # ---------------- oracle chunk
@@ -86,6 +90,9 @@ def test_h2o_chunked_prefill_matches_oracle(prompts, mode):
                 cache.append(prev)
             ctx = np.array(ctx, np.int32)
             cache = np.array(cache, np.int32)
+            # the chunk's causal attention over the (already compressed) physical row: cached prefix + this chunk
+            ref_o = opa.context_attention_fwd(qn[l], kc[l], vc[l], np.array(arows, np.int32), starts, ctx, cache, st.slot_table[l])
+            np.testing.assert_allclose(got_o[l], bf16_round(ref_o), rtol=2e-2, atol=2e-2, err_msg=f"prefill attention layer {l} step {step}")
             qs = np.maximum(cache, ctx - window).astype(np.int32)
             stepsc = np.empty((len(active), int(ctx.max())), np.float32)
             ops.prefill_score_fwd(qn[l], kc[l], stepsc, np.array(arows, np.int32), starts, ctx, cache,
