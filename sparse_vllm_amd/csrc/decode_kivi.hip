@@ -4,9 +4,12 @@
 // (per-channel scale/min: one 16-byte load per 8 channels; codes: one 4-byte word per channel, shared by
 // the 8 tokens of a word), V words (8 codes = 8 head dims of one token) match the P.V lane layout 1:1.
 
+#include <stdlib.h>
+
 #include "svk_common.hpp"
 
 namespace svk {
+int launch_kivi_lds(const SvkKiviDecodeStage1Args& a, hipStream_t s);      // decode_kivi_lds.hip
 namespace {
 
 constexpr int kTile = 32;
@@ -667,6 +670,10 @@ int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
   const int nblk = (a.max_len_in_batch + a.block_seq - 1) / a.block_seq;
   dim3 grid(nblk, a.batch), block(64 * a.num_kv_heads);
   const size_t shm = sizeof(float) * a.num_kv_heads * (kTile * (((G + 3) / 4) * 4) + 16);
+  // 2 = register-staged 128-token tiles (default); 3 = LDS-DMA staged pipeline (decode_kivi_lds.hip): measured slower so far
+  // (582 vs 353 us at B=4 x 256k: 256 VGPRs + 50 KiB LDS leave 6 waves/CU and the waits did not shrink), opt-in for A/B runs
+  static const int variant = getenv("SVK_KIVI_VARIANT") ? atoi(getenv("SVK_KIVI_VARIANT")) : 2;
+  if (a.group_size == 32 && variant == 3) return launch_kivi_lds(a, s);
   if (a.group_size == 32) {
     // 128-token tiles, both products on the matrix cores
     const size_t shm_t = (size_t)a.num_kv_heads * (16 * 128 * 2 + 2 * (D / 32) * 128 * 2);
