@@ -186,6 +186,112 @@ __global__ void __launch_bounds__(256) deltakv_reconstruct_kernel(const SvkDelta
   a.v_cache[ob + HD2] = (uint16_t)f32_to_bf16_bits(v2);
 }
 
+// 16-byte-lane form of the reconstruct kernel for the decode path (dense bf16 delta = compress_up output, bf16 cache,
+// fp32 cos|sin): D/16 lanes per (entry, head), each owning elements p..p+7 of both rotate-half partners, so every father
+// row is fetched as 16-byte pieces (4 loads per father per lane instead of 32 two-byte ones).  Element arithmetic and
+// order are those of the scalar kernel above; only the k-norm sum of squares is reduced in a different order.
+template <int D>
+__global__ void __launch_bounds__(256) deltakv_reconstruct_vec_kernel(const SvkDeltakvReconstructArgs a) {
+  constexpr int HD2 = D / 2, LPH = HD2 / 8;
+  const int H = a.num_kv_heads;
+  const int lanes_per_entry = LPH * H;
+  const int entries_per_block = blockDim.x / lanes_per_entry;
+  const int e = threadIdx.x / lanes_per_entry;
+  const int n = blockIdx.x * entries_per_block + e;
+  const int t = threadIdx.x % lanes_per_entry;
+  const int h = t / LPH, p = (t % LPH) * 8;
+  bool active = e < entries_per_block && n < a.n;
+  int out_slot = 0, out_pos = 0;
+  if (active) {
+    out_slot = a.out_slots[n];
+    out_pos = a.out_pos[n];
+    active = out_slot >= 0 && out_pos >= 0;
+  }
+  auto up8 = [](const uint4& v, float (&f)[8]) {
+    f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+    f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z); f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+  };
+  auto ld8f = [](const float* q, float (&f)[8]) {
+    const float4 x = *reinterpret_cast<const float4*>(q), y = *reinterpret_cast<const float4*>(q + 4);
+    f[0] = x.x; f[1] = x.y; f[2] = x.z; f[3] = x.w; f[4] = y.x; f[5] = y.y; f[6] = y.z; f[7] = y.w;
+  };
+  float k1[8], k2[8], v1[8], v2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k1[i] = k2[i] = v1[i] = v2[i] = 0.f;
+  if (active) {
+    float ak1[8], ak2[8], av1[8], av2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ak1[i] = ak2[i] = av1[i] = av2[i] = 0.f;
+    const int32_t* fathers = a.father_table ? a.father_table + (int64_t)max(a.father_index[n], 0) * a.father_table_stride
+                                            : a.father_slots + (int64_t)n * a.father_stride;
+    for (int kk = 0; kk < a.k_fathers; ++kk) {
+      const int fs = a.father_table ? max(fathers[kk], 0) : fathers[kk];
+      const int64_t base = (int64_t)fs * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
+      float y1[8], y2[8], w1[8], w2[8];
+      up8(*reinterpret_cast<const uint4*>(a.k_cache + base), y1);
+      up8(*reinterpret_cast<const uint4*>(a.k_cache + base + HD2), y2);
+      up8(*reinterpret_cast<const uint4*>(a.v_cache + base), w1);
+      up8(*reinterpret_cast<const uint4*>(a.v_cache + base + HD2), w2);
+      if (a.raw_k_cache) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ak1[i] += y1[i]; ak2[i] += y2[i]; }
+      } else {
+        const int fp = a.slot_to_pos[fs];
+        float c[8], sn[8];
+        ld8f(reinterpret_cast<const float*>(a.cos_sin) + (int64_t)fp * a.cos_stride + p, c);
+        ld8f(reinterpret_cast<const float*>(a.cos_sin) + (int64_t)fp * a.cos_stride + p + HD2, sn);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ak1[i] += y1[i] * c[i] + y2[i] * sn[i]; ak2[i] += y2[i] * c[i] - y1[i] * sn[i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { av1[i] += w1[i]; av2[i] += w2[i]; }
+    }
+    const float inv = 1.0f / (float)a.k_fathers;
+    const int Dtot = H * D;
+    const uint16_t* dl = reinterpret_cast<const uint16_t*>(a.delta) + (int64_t)n * a.delta_stride + h * D + p;
+    float d1[8], d2[8], e1[8], e2[8];
+    up8(*reinterpret_cast<const uint4*>(dl), d1);
+    up8(*reinterpret_cast<const uint4*>(dl + HD2), d2);
+    up8(*reinterpret_cast<const uint4*>(dl + Dtot), e1);
+    up8(*reinterpret_cast<const uint4*>(dl + Dtot + HD2), e2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      k1[i] = d1[i] + ak1[i] * inv; k2[i] = d2[i] + ak2[i] * inv;
+      v1[i] = e1[i] + av1[i] * inv; v2[i] = e2[i] + av2[i] * inv;
+    }
+  }
+  if (a.k_norm_weight != nullptr && !a.store_raw_k) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += k1[i] * k1[i] + k2[i] * k2[i];
+#pragma unroll
+    for (int off = 1; off < LPH; off <<= 1) ss += __shfl_xor(ss, off, 64);
+    const float rstd = rsqrtf(ss / (float)D + a.k_norm_eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { k1[i] = k1[i] * rstd * a.k_norm_weight[p + i]; k2[i] = k2[i] * rstd * a.k_norm_weight[p + HD2 + i]; }
+  }
+  if (!active) return;
+  float o1[8], o2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { o1[i] = k1[i]; o2[i] = k2[i]; }
+  if (!a.store_raw_k) {
+    float c[8], sn[8];
+    ld8f(reinterpret_cast<const float*>(a.cos_sin) + (int64_t)out_pos * a.cos_stride + p, c);
+    ld8f(reinterpret_cast<const float*>(a.cos_sin) + (int64_t)out_pos * a.cos_stride + p + HD2, sn);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { o1[i] = k1[i] * c[i] - k2[i] * sn[i]; o2[i] = k2[i] * c[i] + k1[i] * sn[i]; }
+  }
+  auto pk8 = [](const float (&f)[8]) {
+    return make_uint4(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16), f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16),
+                      f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16), f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16));
+  };
+  const int64_t ob = (int64_t)out_slot * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
+  *reinterpret_cast<uint4*>(a.k_cache + ob) = pk8(o1);
+  *reinterpret_cast<uint4*>(a.k_cache + ob + HD2) = pk8(o2);
+  *reinterpret_cast<uint4*>(a.v_cache + ob) = pk8(v1);
+  *reinterpret_cast<uint4*>(a.v_cache + ob + HD2) = pk8(v2);
+}
+
 // ------------------------------------------------------------------------------------
 // observation-layer token scores
 // ------------------------------------------------------------------------------------
@@ -408,6 +514,17 @@ extern "C" int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs
                 "svk_deltakv_reconstruct_writeback: packed residuals need latent_slots, scale and mn");
   }
   if (a->n <= 0) return SVK_OK;
+  // decode path: dense bf16 delta, fp32 cos|sin, 16-byte aligned rows -> 16-byte lanes
+  if (a->delta_bits == 0 && a->delta_dtype == SVK_DTYPE_BF16 && a->cos_dtype == SVK_DTYPE_F32 && (a->head_dim == 64 || a->head_dim == 128) &&
+      a->num_kv_heads <= 8 && a->delta_stride % 8 == 0 && a->kv_slot_stride % 8 == 0 && a->kv_head_stride % 8 == 0 && a->cos_stride % 4 == 0 &&
+      reinterpret_cast<uintptr_t>(a->delta) % 16 == 0 && reinterpret_cast<uintptr_t>(a->cos_sin) % 16 == 0) {
+    const int lpe = (a->head_dim / 16) * a->num_kv_heads;
+    const int epb2 = 256 / lpe;
+    const dim3 grid((a->n + epb2 - 1) / epb2), block(256);
+    if (a->head_dim == 128) hipLaunchKernelGGL(deltakv_reconstruct_vec_kernel<128>, grid, block, 0, static_cast<hipStream_t>(stream), *a);
+    else hipLaunchKernelGGL(deltakv_reconstruct_vec_kernel<64>, grid, block, 0, static_cast<hipStream_t>(stream), *a);
+    return check_launch("svk_deltakv_reconstruct_writeback");
+  }
   int threads = per_entry;
   if (threads < 256) threads = (256 / per_entry) * per_entry;
   const int epb = threads / per_entry;
