@@ -1061,14 +1061,15 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a, const SvkH2oDecodeScor
   if constexpr (FUSED) fused_row_finish<D>(a, fs, fo, fo_stride_b, fo_stride_h, tickets, b, lds);
 }
 
-template <int D>
-__global__ void __launch_bounds__(256)
+template <int D, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
-  // one (batch lane, q head) per workgroup.  D/4 lanes cover one partial row with 16-byte loads; the 256/(D/4)
-  // lane groups walk the split-KV partials interleaved (long contexts have ~1000 of them), each with its own
-  // running (max, sum, acc); the groups are merged through LDS at the end.
-  constexpr int LPR = D / 4, GROUPS = 256 / LPR;
-  __shared__ float s_m[GROUPS], s_l[GROUPS];
+  // one (batch lane, q head) per workgroup.  D/4 lanes cover one partial row with 16-byte loads; the THREADS/(D/4)
+  // lane groups walk the split-KV partials interleaved (long contexts have ~1000 of them).  The row's maximum lse is
+  // found first, so the weighted sum has no loop-carried exp chain and the partial loads stay in flight together
+  // (the online form cost one HBM latency per partial: 41 us at 1025 partials).
+  constexpr int LPR = D / 4, GROUPS = THREADS / LPR, WAVES = THREADS / 64;
+  __shared__ float s_red[WAVES], s_l[GROUPS];
   __shared__ __attribute__((aligned(16))) float s_acc[GROUPS][D];
   const int b = blockIdx.x, h = blockIdx.y;
   const int g = threadIdx.x / LPR, d = (threadIdx.x % LPR) * 4;
@@ -1076,34 +1077,35 @@ decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
   const int nblk = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq;
   const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h + d;
   const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
-  float sum = 0.f, mx = -INFINITY;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < nblk; i += THREADS) mx = fmaxf(mx, ml[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if constexpr (WAVES > 1) {
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) mx = fmaxf(mx, s_red[w]);
+  }
+  float sum = 0.f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
   for (int i = g; i < nblk; i += GROUPS) {
     const float4 tv = *reinterpret_cast<const float4*>(mo + (int64_t)i * a.mid_o_stride_s);
-    const float tl = ml[i];
-    const float nm = fmaxf(tl, mx);
-    const float os = __expf(mx - nm);
-    const float e = __expf(tl - nm);
-    acc.x = acc.x * os + e * tv.x; acc.y = acc.y * os + e * tv.y;
-    acc.z = acc.z * os + e * tv.z; acc.w = acc.w * os + e * tv.w;
-    sum = sum * os + e;
-    mx = nm;
+    const float e = __expf(ml[i] - mx);
+    acc.x += e * tv.x; acc.y += e * tv.y; acc.z += e * tv.z; acc.w += e * tv.w;
+    sum += e;
   }
   if (nblk > 1) {
-    if (d == 0) { s_m[g] = mx; s_l[g] = sum; }
+    if (d == 0) s_l[g] = sum;
     *reinterpret_cast<float4*>(&s_acc[g][d]) = acc;
     __syncthreads();
     if (g != 0) return;
     const int used = min(nblk, GROUPS);
     for (int j = 1; j < used; ++j) {
-      const float tm = s_m[j];
-      const float nm = fmaxf(tm, mx);
-      const float os = __expf(mx - nm), e = __expf(tm - nm);
       const float4 tv = *reinterpret_cast<const float4*>(&s_acc[j][d]);
-      acc.x = acc.x * os + e * tv.x; acc.y = acc.y * os + e * tv.y;
-      acc.z = acc.z * os + e * tv.z; acc.w = acc.w * os + e * tv.w;
-      sum = sum * os + e * s_l[j];
-      mx = nm;
+      acc.x += tv.x; acc.y += tv.y; acc.z += tv.z; acc.w += tv.w;
+      sum += s_l[j];
     }
   } else if (g != 0) {
     return;
@@ -1267,7 +1269,14 @@ extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_st
   if (a->batch <= 0) return SVK_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(a->batch, a->num_q_heads);
-  if (a->head_dim == 128) hipLaunchKernelGGL((decode_stage2_kernel<128>), grid, dim3(256), 0, s, *a);
-  else hipLaunchKernelGGL((decode_stage2_kernel<64>), grid, dim3(256), 0, s, *a);
+  // the lse row stride is the workspace's partial capacity: long-context workspaces get 1024 threads per (b, head)
+  const bool wide = a->mid_lse_stride_h >= 256;
+  if (a->head_dim == 128) {
+    if (wide) hipLaunchKernelGGL((decode_stage2_kernel<128, 1024>), grid, dim3(1024), 0, s, *a);
+    else hipLaunchKernelGGL((decode_stage2_kernel<128, 256>), grid, dim3(256), 0, s, *a);
+  } else {
+    if (wide) hipLaunchKernelGGL((decode_stage2_kernel<64, 1024>), grid, dim3(1024), 0, s, *a);
+    else hipLaunchKernelGGL((decode_stage2_kernel<64, 256>), grid, dim3(256), 0, s, *a);
+  }
   return check_launch("svk_flash_decode_stage2");
 }

@@ -69,12 +69,20 @@ __global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDec
     const int b = blockIdx.x;
     float* x = a.attn_score + (int64_t)b * a.score_stride_b;
     const int W = a.width;
-    float v[EPT];
+    // the cumulative row's old values are fetched together with the raw scores, not after the two reductions
+    float* cum = nullptr;
+    int len = 0;
+    if (a.cum_score != nullptr) {
+      cum = a.cum_score + (int64_t)a.b_req_idx[b] * a.cum_stride;
+      len = a.b_seqlen[b];
+    }
+    float v[EPT], c[EPT];
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int t = threadIdx.x + i * 1024;
       v[i] = t < W ? mul_rn(x[t], a.scale) : -INFINITY;
+      c[i] = (cum != nullptr && t < len - 1) ? cum[t] : 0.f;
       mx = fmaxf(mx, v[i]);
     }
     mx = block_allmax(mx, red);
@@ -85,19 +93,13 @@ __global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDec
       sum += v[i];
     }
     sum = block_allsum(sum, red);
-    float* cum = nullptr;
-    int len = 0;
-    if (a.cum_score != nullptr) {
-      cum = a.cum_score + (int64_t)a.b_req_idx[b] * a.cum_stride;
-      len = a.b_seqlen[b];
-    }
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int t = threadIdx.x + i * 1024;
       if (t < W) {
         const float p = v[i] / sum;
         x[t] = p;
-        if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : cum[t] + p;
+        if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : c[i] + p;   // pad(prev, 1) + p
       }
     }
     return;

@@ -175,6 +175,9 @@ class SparseDecodeDriver:
                 on_layer_end(layer_idx, ctx)
             if outputs is not None:
                 outputs[layer_idx].copy_(o)
+        join = getattr(sc, "join_side_streams", None)
+        if join is not None:
+            join()
 
     def enable_decode_graph(self):
         """hipGraph replay of the per-step layer loop (the reference's DecodeCudaGraphRunner,

@@ -54,6 +54,11 @@ class SparseController:
         # is opt-in; kept because it halves the launches for callers that are launch-bound.
         self._fused_h2o_layer = os.environ.get("SVK_H2O_FUSED_LAYER", "0") == "1"
         self._layer_score_finished = [False] * self.num_layers
+        # MI355X: the per-layer H2O score epilogue (scale + softmax + accumulate) has no consumer until the step's
+        # eviction check, so it may run on a side stream beside the next layers (joined in `join_side_streams`)
+        self._h2o_score_stream_enabled = os.environ.get("SVK_H2O_SCORE_STREAM", "0") == "1"
+        self._h2o_score_stream = None
+        self._h2o_score_stream_used = False
         self.is_deltakv_family = self.sparse_method == "deltakv"
         self.obs_layer_ids = list(getattr(config, "obs_layer_ids", None) or [])
         self.full_attn_layers = list(getattr(config, "full_attn_layers", None) or [])
@@ -240,7 +245,7 @@ class SparseController:
         """MI355X fusion hook called by the attention backend instead of `flash_decode_stage2`:
         for H2O decode, stage 2 and this layer's `on_layer_attention_end` score epilogue run as
         one launch (svk_h2o_decode_finish).  Returns False when there is nothing to fuse."""
-        if self.sparse_method != "h2o" or get_context().is_prefill:
+        if self.sparse_method != "h2o" or get_context().is_prefill or self._h2o_score_stream_enabled:
             return False
         s = self.layer_batch_sparse_states[layer_idx]
         if s.attn_score is None or s.attn_score.dim() != 2:
@@ -272,8 +277,25 @@ class SparseController:
                                f"layer={layer_idx} shape={tuple(s.attn_score.shape)}.")
         cm = self.cache_manager
         cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
+        if self._h2o_score_stream_enabled and s.attn_score.is_cuda:
+            if self._h2o_score_stream is None:
+                self._h2o_score_stream = torch.cuda.Stream(device=s.attn_score.device)
+            side = self._h2o_score_stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                h2o_ops.h2o_decode_score_update(s.attn_score, self.attn_softmax_scale, cum_score=cum,
+                                                b_req_idx=s.req_indices, b_seqlen=s.context_lens)
+            self._h2o_score_stream_used = True
+            return
         h2o_ops.h2o_decode_score_update(s.attn_score, self.attn_softmax_scale, cum_score=cum,
                                         b_req_idx=s.req_indices, b_seqlen=s.context_lens)
+
+    def join_side_streams(self):
+        """Make the current stream wait for the side-stream score epilogues of this step (end of the layer loop,
+        inside graph capture when the step is captured)."""
+        if self._h2o_score_stream_used:
+            torch.cuda.current_stream().wait_stream(self._h2o_score_stream)
+            self._h2o_score_stream_used = False
 
     # ------------------------------------------------------------------ DeltaKV query-aware top-k
     @torch.no_grad()
