@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
 // keep the per-row dependency chain short (the score rows are latency-, not bandwidth-bound).
 // ------------------------------------------------------------------------------------
 
-template <int EPT>
+template <int EPT, int PW>
 __global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDecodeFinishArgs f) {
   __shared__ float red[16];
   const int B = f.score.batch;
@@ -104,20 +104,29 @@ __global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDec
     }
     return;
   }
-  // ---- stage 2 (flash_decoding_stage2.py:19-46): wave -> (b, h), lane -> 2 (D=128) or 1 (D=64) dims
+  // ---- stage 2 (flash_decoding_stage2.py:19-46): PW waves per (b, h) pair, each taking every PW-th partial;
+  //      lane -> 2 (D=128) or 1 (D=64) dims.  The row maximum of the partial lse's comes first, so the weighted sum
+  //      has no exp chain between iterations and the partial loads are in flight together (small batches split a
+  //      row into 64+ partials: 27 us with the online form and one wave per pair).
+  __shared__ float s_part[16][3 * 64];
   const SvkFlashDecodeStage2Args& a = f.stage2;
-  const int pair = ((int)blockIdx.x - B) * 16 + (threadIdx.x >> 6);
-  if (pair >= a.batch * a.num_q_heads) return;
-  const int b = pair / a.num_q_heads, h = pair % a.num_q_heads;
-  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pair = ((int)blockIdx.x - B) * (16 / PW) + wv / PW;
+  const int sub = wv % PW;
+  const bool live = pair < a.batch * a.num_q_heads;
+  const int b = live ? pair / a.num_q_heads : 0, h = live ? pair % a.num_q_heads : 0;
   const int D = a.head_dim;
   const int len = a.b_seqlen[b];
-  const int nblk = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq;
+  const int nblk = (!live || len <= 0) ? 0 : (len + a.block_seq - 1) / a.block_seq;
   const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h;
   const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
   const int d = D == 128 ? lane * 2 : lane;
-  float sum = 0.f, mxl = -INFINITY, a0 = 0.f, a1 = 0.f;
-  for (int i = 0; i < nblk; ++i) {
+  float mxl = -INFINITY;
+  for (int i = lane; i < nblk; i += 64) mxl = fmaxf(mxl, ml[i]);
+  mxl = wave_allmax(mxl);
+  float sum = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+  for (int i = sub; i < nblk; i += PW) {
     float t0, t1 = 0.f;
     if (D == 128) {
       const float2 tv = *reinterpret_cast<const float2*>(mo + (int64_t)i * a.mid_o_stride_s + d);
@@ -125,15 +134,19 @@ __global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDec
     } else {
       t0 = mo[(int64_t)i * a.mid_o_stride_s + d];
     }
-    const float tl = ml[i];
-    const float nm = fmaxf(tl, mxl);
-    const float os = __expf(mxl - nm);
-    const float e = __expf(tl - nm);
-    a0 = a0 * os + e * t0;
-    a1 = a1 * os + e * t1;
-    sum = sum * os + e;
-    mxl = nm;
+    const float e = __expf(ml[i] - mxl);
+    a0 += e * t0;
+    a1 += e * t1;
+    sum += e;
   }
+  if constexpr (PW > 1) {
+    s_part[wv][lane] = a0; s_part[wv][64 + lane] = a1; s_part[wv][128 + lane] = sum;
+    __syncthreads();
+    if (sub != 0) return;
+#pragma unroll
+    for (int j = 1; j < PW; ++j) { a0 += s_part[wv + j][lane]; a1 += s_part[wv + j][64 + lane]; sum += s_part[wv + j][128 + lane]; }
+  }
+  if (!live) return;
   uint16_t* o = a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d;
   if (D == 128) *reinterpret_cast<uint32_t*>(o) = f32_to_bf16_bits(a0 / sum) | (f32_to_bf16_bits(a1 / sum) << 16);
   else *o = (uint16_t)f32_to_bf16_bits(a0 / sum);
@@ -305,13 +318,23 @@ extern "C" int svk_h2o_decode_finish(const SvkH2oDecodeFinishArgs* f, svk_stream
     return svk_h2o_decode_score_update(&sc, stream);
   }
   const int pairs = s2.batch * s2.num_q_heads;
-  dim3 grid(sc.batch + (pairs + 15) / 16);
+  // waves per (b, h) pair: the lse row stride is the workspace's partial capacity
+  const int pw = s2.mid_lse_stride_h >= 24 ? 16 : (s2.mid_lse_stride_h >= 6 ? 4 : 1);
+  const int ppw = 16 / pw;
+  dim3 grid(sc.batch + (pairs + ppw - 1) / ppw);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ept = (sc.width + 1023) / 1024;
-  if (ept <= 2) hipLaunchKernelGGL((h2o_decode_finish_kernel<2>), grid, dim3(1024), 0, s, *f);
-  else if (ept <= 5) hipLaunchKernelGGL((h2o_decode_finish_kernel<5>), grid, dim3(1024), 0, s, *f);
-  else if (ept <= 16) hipLaunchKernelGGL((h2o_decode_finish_kernel<16>), grid, dim3(1024), 0, s, *f);
-  else hipLaunchKernelGGL((h2o_decode_finish_kernel<32>), grid, dim3(1024), 0, s, *f);
+#define SVK_FINISH(EPT_)                                                                                  \
+  do {                                                                                                    \
+    if (pw == 16) hipLaunchKernelGGL((h2o_decode_finish_kernel<EPT_, 16>), grid, dim3(1024), 0, s, *f);   \
+    else if (pw == 4) hipLaunchKernelGGL((h2o_decode_finish_kernel<EPT_, 4>), grid, dim3(1024), 0, s, *f); \
+    else hipLaunchKernelGGL((h2o_decode_finish_kernel<EPT_, 1>), grid, dim3(1024), 0, s, *f);             \
+  } while (0)
+  if (ept <= 2) SVK_FINISH(2);
+  else if (ept <= 5) SVK_FINISH(5);
+  else if (ept <= 16) SVK_FINISH(16);
+  else SVK_FINISH(32);
+#undef SVK_FINISH
   return check_launch("svk_h2o_decode_finish");
 }
 
