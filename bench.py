@@ -136,10 +136,10 @@ def main():
     record = {"on": False, "calls": []}
     orig = attn_mod.flash_decode_stage1_with_score
 
-    def capturing_stage1(*a):
+    def capturing_stage1(*a, **kw):
         if record["on"]:
-            record["calls"].append(a)
-        return orig(*a)
+            record["calls"].append((a, kw))
+        return orig(*a, **kw)
 
     def time_captured_launches():
         calls, record["calls"] = record["calls"], []
@@ -149,8 +149,8 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        for a in calls:
-            orig(*a)
+        for a, kw in calls:
+            orig(*a, **kw)
         e1.record()
         torch.cuda.synchronize()
         events.append((e0.elapsed_time(e1), len(calls), int(drv.row_len()[0])))

@@ -123,6 +123,14 @@ typedef struct SvkFlashDecodeStage1Args {
   int32_t max_len_in_batch;      /* grid covers ceil(max_len/block_seq) blocks           */
   int32_t block_seq;             /* multiple of 16                                       */
   int32_t score_mode;            /* SVK_SCORE_*                                          */
+  /* Optional fused store_kvcache (kernels/triton/store_kvcache.py:33-71 riding in the attention launch): when
+   * new_k != NULL, the workgroup that owns lane b's newest token (position b_seqlen[b]-1) first writes
+   * new_k[b], new_v[b] ([B, Hkv, D] bf16) to cache slot slot_mapping[b] (-1 = skip, like store_kvcache) and only
+   * then reads the row - the separate svk_store_kvcache launch of the decode step disappears.  All NULL/0 = off. */
+  const uint16_t* new_k;
+  const uint16_t* new_v;
+  const int32_t* slot_mapping;   /* [B] */
+  int64_t new_stride_b, new_stride_h;
 } SvkFlashDecodeStage1Args;
 int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_stream_t stream);
 

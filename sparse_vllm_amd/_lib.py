@@ -54,7 +54,8 @@ class SvkFlashDecodeStage1Args(C.Structure):
                 ("mid_lse_stride_b", _i64), ("mid_lse_stride_h", _i64), ("score_stride_b", _i64),
                 ("score_stride_h", _i64),
                 ("batch", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
-                ("max_len_in_batch", _i32), ("block_seq", _i32), ("score_mode", _i32)]
+                ("max_len_in_batch", _i32), ("block_seq", _i32), ("score_mode", _i32),
+                ("new_k", _p), ("new_v", _p), ("slot_mapping", _p), ("new_stride_b", _i64), ("new_stride_h", _i64)]
 
 
 class SvkFlashDecodeStage2Args(C.Structure):

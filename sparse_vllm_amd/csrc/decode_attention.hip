@@ -833,6 +833,24 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a, const SvkH2oDecodeScor
     return;
   }
 
+  if (a.new_k != nullptr && end == len) {
+    // fused store_kvcache: this workgroup owns the lane's newest token.  Wave w writes its kv head's K and V rows
+    // (2 x D/8 lanes, 16 bytes each) before any read of the row.  Only this wave reads that slot's head row in this
+    // launch and the CU cannot hold a stale line of it (L1 is write-through, invalidated at kernel start), so a
+    // workgroup-scope fence pair (= the store has completed) is enough; agent scope would write back the XCD's L2
+    // (+10 us per launch measured).
+    const int ns = a.slot_mapping[b];
+    if (ns >= 0 && lane < 2 * DW) {
+      const bool is_v = lane >= DW;
+      const int seg = lane % DW;
+      const uint16_t* src = (is_v ? a.new_v : a.new_k) + (int64_t)b * a.new_stride_b + (int64_t)w * a.new_stride_h + seg * 8;
+      uint16_t* dst = const_cast<uint16_t*>(is_v ? a.v_cache : a.k_cache) + (int64_t)ns * a.kv_slot_stride +
+                      (int64_t)w * a.kv_head_stride + seg * 8;
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
   const int32_t* row = a.req_to_tokens + (int64_t)a.b_req_idx[b] * a.req_stride;
   // Byte addressing.  OFF32: the whole K (V) tensor spans < 4 GiB, so a row address is the
   // wave-uniform tensor base (SGPR pair) + a 32-bit per-lane byte offset: one VGPR per address
@@ -1115,6 +1133,12 @@ decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
   *reinterpret_cast<uint2*>(a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d) = make_uint2(w0, w1);
 }
 
+// SVK_STAGE1_VARIANT=1|2 selects the earlier kernels (A/B runs); 3 = default
+inline int stage1_variant() {
+  static const int variant = getenv("SVK_STAGE1_VARIANT") ? atoi(getenv("SVK_STAGE1_VARIANT")) : 3;
+  return variant;
+}
+
 template <int D, int G>
 int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
   using C = Stage1Cfg<D, G>;
@@ -1125,7 +1149,7 @@ int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
   const size_t shm3 = sizeof(float) * ((size_t)a.num_kv_heads * Stage1V3Lds<D, G>::WAVE_FLOATS + score_floats);
   // 32-bit row offsets whenever the caller tells us the KV tensors span < 4 GiB
   const bool off32 = a.kv_num_slots > 0 && (a.kv_num_slots * a.kv_slot_stride * 2) < (int64_t)0xffffffffll;
-  static const int variant = getenv("SVK_STAGE1_VARIANT") ? atoi(getenv("SVK_STAGE1_VARIANT")) : 3;   // 1/2: earlier kernels (A/B runs)
+  const int variant = stage1_variant();
   if (variant == 1 || (variant == 2 && G == 8)) {
     const size_t shm1 = sizeof(float) * ((size_t)a.num_kv_heads * C::WAVE_FLOATS + score_floats);
     hipLaunchKernelGGL((decode_stage1_kernel_v1<D, G>), grid, block, shm1, stream, a);
@@ -1226,6 +1250,14 @@ static int validate_stage1(const SvkFlashDecodeStage1Args* a, const char* who) {
               SVK_ERR_LAYOUT, "%s: q/k/v strides must keep 16-byte alignment", who);
   SVK_REQUIRE((a->mid_o_stride_h % 4) == 0 && (a->mid_o_stride_s % 4) == 0 && (a->mid_o_stride_b % 4) == 0, SVK_ERR_LAYOUT,
               "%s: mid_o strides must keep 16-byte alignment", who);
+  if (a->new_k != nullptr || a->new_v != nullptr) {
+    SVK_REQUIRE(a->new_k != nullptr && a->new_v != nullptr && a->slot_mapping != nullptr, SVK_ERR_VALUE,
+                "%s: the fused store needs new_k, new_v and slot_mapping together", who);
+    SVK_REQUIRE((a->new_stride_b % 8) == 0 && (a->new_stride_h % 8) == 0 && (reinterpret_cast<uintptr_t>(a->new_k) % 16) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a->new_v) % 16) == 0,
+                SVK_ERR_LAYOUT, "%s: new_k/new_v rows must be 16-byte aligned", who);
+    SVK_REQUIRE(stage1_variant() == 3, SVK_ERR_VALUE, "%s: the fused store is only built into stage-1 variant 3", who);
+  }
   return SVK_OK;
 }
 

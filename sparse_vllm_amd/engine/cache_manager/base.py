@@ -178,6 +178,16 @@ class CacheManager(ABC):
         k_cache, v_cache = self.get_layer_store_view(layer_idx)
         store_kvcache(k, v, k_cache, v_cache, self.get_layer_batch_states(layer_idx).slot_mapping)
 
+    def fused_decode_store_slots(self, layer_idx: int):
+        """MI355X: slot_mapping of this decode step when the layer's K/V store may ride in the attention launch
+        (plain slot-table managers whose store has no side effects), else None -> `save_rope_kv_if_needed`."""
+        import os
+        if os.environ.get("SVK_FUSE_DECODE_STORE", "1") != "1":
+            return None
+        if type(self).save_rope_kv_if_needed is not CacheManager.save_rope_kv_if_needed:
+            return None          # Quest page metadata, DeltaKV raw/KIVI stores: keep the explicit store
+        return self.get_layer_batch_states(layer_idx).slot_mapping
+
     def build_decode_compute_view(self, layer_idx: int, q: torch.Tensor, selection: SparseSelection, *,
                                   num_heads: int, num_kv_heads: int) -> DecodeComputeView:
         """base.py:1162-1206: full physical row of every request."""

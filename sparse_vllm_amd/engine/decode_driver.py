@@ -168,8 +168,9 @@ class SparseDecodeDriver:
             save_raw = getattr(cm, "save_raw_kv_if_needed", None)
             if save_raw is not None:          # DeltaKV sparse layers keep the pre-RoPE key (models/qwen2.py attention)
                 save_raw(layer_idx, k[layer_idx], v[layer_idx])
-            cm.save_rope_kv_if_needed(layer_idx, k[layer_idx], v[layer_idx])
-            o = self.attn(q[layer_idx])
+            # Attention.forward(q, k, v) stores this step's K/V rows: as a launch of its own, or inside the
+            # stage-1 launch where the cache manager allows it (`fused_decode_store_slots`)
+            o = self.attn(q[layer_idx], k[layer_idx], v[layer_idx])
             on_layer_end = getattr(sc, "on_layer_end", None)
             if on_layer_end is not None:
                 on_layer_end(layer_idx, ctx)

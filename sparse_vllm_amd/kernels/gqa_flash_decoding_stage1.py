@@ -33,7 +33,7 @@ def _assert_supported_layout(q, k, v, req_to_tokens, b_req_idx, b_seqlen, mid_ou
 
 
 def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                 attn_score, block_seq):
+                 attn_score, block_seq, new_kv=None):
     Lq, Lk = q.shape[-1], k.shape[-1]
     assert Lq == Lk
     assert Lk in {16, 32, 64, 128, 256}
@@ -56,6 +56,16 @@ def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, 
         else:
             mode = _lib.SVK_SCORE_HEADMAX
             ss_b = attn_score.stride(0)
+    store = {}
+    if new_kv is not None:
+        # MI355X: this step's store_kvcache rides in the attention launch (include/svk.h, SvkFlashDecodeStage1Args)
+        new_k, new_v, slot_mapping = new_kv
+        assert new_k.dtype == k.dtype and new_v.dtype == v.dtype and new_k.shape == new_v.shape
+        assert new_k.dim() == 3 and new_k.shape[0] == batch and new_k.shape[1] == kv_head_num and new_k.shape[2] == Lk
+        assert new_k.stride(-1) == 1 and new_v.stride(-1) == 1 and new_k.stride() == new_v.stride()
+        assert slot_mapping.dtype == torch.int32 and slot_mapping.is_contiguous() and slot_mapping.numel() >= batch
+        store = dict(new_k=_lib.ptr(new_k), new_v=_lib.ptr(new_v), slot_mapping=_lib.ptr(slot_mapping),
+                     new_stride_b=new_k.stride(0), new_stride_h=new_k.stride(1))
     return _lib.SvkFlashDecodeStage1Args(
         q=_lib.ptr(q), k_cache=_lib.ptr(k), v_cache=_lib.ptr(v), req_to_tokens=_lib.ptr(Req_to_tokens),
         b_req_idx=_lib.ptr(B_req_idx), b_seqlen=_lib.ptr(B_Seqlen), mid_o=_lib.ptr(mid_out),
@@ -67,13 +77,13 @@ def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, 
         mid_lse_stride_b=mid_out_logsumexp.stride(0), mid_lse_stride_h=mid_out_logsumexp.stride(1),
         score_stride_b=ss_b, score_stride_h=ss_h,
         batch=batch, num_q_heads=q.shape[1], num_kv_heads=kv_head_num, head_dim=Lk,
-        max_len_in_batch=int(max_len_in_batch), block_seq=int(block_seq), score_mode=mode)
+        max_len_in_batch=int(max_len_in_batch), block_seq=int(block_seq), score_mode=mode, **store)
 
 
 def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq):
+            attn_score, block_seq, new_kv=None):
     a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                     attn_score, block_seq)
+                     attn_score, block_seq, new_kv)
     lib = _lib.load()
     _lib.check(lib.svk_flash_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
 
@@ -111,13 +121,14 @@ def h2o_decode_fused(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_bat
 
 @torch.no_grad()
 def flash_decode_stage1(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
-                        mid_out_logsumexp, block_seq, block_n=16, num_warps=2, num_stages=2):
+                        mid_out_logsumexp, block_seq, block_n=16, num_warps=2, num_stages=2, *, new_kv=None):
+    """`new_kv=(new_k, new_v, slot_mapping)` (MI355X extension): store this step's K/V rows inside the launch."""
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp, None,
-            block_seq)
+            block_seq, new_kv)
 
 
 @torch.no_grad()
 def flash_decode_stage1_with_score(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
-                                   mid_out_logsumexp, attn_score, block_seq):
+                                   mid_out_logsumexp, attn_score, block_seq, *, new_kv=None):
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq)
+            attn_score, block_seq, new_kv)

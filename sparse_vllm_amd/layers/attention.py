@@ -40,7 +40,7 @@ class HipAttentionBackend:
 
     def run_decode(self, q: torch.Tensor, view: DecodeComputeView, *, mid_o, mid_o_logexpsum, max_len_in_batch: int,
                    block_seq: int, num_heads: int, num_kv_heads: int, gqa_block_n: int = 16,
-                   gqa_num_warps: int = 2, fused_finish=None, fused_layer=None) -> torch.Tensor:
+                   gqa_num_warps: int = 2, fused_finish=None, fused_layer=None, new_kv=None) -> torch.Tensor:
         payload = view.payload
         if not isinstance(payload, ExplicitKVPayload):
             raise TypeError(f"HIP decode requires ExplicitKVPayload, got {type(payload).__name__}.")
@@ -64,7 +64,10 @@ class HipAttentionBackend:
             o = torch.empty_like(q)
             flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
             return o
-        if fused_layer is not None and payload.backend == "dense" and meta.attn_score is not None and meta.attn_score.dim() == 2:
+        if new_kv is not None and payload.backend != "dense":
+            raise RuntimeError("the fused decode store is only wired into the dense stage-1 launch")
+        if (fused_layer is not None and new_kv is None and payload.backend == "dense" and meta.attn_score is not None
+                and meta.attn_score.dim() == 2):
             # MI355X: stage 1 + stage 2 + the controller's per-layer score epilogue as ONE launch
             o = torch.empty_like(q)
             with profiler.record(f"decode_attention_fused_{kind}"):
@@ -75,11 +78,11 @@ class HipAttentionBackend:
             if meta.attn_score is not None:
                 flash_decode_stage1_with_score(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                                meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum,
-                                               meta.attn_score, block_seq)
+                                               meta.attn_score, block_seq, new_kv=new_kv)
             else:
                 flash_decode_stage1(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                     meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum, block_seq,
-                                    gqa_block_n, gqa_num_warps)
+                                    gqa_block_n, gqa_num_warps, new_kv=new_kv)
         o = torch.empty_like(q)
         with profiler.record(f"decode_attention_stage2_{kind}"):
             # a sparse controller may fuse its per-layer score epilogue into the stage-2 launch
@@ -121,6 +124,15 @@ class Attention(torch.nn.Module):
                                       cache_manager.get_layer_buffer_req_to_token_slots(layer_idx))
             return o
         temp_slots = None
+        # this step's K/V rows: stored here (explicit launch), or inside the stage-1 launch when the manager allows it
+        new_kv = None
+        if k is not None and v is not None:
+            fuse = getattr(cache_manager, "fused_decode_store_slots", None)
+            slots = fuse(layer_idx) if fuse is not None else None
+            if slots is None or getattr(sparse_controller, "_fused_h2o_layer", False):
+                cache_manager.save_rope_kv_if_needed(layer_idx, k, v)
+            else:
+                new_kv = (k, v, slots)
         try:
             batch_size = q.shape[0]
             selection = sparse_controller.get_decode_selection(layer_idx, q)
@@ -157,7 +169,8 @@ class Attention(torch.nn.Module):
                 block_seq=block_seq, num_heads=self.num_heads, num_kv_heads=self.num_kv_heads,
                 gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps,
                 fused_finish=None if finish is None else (lambda *a, _l=layer_idx: finish(_l, *a)),
-                fused_layer=None if layer_fn is None else (lambda *a, _l=layer_idx: layer_fn(_l, *a)))
+                fused_layer=None if layer_fn is None else (lambda *a, _l=layer_idx: layer_fn(_l, *a)),
+                new_kv=new_kv)
             cache_manager.record_decode_query(layer_idx, q)
             sparse_controller.on_layer_attention_end(layer_idx)
             cache_manager.on_layer_attention_end(layer_idx)

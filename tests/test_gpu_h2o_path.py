@@ -447,3 +447,57 @@ def test_single_launch_layer_matches_two_launches():
     torch.testing.assert_close(outs[1][0].float(), outs[0][0].float(), rtol=2e-2, atol=2e-3)
     torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-9)
     torch.testing.assert_close(outs[1][2], outs[0][2], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("shape", [
+    dict(B=3, Hq=28, Hkv=4, D=128, lens=[4224, 4100, 17], block_seq=1056),
+    dict(B=5, Hq=14, Hkv=2, D=64, lens=[1, 16, 33, 256, 300], block_seq=64),
+    dict(B=2, Hq=8, Hkv=8, D=128, lens=[512, 511], block_seq=256),
+])
+def test_decode_with_fused_store_equals_store_then_decode(shape, mode):
+    """`new_kv=(k, v, slot_mapping)`: the K/V rows of the newest token are written by the stage-1 launch itself.
+    Cache contents, partials, lse and scores must be identical to svk_store_kvcache followed by the plain launch;
+    a lane with slot -1 (padded graph lane) stores nothing."""
+    from sparse_vllm_amd.kernels import flash_decode_stage1, flash_decode_stage1_with_score, store_kvcache
+    B, Hq, Hkv, D, lens, block_seq = (shape[k] for k in ("B", "Hq", "Hkv", "D", "lens", "block_seq"))
+    q, k, v, req, bidx, blen = _rand_case(31 + mode, B, Hq, Hkv, D, lens, block_seq)
+    max_len = int(max(lens))
+    rng = np.random.default_rng(5)
+    nk = bf16_round((rng.standard_normal((B, Hkv, D)) * 0.3).astype(np.float32))
+    nv = bf16_round((rng.standard_normal((B, Hkv, D)) * 0.3).astype(np.float32))
+    slot_mapping = np.array([req[bidx[b], blen[b] - 1] for b in range(B)], dtype=np.int32)
+    slot_mapping[B - 1] = -1                                    # padded lane: nothing stored
+    nblk = (max_len + block_seq - 1) // block_seq
+    tq, tnk, tnv = to_bf16(q), to_bf16(nk), to_bf16(nv)
+    treq, tb, tl = (torch.from_numpy(x).to(dev()) for x in (req, bidx, blen))
+    tsm = torch.from_numpy(slot_mapping).to(dev())
+
+    def run(fused):
+        tk, tv = to_bf16(k), to_bf16(v)
+        mid = torch.full((B, Hq, nblk, D), 7.0, dtype=torch.float32, device=dev())
+        lse = torch.full((B, Hq, nblk), 7.0, dtype=torch.float32, device=dev())
+        score = None
+        if mode == 2:
+            score = torch.full((B, max_len), -1e20, dtype=torch.float32, device=dev())
+        elif mode == 3:
+            score = torch.full((B, Hq, max_len), -1e20, dtype=torch.float32, device=dev())
+        new_kv = (tnk, tnv, tsm) if fused else None
+        if not fused:
+            store_kvcache(tnk, tnv, tk, tv, tsm)
+        if score is not None:
+            flash_decode_stage1_with_score(tq, tk, tv, treq, tb, tl, max_len, mid, lse, score, block_seq, new_kv=new_kv)
+        else:
+            flash_decode_stage1(tq, tk, tv, treq, tb, tl, max_len, mid, lse, block_seq, new_kv=new_kv)
+        torch.cuda.synchronize()
+        out = [tk.view(torch.int16).cpu().numpy(), tv.view(torch.int16).cpu().numpy(), mid.cpu().numpy(), lse.cpu().numpy()]
+        if score is not None:
+            out.append(score.cpu().numpy())
+        return out
+
+    ref, got = run(False), run(True)
+    for x, y in zip(ref[:2], got[:2]):
+        np.testing.assert_array_equal(x, y)                     # cache bytes
+    # the padded lane reads a row another lane may be writing: compare the real lanes only
+    for x, y in zip(ref[2:], got[2:]):
+        np.testing.assert_array_equal(x[:B - 1], y[:B - 1])
