@@ -327,14 +327,21 @@ __global__ void __launch_bounds__(256) token_score_stats_kernel(const SvkDeltakv
   }
 }
 
-// 4 consecutive tokens per thread (16-byte loads per head), 1024 tokens per workgroup; the per-head statistics are
-// combined by one wave per head (lane = chunk) instead of one thread per head.
+// one token per thread; the per-head statistics are combined by one wave per head (lane = chunk) from an LDS copy.
 __global__ void __launch_bounds__(256) token_score_final_kernel(const SvkDeltakvTokenScoresArgs a, int nchunk) {
-  extern __shared__ float stats[];      // [H][2]: global max / sum per head
+  extern __shared__ float stats[];      // [H][2] global max / sum per head | [H][nchunk][2] staged chunk statistics
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* wsl = stats + 2 * a.num_heads;
+  {
+    // all chunk statistics of the row with one coalesced sweep (one wave per head walking global memory paid a
+    // dependent round trip per head: 14 us of the kernel's 28)
+    const float* ws = a.workspace + (int64_t)b * a.num_heads * nchunk * 2;
+    for (int i = threadIdx.x; i < a.num_heads * nchunk * 2; i += 256) wsl[i] = ws[i];
+  }
+  __syncthreads();
   for (int h = wv; h < a.num_heads; h += 4) {
-    const float* ws = a.workspace + ((int64_t)b * a.num_heads + h) * nchunk * 2;
+    const float* ws = wsl + (int64_t)h * nchunk * 2;
     float mx = -INFINITY;
     for (int c = lane; c < nchunk; c += 64) mx = fmaxf(mx, ws[2 * c]);
     mx = wave_allmax(mx);
@@ -347,51 +354,31 @@ __global__ void __launch_bounds__(256) token_score_final_kernel(const SvkDeltakv
     if (lane == 0) { stats[2 * h] = mx; stats[2 * h + 1] = sum; }
   }
   __syncthreads();
-  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (t0 >= a.length) return;
+  // one token per thread: the precise exp + division per (token, head) make this kernel VALU-latency-bound, so it
+  // wants waves (4 per SIMD), not wide lanes; 4 heads per trip with their loads issued before the first exp
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.length) return;
   const int len = min(max(a.candidate_lens[b], 0), a.length - a.candidate_start);
-  const float* x = a.raw_scores + (int64_t)b * a.raw_stride_b + t0;
-  float* out = a.token_scores + (int64_t)b * a.out_stride + t0;
-  const bool vec = t0 + 4 <= a.length && (a.raw_stride_h % 4) == 0 && (a.raw_stride_b % 4) == 0 && (a.out_stride % 4) == 0 &&
-                   (reinterpret_cast<uintptr_t>(a.raw_scores) % 16) == 0 && (reinterpret_cast<uintptr_t>(a.token_scores) % 16) == 0;
-  float best[4] = {0.f, 0.f, 0.f, 0.f};
-  bool in[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rel = t0 + j - a.candidate_start;
-    in[j] = t0 + j < a.length && rel >= 0 && rel < len;
-  }
-  if (in[0] || in[1] || in[2] || in[3]) {
-    for (int h = 0; h < a.num_heads; ++h) {
-      const float mx = stats[2 * h], sum = stats[2 * h + 1];
+  const int rel = t - a.candidate_start;
+  float out = a.fill_value;
+  if (rel >= 0 && rel < len) {
+    const float* x = a.raw_scores + (int64_t)b * a.raw_stride_b + t;
+    float best = 0.f;
+    for (int h0 = 0; h0 < a.num_heads; h0 += 4) {
       float xv[4];
-      if (vec) {
-        const float4 q = *reinterpret_cast<const float4*>(x + (int64_t)h * a.raw_stride_h);
-        xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
-      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xv[j] = in[j] ? x[(int64_t)h * a.raw_stride_h + j] : 0.f;
+      for (int u = 0; u < 4; ++u) xv[u] = x[(int64_t)min(h0 + u, a.num_heads - 1) * a.raw_stride_h];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int h = min(h0 + u, a.num_heads - 1);          // a repeated last head leaves the maximum unchanged
+        best = fmaxf(best, expf(mul_rn(xv[u], a.scale) - stats[2 * h]) / stats[2 * h + 1]);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (in[j]) best[j] = fmaxf(best[j], expf(mul_rn(xv[j], a.scale) - mx) / sum);
     }
+    if (a.round_dtype == SVK_DTYPE_BF16) best = bf16_round(best);
+    else if (a.round_dtype == SVK_DTYPE_F16) best = (float)(_Float16)best;
+    out = best;
   }
-  float o[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float v = best[j];
-    if (a.round_dtype == SVK_DTYPE_BF16) v = bf16_round(v);
-    else if (a.round_dtype == SVK_DTYPE_F16) v = (float)(_Float16)v;
-    o[j] = in[j] ? v : a.fill_value;
-  }
-  if (vec) {
-    *reinterpret_cast<float4*>(out) = make_float4(o[0], o[1], o[2], o[3]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (t0 + j < a.length) out[j] = o[j];
-  }
+  a.token_scores[(int64_t)b * a.out_stride + t] = out;
 }
 
 // ------------------------------------------------------------------------------------
@@ -582,8 +569,15 @@ extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nchunk = svk_deltakv_token_scores_chunks(a->length);
   hipLaunchKernelGGL(token_score_stats_kernel, dim3(a->batch, a->num_heads, nchunk), dim3(256), 0, s, *a, nchunk);
-  hipLaunchKernelGGL(token_score_final_kernel, dim3((a->length + 1023) / 1024, a->batch), dim3(256),
-                     sizeof(float) * 2 * a->num_heads, s, *a, nchunk);
+  const size_t final_lds = sizeof(float) * 2 * a->num_heads * (1 + nchunk);
+  SVK_REQUIRE(final_lds <= 156 * 1024, SVK_ERR_VALUE, "svk_deltakv_token_scores: %d heads x %d chunks of statistics do not fit LDS",
+              a->num_heads, nchunk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(token_score_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(token_score_final_kernel, dim3((a->length + 255) / 256, a->batch), dim3(256), final_lds, s, *a, nchunk);
   return check_launch("svk_deltakv_token_scores");
 }
 

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(128) quest_page_minmax_kernel(const SvkQuestPa
 //   S+ = Q+ . Max^T, S- = Q- . Min^T (fp32 accumulate), s = bf16(bf16(S+) + bf16(S-)), max over heads
 // ------------------------------------------------------------------------------------
 
-constexpr int kPagesPerBlock = 128;
+constexpr int kPagesPerBlock = 32;
 
 template <int D, int G>
 __global__ void __launch_bounds__(512) quest_score_pages_kernel(const SvkQuestScorePagesArgs a) {
@@ -91,26 +91,41 @@ __global__ void __launch_bounds__(512) quest_score_pages_kernel(const SvkQuestSc
   const int32_t* ptab = a.page_table + (int64_t)a.req_indices[b] * a.page_table_stride;
   const int64_t head_off = (int64_t)w * D + jq * 8;
   const int64_t row_elems = (int64_t)Hkv * D;
-  for (int g0 = p0; g0 < p1; g0 += 16) {
-    const int p = g0 + n;
-    int slot = 0;
-    if (p < n_valid) slot = max(ptab[p], 0);
-    const uint16_t* pm = a.page_max + (int64_t)slot * row_elems + head_off;
-    const uint16_t* pn = a.page_min + (int64_t)slot * row_elems + head_off;
+  // all page slots of the block first, then every group's metadata loads before the first MFMA: the scan is
+  // latency-bound (two dependent round trips per 16 pages), so keep the whole block's requests in flight together
+  constexpr int NGRP = kPagesPerBlock / 16;
+  int slot[NGRP];
+#pragma unroll
+  for (int g = 0; g < NGRP; ++g) {
+    const int p = p0 + g * 16 + n;
+    slot[g] = p < n_valid ? ptab[p] : 0;
+  }
+  uint4 vmax[NGRP][NC], vmin[NGRP][NC];
+#pragma unroll
+  for (int g = 0; g < NGRP; ++g) {
+    const uint16_t* pm = a.page_max + (int64_t)max(slot[g], 0) * row_elems + head_off;
+    const uint16_t* pn = a.page_min + (int64_t)max(slot[g], 0) * row_elems + head_off;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      vmax[g][c] = *reinterpret_cast<const uint4*>(pm + c * 32);
+      vmin[g][c] = *reinterpret_cast<const uint4*>(pn + c * 32);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < NGRP; ++g) {
+    if (p0 + g * 16 >= p1) break;
     f32x4_t sp = {0.f, 0.f, 0.f, 0.f}, sn = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const uint4 vmax = *reinterpret_cast<const uint4*>(pm + c * 32);
-      const uint4 vmin = *reinterpret_cast<const uint4*>(pn + c * 32);
-      sp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qp[c], __builtin_bit_cast(bf16x8_t, vmax), sp, 0, 0, 0);
-      sn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qn[c], __builtin_bit_cast(bf16x8_t, vmin), sn, 0, 0, 0);
+      sp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qp[c], __builtin_bit_cast(bf16x8_t, vmax[g][c]), sp, 0, 0, 0);
+      sn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qn[c], __builtin_bit_cast(bf16x8_t, vmin[g][c]), sn, 0, 0, 0);
     }
     if (jq < JQ) {
       float best = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (jq * 4 + r < G) best = fmaxf(best, bf16_round(bf16_round(sp[r]) + bf16_round(sn[r])));
-      lds[(g0 - p0 + n) * SP + w * JQ + jq] = best;
+      lds[(g * 16 + n) * SP + w * JQ + jq] = best;
     }
   }
   __syncthreads();

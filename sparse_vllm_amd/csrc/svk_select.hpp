@@ -62,9 +62,10 @@ __device__ __forceinline__ uint32_t desc_key(float f) {
 
 struct SelectScratch {
   int hist[256];
-  int wsum[16];
+  int wsum[16], wsum2[16];
   uint32_t prefix;
   int k;
+  uint32_t or_bits, and_bits;      // OR / AND of all keys: key bytes every element shares need no radix pass
 };
 
 // Exact top-k of sc[0:n) under the order (score descending, index ascending) -- the order of a
@@ -78,42 +79,76 @@ struct SelectScratch {
 // rounds fold the dominant bins into one atomic per wave each; the remaining lanes add individually.
 __device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, bool active) {
   const int lane = threadIdx.x & 63;
-  unsigned long long todo = __ballot(active);
+  // cheap duplicate detector first (one DPP move + ballot): only when a quarter of the wave's neighbouring lanes
+  // carry the same bin are the leader rounds worth their ~2 x (shuffle + ballot) latency; spread digits go straight
+  // to individual LDS atomics (22 k keys per pass: 15 us -> 8 us)
+  const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp((int)~bin, (int)bin, 0x111, 0xf, 0xf, false);   // row_shr:1
+  if (__popcll(__ballot(active && nb == bin)) >= 16) {
+    unsigned long long todo = __ballot(active);
 #pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    if (todo == 0ull) break;
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t lb = (uint32_t)__shfl((int)bin, leader, 64);
-    const unsigned long long same = __ballot(active && bin == lb) & todo;
-    if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
-    todo &= ~same;
+    for (int round = 0; round < 2; ++round) {
+      if (todo == 0ull) break;
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t lb = (uint32_t)__shfl((int)bin, leader, 64);
+      const unsigned long long same = __ballot(active && bin == lb) & todo;
+      if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+      todo &= ~same;
+    }
+    active = (todo >> lane) & 1ull;
   }
-  if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1);
+  if (active) atomicAdd(&hist[bin], 1);
 }
 
 // Core on descending-order keys `key_at(i)` (smaller key = better; callers stage keys in LDS when the row fits, so the
-// five sweeps do not pay a dependent global-load latency each).  Each thread works on strips of kStrip consecutive
-// elements so the ordered emit needs one block scan per kStrip * blockDim elements.
+// sweeps do not pay a dependent global-load latency each).
 template <typename KeyAt, typename Emit>
 __device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int n, int k, SelectScratch& S, Emit emit) {
-  constexpr int kStrip = 4;
   const int tid = threadIdx.x, nt = blockDim.x;
   uint32_t prefix = 0;
   int kk = k;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+  // bytes shared by every key (bf16-valued scores: the two low bytes; probabilities: most of the top byte) are
+  // found with one atomic-free sweep and skip their radix pass
+  if (tid == 0) { S.or_bits = 0u; S.and_bits = 0xffffffffu; }
+  __syncthreads();
+  {
+    uint32_t o = 0u, an = 0xffffffffu;
+    for (int i = tid; i < n; i += nt) {
+      const uint32_t key = key_at(i);
+      o |= key;
+      an &= key;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      o |= (uint32_t)__shfl_xor((int)o, off, 64);
+      an &= (uint32_t)__shfl_xor((int)an, off, 64);
+    }
+    if ((tid & 63) == 0) { atomicOr(&S.or_bits, o); atomicAnd(&S.and_bits, an); }
+  }
+  __syncthreads();
+  const uint32_t all_and = S.and_bits;
+  const uint32_t varying = S.or_bits ^ all_and;              // bit positions on which the keys differ
+  // 8-bit digits are laid from the highest varying bit down to the lowest one (not on byte boundaries): the first
+  // digit then spreads over the bins even when the keys share their leading bits (probabilities share sign and the
+  // upper exponent bits and would pile into a handful of bins - serialised LDS atomics), and digits made of shared
+  // bits only are never histogrammed (bf16-valued scores: 2 passes instead of 4)
+  prefix = all_and;                                           // shared bits are those of every key, the k-th too
+  int top = varying ? 31 - __builtin_clz(varying) : -1;       // highest bit still undecided
+  const int low = varying ? __builtin_ctz(varying) : 0;
+  while (top >= low) {
+    const int shift = max(top - 7, 0);
+    const int width = top - shift + 1;
+    const uint32_t dmask = (width == 32 ? 0xffffffffu : ((1u << width) - 1u));
+    const uint32_t himask = top == 31 ? 0u : (0xffffffffu << (top + 1));
+    prefix &= ~(dmask << shift);                               // this digit is decided now
+    top = shift - 1;
     for (int i = tid; i < 256; i += nt) S.hist[i] = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += nt * kStrip) {
-#pragma unroll
-      for (int e = 0; e < kStrip; ++e) {
-        const int i = c0 + tid * kStrip + e;
-        uint32_t key = 0u;
-        const bool in = i < n;
-        if (in) key = key_at(i);
-        hist_add_aggregated(S.hist, (key >> shift) & 255u, in && (key & himask) == prefix);
-      }
+    for (int c0 = 0; c0 < n; c0 += nt) {                        // all threads iterate together (wave-wide ballots inside)
+      const int i = c0 + tid;
+      uint32_t key = 0u;
+      const bool in = i < n;
+      if (in) key = key_at(i);
+      hist_add_aggregated(S.hist, (key >> shift) & dmask, in && (key & himask) == (prefix & himask));
     }
     __syncthreads();
     if (tid < 64) {
@@ -147,53 +182,36 @@ __device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int
   }
   const uint32_t T = prefix;   // threshold key
   const int take_eq = kk;      // elements equal to T that are taken, lowest index first
-  int out_base = 0, eq_base = 0;
+  // ordered emit: thread t owns the contiguous index range [t*chunk, (t+1)*chunk) (odd chunk: conflict-free LDS
+  // strides), so ONE block scan of (#keys < T, #keys == T) gives every element its rank among the selected
   const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
-  for (int c0 = 0; c0 < n; c0 += nt * kStrip) {
-    uint32_t key[kStrip];
-    int n_lt = 0, n_eq = 0;
+  const int chunk = ((n + nt - 1) / nt) | 1;
+  const int i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
+  int n_lt = 0, n_eq = 0;
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t key = key_at(i);
+    n_lt += key < T;
+    n_eq += key == T;
+  }
+  int il = n_lt, ie = n_eq;
 #pragma unroll
-    for (int e = 0; e < kStrip; ++e) {
-      const int i = c0 + tid * kStrip + e;
-      key[e] = 0xffffffffu;
-      if (i < n) {
-        key[e] = key_at(i);
-        n_lt += key[e] < T;
-        n_eq += key[e] == T;
-      }
-    }
-    // block-wide exclusive prefix of (n_lt, n_eq) packed in one int (each < 2^15 per block of <= 4096 elements)
-    const int packed = (n_lt << 16) | n_eq;
-    int incl = packed;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    __syncthreads();
-    if (lane == 63) S.wsum[w] = incl;
-    __syncthreads();
-    int base = 0, tot = 0;
-    for (int j = 0; j < nw; ++j) {
-      const int c = S.wsum[j];
-      if (j < w) base += c;
-      tot += c;
-    }
-    const int excl = base + incl - packed;
-    int lt_before = excl >> 16, eq_before = eq_base + (excl & 0xffff);
-    // selected-before = (all < T before) + (equal-to-T before that are taken)
-#pragma unroll
-    for (int e = 0; e < kStrip; ++e) {
-      const int i = c0 + tid * kStrip + e;
-      if (i < n) {
-        const bool lt = key[e] < T, eq = key[e] == T;
-        if (lt || (eq && eq_before < take_eq)) emit(out_base + lt_before + min(eq_before, take_eq) - min(eq_base, take_eq), i);
-        lt_before += lt;
-        eq_before += eq;
-      }
-    }
-    out_base += (tot >> 16) + (min(eq_base + (tot & 0xffff), take_eq) - min(eq_base, take_eq));
-    eq_base += tot & 0xffff;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(il, o, 64), u = __shfl_up(ie, o, 64);
+    if (lane >= o) { il += v; ie += u; }
+  }
+  __syncthreads();
+  if (lane == 63) { S.wsum[w] = il; S.wsum2[w] = ie; }
+  __syncthreads();
+  int lt_before = il - n_lt, eq_before = ie - n_eq;
+  for (int j = 0; j < w; ++j) { lt_before += S.wsum[j]; eq_before += S.wsum2[j]; }
+  (void)nw;
+  // selected-before = (all < T before) + (equal-to-T before that are taken)
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t key = key_at(i);
+    const bool lt = key < T, eq = key == T;
+    if (lt || (eq && eq_before < take_eq)) emit(lt_before + min(eq_before, take_eq), i);
+    lt_before += lt;
+    eq_before += eq;
   }
 }
 
