@@ -505,6 +505,26 @@ typedef struct SvkDequantGroupedArgs {
 } SvkDequantGroupedArgs;
 int svk_dequantize_grouped(const SvkDequantGroupedArgs* a, svk_stream_t stream);
 
+/* Residual load, fused: out = act(bf16(dequant_int4(packed[row_index]) . weight^T + bias)), bf16 [rows, N].
+ * One MFMA launch for the int4 latent dequantisation (kernels/triton/quant.py:160-216), the first nn.Linear and the
+ * nn.GELU of the `compress_up` module (utils/compressor.py:69-73) in `_load_residual`
+ * (engine/cache_manager/deltakv_less_memory.py:2841-2848).  Rounding points as in the separate ops: q*scale and +min
+ * rounded separately, bf16 dequant output, fp32 accumulate, bf16 Linear output, erf-GELU evaluated in fp32. */
+typedef struct SvkDequantLinearArgs {
+  const int32_t* packed;    /* [latent_rows, K/8] int4 codes, LSB first            */
+  const void* scale;        /* [latent_rows, K/group_size] (scale_dtype)           */
+  const void* mn;
+  const int32_t* row_index; /* NULL or [rows]: row r reads latent row max(row_index[r], 0) */
+  const uint16_t* weight;   /* [N, K] bf16 (nn.Linear weight), row stride weight_stride */
+  const uint16_t* bias;     /* NULL or [N] bf16                                    */
+  uint16_t* out;            /* [rows, N] bf16                                      */
+  int64_t packed_stride, scale_stride, weight_stride, out_stride;
+  int32_t rows, k, n, group_size;
+  int32_t scale_dtype;
+  int32_t activation;       /* 0 = none, 1 = erf-GELU                              */
+} SvkDequantLinearArgs;
+int svk_dequant_linear_act(const SvkDequantLinearArgs* a, svk_stream_t stream);
+
 /* Attention-facing contiguous copy of a DeltaKV sparse layer's active slots: entry n = b*width + w takes slot
  * active_slots[b, w] (clamped into [0, num_slots)); V is copied; K is copied when postrope_mask[slot] != 0,
  * otherwise (optional RMS k-norm, then) rotated at slot_to_pos[slot] (clamped at 0).  Every entry is written.

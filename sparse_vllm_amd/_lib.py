@@ -175,6 +175,13 @@ class SvkDequantGroupedArgs(C.Structure):
                 ("scale_dtype", _i32), ("out_dtype", _i32), ("row_index", _p)]
 
 
+class SvkDequantLinearArgs(C.Structure):
+    _fields_ = [("packed", _p), ("scale", _p), ("mn", _p), ("row_index", _p), ("weight", _p), ("bias", _p), ("out", _p),
+                ("packed_stride", _i64), ("scale_stride", _i64), ("weight_stride", _i64), ("out_stride", _i64),
+                ("rows", _i32), ("k", _i32), ("n", _i32), ("group_size", _i32), ("scale_dtype", _i32),
+                ("activation", _i32)]
+
+
 class SvkDeltakvTokenScoresArgs(C.Structure):
     _fields_ = [("raw_scores", _p), ("candidate_lens", _p), ("token_scores", _p), ("workspace", _p),
                 ("raw_stride_b", _i64), ("raw_stride_h", _i64), ("out_stride", _i64),
@@ -262,6 +269,7 @@ ENTRY_POINTS = {
     "svk_deltakv_static_decode_plan": ([C.POINTER(SvkDeltakvPlanArgs), _p], C.c_int),
     "svk_deltakv_reconstruct_writeback": ([C.POINTER(SvkDeltakvReconstructArgs), _p], C.c_int),
     "svk_dequantize_grouped": ([C.POINTER(SvkDequantGroupedArgs), _p], C.c_int),
+    "svk_dequant_linear_act": ([C.POINTER(SvkDequantLinearArgs), _p], C.c_int),
     "svk_deltakv_token_scores": ([C.POINTER(SvkDeltakvTokenScoresArgs), _p], C.c_int),
     "svk_deltakv_token_scores_chunks": ([_i32], C.c_int),
     "svk_topk_sorted_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),

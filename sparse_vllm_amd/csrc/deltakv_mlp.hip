@@ -1,0 +1,253 @@
+// DeltaKV residual load, first half of `compress_up` fused with the latent dequantisation (gfx950):
+//   h = gelu(bf16(dequant_int4(latent[row_index]) . W1^T + b1))         [rows, N] bf16
+// replacing three launches of the reference flow (deltakv_less_memory.py:2841-2848 `_load_residual`):
+// triton_dequantize_2d_int4_grouped (quant.py:160-216), nn.Linear and nn.GELU of utils/compressor.py:69-73.
+// MFMA-bound: rows x K x N x 2 flop (2.1 GFLOP at 2048 x 256 x 2048) against 1.3 MB of operands; the library GEMM this
+// replaces ran at 17 us for this skinny-K shape, plus 5 us each for the dequant and GELU launches.
+//
+// Workgroup = 128 rows x 64 output features, 4 waves of 64 rows x 32 features.  The A tile (the workgroup's 128 latent rows) is
+// dequantised ONCE into LDS as bf16 with the reference's two roundings (q*scale, +min) and the bf16 cast of the
+// dequant output; the MFMA loop computes C^T = W1 . x^T (A operand = 16 weight rows straight from global/L2, B operand
+// = 16 latent rows from LDS), so a lane's 4 accumulator rows are 4 consecutive output features of one token: bias,
+// bf16 rounding of the linear output, erf-GELU in fp32 (torch's formula and operation order) and 8-byte stores.
+
+#include "svk_common.hpp"
+
+namespace svk {
+namespace {
+
+constexpr int kBM = 128, kBN = 64;       // 2 workgroups per CU: one's erf epilogue runs under the other's staging / MFMAs
+constexpr int kNI = kBN / 32;           // 16-feature MFMA tiles per wave
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2m_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2m_t;
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  const f32x2m_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2m_t));      // v_cvt_pk_bf16_f32 (RNE)
+}
+
+__device__ __forceinline__ float load_param(const void* p, int64_t i, int dtype) {
+  if (dtype == SVK_DTYPE_F32) return reinterpret_cast<const float*>(p)[i];
+  if (dtype == SVK_DTYPE_BF16) return __builtin_bit_cast(float, (uint32_t)reinterpret_cast<const uint16_t*>(p)[i] << 16);
+  return (float)reinterpret_cast<const _Float16*>(p)[i];
+}
+
+template <bool GELU, int KT>
+__global__ void __launch_bounds__(256) dequant_linear_act_kernel(const SvkDequantLinearArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];      // [kBM][K + 8] bf16
+  const int K = KT > 0 ? KT : a.k, ldx = K + 8;
+  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wn = w & 1, wm = w >> 1;
+  const int fr = lane & 15, kc = lane >> 4;
+  const uint16_t* wrow[kNI];
+#pragma unroll
+  for (int i = 0; i < kNI; ++i) {
+    const int n = min(n0 + wn * (kBN / 2) + i * 16 + fr, a.n - 1);           // clamped: rows past N are never stored
+    wrow[i] = a.weight + (int64_t)n * a.weight_stride + kc * 8;
+  }
+  // compile-time K: every weight fragment of the wave is requested before the dequantisation below, so the L2 round
+  // trips of the A operand run under the staging instead of once per k-step
+  constexpr int KS = KT > 0 ? KT / 32 : 1;
+  uint4 wf[KS][kNI];
+  if constexpr (KT > 0) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < kNI; ++i) wf[ks][i] = *reinterpret_cast<const uint4*>(wrow[i] + ks * 32);
+  }
+  // ---- dequantise the tile's rows into LDS: two threads per row, each a contiguous half row; the row index first, then
+  //      every code / scale / min load of the thread in one batch (two dependent round trips in all)
+  {
+    const int r = tid >> 1, half = tid & 1;
+    const int row = m0 + r;
+    const int wpt = K / 16;                                           // int4 words per thread (K/8 per row, 2 threads)
+    uint16_t* dst = xs + r * ldx + half * (K / 2);
+    if (row < a.rows) {
+      const int64_t src = a.row_index ? max(a.row_index[row], 0) : row;
+      const int32_t* pw = a.packed + src * a.packed_stride + half * wpt;
+      const int64_t sb = src * a.scale_stride;
+      auto dequant4 = [&](const uint4 w4, int w0) {                   // 4 words starting at word w0 of the half row
+        const uint32_t wd[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int g = ((half * wpt + w0 + u) * 8) / a.group_size;
+          const float sc = load_param(a.scale, sb + g, a.scale_dtype), mn = load_param(a.mn, sb + g, a.scale_dtype);
+          uint32_t p[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float q0 = (float)((wd[u] >> (8 * e)) & 15u), q1 = (float)((wd[u] >> (8 * e + 4)) & 15u);
+            p[e] = pack2_bf16(add_rn(mul_rn(q0, sc), mn), add_rn(mul_rn(q1, sc), mn));
+          }
+          *reinterpret_cast<uint4*>(dst + (w0 + u) * 8) = make_uint4(p[0], p[1], p[2], p[3]);
+        }
+      };
+      if constexpr (KT > 0) {
+        constexpr int NQ = KT / 64;                                   // 16-byte code loads per thread
+        uint4 cw[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) cw[q] = *reinterpret_cast<const uint4*>(pw + q * 4);
+        if (a.scale_dtype == SVK_DTYPE_BF16 && a.group_size == 32 && (a.scale_stride % 4) == 0 &&
+            (reinterpret_cast<uintptr_t>(a.scale) % 8) == 0 && (reinterpret_cast<uintptr_t>(a.mn) % 8) == 0) {
+          // group 32 = 4 words = one 16-byte code load: the half row's NQ scales / mins are one short vector each
+          // (behind the dtype switch of load_param every parameter load was a round trip of its own: 12 us)
+          static_assert(NQ == 4, "KT == 256");
+          const uint2 sv = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.scale) + sb + half * NQ);
+          const uint2 mv = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.mn) + sb + half * NQ);
+          const float scs[4] = {bf16_lo(sv.x), bf16_hi(sv.x), bf16_lo(sv.y), bf16_hi(sv.y)};
+          const float mns[4] = {bf16_lo(mv.x), bf16_hi(mv.x), bf16_lo(mv.y), bf16_hi(mv.y)};
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const uint32_t wd[4] = {cw[q].x, cw[q].y, cw[q].z, cw[q].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              uint32_t p[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float q0 = (float)((wd[u] >> (8 * e)) & 15u), q1 = (float)((wd[u] >> (8 * e + 4)) & 15u);
+                p[e] = pack2_bf16(add_rn(mul_rn(q0, scs[q]), mns[q]), add_rn(mul_rn(q1, scs[q]), mns[q]));
+              }
+              *reinterpret_cast<uint4*>(dst + (q * 4 + u) * 8) = make_uint4(p[0], p[1], p[2], p[3]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) dequant4(cw[q], q * 4);
+        }
+      } else {
+        const bool vec = (wpt % 4) == 0 && (a.packed_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(a.packed) % 16) == 0;
+        const int nq = vec ? wpt / 4 : 0;
+        for (int q = 0; q < nq; ++q) dequant4(*reinterpret_cast<const uint4*>(pw + q * 4), q * 4);
+        for (int u = nq * 4; u < wpt; ++u) {                           // unaligned rows / K not a multiple of 64
+          const uint32_t wd = (uint32_t)pw[u];
+          const int g = ((half * wpt + u) * 8) / a.group_size;
+          const float sc = load_param(a.scale, sb + g, a.scale_dtype), mn = load_param(a.mn, sb + g, a.scale_dtype);
+          uint32_t p[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float q0 = (float)((wd >> (8 * e)) & 15u), q1 = (float)((wd >> (8 * e + 4)) & 15u);
+            p[e] = pack2_bf16(add_rn(mul_rn(q0, sc), mn), add_rn(mul_rn(q1, sc), mn));
+          }
+          *reinterpret_cast<uint4*>(dst + u * 8) = make_uint4(p[0], p[1], p[2], p[3]);
+        }
+      }
+    } else {
+      for (int u = 0; u < wpt; ++u) *reinterpret_cast<uint4*>(dst + u * 8) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  __syncthreads();
+  // ---- C^T tile of this wave: features n0 + wn*64 .. +64 (MFMA rows), tokens m0 + wm*64 .. +64 (MFMA columns)
+  f32x4_t acc[kNI][4];                                                // [feature tile][token tile]
+#pragma unroll
+  for (int i = 0; i < kNI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const uint16_t* xrow = xs + (wm * 64 + fr) * ldx + kc * 8;
+  if constexpr (KT > 0) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8_t bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xrow + j * 16 * ldx + ks * 32));
+#pragma unroll
+      for (int i = 0; i < kNI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[ks][i]), bfr[j], acc[i][j], 0, 0, 0);
+    }
+  } else {
+    for (int k0 = 0; k0 < K; k0 += 32) {
+      bf16x8_t af[kNI], bfr[4];
+#pragma unroll
+      for (int i = 0; i < kNI; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wrow[i] + k0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xrow + j * 16 * ldx + k0));
+#pragma unroll
+      for (int i = 0; i < kNI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: lane (col = token fr of tile j, rows = features (lane>>4)*4 + r of tile i).  The bf16 results go
+  //      through LDS (the A tile is dead by now) so that the global stores are full 128-byte row segments
+  __syncthreads();
+  constexpr int ldy = kBN + 8;                                        // halfwords per staged output row
+  uint16_t* ys = xs;
+#pragma unroll
+  for (int i = 0; i < kNI; ++i) {
+    const int nl = wn * (kBN / 2) + i * 16 + kc * 4;                  // feature within the tile
+    const int n = n0 + nl;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.n) bias[r] = __builtin_bit_cast(float, (uint32_t)a.bias[n + r] << 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float y[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = bf16_round(acc[i][j][r] + bias[r]);                 // the Linear's bf16 output
+        if (GELU) {
+          // aten/src/ATen/native/cuda/ActivationGeluKernel.cu (approximate='none'), computed in fp32
+          v = mul_rn(mul_rn(v, 0.5f), add_rn(1.0f, erff(mul_rn(v, 0.70710678118654752440f))));
+        }
+        y[r] = v;
+      }
+      *reinterpret_cast<uint2*>(ys + (wm * 64 + j * 16 + fr) * ldy + nl) = make_uint2(pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3]));
+    }
+  }
+  __syncthreads();
+  const bool vec_out = (a.out_stride % 8) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16) == 0;
+  for (int c = tid; c < kBM * (kBN / 8); c += 256) {
+    const int r = c / (kBN / 8), seg = c % (kBN / 8);
+    const int row = m0 + r, n = n0 + seg * 8;
+    if (row >= a.rows || n >= a.n) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(ys + r * ldy + seg * 8);
+    uint16_t* o = a.out + (int64_t)row * a.out_stride + n;
+    if (vec_out && n + 8 <= a.n) {
+      *reinterpret_cast<uint4*>(o) = v;
+    } else {
+      const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+      for (int e = 0; e < 8 && n + e < a.n; ++e) o[e] = (uint16_t)(wd[e >> 1] >> ((e & 1) * 16));
+    }
+  }
+}
+
+}  // namespace
+}  // namespace svk
+
+extern "C" int svk_dequant_linear_act(const SvkDequantLinearArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->packed != nullptr && a->scale != nullptr && a->mn != nullptr && a->weight != nullptr && a->out != nullptr,
+              SVK_ERR_VALUE, "svk_dequant_linear_act: null args");
+  SVK_REQUIRE(a->k > 0 && a->k % 32 == 0 && a->k <= 512, SVK_ERR_LAYOUT, "svk_dequant_linear_act: K = %d must be a multiple of 32, <= 512", a->k);
+  SVK_REQUIRE(a->group_size > 0 && a->group_size % 8 == 0 && a->k % a->group_size == 0, SVK_ERR_VALUE,
+              "dequantization requires output_dim divisible by group_size, got output_dim=%d, group_size=%d.", a->k, a->group_size);
+  SVK_REQUIRE(a->n > 0 && (a->weight_stride % 8) == 0 && (reinterpret_cast<uintptr_t>(a->weight) % 16) == 0, SVK_ERR_LAYOUT,
+              "svk_dequant_linear_act: weight rows must be 16-byte aligned");
+  SVK_REQUIRE(a->activation == 0 || a->activation == 1, SVK_ERR_VALUE, "svk_dequant_linear_act: activation %d (0 none, 1 erf-GELU)", a->activation);
+  if (a->rows <= 0) return SVK_OK;
+  const size_t shm = sizeof(uint16_t) * kBM * (size_t)(a->k + 8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dequant_linear_act_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dequant_linear_act_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dequant_linear_act_kernel<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dequant_linear_act_kernel<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    attr_set = true;
+  }
+  const dim3 grid((a->n + kBN - 1) / kBN, (a->rows + kBM - 1) / kBM), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a->k == 256 && (a->packed_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(a->packed) % 16) == 0) {
+    // the latent width of the published compressors: fully unrolled
+    if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_kernel<true, 256>), grid, block, shm, s, *a);
+    else hipLaunchKernelGGL((dequant_linear_act_kernel<false, 256>), grid, block, shm, s, *a);
+  } else {
+    if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_kernel<true, 0>), grid, block, shm, s, *a);
+    else hipLaunchKernelGGL((dequant_linear_act_kernel<false, 0>), grid, block, shm, s, *a);
+  }
+  return check_launch("svk_dequant_linear_act");
+}

@@ -602,13 +602,38 @@ class DeltaKVCacheManager(CacheManager):
     def _load_residual(self, l_idx: int, recon_latent: torch.Tensor) -> torch.Tensor:
         """deltakv_less_memory.py:2841-2848: latent gather -> (int4 dequant) -> compress_up (library GEMMs)."""
         if int(self.config.kv_quant_bits or 0) == 4:
-            # gather + dequant in one launch (row_index = recon_latent, -1 entries read latent 0 and are never written back)
             cache = self.deltakv_latent_cache[l_idx]
+            up = self.compress_up[l_idx]
+            fused = self._fused_up_parts(up, cache)
+            if fused is not None:
+                # gather + dequant + Linear + GELU as one MFMA launch, the second Linear stays a library GEMM
+                lin1, lin2 = fused
+                h = dk.dequant_linear_act(cache, self.deltakv_latent_scales[l_idx], self.deltakv_latent_mins[l_idx],
+                                          self._quant_group_size(), lin1.weight, lin1.bias, activation="gelu",
+                                          row_index=recon_latent)
+                return torch.nn.functional.linear(h, lin2.weight, lin2.bias)
+            # gather + dequant in one launch (row_index = recon_latent, -1 entries read latent 0 and are never written back)
             residual = dk.dequantize_grouped(cache, self.deltakv_latent_scales[l_idx], self.deltakv_latent_mins[l_idx],
                                              self._quant_group_size(), int(cache.shape[-1]) * 8, 4, row_index=recon_latent)
         else:
             residual = self.deltakv_latent_cache[l_idx, recon_latent.clamp_min(0).long()]
         return self.compress_up[l_idx](residual)
+
+    @staticmethod
+    def _fused_up_parts(up, cache):
+        """(Linear, Linear) of an `mlp_gelu` compress_up the fused dequant+Linear+GELU kernel can serve, else None."""
+        import os
+        if os.environ.get("SVK_DELTAKV_FUSED_UP", "1") != "1" or not isinstance(up, torch.nn.Sequential) or len(up) != 3:
+            return None
+        lin1, act, lin2 = up[0], up[1], up[2]
+        if not (isinstance(lin1, torch.nn.Linear) and isinstance(lin2, torch.nn.Linear) and isinstance(act, torch.nn.GELU)):
+            return None
+        if getattr(act, "approximate", "none") != "none" or lin1.weight.dtype != torch.bfloat16:
+            return None
+        k = int(lin1.weight.shape[1])
+        if k % 32 != 0 or k > 512 or int(cache.shape[-1]) * 8 != k or not lin1.weight.is_contiguous():
+            return None
+        return lin1, lin2
 
     def _set_postrope_slots(self, layer_idx: int, slots: torch.Tensor):
         """deltakv_less_memory_cuda_graph.py:476-500 (-1 entries fall on a dummy slot that no row owns)."""

@@ -190,6 +190,44 @@ def dequantize_grouped(packed, scale, mn, group_size: int, output_dim: int, bits
     return out
 
 
+def dequant_linear_act(packed, scale, mn, group_size: int, weight, bias=None, *, activation: str = "gelu", row_index=None):
+    """`act(F.linear(dequant_int4(packed[row_index]), weight, bias))` as one MFMA launch (MI355X fusion of the residual
+    load's dequantisation with the first Linear (+ erf-GELU) of `compress_up`; `_load_residual`,
+    deltakv_less_memory.py:2841-2848, utils/compressor.py:69-73).  bf16 weights and output, int4 codes."""
+    if packed.dim() != 2 or scale.dim() != 2 or mn.dim() != 2:
+        raise ValueError("2D dequantization expects rank-2 packed/scale/min tensors, "
+                         f"got packed={tuple(packed.shape)}, scale={tuple(scale.shape)}, mn={tuple(mn.shape)}.")
+    if activation not in ("none", "gelu"):
+        raise ValueError(f"activation must be 'none' or 'gelu', got {activation!r}")
+    K, N = int(weight.shape[1]), int(weight.shape[0])
+    group_size = int(group_size)
+    if int(packed.shape[1]) * 8 != K:
+        raise ValueError(f"dequantization packed width mismatch: packed={packed.shape[1]}, expected={K // 8}.")
+    if group_size <= 0 or K % group_size != 0:
+        raise ValueError("dequantization requires output_dim divisible by group_size, "
+                         f"got output_dim={K}, group_size={group_size}.")
+    src_rows = int(packed.shape[0])
+    if tuple(scale.shape) != (src_rows, K // group_size) or tuple(mn.shape) != tuple(scale.shape):
+        raise ValueError("dequantization scale/min shape mismatch: "
+                         f"scale={tuple(scale.shape)}, mn={tuple(mn.shape)}, expected={(src_rows, K // group_size)}.")
+    assert weight.dtype == torch.bfloat16 and weight.stride(1) == 1
+    assert bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N)
+    assert packed.dtype == torch.int32 and packed.stride(1) == 1 and scale.stride(1) == 1 and scale.stride() == mn.stride()
+    assert scale.dtype == mn.dtype
+    if row_index is not None:
+        assert row_index.dtype == torch.int32 and row_index.is_contiguous()
+    n = src_rows if row_index is None else int(row_index.numel())
+    out = torch.empty((n, N), device=packed.device, dtype=torch.bfloat16)
+    lib = _lib.load()
+    a = _lib.SvkDequantLinearArgs(packed=_lib.ptr(packed), scale=_lib.ptr(scale), mn=_lib.ptr(mn), row_index=_lib.ptr(row_index),
+                                  weight=_lib.ptr(weight), bias=_lib.ptr(bias), out=_lib.ptr(out),
+                                  packed_stride=packed.stride(0), scale_stride=scale.stride(0), weight_stride=weight.stride(0),
+                                  out_stride=out.stride(0), rows=n, k=K, n=N, group_size=group_size, scale_dtype=_dt(scale),
+                                  activation=1 if activation == "gelu" else 0)
+    _lib.check(lib.svk_dequant_linear_act(C.byref(a), _lib.current_stream_handle()), lib)
+    return out
+
+
 def triton_dequantize_2d_int4_grouped(packed, scale, mn, group_size: int, output_dim: int):
     """Reference name kept for call-site compatibility (quant.py:160-216)."""
     return dequantize_grouped(packed, scale, mn, group_size, output_dim, 4)

@@ -300,3 +300,38 @@ def test_fused_static_decode_variants_match_unfused():
         outs.append((ok, ov))
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("shape", [dict(rows=300, src=157, K=256, N=2048), dict(rows=129, src=129, K=64, N=200),
+                                   dict(rows=5, src=9, K=512, N=136)])
+@pytest.mark.parametrize("act", ["gelu", "none"])
+def test_dequant_linear_act_matches_separate_ops(shape, act):
+    """Fused residual load (int4 dequant + first Linear + erf-GELU of compress_up) against the numpy restatement of
+    the three separate ops with the same rounding points (bf16 dequant output, fp32 accumulate, bf16 Linear output,
+    fp32 GELU, bf16 result).  Only the accumulation order differs: a few bf16 ulps."""
+    import math
+    from sparse_vllm_amd.kernels.deltakv_kernels import dequant_linear_act, dequantize_grouped
+    rows, src, K, N = (shape[k] for k in ("rows", "src", "K", "N"))
+    rng = np.random.default_rng(rows + K)
+    x = rng.standard_normal((src, K)).astype(np.float32)
+    code, scale, mn = od.quantize_pack_grouped(x, 32, 4)
+    scale, mn = bf16_round(scale), bf16_round(mn)
+    W = bf16_round((rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32))
+    b = bf16_round((rng.standard_normal((N,)) * 0.1).astype(np.float32))
+    ridx = rng.integers(-1, src, size=rows).astype(np.int32)
+    out = dequant_linear_act(t(code), to_bf16(scale), to_bf16(mn), 32, to_bf16(W), to_bf16(b), activation=act, row_index=t(ridx))
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (rows, N)
+    # the dequantised operand is bit-identical to the stand-alone kernel's bf16 output
+    xd = dequantize_grouped(t(code), to_bf16(scale), to_bf16(mn), 32, K, 4, row_index=t(ridx)).float().cpu().numpy()
+    y = bf16_round((xd.astype(np.float64) @ W.astype(np.float64).T + b.astype(np.float64)).astype(np.float32))
+    if act == "gelu":
+        erf = np.vectorize(math.erf)
+        y = (y.astype(np.float64) * 0.5 * (1.0 + erf(y.astype(np.float64) * math.sqrt(0.5)))).astype(np.float32)
+    ref = bf16_round(y)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2e-2, atol=2e-2)
+    assert np.mean(out.float().cpu().numpy() == ref) > 0.97      # almost every element lands on the same bf16 value
+    # no bias / no row_index form
+    out2 = dequant_linear_act(t(code), to_bf16(scale), to_bf16(mn), 32, to_bf16(W), None, activation="none")
+    xd2 = dequantize_grouped(t(code), to_bf16(scale), to_bf16(mn), 32, K, 4).float().cpu().numpy()
+    np.testing.assert_allclose(out2.float().cpu().numpy(), bf16_round((xd2.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32)),
+                               rtol=2e-2, atol=2e-2)
