@@ -573,6 +573,7 @@ typedef struct SvkContextAttentionArgs {
   const int32_t* req_to_tokens;  /* [rows, req_stride]                                    */
   int64_t q_stride_t, q_stride_h, kv_slot_stride, kv_head_stride, o_stride_t, o_stride_h, req_stride;
   int32_t batch, num_q_heads, num_kv_heads, head_dim, max_input_len;
+  int64_t kv_num_slots;          /* slots in k_cache / v_cache (0 = unknown): < 4 GiB tensors get 32-bit row offsets */
 } SvkContextAttentionArgs;
 int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_stream_t stream);
 

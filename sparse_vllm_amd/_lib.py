@@ -210,7 +210,8 @@ class SvkContextAttentionArgs(C.Structure):
                                   "b_prompt_cache_len", "req_to_tokens")] + \
                [(n, _i64) for n in ("q_stride_t", "q_stride_h", "kv_slot_stride", "kv_head_stride", "o_stride_t", "o_stride_h",
                                     "req_stride")] + \
-               [(n, _i32) for n in ("batch", "num_q_heads", "num_kv_heads", "head_dim", "max_input_len")]
+               [(n, _i32) for n in ("batch", "num_q_heads", "num_kv_heads", "head_dim", "max_input_len")] + \
+               [("_pad", _i32), ("kv_num_slots", _i64)]
 
 
 class SvkQuantPackArgs(C.Structure):

@@ -29,7 +29,7 @@ __device__ __forceinline__ uint32_t pack_bf16_pair(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pa_bf16x2_t));      // v_cvt_pk_bf16_f32 (RNE)
 }
 
-template <int D>
+template <int D, bool OFF32>
 __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContextAttentionArgs a) {
   constexpr int NC = D / 32, DW = D / 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
     for (int c = 0; c < NC; ++c) qa[t][c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qp + c * 32));
   }
   const float sm_scale = rsqrtf((float)D) * 1.4426950408889634f;
+  const float mask_raw = -1.0e8f / sm_scale;
   float m[2][4], l[2][4];
   f32x4_t acc[2][8];
 #pragma unroll
@@ -70,8 +71,21 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  const uint16_t* kbase = a.k_cache + (int64_t)kvh * a.kv_head_stride + kc * 8;
-  const uint16_t* vbase = a.v_cache + (int64_t)kvh * a.kv_head_stride + dg * 8;
+  // Row addressing.  OFF32: the K (V) tensor spans < 4 GiB, so a row address is the tensor base + a 32-bit byte
+  // offset: one v_mul_lo + one add per row instead of 64-bit multiply-adds (10 row addresses per key tile).
+  const char* const kt = reinterpret_cast<const char*>(a.k_cache);
+  const char* const vt = reinterpret_cast<const char*>(a.v_cache);
+  const int64_t slot_bytes = a.kv_slot_stride * 2;
+  const int64_t k_lane_bytes = ((int64_t)kvh * a.kv_head_stride + kc * 8) * 2;
+  const int64_t v_lane_bytes = ((int64_t)kvh * a.kv_head_stride + dg * 8) * 2;
+  auto k_ptr = [&](int slot) -> const uint16_t* {
+    if (OFF32) return reinterpret_cast<const uint16_t*>(kt + (size_t)((uint32_t)slot * (uint32_t)slot_bytes + (uint32_t)k_lane_bytes));
+    return reinterpret_cast<const uint16_t*>(kt + (int64_t)slot * slot_bytes + k_lane_bytes);
+  };
+  auto v_ptr = [&](int slot) -> const uint16_t* {
+    if (OFF32) return reinterpret_cast<const uint16_t*>(vt + (size_t)((uint32_t)slot * (uint32_t)slot_bytes + (uint32_t)v_lane_bytes));
+    return reinterpret_cast<const uint16_t*>(vt + (int64_t)slot * slot_bytes + v_lane_bytes);
+  };
   uint32_t* Pl32 = reinterpret_cast<uint32_t*>(Pl);
   auto wave_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -91,7 +105,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
   uint4 kr[2][NC];
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    const uint16_t* kp = kbase + (int64_t)slot_lds[g * 16 + n] * a.kv_slot_stride;
+    const uint16_t* kp = k_ptr(slot_lds[g * 16 + n]);
 #pragma unroll
     for (int c = 0; c < NC; ++c) kr[g][c] = *reinterpret_cast<const uint4*>(kp + c * 32);
   }
@@ -105,7 +119,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
     uint4 vr[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      vr[e] = *reinterpret_cast<const uint4*>(vbase + (int64_t)cur[(e & 1) * 16 + vcol0 + (e >> 1)] * a.kv_slot_stride);
+      vr[e] = *reinterpret_cast<const uint4*>(v_ptr(cur[(e & 1) * 16 + vcol0 + (e >> 1)]));
     if (lane < kKTile) nxt[lane] = s_next;
     s_next = fetch_slots(k0 + 2 * kKTile);
     // ---- S = Q K^T for both query tiles, then the K registers are dead: re-arm them with K(i+1)
@@ -123,7 +137,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
     if constexpr (has_next) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const uint16_t* kp = kbase + (int64_t)nxt[g * 16 + n] * a.kv_slot_stride;
+        const uint16_t* kp = k_ptr(nxt[g * 16 + n]);
 #pragma unroll
         for (int c = 0; c < NC; ++c) kr[g][c] = *reinterpret_cast<const uint4*>(kp + c * 32);
       }
@@ -137,17 +151,26 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qrow = m0 + t * 16 + kc * 4 + r;
-        float x0 = s[t][0][r] * sm_scale, x1 = s[t][1][r] * sm_scale;
+        // the running maximum lives in the raw-logit domain (sm_scale > 0 keeps the order): p = exp2(s*scale - m*scale)
+        // is one fma per element instead of a multiply and a subtract; masked logits sit at -1e8 / scale like the
+        // reference's -1e8 after scaling
+        float x0 = s[t][0][r], x1 = s[t][1][r];
         if (diag) {
           const int key = k0 + n;
-          if (!(key <= qrow + pc && key < kv_end)) x0 = -1.0e8f;
-          if (!(key + 16 <= qrow + pc && key + 16 < kv_end)) x1 = -1.0e8f;
+          if (!(key <= qrow + pc && key < kv_end)) x0 = mask_raw;
+          if (!(key + 16 <= qrow + pc && key + 16 < kv_end)) x1 = mask_raw;
         }
-        const float nm = fmaxf(m[t][r], row16_allmax(fmaxf(x0, x1)));
-        const float p0 = __builtin_amdgcn_exp2f(x0 - nm), p1 = __builtin_amdgcn_exp2f(x1 - nm);
-        alpha[t][r] = __builtin_amdgcn_exp2f(m[t][r] - nm);
-        rescale |= (nm != m[t][r]);
-        l[t][r] = l[t][r] * alpha[t][r] + (p0 + p1);      // lane-partial row sum: reduced across the 16 columns once, in the epilogue
+        const float nm = vmax(m[t][r], row16_allmax(vmax(x0, x1)));
+        const float nms = nm * sm_scale;
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(x0, sm_scale, -nms));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(x1, sm_scale, -nms));
+        float al = 1.0f;
+        if (nm != m[t][r]) {                                // the rescale factor only when the row maximum moved
+          al = __builtin_amdgcn_exp2f(m[t][r] * sm_scale - nms);
+          rescale = true;
+        }
+        alpha[t][r] = al;
+        l[t][r] = l[t][r] * al + (p0 + p1);               // lane-partial row sum: reduced across the 16 columns once, in the epilogue
         m[t][r] = nm;
         Pl32[(t * 16 + kc * 4 + r) * (kPRowP / 2) + n] = pack_bf16_pair(p0, p1);
       }
@@ -226,7 +249,13 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
   dim3 grid((a->max_input_len + kQTile - 1) / kQTile, a->num_kv_heads, a->batch), block(64 * G);
   const size_t shm = (size_t)G * (kQTile * kPRowP * 2 + 256);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (a->head_dim == 128) hipLaunchKernelGGL(context_attention_kernel<128>, grid, block, shm, s, *a);
-  else hipLaunchKernelGGL(context_attention_kernel<64>, grid, block, shm, s, *a);
+  const bool off32 = a->kv_num_slots > 0 && (a->kv_num_slots * a->kv_slot_stride * 2) < (int64_t)0xffffffffll;
+  if (a->head_dim == 128) {
+    if (off32) hipLaunchKernelGGL((context_attention_kernel<128, true>), grid, block, shm, s, *a);
+    else hipLaunchKernelGGL((context_attention_kernel<128, false>), grid, block, shm, s, *a);
+  } else {
+    if (off32) hipLaunchKernelGGL((context_attention_kernel<64, true>), grid, block, shm, s, *a);
+    else hipLaunchKernelGGL((context_attention_kernel<64, false>), grid, block, shm, s, *a);
+  }
   return check_launch("svk_context_attention_fwd");
 }

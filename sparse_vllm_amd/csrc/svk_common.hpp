@@ -71,12 +71,26 @@ __device__ __forceinline__ float row_ror(float x) {
   return __builtin_bit_cast(
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
 }
+// max(x, x rotated by N inside the 16-lane row) as ONE instruction.  The compiler's form of fmaxf(x, row_ror(x)) is
+// v_mov 0 / v_mov_dpp / v_max (canonicalise) / v_max: the DPP move cannot be folded because the `old` operand (0) is
+// not the identity of max, and fmaxf quiets NaNs.  `s_nop 1` covers the 2 wait states a DPP read needs after the VALU
+// write of its source (inline asm is opaque to the hazard recogniser).
+#define SVK_ROW_ROR_MAX(N_)                                                                                       \
+  __device__ __forceinline__ float row_ror_max##N_(float x) {                                                     \
+    float y;                                                                                                      \
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:" #N_ " row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));   \
+    return y;                                                                                                     \
+  }
+SVK_ROW_ROR_MAX(8) SVK_ROW_ROR_MAX(4) SVK_ROW_ROR_MAX(2) SVK_ROW_ROR_MAX(1)
+#undef SVK_ROW_ROR_MAX
+// plain v_max_f32 (no NaN-quieting canonicalisation of the operands; callers pass finite values or -inf)
+__device__ __forceinline__ float vmax(float a, float b) {
+  float y;
+  asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+  return y;
+}
 __device__ __forceinline__ float row16_allmax(float x) {
-  x = fmaxf(x, row_ror<8>(x));
-  x = fmaxf(x, row_ror<4>(x));
-  x = fmaxf(x, row_ror<2>(x));
-  x = fmaxf(x, row_ror<1>(x));
-  return x;
+  return row_ror_max1(row_ror_max2(row_ror_max4(row_ror_max8(x))));
 }
 __device__ __forceinline__ float row16_allsum(float x) {
   x += row_ror<8>(x);

@@ -37,5 +37,5 @@ def context_attention_fwd(q, k, v, o, b_req_idx, b_start_loc, b_seq_len, b_promp
         req_to_tokens=_lib.ptr(req_to_token_indexs), q_stride_t=q.stride(0), q_stride_h=q.stride(1),
         kv_slot_stride=k.stride(0), kv_head_stride=k.stride(1), o_stride_t=o.stride(0), o_stride_h=o.stride(1),
         req_stride=req_to_token_indexs.stride(0), batch=int(b_seq_len.shape[0]), num_q_heads=int(q.shape[1]),
-        num_kv_heads=int(k.shape[1]), head_dim=int(Lk), max_input_len=int(max_input_len))
+        num_kv_heads=int(k.shape[1]), head_dim=int(Lk), max_input_len=int(max_input_len), kv_num_slots=int(k.shape[0]))
     _lib.check(lib.svk_context_attention_fwd(C.byref(a), _lib.current_stream_handle()), lib)
