@@ -664,6 +664,412 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 128-token tiles with a whole tile in flight (variant 4, <= 4 KV heads).  The tile kernel above is latency-bound: a
+// tile costs ~7 dependent global round trips (group classification x2, K chunk pipeline, V blocks) at 2 waves/SIMD,
+// 22-33 us per tile against 4.5 us of VALU work.  Here
+//   * the 8-token groups of the workgroup's whole token range are classified ONCE by all threads into LDS
+//     (block id / offset per group), so a tile's addresses need no memory round trip;
+//   * every load of tile i+1 (32 K words, 2 x 32 K scale/min floats, 32 V words, V scale/min words: 136 registers)
+//     is issued before tile i is computed - two register tile buffers, one wave per SIMD (512-register budget,
+//     amdgpu_waves_per_eu(1,1)), long token ranges per workgroup (the caller picks block_seq so that the grid is one
+//     round of <= 256 workgroups);
+//   * the arithmetic is the tile kernel's, instruction for instruction (same fragments, same roundings).
+// ------------------------------------------------------------------------------------------------
+
+template <int D, bool KF32>
+struct KiviTileRegs {
+  static constexpr int NC = D / 32, NG = D / 32;
+  uint32_t wq[NC][8];       // K words: chunk c, channel kc*8 + e, tokens 8n..8n+7
+  float scq[NC][8], mnq[NC][8];
+  uint32_t vq[4][8];        // V words: 32-token block j, token kc*8 + e, head dims dg*8..+8
+  uint32_t vsw[NG], vmw[NG];
+};
+
+template <int D, int G, bool KF32>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+kivi_stage1_tile128_pf_kernel(const SvkKiviDecodeStage1Args a) {
+  constexpr int NC = D / 32, JQ = (G + 3) / 4, DW = D / 8, NG = D / 32;
+  constexpr int kT = 128, GS = 32;
+  constexpr int P_BYTES = 16 * kT * 2, VS_BYTES = NG * kT * 2, WAVE_BYTES = P_BYTES + 2 * VS_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Hkv = a.num_kv_heads;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int n = lane & 15, kc = lane >> 4;
+  const int dg = n % DW;
+  unsigned char* wl = lds_raw + w * WAVE_BYTES;
+  uint16_t* Pl = reinterpret_cast<uint16_t*>(wl);
+  uint16_t* Vs = reinterpret_cast<uint16_t*>(wl + P_BYTES);
+  uint16_t* Vm = reinterpret_cast<uint16_t*>(wl + P_BYTES + VS_BYTES);
+  int* grp_b = reinterpret_cast<int*>(lds_raw + (size_t)Hkv * WAVE_BYTES);      // [block_seq / 8] block id, -1 = slow
+  int* grp_lt = grp_b + a.block_seq / 8;                                         // offset of the group in its block
+  const int len = a.context_lens[b];
+  const int start = blk * a.block_seq;
+  const int end = min(len, start + a.block_seq);
+  float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)blk * a.mid_o_stride_s;
+  float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + blk;
+  if (end <= start) {
+    for (int h = 0; h < G; ++h) {
+      float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h;
+      for (int d = lane; d < D; d += 64) o[d] = 0.f;
+      if (lane == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = -INFINITY;
+    }
+    return;
+  }
+  const int row = a.req_indices[b];
+  const int32_t* raw_map = a.raw_slots_map + (int64_t)row * a.map_stride;
+  const int32_t* blk_map = a.kivi_block_slots_map + (int64_t)row * a.map_stride;
+  // ---- classify every 8-token group of [start, end) once (all threads of the workgroup)
+  for (int g = threadIdx.x; g < a.block_seq / 8; g += blockDim.x) {
+    const int tg = start + g * 8;
+    int gb = -1, glt = 0;
+    if (tg + 8 <= end) {
+      const int b0 = blk_map[tg];
+      bool ok = b0 >= 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ok = ok && raw_map[tg + e] < 0 && blk_map[tg + e] == b0;
+      if (ok) {
+        const int lt0 = tg - a.kivi_block_start_pos[b0];
+        if (lt0 >= 0 && (lt0 & 7) == 0 && lt0 + 8 <= GS) { gb = b0; glt = lt0; }
+      }
+    }
+    grp_b[g] = gb;
+    grp_lt[g] = glt;
+  }
+  for (int i = lane; i < P_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(Pl)[i] = 0u;     // rows >= G stay zero
+  bf16x8_t qa[NC];
+  {
+    const uint16_t* qp = a.q + (int64_t)b * a.q_stride_b + (int64_t)(w * G + n) * a.q_stride_h + kc * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (n < G) t = *reinterpret_cast<const uint4*>(qp + c * 32);
+      qa[c] = __builtin_bit_cast(bf16x8_t, t);
+    }
+  }
+  __syncthreads();
+  const float sm_scale = rsqrtf((float)D);
+  const bool score_vec = a.attn_score != nullptr && (a.score_stride_b % 4) == 0 && (a.score_stride_h % 4) == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.attn_score) % 16) == 0 && (start % 8) == 0;
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+  f32x4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // generic per-token fragments (tiles with raw tokens, ragged ends, unaligned blocks): as in the tile kernel
+  auto token_k = [&](int t, uint4 (&kr)[NC]) -> bool {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) kr[c] = make_uint4(0, 0, 0, 0);
+    if (t >= end) return false;
+    const int rs = raw_map[t];
+    if (rs >= 0) {
+      const uint16_t* kp = a.raw_k + (int64_t)rs * a.raw_slot_stride + (int64_t)w * a.raw_head_stride + kc * 8;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) kr[c] = *reinterpret_cast<const uint4*>(kp + c * 32);
+      return true;
+    }
+    const int bs = blk_map[t];
+    if (bs < 0) return false;
+    const int lt = t - a.kivi_block_start_pos[bs];
+    if (lt < 0 || lt >= GS) return false;
+    const int64_t hb = (int64_t)bs * Hkv + w;
+    const int shift = (lt & 7) * 4, widx = lt >> 3;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int d0 = c * 32 + kc * 8;
+      uint32_t ow[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        float s0, s1, m0, m1;
+        if constexpr (KF32) {
+          const float* sp = reinterpret_cast<const float*>(a.key_scales) + hb * D + d0 + e2 * 2;
+          const float* mp = reinterpret_cast<const float*>(a.key_mins) + hb * D + d0 + e2 * 2;
+          s0 = sp[0]; s1 = sp[1]; m0 = mp[0]; m1 = mp[1];
+        } else {
+          const uint32_t sw = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.key_scales) + hb * D + d0 + e2 * 2);
+          const uint32_t mw = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.key_mins) + hb * D + d0 + e2 * 2);
+          s0 = bf16_lo(sw); s1 = bf16_hi(sw); m0 = bf16_lo(mw); m1 = bf16_hi(mw);
+        }
+        const int32_t* cw = a.key_packed + (hb * D + d0 + e2 * 2) * (GS / 8) + widx;
+        const float q0 = (float)(((uint32_t)cw[0] >> shift) & 15u), q1 = (float)(((uint32_t)cw[GS / 8] >> shift) & 15u);
+        ow[e2] = pack_bf16(add_rn(mul_rn(q0, s0), m0), add_rn(mul_rn(q1, s1), m1));
+      }
+      kr[c] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+    return true;
+  };
+  auto token_v = [&](int t) -> uint4 {
+    if (t >= end) return make_uint4(0, 0, 0, 0);
+    const int rs = raw_map[t];
+    if (rs >= 0) return *reinterpret_cast<const uint4*>(a.raw_v + (int64_t)rs * a.raw_slot_stride + (int64_t)w * a.raw_head_stride + dg * 8);
+    const int bs = blk_map[t];
+    if (bs < 0) return make_uint4(0, 0, 0, 0);
+    const int lt = t - a.kivi_block_start_pos[bs];
+    if (lt < 0 || lt >= GS) return make_uint4(0, 0, 0, 0);
+    const int64_t tb = ((int64_t)bs * Hkv + w) * GS + lt;
+    const uint32_t word = (uint32_t)a.value_packed[tb * DW + dg];
+    const float sc = __builtin_bit_cast(float, (uint32_t)a.value_scales[tb * NG + dg / 4] << 16);
+    const float mn = __builtin_bit_cast(float, (uint32_t)a.value_mins[tb * NG + dg / 4] << 16);
+    uint32_t o[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2)
+      o[e2] = pack_bf16(add_rn(mul_rn((float)((word >> (e2 * 8)) & 15u), sc), mn),
+                        add_rn(mul_rn((float)((word >> (e2 * 8 + 4)) & 15u), sc), mn));
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
+
+  // a tile is fast when all 16 of its groups are (wave-uniform answer from the LDS classification)
+  auto tile_fast = [&](int t0) -> bool {
+    const int g0 = (t0 - start) / 8;
+    return __all(lane >= 16 || grp_b[g0 + lane] >= 0);
+  };
+  // issue the K loads (codes, scales, mins) / the V loads (codes, scale and min words) of a fast tile
+  auto load_k = [&](KiviTileRegs<D, KF32>& T, int t0) __attribute__((always_inline)) {
+    const int g0 = (t0 - start) / 8;
+    {
+      const int kb = grp_b[g0 + n], klt = grp_lt[g0 + n];
+      const int64_t hb = (int64_t)kb * Hkv + w;
+      const int32_t* kw = a.key_packed + (hb * D + kc * 8) * (GS / 8) + (klt >> 3);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) T.wq[c][e] = (uint32_t)kw[(c * 32 + e) * (GS / 8)];
+        if constexpr (KF32) {
+          const float* sp = reinterpret_cast<const float*>(a.key_scales) + hb * D + c * 32 + kc * 8;
+          const float* mp = reinterpret_cast<const float*>(a.key_mins) + hb * D + c * 32 + kc * 8;
+          const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+          const float4 m0 = *reinterpret_cast<const float4*>(mp), m1 = *reinterpret_cast<const float4*>(mp + 4);
+          T.scq[c][0] = s0.x; T.scq[c][1] = s0.y; T.scq[c][2] = s0.z; T.scq[c][3] = s0.w;
+          T.scq[c][4] = s1.x; T.scq[c][5] = s1.y; T.scq[c][6] = s1.z; T.scq[c][7] = s1.w;
+          T.mnq[c][0] = m0.x; T.mnq[c][1] = m0.y; T.mnq[c][2] = m0.z; T.mnq[c][3] = m0.w;
+          T.mnq[c][4] = m1.x; T.mnq[c][5] = m1.y; T.mnq[c][6] = m1.z; T.mnq[c][7] = m1.w;
+        } else {
+          const uint4 sv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.key_scales) + hb * D + c * 32 + kc * 8);
+          const uint4 mv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.key_mins) + hb * D + c * 32 + kc * 8);
+          T.scq[c][0] = bf16_lo(sv.x); T.scq[c][1] = bf16_hi(sv.x); T.scq[c][2] = bf16_lo(sv.y); T.scq[c][3] = bf16_hi(sv.y);
+          T.scq[c][4] = bf16_lo(sv.z); T.scq[c][5] = bf16_hi(sv.z); T.scq[c][6] = bf16_lo(sv.w); T.scq[c][7] = bf16_hi(sv.w);
+          T.mnq[c][0] = bf16_lo(mv.x); T.mnq[c][1] = bf16_hi(mv.x); T.mnq[c][2] = bf16_lo(mv.y); T.mnq[c][3] = bf16_hi(mv.y);
+          T.mnq[c][4] = bf16_lo(mv.z); T.mnq[c][5] = bf16_hi(mv.z); T.mnq[c][6] = bf16_lo(mv.w); T.mnq[c][7] = bf16_hi(mv.w);
+        }
+      }
+    }
+  };
+  auto load_v = [&](KiviTileRegs<D, KF32>& T, int t0) __attribute__((always_inline)) {
+    const int g0 = (t0 - start) / 8;
+    {
+      // V scale / min rows of the tile: lane l covers tokens 2l, 2l+1
+      const int gsrc = lane >> 2;
+      const int vb = grp_b[g0 + gsrc], vlt = grp_lt[g0 + gsrc] + ((2 * lane) & 7);
+      const int64_t tb = (((int64_t)vb * Hkv + w) * GS + vlt) * NG;
+      if constexpr (NG == 4) {
+        const uint4 s4 = *reinterpret_cast<const uint4*>(a.value_scales + tb), m4 = *reinterpret_cast<const uint4*>(a.value_mins + tb);
+        T.vsw[0] = s4.x; T.vsw[1] = s4.y; T.vsw[2] = s4.z; T.vsw[3] = s4.w; T.vmw[0] = m4.x; T.vmw[1] = m4.y; T.vmw[2] = m4.z; T.vmw[3] = m4.w;
+      } else {
+        const uint2 s2 = *reinterpret_cast<const uint2*>(a.value_scales + tb), m2 = *reinterpret_cast<const uint2*>(a.value_mins + tb);
+        T.vsw[0] = s2.x; T.vsw[1] = s2.y; T.vmw[0] = m2.x; T.vmw[1] = m2.y;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int vb = grp_b[g0 + 4 * j + kc], vlt = grp_lt[g0 + 4 * j + kc];
+      const int32_t* vw = a.value_packed + ((((int64_t)vb * Hkv + w) * GS + vlt) * DW + dg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) T.vq[j][e] = (uint32_t)vw[e * DW];
+    }
+  };
+
+  // ---- one register set, reloaded right after its last use: the K registers of tile i+1 are requested as soon as the
+  //      Q.K^T phase of tile i is over (they fly under its softmax and P.V phases), the V registers as soon as its P.V
+  //      phase is over (they fly under the next Q.K^T phase).  One copy of the tile code (the instruction cache is
+  //      shared by two CUs; two unrolled copies of this loop do not fit).
+  KiviTileRegs<D, KF32> T;
+  bool fast = tile_fast(start);
+  if (fast) { load_k(T, start); load_v(T, start); }
+  for (int t0 = start; t0 < end; t0 += kT) {
+    const int t1 = t0 + kT;
+    const bool fast_next = t1 < end && tile_fast(t1);
+    f32x4_t s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    unsigned tvmask = 0xffu;
+    if (fast) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const uint32_t (&wd)[8] = T.wq[c];
+        const float (&sc)[8] = T.scq[c];
+        const float (&mn)[8] = T.mnq[c];
+        uint32_t lo[8], hi[8];
+        float sc16[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lo[e] = wd[e] & 0x0f0f0f0fu; hi[e] = wd[e] & 0xf0f0f0f0u; sc16[e] = sc[e] * 0.0625f; }
+#define SVK_K_MFMA(I_)                                                                                         \
+        {                                                                                                      \
+          uint32_t kf[4];                                                                                      \
+          _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                                   \
+            const float x0 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2], hi[2 * e2]), ((I_) & 1) ? sc16[2 * e2] : sc[2 * e2]), mn[2 * e2]);             \
+            const float x1 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2 + 1], hi[2 * e2 + 1]), ((I_) & 1) ? sc16[2 * e2 + 1] : sc[2 * e2 + 1]), mn[2 * e2 + 1]); \
+            kf[e2] = pack_bf16(x0, x1);                                                                        \
+          }                                                                                                    \
+          s[I_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, make_uint4(kf[0], kf[1], kf[2], kf[3])), s[I_], 0, 0, 0); \
+        }
+        SVK_K_MFMA(0) SVK_K_MFMA(1) SVK_K_MFMA(2) SVK_K_MFMA(3) SVK_K_MFMA(4) SVK_K_MFMA(5) SVK_K_MFMA(6) SVK_K_MFMA(7)
+#undef SVK_K_MFMA
+      }
+    } else {
+      tvmask = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        uint4 kr[NC];
+        if (token_k(t0 + 8 * n + i, kr)) tvmask |= 1u << i;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, kr[c]), s[i], 0, 0, 0);
+      }
+    }
+    if (fast_next) load_k(T, t1);
+    if (a.attn_score != nullptr && kc < JQ) {
+      const bool vec = score_vec && tvmask == 0xffu;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int h = kc * 4 + r;
+        if (h < G) {
+          float* dst = a.attn_score + (int64_t)b * a.score_stride_b + (int64_t)(w * G + h) * a.score_stride_h + t0 + 8 * n;
+          if (vec) {
+            *reinterpret_cast<float4*>(dst) = make_float4(s[0][r], s[1][r], s[2][r], s[3][r]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(s[4][r], s[5][r], s[6][r], s[7][r]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if ((tvmask >> i) & 1u) dst[i] = s[i][r];
+          }
+        }
+      }
+    }
+    float alpha[4];
+    bool rescale = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool hv = (kc * 4 + r < G);
+      float x[8], tmax = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[i] = (hv && ((tvmask >> i) & 1u)) ? s[i][r] * sm_scale : -INFINITY;
+        tmax = fmaxf(tmax, x[i]);
+      }
+      tmax = row16_allmax(tmax);
+      const float nm = fmaxf(m[r], tmax);
+      float psum = 0.f;
+      uint32_t pw[4] = {0u, 0u, 0u, 0u};
+      alpha[r] = 1.f;
+      if (hv && nm > -INFINITY) {
+        alpha[r] = __expf(m[r] - nm);
+        float p[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { p[i] = __expf(x[i] - nm); psum += p[i]; }
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) pw[e2] = pack_bf16(p[2 * e2], p[2 * e2 + 1]);
+        rescale |= (nm != m[r]);
+        m[r] = nm;
+      }
+      l[r] = l[r] * alpha[r] + row16_allsum(psum);
+      if (kc < JQ) *reinterpret_cast<uint4*>(Pl + (kc * 4 + r) * kT + 8 * n) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+    }
+    if (__any(rescale)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] *= alpha[r];
+    }
+    if (fast) {
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int flat = tk * NG + g;
+          const uint32_t sword = T.vsw[flat >> 1], mword = T.vmw[flat >> 1];
+          Vs[g * kT + 2 * lane + tk] = (uint16_t)((flat & 1) ? (sword >> 16) : (sword & 0xffffu));
+          Vm[g * kT + 2 * lane + tk] = (uint16_t)((flat & 1) ? (mword >> 16) : (mword & 0xffffu));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint4 pa = *reinterpret_cast<const uint4*>(Pl + n * kT + 32 * j + kc * 8);
+      const bf16x8_t pfrag = __builtin_bit_cast(bf16x8_t, pa);
+      if (fast) {
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t wd = T.vq[j][e];
+          lo[e] = wd & 0x0f0f0f0fu;
+          hi[e] = wd & 0xf0f0f0f0u;
+        }
+        const uint4 s8 = *reinterpret_cast<const uint4*>(Vs + (dg / 4) * kT + 32 * j + kc * 8);
+        const uint4 m8 = *reinterpret_cast<const uint4*>(Vm + (dg / 4) * kT + 32 * j + kc * 8);
+        float sc[8], sc16[8], mn[8];
+        sc[0] = bf16_lo(s8.x); sc[1] = bf16_hi(s8.x); sc[2] = bf16_lo(s8.y); sc[3] = bf16_hi(s8.y);
+        sc[4] = bf16_lo(s8.z); sc[5] = bf16_hi(s8.z); sc[6] = bf16_lo(s8.w); sc[7] = bf16_hi(s8.w);
+        mn[0] = bf16_lo(m8.x); mn[1] = bf16_hi(m8.x); mn[2] = bf16_lo(m8.y); mn[3] = bf16_hi(m8.y);
+        mn[4] = bf16_lo(m8.z); mn[5] = bf16_hi(m8.z); mn[6] = bf16_lo(m8.w); mn[7] = bf16_hi(m8.w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sc16[e] = sc[e] * 0.0625f;
+#define SVK_V_MFMA(I_)                                                                                         \
+        {                                                                                                      \
+          uint32_t vf[4];                                                                                      \
+          _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                                   \
+            const float x0 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2], hi[2 * e2]), ((I_) & 1) ? sc16[2 * e2] : sc[2 * e2]), mn[2 * e2]);             \
+            const float x1 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2 + 1], hi[2 * e2 + 1]), ((I_) & 1) ? sc16[2 * e2 + 1] : sc[2 * e2 + 1]), mn[2 * e2 + 1]); \
+            vf[e2] = pack_bf16(x0, x1);                                                                        \
+          }                                                                                                    \
+          acc[I_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag, __builtin_bit_cast(bf16x8_t, make_uint4(vf[0], vf[1], vf[2], vf[3])), acc[I_], 0, 0, 0); \
+        }
+        SVK_V_MFMA(0) SVK_V_MFMA(1) SVK_V_MFMA(2) SVK_V_MFMA(3) SVK_V_MFMA(4) SVK_V_MFMA(5) SVK_V_MFMA(6) SVK_V_MFMA(7)
+#undef SVK_V_MFMA
+      } else {
+        uint4 vr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vr[e] = token_v(t0 + 32 * j + kc * 8 + e);
+        const uint32_t* vv = reinterpret_cast<const uint32_t*>(vr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          uint32_t vf[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const uint32_t w0 = vv[(2 * e2) * 4 + i / 2], w1 = vv[(2 * e2 + 1) * 4 + i / 2];
+            vf[e2] = (i & 1) ? ((w0 >> 16) | (w1 & 0xffff0000u)) : ((w0 & 0xffffu) | (w1 << 16));
+          }
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag, __builtin_bit_cast(bf16x8_t, make_uint4(vf[0], vf[1], vf[2], vf[3])), acc[i], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (fast_next) load_v(T, t1);
+    fast = fast_next;
+  }
+  if (kc < JQ) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = kc * 4 + r;
+      if (h < G) {
+        if (n == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = m[r] + __logf(l[r]);
+        if (n < DW) {
+          float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h + dg * 8;
+          const float inv = 1.0f / l[r];
+          *reinterpret_cast<float4*>(o) = make_float4(acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4][r] * inv, acc[5][r] * inv, acc[6][r] * inv, acc[7][r] * inv);
+        }
+      }
+    }
+  }
+}
+
 template <int D>
 int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
   const int G = a.num_q_heads / a.num_kv_heads;
@@ -674,6 +1080,23 @@ int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
   // (582 vs 353 us at B=4 x 256k: 256 VGPRs + 50 KiB LDS leave 6 waves/CU and the waits did not shrink), opt-in for A/B runs
   static const int variant = getenv("SVK_KIVI_VARIANT") ? atoi(getenv("SVK_KIVI_VARIANT")) : 2;
   if (a.group_size == 32 && variant == 3) return launch_kivi_lds(a, s);
+  if (a.group_size == 32 && variant == 4 && a.num_kv_heads <= 4 && a.block_seq % 128 == 0) {
+    // whole-tile prefetch, one wave per SIMD (see kivi_stage1_tile128_pf_kernel)
+    const size_t shm_pf = (size_t)a.num_kv_heads * (16 * 128 * 2 + 2 * (D / 32) * 128 * 2) + 2 * sizeof(int) * (a.block_seq / 8);
+    switch (G) {
+#define SVK_CASE(G_)                                                                                          \
+  case G_:                                                                                                    \
+    if (a.key_param_dtype == SVK_DTYPE_F32) hipLaunchKernelGGL((kivi_stage1_tile128_pf_kernel<D, G_, true>), grid, block, shm_pf, s, a); \
+    else hipLaunchKernelGGL((kivi_stage1_tile128_pf_kernel<D, G_, false>), grid, block, shm_pf, s, a);         \
+    break;
+      SVK_CASE(1) SVK_CASE(2) SVK_CASE(3) SVK_CASE(4) SVK_CASE(5) SVK_CASE(6) SVK_CASE(7) SVK_CASE(8)
+#undef SVK_CASE
+      default:
+        set_error("svk_kivi_decode_stage1: GQA group size %d unsupported (1..8)", G);
+        return SVK_ERR_LAYOUT;
+    }
+    return check_launch("svk_kivi_decode_stage1");
+  }
   if (a.group_size == 32) {
     // 128-token tiles, both products on the matrix cores
     const size_t shm_t = (size_t)a.num_kv_heads * (16 * 128 * 2 + 2 * (D / 32) * 128 * 2);

@@ -30,6 +30,8 @@ from __future__ import annotations
 
 from collections import deque
 
+import os
+
 import numpy as np
 import torch
 
@@ -314,7 +316,14 @@ class DeltaKVCacheManager(CacheManager):
 
     def get_decode_block_seq(self, layer_idx: int, default: int) -> int:
         if self._full_layer_kivi_enabled() and layer_idx in self.full_layer_to_idx:
-            return int(self.config.full_layer_kivi_decode_block_seq or default)
+            bs = int(self.config.full_layer_kivi_decode_block_seq or default)
+            if os.environ.get("SVK_KIVI_BLOCK_SEQ", "") == "auto":
+                # MI355X launch geometry for the whole-tile-prefetch kernel: one round of <= 256 workgroups
+                # (one per CU), 128-token tiles
+                rows = max(1, int(self.config.max_num_seqs_in_gpu))
+                per_row = max(1, 256 // rows)
+                bs = max(bs, -(-(-(-int(self.max_model_len) // per_row)) // 128) * 128)
+            return bs
         return super().get_decode_block_seq(layer_idx, default)
 
     def free_part_slots(self, layer_idx: int, seq, keep_indices, *, keep_indices_sorted: bool = False):
