@@ -1,0 +1,38 @@
+#!/bin/bash
+# Regenerates the artifacts kept under profiles/rNN (run on the GPU box through gpurun; writes gpurun_out/refresh/).
+#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'
+# Every rocprofv3 call puts the program itself after `--`, keeps counters in their own passes and reads no stdin.
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/refresh
+rm -rf "$O"; mkdir -p "$O/paths"
+cd /tmp && export TMPDIR=/tmp
+stats() {  # stats <name> <cmd...>: kernel-trace stats csv of one command
+  local name=$1; shift
+  local tag=${name//\//_}; tag=${tag%.csv}
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/_prof_$tag" -- "$@" < /dev/null > "$O/_$tag.log" 2>&1
+  local f; f=$(find "$O/_prof_$tag" -type f -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" "$O/$name" || echo "no stats for $name" >&2
+}
+# headline bench: plain run (the judged line) and the same command under the profiler
+timeout 600 python3 "$R/bench.py" < /dev/null > "$O/bench_stdout.log" 2> "$O/bench_stderr.log"; tail -1 "$O/bench_stdout.log" > "$O/bench_line.json"
+stats bench_kernel_stats.csv python3 "$R/bench.py" --steps 128 --warmup 8 --no-cpu-baseline
+grep '^{' "$O/_bench_kernel_stats.log" | tail -1 > "$O/bench_line_profiled.json"
+for b in 1 8 32; do timeout 300 python3 "$R/bench.py" --batch $b --no-cpu-baseline --no-kernel-events < /dev/null 2>/dev/null | tail -1 >> "$O/bench_small_batches.jsonl"; done
+# other configurations
+timeout 600 python3 "$R/tools/pathbench.py" --graph < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_graph.jsonl"
+timeout 600 python3 "$R/tools/pathbench.py" < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_eager.jsonl"
+for c in streamingllm quest deltakv_raw deltakv vanilla; do
+  stats paths/${c}_kernel_stats.csv python3 "$R/tools/pathbench.py" --graph --configs $c --steps 20
+done
+timeout 300 python3 "$R/tools/kbench_kivi.py" < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi.txt"
+timeout 300 python3 "$R/tools/kbench_prefill.py" < /dev/null 2>/dev/null | grep prefill > "$O/paths/kbench_prefill.txt"
+timeout 300 python3 "$R/tools/kbench.py" --batches 64 --block-seqs 1056 --modes 2 --layers 6 < /dev/null 2>/dev/null | tail -3 > "$O/kbench_stage1.txt"
+# HBM traffic of stage 1: separate counter passes, nothing else traced
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --pmc $ctr --output-format csv -d "$O/_pmc_$ctr" -- python3 "$R/tools/kbench.py" --batches 64 --block-seqs 1056 --modes 2 --iters 3 < /dev/null > "$O/_pmc_$ctr.log" 2>&1
+  f=$(find "$O/_pmc_$ctr" -type f -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && cp "$f" "$O/kbench_pmc_$ctr.csv"
+done
+rm -rf "$O"/_prof_* "$O"/_pmc_*/
+ls -la "$O" "$O/paths"
