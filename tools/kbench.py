@@ -84,7 +84,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         print(f"   score_update B={B}: {e0.elapsed_time(e1) * 1e3 / args.iters:8.2f} us", flush=True)
-        del kc, vc
+        del kcs, vcs
 
 
 if __name__ == "__main__":
