@@ -178,6 +178,55 @@ class CacheManager(ABC):
         k_cache, v_cache = self.get_layer_store_view(layer_idx)
         store_kvcache(k, v, k_cache, v_cache, self.get_layer_batch_states(layer_idx).slot_mapping)
 
+    # ------------------------------------------------------------------ scheduler capacity hooks
+    # base.py:1290-1393 of the reference: what the scheduler asks a cache manager before it admits a prompt or schedules a
+    # prefill chunk / decode token.  Defaults: one persistent slot per token, one shared slot budget.
+    def reserved_prefill_slots(self, waiting_seqs, chunk_prefill_size: int) -> int:
+        """Slots still owed to prompts that are part-way through their prefill."""
+        total = 0
+        for seq in waiting_seqs:
+            done, prompt = int(seq.num_prefilled_tokens), int(seq.num_prompt_tokens)
+            if 0 < done < prompt:
+                total += prompt - done
+        return total
+
+    def prefill_step_free_slots(self) -> int:
+        return int(self.num_free_slots)
+
+    def prefill_step_free_slots_for(self, seq) -> int:
+        return int(self.prefill_step_free_slots())
+
+    def prefill_step_reservation_cost(self, seq, scheduled_tokens: int) -> int:
+        return int(scheduled_tokens)
+
+    def decode_step_free_slots(self) -> int:
+        return int(self.num_free_slots)
+
+    def decode_step_free_slots_for(self, seq) -> int:
+        return int(self.decode_step_free_slots())
+
+    def decode_step_reservation_cost(self, seq) -> int:
+        return 1
+
+    def prompt_admission_free_slots(self) -> int:
+        return int(self.num_free_slots)
+
+    def prompt_admission_cost(self, seq) -> int:
+        return int(seq.num_prompt_tokens) - int(getattr(seq, "prefix_cache_hit_len", 0) or 0)
+
+    def prompt_logical_reservation_cost(self, seq) -> int:
+        return int(self.prompt_admission_cost(seq))
+
+    def prompt_admission_failure_action(self) -> str:
+        return "defer"
+
+    def prompt_admission_budgets(self, waiting_seqs, chunk_prefill_size: int) -> dict:
+        headroom = int(self.prompt_admission_free_slots()) - int(self.reserved_prefill_slots(waiting_seqs, chunk_prefill_size))
+        return {"slots": max(0, headroom)}
+
+    def prompt_admission_costs(self, seq) -> dict:
+        return {"slots": int(self.prompt_admission_cost(seq))}
+
     def fused_decode_store_slots(self, layer_idx: int):
         """MI355X: slot_mapping of this decode step when the layer's K/V store may ride in the attention launch
         (plain slot-table managers whose store has no side effects), else None -> `save_rope_kv_if_needed`."""

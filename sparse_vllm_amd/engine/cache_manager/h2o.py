@@ -68,6 +68,96 @@ class H2OCacheManager(SnapKVCacheManager):
         return max(1, capacity), False
 
     # ---- selection (device, bit-exact with h2o.py:478-563)
+    # ------------------------------------------------------------------ scheduler capacity hooks (h2o.py:73-230)
+    # An H2O row never holds more than max(resident, prefill budget) + one chunk during prefill (append, then evict), and
+    # budget + interval during decode; the scheduler reserves those physical peaks, not the logical prompt length.
+    def _prefill_append_peak(self, resident_len: int, remaining_tokens: int, chunk_prefill_size: int) -> int:
+        resident, remaining = int(resident_len), max(0, int(remaining_tokens))
+        chunk = max(1, int(chunk_prefill_size))
+        return min(resident + remaining, max(resident, self.h2o_prefill_budget) + chunk)
+
+    def _prompt_prefill_peak(self, seq, chunk_prefill_size: int) -> int:
+        return self._prefill_append_peak(0, int(seq.num_prompt_tokens), chunk_prefill_size)
+
+    def prompt_admission_cost(self, seq) -> int:
+        return self._prompt_prefill_peak(seq, int(self.config.chunk_prefill_size))
+
+    def prompt_admission_free_slots(self) -> int:
+        return int(self.num_free_slots)
+
+    def prompt_admission_budgets(self, waiting_seqs, chunk_prefill_size: int) -> dict:
+        return {"slots": max(0, int(self.num_free_slots) - int(self.reserved_prefill_slots(waiting_seqs, chunk_prefill_size)))}
+
+    def prompt_admission_costs(self, seq) -> dict:
+        return {"slots": self.prompt_admission_cost(seq)}
+
+    def prompt_logical_reservation_cost(self, seq) -> int:
+        return self.prompt_admission_cost(seq)
+
+    def reserved_prefill_slots(self, waiting_seqs, chunk_prefill_size: int) -> int:
+        """Growth still needed by the prompts that are part-way through prefill, measured on their physical rows."""
+        first_layer = int(self.kv_transformer_layer_indices()[0])
+        total = 0
+        for seq in waiting_seqs:
+            done, prompt = int(seq.num_prefilled_tokens), int(seq.num_prompt_tokens)
+            if not 0 < done < prompt:
+                continue
+            have = self._physical_row_len(first_layer, seq)
+            total += max(0, self._prefill_append_peak(have, prompt - done, chunk_prefill_size) - have)
+        return int(total)
+
+    def prefill_step_free_slots(self) -> int:
+        return int(self.num_free_slots)
+
+    def prefill_step_free_slots_for(self, seq) -> int:
+        return int(self.num_free_slots)
+
+    def prefill_step_reservation_cost(self, seq, scheduled_tokens: int) -> int:
+        return int(scheduled_tokens)
+
+    def decode_step_free_slots(self) -> int:
+        return int(self.num_free_slots)
+
+    def decode_step_free_slots_for(self, seq) -> int:
+        return int(self.num_free_slots)
+
+    def decode_step_reservation_cost(self, seq) -> int:
+        return 1
+
+    def chain_capacity_deficits(self, *, suffix_tokens: int, generation_tokens: int = 0, existing_slots_by_layer=(),
+                                outstanding_reserved_slots_by_layer=(), outstanding_reserved_rows: int = 0,
+                                needs_resident_row: bool):
+        """(required slots per layer, required rows, slot deficits per layer, row deficit) of one chain turn: `suffix_tokens`
+        of prefill on top of the existing rows, then `generation_tokens` of decode (the first token is produced by the
+        prefill itself)."""
+        suffix = max(0, int(suffix_tokens))
+        new_kv = max(0, int(generation_tokens) - 1)
+        chunk = max(1, int(self.config.chunk_prefill_size))
+        trigger = self.h2o_decode_budget + self.h2o_decode_eviction_interval
+        layers = self.kv_transformer_layer_indices()
+
+        def at(seq_, i):
+            return int(seq_[i]) if i < len(seq_) else 0
+
+        required = []
+        for i in range(len(layers)):
+            have = at(existing_slots_by_layer, i)
+            prefill_peak = self._prefill_append_peak(have, suffix, chunk)
+            resident = min(have + suffix, self.h2o_decode_budget) if suffix > 0 else have   # final-prefill compaction
+            if new_kv <= 0:
+                decode_peak = resident
+            elif resident >= trigger:
+                decode_peak = resident + 1
+            else:
+                decode_peak = resident + min(new_kv, trigger - resident)
+            required.append(max(0, max(prefill_peak, decode_peak) - have))
+        slot_deficits = tuple(
+            max(0, need - max(0, int(self._num_free_slots[layer]) - at(outstanding_reserved_slots_by_layer, i)))
+            for i, (layer, need) in enumerate(zip(layers, required)))
+        rows_needed = 1 if needs_resident_row else 0
+        rows_free = max(0, min((len(self.free_rows[layer]) for layer in layers), default=0) - max(0, int(outstanding_reserved_rows)))
+        return tuple(required), rows_needed, slot_deficits, max(0, rows_needed - rows_free)
+
     @staticmethod
     def select_h2o_indices_batch(scores: torch.Tensor, *, budget: int, recent_ratio: float) -> torch.Tensor:
         return h2o_ops.select_h2o_indices_batch(scores, budget=budget, recent_ratio=recent_ratio)

@@ -802,12 +802,75 @@ def gen_prefill_attention():
          seq_len=seq_len.numpy(), pcl=pcl.numpy(), o=o.numpy())
 
 
+def gen_h2o_capacity():
+    """Scheduler capacity hooks of H2OCacheManager (h2o.py:73-230) on hand-built managers: one case per row of `cases`,
+    every hook's answer stored as int64 arrays."""
+    from collections import deque
+    cases = []
+    rng = np.random.default_rng(11)
+    for case in range(12):
+        L = int(rng.integers(1, 4))
+        B = int(rng.integers(2, 5))
+        budget = int(rng.choice([8, 16, 32]))
+        interval = int(rng.choice([4, 8]))
+        prefill_budget = int(rng.choice([16, 24, 48]))
+        chunk = int(rng.choice([4, 8, 16]))
+        lens = [[int(x) for x in rng.integers(0, budget + interval, B)] for _ in range(L)]
+        for li in range(1, L):
+            lens[li] = list(lens[0])                       # uniform rows across layers like the real manager
+        free_ptr = int(rng.integers(0, 60))
+        m = _make_manager(lens, cap=128, nslots=512, budget=budget, interval=interval, prefill_budget=prefill_budget,
+                          free_ptr=free_ptr)
+        m.config.chunk_prefill_size = chunk
+        m.free_rows = [deque(range(int(rng.integers(0, 3)))) for _ in range(L)]
+        seqs = []
+        for r in range(B):
+            prompt = int(rng.integers(1, 200))
+            done = int(rng.integers(0, prompt + 1))
+            seqs.append(SimpleNamespace(seq_id=r, num_prompt_tokens=prompt, num_prefilled_tokens=done, prefix_cache_hit_len=0))
+        waiting = deque(seqs)
+        out = dict(L=L, B=B, budget=budget, interval=interval, prefill_budget=prefill_budget, chunk=chunk,
+                   lens=np.asarray(lens, np.int64), free=np.asarray(m._num_free_slots, np.int64),
+                   free_rows=np.asarray([len(x) for x in m.free_rows], np.int64),
+                   prompt=np.asarray([s_.num_prompt_tokens for s_ in seqs], np.int64),
+                   done=np.asarray([s_.num_prefilled_tokens for s_ in seqs], np.int64))
+        out["admission_cost"] = np.asarray([m.prompt_admission_cost(s_) for s_ in seqs], np.int64)
+        out["logical_cost"] = np.asarray([m.prompt_logical_reservation_cost(s_) for s_ in seqs], np.int64)
+        out["admission_free"] = np.int64(m.prompt_admission_free_slots())
+        out["reserved"] = np.int64(m.reserved_prefill_slots(waiting, chunk))
+        out["budget_slots"] = np.int64(m.prompt_admission_budgets(waiting, chunk)["slots"])
+        out["costs_slots"] = np.asarray([m.prompt_admission_costs(s_)["slots"] for s_ in seqs], np.int64)
+        out["prefill_free"] = np.int64(m.prefill_step_free_slots())
+        out["prefill_free_for"] = np.asarray([m.prefill_step_free_slots_for(s_) for s_ in seqs], np.int64)
+        out["prefill_cost"] = np.asarray([m.prefill_step_reservation_cost(s_, 7 + i) for i, s_ in enumerate(seqs)], np.int64)
+        out["decode_free"] = np.int64(m.decode_step_free_slots())
+        out["decode_cost"] = np.asarray([m.decode_step_reservation_cost(s_) for s_ in seqs], np.int64)
+        chain = []
+        for suffix, gen_t, need_row in ((0, 0, False), (5, 1, True), (40, 30, True), (0, 25, False), (300, 2, True)):
+            existing = tuple(int(x) for x in rng.integers(0, budget + interval, L))
+            reserved = tuple(int(x) for x in rng.integers(0, 20, L))
+            req, rows_req, deficits, row_def = m.chain_capacity_deficits(
+                suffix_tokens=suffix, generation_tokens=gen_t, existing_slots_by_layer=existing,
+                outstanding_reserved_slots_by_layer=reserved, outstanding_reserved_rows=int(rng.integers(0, 2)),
+                needs_resident_row=need_row)
+            chain.append(np.concatenate([[suffix, gen_t, int(need_row)], existing, reserved, req, [rows_req], deficits, [row_def]]))
+        out["chain"] = np.asarray(chain, np.int64)
+        cases.append(out)
+    flat = {}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            flat[f"c{i}_{k}"] = np.asarray(v)
+    flat["n_cases"] = np.int64(len(cases))
+    save("h2o_capacity", **flat)
+
+
 GROUPS = {
     "decode": gen_decode,
     "h2o_select": gen_h2o_select,
     "h2o_scores": gen_h2o_scores,
     "compaction": gen_compaction,
     "h2o_burst": gen_h2o_burst,
+    "h2o_capacity": gen_h2o_capacity,
     "quest": gen_quest,
     "prefill_score": gen_prefill_score,
     "deltakv": gen_deltakv,

@@ -1,0 +1,79 @@
+"""Scheduler capacity hooks of the H2O cache manager (reference h2o.py:73-230, base.py:1290-1393)
+against answers recorded from the reference itself on hand-built managers (tests/golden/gen_fixtures.py h2o_capacity).
+Host logic only: no GPU, no kernels."""
+
+from collections import deque
+from types import SimpleNamespace
+
+import numpy as np
+
+
+def _manager(g, i):
+    from sparse_vllm_amd.engine.cache_manager.h2o import H2OCacheManager
+    L, B = int(g[f"c{i}_L"]), int(g[f"c{i}_B"])
+    m = object.__new__(H2OCacheManager)
+    m.num_layers = L
+    m.config = SimpleNamespace(h2o_decode_budget=int(g[f"c{i}_budget"]), h2o_decode_eviction_interval=int(g[f"c{i}_interval"]),
+                               h2o_prefill_budget=int(g[f"c{i}_prefill_budget"]), h2o_recent_ratio=0.5,
+                               chunk_prefill_size=int(g[f"c{i}_chunk"]))
+    m._num_free_slots = [int(x) for x in g[f"c{i}_free"]]
+    m.row_seq_lens = [np.asarray(x, dtype=np.int32) for x in g[f"c{i}_lens"]]
+    m.seq_id_to_row = [{r: r for r in range(B)} for _ in range(L)]
+    m.free_rows = [deque(range(int(n))) for n in g[f"c{i}_free_rows"]]
+    return m, L, B
+
+
+def test_h2o_capacity_hooks_match_reference(golden):
+    g = golden("h2o_capacity")
+    for i in range(int(g["n_cases"])):
+        m, L, B = _manager(g, i)
+        chunk = int(g[f"c{i}_chunk"])
+        seqs = [SimpleNamespace(seq_id=r, num_prompt_tokens=int(g[f"c{i}_prompt"][r]), num_prefilled_tokens=int(g[f"c{i}_done"][r]),
+                                prefix_cache_hit_len=0) for r in range(B)]
+        waiting = deque(seqs)
+        assert [m.prompt_admission_cost(s) for s in seqs] == list(g[f"c{i}_admission_cost"])
+        assert [m.prompt_logical_reservation_cost(s) for s in seqs] == list(g[f"c{i}_logical_cost"])
+        assert m.prompt_admission_free_slots() == int(g[f"c{i}_admission_free"])
+        assert m.reserved_prefill_slots(waiting, chunk) == int(g[f"c{i}_reserved"])
+        assert m.prompt_admission_budgets(waiting, chunk) == {"slots": int(g[f"c{i}_budget_slots"])}
+        assert [m.prompt_admission_costs(s)["slots"] for s in seqs] == list(g[f"c{i}_costs_slots"])
+        assert m.prefill_step_free_slots() == int(g[f"c{i}_prefill_free"])
+        assert [m.prefill_step_free_slots_for(s) for s in seqs] == list(g[f"c{i}_prefill_free_for"])
+        assert [m.prefill_step_reservation_cost(s, 7 + j) for j, s in enumerate(seqs)] == list(g[f"c{i}_prefill_cost"])
+        assert m.decode_step_free_slots() == int(g[f"c{i}_decode_free"])
+        assert [m.decode_step_reservation_cost(s) for s in seqs] == list(g[f"c{i}_decode_cost"])
+        assert m.prompt_admission_failure_action() == "defer"
+        # chain turns: row = [suffix, gen, needs_row, existing[L], reserved[L]] -> [required[L], rows, deficits[L], row deficit]
+        rng = np.random.default_rng(0)
+        for row in g[f"c{i}_chain"]:
+            row = [int(x) for x in row]
+            suffix, gen_t, need_row = row[0], row[1], bool(row[2])
+            existing, reserved = tuple(row[3:3 + L]), tuple(row[3 + L:3 + 2 * L])
+            want_req, want_rows = tuple(row[3 + 2 * L:3 + 3 * L]), row[3 + 3 * L]
+            want_def, want_row_def = tuple(row[4 + 3 * L:4 + 4 * L]), row[4 + 4 * L]
+            # outstanding_reserved_rows was drawn in {0, 1} by the generator and is not stored: the recorded row deficit
+            # must be reproduced by one of the two
+            got = [m.chain_capacity_deficits(suffix_tokens=suffix, generation_tokens=gen_t, existing_slots_by_layer=existing,
+                                             outstanding_reserved_slots_by_layer=reserved, outstanding_reserved_rows=k,
+                                             needs_resident_row=need_row) for k in (0, 1)]
+            assert all(x[0] == want_req and x[1] == want_rows and x[2] == want_def for x in got)
+            assert want_row_def in (got[0][3], got[1][3])
+        del rng
+
+
+def test_base_capacity_hooks_defaults():
+    """base.py:1290-1393 defaults: one persistent slot per token, one shared slot budget."""
+    from sparse_vllm_amd.engine.cache_manager.base import CacheManager
+
+    class _Plain(CacheManager):
+        num_free_slots = property(lambda self: 37)
+
+    m = object.__new__(_Plain)
+    seqs = deque([SimpleNamespace(seq_id=0, num_prompt_tokens=30, num_prefilled_tokens=10, prefix_cache_hit_len=4),
+                  SimpleNamespace(seq_id=1, num_prompt_tokens=9, num_prefilled_tokens=0, prefix_cache_hit_len=0),
+                  SimpleNamespace(seq_id=2, num_prompt_tokens=9, num_prefilled_tokens=9, prefix_cache_hit_len=0)])
+    assert m.reserved_prefill_slots(seqs, 8) == 20
+    assert m.prompt_admission_budgets(seqs, 8) == {"slots": 17}
+    assert m.prompt_admission_cost(seqs[0]) == 26 and m.prompt_admission_costs(seqs[1]) == {"slots": 9}
+    assert m.prefill_step_free_slots() == 37 == m.decode_step_free_slots_for(seqs[0])
+    assert m.prefill_step_reservation_cost(seqs[0], 5) == 5 and m.decode_step_reservation_cost(seqs[0]) == 1
