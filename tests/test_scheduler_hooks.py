@@ -65,10 +65,13 @@ def test_base_capacity_hooks_defaults():
     """base.py:1290-1393 defaults: one persistent slot per token, one shared slot budget."""
     from sparse_vllm_amd.engine.cache_manager.base import CacheManager
 
-    class _Plain(CacheManager):
-        num_free_slots = property(lambda self: 37)
-
-    m = object.__new__(_Plain)
+    class _Plain:                                       # the hooks only need `num_free_slots`
+        num_free_slots = 37
+    for name in ("reserved_prefill_slots", "prefill_step_free_slots", "prefill_step_free_slots_for", "prefill_step_reservation_cost",
+                 "decode_step_free_slots", "decode_step_free_slots_for", "decode_step_reservation_cost", "prompt_admission_free_slots",
+                 "prompt_admission_cost", "prompt_logical_reservation_cost", "prompt_admission_budgets", "prompt_admission_costs"):
+        setattr(_Plain, name, getattr(CacheManager, name))
+    m = _Plain()
     seqs = deque([SimpleNamespace(seq_id=0, num_prompt_tokens=30, num_prefilled_tokens=10, prefix_cache_hit_len=4),
                   SimpleNamespace(seq_id=1, num_prompt_tokens=9, num_prefilled_tokens=0, prefix_cache_hit_len=0),
                   SimpleNamespace(seq_id=2, num_prompt_tokens=9, num_prefilled_tokens=9, prefix_cache_hit_len=0)])
