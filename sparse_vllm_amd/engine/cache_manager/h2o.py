@@ -238,9 +238,15 @@ class H2OCacheManager(SnapKVCacheManager):
         if not ranges:
             return None
         d = q.device
-        cache_lens = torch.tensor([r[2] for r in ranges], dtype=torch.int32, device=d)
-        starts = torch.tensor([r[3] for r in ranges], dtype=torch.int32, device=d)
-        ends = torch.tensor([r[4] for r in ranges], dtype=torch.int32, device=d)
+        # rows are uniform across layers: one upload per chunk, not per layer (the reference caches the same tensors,
+        # snapkv.py:1155-1214 `_cached_prefill_score_metadata_tensors`)
+        key = tuple((r[2], r[3], r[4]) for r in ranges)
+        cached = getattr(self, "_prefill_score_meta", None)
+        if cached is None or cached[0] != key or cached[1].device != d:
+            meta = torch.tensor([[r[2] for r in ranges], [r[3] for r in ranges], [r[4] for r in ranges]], dtype=torch.int32, device=d)
+            cached = (key, meta)
+            self._prefill_score_meta = cached
+        cache_lens, starts, ends = cached[1][0], cached[1][1], cached[1][2]
         max_ctx = max(r[4] for r in ranges)
         step = torch.empty((len(seqs), max_ctx), dtype=torch.float32, device=d)
         k_cache, _ = self.get_layer_kv_cache(layer_idx)
