@@ -16,11 +16,12 @@ __device__ __forceinline__ float load_scalar(const void* p, int64_t i, int dtype
 }
 
 // ------------------------------------------------------------------------------------
-// static decode plan (one workgroup per batch lane)
+// static decode plan: grid (ceil(S / 256), batch) - every output column is independent and costs two dependent gathers
+// into the 262 k-entry slot maps, so a row is spread over workgroups instead of looped by one (19 -> 6 us)
 // ------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256) deltakv_plan_kernel(const SvkDeltakvPlanArgs a) {
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
   const int K = a.k_max, SINK = a.sink;
   const int S = SINK + K + a.max_buffer;
   const int max_pos = a.max_positions - 1;
@@ -34,7 +35,7 @@ __global__ void __launch_bounds__(256) deltakv_plan_kernel(const SvkDeltakvPlanA
   const int buf_start = SINK + clen;
   const int buf_len = min(max(ctx - buf_start, 0), a.max_buffer);
   const int start_out = SINK + top_len;
-  for (int c = threadIdx.x; c < S; c += blockDim.x) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < S; c += gridDim.x * blockDim.x) {
     int o_slot = safe, o_pos = 0;
     if (c < SINK) {
       const int sp = min(c, max_pos);
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(256) deltakv_plan_kernel(const SvkDeltakvPlanA
     a.active_slots_out[(int64_t)b * a.out_stride + c] = o_slot;
     a.active_pos_out[(int64_t)b * a.pos_stride + c] = o_pos;
   }
-  if (threadIdx.x == 0) a.new_context_lens_out[b] = SINK + top_len + buf_len;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.new_context_lens_out[b] = SINK + top_len + buf_len;
 }
 
 // ------------------------------------------------------------------------------------
@@ -502,7 +503,8 @@ extern "C" int svk_deltakv_static_decode_plan(const SvkDeltakvPlanArgs* a, svk_s
   SVK_REQUIRE(a->k_max >= 0 && a->sink >= 0 && a->max_buffer >= 0 && a->max_positions > 0, SVK_ERR_VALUE,
               "svk_deltakv_static_decode_plan: bad shape parameters");
   if (a->batch <= 0) return SVK_OK;
-  hipLaunchKernelGGL(deltakv_plan_kernel, dim3(a->batch), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  const int plan_cols = a->sink + a->k_max + a->max_buffer;
+  hipLaunchKernelGGL(deltakv_plan_kernel, dim3((plan_cols + 255) / 256, a->batch), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   return check_launch("svk_deltakv_static_decode_plan");
 }
 
