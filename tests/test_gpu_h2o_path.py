@@ -501,3 +501,36 @@ def test_decode_with_fused_store_equals_store_then_decode(shape, mode):
     # the padded lane reads a row another lane may be writing: compare the real lanes only
     for x, y in zip(ref[2:], got[2:]):
         np.testing.assert_array_equal(x[:B - 1], y[:B - 1])
+
+
+@pytest.mark.parametrize("case", [dict(B=1, Hq=28, D=128, nblk=64, block_seq=66), dict(B=3, Hq=28, D=128, nblk=700, block_seq=256),
+                                  dict(B=2, Hq=14, D=64, nblk=33, block_seq=128), dict(B=4, Hq=8, D=128, nblk=3, block_seq=2048, cap=1025)])
+def test_split_kv_merge_many_partials_vs_float64(case):
+    """Stage-2 merge (max-first form; 256- or 1024-thread workgroups by workspace capacity) and the merge inside
+    svk_h2o_decode_finish (1 / 4 / 16 waves per (lane, head)) against a float64 log-sum-exp merge: bf16 outputs within
+    one bf16 ulp of the exact result, ragged partial counts per lane."""
+    from sparse_vllm_amd.kernels import flash_decode_stage2
+    from sparse_vllm_amd.kernels.h2o_ops import h2o_decode_finish
+    B, Hq, D, nblk, block_seq = (case[k] for k in ("B", "Hq", "D", "nblk", "block_seq"))
+    cap = case.get("cap", nblk)
+    d = dev()
+    g = torch.Generator(device="cpu").manual_seed(nblk)
+    lens = torch.randint(1, nblk * block_seq + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = nblk * block_seq
+    mid = torch.randn(B, Hq, cap, D, generator=g)
+    lse = torch.randn(B, Hq, cap, generator=g) * 4
+    ref = np.zeros((B, Hq, D))
+    for b in range(B):
+        n = (int(lens[b]) + block_seq - 1) // block_seq
+        w = np.exp(lse[b, :, :n].double().numpy() - lse[b, :, :n].double().numpy().max(axis=1, keepdims=True))
+        ref[b] = (w[:, :, None] * mid[b, :, :n].double().numpy()).sum(axis=1) / w.sum(axis=1, keepdims=True)
+    o1 = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=d)
+    flash_decode_stage2(mid.to(d), lse.to(d), lens.to(d), o1, block_seq)
+    W = nblk * block_seq
+    raw = torch.zeros((B, min(W, 8192)), device=d)
+    o2 = torch.empty_like(o1)
+    h2o_decode_finish(mid.to(d), lse.to(d), lens.to(d), o2, block_seq, raw, D ** -0.5)
+    torch.cuda.synchronize()
+    for o in (o1, o2):
+        got = o.float().cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=1e-3)
