@@ -130,6 +130,9 @@ def test_decode_split_invariance_and_fused_store_full_size():
     np.testing.assert_allclose(o1, o3, rtol=2e-2, atol=2e-2)
     valid = np.arange(L)[None, :] < lens.cpu().numpy()[:, None]
     assert (s1[~valid] == np.float32(-1e20)).all() and np.isfinite(s1[valid]).all()
+    import os
+    if os.environ.get("SVK_STAGE1_VARIANT", "3") != "3":
+        return
     # fused store at full size == store then launch (bit-exact cache, scores and outputs)
     nk = (torch.randn((B, Hkv, D), device=d, generator=g) * 0.3).to(torch.bfloat16)
     nv = (torch.randn((B, Hkv, D), device=d, generator=g) * 0.3).to(torch.bfloat16)
