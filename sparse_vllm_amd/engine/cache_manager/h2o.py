@@ -331,33 +331,44 @@ class H2OCacheManager(SnapKVCacheManager):
     def _evict_prefill(self, seqs):
         """h2o.py:1351-1480.  Per layer, sequences are visited in batch order (that order fixes the
         free-stack contents); maximal runs of consecutive sequences with the same finality and the
-        same physical length are selected/compacted in one launch."""
+        same physical length are selected/compacted in one launch.  Rows are uniform across layers, so an
+        intermediate-chunk run is selected and compacted for ALL layers in one launch each (every layer's free stack
+        still sees its own operations in the same order); the final chunk's dense compaction stays per layer."""
         ratio = float(self.config.h2o_recent_ratio)
-        for layer_idx in self.kv_transformer_layer_indices():
+        layers = [int(l) for l in self.kv_transformer_layer_indices()]
+        lens0 = [self._physical_row_len(layers[0], s) for s in seqs]
+        uniform = all([self._physical_row_len(l, s) for s in seqs] == lens0 for l in layers[1:])
+        layer_sets = [layers] if uniform else [[l] for l in layers]
+        for lset in layer_sets:
+            first = lset[0]
             i = 0
             while i < len(seqs):
                 final = bool(seqs[i].is_last_chunk_prefill)
-                kv_len = self._physical_row_len(layer_idx, seqs[i])
+                kv_len = self._physical_row_len(first, seqs[i])
                 j = i + 1
                 while (j < len(seqs) and bool(seqs[j].is_last_chunk_prefill) == final
-                       and self._physical_row_len(layer_idx, seqs[j]) == kv_len):
+                       and self._physical_row_len(first, seqs[j]) == kv_len):
                     j += 1
                 group = seqs[i:j]
                 i = j
                 budget = self.h2o_decode_budget if final else self.h2o_prefill_budget
                 if kv_len <= budget:
                     continue
-                rows = np.array([[self.seq_id_to_row[layer_idx][int(s.seq_id)] for s in group]])
-                rows_gpu = torch.from_numpy(rows[0]).to(self.device)
-                scores = self.h2o_score_tensor[self.kv_layer_index(layer_idx), rows_gpu, :kv_len]
-                keep = self.select_h2o_indices_batch(scores, budget=budget, recent_ratio=ratio)
+                rows = np.array([[self.seq_id_to_row[l][int(s.seq_id)] for s in group] for l in lset])     # [L', n]
+                rows_gpu = torch.from_numpy(rows).to(self.device)
                 if final:
-                    self._compact_final_prefill_dense_batch(layer_idx, group, keep)
+                    for li, l in enumerate(lset):
+                        scores = self.h2o_score_tensor[self.kv_layer_index(l), rows_gpu[li], :kv_len]
+                        keep = self.select_h2o_indices_batch(scores, budget=budget, recent_ratio=ratio)
+                        self._compact_final_prefill_dense_batch(l, group, keep)
                 else:
-                    self._compact([layer_idx], rows, keep.unsqueeze(0), kv_len)
+                    kv_idx = torch.tensor([self.kv_layer_index(l) for l in lset], device=self.device)
+                    scores = self.h2o_score_tensor[kv_idx[:, None], rows_gpu, :kv_len]                   # [L', n, kv_len]
+                    keep = self.select_h2o_indices_batch(scores.reshape(-1, kv_len), budget=budget, recent_ratio=ratio)
+                    self._compact(lset, rows, keep.view(len(lset), len(group), -1), kv_len)
                 key = "final_prefill_evictions" if final else "intermediate_prefill_evictions"
-                self._h2o_counters[key] += len(group)
-                self._h2o_counters["dropped_tokens"] += (kv_len - budget) * len(group)
+                self._h2o_counters[key] += len(group) * len(lset)
+                self._h2o_counters["dropped_tokens"] += (kv_len - budget) * len(group) * len(lset)
 
     def evict_after_prefill(self, seqs):
         self._evict_prefill(seqs)
