@@ -335,3 +335,20 @@ def test_dequant_linear_act_matches_separate_ops(shape, act):
     xd2 = dequantize_grouped(t(code), to_bf16(scale), to_bf16(mn), 32, K, 4).float().cpu().numpy()
     np.testing.assert_allclose(out2.float().cpu().numpy(), bf16_round((xd2.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32)),
                                rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("n,k", [(262144, 2048), (5000, 2048), (3000, 1000), (70000, 4096), (300, 7), (24576, 64)])
+@pytest.mark.parametrize("kind", ["f32", "bf16", "ties"])
+def test_topk_sorted_desc_equals_stable_argsort(n, k, kind):
+    """(score descending, index ascending) = the first k of a stable descending argsort, for row lengths on both sides
+    of the single-workgroup / chunked boundary, bf16-valued scores (two radix passes) and heavy ties."""
+    from sparse_vllm_amd.kernels.deltakv_kernels import topk_sorted_desc
+    rng = np.random.default_rng(n + k)
+    x = rng.random((2, n)).astype(np.float32)
+    if kind == "bf16":
+        x = bf16_round(x)
+    elif kind == "ties":
+        x = np.floor(x * 8) / 8
+    idx = topk_sorted_desc(t(x), k).cpu().numpy()
+    ref = np.argsort(-x, axis=1, kind="stable")[:, :k]
+    np.testing.assert_array_equal(idx, ref)
