@@ -212,6 +212,16 @@ class QuestCacheManager(CacheManager):
         super().save_rope_kv_if_needed(layer_idx, k, v)
         self.on_kv_stored(layer_idx, k, self.layer_batch_state.slot_mapping)
 
+    def fused_decode_store_slots(self, layer_idx: int):
+        """Decode stores have no side effect here (page min/max is refreshed after the step, `on_forward_end`), and the
+        newest token is always the last entry of the attention view (the last page is always attended), so the store can
+        ride in the stage-1 launch like for the plain slot-table managers."""
+        import os
+        if (get_context().is_prefill or os.environ.get("SVK_FUSE_DECODE_STORE", "1") != "1"
+                or os.environ.get("SVK_STAGE1_VARIANT", "3") != "3"):
+            return None
+        return self.layer_batch_state.slot_mapping
+
     @torch.no_grad()
     def on_kv_stored(self, layer_idx: int, k: torch.Tensor, slot_mapping: torch.Tensor):
         """quest.py:1607-1685: prefill refreshes the pages completed by this chunk (after the
