@@ -161,19 +161,50 @@ __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBu
   const float* sc = a.page_scores + (int64_t)b * a.score_stride;
   if (lds_keys) {
     uint32_t* keys = reinterpret_cast<uint32_t*>(sel_pages + a.prev_budget);
-    for (int i = tid; i < a.n_prev; i += nt) keys[i] = desc_key(sc[i]);
+    // staging: 8 scores per thread and trip with the loads first (one round trip instead of one per element), the
+    // select's OR / AND sweep folded in
+    select_bits_begin(scratch);
+    uint32_t o_bits = 0u, a_bits = 0xffffffffu;
+    for (int i0 = 0; i0 < a.n_prev; i0 += 8 * nt) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * nt + tid;
+        v[j] = i < a.n_prev ? sc[i] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * nt + tid;
+        if (i < a.n_prev) {
+          const uint32_t key = desc_key(v[j]);
+          keys[i] = key;
+          o_bits |= key;
+          a_bits &= key;
+        }
+      }
+    }
+    select_bits_add(scratch, o_bits, a_bits);
     __syncthreads();
     block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, a.n_prev, a.prev_budget, scratch,
-                                   [&](int pos, int idx) { sel_pages[pos] = idx; });
+                                   [&](int pos, int idx) { sel_pages[pos] = idx; }, true);
   } else {
     block_select_topk_ordered(sc, a.n_prev, a.prev_budget, scratch, [&](int pos, int idx) { sel_pages[pos] = idx; });
   }
   __syncthreads();
   const int sparse_keep = (a.prev_budget + 1) * ps;
-  for (int i = tid; i < sparse_keep; i += nt) {
-    const int j = i / ps, o = i - j * ps;
-    const int page = j < a.prev_budget ? sel_pages[j] : num_pages - 1;
-    packed[i] = max(ptab[page], 0) * ps + o;
+  for (int i0 = 0; i0 < sparse_keep; i0 += 8 * nt) {          // page-table gathers of 8 entries per thread in flight together
+    int slot[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nt + tid;
+      const int j = i / ps;
+      slot[u] = i < sparse_keep ? ptab[j < a.prev_budget ? sel_pages[j] : num_pages - 1] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nt + tid;
+      if (i < sparse_keep) packed[i] = max(slot[u], 0) * ps + (i - (i / ps) * ps);
+    }
   }
   if (!a.is_long_text)
     for (int i = sparse_keep + tid; i < a.max_keep; i += nt) packed[i] = ttab[i];

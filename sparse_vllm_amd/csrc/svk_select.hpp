@@ -101,30 +101,42 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, boo
 
 // Core on descending-order keys `key_at(i)` (smaller key = better; callers stage keys in LDS when the row fits, so the
 // sweeps do not pay a dependent global-load latency each).
+// OR / AND of all keys, accumulated in the scratch (workgroup-wide): begin (includes a barrier), add per thread, then a
+// barrier before the select reads them
+__device__ __forceinline__ void select_bits_begin(SelectScratch& S) {
+  if (threadIdx.x == 0) { S.or_bits = 0u; S.and_bits = 0xffffffffu; }
+  __syncthreads();
+}
+__device__ __forceinline__ void select_bits_add(SelectScratch& S, uint32_t o, uint32_t an) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    o |= (uint32_t)__shfl_xor((int)o, off, 64);
+    an &= (uint32_t)__shfl_xor((int)an, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { atomicOr(&S.or_bits, o); atomicAnd(&S.and_bits, an); }
+}
+
 template <typename KeyAt, typename Emit>
-__device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int n, int k, SelectScratch& S, Emit emit) {
+__device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int n, int k, SelectScratch& S, Emit emit,
+                                                               bool bits_ready = false) {
   const int tid = threadIdx.x, nt = blockDim.x;
   uint32_t prefix = 0;
   int kk = k;
   // bytes shared by every key (bf16-valued scores: the two low bytes; probabilities: most of the top byte) are
   // found with one atomic-free sweep and skip their radix pass
-  if (tid == 0) { S.or_bits = 0u; S.and_bits = 0xffffffffu; }
-  __syncthreads();
-  {
+  // (callers that stage the keys themselves fold this sweep into their staging loop: `select_bits_begin` before,
+  //  `select_bits_add` with each thread's OR / AND, then `bits_ready` = true)
+  if (!bits_ready) {
+    select_bits_begin(S);
     uint32_t o = 0u, an = 0xffffffffu;
     for (int i = tid; i < n; i += nt) {
       const uint32_t key = key_at(i);
       o |= key;
       an &= key;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      o |= (uint32_t)__shfl_xor((int)o, off, 64);
-      an &= (uint32_t)__shfl_xor((int)an, off, 64);
-    }
-    if ((tid & 63) == 0) { atomicOr(&S.or_bits, o); atomicAnd(&S.and_bits, an); }
+    select_bits_add(S, o, an);
+    __syncthreads();
   }
-  __syncthreads();
   const uint32_t all_and = S.and_bits;
   const uint32_t varying = S.or_bits ^ all_and;              // bit positions on which the keys differ
   // 8-bit digits are laid from the highest varying bit down to the lowest one (not on byte boundaries): the first
