@@ -434,14 +434,35 @@ __global__ void __launch_bounds__(1024) topk_stage_kernel(const SvkTopkSortedArg
   const int vlen = a.valid_len ? min(max(a.valid_len[r], 0), a.n) : a.n;
   const int i0 = c * chunk, m = min(a.n, i0 + chunk) - i0;
   const float masked = a.masked_value;
-  for (int i = tid; i < m; i += nt) keys[i] = desc_key(i0 + i < vlen ? sc[i0 + i] : masked);
+  // staging with 8 loads in flight per thread and the select's OR / AND sweep folded in
+  select_bits_begin(scratch);
+  uint32_t o_bits = 0u, a_bits = 0xffffffffu;
+  for (int j0 = 0; j0 < m; j0 += 8 * nt) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = j0 + u * nt + tid;
+      v[u] = (i < m && i0 + i < vlen) ? sc[i0 + i] : masked;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = j0 + u * nt + tid;
+      if (i < m) {
+        const uint32_t key = desc_key(v[u]);
+        keys[i] = key;
+        o_bits |= key;
+        a_bits &= key;
+      }
+    }
+  }
+  select_bits_add(scratch, o_bits, a_bits);
   if (chunks == 1)
     for (int i = tid; i < kpad; i += nt) sorted[i] = ~0ull;
   __syncthreads();
   if (chunks == 1) {
     block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, m, a.k, scratch, [&](int pos, int i) {
       sorted[pos] = ((unsigned long long)keys[i] << 32) | (unsigned)i;
-    });
+    }, true);
     __syncthreads();
     bitonic_sort_keys(sorted, kpad);
     for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(sorted[i] & 0xffffffffull);
@@ -454,7 +475,7 @@ __global__ void __launch_bounds__(1024) topk_stage_kernel(const SvkTopkSortedArg
   }
   block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, m, a.k, scratch, [&](int pos, int i) {
     out[pos] = ((unsigned long long)keys[i] << 32) | (unsigned)(i0 + i);
-  });
+  }, true);
 }
 
 // one workgroup per row over the chunks * k candidates (ascending index by construction)
@@ -467,14 +488,34 @@ __global__ void __launch_bounds__(1024) topk_merge_kernel(const SvkTopkSortedArg
   const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int total = chunks * a.k;
   const unsigned long long* in = cand + (int64_t)r * total;
-  for (int i = tid; i < total; i += nt) keys[i] = (uint32_t)(in[i] >> 32);
+  select_bits_begin(scratch);
+  uint32_t o_bits = 0u, a_bits = 0xffffffffu;
+  for (int j0 = 0; j0 < total; j0 += 8 * nt) {
+    unsigned long long c8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = j0 + u * nt + tid;
+      c8[u] = i < total ? in[i] : ~0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = j0 + u * nt + tid;
+      if (i < total) {
+        const uint32_t key = (uint32_t)(c8[u] >> 32);
+        keys[i] = key;
+        o_bits |= key;
+        a_bits &= key;
+      }
+    }
+  }
+  select_bits_add(scratch, o_bits, a_bits);
   for (int i = tid; i < kpad; i += nt) sorted[i] = ~0ull;
   __syncthreads();
   // padding entries carry key 0xffffffff with index 0xffffffff: they lose every tie against real entries because
   // real entries of equal key (there are none unless a score is the all-ones NaN pattern) come first in a chunk
   block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, total, a.k, scratch, [&](int pos, int i) {
     sorted[pos] = in[i];
-  });
+  }, true);
   __syncthreads();
   bitonic_sort_keys(sorted, kpad);
   for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(sorted[i] & 0xffffffffull);
