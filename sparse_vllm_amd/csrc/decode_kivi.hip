@@ -251,7 +251,9 @@ __global__ void __launch_bounds__(512) kivi_stage1_kernel(const SvkKiviDecodeSta
 
 // ------------------------------------------------------------------------------------------------
 // 128-token-tile kernel (group_size 32): both products on the matrix cores, K/V dequantised straight
-// into MFMA operand registers.
+// into MFMA operand registers.  V side: the scale is a bf16 value and the code a 4-bit integer (times 16 for the odd
+// nibbles, against scale/16), so code*scale is exact in fp32 and fma(code, scale, min) is bit-identical to the
+// reference's separately rounded multiply and add - one packed fma instead of a packed multiply and a packed add.
 //
 //   Q.K^T  tile = 128 tokens = 16 "groups" of 8 consecutive tokens.  MFMA i (0..7) of d-chunk c takes as
 //          column n the token 8n+i, so lane (n, kc) needs nibble i of the 8 words
@@ -618,8 +620,8 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
         {                                                                                                      \
           uint32_t vf[4];                                                                                      \
           _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                                   \
-            const float x0 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2], hi[2 * e2]), ((I_) & 1) ? sc16[2 * e2] : sc[2 * e2]), mn[2 * e2]);             \
-            const float x1 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2 + 1], hi[2 * e2 + 1]), ((I_) & 1) ? sc16[2 * e2 + 1] : sc[2 * e2 + 1]), mn[2 * e2 + 1]); \
+            const float x0 = __builtin_fmaf(nibble_f32<I_>(lo[2 * e2], hi[2 * e2]), ((I_) & 1) ? sc16[2 * e2] : sc[2 * e2], mn[2 * e2]);             \
+            const float x1 = __builtin_fmaf(nibble_f32<I_>(lo[2 * e2 + 1], hi[2 * e2 + 1]), ((I_) & 1) ? sc16[2 * e2 + 1] : sc[2 * e2 + 1], mn[2 * e2 + 1]); \
             vf[e2] = pack_bf16(x0, x1);                                                                        \
           }                                                                                                    \
           acc[I_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag, __builtin_bit_cast(bf16x8_t, make_uint4(vf[0], vf[1], vf[2], vf[3])), acc[I_], 0, 0, 0); \
@@ -1023,8 +1025,8 @@ kivi_stage1_tile128_pf_kernel(const SvkKiviDecodeStage1Args a) {
         {                                                                                                      \
           uint32_t vf[4];                                                                                      \
           _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                                   \
-            const float x0 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2], hi[2 * e2]), ((I_) & 1) ? sc16[2 * e2] : sc[2 * e2]), mn[2 * e2]);             \
-            const float x1 = add_rn(mul_rn(nibble_f32<I_>(lo[2 * e2 + 1], hi[2 * e2 + 1]), ((I_) & 1) ? sc16[2 * e2 + 1] : sc[2 * e2 + 1]), mn[2 * e2 + 1]); \
+            const float x0 = __builtin_fmaf(nibble_f32<I_>(lo[2 * e2], hi[2 * e2]), ((I_) & 1) ? sc16[2 * e2] : sc[2 * e2], mn[2 * e2]);             \
+            const float x1 = __builtin_fmaf(nibble_f32<I_>(lo[2 * e2 + 1], hi[2 * e2 + 1]), ((I_) & 1) ? sc16[2 * e2 + 1] : sc[2 * e2 + 1], mn[2 * e2 + 1]); \
             vf[e2] = pack_bf16(x0, x1);                                                                        \
           }                                                                                                    \
           acc[I_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag, __builtin_bit_cast(bf16x8_t, make_uint4(vf[0], vf[1], vf[2], vf[3])), acc[I_], 0, 0, 0); \
