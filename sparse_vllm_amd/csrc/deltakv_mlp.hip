@@ -230,7 +230,8 @@ extern "C" int svk_dequant_linear_act(const SvkDequantLinearArgs* a, svk_stream_
               "svk_dequant_linear_act: weight rows must be 16-byte aligned");
   SVK_REQUIRE(a->activation == 0 || a->activation == 1, SVK_ERR_VALUE, "svk_dequant_linear_act: activation %d (0 none, 1 erf-GELU)", a->activation);
   if (a->rows <= 0) return SVK_OK;
-  const size_t shm = sizeof(uint16_t) * kBM * (size_t)(a->k + 8);
+  // the staged A tile, reused for the transposed output tile of the epilogue (K = 32 needs the larger of the two)
+  const size_t shm = sizeof(uint16_t) * kBM * (size_t)((a->k > kBN ? a->k : kBN) + 8);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dequant_linear_act_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
