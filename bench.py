@@ -50,7 +50,7 @@ def parse():
 
 def cpu_baseline(seed: int = 20260625):
     """Oracle (numpy restatement of the reference) on a bounded sample: 2 sequences x 28 layers
-    x 12 decode steps at row length 4160 (the mean of the 4096..4224 cycle) + one burst
+    x 16 decode steps at row length 4160 (the mean of the 4096..4224 cycle) + one burst
     selection over the 56 (layer, sequence) rows amortised over the 128-step interval."""
     from oracle import bf16_round
     from oracle import decode_attention as oda
@@ -61,7 +61,7 @@ def cpu_baseline(seed: int = 20260625):
     except Exception:      # pragma: no cover
         limiter = None
     rng = np.random.default_rng(seed)
-    B, Hq, Hkv, D, Lrow, layers, steps = 2, 28, 4, 128, 4160, 28, 12
+    B, Hq, Hkv, D, Lrow, layers, steps = 2, 28, 4, 128, 4160, 28, 16
     slots = B * 4224 + 64
     k = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.3).astype(np.float32))
     v = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.3).astype(np.float32))
