@@ -100,13 +100,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the N ranks ourselves (child processes, before anything here touches a GPU)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:]))
+    if args.gpus != world:
+        print(f"[bench] --gpus {args.gpus} does not match WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     n_gpus = world if use_dist else 1
-    if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; running {n_gpus} rank(s)", file=sys.stderr)
     device = f"cuda:{local_rank}"
 
     from sparse_vllm_amd.config import Config
@@ -127,11 +138,14 @@ def main():
     q, k, v = drv.random_step_inputs(seed=7 + rank)
 
     # ---- stage-1 launch timing with HIP events on the launch stream (torch's current stream).
-    # Eager mode: the arguments of every stage-1 launch of a step are captured, and after the step
-    # the same 28 launches (same data, same state) are re-issued back to back between ONE pair of
-    # events.  (Bracketing each launch separately measures the event markers' own system-scope
-    # cache flushes and the Python launch latency, 2x the kernel time on this box; the re-issue is
-    # idempotent: identical partials, and the score max-combine sees identical values.)
+    # Eager mode: the arguments of every stage-1 launch of a step are captured, and right after the
+    # step's layer loop - BEFORE post_forward, so before a burst can compact the slot table or change
+    # the lengths - the same 28 launches are re-issued back to back between ONE pair of events: same
+    # K/V rows, slot table, lengths and queries as the launches of the step itself.  (Bracketing each
+    # launch separately measures the event markers' own system-scope cache flushes and the Python launch
+    # latency, 2x the kernel time on this box.  The re-issue is idempotent for the partials and the
+    # fused store; the raw-score buffer already holds this layer's probabilities, the max-combine's
+    # traffic is the same.)
     events = []          # (total_ms, n_launches, row_len)
     record = {"on": False, "calls": []}
     orig = attn_mod.flash_decode_stage1_with_score
@@ -184,11 +198,13 @@ def main():
         # roofline leg: the same workload continues for a few eagerly launched steps
         drv.config.decode_cuda_graph = False
         drv.sparse_controller._fused_h2o_layer = False
-        for _ in range(args.event_steps):
-            record["on"] = True
-            drv.step(q, k, v)
+        def after_layers():
             record["on"] = False
             time_captured_launches()
+
+        for _ in range(args.event_steps):
+            record["on"] = True
+            drv.step(q, k, v, after_layers=after_layers)
     from sparse_vllm_amd.replicas import aggregate_throughput
     tokens, elapsed = aggregate_throughput(B * args.steps, elapsed, device=device)
     out = {
@@ -221,9 +237,9 @@ def main():
             "frac": achieved / HBM_PEAK, "traffic": traffic,
             "kernel": "decode_stage1_kernel_v3<128,7,HEADMAX,nt,off32> (scored GQA split-KV decode)",
             "launches_timed": n_launch, "avg_launch_us": ms_total * 1e3 / n_launch,
-            "timing": (f"{args.event_steps} eagerly launched steps continue the timed region; after each, its 28 "
-                       "stage-1 launches are re-issued back to back on the same data between one pair of HIP "
-                       "events on the launch stream"),
+            "timing": (f"{args.event_steps} eagerly launched steps continue the timed region; after each step's layer "
+                       "loop and before its post_forward, its 28 stage-1 launches are re-issued back to back on the same "
+                       "data and state between one pair of HIP events on the launch stream"),
             "algorithmic_bytes_per_launch": bytes_total / n_launch,
         }
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

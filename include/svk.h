@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 3
+#define SVK_ABI_VERSION 4
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -168,6 +168,10 @@ typedef struct SvkH2oDecodeScoreArgs {
   float* cum_score;         /* NULL or [rows, cum_stride] persistent cumulative scores   */
   const int32_t* b_req_idx; /* [B] (used when cum_score != NULL)                         */
   const int32_t* b_seqlen;  /* [B] current physical length incl. the new token          */
+  const int32_t* b_new_slot;/* NULL or [B] this step's slot_mapping: lanes holding -1 are the padded hipGraph lanes
+                             * of prepare_decode_static (h2o.py:419-424, they mirror lane 0's row); they are normalised
+                             * but never accumulated - the reference adds only normalized[:, :len(seqs)]
+                             * (sparse_controller.py:1226-1282)                                                    */
   int64_t score_stride_b;
   int64_t cum_stride;
   float scale;              /* head_dim ** -0.5                                          */
@@ -274,14 +278,17 @@ typedef struct SvkDecodeAllocArgs {
   int32_t* slot_table;
   const int32_t* free_stack;
   const int32_t* layer_ids;   /* [n_layers]                                         */
-  const int32_t* row_ids;     /* [B]                                                */
-  const int32_t* cur_lens;    /* [B] length before the append                       */
+  const int32_t* row_ids;     /* [B], or [n_layers, B] with meta_stride_layer = B   */
+  const int32_t* cur_lens;    /* [B] length before the append (same layout)         */
+  const int64_t* free_ptrs;   /* NULL (every layer pops at free_ptr) or [n_layers]: the per-layer stack pointers of
+                               * the reference's non-uniform branch (snapkv.py:2656-2673)                  */
   int32_t* slot_mapping;      /* [n_layers, out_stride]  (lanes >= B get -1)        */
   int32_t* context_lens;      /* [n_layers, out_stride]                             */
   int32_t* req_indices;       /* [n_layers, out_stride]                             */
   int64_t table_stride_layer, table_stride_row;
   int64_t stack_stride;
   int64_t out_stride;
+  int64_t meta_stride_layer;  /* 0: row_ids / cur_lens shared by all layers          */
   int64_t free_ptr;           /* common stack pointer before the pop                */
   int32_t n_layers, batch, graph_batch;
 } SvkDecodeAllocArgs;

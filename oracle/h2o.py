@@ -186,6 +186,42 @@ def decode_allocate_batch_layers(state: SlotState, layers, rows) -> np.ndarray:
     return out
 
 
+def decode_allocate_per_layer(state: SlotState, layers, rows_by_layer):
+    """SnapKVCacheManager._prepare_decode, non-uniform branch (snapkv.py:2656-2673): every layer pops its OWN
+    window [ptr_l - B, ptr_l) and appends lane b's slot at that layer's own row length.
+    -> (new_slots [len(layers), B], context_lens [len(layers), B], max_context_len [len(layers)])."""
+    layers = list(layers)
+    B = len(rows_by_layer[0])
+    new_slots = np.zeros((len(layers), B), dtype=np.int32)
+    ctx = np.zeros((len(layers), B), dtype=np.int32)
+    for i, l in enumerate(layers):
+        ptr = int(state.free_ptr[l])
+        if ptr < B:
+            raise AssertionError(f"Out of KV slots: need {B}, free {ptr}")
+        new = state.free_stack[l, ptr - B: ptr].copy()
+        state.free_ptr[l] -= B
+        for b, r in enumerate(rows_by_layer[i]):
+            cur = int(state.row_len[l, r])
+            state.slot_table[l, r, cur] = new[b]
+            state.row_len[l, r] = cur + 1
+            ctx[i, b] = cur + 1
+        new_slots[i] = new
+    return new_slots, ctx, ctx.max(axis=1)
+
+
+def pad_static_decode_metadata(new_slots: np.ndarray, context_lens: np.ndarray, rows, graph_batch: int):
+    """Padded lanes of a graph-sized decode batch (h2o.py:419-437): slot -1, lane 0's length and row.
+    new_slots / context_lens [L, B] -> (slot_mapping, context_lens, req_indices) [L, graph_batch] i32."""
+    L, B = new_slots.shape
+    rows = np.asarray(rows, dtype=np.int32)
+    rows2 = np.broadcast_to(rows, (L, B)) if rows.ndim == 1 else rows
+    sm = np.full((L, graph_batch), -1, dtype=np.int32)
+    cl = np.repeat(context_lens[:, :1].astype(np.int32), graph_batch, axis=1)
+    ri = np.repeat(rows2[:, :1].astype(np.int32), graph_batch, axis=1)
+    sm[:, :B], cl[:, :B], ri[:, :B] = new_slots, context_lens, rows2
+    return sm, cl, ri
+
+
 def free_seq(state: SlotState, layers, row: int) -> None:
     """snapkv.py:1489-1514: push the whole row back, zero it."""
     for l in layers:

@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 3
+SVK_ABI_VERSION = 4
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -66,7 +66,7 @@ class SvkFlashDecodeStage2Args(C.Structure):
 
 
 class SvkH2oDecodeScoreArgs(C.Structure):
-    _fields_ = [("attn_score", _p), ("cum_score", _p), ("b_req_idx", _p), ("b_seqlen", _p),
+    _fields_ = [("attn_score", _p), ("cum_score", _p), ("b_req_idx", _p), ("b_seqlen", _p), ("b_new_slot", _p),
                 ("score_stride_b", _i64), ("cum_stride", _i64), ("scale", _f32), ("batch", _i32), ("width", _i32)]
 
 
@@ -99,9 +99,9 @@ class SvkCompactRowsArgs(C.Structure):
 
 class SvkDecodeAllocArgs(C.Structure):
     _fields_ = [("slot_table", _p), ("free_stack", _p), ("layer_ids", _p), ("row_ids", _p), ("cur_lens", _p),
-                ("slot_mapping", _p), ("context_lens", _p), ("req_indices", _p),
+                ("free_ptrs", _p), ("slot_mapping", _p), ("context_lens", _p), ("req_indices", _p),
                 ("table_stride_layer", _i64), ("table_stride_row", _i64), ("stack_stride", _i64),
-                ("out_stride", _i64), ("free_ptr", _i64),
+                ("out_stride", _i64), ("meta_stride_layer", _i64), ("free_ptr", _i64),
                 ("n_layers", _i32), ("batch", _i32), ("graph_batch", _i32)]
 
 

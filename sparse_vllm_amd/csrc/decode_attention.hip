@@ -744,7 +744,8 @@ __device__ __forceinline__ void fused_row_finish(const SvkFlashDecodeStage1Args&
   float* red = lds;                                   // the tile loop is over: reuse the dynamic LDS
   float* x = fs.attn_score + (int64_t)b * fs.score_stride_b;
   const int W = fs.width;
-  float* cum = fs.cum_score != nullptr ? fs.cum_score + (int64_t)fs.b_req_idx[b] * fs.cum_stride : nullptr;
+  float* cum = (fs.cum_score != nullptr && !(fs.b_new_slot != nullptr && fs.b_new_slot[b] < 0))   // padded lanes: no update
+                   ? fs.cum_score + (int64_t)fs.b_req_idx[b] * fs.cum_stride : nullptr;
   const int nt = blockDim.x;
   if (W <= 32 * nt) {
     float v[32], c[32];

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
   sum = block_allsum(sum, red);
   float* cum = nullptr;
   int len = 0;
-  if (a.cum_score != nullptr) {
+  if (a.cum_score != nullptr && !(a.b_new_slot != nullptr && a.b_new_slot[b] < 0)) {   // padded graph lanes: no update
     cum = a.cum_score + (int64_t)a.b_req_idx[b] * a.cum_stride;
     len = a.b_seqlen[b];
   }
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDec
     // the cumulative row's old values are fetched together with the raw scores, not after the two reductions
     float* cum = nullptr;
     int len = 0;
-    if (a.cum_score != nullptr) {
+    if (a.cum_score != nullptr && !(a.b_new_slot != nullptr && a.b_new_slot[b] < 0)) {   // padded graph lanes: no update
       cum = a.cum_score + (int64_t)a.b_req_idx[b] * a.cum_stride;
       len = a.b_seqlen[b];
     }
@@ -259,16 +259,20 @@ __global__ void __launch_bounds__(256) decode_alloc_kernel(const SvkDecodeAllocA
   int32_t* sm = a.slot_mapping + (int64_t)li * a.out_stride;
   int32_t* cl = a.context_lens + (int64_t)li * a.out_stride;
   int32_t* ri = a.req_indices + (int64_t)li * a.out_stride;
+  // non-uniform layers (snapkv.py:2656-2673): rows, lengths and the stack pointer are per layer
+  const int32_t* row_ids = a.row_ids + (int64_t)li * a.meta_stride_layer;
+  const int32_t* cur_lens = a.cur_lens + (int64_t)li * a.meta_stride_layer;
+  const int64_t free_ptr = a.free_ptrs != nullptr ? a.free_ptrs[li] : a.free_ptr;
   if (b >= a.batch) {
     // padded graph lanes: slot -1, metadata of lane 0 (h2o.py:419-424 index_fill_)
     sm[b] = -1;
-    cl[b] = a.cur_lens[0] + 1;
-    ri[b] = a.row_ids[0];
+    cl[b] = cur_lens[0] + 1;
+    ri[b] = row_ids[0];
     return;
   }
-  const int32_t slot = a.free_stack[(int64_t)layer * a.stack_stride + a.free_ptr - a.batch + b];
-  const int row = a.row_ids[b];
-  const int cur = a.cur_lens[b];
+  const int32_t slot = a.free_stack[(int64_t)layer * a.stack_stride + free_ptr - a.batch + b];
+  const int row = row_ids[b];
+  const int cur = cur_lens[b];
   a.slot_table[(int64_t)layer * a.table_stride_layer + (int64_t)row * a.table_stride_row + cur] = slot;
   sm[b] = slot;
   cl[b] = cur + 1;
@@ -379,8 +383,8 @@ extern "C" int svk_decode_alloc_slots(const SvkDecodeAllocArgs* a, svk_stream_t 
   SVK_REQUIRE(a->batch > 0, SVK_ERR_VALUE, "Static decode requires a non-empty real decode batch.");
   SVK_REQUIRE(a->graph_batch >= a->batch, SVK_ERR_VALUE,
               "Static decode graph batch is smaller than the real decode batch: graph=%d, real=%d.", a->graph_batch, a->batch);
-  SVK_REQUIRE(a->free_ptr >= a->batch, SVK_ERR_STATE, "Out of KV cache slots in static decode: need=%d free=%lld.", a->batch,
-              (long long)a->free_ptr);
+  SVK_REQUIRE(a->free_ptrs != nullptr || a->free_ptr >= a->batch, SVK_ERR_STATE,
+              "Out of KV cache slots in static decode: need=%d free=%lld.", a->batch, (long long)a->free_ptr);
   if (a->n_layers <= 0) return SVK_OK;
   hipLaunchKernelGGL(decode_alloc_kernel, dim3((a->graph_batch + 255) / 256, a->n_layers), dim3(256), 0,
                      static_cast<hipStream_t>(stream), *a);

@@ -67,7 +67,11 @@ class H2OCacheManager(SnapKVCacheManager):
         capacity = min(self.h2o_decode_budget + self.h2o_decode_eviction_interval, int(self.config.max_model_len))
         return max(1, capacity), False
 
-    # ---- selection (device, bit-exact with h2o.py:478-563)
+    def _supports_nonuniform_decode_layers(self) -> bool:
+        """H2O appends and evicts one token on every KV layer: rows, lengths and stack pointers stay aligned and the
+        static decode path relies on it (h2o.py:256-271, :306-330)."""
+        return False
+
     # ------------------------------------------------------------------ scheduler capacity hooks (h2o.py:73-230)
     # An H2O row never holds more than max(resident, prefill budget) + one chunk during prefill (append, then evict), and
     # budget + interval during decode; the scheduler reserves those physical peaks, not the logical prompt length.

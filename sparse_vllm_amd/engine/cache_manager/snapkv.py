@@ -56,7 +56,8 @@ class SnapKVCacheManager(CacheManager):
         self.free_slots_stack_tensor = torch.arange(self.num_slots, dtype=torch.int32, device=d).repeat(L, 1)
         self.free_slots_stack = [self.free_slots_stack_tensor[i] for i in range(L)]
         self._num_free_slots = [self.num_slots for _ in range(L)]
-        self.row_seq_lens = [np.zeros((rows,), dtype=np.int32) for _ in range(L)]
+        self._row_seq_lens_all = np.zeros((L, rows), dtype=np.int32)        # one array: per-layer checks are one numpy op
+        self.row_seq_lens = [self._row_seq_lens_all[i] for i in range(L)]   # views, the reference's list-of-arrays face
         self.seq_id_to_row = [dict() for _ in range(L)]
         self.free_rows = [deque(range(rows)) for _ in range(L)]
         self._layer_ids_all = torch.arange(L, dtype=torch.int32, device=d)
@@ -256,15 +257,28 @@ class SnapKVCacheManager(CacheManager):
         if real_batch_size > graph_batch_size:
             raise ValueError("Static decode graph batch is smaller than the real decode batch: "
                              f"graph={graph_batch_size}, real={real_batch_size}.")
-        layer_ids = self.kv_transformer_layer_indices()
+        layer_ids = [int(l) for l in self.kv_transformer_layer_indices()]
         first = layer_ids[0]
-        rows = [self._row_of(first, s) for s in seqs]
-        cur_lens = self.row_seq_lens[first][rows].copy()
-        if self.validate_runtime_invariants:
-            for l in layer_ids[1:]:
-                if [self._row_of(l, s) for s in seqs] != rows or not np.array_equal(self.row_seq_lens[l][rows], cur_lens):
-                    raise RuntimeError("static decode requires uniform request rows/lengths across KV layers")
-        max_cur = int(cur_lens.max())
+        d = self.device
+        L = len(layer_ids)
+        # request rows of every layer: cached per batch composition (the dict lookups are the host cost of this
+        # function); the first layer's rows are looked up every step and are part of the key
+        rows0 = tuple(self._row_of(first, s) for s in seqs)
+        key = (tuple(s.seq_id for s in seqs), rows0, tuple(layer_ids))
+        cached = getattr(self, "_decode_static_rows", None)
+        if cached is None or cached[0] != key:
+            rows_2d = np.array([rows0] + [[self._row_of(l, s) for s in seqs] for l in layer_ids[1:]], dtype=np.int64)
+            rows_uniform = bool((rows_2d == rows_2d[0]).all())
+            kv_idx = np.array([self.kv_layer_index(l) for l in layer_ids], dtype=np.int64)
+            cached = (key, rows_2d, rows_uniform, kv_idx,
+                      torch.from_numpy(rows_2d[0].astype(np.int32)).to(d),
+                      None if rows_uniform else torch.from_numpy(rows_2d.astype(np.int32)).to(d))
+            self._decode_static_rows = cached
+        _, rows_2d, rows_uniform, kv_idx, rows_gpu, rows_2d_gpu = cached
+        cur_2d = self._row_seq_lens_all[kv_idx[:, None], rows_2d]                    # [L, B] lengths before the append
+        free_ptrs = [int(self._num_free_slots[l]) for l in layer_ids]
+        uniform = rows_uniform and bool((cur_2d == cur_2d[0]).all()) and all(p == free_ptrs[0] for p in free_ptrs[1:])
+        max_cur = int(cur_2d.max())
         if max_cur + 1 > self.max_model_len:
             raise RuntimeError(f"KV row length exceeds max_model_len in static decode: max_cur_len={max_cur} "
                                f"max_model_len={self.max_model_len}.")
@@ -272,36 +286,44 @@ class SnapKVCacheManager(CacheManager):
         if static_cap is not None and max_cur + 1 > int(static_cap):
             raise RuntimeError("static decode context exceeds the captured graph capacity: "
                                f"next_len={max_cur + 1} static_cap={int(static_cap)}.")
-        free_ptrs = [int(self._num_free_slots[l]) for l in layer_ids]
-        if any(p != free_ptrs[0] for p in free_ptrs[1:]):
-            raise RuntimeError(f"static decode requires aligned per-layer free-stack pointers: ptrs={free_ptrs}.")
-        if free_ptrs[0] < real_batch_size:
-            raise RuntimeError(f"Out of KV cache slots in static decode: need={real_batch_size} free={free_ptrs[0]}.")
-        d = self.device
-        key = (tuple(s.seq_id for s in seqs), tuple(rows))
-        cached = getattr(self, "_decode_static_rows", None)
-        if cached is None or cached[0] != key:
-            cached = (key, torch.tensor(rows, dtype=torch.int32, device=d))
-            self._decode_static_rows = cached
-        rows_gpu = cached[1]
-        cur_gpu = torch.from_numpy(cur_lens.astype(np.int32)).to(d, non_blocking=True)
+        if min(free_ptrs) < real_batch_size:
+            raise RuntimeError(f"Out of KV cache slots in static decode: need={real_batch_size} free={min(free_ptrs)}.")
+        if not uniform and not self._supports_nonuniform_decode_layers():
+            raise RuntimeError("static decode requires uniform request rows, row lengths and free-stack pointers across "
+                               f"KV layers: ptrs={free_ptrs} lens_first_lane={cur_2d[:, 0].tolist()}.")
         sm, cl, ri = self._get_decode_static_buffers(graph_batch_size)
-        h2o_ops.decode_alloc_slots(self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor,
-                                   self._layer_ids_all, rows_gpu, cur_gpu, sm, cl, ri,
-                                   free_ptr=free_ptrs[0], batch=real_batch_size)
-        for l in layer_ids:
+        if uniform:
+            cur_gpu = torch.from_numpy(cur_2d[0].astype(np.int32)).to(d, non_blocking=True)
+            h2o_ops.decode_alloc_slots(self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor,
+                                       self._layer_ids_all, rows_gpu, cur_gpu, sm, cl, ri,
+                                       free_ptr=free_ptrs[0], batch=real_batch_size)
+        else:
+            # per-layer rows / lengths / stack pointers: the non-uniform branch of the reference's _prepare_decode
+            # (snapkv.py:2656-2673; e.g. snapkv_num_full_layers > 0 leaves the full layers uncompressed)
+            if rows_2d_gpu is None:
+                rows_2d_gpu = torch.from_numpy(rows_2d.astype(np.int32)).to(d)
+            cur_gpu = torch.from_numpy(np.ascontiguousarray(cur_2d, dtype=np.int32)).to(d, non_blocking=True)
+            ptr_gpu = torch.tensor(free_ptrs, dtype=torch.long, device=d)
+            h2o_ops.decode_alloc_slots(self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor,
+                                       torch.from_numpy(kv_idx.astype(np.int32)).to(d), rows_2d_gpu, cur_gpu, sm, cl, ri,
+                                       free_ptr=min(free_ptrs), batch=real_batch_size, free_ptrs=ptr_gpu)
+        for i, l in enumerate(layer_ids):
             self._num_free_slots[l] -= real_batch_size
-            self.row_seq_lens[l][rows] = cur_lens + 1
-        max_context_len = int(static_cap) if static_cap is not None else max_cur + 1
-        for l in layer_ids:
+        self._row_seq_lens_all[kv_idx[:, None], rows_2d] = cur_2d + 1
+        for i, l in enumerate(layer_ids):
             st = self.layer_batch_states[l]
-            st.slot_mapping, st.context_lens, st.req_indices = sm[l], cl[l], ri[l]
-            st.max_context_len = max_context_len
+            st.slot_mapping, st.context_lens, st.req_indices = sm[i], cl[i], ri[i]
+            st.max_context_len = int(static_cap) if static_cap is not None else int(cur_2d[i].max()) + 1
         if slot_mapping is not None:
-            slot_mapping.copy_(sm[first])
-            context_lens.copy_(cl[first])
-            req_indices.copy_(ri[first])
+            slot_mapping.copy_(sm[0])
+            context_lens.copy_(cl[0])
+            req_indices.copy_(ri[0])
         return input_ids, positions, None
+
+    def _supports_nonuniform_decode_layers(self) -> bool:
+        """SnapKV-family rows may differ across layers (full layers, per-layer budgets); H2O overrides this to False:
+        its decode path needs aligned rows (h2o.py:256-271)."""
+        return True
 
     def _prepare_decode(self, seqs):
         return self.prepare_decode_static(seqs)
@@ -309,6 +331,7 @@ class SnapKVCacheManager(CacheManager):
     # ------------------------------------------------------------------ release / compaction
     def free_seq(self, seq_id: int):
         """snapkv.py:1489-1514."""
+        self._decode_static_rows = None
         for layer_idx in self.kv_transformer_layer_indices():
             row = self.seq_id_to_row[layer_idx].pop(seq_id, None)
             if row is None:

@@ -39,6 +39,9 @@ class SparseDecodeDriver:
         self.attn = Attention(cm.num_heads, cm.head_dim, cm.head_dim ** -0.5, cm.num_kv_heads,
                               decode_launch_op=launch_op)
         self.seqs: list[Sequence] = []
+        # lanes of the step's static buffers (>= len(seqs)); the extra lanes are the padded lanes of a hipGraph
+        # captured for a larger batch (decode_cuda_graph.py:266-303)
+        self.graph_batch_size: int | None = None
 
     # ------------------------------------------------------------------ synthetic state
     def admit_resident_rows(self, batch: int, resident_len: int, *, logical_len: int | None = None, seed: int = 0,
@@ -154,7 +157,7 @@ class SparseDecodeDriver:
         """Per-layer q [L,B,Hq,D] and new-token k,v [L,B,Hkv,D] (bf16)."""
         cm = self.cache_manager
         g = torch.Generator(device="cpu").manual_seed(seed)
-        B, L = len(self.seqs), cm.num_layers
+        B, L = int(self.graph_batch_size or len(self.seqs)), cm.num_layers
         mk = lambda h: (torch.randn((L, B, h, cm.head_dim), generator=g) * scale).to(torch.bfloat16).to(self.device)
         return mk(cm.num_heads), mk(cm.num_kv_heads), mk(cm.num_kv_heads)
 
@@ -195,10 +198,15 @@ class SparseDecodeDriver:
         self._graph_steps_seen = 0
 
     @torch.no_grad()
-    def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None):
+    def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None, *,
+             after_layers=None):
+        """`after_layers()` (measurement hook) runs between the layer loop and post_forward."""
         cm, sc = self.cache_manager, self.sparse_controller
         seqs = self.seqs
-        cm.prepare_decode_static(seqs)
+        if self.graph_batch_size is not None:
+            cm.prepare_decode_static(seqs, graph_batch_size=int(self.graph_batch_size))
+        else:
+            cm.prepare_decode_static(seqs)
         if not getattr(self.config, "decode_cuda_graph", False):
             self._forward_layers(q, k, v, outputs)
         else:
@@ -220,6 +228,8 @@ class SparseDecodeDriver:
                     g.replay()
             else:
                 self._graph.replay()
+        if after_layers is not None:
+            after_layers()
         sc.post_forward(seqs, False)
         cm.on_forward_end(seqs, False)
         for s in seqs:

@@ -224,6 +224,15 @@ class SparseController:
                                max_context_len=s.max_context_len, attn_score=s.attn_score,
                                global_req_indices=s.global_req_indices)
 
+    def _h2o_new_slots(self, layer_idx: int):
+        """This step's slot_mapping of the layer: -1 marks the padded lanes of a graph-sized batch, whose scores the
+        reference drops (`normalized[:, :len(seqs)]`, sparse_controller.py:1226-1282)."""
+        sm = self.cache_manager.get_layer_batch_states(layer_idx).slot_mapping
+        s = self.layer_batch_sparse_states[layer_idx]
+        if sm is None or sm.dtype != torch.int32 or s.attn_score is None or sm.numel() != s.attn_score.shape[0]:
+            return None
+        return sm
+
     def fused_decode_layer(self, layer_idx: int, q, k_cache, v_cache, active_slots, req_indices, context_lens, max_len_in_batch,
                            mid_o, mid_lse, attn_score, block_seq, o) -> bool:
         """MI355X fusion hook: the whole H2O decode layer (scored stage 1, stage 2, score normalise + cumulative
@@ -237,7 +246,8 @@ class SparseController:
         cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
         from ..kernels.gqa_flash_decoding_stage1 import h2o_decode_fused
         h2o_decode_fused(q, k_cache, v_cache, active_slots, req_indices, context_lens, max_len_in_batch, mid_o, mid_lse,
-                         attn_score, block_seq, o, self.attn_softmax_scale, cum_score=cum)
+                         attn_score, block_seq, o, self.attn_softmax_scale, cum_score=cum,
+                         b_new_slot=self._h2o_new_slots(layer_idx))
         self._layer_score_finished[layer_idx] = True
         return True
 
@@ -253,7 +263,7 @@ class SparseController:
         cm = self.cache_manager
         cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
         h2o_ops.h2o_decode_finish(mid_o, mid_lse, context_lens, o, block_seq, s.attn_score, self.attn_softmax_scale,
-                                  cum_score=cum, b_req_idx=s.req_indices)
+                                  cum_score=cum, b_req_idx=s.req_indices, b_new_slot=self._h2o_new_slots(layer_idx))
         self._layer_score_finished[layer_idx] = True
         return True
 
@@ -284,11 +294,13 @@ class SparseController:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 h2o_ops.h2o_decode_score_update(s.attn_score, self.attn_softmax_scale, cum_score=cum,
-                                                b_req_idx=s.req_indices, b_seqlen=s.context_lens)
+                                                b_req_idx=s.req_indices, b_seqlen=s.context_lens,
+                                                b_new_slot=self._h2o_new_slots(layer_idx))
             self._h2o_score_stream_used = True
             return
         h2o_ops.h2o_decode_score_update(s.attn_score, self.attn_softmax_scale, cum_score=cum,
-                                        b_req_idx=s.req_indices, b_seqlen=s.context_lens)
+                                        b_req_idx=s.req_indices, b_seqlen=s.context_lens,
+                                        b_new_slot=self._h2o_new_slots(layer_idx))
 
     def join_side_streams(self):
         """Make the current stream wait for the side-stream score epilogues of this step (end of the layer loop,

@@ -93,7 +93,7 @@ _TICKETS: dict = {}
 
 @torch.no_grad()
 def h2o_decode_fused(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp, attn_score,
-                     block_seq, O, scale, *, cum_score=None):
+                     block_seq, O, scale, *, cum_score=None, b_new_slot=None):
     """One launch = flash_decode_stage1_with_score (2-D head-max scores) + flash_decode_stage2 + the H2O score
     normalise / accumulate of `h2o_decode_finish` (ticketed last-workgroup epilogue).  Same results."""
     assert attn_score is not None and attn_score.dim() == 2
@@ -112,7 +112,7 @@ def h2o_decode_fused(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_bat
         stage1=a,
         score=_lib.SvkH2oDecodeScoreArgs(
             attn_score=_lib.ptr(attn_score), cum_score=_lib.ptr(cum_score), b_req_idx=_lib.ptr(B_req_idx),
-            b_seqlen=_lib.ptr(B_Seqlen), score_stride_b=attn_score.stride(0),
+            b_seqlen=_lib.ptr(B_Seqlen), b_new_slot=_lib.ptr(b_new_slot), score_stride_b=attn_score.stride(0),
             cum_stride=0 if cum_score is None else cum_score.stride(0), scale=float(scale),
             batch=attn_score.shape[0], width=attn_score.shape[1]),
         o=_lib.ptr(O), o_stride_b=O.stride(0), o_stride_h=O.stride(1), tickets=_lib.ptr(tickets))

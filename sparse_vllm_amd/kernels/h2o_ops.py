@@ -19,18 +19,23 @@ def fill_f32(t: torch.Tensor, value: float):
 
 
 def h2o_decode_score_update(attn_score: torch.Tensor, scale: float, *, cum_score: torch.Tensor | None = None,
-                            b_req_idx: torch.Tensor | None = None, b_seqlen: torch.Tensor | None = None):
+                            b_req_idx: torch.Tensor | None = None, b_seqlen: torch.Tensor | None = None,
+                            b_new_slot: torch.Tensor | None = None):
     """In place `attn_score.mul_(scale); softmax(attn_score, -1, out=attn_score)`
     (sparse_controller.py:762-767) and, when `cum_score` is given, the cumulative update of
     H2OCacheManager.update_decode_attention_scores_all_layers (h2o.py:957-1038) on the
-    persistent [rows, cap] score rows."""
+    persistent [rows, cap] score rows.  `b_new_slot` = the step's slot_mapping: lanes holding -1 (padded
+    hipGraph lanes of prepare_decode_static, which mirror lane 0's row) are normalised but not accumulated,
+    like the reference's `normalized[:, :len(seqs)]` (sparse_controller.py:1226-1282)."""
     assert attn_score.dim() == 2 and attn_score.dtype == torch.float32 and attn_score.stride(1) == 1
     lib = _lib.load()
     a = _lib.SvkH2oDecodeScoreArgs(
         attn_score=_lib.ptr(attn_score), cum_score=_lib.ptr(cum_score), b_req_idx=_lib.ptr(b_req_idx),
-        b_seqlen=_lib.ptr(b_seqlen), score_stride_b=attn_score.stride(0),
+        b_seqlen=_lib.ptr(b_seqlen), b_new_slot=_lib.ptr(b_new_slot), score_stride_b=attn_score.stride(0),
         cum_stride=0 if cum_score is None else cum_score.stride(0), scale=float(scale),
         batch=attn_score.shape[0], width=attn_score.shape[1])
+    if b_new_slot is not None:
+        assert b_new_slot.dtype == torch.int32 and b_new_slot.numel() >= attn_score.shape[0] and b_new_slot.stride(-1) == 1
     if cum_score is not None:
         assert cum_score.dim() == 2 and cum_score.dtype == torch.float32 and cum_score.stride(1) == 1
         assert b_req_idx is not None and b_seqlen is not None
@@ -38,7 +43,7 @@ def h2o_decode_score_update(attn_score: torch.Tensor, scale: float, *, cum_score
 
 
 def h2o_decode_finish(mid_out, mid_out_logexpsum, B_Seqlen, O, block_seq, attn_score, scale, *, cum_score=None,
-                      b_req_idx=None):
+                      b_req_idx=None, b_new_slot=None):
     """flash_decode_stage2 + h2o_decode_score_update in one launch (same results)."""
     assert mid_out.stride(-1) == 1 and mid_out_logexpsum.stride(-1) == 1 and O.stride(-1) == 1
     assert O.dtype == torch.bfloat16 and mid_out.dtype == torch.float32
@@ -56,7 +61,7 @@ def h2o_decode_finish(mid_out, mid_out_logexpsum, B_Seqlen, O, block_seq, attn_s
             head_dim=mid_out.shape[-1], block_seq=int(block_seq)),
         score=_lib.SvkH2oDecodeScoreArgs(
             attn_score=_lib.ptr(attn_score), cum_score=_lib.ptr(cum_score), b_req_idx=_lib.ptr(b_req_idx),
-            b_seqlen=_lib.ptr(B_Seqlen), score_stride_b=attn_score.stride(0),
+            b_seqlen=_lib.ptr(B_Seqlen), b_new_slot=_lib.ptr(b_new_slot), score_stride_b=attn_score.stride(0),
             cum_stride=0 if cum_score is None else cum_score.stride(0), scale=float(scale),
             batch=attn_score.shape[0], width=attn_score.shape[1]))
     _lib.check(lib.svk_h2o_decode_finish(C.byref(a), _lib.current_stream_handle()), lib)
@@ -138,18 +143,30 @@ def compact_rows(slot_table: torch.Tensor, free_stack: torch.Tensor, keep: torch
 
 
 def decode_alloc_slots(slot_table, free_stack, layer_ids, row_ids, cur_lens, slot_mapping, context_lens,
-                       req_indices, *, free_ptr: int, batch: int):
-    """Device half of H2OCacheManager.prepare_decode_static (h2o.py:386-437)."""
+                       req_indices, *, free_ptr: int, batch: int, free_ptrs: torch.Tensor | None = None):
+    """Device half of H2OCacheManager.prepare_decode_static (h2o.py:386-437).  `row_ids` / `cur_lens` are [B]
+    (uniform rows) or [n_layers, B] together with int64 `free_ptrs` [n_layers]: the per-layer branch of
+    SnapKVCacheManager._prepare_decode (snapkv.py:2656-2673)."""
     assert slot_mapping.dim() == 2 and slot_mapping.dtype == torch.int32 and slot_mapping.stride(1) == 1
     assert context_lens.stride() == slot_mapping.stride() and req_indices.stride() == slot_mapping.stride()
+    assert row_ids.dtype == torch.int32 and cur_lens.dtype == torch.int32 and row_ids.shape == cur_lens.shape
+    assert row_ids.is_contiguous() and cur_lens.is_contiguous()
+    n_layers = layer_ids.numel()
+    meta_stride = 0
+    if row_ids.dim() == 2:
+        assert row_ids.shape[0] == n_layers and row_ids.shape[1] >= int(batch)
+        meta_stride = row_ids.stride(0)
+    if free_ptrs is not None:
+        assert free_ptrs.dtype == torch.long and free_ptrs.numel() == n_layers and free_ptrs.is_contiguous()
     lib = _lib.load()
     a = _lib.SvkDecodeAllocArgs(
         slot_table=_lib.ptr(slot_table), free_stack=_lib.ptr(free_stack), layer_ids=_lib.ptr(layer_ids),
-        row_ids=_lib.ptr(row_ids), cur_lens=_lib.ptr(cur_lens), slot_mapping=_lib.ptr(slot_mapping),
+        row_ids=_lib.ptr(row_ids), cur_lens=_lib.ptr(cur_lens), free_ptrs=_lib.ptr(free_ptrs),
+        slot_mapping=_lib.ptr(slot_mapping),
         context_lens=_lib.ptr(context_lens), req_indices=_lib.ptr(req_indices),
         table_stride_layer=slot_table.stride(0), table_stride_row=slot_table.stride(1),
-        stack_stride=free_stack.stride(0), out_stride=slot_mapping.stride(0), free_ptr=int(free_ptr),
-        n_layers=layer_ids.numel(), batch=int(batch), graph_batch=slot_mapping.shape[1])
+        stack_stride=free_stack.stride(0), out_stride=slot_mapping.stride(0), meta_stride_layer=meta_stride,
+        free_ptr=int(free_ptr), n_layers=n_layers, batch=int(batch), graph_batch=slot_mapping.shape[1])
     _lib.check(lib.svk_decode_alloc_slots(C.byref(a), _lib.current_stream_handle()), lib)
 
 

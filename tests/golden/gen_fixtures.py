@@ -864,7 +864,57 @@ def gen_h2o_capacity():
     save("h2o_capacity", **flat)
 
 
+def gen_decode_alloc():
+    """Decode slot allocation: (1) SnapKVCacheManager._prepare_decode on NON-uniform layers (per-layer rows /
+    lengths / stack pointers, snapkv.py:2656-2673), (2) H2OCacheManager.prepare_decode_static with a graph batch
+    larger than the real batch (padded lanes: slot -1, lane 0's metadata, h2o.py:419-437), two consecutive steps."""
+    from sparsevllm.engine.cache_manager.snapkv import SnapKVCacheManager
+    from sparsevllm.engine.cache_manager.h2o import H2OCacheManager
+
+    out = {}
+    seqs = [SimpleNamespace(seq_id=i, decode_input_token=7 + i, decode_input_position=40 + i) for i in range(3)]
+    states = lambda L: [SimpleNamespace(slot_mapping=None, context_lens=None, req_indices=None, max_context_len=0)
+                        for _ in range(L)]
+
+    # (1) layer 0 is a "full" layer (long rows, fewer free slots), layers 1-2 are compressed
+    m = _make_manager([[30, 22, 27], [12, 9, 12], [12, 9, 11]], cls_name="SnapKVCacheManager")
+    m._num_free_slots[0] -= 5
+    m._num_free_slots[2] -= 1
+    m.layer_batch_states = states(3)
+    _put(out, "nu_before", _state(m))
+    for step in range(2):
+        SnapKVCacheManager._prepare_decode(m, seqs)
+        out[f"nu{step}_slot_mapping"] = np.stack([st.slot_mapping.numpy().copy() for st in m.layer_batch_states])
+        out[f"nu{step}_context_lens"] = np.stack([st.context_lens.numpy().copy() for st in m.layer_batch_states])
+        out[f"nu{step}_req_indices"] = np.stack([st.req_indices.numpy().copy() for st in m.layer_batch_states])
+        out[f"nu{step}_max_context_len"] = np.array([int(st.max_context_len) for st in m.layer_batch_states])
+        _put(out, f"nu{step}_after", _state(m))
+
+    # (2) real batch 3 in a graph batch of 6
+    m = _make_manager([[30, 22, 27], [30, 22, 27]], cls_name="H2OCacheManager")
+    m.layer_batch_states = states(2)
+    m._decode_static_state_binding_key = None
+    m._decode_static_buffers = {}
+    m._decode_static_max_context_len = None
+    m.validate_decode_cuda_graph_slot_mappings = lambda: None
+    GB = 6
+    _put(out, "pad_before", _state(m))
+    for step in range(2):
+        ii, pp = torch.zeros(GB, dtype=torch.int64), torch.zeros(GB, dtype=torch.int64)
+        sm, cl, ri = (torch.zeros(GB, dtype=torch.int32) for _ in range(3))
+        H2OCacheManager.prepare_decode_static(m, seqs, ii, pp, sm, cl, ri)
+        out[f"pad{step}_slot_mapping"] = np.stack([st.slot_mapping.numpy().copy() for st in m.layer_batch_states])
+        out[f"pad{step}_context_lens"] = np.stack([st.context_lens.numpy().copy() for st in m.layer_batch_states])
+        out[f"pad{step}_req_indices"] = np.stack([st.req_indices.numpy().copy() for st in m.layer_batch_states])
+        out[f"pad{step}_first"] = np.stack([sm.numpy(), cl.numpy(), ri.numpy()])
+        out[f"pad{step}_input_ids"] = ii.numpy()
+        out[f"pad{step}_positions"] = pp.numpy()
+        _put(out, f"pad{step}_after", _state(m))
+    save("decode_alloc", **out)
+
+
 GROUPS = {
+    "decode_alloc": gen_decode_alloc,
     "decode": gen_decode,
     "h2o_select": gen_h2o_select,
     "h2o_scores": gen_h2o_scores,
