@@ -1134,10 +1134,54 @@ decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
   *reinterpret_cast<uint2*>(a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d) = make_uint2(w0, w1);
 }
 
-// SVK_STAGE1_VARIANT=1|2 selects the earlier kernels (A/B runs); 3 = default
+#include "decode_stage1_dma.hpp"
+
+// SVK_STAGE1_VARIANT=1|2 selects the earlier kernels (A/B runs); 3 = default; 4 = the LDS-DMA kernel where it applies
+// (Qwen2.5-7B heads: head_dim 128, GQA group 7, block_seq <= kV4MaxRange, KV tensors < 4 GiB), v3 elsewhere.  v4 is
+// parity-green and streams at the same rate as v3 (both sit at the ~6.0-6.3 TB/s this gather reaches
+// on the chip), so it stays opt-in.
 inline int stage1_variant() {
   static const int variant = getenv("SVK_STAGE1_VARIANT") ? atoi(getenv("SVK_STAGE1_VARIANT")) : 3;
   return variant;
+}
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// v4 launch: K ring depth S by how many workgroups share a CU (the ring lives in LDS); SVK_STAGE1_KSTAGES / SVK_STAGE1_KNT
+// override the depth and the K cache policy for A/B runs.
+template <int G, int MODE, int S, bool NT>
+void launch_stage1_v4_one(const SvkFlashDecodeStage1Args& a, dim3 grid, dim3 block, size_t shm, hipStream_t stream) {
+  auto kfn = decode_stage1_kernel_v4<G, MODE, S, 2, NT, true>;
+  static bool attr_set = false;
+  if (!attr_set) {      // more than 64 KiB of dynamic LDS needs the opt-in, once per kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, grid, block, shm, stream, a);
+}
+
+template <int G, int MODE>
+bool launch_stage1_v4(const SvkFlashDecodeStage1Args& a, dim3 grid, dim3 block, bool off32, hipStream_t stream) {
+  using C = Stage1Cfg<128, G>;
+  static const int kstages = env_int("SVK_STAGE1_KSTAGES", 0), knt = env_int("SVK_STAGE1_KNT", 1);
+  if (!off32 || a.block_seq > kV4MaxRange) return false;
+  const int range32 = ((a.block_seq + kTileTokens - 1) / kTileTokens) * kTileTokens;
+  const long wgs = (long)grid.x * grid.y;
+  int S = kstages >= 4 ? 4 : (kstages > 0 ? 2 : (wgs <= 256 ? 4 : 2));
+  auto total = [&](int s_) { return Stage1V4Lds(range32, a.num_kv_heads, C::JQ, s_, MODE == SVK_SCORE_HEADMAX).total; };
+  if (S == 4 && total(4) > 160 * 1024) S = 2;
+  if (total(S) > 160 * 1024) return false;
+  const size_t shm = (size_t)total(S);
+  if (S == 4) {
+    if (knt) launch_stage1_v4_one<G, MODE, 4, true>(a, grid, block, shm, stream);
+    else launch_stage1_v4_one<G, MODE, 4, false>(a, grid, block, shm, stream);
+  } else {
+    if (knt) launch_stage1_v4_one<G, MODE, 2, true>(a, grid, block, shm, stream);
+    else launch_stage1_v4_one<G, MODE, 2, false>(a, grid, block, shm, stream);
+  }
+  return true;
 }
 
 template <int D, int G>
@@ -1151,6 +1195,15 @@ int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
   // 32-bit row offsets whenever the caller tells us the KV tensors span < 4 GiB
   const bool off32 = a.kv_num_slots > 0 && (a.kv_num_slots * a.kv_slot_stride * 2) < (int64_t)0xffffffffll;
   const int variant = stage1_variant();
+  if constexpr (D == 128 && G == 7) {
+    if (variant == 4) {
+      bool done = false;
+      if (a.score_mode == SVK_SCORE_HEADMAX) done = launch_stage1_v4<G, SVK_SCORE_HEADMAX>(a, grid, block, off32, stream);
+      else if (a.score_mode == SVK_SCORE_PERHEAD) done = launch_stage1_v4<G, SVK_SCORE_PERHEAD>(a, grid, block, off32, stream);
+      else done = launch_stage1_v4<G, SVK_SCORE_NONE>(a, grid, block, off32, stream);
+      if (done) return check_launch("svk_flash_decode_stage1");
+    }
+  }
   if (variant == 1 || (variant == 2 && G == 8)) {
     const size_t shm1 = sizeof(float) * ((size_t)a.num_kv_heads * C::WAVE_FLOATS + score_floats);
     hipLaunchKernelGGL((decode_stage1_kernel_v1<D, G>), grid, block, shm1, stream, a);
@@ -1257,7 +1310,7 @@ static int validate_stage1(const SvkFlashDecodeStage1Args* a, const char* who) {
     SVK_REQUIRE((a->new_stride_b % 8) == 0 && (a->new_stride_h % 8) == 0 && (reinterpret_cast<uintptr_t>(a->new_k) % 16) == 0 &&
                     (reinterpret_cast<uintptr_t>(a->new_v) % 16) == 0,
                 SVK_ERR_LAYOUT, "%s: new_k/new_v rows must be 16-byte aligned", who);
-    SVK_REQUIRE(stage1_variant() == 3, SVK_ERR_VALUE, "%s: the fused store is only built into stage-1 variant 3", who);
+    SVK_REQUIRE(stage1_variant() >= 3, SVK_ERR_VALUE, "%s: the fused store is only built into stage-1 variants 3 and 4", who);
   }
   return SVK_OK;
 }
