@@ -6,6 +6,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "svk_common.hpp"
 
 namespace svk {
@@ -22,7 +24,8 @@ __global__ void __launch_bounds__(512) kivi_stage1_kernel(const SvkKiviDecodeSta
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Hkv = a.num_kv_heads, GS = a.group_size;
-  const int b = blockIdx.y, blk = blockIdx.x;
+  int b, blk;
+  kivi_wg_to_range(b, blk);
   const int n = lane & 15, jq = lane >> 4, dc = lane % DC, tq = lane / DC;
   const int len = a.context_lens[b];
   const int start = blk * a.block_seq;
@@ -303,7 +306,8 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Hkv = a.num_kv_heads;
-  const int b = blockIdx.y, blk = blockIdx.x;
+  int b, blk;
+  kivi_wg_to_range(b, blk);
   const int n = lane & 15, kc = lane >> 4;          // MFMA column / k chunk; kc doubles as accumulator row group
   const int dg = n % DW;                            // V word (8 head dims) of this lane
   unsigned char* wl = lds_raw + w * WAVE_BYTES;
@@ -411,31 +415,76 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     return make_uint4(o[0], o[1], o[2], o[3]);
   };
 
-  for (int t0 = start; t0 < end; t0 += kT) {
-    // ---- classify the 16 groups of 8 tokens (lanes 0..15, one group each)
-    int gb = 0, glt = 0;
-    bool gfast = true;
+  // A tile is processed in passes over disjoint token subsets (the online softmax does not care how the tokens are
+  // partitioned): MODE_FAST = the groups that are 8 aligned tokens of one KIVI block (word loads; lanes of other groups
+  // masked), MODE_RAW = the groups made of raw bf16 rows (slot ids staged in LDS, straight-line vector loads),
+  // MODE_TOKEN = per-token fallback for anything else.  The sink tile of a row (8 raw tokens + 120 quantised ones) used
+  // to take the per-token path as a whole: ~64 us of dependent loads on the critical path of every launch.
+  // The tile body is instantiated twice: HOT = all 16 groups fast (the code of the steady state, nothing else in its
+  // register allocation), and the general form; the driver loop below switches between them.
+  constexpr int MODE_FAST = 0, MODE_RAW = 1, MODE_TOKEN = 2;
+  struct Cls { int gb, glt; bool gfast, graw, gempty; };
+  auto classify = [&](int t0) -> Cls {
+    // the 16 groups of 8 tokens (lanes 0..15, one group each)
+    Cls c{0, 0, true, false, false};
     if (lane < 16) {
       const int tg = t0 + lane * 8;
-      gfast = false;
+      c.gfast = false;
+      c.gempty = tg >= end;
+      int rm[8], bm[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { rm[e] = raw_map[min(tg + e, end - 1)]; bm[e] = blk_map[min(tg + e, end - 1)]; }
+      if (!c.gempty) {
+        c.graw = true;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c.graw = c.graw && (tg + e >= end || rm[e] >= 0);
+      }
       if (tg + 8 <= end) {
-        const int b0 = blk_map[tg];
+        const int b0 = bm[0];
         bool ok = b0 >= 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ok = ok && raw_map[tg + e] < 0 && blk_map[tg + e] == b0;
+        for (int e = 0; e < 8; ++e) ok = ok && rm[e] < 0 && bm[e] == b0;
         if (ok) {
           const int lt0 = tg - a.kivi_block_start_pos[b0];
-          gfast = lt0 >= 0 && (lt0 & 7) == 0 && lt0 + 8 <= GS;
-          gb = b0;
-          glt = lt0;
+          c.gfast = lt0 >= 0 && (lt0 & 7) == 0 && lt0 + 8 <= GS;
+          if (c.gfast) { c.gb = b0; c.glt = lt0; }
         }
       }
     }
-    const bool fast = __all(gfast);
+    return c;
+  };
+  auto tile_body = [&](auto hot_c, int t0, const Cls& cls) __attribute__((always_inline)) {
+    constexpr bool HOT = decltype(hot_c)::value;
+    const int gb = cls.gb, glt = cls.glt;
+    bool split_ok = true, any_fast = true, any_raw = false;
+    if constexpr (!HOT) {
+      split_ok = __all(cls.gfast || cls.graw || cls.gempty);      // every group has a vector path
+      any_fast = __any(lane < 16 && cls.gfast);
+      any_raw = __any(cls.graw);
+    }
+    const int npass = HOT ? 1 : (split_ok ? (int)any_fast + (int)any_raw : 1);
+    for (int pass = 0; pass < npass; ++pass) {
+    const int mode = HOT ? MODE_FAST : (!split_ok ? MODE_TOKEN : ((pass == 0 && any_fast) ? MODE_FAST : MODE_RAW));
+    const bool fast = mode == MODE_FAST;
+    int* slot_lds = reinterpret_cast<int*>(Vs);          // raw pass: the tile's 128 raw slot ids (the V scale rows are idle)
+    if constexpr (!HOT) {
+      if (mode == MODE_RAW) {
+        const int t = t0 + 2 * lane;
+        const int s0 = raw_map[min(t, end - 1)], s1 = raw_map[min(t + 1, end - 1)];
+        // -1 = not part of this pass (past the end, or not a raw row)
+        const bool mine = __shfl((int)cls.graw, lane >> 2, 64) != 0;
+        slot_lds[2 * lane] = (mine && t < end) ? s0 : -1;
+        slot_lds[2 * lane + 1] = (mine && t + 1 < end) ? s1 : -1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
     f32x4_t s[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     unsigned tvmask = 0xffu;                          // bit i: token 8n+i of this lane's column is valid
+    if constexpr (!HOT) tvmask = __shfl((int)cls.gfast, n, 64) ? 0xffu : 0u;      // fast pass of a mixed tile
     uint32_t vsw[NG], vmw[NG];                        // V scale / min words of tokens 2*lane, 2*lane+1 (fast tiles)
     uint32_t vq[2][8];                                // V words of block j (double buffered)
     auto issue_v = [&](int j, uint32_t (&vw8)[8]) {
@@ -510,7 +559,30 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
         SVK_K_MFMA(0) SVK_K_MFMA(1) SVK_K_MFMA(2) SVK_K_MFMA(3) SVK_K_MFMA(4) SVK_K_MFMA(5) SVK_K_MFMA(6) SVK_K_MFMA(7)
 #undef SVK_K_MFMA
       }
-    } else {
+    } else if (!HOT && mode == MODE_RAW) {
+      // raw rows: every row segment of a chunk at once, no per-token branch (invalid tokens read slot 0 and are masked)
+      int sl[8];
+      {
+        const int4 s0 = *reinterpret_cast<const int4*>(slot_lds + 8 * n), s1 = *reinterpret_cast<const int4*>(slot_lds + 8 * n + 4);
+        sl[0] = s0.x; sl[1] = s0.y; sl[2] = s0.z; sl[3] = s0.w; sl[4] = s1.x; sl[5] = s1.y; sl[6] = s1.z; sl[7] = s1.w;
+      }
+      tvmask = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (sl[i] >= 0) tvmask |= 1u << i;
+        sl[i] = max(sl[i], 0);
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        uint4 kr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          kr[i] = *reinterpret_cast<const uint4*>(a.raw_k + (int64_t)sl[i] * a.raw_slot_stride + (int64_t)w * a.raw_head_stride + c * 32 + kc * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, kr[i]), s[i], 0, 0, 0);
+      }
+    } else if (!HOT) {
       tvmask = 0u;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -628,10 +700,19 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
         }
         SVK_V_MFMA(0) SVK_V_MFMA(1) SVK_V_MFMA(2) SVK_V_MFMA(3) SVK_V_MFMA(4) SVK_V_MFMA(5) SVK_V_MFMA(6) SVK_V_MFMA(7)
 #undef SVK_V_MFMA
-      } else {
+      } else if (!HOT) {
         uint4 vr[8];                                  // vr[e] = 8 head dims (i = 0..7) of token 32j + kc*8 + e
+        if (mode == MODE_RAW) {
+          // raw rows straight from the staged slot ids; P is zero for every token outside this pass
+          const int4 s0 = *reinterpret_cast<const int4*>(slot_lds + 32 * j + kc * 8), s1 = *reinterpret_cast<const int4*>(slot_lds + 32 * j + kc * 8 + 4);
+          const int sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vr[e] = token_v(t0 + 32 * j + kc * 8 + e);
+          for (int e = 0; e < 8; ++e)
+            vr[e] = *reinterpret_cast<const uint4*>(a.raw_v + (int64_t)max(sv[e], 0) * a.raw_slot_stride + (int64_t)w * a.raw_head_stride + dg * 8);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vr[e] = token_v(t0 + 32 * j + kc * 8 + e);
+        }
         const uint32_t* vv = reinterpret_cast<const uint32_t*>(vr);        // vv[e*4 + i/2], half i&1
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -647,6 +728,24 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    }   // pass
+  };
+  // driver: general tiles until an all-fast tile shows up, then the hot loop until one is not, and so on
+  {
+    int t0 = start;
+    Cls cls = classify(t0);
+    while (t0 < end) {
+      while (t0 < end && !__all(cls.gfast)) {
+        tile_body(std::false_type{}, t0, cls);
+        t0 += kT;
+        if (t0 < end) cls = classify(t0);
+      }
+      while (t0 < end && __all(cls.gfast)) {
+        tile_body(std::true_type{}, t0, cls);
+        t0 += kT;
+        if (t0 < end) cls = classify(t0);
+      }
+    }
   }
   // ---- epilogue: lane (n, kc) owns heads kc*4+r and head dims dg*8 .. +8
   if (kc < JQ) {
@@ -698,7 +797,8 @@ kivi_stage1_tile128_pf_kernel(const SvkKiviDecodeStage1Args a) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Hkv = a.num_kv_heads;
-  const int b = blockIdx.y, blk = blockIdx.x;
+  int b, blk;
+  kivi_wg_to_range(b, blk);
   const int n = lane & 15, kc = lane >> 4;
   const int dg = n % DW;
   unsigned char* wl = lds_raw + w * WAVE_BYTES;

@@ -78,7 +78,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) k
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int w = blockIdx.z * waves_per_wg + wv;      // KV head of this wave
   const int Hkv = a.num_kv_heads;
-  const int b = blockIdx.y, blk = blockIdx.x;
+  int b, blk;
+  kivi_wg_to_range(b, blk);
   const int n = lane & 15, kc = lane >> 4;
   const int dg = n % DW;
   unsigned char* wl = lds_raw + wv * L::WAVE_BYTES;

@@ -111,4 +111,18 @@ __device__ __forceinline__ float wave_allsum(float x) {
   return x;
 }
 
+
+// Workgroup -> (row lane, range) with the expensive ranges first.  The first range of a row holds the raw sink tokens
+// and the last one the raw tail and the ragged end: their per-token tiles cost 50-100 us of dependent loads and used to
+// start LAST (x-major dispatch), alone on the critical path (B = 4 x 256k: 357 us against 241 us without raw tokens).
+// Dispatched first they run under the bulk of the grid.  Any bijection is valid: the mapping only changes start order.
+__device__ __forceinline__ void kivi_wg_to_range(int& b, int& blk) {
+  const int nblk = gridDim.x, B = gridDim.y;
+  const int id = blockIdx.x + nblk * blockIdx.y;
+  if (nblk < 3) { b = blockIdx.y; blk = blockIdx.x; return; }
+  if (id < B) { b = id; blk = nblk - 1; }
+  else if (id < 2 * B) { b = id - B; blk = 0; }
+  else { const int r = id - 2 * B; b = r / (nblk - 2); blk = 1 + r % (nblk - 2); }
+}
+
 }  // namespace svk

@@ -168,6 +168,27 @@ def test_kivi_stage1_random(Hq, Hkv, D, G, block_seq, with_score, key_f32):
     compare(got, ref, lens, block_seq)
 
 
+@pytest.mark.parametrize("sink,raw_tail,lens,block_seq", [
+    (8, 40, [1500, 777, 136, 8], 512),       # sink tile = 8 raw rows + 120 quantised tokens: fast pass + raw pass
+    (32, 64, [1500, 1181], 256),             # whole raw block in front, 64..95 raw rows behind, ragged ends
+    (0, 0, [1024, 515], 256),                # no raw row at all but a ragged end
+    (4, 21, [700, 300], 128),                # groups not aligned to 8 tokens: the per-token fallback
+    (8, 200, [1000, 420], 1024),             # raw tail longer than a tile: pure raw tiles
+])
+def test_kivi_stage1_tile_passes(sink, raw_tail, lens, block_seq):
+    """Tiles are split into a pass over the 8-aligned quantised groups (word loads), a pass over the raw rows
+    (vector loads) and the per-token fallback; every combination must give the oracle's merged output and scores."""
+    rng = np.random.default_rng(sink * 1000 + raw_tail)
+    Hq, Hkv, D, G = 28, 4, 128, 32
+    B = len(lens)
+    bits, maps, max_len = make_case(rng, B=B, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=lens, rows=B + 1, raw_tail=raw_tail,
+                                     sink=sink, key_f32=True)
+    shape = (B, Hq, max_len)
+    got = run_gpu(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
+    ref = run_oracle(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
+    compare(got, ref, lens, block_seq)
+
+
 def test_kivi_stage1_all_raw_matches_plain_stage1():
     """With no KIVI block the kernel is the ordinary slot-table decode: compare with svk_flash_decode_stage1.
     The two kernels tile the row differently (128 vs 32 tokens per online-softmax step), so P is rounded to bf16

@@ -22,9 +22,11 @@ def main():
     ap.add_argument("--block-seqs", default="256,512,1024")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--score", action="store_true")
+    ap.add_argument("--sink", type=int, default=8)
+    ap.add_argument("--tail", type=int, default=48)
     args = ap.parse_args()
     d = torch.device("cuda:0")
-    Hq, Hkv, D, G, sink, tail = 28, 4, 128, 32, 8, 48
+    Hq, Hkv, D, G, sink, tail = 28, 4, 128, 32, args.sink, args.tail
     torch.manual_seed(1)
     for B in [int(x) for x in args.batches.split(",")]:
         L = args.ctx
