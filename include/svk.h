@@ -190,6 +190,14 @@ typedef struct SvkH2oDecodeFinishArgs {
 } SvkH2oDecodeFinishArgs;
 int svk_h2o_decode_finish(const SvkH2oDecodeFinishArgs* a, svk_stream_t stream);
 
+/* svk_flash_decode_stage1 of layer l+1 with svk_h2o_decode_score_update of layer l (`prev`) in the SAME launch: the
+ * score epilogue of a layer has no consumer before the step's eviction check (sparse_controller.py:1226-1282), so it
+ * need not sit between two layers as a latency-bound launch of its own; B extra workgroups do it under the streaming
+ * workgroups of the next layer.  Same results as the two calls (prev == NULL: plain stage 1).  Kernels that cannot
+ * carry the rows (stage-1 variants other than 3) run the two launches back to back. */
+int svk_flash_decode_stage1_deferred(const SvkFlashDecodeStage1Args* a, const SvkH2oDecodeScoreArgs* prev,
+                                     svk_stream_t stream);
+
 /* One launch for a whole H2O decode layer: svk_flash_decode_stage1 (score_mode HEADMAX) + svk_h2o_decode_finish.  Every
  * workgroup of a batch lane takes a ticket after publishing its partials / token scores; the last one merges the lane's
  * split-KV partials into `o` and normalises + accumulates its token scores.  `tickets` is a caller-owned int32 [B]

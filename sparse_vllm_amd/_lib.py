@@ -261,6 +261,7 @@ ENTRY_POINTS = {
     "svk_h2o_decode_score_update": ([C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
     "svk_h2o_decode_fused": ([C.POINTER(SvkH2oDecodeFusedArgs), _p], C.c_int),
     "svk_h2o_decode_finish": ([C.POINTER(SvkH2oDecodeFinishArgs), _p], C.c_int),
+    "svk_flash_decode_stage1_deferred": ([C.POINTER(SvkFlashDecodeStage1Args), C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
     "svk_h2o_select_indices": ([C.POINTER(SvkH2oSelectArgs), _p], C.c_int),
     "svk_select_prefix_topk_suffix": ([C.POINTER(SvkSelectTopkArgs), _p], C.c_int),
     "svk_compact_rows": ([C.POINTER(SvkCompactRowsArgs), _p], C.c_int),

@@ -789,6 +789,61 @@ __device__ __forceinline__ void fused_row_finish(const SvkFlashDecodeStage1Args&
   }
 }
 
+// One token-score row of the PREVIOUS layer inside this layer's stage-1 launch (svk_flash_decode_stage1_deferred):
+// x *= scale; softmax over the full width; cum = pad(prev, 1) + p (sparse_controller.py:762-767, h2o.py:957-1038) - the
+// arithmetic of h2o_decode_score_kernel, row held in registers when it fits.
+__device__ __forceinline__ void deferred_score_row(const SvkH2oDecodeScoreArgs& fs, int b, float* red) {
+  float* x = fs.attn_score + (int64_t)b * fs.score_stride_b;
+  const int W = fs.width;
+  const int nt = blockDim.x;
+  float* cum = nullptr;
+  int len = 0;
+  if (fs.cum_score != nullptr && !(fs.b_new_slot != nullptr && fs.b_new_slot[b] < 0)) {   // padded graph lanes: no update
+    cum = fs.cum_score + (int64_t)fs.b_req_idx[b] * fs.cum_stride;
+    len = fs.b_seqlen[b];
+  }
+  if (W <= 32 * nt) {
+    float v[32], c[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int t = threadIdx.x + i * nt;
+      v[i] = t < W ? mul_rn(x[t], fs.scale) : -INFINITY;
+      c[i] = (cum != nullptr && t < len - 1) ? cum[t] : 0.f;
+      mx = fmaxf(mx, v[i]);
+    }
+    mx = block_allmax(mx, red);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      v[i] = expf(v[i] - mx);
+      sum += v[i];
+    }
+    sum = block_allsum(sum, red);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int t = threadIdx.x + i * nt;
+      if (t < W) {
+        const float p = v[i] / sum;
+        x[t] = p;
+        if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : c[i] + p;
+      }
+    }
+    return;
+  }
+  float mx = -INFINITY;
+  for (int t = threadIdx.x; t < W; t += nt) mx = fmaxf(mx, mul_rn(x[t], fs.scale));
+  mx = block_allmax(mx, red);
+  float sum = 0.f;
+  for (int t = threadIdx.x; t < W; t += nt) sum += expf(mul_rn(x[t], fs.scale) - mx);
+  sum = block_allsum(sum, red);
+  for (int t = threadIdx.x; t < W; t += nt) {
+    const float p = expf(mul_rn(x[t], fs.scale) - mx) / sum;
+    x[t] = p;
+    if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : cum[t] + p;
+  }
+}
+
 template <int D, int G, int MODE, bool NTV, bool OFF32, bool FUSED>
 __global__ void __launch_bounds__(512)
 decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a, const SvkH2oDecodeScoreArgs fs, uint16_t* fo, int64_t fo_stride_b,
@@ -799,6 +854,15 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a, const SvkH2oDecodeScor
   constexpr int DW = D / 8;                       // 16-byte segments per head row
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
+  if constexpr (!FUSED) {
+    // grid rows >= batch: the deferred score epilogue of the previous layer (one workgroup per row, the others of that
+    // grid row leave at once).  It rides with this launch's 256+ streaming workgroups instead of having its own
+    // latency-bound launch between two layers.
+    if ((int)blockIdx.y >= a.batch) {
+      if (blockIdx.x == 0) deferred_score_row(fs, (int)blockIdx.y - a.batch, lds);
+      return;
+    }
+  }
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Hkv = a.num_kv_heads;
@@ -1185,10 +1249,16 @@ bool launch_stage1_v4(const SvkFlashDecodeStage1Args& a, dim3 grid, dim3 block, 
 }
 
 template <int D, int G>
-int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
+int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream, const SvkH2oDecodeScoreArgs* deferred = nullptr) {
   using C = Stage1Cfg<D, G>;
   const int nblk = (a.max_len_in_batch + a.block_seq - 1) / a.block_seq;
-  dim3 grid(nblk, a.batch);
+  const bool carry = deferred != nullptr && stage1_variant() == 3;     // only v3 carries the deferred rows
+  if (deferred != nullptr && !carry) {
+    const int rc = svk_h2o_decode_score_update(deferred, stream);
+    if (rc != SVK_OK) return rc;
+  }
+  dim3 grid(nblk, a.batch + (carry ? deferred->batch : 0));
+  const SvkH2oDecodeScoreArgs dfs = carry ? *deferred : SvkH2oDecodeScoreArgs{};
   dim3 block(64 * a.num_kv_heads);
   const size_t score_floats = a.score_mode == SVK_SCORE_HEADMAX ? (size_t)kScoreChunk * a.num_kv_heads * C::JQ : 0;
   const size_t shm3 = sizeof(float) * ((size_t)a.num_kv_heads * Stage1V3Lds<D, G>::WAVE_FLOATS + score_floats);
@@ -1226,8 +1296,8 @@ int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
   }
 #define SVK_LAUNCH_V3(MODE_)                                                                                      \
   do {                                                                                                            \
-    if (off32) hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, true, false>), grid, block, shm3, stream, a, SvkH2oDecodeScoreArgs{}, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int32_t*)nullptr);  \
-    else hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, false, false>), grid, block, shm3, stream, a, SvkH2oDecodeScoreArgs{}, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int32_t*)nullptr);       \
+    if (off32) hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, true, false>), grid, block, shm3, stream, a, dfs, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int32_t*)nullptr);  \
+    else hipLaunchKernelGGL((decode_stage1_kernel_v3<D, G, MODE_, true, false, false>), grid, block, shm3, stream, a, dfs, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int32_t*)nullptr);       \
   } while (0)
   if (a.score_mode == SVK_SCORE_HEADMAX) SVK_LAUNCH_V3(SVK_SCORE_HEADMAX);
   else if (a.score_mode == SVK_SCORE_PERHEAD) SVK_LAUNCH_V3(SVK_SCORE_PERHEAD);
@@ -1267,16 +1337,16 @@ int dispatch_fused(const SvkH2oDecodeFusedArgs& f, int G, hipStream_t stream) {
 }
 
 template <int D>
-int dispatch_group(const SvkFlashDecodeStage1Args& a, int G, hipStream_t stream) {
+int dispatch_group(const SvkFlashDecodeStage1Args& a, int G, hipStream_t stream, const SvkH2oDecodeScoreArgs* deferred = nullptr) {
   switch (G) {
-    case 1: return launch_stage1<D, 1>(a, stream);
-    case 2: return launch_stage1<D, 2>(a, stream);
-    case 3: return launch_stage1<D, 3>(a, stream);
-    case 4: return launch_stage1<D, 4>(a, stream);
-    case 5: return launch_stage1<D, 5>(a, stream);
-    case 6: return launch_stage1<D, 6>(a, stream);
-    case 7: return launch_stage1<D, 7>(a, stream);
-    case 8: return launch_stage1<D, 8>(a, stream);
+    case 1: return launch_stage1<D, 1>(a, stream, deferred);
+    case 2: return launch_stage1<D, 2>(a, stream, deferred);
+    case 3: return launch_stage1<D, 3>(a, stream, deferred);
+    case 4: return launch_stage1<D, 4>(a, stream, deferred);
+    case 5: return launch_stage1<D, 5>(a, stream, deferred);
+    case 6: return launch_stage1<D, 6>(a, stream, deferred);
+    case 7: return launch_stage1<D, 7>(a, stream, deferred);
+    case 8: return launch_stage1<D, 8>(a, stream, deferred);
     default:
       set_error("svk_flash_decode_stage1: GQA group size %d unsupported (1..8)", G);
       return SVK_ERR_LAYOUT;
@@ -1323,6 +1393,21 @@ extern "C" int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_st
   const int G = a->num_q_heads / a->num_kv_heads;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return a->head_dim == 128 ? dispatch_group<128>(*a, G, s) : dispatch_group<64>(*a, G, s);
+}
+
+extern "C" int svk_flash_decode_stage1_deferred(const SvkFlashDecodeStage1Args* a, const SvkH2oDecodeScoreArgs* prev,
+                                                svk_stream_t stream) {
+  using namespace svk;
+  if (prev == nullptr || prev->batch <= 0) return svk_flash_decode_stage1(a, stream);
+  const int rc = validate_stage1(a, "svk_flash_decode_stage1_deferred");
+  if (rc != SVK_OK) return rc;
+  SVK_REQUIRE(prev->attn_score != nullptr && prev->width > 0, SVK_ERR_VALUE, "svk_flash_decode_stage1_deferred: bad score args");
+  SVK_REQUIRE(prev->cum_score == nullptr || (prev->b_req_idx != nullptr && prev->b_seqlen != nullptr), SVK_ERR_VALUE,
+              "svk_flash_decode_stage1_deferred: cum_score needs b_req_idx and b_seqlen");
+  if (a->batch <= 0 || a->max_len_in_batch <= 0) return svk_h2o_decode_score_update(prev, stream);
+  const int G = a->num_q_heads / a->num_kv_heads;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return a->head_dim == 128 ? dispatch_group<128>(*a, G, s, prev) : dispatch_group<64>(*a, G, s, prev);
 }
 
 extern "C" int svk_h2o_decode_fused(const SvkH2oDecodeFusedArgs* f, svk_stream_t stream) {

@@ -8,11 +8,13 @@ kernels).  Call order (fixed by ModelRunner.run, model_runner.py:1447-1481):
 
 from __future__ import annotations
 
+import ctypes as C
 import os
 from dataclasses import dataclass
 
 import torch
 
+from .. import _lib
 from ..kernels import deltakv_kernels, h2o_ops
 from ..method_registry import normalize_sparse_method
 from ..utils.context import get_context
@@ -59,6 +61,11 @@ class SparseController:
         self._h2o_score_stream_enabled = os.environ.get("SVK_H2O_SCORE_STREAM", "0") == "1"
         self._h2o_score_stream = None
         self._h2o_score_stream_used = False
+        # MI355X: a layer's score epilogue (scale + softmax + accumulate) rides in the NEXT layer's stage-1 launch
+        # (svk_flash_decode_stage1_deferred) instead of sitting between two layers as a latency-bound launch of its own;
+        # the last layer's is flushed at the end of the layer loop (`join_side_streams`) / before the eviction check
+        self._defer_h2o_score = os.environ.get("SVK_H2O_DEFER_SCORE", "1") == "1"
+        self._deferred_score = None          # (SvkH2oDecodeScoreArgs, keep-alive tensors)
         self.is_deltakv_family = self.sparse_method == "deltakv"
         self.obs_layer_ids = list(getattr(config, "obs_layer_ids", None) or [])
         self.full_attn_layers = list(getattr(config, "full_attn_layers", None) or [])
@@ -262,10 +269,33 @@ class SparseController:
             return False
         cm = self.cache_manager
         cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
+        if self._defer_h2o_score:
+            from ..kernels.flash_decoding_stage2 import flash_decode_stage2
+            from ..kernels.gqa_flash_decoding_stage1 import h2o_score_args
+            self.flush_deferred_score()              # at most one layer is ever pending
+            flash_decode_stage2(mid_o, mid_lse, context_lens, o, block_seq)
+            new_slots = self._h2o_new_slots(layer_idx)
+            self._deferred_score = (h2o_score_args(s.attn_score, self.attn_softmax_scale, cum_score=cum,
+                                                   b_req_idx=s.req_indices, b_seqlen=context_lens, b_new_slot=new_slots),
+                                    (s.attn_score, cum, s.req_indices, context_lens, new_slots))
+            self._layer_score_finished[layer_idx] = True
+            return True
         h2o_ops.h2o_decode_finish(mid_o, mid_lse, context_lens, o, block_seq, s.attn_score, self.attn_softmax_scale,
                                   cum_score=cum, b_req_idx=s.req_indices, b_new_slot=self._h2o_new_slots(layer_idx))
         self._layer_score_finished[layer_idx] = True
         return True
+
+    def take_deferred_score(self):
+        """The previous layer's pending score epilogue, for the stage-1 launch that is about to be issued."""
+        pending, self._deferred_score = self._deferred_score, None
+        return None if pending is None else pending[0]
+
+    def flush_deferred_score(self):
+        """Run a still pending score epilogue on its own (last layer of the step; callers that do not carry it)."""
+        pending, self._deferred_score = self._deferred_score, None
+        if pending is not None:
+            lib = _lib.load()
+            _lib.check(lib.svk_h2o_decode_score_update(C.byref(pending[0]), _lib.current_stream_handle()), lib)
 
     @torch.no_grad()
     def on_layer_attention_end(self, layer_idx: int):
@@ -304,7 +334,8 @@ class SparseController:
 
     def join_side_streams(self):
         """Make the current stream wait for the side-stream score epilogues of this step (end of the layer loop,
-        inside graph capture when the step is captured)."""
+        inside graph capture when the step is captured) and issue the last layer's deferred score epilogue."""
+        self.flush_deferred_score()
         if self._h2o_score_stream_used:
             torch.cuda.current_stream().wait_stream(self._h2o_score_stream)
             self._h2o_score_stream_used = False
@@ -457,6 +488,7 @@ class SparseController:
 
     def _h2o_decode_eviction(self, seqs):
         """sparse_controller.py:1226-1282: scores are already accumulated (fused), evict."""
+        self.flush_deferred_score()
         with profiler.record("h2o_decode_eviction"):
             if not self._fused_h2o_accumulate:
                 layer_indices = self._h2o_kv_layer_indices()

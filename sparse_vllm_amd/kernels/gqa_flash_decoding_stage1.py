@@ -80,11 +80,27 @@ def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, 
         max_len_in_batch=int(max_len_in_batch), block_seq=int(block_seq), score_mode=mode, **store)
 
 
+def h2o_score_args(attn_score, scale, *, cum_score=None, b_req_idx=None, b_seqlen=None, b_new_slot=None):
+    """SvkH2oDecodeScoreArgs of one layer's score epilogue (what `h2o_ops.h2o_decode_score_update` would launch)."""
+    assert attn_score.dim() == 2 and attn_score.dtype == torch.float32 and attn_score.stride(1) == 1
+    if cum_score is not None:
+        assert cum_score.dim() == 2 and cum_score.dtype == torch.float32 and cum_score.stride(1) == 1
+        assert b_req_idx is not None and b_seqlen is not None
+    return _lib.SvkH2oDecodeScoreArgs(
+        attn_score=_lib.ptr(attn_score), cum_score=_lib.ptr(cum_score), b_req_idx=_lib.ptr(b_req_idx),
+        b_seqlen=_lib.ptr(b_seqlen), b_new_slot=_lib.ptr(b_new_slot), score_stride_b=attn_score.stride(0),
+        cum_stride=0 if cum_score is None else cum_score.stride(0), scale=float(scale),
+        batch=attn_score.shape[0], width=attn_score.shape[1])
+
+
 def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv=None):
+            attn_score, block_seq, new_kv=None, deferred_score=None):
     a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
                      attn_score, block_seq, new_kv)
     lib = _lib.load()
+    if deferred_score is not None:
+        _lib.check(lib.svk_flash_decode_stage1_deferred(C.byref(a), C.byref(deferred_score), _lib.current_stream_handle()), lib)
+        return
     _lib.check(lib.svk_flash_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
 
 
@@ -129,6 +145,8 @@ def flash_decode_stage1(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_
 
 @torch.no_grad()
 def flash_decode_stage1_with_score(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
-                                   mid_out_logsumexp, attn_score, block_seq, *, new_kv=None):
+                                   mid_out_logsumexp, attn_score, block_seq, *, new_kv=None, deferred_score=None):
+    """`deferred_score` (MI355X extension, `h2o_score_args(...)` of the PREVIOUS layer): its score epilogue runs inside
+    this launch (svk_flash_decode_stage1_deferred)."""
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv)
+            attn_score, block_seq, new_kv, deferred_score)

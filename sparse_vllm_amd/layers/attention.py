@@ -40,7 +40,8 @@ class HipAttentionBackend:
 
     def run_decode(self, q: torch.Tensor, view: DecodeComputeView, *, mid_o, mid_o_logexpsum, max_len_in_batch: int,
                    block_seq: int, num_heads: int, num_kv_heads: int, gqa_block_n: int = 16,
-                   gqa_num_warps: int = 2, fused_finish=None, fused_layer=None, new_kv=None) -> torch.Tensor:
+                   gqa_num_warps: int = 2, fused_finish=None, fused_layer=None, new_kv=None,
+                   take_deferred_score=None) -> torch.Tensor:
         payload = view.payload
         if not isinstance(payload, ExplicitKVPayload):
             raise TypeError(f"HIP decode requires ExplicitKVPayload, got {type(payload).__name__}.")
@@ -76,9 +77,11 @@ class HipAttentionBackend:
                     return o
         with profiler.record(f"decode_attention_stage1_{kind}"):
             if meta.attn_score is not None:
+                # a sparse controller may hand over the previous layer's score epilogue to ride in this launch
+                deferred = take_deferred_score() if take_deferred_score is not None else None
                 flash_decode_stage1_with_score(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                                meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum,
-                                               meta.attn_score, block_seq, new_kv=new_kv)
+                                               meta.attn_score, block_seq, new_kv=new_kv, deferred_score=deferred)
             else:
                 flash_decode_stage1(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                     meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum, block_seq,
@@ -170,7 +173,7 @@ class Attention(torch.nn.Module):
                 gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps,
                 fused_finish=None if finish is None else (lambda *a, _l=layer_idx: finish(_l, *a)),
                 fused_layer=None if layer_fn is None else (lambda *a, _l=layer_idx: layer_fn(_l, *a)),
-                new_kv=new_kv)
+                new_kv=new_kv, take_deferred_score=getattr(sparse_controller, "take_deferred_score", None))
             cache_manager.record_decode_query(layer_idx, q)
             sparse_controller.on_layer_attention_end(layer_idx)
             cache_manager.on_layer_attention_end(layer_idx)
