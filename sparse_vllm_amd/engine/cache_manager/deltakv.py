@@ -22,8 +22,9 @@ temp slots -> contiguous attention view (raw K rotated on the way) -> ordinary s
 
 Compression side: `deltakv_evict` compresses `recent` tokens of a row's raw tail every `recent`
 decode steps (centres, causal L2 top-k fathers, compress_down residual, int4 pack) and `_full_layer_kivi_evict` moves
-full-layer rows that left the residual window into KIVI blocks.  Prompts are still ingested already compressed
-(`admit_compressed_row`): the prefill-time bulk compression is SURVEY section 8(f).3.
+full-layer rows that left the residual window into KIVI blocks.  Prompts arrive either already compressed
+(`admit_compressed_row`, synthetic benchmarks) or raw through `_prepare_prefill` + the store hooks, after which the same
+`deltakv_evict` / KIVI eviction compress the chunk in bulk.
 """
 
 from __future__ import annotations
@@ -182,6 +183,11 @@ class DeltaKVCacheManager(CacheManager):
         return max(recent + 1, 2 * recent)
 
     # ------------------------------------------------------------------ storage
+    def _prefill_staging_tokens(self) -> int:
+        """Raw slots one prefill chunk needs before `deltakv_evict` / the KIVI eviction compress it (the reference
+        stages a chunk the same way, deltakv_less_memory.py `_deltakv_full_prefill_*`): one chunk in flight."""
+        return int(getattr(self.config, "chunk_prefill_size", 0) or 0)
+
     def allocate_kv_cache(self):
         """deltakv_less_memory.py:940-1190 (explicit sizes; 0 = derive a synthetic-workload default)."""
         cfg, d = self.config, self.device
@@ -193,11 +199,13 @@ class DeltaKVCacheManager(CacheManager):
         if n_sparse <= 0:
             step = max(1, int(1.0 / max(1e-6, float(cfg.cluster_ratio))))
             centers = -(-L // max(1, recent)) * -(-max(1, recent) // step)      # range(start, end, step) per evicted block
-            n_sparse = rows * (sink + 2 * recent + 1 + centers + keep) + 64
+            n_sparse = rows * (sink + 2 * recent + 1 + centers + keep) + 64 + self._prefill_staging_tokens()
         n_latent = int(cfg.deltakv_num_latent_slots or 0) or rows * L
         n_full = int(cfg.deltakv_num_full_layer_slots or 0)
         if n_full <= 0:
             n_full = rows * ((sink + int(cfg.full_layer_kivi_residual_length) + 2 * G + 1) if kivi else L) + 64
+            if kivi:
+                n_full += self._prefill_staging_tokens()
         n_blocks = int(cfg.deltakv_num_kivi_blocks or 0) or (rows * (L // G + 1) if kivi else 0)
         self.deltakv_full_num_slots, self.deltakv_latent_num_slots = n_sparse, n_latent
         self.full_num_slots, self.full_layer_kivi_num_blocks = n_full, n_blocks
@@ -329,9 +337,47 @@ class DeltaKVCacheManager(CacheManager):
     def free_part_slots(self, layer_idx: int, seq, keep_indices, *, keep_indices_sorted: bool = False):
         raise ValueError("DeltaKV does not evict through free_part_slots; it compresses the raw tail (deltakv_evict).")
 
+    @torch.no_grad()
     def _prepare_prefill(self, seqs):
-        raise NotImplementedError("DeltaKV prefill + compression is SURVEY section 8(f).3; ingest rows with "
-                                  "admit_compressed_row().")
+        """One prompt chunk per sequence appended RAW on both layer kinds (deltakv_base.py:1881-2036): every token gets a
+        full-layer slot and a sparse-layer slot; `SparseController.post_forward` -> `deltakv_evict` then compresses
+        whole multiples of `recent` of the raw tail in one go and the KIVI eviction quantises the full-layer groups
+        that left the residual window - the prompt's compressed state is produced by the same operators as in decode.
+        -> (cu_seqlens_q int32 [B + 1], total tokens)"""
+        self._deltakv_reset_view_cache()
+        d = self.device
+        chunk_lens = [int(s.current_chunk_size) for s in seqs]
+        rows, ctx, full_parts, sparse_parts = [], [], [], []
+        for s, n in zip(seqs, chunk_lens):
+            row = self._get_free_row(s.seq_id)
+            cur = int(self.row_seq_lens[row])
+            if n <= 0:
+                raise ValueError(f"DeltaKV prefill chunk must be positive, got {n} for seq_id={s.seq_id}.")
+            if cur + n > self.max_model_len:
+                raise RuntimeError(f"KV row length exceeds max_model_len in DeltaKV prefill: cur_len={cur} chunk={n} "
+                                   f"max_model_len={self.max_model_len}")
+            fs, ss = self._pool_full.pop(n), self._pool_sparse.pop(n)
+            fs_gpu, ss_gpu = torch.from_numpy(fs).to(d), torch.from_numpy(ss).to(d)
+            pos = torch.arange(cur, cur + n, dtype=torch.int32, device=d)
+            self.full_layer_slots_map[row, cur: cur + n] = fs_gpu
+            self.full_layer_slot_to_pos[fs_gpu.long()] = pos
+            self.sparse_layer_raw_slots_map[row, cur: cur + n] = ss_gpu
+            self.deltakv_slot_to_pos[ss_gpu.long()] = pos
+            self.row_seq_lens[row] = cur + n
+            rows.append(row)
+            ctx.append(cur + n)
+            full_parts.append(fs_gpu)
+            sparse_parts.append(ss_gpu)
+        context_lens = torch.tensor(ctx, dtype=torch.int32, device=d)
+        req_indices = torch.tensor(rows, dtype=torch.int32, device=d)
+        for state, parts in ((self.full_layer_batch_states, full_parts), (self.deltakv_layer_batch_states, sparse_parts)):
+            state.slot_mapping = torch.cat(parts)
+            state.context_lens, state.req_indices = context_lens, req_indices
+            state.max_context_len = max(ctx)
+        self._deltakv_decode_static_slot_mapping = None
+        self._deltakv_decode_static_compressed_lens = None
+        cu = np.concatenate(([0], np.cumsum(chunk_lens))).astype(np.int32)
+        return torch.from_numpy(cu).to(d), int(sum(chunk_lens))
 
     def _prepare_decode(self, seqs):
         return self.prepare_decode_static(seqs)

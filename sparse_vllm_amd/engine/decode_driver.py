@@ -253,8 +253,11 @@ class SparseDecodeDriver:
         ctx.max_chunk_len = max(int(s.current_chunk_size) for s in seqs)
         sc.prepare_forward(seqs, True)
         collect = getattr(cm, "collect_prefill_attention_score", None)
+        save_raw = getattr(cm, "save_raw_kv_if_needed", None)
         for layer_idx in range(cm.num_layers):
             ctx.now_layer_idx = layer_idx
+            if save_raw is not None:          # DeltaKV sparse layers keep the pre-RoPE key
+                save_raw(layer_idx, k[layer_idx], v[layer_idx])
             cm.save_rope_kv_if_needed(layer_idx, k[layer_idx], v[layer_idx])
             if outputs is not None:
                 outputs[layer_idx].copy_(self.attn(q[layer_idx]))

@@ -410,6 +410,11 @@ class SparseController:
                 self._streamingllm_prefill_eviction(seqs)
             elif self.sparse_method == "snapkv":
                 self._snapkv_prefill_eviction(seqs)
+            elif self.is_deltakv_family:
+                # sparse_controller.py:857-866 (on_every_chunk_prefill_end): compress the chunk's raw tail in bulk
+                evict = getattr(self.cache_manager, "deltakv_evict", None)
+                if evict is not None:
+                    evict(seqs)
             return
         if self.sparse_method == "h2o":
             self._h2o_decode_eviction(seqs)
