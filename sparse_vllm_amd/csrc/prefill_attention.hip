@@ -11,6 +11,7 @@
 //           B-operand token order and MFMA i takes head dim n*8+i as its column (byte permutes), so a lane's
 //           accumulator is 8 consecutive head dims of 4 query rows -> 16-byte bf16 output stores.
 
+#include <stdlib.h>
 #include <type_traits>
 
 #include "svk_common.hpp"
@@ -231,6 +232,249 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Second generation: the key / value tile is staged ONCE per workgroup in LDS and shared by the G query-head waves
+// (the kernel above lets every wave fetch the whole tile itself: G x the L1 requests, one tile of prefetch).
+//   * tile = 64 keys; K rows land in LDS with their 16-byte chunks XOR-swizzled by the key index, so the A-operand
+//     reads of Q.K^T (lane = key row, stride 256 B) are conflict-free; V rows are stored as they are;
+//   * Q.K^T is computed SWAPPED on v_mfma_f32_32x32x16_bf16: A = K (32 keys x 16 dims), B = Q^T, so that a lane's 16
+//     accumulator registers are 16 keys of ONE query row: the row maximum / sum are in-lane reductions plus one
+//     exchange with the lane that holds the other 16 keys (lane ^ 32), no DPP ladders, and P never leaves the
+//     registers: the 8 accumulator registers [8s, 8s+8) ARE the A operand of P.V step s once packed to bf16 (the k
+//     index of that product is free as long as V is read in the same key order);
+//   * P.V: B = V with MFMA column n <-> head dim (n & 15) * 8 + 2i + (n >> 4) (i = which of the four 32-column MFMAs),
+//     so a lane reads eight 16-byte row segments from LDS and picks one bf16 of each with a byte permute (lane-dependent
+//     selector) - no transposed copy of V;
+//   * the per-row rescale factor lives in "lane = query row" layout while the output accumulator has its query rows in
+//     registers: it crosses through a 128-byte per-wave LDS row only when some row maximum moved.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+constexpr int kKV2 = 64;                 // keys per tile
+constexpr int kRowB = 256;               // bytes of one K or V head row (D = 128)
+
+__device__ __forceinline__ float lane_xor32(float x) {
+  // the value of lane ^ 32 (the other half of the 32x32 accumulator's row split)
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((int)(threadIdx.x & 63) ^ 32) << 2, __builtin_bit_cast(int, x)));
+}
+
+// 16 bytes per lane HBM/L2 -> LDS (wave-uniform base + 16 * lane), hidden from hipcc: with the builtin the compiler drains
+// vmcnt(0) in front of every ds_read of the written region and the double buffer would buy nothing.  M0 is saved and
+// restored inside the statement (it is compiler-reserved).
+__device__ __forceinline__ void pa_dma16(const void* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+
+template <bool OFF32>
+__global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkContextAttentionArgs a) {
+  constexpr int D = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = a.num_q_heads / a.num_kv_heads;
+  const int b = blockIdx.z, kvh = blockIdx.y;
+  const int head = kvh * G + w;
+  const int lq = lane & 31, half = lane >> 5;
+  const int pc = a.b_prompt_cache_len[b];
+  const int q_len = a.b_seq_len[b] - pc;
+  const int m0 = blockIdx.x * kQTile;
+  if (m0 >= q_len) return;
+  const int start_loc = a.b_start_loc[b];
+  const int kv_end = min(m0 + kQTile + pc, q_len + pc);
+  // LDS: two tile buffers of (K | V) (the epilogue reuses this part as per-wave output staging, G x 8 KiB) |
+  //      2 x 64 slot ids | per-wave 32-float rows (rescale factors / 1 / row sum)
+  constexpr int kBuf = 2 * kKV2 * kRowB;             // one (K | V) tile
+  const int aux0 = max(2 * kBuf, G * kQTile * D * 2);
+  int* slot_lds = reinterpret_cast<int*>(lds_raw + aux0);
+  float* fac = reinterpret_cast<float*>(slot_lds + 2 * kKV2) + w * 32;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw);
+  const int32_t* row = a.req_to_tokens + (int64_t)a.b_req_idx[b] * a.req_stride;
+
+  // Q^T fragments (B operand): lane (q = lq, half) holds Q[m0 + q][head][ds*16 + half*8 .. +8]
+  bf16x8_t qb[D / 16];
+  {
+    const uint16_t* qp = a.q + (int64_t)(start_loc + min(m0 + lq, q_len - 1)) * a.q_stride_t + (int64_t)head * a.q_stride_h + half * 8;
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) qb[ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qp + ds * 16));
+  }
+  const float sm_scale = rsqrtf((float)D) * 1.4426950408889634f;
+  const float mask_raw = -1.0e8f / sm_scale;
+  float m_run = -INFINITY, l_part = 0.f;            // of query row lq (both halves keep the same maximum)
+  f32x16_t o[4];                                    // o[i][r]: query row (r&3) + 8(r>>2) + 4 half, head dim (lq&15)*8 + 2i + (lq>>4)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  const char* const kt = reinterpret_cast<const char*>(a.k_cache);
+  const char* const vt = reinterpret_cast<const char*>(a.v_cache);
+  const int64_t slot_bytes = a.kv_slot_stride * 2;
+  const int64_t head_bytes = (int64_t)kvh * a.kv_head_stride * 2;
+  const uint32_t vsel = (lq >> 4) ? 0x07060302u : 0x05040100u;
+  const int qrow = m0 + lq;
+
+  // ---- pipeline: while tile t is computed out of buffer t & 1, the DMA of tile t+1 fills the other buffer and the slot
+  //      ids of tile t+2 travel to a register; ONE wait (vmcnt(0): this wave's DMA pieces and id load) + ONE workgroup
+  //      barrier per tile.  The 32 DMA instructions of a tile (16 x 4 K rows, 16 x 4 V rows) are dealt round-robin to the
+  //      G waves.  K chunks are swizzled on the SOURCE address (position p of row `key` holds chunk p ^ (key & 15)).
+  const int ntiles = (kv_end + kKV2 - 1) / kKV2;
+  auto issue_tile = [&](int t) {
+    const int* ids = slot_lds + (t & 1) * kKV2;
+    for (int j = w; j < 32; j += G) {
+      const int is_v = j >> 4, jj = j & 15;
+      const int key = jj * 4 + (lane >> 4);
+      const int chunk = is_v ? (lane & 15) : ((lane & 15) ^ (key & 15));
+      const int slot = ids[key];
+      const char* src = (is_v ? vt : kt) + (OFF32 ? (int64_t)((uint32_t)slot * (uint32_t)slot_bytes) : (int64_t)slot * slot_bytes) +
+                        head_bytes + chunk * 16;
+      pa_dma16(src, lds0 + (t & 1) * kBuf + is_v * (kKV2 * kRowB) + jj * 1024);
+    }
+  };
+  // slot ids of tile t: 64 x 4 bytes by LDS-DMA as well (wave 0), straight into the id buffer t & 1 - no register in flight
+  auto issue_ids = [&](int t) {
+    if (w == 0) {
+      const int32_t* p = row + min(t * kKV2 + lane, kv_end - 1);
+      uint32_t keep;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)(slot_lds + (t & 1) * kKV2));
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+    }
+  };
+  issue_ids(0);
+  issue_ids(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  issue_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int ds = 0; ds < D / 16; ++ds) asm volatile("" : "+v"(qb[ds]));
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * kKV2;
+    const unsigned char* Kt = lds_raw + (t & 1) * kBuf;
+    const unsigned char* Vt = Kt + kKV2 * kRowB;
+    if (t + 1 < ntiles) issue_tile(t + 1);
+    if (t + 2 < ntiles) issue_ids(t + 2);            // into the id buffer of tile t, which nobody reads any more
+    // ---- S^T = K Q^T: two key blocks of 32, K = 128 in 8 steps
+    f32x16_t s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      const unsigned char* krow = Kt + (kb * 32 + lq) * kRowB;
+#pragma unroll
+      for (int ds = 0; ds < D / 16; ++ds) {
+        const uint4 ka = *reinterpret_cast<const uint4*>(krow + (((ds * 2 + half) ^ (lq & 15)) << 4));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka), qb[ds], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- mask + base-2 online softmax of query row lq (register r of block kb = key k0 + kb*32 + (r&3) + 8(r>>2) + 4 half)
+    const bool diag = k0 + kKV2 > m0 + pc || k0 + kKV2 > kv_end;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (diag) {
+          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (!(key <= qrow + pc && key < kv_end)) s[kb][r] = mask_raw;
+        }
+        mx = vmax(mx, s[kb][r]);
+      }
+    mx = vmax(mx, lane_xor32(mx));
+    const float nm = vmax(m_run, mx);
+    const float nms = nm * sm_scale;
+    const bool moved = nm != m_run;
+    const float al = moved ? __builtin_amdgcn_exp2f(m_run * sm_scale - nms) : 1.0f;
+    m_run = nm;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sm_scale, -nms));
+        psum += s[kb][r];
+      }
+    l_part = l_part * al + psum;
+    if (__any(moved)) {
+      // rescale factors: "lane = query row" -> "register = query row" through the wave's LDS row
+      if (half == 0) fac[lq] = al;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 f4 = *reinterpret_cast<const float4*>(fac + 8 * j + 4 * half);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i][4 * j + 0] *= f4.x; o[i][4 * j + 1] *= f4.y; o[i][4 * j + 2] *= f4.z; o[i][4 * j + 3] *= f4.w;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- O += P V: step (kb, sp) uses the keys of registers [8 sp, 8 sp + 8): key kb*32 + 8(2 sp + (e>>2)) + 4 half + (e&3)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        uint32_t pw[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) pw[e2] = pack_bf16_pair(s[kb][8 * sp + 2 * e2], s[kb][8 * sp + 2 * e2 + 1]);
+        const bf16x8_t pa = __builtin_bit_cast(bf16x8_t, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+        uint4 vr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int key = kb * 32 + 8 * (2 * sp + (e >> 2)) + 4 * half + (e & 3);
+          vr[e] = *reinterpret_cast<const uint4*>(Vt + key * kRowB + ((lq & 15) << 4));
+        }
+        const uint32_t* vv = reinterpret_cast<const uint32_t*>(vr);          // vv[e * 4 + word]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint32_t vf[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) vf[e2] = __builtin_amdgcn_perm(vv[(2 * e2 + 1) * 4 + i], vv[(2 * e2) * 4 + i], vsel);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8_t, make_uint4(vf[0], vf[1], vf[2], vf[3])), o[i], 0, 0, 0);
+        }
+      }
+    // tile t+1 (and the ids of tile t+2/t+3) have landed for every wave after this pair
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---- epilogue: row sums across the two halves, 1/l into register-row layout, outputs through LDS as whole rows
+  l_part += lane_xor32(l_part);
+  if (half == 0) fac[lq] = 1.0f / l_part;            // (the loop's last barrier retired the tiles: staging may reuse them)
+  uint16_t* ost = reinterpret_cast<uint16_t*>(lds_raw + (size_t)w * (kQTile * D * 2));     // [32 rows][128] bf16 per wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 f4 = *reinterpret_cast<const float4*>(fac + 8 * j + 4 * half);
+    const float f[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r3 = 0; r3 < 4; ++r3) {
+        const int qr = 8 * j + 4 * half + r3;
+        ost[qr * D + (lq & 15) * 8 + 2 * i + (lq >> 4)] = (uint16_t)f32_to_bf16_bits(o[i][4 * j + r3] * f[r3]);
+      }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // 32 rows x 256 B: lane -> (row = it*4 + lane/16, 16-byte piece lane%16)
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int qr = it * 4 + (lane >> 4);
+    if (m0 + qr < q_len)
+      *reinterpret_cast<uint4*>(a.o + (int64_t)(start_loc + m0 + qr) * a.o_stride_t + (int64_t)head * a.o_stride_h + (lane & 15) * 8) =
+          *reinterpret_cast<const uint4*>(ost + qr * D + (lane & 15) * 8);
+  }
+}
+
 }  // namespace
 }  // namespace svk
 
@@ -250,6 +494,21 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
   const size_t shm = (size_t)G * (kQTile * kPRowP * 2 + 256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool off32 = a->kv_num_slots > 0 && (a->kv_num_slots * a->kv_slot_stride * 2) < (int64_t)0xffffffffll;
+  // SVK_PREFILL_ATTN_VARIANT=1 keeps the first kernel (every wave fetches its own K/V tile); 2 = LDS-shared tiles
+  static const int variant = getenv("SVK_PREFILL_ATTN_VARIANT") ? atoi(getenv("SVK_PREFILL_ATTN_VARIANT")) : 2;
+  if (a->head_dim == 128 && variant == 2) {
+    const size_t tiles = 2 * 2 * kKV2 * kRowB, stage = (size_t)G * kQTile * 128 * 2;
+    const size_t shm2 = (tiles > stage ? tiles : stage) + 2 * kKV2 * sizeof(int) + (size_t)G * 32 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(context_attention_kernel_v2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(context_attention_kernel_v2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    if (off32) hipLaunchKernelGGL((context_attention_kernel_v2<true>), grid, block, shm2, s, *a);
+    else hipLaunchKernelGGL((context_attention_kernel_v2<false>), grid, block, shm2, s, *a);
+    return check_launch("svk_context_attention_fwd");
+  }
   if (a->head_dim == 128) {
     if (off32) hipLaunchKernelGGL((context_attention_kernel<128, true>), grid, block, shm, s, *a);
     else hipLaunchKernelGGL((context_attention_kernel<128, false>), grid, block, shm, s, *a);
