@@ -250,12 +250,15 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
 //     registers: it crosses through a 128-byte per-wave LDS row only when some row maximum moved.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int pa_u32x4_t;
 constexpr int kKV2 = 64;                 // keys per tile
 constexpr int kRowB = 256;               // bytes of one K or V head row (D = 128)
 
 __device__ __forceinline__ float lane_xor32(float x) {
-  // the value of lane ^ 32 (the other half of the 32x32 accumulator's row split)
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((int)(threadIdx.x & 63) ^ 32) << 2, __builtin_bit_cast(int, x)));
+  // the value of lane ^ 32 (the other half of the 32x32 accumulator's row split): v_permlane32_swap exchanges the upper
+  // half of its first operand with the lower half of its second
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 
 // 16 bytes per lane HBM/L2 -> LDS (wave-uniform base + 16 * lane), hidden from hipcc: with the builtin the compiler drains
@@ -266,6 +269,62 @@ __device__ __forceinline__ void pa_dma16(const void* gsrc, uint32_t lds_addr) {
   lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+
+// Developer build (make EXTRA=-DSVK_PA_TIMING, then tools/pa_timing.py): per-wave s_memrealtime sums of the five phases of
+// a tile, written behind the output rows when bit 30 of max_input_len is set.  Not part of the product build.
+#ifdef SVK_PA_TIMING
+constexpr int kPaLenMask = 0xfffffff;
+#define PA_TIMING_BEGIN()                                        \
+  const bool timing = (a.max_input_len >> 30) & 1;               \
+  long long T[6] = {0, 0, 0, 0, 0, 0};                           \
+  const long long t_entry = __builtin_amdgcn_s_memrealtime();    \
+  long long t_last = t_entry
+#define PA_STAMP(i)                                              \
+  do {                                                           \
+    const long long now_ = __builtin_amdgcn_s_memrealtime();     \
+    T[i] += now_ - t_last;                                       \
+    t_last = now_;                                               \
+  } while (0)
+#define PA_SETTLE(x, y) asm volatile("s_nop 0" ::"v"(x), "v"(y))   /* results complete before the stamp */
+#define PA_TIMING_END()                                                                                                  \
+  if (timing && lane == 0) {                                                                                             \
+    long long* dbg = reinterpret_cast<long long*>(a.o + (int64_t)(a.max_input_len & kPaLenMask) * a.o_stride_t);         \
+    long long* e = dbg + ((int64_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8 + w) * 8;                                   \
+    e[0] = T[0]; e[1] = T[1]; e[2] = T[2]; e[3] = T[3]; e[4] = T[4];                                                     \
+    e[5] = __builtin_amdgcn_s_memrealtime() - t_entry; e[6] = ntiles;                                                    \
+  }
+#else
+constexpr int kPaLenMask = -1;
+#define PA_TIMING_BEGIN()
+#define PA_STAMP(i)
+#define PA_SETTLE(x, y)
+#define PA_TIMING_END()
+#endif
+
+typedef __attribute__((ext_vector_type(4))) short pa_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short pa_s16x8_t;
+
+// Four 16-byte-per-lane LDS-DMA loads to the consecutive KiBs at `lds_addr` behind ONE M0 write: the instruction offset
+// moves BOTH the LDS destination and the global source (tools/probe_dma_offset.hip), so the caller's offsets carry
+// 3072 - 1024 i and `base` is the tensor base - 3072.
+__device__ __forceinline__ void pa_dma4x16_off32(const uint32_t (&voff)[4], const char* base, uint32_t lds_addr) {
+  uint32_t keep;
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+               "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void pa_dma4x16(const char* const (&src)[4], uint32_t lds_addr) {
+  uint32_t keep;
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
+               "global_load_lds_dwordx4 %3, off offset:2048\n\tglobal_load_lds_dwordx4 %4, off offset:3072\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(lds_addr) : "memory");
 }
 
 template <bool OFF32>
@@ -282,6 +341,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   const int q_len = a.b_seq_len[b] - pc;
   const int m0 = blockIdx.x * kQTile;
   if (m0 >= q_len) return;
+  PA_TIMING_BEGIN();
   const int start_loc = a.b_start_loc[b];
   const int kv_end = min(m0 + kQTile + pc, q_len + pc);
   // LDS: two tile buffers of (K | V) (the epilogue reuses this part as per-wave output staging, G x 8 KiB) |
@@ -303,7 +363,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   const float sm_scale = rsqrtf((float)D) * 1.4426950408889634f;
   const float mask_raw = -1.0e8f / sm_scale;
   float m_run = -INFINITY, l_part = 0.f;            // of query row lq (both halves keep the same maximum)
-  f32x16_t o[4];                                    // o[i][r]: query row (r&3) + 8(r>>2) + 4 half, head dim (lq&15)*8 + 2i + (lq>>4)
+  f32x16_t o[4];                                    // o[i][r]: query row (r&3) + 8(r>>2) + 4 half, head dim 32 i + lq
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -312,7 +372,16 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   const char* const vt = reinterpret_cast<const char*>(a.v_cache);
   const int64_t slot_bytes = a.kv_slot_stride * 2;
   const int64_t head_bytes = (int64_t)kvh * a.kv_head_stride * 2;
-  const uint32_t vsel = (lq >> 4) ? 0x07060302u : 0x05040100u;
+  // transpose-read addresses into the V half of buffer 0 (LDS byte addresses): lane (group member q = lane & 15) points at
+  // key (q >> 2) + 4 half of a block of 8 keys, dims 32 i + 16 (lq >> 4) + 4 (q & 3) .. + 3, through the V swizzle
+  uint32_t vbase[4];
+  {
+    const uint32_t q16 = lane & 15;
+    const uint32_t v0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw + kKV2 * kRowB +
+                        ((q16 >> 2) + 4 * half) * kRowB + (lq >> 4) * 32 + (q16 & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vbase[i] = v0 + ((i ^ (q16 >> 2)) << 6);
+  }
   const int qrow = m0 + lq;
 
   // ---- pipeline: while tile t is computed out of buffer t & 1, the DMA of tile t+1 fills the other buffer and the slot
@@ -320,16 +389,42 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   //      barrier per tile.  The 32 DMA instructions of a tile (16 x 4 K rows, 16 x 4 V rows) are dealt round-robin to the
   //      G waves.  K chunks are swizzled on the SOURCE address (position p of row `key` holds chunk p ^ (key & 15)).
   const int ntiles = (kv_end + kKV2 - 1) / kKV2;
+  // A tile is 32 DMA instructions (16 x 4 K rows, 16 x 4 V rows) = 8 groups of four that share one M0 write (group g <
+  // 4: K rows 16 g .. 16 g + 15, else V rows).  Everything about a lane's source address except the slot id is a
+  // constant of (K or V, position in the group): an instruction costs one ds_read of the id and one multiply-add - the
+  // first version computed the addresses per instruction (25 instructions each; at the ~5 cycles per instruction one wave
+  // gets, 0.55 us of every 2.5 us tile).  With 7 waves on 4 SIMDs wave 3 has a SIMD to itself (waves go to the SIMDs
+  // cyclically) and takes two groups, the others one.  (Placement is a speed heuristic only.)
+  const int widx = G == 7 ? (w == 3 ? 0 : (w < 3 ? w + 1 : w)) : w;
+  const uint32_t lane_row = lane >> 4, lane_pos = lane & 15;
+  uint32_t kc[4], vc;                                  // byte offset inside a slot (+ the instruction-offset bias)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) kc[i] = (uint32_t)head_bytes + ((lane_pos ^ ((i << 2) + lane_row)) << 4) + 3072 - 1024 * i;
+  vc = (uint32_t)head_bytes + ((lane_pos ^ (lane_row << 2)) << 4) + 3072;   // V: position p of row `key` holds chunk p ^ 4 (key & 3)
+  const uint32_t slot_b32 = (uint32_t)slot_bytes;
+  auto issue_group = [&](int t, int g, auto is_v_c) {
+    constexpr bool is_v = decltype(is_v_c)::value;
+    const int* ids = slot_lds + (t & 1) * kKV2 + (g & 3) * 16 + lane_row;
+    int slot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) slot[i] = ids[4 * i];
+    const uint32_t dst = lds0 + (t & 1) * kBuf + g * 4096;
+    if constexpr (OFF32) {
+      uint32_t voff[4];
+      // (slot < 2^24: a slot is >= 256 bytes and the tensor < 4 GiB)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) voff[i] = __umul24((uint32_t)slot[i], slot_b32) + (is_v ? vc - 1024 * i : kc[i]);
+      pa_dma4x16_off32(voff, (is_v ? vt : kt) - 3072, dst);
+    } else {
+      const char* src[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) src[i] = (is_v ? vt : kt) + ((int64_t)slot[i] * slot_bytes + (int64_t)(is_v ? vc - 1024 * i : kc[i]) - 3072);
+      pa_dma4x16(src, dst);
+    }
+  };
   auto issue_tile = [&](int t) {
-    const int* ids = slot_lds + (t & 1) * kKV2;
-    for (int j = w; j < 32; j += G) {
-      const int is_v = j >> 4, jj = j & 15;
-      const int key = jj * 4 + (lane >> 4);
-      const int chunk = is_v ? (lane & 15) : ((lane & 15) ^ (key & 15));
-      const int slot = ids[key];
-      const char* src = (is_v ? vt : kt) + (OFF32 ? (int64_t)((uint32_t)slot * (uint32_t)slot_bytes) : (int64_t)slot * slot_bytes) +
-                        head_bytes + chunk * 16;
-      pa_dma16(src, lds0 + (t & 1) * kBuf + is_v * (kKV2 * kRowB) + jj * 1024);
+    for (int g = widx; g < 8; g += G) {
+      if (g < 4) issue_group(t, g, std::false_type{}); else issue_group(t, g, std::true_type{});
     }
   };
   // slot ids of tile t: 64 x 4 bytes by LDS-DMA as well (wave 0), straight into the id buffer t & 1 - no register in flight
@@ -355,94 +450,106 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * kKV2;
     const unsigned char* Kt = lds_raw + (t & 1) * kBuf;
-    const unsigned char* Vt = Kt + kKV2 * kRowB;
+    PA_STAMP(5);
     if (t + 1 < ntiles) issue_tile(t + 1);
     if (t + 2 < ntiles) issue_ids(t + 2);            // into the id buffer of tile t, which nobody reads any more
-    // ---- S^T = K Q^T: two key blocks of 32, K = 128 in 8 steps
+    PA_STAMP(0);
+    // ---- two key blocks of 32: S^T = K Q^T (K = 128 in 8 steps), online softmax of query row lq, O += P V.  The blocks
+    //      are independent until the softmax, so the matrix work of one runs under the vector work of the other.
+    const bool diag = k0 + kKV2 > m0 + pc || k0 + kKV2 > kv_end;
     f32x16_t s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
       const unsigned char* krow = Kt + (kb * 32 + lq) * kRowB;
+      // all eight A fragments of the block are requested before the first product (left alone, hipcc re-uses ONE
+      // register quad and waits for every ds_read in turn: 16 exposed LDS round trips per tile)
+      pa_u32x4_t ka[D / 16];
 #pragma unroll
-      for (int ds = 0; ds < D / 16; ++ds) {
-        const uint4 ka = *reinterpret_cast<const uint4*>(krow + (((ds * 2 + half) ^ (lq & 15)) << 4));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka), qb[ds], s[kb], 0, 0, 0);
-      }
+      for (int ds = 0; ds < D / 16; ++ds) ka[ds] = *reinterpret_cast<const pa_u32x4_t*>(krow + (((ds * 2 + half) ^ (lq & 15)) << 4));
+#pragma unroll
+      for (int ds = 0; ds < D / 16; ++ds) asm volatile("" : "+v"(ka[ds]));       // keep the loads in one batch
+#pragma unroll
+      for (int ds = 0; ds < D / 16; ++ds)
+        // the first step starts from the constant 0 (an inline operand, no register zeroing)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka[ds]), qb[ds], ds == 0 ? f32x16_t{} : s[kb], 0, 0, 0);
     }
-    // ---- mask + base-2 online softmax of query row lq (register r of block kb = key k0 + kb*32 + (r&3) + 8(r>>2) + 4 half)
-    const bool diag = k0 + kKV2 > m0 + pc || k0 + kKV2 > kv_end;
-    float mx = -INFINITY;
+    PA_SETTLE(s[0][0], s[1][15]);
+    PA_STAMP(1);
+    if (diag) {
+      // only the tiles on the diagonal / at the end of the row: branch-free selects (register r of block kb = key
+      // k0 + kb*32 + (r&3) + 8(r>>2) + 4 half)
+      const int lim = min(qrow + pc, kv_end - 1) - k0 - 4 * half;        // the key offset (inside the tile) must be <= lim
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (diag) {
-          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (!(key <= qrow + pc && key < kv_end)) s[kb][r] = mask_raw;
-        }
-        mx = vmax(mx, s[kb][r]);
-      }
-    mx = vmax(mx, lane_xor32(mx));
-    const float nm = vmax(m_run, mx);
-    const float nms = nm * sm_scale;
-    const bool moved = nm != m_run;
-    const float al = moved ? __builtin_amdgcn_exp2f(m_run * sm_scale - nms) : 1.0f;
-    m_run = nm;
-    float psum = 0.f;
+        for (int r = 0; r < 16; ++r) s[kb][r] = (kb * 32 + (r & 3) + 8 * (r >> 2) <= lim) ? s[kb][r] : mask_raw;
+    }
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = vmax(mx, s[kb][r]);
+      mx = vmax(mx, lane_xor32(mx));
+      const float nm = vmax(m_run, mx);
+      const float nms = nm * sm_scale;
+      const bool moved = nm != m_run;
+      const float al = moved ? __builtin_amdgcn_exp2f(m_run * sm_scale - nms) : 1.0f;
+      m_run = nm;
+      float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         s[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sm_scale, -nms));
         psum += s[kb][r];
       }
-    l_part = l_part * al + psum;
-    if (__any(moved)) {
-      // rescale factors: "lane = query row" -> "register = query row" through the wave's LDS row
-      if (half == 0) fac[lq] = al;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      l_part = l_part * al + psum;
+      if (__any(moved)) {
+        // rescale factors: "lane = query row" -> "register = query row" through the wave's LDS row
+        if (half == 0) fac[lq] = al;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 f4 = *reinterpret_cast<const float4*>(fac + 8 * j + 4 * half);
+        for (int j = 0; j < 4; ++j) {
+          const float4 f4 = *reinterpret_cast<const float4*>(fac + 8 * j + 4 * half);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o[i][4 * j + 0] *= f4.x; o[i][4 * j + 1] *= f4.y; o[i][4 * j + 2] *= f4.z; o[i][4 * j + 3] *= f4.w;
+          for (int i = 0; i < 4; ++i) {
+            o[i][4 * j + 0] *= f4.x; o[i][4 * j + 1] *= f4.y; o[i][4 * j + 2] *= f4.z; o[i][4 * j + 3] *= f4.w;
+          }
         }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
-    }
-    // ---- O += P V: step (kb, sp) uses the keys of registers [8 sp, 8 sp + 8): key kb*32 + 8(2 sp + (e>>2)) + 4 half + (e&3)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      // O += P V: step sp uses the keys of registers [8 sp, 8 sp + 8): key kb*32 + 16 sp + 8(e>>2) + 4 half + (e&3).  The
+      // B operand (lane = head dim 32 i + lq, 8 keys) comes out of the row-major V tile by the LDS transpose read: each
+      // 16-lane group reads a [4 keys][16 dims] block, a lane supplying the address of 4 consecutive dims of one key.
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
         uint32_t pw[4];
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) pw[e2] = pack_bf16_pair(s[kb][8 * sp + 2 * e2], s[kb][8 * sp + 2 * e2 + 1]);
         const bf16x8_t pa = __builtin_bit_cast(bf16x8_t, make_uint4(pw[0], pw[1], pw[2], pw[3]));
-        uint4 vr[8];
+        pa_s16x4_t vr[4][2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int key = kb * 32 + 8 * (2 * sp + (e >> 2)) + 4 * half + (e & 3);
-          vr[e] = *reinterpret_cast<const uint4*>(Vt + key * kRowB + ((lq & 15) << 4));
-        }
-        const uint32_t* vv = reinterpret_cast<const uint32_t*>(vr);          // vv[e * 4 + word]
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int eh = 0; eh < 2; ++eh)
+            vr[i][eh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) pa_s16x4_t*>(
+                vbase[i] + (uint32_t)((t & 1) * kBuf + (kb * 32 + sp * 16 + eh * 8) * kRowB)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          uint32_t vf[4];
-#pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) vf[e2] = __builtin_amdgcn_perm(vv[(2 * e2 + 1) * 4 + i], vv[(2 * e2) * 4 + i], vsel);
-          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8_t, make_uint4(vf[0], vf[1], vf[2], vf[3])), o[i], 0, 0, 0);
+          const pa_s16x8_t vb = __builtin_shufflevector(vr[i][0], vr[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8_t, vb), o[i], 0, 0, 0);
         }
       }
+    }
+    PA_SETTLE(o[0][0], o[3][15]);
+    PA_STAMP(2);
     // tile t+1 (and the ids of tile t+2/t+3) have landed for every wave after this pair
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PA_STAMP(3);
     __syncthreads();
+    PA_STAMP(4);
   }
+  PA_TIMING_END();
   // ---- epilogue: row sums across the two halves, 1/l into register-row layout, outputs through LDS as whole rows
   l_part += lane_xor32(l_part);
   if (half == 0) fac[lq] = 1.0f / l_part;            // (the loop's last barrier retired the tiles: staging may reuse them)
@@ -459,7 +566,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
 #pragma unroll
       for (int r3 = 0; r3 < 4; ++r3) {
         const int qr = 8 * j + 4 * half + r3;
-        ost[qr * D + (lq & 15) * 8 + 2 * i + (lq >> 4)] = (uint16_t)f32_to_bf16_bits(o[i][4 * j + r3] * f[r3]);
+        ost[qr * D + 32 * i + lq] = (uint16_t)f32_to_bf16_bits(o[i][4 * j + r3] * f[r3]);
       }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -490,10 +597,10 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
                   (a->kv_slot_stride % 8) == 0 && (a->kv_head_stride % 8) == 0,
               SVK_ERR_LAYOUT, "svk_context_attention_fwd: q/k/v/o strides must keep 16-byte alignment");
   if (a->batch <= 0 || a->max_input_len <= 0) return SVK_OK;
-  dim3 grid((a->max_input_len + kQTile - 1) / kQTile, a->num_kv_heads, a->batch), block(64 * G);
+  dim3 grid(((a->max_input_len & kPaLenMask) + kQTile - 1) / kQTile, a->num_kv_heads, a->batch), block(64 * G);
   const size_t shm = (size_t)G * (kQTile * kPRowP * 2 + 256);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool off32 = a->kv_num_slots > 0 && (a->kv_num_slots * a->kv_slot_stride * 2) < (int64_t)0xffffffffll;
+  const bool off32 = a->kv_num_slots > 0 && (a->kv_num_slots * a->kv_slot_stride * 2) < (int64_t)0xffffffffll - 8192;
   // SVK_PREFILL_ATTN_VARIANT=1 keeps the first kernel (every wave fetches its own K/V tile); 2 = LDS-shared tiles
   static const int variant = getenv("SVK_PREFILL_ATTN_VARIANT") ? atoi(getenv("SVK_PREFILL_ATTN_VARIANT")) : 2;
   if (a->head_dim == 128 && variant == 2) {
