@@ -231,7 +231,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "stage1_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                tr = json.load(open(pmc))
+                # measured per launch at one batch size (tools/make_traffic_json.py): reported for that workload only
+                traffic = tr.get("hbm_bytes_per_launch") if int(tr.get("batch", 64)) == B else None
             except Exception:
                 traffic = None
         out["roofline"] = {

@@ -19,6 +19,8 @@ timeout 600 python3 "$R/bench.py" < /dev/null > "$O/bench_stdout.log" 2> "$O/ben
 stats bench_kernel_stats.csv python3 "$R/bench.py" --steps 128 --warmup 8 --no-cpu-baseline
 grep '^{' "$O/_bench_kernel_stats.log" | tail -1 > "$O/bench_line_profiled.json"
 for b in 1 8 32; do timeout 300 python3 "$R/bench.py" --batch $b --no-cpu-baseline --no-kernel-events < /dev/null 2>/dev/null | tail -1 >> "$O/bench_small_batches.jsonl"; done
+# the roofline leg at the neighbouring batch sizes (the default is 128)
+for b in 64 256; do timeout 400 python3 "$R/bench.py" --batch $b --no-cpu-baseline < /dev/null 2>/dev/null | tail -1 >> "$O/bench_other_batches.jsonl"; done
 # other configurations
 timeout 600 python3 "$R/tools/pathbench.py" --graph < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_graph.jsonl"
 timeout 600 python3 "$R/tools/pathbench.py" < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_eager.jsonl"
@@ -26,13 +28,18 @@ for c in streamingllm quest deltakv_raw deltakv vanilla; do
   stats paths/${c}_kernel_stats.csv python3 "$R/tools/pathbench.py" --graph --configs $c --steps 20
 done
 timeout 300 python3 "$R/tools/kbench_kivi.py" < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi.txt"
+timeout 300 python3 "$R/tools/kbench_kivi.py" --sink 0 --tail 0 < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi_no_raw.txt"
 timeout 300 python3 "$R/tools/kbench_prefill.py" < /dev/null 2>/dev/null | grep prefill > "$O/paths/kbench_prefill.txt"
-timeout 300 python3 "$R/tools/kbench.py" --batches 64 --block-seqs 1056 --modes 2 --layers 6 < /dev/null 2>/dev/null | tail -3 > "$O/kbench_stage1.txt"
+timeout 300 python3 "$R/tools/kbench.py" --batches 64,128 --block-seqs 1056,2112 --modes 2 --layers 6 < /dev/null 2>/dev/null | tail -6 > "$O/kbench_stage1.txt"
 # HBM traffic of stage 1: separate counter passes, nothing else traced
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $ctr --output-format csv -d "$O/_pmc_$ctr" -- python3 "$R/tools/kbench.py" --batches 64 --block-seqs 1056 --modes 2 --iters 3 < /dev/null > "$O/_pmc_$ctr.log" 2>&1
+  timeout 400 rocprofv3 --pmc $ctr --output-format csv -d "$O/_pmc_$ctr" -- python3 "$R/tools/kbench.py" --batches 128 --block-seqs 2112 --modes 2 --iters 3 < /dev/null > "$O/_pmc_$ctr.log" 2>&1
   f=$(find "$O/_pmc_$ctr" -type f -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$O/kbench_pmc_$ctr.csv"
+done
+# bare access-pattern and instruction probes (built here by hipcc, see the header of each file)
+for p in probe_gather probe_kdma probe_dma_offset; do
+  [ -x "$R/tools/bin/$p" ] && timeout 120 "$R/tools/bin/$p" < /dev/null > "$O/$p.txt" 2>&1
 done
 rm -rf "$O"/_prof_* "$O"/_pmc_*/
 ls -la "$O" "$O/paths"
