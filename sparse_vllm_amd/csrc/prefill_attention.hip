@@ -486,22 +486,26 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      float mx = -INFINITY;
+      // the block's V operands (16 transpose reads, see below) are requested first: they travel under the softmax
+      pa_s16x4_t vr[2][4][2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = vmax(mx, s[kb][r]);
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int eh = 0; eh < 2; ++eh)
+            vr[sp][i][eh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) pa_s16x4_t*>(
+                vbase[i] + (uint32_t)((t & 1) * kBuf + (kb * 32 + sp * 16 + eh * 8) * kRowB)));
+      // row maximum as a tree of three-input maxima (depth 3 instead of a 16-long chain)
+      const f32x16_t& x = s[kb];
+      float mx = vmax(vmax3(vmax3(x[0], x[1], x[2]), vmax3(x[3], x[4], x[5]), x[15]),
+                      vmax3(vmax3(x[6], x[7], x[8]), vmax3(x[9], x[10], x[11]), vmax3(x[12], x[13], x[14])));
       mx = vmax(mx, lane_xor32(mx));
       const float nm = vmax(m_run, mx);
       const float nms = nm * sm_scale;
       const bool moved = nm != m_run;
       const float al = moved ? __builtin_amdgcn_exp2f(m_run * sm_scale - nms) : 1.0f;
       m_run = nm;
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sm_scale, -nms));
-        psum += s[kb][r];
-      }
-      l_part = l_part * al + psum;
       if (__any(moved)) {
         // rescale factors: "lane = query row" -> "register = query row" through the wave's LDS row
         if (half == 0) fac[lq] = al;
@@ -518,6 +522,13 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
         }
         __builtin_amdgcn_wave_barrier();
       }
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sm_scale, -nms));
+        psum += s[kb][r];
+      }
+      l_part = l_part * al + psum;
       // O += P V: step sp uses the keys of registers [8 sp, 8 sp + 8): key kb*32 + 16 sp + 8(e>>2) + 4 half + (e&3).  The
       // B operand (lane = head dim 32 i + lq, 8 keys) comes out of the row-major V tile by the LDS transpose read: each
       // 16-lane group reads a [4 keys][16 dims] block, a lane supplying the address of 4 consecutive dims of one key.
@@ -527,16 +538,13 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) pw[e2] = pack_bf16_pair(s[kb][8 * sp + 2 * e2], s[kb][8 * sp + 2 * e2 + 1]);
         const bf16x8_t pa = __builtin_bit_cast(bf16x8_t, make_uint4(pw[0], pw[1], pw[2], pw[3]));
-        pa_s16x4_t vr[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int eh = 0; eh < 2; ++eh)
-            vr[i][eh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) pa_s16x4_t*>(
-                vbase[i] + (uint32_t)((t & 1) * kBuf + (kb * 32 + sp * 16 + eh * 8) * kRowB)));
+          for (int eh = 0; eh < 2; ++eh) asm volatile("" : "+v"(vr[sp][i][eh]));     // one batch of reads, one wait
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const pa_s16x8_t vb = __builtin_shufflevector(vr[i][0], vr[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          const pa_s16x8_t vb = __builtin_shufflevector(vr[sp][i][0], vr[sp][i][1], 0, 1, 2, 3, 4, 5, 6, 7);
           o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8_t, vb), o[i], 0, 0, 0);
         }
       }

@@ -89,6 +89,11 @@ __device__ __forceinline__ float vmax(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
   return y;
 }
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float y;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a), "v"(b), "v"(c));
+  return y;
+}
 __device__ __forceinline__ float row16_allmax(float x) {
   return row_ror_max1(row_ror_max2(row_ror_max4(row_ror_max8(x))));
 }
