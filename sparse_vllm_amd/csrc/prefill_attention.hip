@@ -347,7 +347,8 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   // LDS: two tile buffers of (K | V) (the epilogue reuses this part as per-wave output staging, G x 8 KiB) |
   //      2 x 64 slot ids | per-wave 32-float rows (rescale factors / 1 / row sum)
   constexpr int kBuf = 2 * kKV2 * kRowB;             // one (K | V) tile
-  const int aux0 = max(2 * kBuf, G * kQTile * D * 2);
+  constexpr int kRing = 3;                             // K|V tiles in LDS: t-1 (its last P V), t, t+1
+  const int aux0 = max(kRing * kBuf, G * kQTile * D * 2);
   int* slot_lds = reinterpret_cast<int*>(lds_raw + aux0);
   float* fac = reinterpret_cast<float*>(slot_lds + 2 * kKV2) + w * 32;
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw);
@@ -408,7 +409,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
     int slot[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) slot[i] = ids[4 * i];
-    const uint32_t dst = lds0 + (t & 1) * kBuf + g * 4096;
+    const uint32_t dst = lds0 + (t % kRing) * kBuf + g * 4096;
     if constexpr (OFF32) {
       uint32_t voff[4];
       // (slot < 2^24: a slot is >= 256 bytes and the tensor < 4 GiB)
@@ -438,125 +439,181 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
                    : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
     }
   };
+  // K fragment addresses (A operand of S^T = K Q^T): lane (key row lq of a 32-key block, k-chunk ds*2 + half) through the
+  // K swizzle; LDS byte addresses relative to the block's first row
+  uint32_t kaddr[D / 16];
+#pragma unroll
+  for (int ds = 0; ds < D / 16; ++ds)
+    kaddr[ds] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw + lq * kRowB + (((ds * 2 + half) ^ (lq & 15)) << 4);
+
   issue_ids(0);
   issue_ids(1);
+  // (step 0 multiplies the V rows of "tile -1, block 1" - ring slot 2 - by P = 0: they must be finite)
+  for (int i = threadIdx.x; i < 32 * kRowB / 16; i += blockDim.x)
+    *reinterpret_cast<uint4*>(lds_raw + 2 * kBuf + kKV2 * kRowB + 32 * kRowB + i * 16) = make_uint4(0u, 0u, 0u, 0u);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   issue_tile(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (ntiles > 1) issue_tile(1);
+  if (ntiles > 2) issue_ids(2);
 #pragma unroll
   for (int ds = 0; ds < D / 16; ++ds) asm volatile("" : "+v"(qb[ds]));
-  for (int t = 0; t < ntiles; ++t) {
+
+  // ---- software pipeline over 32-key blocks j = 2 t + kb.  Step j holds three stages of three different blocks:
+  //        C(j-1): O += P(j-1) V(j-1)        8 MFMAs, V by LDS transpose reads
+  //        B(j)  : online softmax of S(j)    the vector work (maximum, exp2, row sum, bf16 packing)
+  //        A(j+1): S(j+1) = K(j+1) Q^T       8 MFMAs, K fragments by ds_read_b128
+  //      so the vector unit and the matrix unit of the SIMD are busy at the same time inside ONE wave (with the stages of
+  //      a block back to back, the softmax waits for its QK and the P V for its softmax: measured 1.5 us per tile for a
+  //      wave that has a SIMD to itself, the sum of its MFMA and VALU times).  The rescale of O by 2^(m_old - m_new) of
+  //      block j (only when some row's maximum moved) sits between C(j-1) and C(j).  Tile t+1 must have landed before
+  //      A(2t+2) in step 2t+1 and tile t-1 is read last by C(2t-1) in step 2t: the workgroup barrier of tile t sits
+  //      between those two steps and the DMA of tile t+2 is issued right behind it - a ring of three tile buffers.
+  uint32_t ob_prev = 2 * kBuf, ob_cur = 0, ob_next = kBuf;          // ring offsets of tiles t-1, t, t+1
+  f32x16_t s_a, s_b;                                                 // S of the even / odd block of a tile
+  {
+    pa_u32x4_t ka[D / 16];
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) ka[ds] = *reinterpret_cast<const __attribute__((address_space(3))) pa_u32x4_t*>(kaddr[ds]);
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) asm volatile("" : "+v"(ka[ds]));
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds)
+      s_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka[ds]), qb[ds], ds == 0 ? f32x16_t{} : s_a, 0, 0, 0);
+  }
+  uint32_t pp_a[8], pp_b[8];                                         // P of the even / odd block as bf16 pairs (A operand of P V)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pp_b[e] = 0u;                          // (step 0 multiplies V of block 0 by P = 0)
+  // one step: kb = which block of tile t the softmax works on; s_in / p_prev are consumed, s_out / p_out produced
+  auto step = [&](int t, auto kb_c, f32x16_t& s_in, f32x16_t& s_out, const uint32_t (&p_prev)[8], uint32_t (&p_out)[8])
+                  __attribute__((always_inline)) {
+    constexpr int kb = decltype(kb_c)::value;
     const int k0 = t * kKV2;
-    const unsigned char* Kt = lds_raw + (t & 1) * kBuf;
-    PA_STAMP(5);
-    if (t + 1 < ntiles) issue_tile(t + 1);
-    if (t + 2 < ntiles) issue_ids(t + 2);            // into the id buffer of tile t, which nobody reads any more
-    PA_STAMP(0);
-    // ---- two key blocks of 32: S^T = K Q^T (K = 128 in 8 steps), online softmax of query row lq, O += P V.  The blocks
-    //      are independent until the softmax, so the matrix work of one runs under the vector work of the other.
-    const bool diag = k0 + kKV2 > m0 + pc || k0 + kKV2 > kv_end;
-    f32x16_t s[2];
+    // K of block j+1: the other block of this tile, or the first one of the next tile; V of block j-1 likewise
+    const uint32_t k_off_next = kb == 0 ? ob_cur + 32 * kRowB : ob_next;
+    const uint32_t v_off_prev = kb == 0 ? ob_prev + 32 * kRowB : ob_cur;
+    // operands of the two matrix stages (K first: its products form the dependent chain)
+    pa_u32x4_t ka[D / 16];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const unsigned char* krow = Kt + (kb * 32 + lq) * kRowB;
-      // all eight A fragments of the block are requested before the first product (left alone, hipcc re-uses ONE
-      // register quad and waits for every ds_read in turn: 16 exposed LDS round trips per tile)
-      pa_u32x4_t ka[D / 16];
+    for (int ds = 0; ds < D / 16; ++ds) ka[ds] = *reinterpret_cast<const __attribute__((address_space(3))) pa_u32x4_t*>(kaddr[ds] + k_off_next);
+    pa_s16x4_t vr[2][4][2];
 #pragma unroll
-      for (int ds = 0; ds < D / 16; ++ds) ka[ds] = *reinterpret_cast<const pa_u32x4_t*>(krow + (((ds * 2 + half) ^ (lq & 15)) << 4));
-#pragma unroll
-      for (int ds = 0; ds < D / 16; ++ds) asm volatile("" : "+v"(ka[ds]));       // keep the loads in one batch
-#pragma unroll
-      for (int ds = 0; ds < D / 16; ++ds)
-        // the first step starts from the constant 0 (an inline operand, no register zeroing)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka[ds]), qb[ds], ds == 0 ? f32x16_t{} : s[kb], 0, 0, 0);
-    }
-    PA_SETTLE(s[0][0], s[1][15]);
-    PA_STAMP(1);
-    if (diag) {
-      // only the tiles on the diagonal / at the end of the row: branch-free selects (register r of block kb = key
-      // k0 + kb*32 + (r&3) + 8(r>>2) + 4 half)
-      const int lim = min(qrow + pc, kv_end - 1) - k0 - 4 * half;        // the key offset (inside the tile) must be <= lim
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = (kb * 32 + (r & 3) + 8 * (r >> 2) <= lim) ? s[kb][r] : mask_raw;
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      // the block's V operands (16 transpose reads, see below) are requested first: they travel under the softmax
-      pa_s16x4_t vr[2][4][2];
+    for (int i = 0; i < 4; ++i) {
+      const auto* vp = reinterpret_cast<__attribute__((address_space(3))) pa_s16x4_t*>(vbase[i] + v_off_prev);
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int eh = 0; eh < 2; ++eh)
+          vr[sp][i][eh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<__attribute__((address_space(3))) pa_s16x4_t*>(vp) + (sp * 16 + eh * 8) * kRowB / 8);
+    }
+    if (k0 + kKV2 > m0 + pc || k0 + kKV2 > kv_end) {
+      // only the tiles on the diagonal / at the end of the row: branch-free selects (register r = key k0 + kb*32 +
+      // (r&3) + 8(r>>2) + 4 half)
+      const int lim = min(qrow + pc, kv_end - 1) - k0 - kb * 32 - 4 * half;        // the key offset (inside the block) must be <= lim
 #pragma unroll
-          for (int eh = 0; eh < 2; ++eh)
-            vr[sp][i][eh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) pa_s16x4_t*>(
-                vbase[i] + (uint32_t)((t & 1) * kBuf + (kb * 32 + sp * 16 + eh * 8) * kRowB)));
-      // row maximum as a tree of three-input maxima (depth 3 instead of a 16-long chain)
-      const f32x16_t& x = s[kb];
-      float mx = vmax(vmax3(vmax3(x[0], x[1], x[2]), vmax3(x[3], x[4], x[5]), x[15]),
-                      vmax3(vmax3(x[6], x[7], x[8]), vmax3(x[9], x[10], x[11]), vmax3(x[12], x[13], x[14])));
-      mx = vmax(mx, lane_xor32(mx));
-      const float nm = vmax(m_run, mx);
-      const float nms = nm * sm_scale;
-      const bool moved = nm != m_run;
-      const float al = moved ? __builtin_amdgcn_exp2f(m_run * sm_scale - nms) : 1.0f;
-      m_run = nm;
-      if (__any(moved)) {
-        // rescale factors: "lane = query row" -> "register = query row" through the wave's LDS row
-        if (half == 0) fac[lq] = al;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int r = 0; r < 16; ++r) s_in[r] = ((r & 3) + 8 * (r >> 2) <= lim) ? s_in[r] : mask_raw;
+    }
+    // B(j): row maximum as a tree of three-input maxima
+    float mx = vmax(vmax3(vmax3(s_in[0], s_in[1], s_in[2]), vmax3(s_in[3], s_in[4], s_in[5]), s_in[15]),
+                    vmax3(vmax3(s_in[6], s_in[7], s_in[8]), vmax3(s_in[9], s_in[10], s_in[11]), vmax3(s_in[12], s_in[13], s_in[14])));
+    mx = vmax(mx, lane_xor32(mx));
+    const float nm = vmax(m_run, mx);
+    const float nms = nm * sm_scale;
+    const bool moved = nm != m_run;
+    const float al = moved ? __builtin_amdgcn_exp2f(m_run * sm_scale - nms) : 1.0f;
+    m_run = nm;
+    // A(j+1) and C(j-1) alternate (the A products form a dependent chain, the C products of one step are independent), each
+    // followed by the softmax of one S register (multiply-add, exp2, row sum, every other time a bf16 pack); scheduling
+    // barriers keep exactly this order - left to itself hipcc issues the sixteen products back to back behind the vector
+    // work.  C step sp uses the keys of registers [8 sp, 8 sp + 8): key 16 sp + 8(e>>2) + 4 half + (e&3) of the block.  Its
+    // B operand (lane = head dim 32 i + lq, 8 keys) comes out of the row-major V tile by the LDS transpose read: each
+    // 16-lane group reads a [4 keys][16 dims] block, a lane supplying the address of 4 consecutive dims of one key.
+    float psum = 0.f;
+    {
+      const bf16x8_t pa0 = __builtin_bit_cast(bf16x8_t, make_uint4(p_prev[0], p_prev[1], p_prev[2], p_prev[3]));
+      const bf16x8_t pa1 = __builtin_bit_cast(bf16x8_t, make_uint4(p_prev[4], p_prev[5], p_prev[6], p_prev[7]));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 f4 = *reinterpret_cast<const float4*>(fac + 8 * j + 4 * half);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            o[i][4 * j + 0] *= f4.x; o[i][4 * j + 1] *= f4.y; o[i][4 * j + 2] *= f4.z; o[i][4 * j + 3] *= f4.w;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sm_scale, -nms));
-        psum += s[kb][r];
-      }
-      l_part = l_part * al + psum;
-      // O += P V: step sp uses the keys of registers [8 sp, 8 sp + 8): key kb*32 + 16 sp + 8(e>>2) + 4 half + (e&3).  The
-      // B operand (lane = head dim 32 i + lq, 8 keys) comes out of the row-major V tile by the LDS transpose read: each
-      // 16-lane group reads a [4 keys][16 dims] block, a lane supplying the address of 4 consecutive dims of one key.
-#pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        uint32_t pw[4];
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) pw[e2] = pack_bf16_pair(s[kb][8 * sp + 2 * e2], s[kb][8 * sp + 2 * e2 + 1]);
-        const bf16x8_t pa = __builtin_bit_cast(bf16x8_t, make_uint4(pw[0], pw[1], pw[2], pw[3]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int eh = 0; eh < 2; ++eh) asm volatile("" : "+v"(vr[sp][i][eh]));     // one batch of reads, one wait
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+      for (int g = 0; g < 16; ++g) {
+        if ((g & 1) == 0) {
+          s_out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka[g >> 1]), qb[g >> 1], g == 0 ? f32x16_t{} : s_out, 0, 0, 0);
+        } else {
+          const int sp = g >> 3, i = (g >> 1) & 3;
           const pa_s16x8_t vb = __builtin_shufflevector(vr[sp][i][0], vr[sp][i][1], 0, 1, 2, 3, 4, 5, 6, 7);
-          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8_t, vb), o[i], 0, 0, 0);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp ? pa1 : pa0, __builtin_bit_cast(bf16x8_t, vb), o[i], 0, 0, 0);
         }
+        s_in[g] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_in[g], sm_scale, -nms));
+        psum += s_in[g];
+        if (g & 1) p_out[g >> 1] = pack_bf16_pair(s_in[g - 1], s_in[g]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    PA_SETTLE(o[0][0], o[3][15]);
+    l_part = l_part * al + psum;
+    // (pin the softmax results to this block: left alone, the compiler sinks the exp2 work below the barrier branch)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(p_out[e]));
+    asm volatile("" : "+v"(l_part));
+    PA_SETTLE(o[0][0], s_out[15]);
+    PA_STAMP(1);
+    if (__any(moved)) {
+      // rescale factors: "lane = query row" -> "register = query row" through the wave's LDS row
+      if (half == 0) fac[lq] = al;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float4 f4 = *reinterpret_cast<const float4*>(fac + 8 * jj + 4 * half);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i][4 * jj + 0] *= f4.x; o[i][4 * jj + 1] *= f4.y; o[i][4 * jj + 2] *= f4.z; o[i][4 * jj + 3] *= f4.w;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     PA_STAMP(2);
-    // tile t+1 (and the ids of tile t+2/t+3) have landed for every wave after this pair
+  };
+  for (int t = 0; t < ntiles; ++t) {
+    PA_STAMP(5);
+    step(t, std::integral_constant<int, 0>{}, s_a, s_b, pp_b, pp_a);
+    // tile t+1 has landed for every wave after this pair, and nobody reads tile t-1 any more
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PA_STAMP(3);
     __syncthreads();
     PA_STAMP(4);
+    if (t + 2 < ntiles) issue_tile(t + 2);
+    if (t + 3 < ntiles) issue_ids(t + 3);            // into the id buffer of tile t+1, whose DMA was issued one barrier ago
+    PA_STAMP(0);
+    step(t, std::integral_constant<int, 1>{}, s_b, s_a, pp_a, pp_b);
+    const uint32_t x = ob_prev;
+    ob_prev = ob_cur; ob_cur = ob_next; ob_next = x;
   }
+  const uint32_t v_off_prev = ob_prev + 32 * kRowB;                  // V of the last block
+  const uint32_t (&pp)[8] = pp_b;
+  // C of the last block
+  {
+    pa_s16x4_t vr[2][4][2];
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int eh = 0; eh < 2; ++eh)
+          vr[sp][i][eh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) pa_s16x4_t*>(
+              vbase[i] + v_off_prev + (uint32_t)((sp * 16 + eh * 8) * kRowB)));
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      const bf16x8_t pa = __builtin_bit_cast(bf16x8_t, make_uint4(pp[4 * sp], pp[4 * sp + 1], pp[4 * sp + 2], pp[4 * sp + 3]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const pa_s16x8_t vb = __builtin_shufflevector(vr[sp][i][0], vr[sp][i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8_t, vb), o[i], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                   // (the epilogue stages through the tile buffers)
   PA_TIMING_END();
   // ---- epilogue: row sums across the two halves, 1/l into register-row layout, outputs through LDS as whole rows
   l_part += lane_xor32(l_part);
@@ -612,7 +669,7 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
   // SVK_PREFILL_ATTN_VARIANT=1 keeps the first kernel (every wave fetches its own K/V tile); 2 = LDS-shared tiles
   static const int variant = getenv("SVK_PREFILL_ATTN_VARIANT") ? atoi(getenv("SVK_PREFILL_ATTN_VARIANT")) : 2;
   if (a->head_dim == 128 && variant == 2) {
-    const size_t tiles = 2 * 2 * kKV2 * kRowB, stage = (size_t)G * kQTile * 128 * 2;
+    const size_t tiles = 3 * 2 * kKV2 * kRowB, stage = (size_t)G * kQTile * 128 * 2;
     const size_t shm2 = (tiles > stage ? tiles : stage) + 2 * kKV2 * sizeof(int) + (size_t)G * 32 * sizeof(float);
     static bool attr = false;
     if (!attr) {

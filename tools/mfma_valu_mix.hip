@@ -9,8 +9,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-template <int N, int KIND>
-__global__ void __launch_bounds__(512) mix(float* out, long long* cyc, int iters) {
+template <int N, int KIND, bool MFMA = true>
+__global__ void __launch_bounds__(1024) mix(float* out, long long* cyc, int iters) {
   f32x16_t acc[4];
   for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = threadIdx.x * 0.001f + r;
   bf16x8_t a, b;
@@ -18,18 +18,22 @@ __global__ void __launch_bounds__(512) mix(float* out, long long* cyc, int iters
   float v[16];
   for (int i = 0; i < 16; ++i) v[i] = threadIdx.x + i * 0.25f;
   const float c1 = 1.0001f, c2 = 0.0003f;
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  f2 vp[8]; for (int i = 0; i < 8; ++i) vp[i] = f2{v[i], v[i + 8]};
+  const f2 cp1 = {c1, c1}, cp2 = {c2, c2};
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
+      if (MFMA) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         float& x = v[(m * N + j) % 16];
         if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
         else if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
-        else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
+        else if (KIND == 2) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
+        else asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(vp[(m * N + j) % 8]) : "v"(cp1), "v"(cp2));
       }
     }
   }
@@ -37,26 +41,29 @@ __global__ void __launch_bounds__(512) mix(float* out, long long* cyc, int iters
   float sum = 0.f;
   for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) sum += acc[i][r];
   for (int i = 0; i < 16; ++i) sum += v[i];
+  for (int i = 0; i < 8; ++i) sum += vp[i].x + vp[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
-  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int N, int KIND>
+template <int N, int KIND, bool MFMA = true>
 int run(const char* kind, int waves, float* out, long long* cyc) {
   const int iters = 2000;
-  mix<N, KIND><<<1, 64 * waves>>>(out, cyc, iters);
+  mix<N, KIND, MFMA><<<1, 64 * waves>>>(out, cyc, iters);
   CK(hipDeviceSynchronize());
-  long long h[8];
+  long long h[16];
   CK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
   double mx = 0;
   for (int w = 0; w < waves; ++w) mx = h[w] > mx ? h[w] : mx;
-  printf("%-10s waves/WG %d  VALU per MFMA %2d : %7.1f cycles per MFMA (slowest wave)\n", kind, waves, N, mx / (iters * 4.0));
+  if (MFMA) printf("%-10s waves/WG %2d  VALU per MFMA %2d : %7.1f cycles per MFMA (slowest wave)\n", kind, waves, N, mx / (iters * 4.0));
+  else printf("%-10s waves/WG %2d  no MFMA, %2d VALU per group : %6.2f cycles per VALU per wave, %5.2f per VALU per SIMD\n", kind, waves, N,
+              mx / (iters * 4.0 * N), mx / (iters * 4.0 * N) / (waves / 4.0));
   return 0;
 }
 
 int main() {
   float* out; long long* cyc;
-  CK(hipMalloc(&out, 512 * 4)); CK(hipMalloc(&cyc, 64));
+  CK(hipMalloc(&out, 1024 * 4)); CK(hipMalloc(&cyc, 128));
   for (int waves : {4, 8}) {
     run<0, 0>("v_fma", waves, out, cyc); run<2, 0>("v_fma", waves, out, cyc); run<4, 0>("v_fma", waves, out, cyc);
     run<6, 0>("v_fma", waves, out, cyc); run<8, 0>("v_fma", waves, out, cyc); run<12, 0>("v_fma", waves, out, cyc);
@@ -64,5 +71,12 @@ int main() {
     run<4, 1>("v_exp", waves, out, cyc); run<8, 1>("v_exp", waves, out, cyc);
     run<8, 2>("v_max3", waves, out, cyc);
   }
+  for (int waves : {4, 8, 16}) {
+    run<8, 0, false>("v_fma", waves, out, cyc);
+    run<8, 1, false>("v_exp", waves, out, cyc);
+    run<8, 2, false>("v_max3", waves, out, cyc);
+    run<8, 3, false>("v_pk_fma", waves, out, cyc);
+  }
+  for (int waves : {4, 8}) { run<4, 3>("v_pk_fma", waves, out, cyc); run<8, 3>("v_pk_fma", waves, out, cyc); }
   return 0;
 }
