@@ -64,7 +64,11 @@ class SparseController:
         # MI355X: a layer's score epilogue (scale + softmax + accumulate) rides in the NEXT layer's stage-1 launch
         # (svk_flash_decode_stage1_deferred) instead of sitting between two layers as a latency-bound launch of its own;
         # the last layer's is flushed at the end of the layer loop (`join_side_streams`) / before the eviction check
-        self._defer_h2o_score = os.environ.get("SVK_H2O_DEFER_SCORE", "1") == "1"
+        # SVK_H2O_DEFER_SCORE: "1" always, "0" never (fused finish launch), default "auto": from 16 sequences per step up
+        # (measured B=1/8/16/32: 0.500/0.836/1.077/1.622 ms per step deferred vs 0.459/0.776/1.090/1.712 fused - below 16
+        # sequences the single epilogue workgroup per row outlasts the stage-1 blocks it rides with)
+        self._defer_h2o_mode = os.environ.get("SVK_H2O_DEFER_SCORE", "auto")
+        self._defer_h2o_min_batch = 16
         self._deferred_score = None          # (SvkH2oDecodeScoreArgs, keep-alive tensors)
         self.is_deltakv_family = self.sparse_method == "deltakv"
         self.obs_layer_ids = list(getattr(config, "obs_layer_ids", None) or [])
@@ -258,6 +262,11 @@ class SparseController:
         self._layer_score_finished[layer_idx] = True
         return True
 
+    def _defer_h2o_score(self, batch: int) -> bool:
+        if self._defer_h2o_mode == "auto":
+            return batch >= self._defer_h2o_min_batch
+        return self._defer_h2o_mode == "1"
+
     def fused_decode_finish(self, layer_idx: int, mid_o, mid_lse, context_lens, o, block_seq) -> bool:
         """MI355X fusion hook called by the attention backend instead of `flash_decode_stage2`:
         for H2O decode, stage 2 and this layer's `on_layer_attention_end` score epilogue run as
@@ -269,7 +278,7 @@ class SparseController:
             return False
         cm = self.cache_manager
         cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
-        if self._defer_h2o_score:
+        if self._defer_h2o_score(int(context_lens.shape[0])):
             from ..kernels.flash_decoding_stage2 import flash_decode_stage2
             from ..kernels.gqa_flash_decoding_stage1 import h2o_score_args
             self.flush_deferred_score()              # at most one layer is ever pending

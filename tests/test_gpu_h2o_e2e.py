@@ -23,7 +23,11 @@ def _bf(t):
     dict(B=3, L=3, budget=48, interval=16, start=48, steps=40, Hq=28, Hkv=4, D=128),
     dict(B=2, L=2, budget=112, interval=16, start=100, steps=50, Hq=14, Hkv=2, D=64),
 ])
-def test_h2o_decode_steps_match_oracle(cfg):
+@pytest.mark.parametrize("defer", ["0", "1", "auto"])
+def test_h2o_decode_steps_match_oracle(cfg, defer, monkeypatch):
+    # the score epilogue of a layer either runs in the fused finish launch ("0") or rides in the next layer's stage-1
+    # launch ("1"); "auto" picks by batch size (SparseController._defer_h2o_score)
+    monkeypatch.setenv("SVK_H2O_DEFER_SCORE", defer)
     from sparse_vllm_amd.config import Config
     from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
     B, L, budget, interval = cfg["B"], cfg["L"], cfg["budget"], cfg["interval"]

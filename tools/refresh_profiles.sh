@@ -38,7 +38,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   [ -n "$f" ] && cp "$f" "$O/kbench_pmc_$ctr.csv"
 done
 # bare access-pattern and instruction probes (built here by hipcc, see the header of each file)
-for p in probe_gather probe_kdma probe_dma_offset; do
+for p in probe_gather probe_kdma probe_dma_offset mfma_valu_mix; do
   [ -x "$R/tools/bin/$p" ] && timeout 120 "$R/tools/bin/$p" < /dev/null > "$O/$p.txt" 2>&1
 done
 rm -rf "$O"/_prof_* "$O"/_pmc_*/
