@@ -854,19 +854,23 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a, const SvkH2oDecodeScor
   constexpr int DW = D / 8;                       // 16-byte segments per head row
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
+  int b = blockIdx.y;
   if constexpr (!FUSED) {
-    // grid rows >= batch: the deferred score epilogue of the previous layer (one workgroup per row, the others of that
-    // grid row leave at once).  It rides with this launch's 256+ streaming workgroups instead of having its own
-    // latency-bound launch between two layers.
-    if ((int)blockIdx.y >= a.batch) {
-      if (blockIdx.x == 0) deferred_score_row(fs, (int)blockIdx.y - a.batch, lds);
+    // the first gridDim.y - batch grid rows: the deferred score epilogue of the previous layer (one workgroup per row,
+    // the others of that grid row leave at once).  It rides with this launch's 256+ streaming workgroups instead of
+    // having its own latency-bound launch between two layers - and FIRST in dispatch order, so that its 8 us of
+    // dependent latency run under the streaming work instead of trailing it (as the last grid rows it added 9 us to
+    // a 176 us launch).
+    const int n_def = (int)gridDim.y - a.batch;
+    if (b < n_def) {
+      if (blockIdx.x == 0) deferred_score_row(fs, b, lds);
       return;
     }
+    b -= n_def;
   }
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Hkv = a.num_kv_heads;
-  const int b = blockIdx.y;
   const int blk = blockIdx.x;
   const int n = lane & 15;
   const int jq = lane >> 4;
