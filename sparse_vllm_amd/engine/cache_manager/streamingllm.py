@@ -18,6 +18,24 @@ class StreamingLLMCacheManager(SnapKVCacheManager):
     def _window(self) -> int:
         return int(self.config.num_recent_tokens)
 
+    def decode_cuda_graph_context_capacity(self, seqs=None, *, requested_context_capacity: int = 0,
+                                           current_context_capacity: int = 0) -> tuple[int, bool]:
+        """Graph context capacity = the physical decode peak of a sink + recent row, like H2O's hook (h2o.py:241-254):
+        a row is compacted back to sink + recent once it holds 2 x (sink + recent) tokens
+        (sparse_controller.py:1558-1653), so no decode step attends over more than that.  The reference leaves this
+        method on the runner's default (the logical context bucket, decode_cuda_graph.py:172-203), which sizes the
+        split-KV grid for 32 k tokens when a row holds 576..1152: on MI355X that is one workgroup per row and
+        33.9 us per layer instead of 17 (B=64).  Rows admitted longer than the peak keep their own length."""
+        budget = int(self.config.num_sink_tokens) + int(self.config.num_recent_tokens)
+        if budget <= 0:
+            return max(1, int(self.config.max_model_len)), False
+        longest = 0
+        for seq in seqs or []:
+            row = self.seq_id_to_row[0].get(seq.seq_id)
+            if row is not None:
+                longest = max(longest, int(self.row_seq_lens[0][row]) + 1)
+        return max(1, min(max(2 * budget, longest), int(self.config.max_model_len))), False
+
     def prefill_batched_tokens_margin(self) -> int:
         """Extra batched-token budget the scheduler grants a prefill step of this method."""
         return self._window()
