@@ -64,11 +64,13 @@ class SparseController:
         # MI355X: a layer's score epilogue (scale + softmax + accumulate) rides in the NEXT layer's stage-1 launch
         # (svk_flash_decode_stage1_deferred) instead of sitting between two layers as a latency-bound launch of its own;
         # the last layer's is flushed at the end of the layer loop (`join_side_streams`) / before the eviction check
-        # SVK_H2O_DEFER_SCORE: "1" always, "0" never (fused finish launch), default "auto": from 16 sequences per step up
-        # (measured B=1/8/16/32: 0.500/0.836/1.077/1.622 ms per step deferred vs 0.459/0.776/1.090/1.712 fused - below 16
-        # sequences the single epilogue workgroup per row outlasts the stage-1 blocks it rides with)
+        # SVK_H2O_DEFER_SCORE: "1" always, "0" never (fused finish launch), default "auto": for 16..127 sequences per step.
+        # Measured ms per step deferred vs fused: B=1 0.500 / 0.459, B=8 0.836 / 0.776 (the single epilogue workgroup per row
+        # outlasts the stage-1 blocks it rides with), B=16 1.077 / 1.090, B=32 1.622 / 1.712, B=64 2.916 / 2.951,
+        # B=128 5.40 / 5.43: from 128 rows up the epilogue workgroups cost the launch what the separate launch cost
+        # (+4.9 us on a 180 us launch against 10.8 - 5.9 us), so the plain pair of launches is kept there.
         self._defer_h2o_mode = os.environ.get("SVK_H2O_DEFER_SCORE", "auto")
-        self._defer_h2o_min_batch = 16
+        self._defer_h2o_min_batch, self._defer_h2o_max_batch = 16, 127
         self._deferred_score = None          # (SvkH2oDecodeScoreArgs, keep-alive tensors)
         self.is_deltakv_family = self.sparse_method == "deltakv"
         self.obs_layer_ids = list(getattr(config, "obs_layer_ids", None) or [])
@@ -264,7 +266,7 @@ class SparseController:
 
     def _defer_h2o_score(self, batch: int) -> bool:
         if self._defer_h2o_mode == "auto":
-            return batch >= self._defer_h2o_min_batch
+            return self._defer_h2o_min_batch <= batch <= self._defer_h2o_max_batch
         return self._defer_h2o_mode == "1"
 
     def fused_decode_finish(self, layer_idx: int, mid_o, mid_lse, context_lens, o, block_seq) -> bool:
