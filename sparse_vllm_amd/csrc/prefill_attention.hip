@@ -339,7 +339,9 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   const int lq = lane & 31, half = lane >> 5;
   const int pc = a.b_prompt_cache_len[b];
   const int q_len = a.b_seq_len[b] - pc;
-  const int m0 = blockIdx.x * kQTile;
+  // query tiles in DESCENDING order of their key count (causal rows: the last tile of the chunk has the longest key
+  // range): the longest workgroups start first and the short ones fill the tail of the launch
+  const int m0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * kQTile;
   if (m0 >= q_len) return;
   PA_TIMING_BEGIN();
   const int start_loc = a.b_start_loc[b];
