@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
   const int dg = n % DW;
   const int pc = a.b_prompt_cache_len[b];
   const int q_len = a.b_seq_len[b] - pc;                     // queries of this chunk
-  const int m0 = blockIdx.x * kQTile;
+  const int m0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * kQTile;   // longest key ranges first (see the v2 kernel)
   if (m0 >= q_len) return;
   const int start_loc = a.b_start_loc[b];
   const int kv_end = min(m0 + kQTile + pc, q_len + pc);       // keys visible to the last query of the block
