@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "svk_common.hpp"
+#include "lds_dma.hpp"
 
 namespace svk {
 namespace {
@@ -249,17 +250,9 @@ __global__ void __launch_bounds__(512) context_attention_kernel(const SvkContext
 //   * the per-row rescale factor lives in "lane = query row" layout while the output accumulator has its query rows in
 //     registers: it crosses through a 128-byte per-wave LDS row only when some row maximum moved.
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int pa_u32x4_t;
 constexpr int kKV2 = 64;                 // keys per tile
 constexpr int kRowB = 256;               // bytes of one K or V head row (D = 128)
 
-__device__ __forceinline__ float lane_xor32(float x) {
-  // the value of lane ^ 32 (the other half of the 32x32 accumulator's row split): v_permlane32_swap exchanges the upper
-  // half of its first operand with the lower half of its second
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
-}
 
 // 16 bytes per lane HBM/L2 -> LDS (wave-uniform base + 16 * lane), hidden from hipcc: with the builtin the compiler drains
 // vmcnt(0) in front of every ds_read of the written region and the double buffer would buy nothing.  M0 is saved and
@@ -304,28 +297,6 @@ constexpr int kPaLenMask = -1;
 
 typedef __attribute__((ext_vector_type(4))) short pa_s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short pa_s16x8_t;
-
-// Four 16-byte-per-lane LDS-DMA loads to the consecutive KiBs at `lds_addr` behind ONE M0 write: the instruction offset
-// moves BOTH the LDS destination and the global source (tools/probe_dma_offset.hip), so the caller's offsets carry
-// 3072 - 1024 i and `base` is the tensor base - 3072.
-__device__ __forceinline__ void pa_dma4x16_off32(const uint32_t (&voff)[4], const char* base, uint32_t lds_addr) {
-  uint32_t keep;
-  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
-               "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(base), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ void pa_dma4x16(const char* const (&src)[4], uint32_t lds_addr) {
-  uint32_t keep;
-  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
-               "global_load_lds_dwordx4 %3, off offset:2048\n\tglobal_load_lds_dwordx4 %4, off offset:3072\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(lds_addr) : "memory");
-}
 
 template <bool OFF32>
 __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkContextAttentionArgs a) {
