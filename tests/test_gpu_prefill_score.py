@@ -61,6 +61,15 @@ def test_prefill_score_golden(golden, case):
     (28, 4, 128, [(1000, 600)], 128, 0, 0, "logits"),
     (14, 2, 64, [(300, 300), (10, 100), (0, 50)], 100, 0, 0, "probability"),
     (8, 8, 64, [(100, 200)], 200, 0, 0, "logits"),                      # logits window > 128
+    # head_dim 128 (LDS-shared K tile kernel): group sizes 1 / 2 / 4 / 5 / 8, windows that are not a multiple of 32,
+    # candidate ranges that start / end inside a 128-key block, a window longer than the chunk, logits windows up to 128
+    (32, 8, 128, [(777, 300)], 100, 0, 0, "probability"),
+    (8, 8, 128, [(130, 190), (0, 17)], 17, 3, 40, "probability"),
+    (16, 8, 128, [(255, 129), (640, 1)], 128, 0, 0, "probability"),
+    (10, 2, 128, [(64, 65)], 90, 70, 30, "probability"),
+    (16, 2, 128, [(511, 513)], 128, 130, 200, "probability"),
+    (32, 8, 128, [(300, 260), (5, 130)], 128, 0, 0, "logits"),
+    (10, 2, 128, [(90, 70)], 48, 16, 0, "logits"),
 ])
 def test_prefill_score_vs_oracle(cfg):
     Hq, Hkv, D, seqs, window, cstart, nrecent, mode = cfg

@@ -30,6 +30,8 @@ done
 timeout 300 python3 "$R/tools/kbench_kivi.py" < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi.txt"
 timeout 300 python3 "$R/tools/kbench_kivi.py" --sink 0 --tail 0 < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi_no_raw.txt"
 timeout 300 python3 "$R/tools/kbench_prefill.py" < /dev/null 2>/dev/null | grep prefill > "$O/paths/kbench_prefill.txt"
+timeout 300 python3 "$R/tools/kbench_prefill_score.py" < /dev/null 2>/dev/null | grep prefill_score > "$O/paths/kbench_prefill_score.txt"
+stats paths/prefill_h2o_kernel_stats.csv python3 "$R/tools/prefillbench.py"
 timeout 300 python3 "$R/tools/kbench.py" --batches 64,128 --block-seqs 1056,2112 --modes 2 --layers 6 < /dev/null 2>/dev/null | tail -6 > "$O/kbench_stage1.txt"
 # HBM traffic of stage 1: separate counter passes, nothing else traced
 for ctr in FETCH_SIZE WRITE_SIZE; do
