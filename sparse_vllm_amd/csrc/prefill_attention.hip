@@ -254,16 +254,6 @@ constexpr int kKV2 = 64;                 // keys per tile
 constexpr int kRowB = 256;               // bytes of one K or V head row (D = 128)
 
 
-// 16 bytes per lane HBM/L2 -> LDS (wave-uniform base + 16 * lane), hidden from hipcc: with the builtin the compiler drains
-// vmcnt(0) in front of every ds_read of the written region and the double buffer would buy nothing.  M0 is saved and
-// restored inside the statement (it is compiler-reserved).
-__device__ __forceinline__ void pa_dma16(const void* gsrc, uint32_t lds_addr) {
-  uint32_t keep;
-  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
-}
-
 // Developer build (make EXTRA=-DSVK_PA_TIMING, then tools/pa_timing.py): per-wave s_memrealtime sums of the five phases of
 // a tile, written behind the output rows when bit 30 of max_input_len is set.  Not part of the product build.
 #ifdef SVK_PA_TIMING
