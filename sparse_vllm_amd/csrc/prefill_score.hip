@@ -269,6 +269,12 @@ __global__ void __launch_bounds__(512, 4) prefill_score_kernel_v2(const SvkPrefi
   const int nrb = Wpad32 / 32;
   const int64_t grp = (int64_t)i * a.num_kv_heads + h;
   float* hs = reinterpret_cast<float*>(lds_raw + kPsKeys * kPsRowB);
+  if (PASS == 0 && h == 0) {
+    // the score row starts from 0 (pass 1 publishes by atomic max): this range's workgroup of KV head 0 clears its
+    // 128 columns here, so the probability mode needs no fill launch
+    float* dst = a.attn_score + (int64_t)i * a.score_stride;
+    for (int c = k0 + (int)threadIdx.x; c < min(k0 + kPsKeys, a.score_cols); c += blockDim.x) dst[c] = 0.f;
+  }
   if (key_lo >= key_hi) {
     if (PASS == 0 && half == 0)
       for (int rb = 0; rb < nrb; ++rb) {
@@ -590,9 +596,11 @@ extern "C" int svk_prefill_score(const SvkPrefillScoreArgs* a, svk_stream_t stre
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Tiling t = make_tiling(a->n_ranges, a->num_q_heads, a->num_kv_heads, a->max_query_len, a->score_cols, a->score_mode);
   const bool logits = a->score_mode == SVK_PREFILL_SCORE_LOGITS;
-  hipLaunchKernelGGL(fill_rows_kernel, dim3(std::min(64, (a->score_cols + 255) / 256), a->n_ranges), dim3(256), 0, s,
-                     a->attn_score, a->score_stride, a->score_cols, logits ? -INFINITY : 0.f);
-  if (a->head_dim == 128 && t.G <= 8 && t.Wpad <= 128 && prefill_score_variant() == 2) {
+  const bool v2 = a->head_dim == 128 && t.G <= 8 && t.Wpad <= 128 && prefill_score_variant() == 2;
+  if (logits || !v2)      // (the v2 probability path clears the row inside its first pass)
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(std::min(64, (a->score_cols + 255) / 256), a->n_ranges), dim3(256), 0, s,
+                       a->attn_score, a->score_stride, a->score_cols, logits ? -INFINITY : 0.f);
+  if (v2) {
     const Tiling2 u = make_tiling2(t, a->n_ranges, a->num_kv_heads, a->score_cols);
     dim3 grid2(u.NKB, (unsigned)u.groups), block2(64 * t.G);
     const size_t shm = (size_t)kPsKeys * kPsRowB + (size_t)t.G * kPsKeys * sizeof(float);
