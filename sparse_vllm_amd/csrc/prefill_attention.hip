@@ -295,14 +295,27 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = a.num_q_heads / a.num_kv_heads;
-  const int b = blockIdx.z, kvh = blockIdx.y;
+  const int b = blockIdx.z;
+  // (query tile, KV head) of this workgroup.  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), each
+  // XCD with its own L2: when the grid allows it, a KV head is served by 8 / Hkv XCDs only, so an L2 streams one head's
+  // K/V rows instead of all of them.
+  int qt = blockIdx.x, kvh = blockIdx.y;
+  {
+    const unsigned nx = gridDim.x, ny = gridDim.y;
+    if ((ny == 1 || ny == 2 || ny == 4 || ny == 8) && ((nx * ny) & 7) == 0) {
+      const unsigned L = blockIdx.x + nx * blockIdx.y;
+      const unsigned xcd = L & 7, j = L >> 3;
+      kvh = xcd % ny;
+      qt = j * (8 / ny) + xcd / ny;
+    }
+  }
   const int head = kvh * G + w;
   const int lq = lane & 31, half = lane >> 5;
   const int pc = a.b_prompt_cache_len[b];
   const int q_len = a.b_seq_len[b] - pc;
   // query tiles in DESCENDING order of their key count (causal rows: the last tile of the chunk has the longest key
   // range): the longest workgroups start first and the short ones fill the tail of the launch
-  const int m0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * kQTile;
+  const int m0 = ((int)gridDim.x - 1 - qt) * kQTile;
   if (m0 >= q_len) return;
   PA_TIMING_BEGIN();
   const int start_loc = a.b_start_loc[b];
