@@ -495,9 +495,14 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
     float mx = vmax(vmax3(vmax3(s_in[0], s_in[1], s_in[2]), vmax3(s_in[3], s_in[4], s_in[5]), s_in[15]),
                     vmax3(vmax3(s_in[6], s_in[7], s_in[8]), vmax3(s_in[9], s_in[10], s_in[11]), vmax3(s_in[12], s_in[13], s_in[14])));
     mx = vmax(mx, lane_xor32(mx));
-    const float nm = vmax(m_run, mx);
+    // The reference point of the row's exponents follows the row maximum lazily: it moves only when the maximum grew by
+    // more than 2^8 in the exponent domain (the probabilities of a row are then at most 256 instead of 1 until the next
+    // move: no precision is lost in fp32 / bf16, sums and outputs scale together).  With the exact maximum as the
+    // reference, almost every block of a workgroup's first tiles rescales O (64 multiplies + an LDS round trip).
+    const float nm_true = vmax(m_run, mx);
+    const bool moved = (nm_true - m_run) * sm_scale > 8.0f;
+    const float nm = moved ? nm_true : m_run;
     const float nms = nm * sm_scale;
-    const bool moved = nm != m_run;
     const float al = moved ? __builtin_amdgcn_exp2f(m_run * sm_scale - nms) : 1.0f;
     m_run = nm;
     // A(j+1) and C(j-1) alternate (the A products form a dependent chain, the C products of one step are independent), each
