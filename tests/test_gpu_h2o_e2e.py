@@ -22,6 +22,7 @@ def _bf(t):
 @pytest.mark.parametrize("cfg", [
     dict(B=3, L=3, budget=48, interval=16, start=48, steps=40, Hq=28, Hkv=4, D=128),
     dict(B=2, L=2, budget=112, interval=16, start=100, steps=50, Hq=14, Hkv=2, D=64),
+    dict(B=2, L=2, budget=112, interval=16, start=104, steps=45, Hq=7, Hkv=1, D=128),    # one TP=4 rank of Qwen2.5-7B
 ])
 @pytest.mark.parametrize("defer", ["0", "1", "auto"])
 def test_h2o_decode_steps_match_oracle(cfg, defer, monkeypatch):

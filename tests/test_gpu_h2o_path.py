@@ -101,6 +101,11 @@ def _rand_case(seed, B, Hq, Hkv, D, lens, block_seq, cap=None, scale=0.3):
     (2, 14, 2, 64, (777, 300), 64),             # Qwen2.5-0.5B heads
     (2, 32, 8, 128, (513, 512), 512),           # G=4, 8 kv heads
     (1, 8, 8, 64, (100,), 48),                  # MHA-as-GQA G=1, block_seq not multiple of 32
+    (3, 7, 1, 128, (2113, 640, 5), 272),        # one TP=4 rank of Qwen2.5-7B: 1 KV head, G=7
+    (2, 14, 2, 128, (1500, 1499), 512),         # TP=2 rank: 2 KV heads
+    (2, 8, 1, 128, (300, 257), 64),             # Llama-3.1-8B at TP=8: 1 KV head, G=8
+    (2, 10, 2, 128, (95, 400), 96),             # G=5
+    (2, 12, 4, 128, (333, 64), 176),            # G=3
 ])
 def test_decode_vs_oracle(shape, mode):
     B, Hq, Hkv, D, lens, block_seq = shape
