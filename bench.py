@@ -260,8 +260,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic,
-            "kernel": "decode_stage1_kernel_v3<128,7,HEADMAX,nt,off32> (scored GQA split-KV decode; from 16 sequences up the launch also "
-                      "carries the previous layer's H2O score epilogue, whose 16 B per (row, token) are NOT counted in achieved)",
+            "kernel": "decode_stage1_kernel_v3<128,7,HEADMAX,nt,off32> (scored GQA split-KV decode)",
             "launches_timed": n_launch, "avg_launch_us": ms_total * 1e3 / n_launch,
             "timing": (f"{args.event_steps} eagerly launched steps continue the timed region; after each step's layer "
                        "loop and before its post_forward, its 28 stage-1 launches are re-issued back to back on the same "

@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 4
+#define SVK_ABI_VERSION 5
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -179,6 +179,15 @@ typedef struct SvkH2oDecodeScoreArgs {
   int32_t width;
 } SvkH2oDecodeScoreArgs;
 int svk_h2o_decode_score_update(const SvkH2oDecodeScoreArgs* a, svk_stream_t stream);
+/* The same for `n_layers` layers in ONE launch (engine/cache_manager/h2o.py:957-1038
+ * `update_decode_attention_scores_all_layers`: the reference, too, folds the step's scores into the cumulative
+ * rows of all layers at once): `first` describes layer 0; layer l uses attn_score + l * score_stride_layer,
+ * cum_score + l * cum_stride_layer, b_new_slot + l * new_slot_stride_layer, b_req_idx + l * req_stride_layer and
+ * b_seqlen + l * seqlen_stride_layer (element strides; 0 = shared by all layers).  Issued once per decode step after
+ * the layer loop: 28 latency-bound row launches become one bandwidth-bound launch. */
+int svk_h2o_decode_score_update_layers(const SvkH2oDecodeScoreArgs* first, int32_t n_layers, int64_t score_stride_layer,
+                                       int64_t cum_stride_layer, int64_t new_slot_stride_layer, int64_t req_stride_layer,
+                                       int64_t seqlen_stride_layer, svk_stream_t stream);
 
 /* Fused decode epilogue of one H2O layer: svk_flash_decode_stage2 and
  * svk_h2o_decode_score_update in ONE launch (independent workgroups of the same grid), i.e.

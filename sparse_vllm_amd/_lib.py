@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 4
+SVK_ABI_VERSION = 5
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -259,6 +259,7 @@ ENTRY_POINTS = {
     "svk_flash_decode_stage2": ([C.POINTER(SvkFlashDecodeStage2Args), _p], C.c_int),
     "svk_fill_f32": ([_p, _i64, _f32, _p], C.c_int),
     "svk_h2o_decode_score_update": ([C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
+    "svk_h2o_decode_score_update_layers": ([C.POINTER(SvkH2oDecodeScoreArgs), C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _p], C.c_int),
     "svk_h2o_decode_fused": ([C.POINTER(SvkH2oDecodeFusedArgs), _p], C.c_int),
     "svk_h2o_decode_finish": ([C.POINTER(SvkH2oDecodeFinishArgs), _p], C.c_int),
     "svk_flash_decode_stage1_deferred": ([C.POINTER(SvkFlashDecodeStage1Args), C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),

@@ -53,6 +53,51 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
   }
 }
 
+// All layers of a decode step in one launch (grid = (batch lane, layer)): the score half of h2o_decode_finish_kernel
+// with the layer's pointers.  The row lives in registers (one read, one write of the raw scores and of the cumulative row).
+template <int EPT>
+__global__ void __launch_bounds__(1024) h2o_decode_score_layers_kernel(const SvkH2oDecodeScoreArgs a, int64_t score_stride_layer,
+                                                                       int64_t cum_stride_layer, int64_t new_slot_stride_layer,
+                                                                       int64_t req_stride_layer, int64_t seqlen_stride_layer) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const int64_t l = blockIdx.y;
+  float* x = a.attn_score + l * score_stride_layer + (int64_t)b * a.score_stride_b;
+  const int W = a.width;
+  float* cum = nullptr;
+  int len = 0;
+  if (a.cum_score != nullptr && !(a.b_new_slot != nullptr && a.b_new_slot[l * new_slot_stride_layer + b] < 0)) {   // padded graph lanes
+    cum = a.cum_score + l * cum_stride_layer + (int64_t)a.b_req_idx[l * req_stride_layer + b] * a.cum_stride;
+    len = a.b_seqlen[l * seqlen_stride_layer + b];
+  }
+  float v[EPT], c[EPT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int t = threadIdx.x + i * 1024;
+    v[i] = t < W ? mul_rn(x[t], a.scale) : -INFINITY;
+    c[i] = (cum != nullptr && t < len - 1) ? cum[t] : 0.f;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = block_allmax(mx, red);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    v[i] = expf(v[i] - mx);          // exp(-inf) = 0 for the padding lanes
+    sum += v[i];
+  }
+  sum = block_allsum(sum, red);
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int t = threadIdx.x + i * 1024;
+    if (t < W) {
+      const float p = v[i] / sum;
+      x[t] = p;
+      if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : c[i] + p;   // pad(prev, 1) + p
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // fused decode epilogue: [0, B) workgroups normalise + accumulate one score row each (row kept
 // in registers: one HBM/L2 read, one write), the remaining workgroups merge the split-KV
@@ -302,6 +347,41 @@ extern "C" int svk_h2o_decode_score_update(const SvkH2oDecodeScoreArgs* a, svk_s
   const int threads = a->width >= 4096 ? 1024 : (a->width >= 1024 ? 512 : 256);
   hipLaunchKernelGGL(h2o_decode_score_kernel, dim3(a->batch), dim3(threads), 0, static_cast<hipStream_t>(stream), *a);
   return check_launch("svk_h2o_decode_score_update");
+}
+
+extern "C" int svk_h2o_decode_score_update_layers(const SvkH2oDecodeScoreArgs* first, int32_t n_layers, int64_t score_stride_layer,
+                                                  int64_t cum_stride_layer, int64_t new_slot_stride_layer, int64_t req_stride_layer,
+                                                  int64_t seqlen_stride_layer, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(first != nullptr && first->attn_score != nullptr, SVK_ERR_VALUE, "svk_h2o_decode_score_update_layers: null args");
+  SVK_REQUIRE(first->width > 0 && n_layers >= 0, SVK_ERR_VALUE, "svk_h2o_decode_score_update_layers: bad shape");
+  SVK_REQUIRE(first->cum_score == nullptr || (first->b_req_idx != nullptr && first->b_seqlen != nullptr), SVK_ERR_VALUE,
+              "svk_h2o_decode_score_update_layers: cum_score needs b_req_idx and b_seqlen");
+  if (first->batch <= 0 || n_layers == 0) return SVK_OK;
+  if (first->width > 1024 * 32) {      // rows that do not fit the register-resident form: layer by layer
+    for (int l = 0; l < n_layers; ++l) {
+      SvkH2oDecodeScoreArgs a = *first;
+      a.attn_score += (int64_t)l * score_stride_layer;
+      if (a.cum_score != nullptr) a.cum_score += (int64_t)l * cum_stride_layer;
+      if (a.b_new_slot != nullptr) a.b_new_slot += (int64_t)l * new_slot_stride_layer;
+      if (a.b_req_idx != nullptr) a.b_req_idx += (int64_t)l * req_stride_layer;
+      if (a.b_seqlen != nullptr) a.b_seqlen += (int64_t)l * seqlen_stride_layer;
+      const int rc = svk_h2o_decode_score_update(&a, stream);
+      if (rc != SVK_OK) return rc;
+    }
+    return SVK_OK;
+  }
+  dim3 grid(first->batch, n_layers);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int ept = (first->width + 1023) / 1024;
+#define SVK_SCORE_LAYERS(EPT_) \
+  hipLaunchKernelGGL((h2o_decode_score_layers_kernel<EPT_>), grid, dim3(1024), 0, s, *first, score_stride_layer, cum_stride_layer, new_slot_stride_layer, req_stride_layer, seqlen_stride_layer)
+  if (ept <= 2) SVK_SCORE_LAYERS(2);
+  else if (ept <= 5) SVK_SCORE_LAYERS(5);
+  else if (ept <= 16) SVK_SCORE_LAYERS(16);
+  else SVK_SCORE_LAYERS(32);
+#undef SVK_SCORE_LAYERS
+  return check_launch("svk_h2o_decode_score_update_layers");
 }
 
 extern "C" int svk_h2o_decode_finish(const SvkH2oDecodeFinishArgs* f, svk_stream_t stream) {

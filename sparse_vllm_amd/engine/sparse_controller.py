@@ -64,13 +64,14 @@ class SparseController:
         # MI355X: a layer's score epilogue (scale + softmax + accumulate) rides in the NEXT layer's stage-1 launch
         # (svk_flash_decode_stage1_deferred) instead of sitting between two layers as a latency-bound launch of its own;
         # the last layer's is flushed at the end of the layer loop (`join_side_streams`) / before the eviction check
-        # SVK_H2O_DEFER_SCORE: "1" always, "0" never (fused finish launch), default "auto": for 16..127 sequences per step.
-        # Measured ms per step deferred vs fused: B=1 0.500 / 0.459, B=8 0.836 / 0.776 (the single epilogue workgroup per row
-        # outlasts the stage-1 blocks it rides with), B=16 1.077 / 1.090, B=32 1.622 / 1.712, B=64 2.916 / 2.951,
-        # B=128 5.40 / 5.43: from 128 rows up the epilogue workgroups cost the launch what the separate launch cost
-        # (+4.9 us on a 180 us launch against 10.8 - 5.9 us), so the plain pair of launches is kept there.
-        self._defer_h2o_mode = os.environ.get("SVK_H2O_DEFER_SCORE", "auto")
-        self._defer_h2o_min_batch, self._defer_h2o_max_batch = 16, 127
+        # Where a layer's H2O score epilogue (scale + softmax of the raw score row, cumulative add) runs.
+        # SVK_H2O_DEFER_SCORE = "end" (default): all layers of the step in ONE launch after the layer loop, like the
+        # reference's update_decode_attention_scores_all_layers (h2o.py:957-1038); "0": in every layer's fused finish
+        # launch; "1": as extra workgroups of the next layer's stage-1 launch.  Measured ms per step, end / fused:
+        # B=1 0.407 / 0.460, B=8 0.689 / 0.776, B=16 0.999 / 1.090, B=64 2.833 / 2.951, B=128 5.306 / 5.491 (same box
+        # per pair); riding in stage 1: B=1 0.500, B=16 1.077, B=64 2.92, B=128 5.40.
+        self._defer_h2o_mode = os.environ.get("SVK_H2O_DEFER_SCORE", "end")
+        self._pending_scores: list = []      # (SvkH2oDecodeScoreArgs, keep-alive tensors) of this step's layers ("end")
         self._deferred_score = None          # (SvkH2oDecodeScoreArgs, keep-alive tensors)
         self.is_deltakv_family = self.sparse_method == "deltakv"
         self.obs_layer_ids = list(getattr(config, "obs_layer_ids", None) or [])
@@ -264,10 +265,9 @@ class SparseController:
         self._layer_score_finished[layer_idx] = True
         return True
 
-    def _defer_h2o_score(self, batch: int) -> bool:
-        if self._defer_h2o_mode == "auto":
-            return self._defer_h2o_min_batch <= batch <= self._defer_h2o_max_batch
-        return self._defer_h2o_mode == "1"
+    def _h2o_score_mode(self, batch: int) -> str:
+        """"fused" | "stage1" | "end" (see __init__)."""
+        return {"0": "fused", "1": "stage1"}.get(self._defer_h2o_mode, "end")
 
     def fused_decode_finish(self, layer_idx: int, mid_o, mid_lse, context_lens, o, block_seq) -> bool:
         """MI355X fusion hook called by the attention backend instead of `flash_decode_stage2`:
@@ -280,15 +280,21 @@ class SparseController:
             return False
         cm = self.cache_manager
         cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
-        if self._defer_h2o_score(int(context_lens.shape[0])):
+        mode = self._h2o_score_mode(int(context_lens.shape[0]))
+        if mode != "fused":
             from ..kernels.flash_decoding_stage2 import flash_decode_stage2
             from ..kernels.gqa_flash_decoding_stage1 import h2o_score_args
-            self.flush_deferred_score()              # at most one layer is ever pending
+            if mode == "stage1":
+                self.flush_deferred_score()          # at most one layer is ever pending
             flash_decode_stage2(mid_o, mid_lse, context_lens, o, block_seq)
             new_slots = self._h2o_new_slots(layer_idx)
-            self._deferred_score = (h2o_score_args(s.attn_score, self.attn_softmax_scale, cum_score=cum,
-                                                   b_req_idx=s.req_indices, b_seqlen=context_lens, b_new_slot=new_slots),
-                                    (s.attn_score, cum, s.req_indices, context_lens, new_slots))
+            entry = (h2o_score_args(s.attn_score, self.attn_softmax_scale, cum_score=cum, b_req_idx=s.req_indices,
+                                    b_seqlen=context_lens, b_new_slot=new_slots),
+                     (s.attn_score, cum, s.req_indices, context_lens, new_slots))
+            if mode == "stage1":
+                self._deferred_score = entry
+            else:
+                self._pending_scores.append(entry)
             self._layer_score_finished[layer_idx] = True
             return True
         h2o_ops.h2o_decode_finish(mid_o, mid_lse, context_lens, o, block_seq, s.attn_score, self.attn_softmax_scale,
@@ -302,11 +308,15 @@ class SparseController:
         return None if pending is None else pending[0]
 
     def flush_deferred_score(self):
-        """Run a still pending score epilogue on its own (last layer of the step; callers that do not carry it)."""
+        """Run the still pending score epilogues: the last layer's in "stage1" mode, all layers of the step in "end" mode
+        (end of the layer loop - inside the captured graph - and before anything reads the scores)."""
         pending, self._deferred_score = self._deferred_score, None
         if pending is not None:
             lib = _lib.load()
             _lib.check(lib.svk_h2o_decode_score_update(C.byref(pending[0]), _lib.current_stream_handle()), lib)
+        if self._pending_scores:
+            batch, self._pending_scores = self._pending_scores, []
+            h2o_ops.h2o_decode_score_update_layers([e[0] for e in batch])
 
     @torch.no_grad()
     def on_layer_attention_end(self, layer_idx: int):

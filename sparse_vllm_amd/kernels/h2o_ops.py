@@ -42,6 +42,44 @@ def h2o_decode_score_update(attn_score: torch.Tensor, scale: float, *, cum_score
     _lib.check(lib.svk_h2o_decode_score_update(C.byref(a), _lib.current_stream_handle()), lib)
 
 
+SCORE_LAYERS_LAUNCHES = {"batched": 0, "per_layer": 0}     # which form h2o_decode_score_update_layers took (tests)
+
+
+def h2o_decode_score_update_layers(pending) -> None:
+    """`h2o_decode_score_update` of several layers of one decode step (H2OCacheManager.
+    update_decode_attention_scores_all_layers, h2o.py:957-1038).  `pending` = the layers' SvkH2oDecodeScoreArgs in
+    layer order.  When the layers' buffers are equally spaced slices of one tensor each (the controller's [L, B, W]
+    raw-score scratch, the manager's [L, rows, cap] cumulative tensor, the [L, B] slot mapping / row ids / lengths),
+    they run as ONE launch (svk_h2o_decode_score_update_layers); otherwise one launch per layer."""
+    if not pending:
+        return
+    lib = _lib.load()
+    stream = _lib.current_stream_handle()
+    first = pending[0]
+
+    def delta(name, esize):
+        a0 = getattr(first, name)
+        if not a0:
+            return 0 if all(not getattr(x, name) for x in pending) else None
+        if len(pending) == 1:
+            return 0
+        d = getattr(pending[1], name) - a0
+        if d % esize or any(getattr(x, name) != a0 + i * d for i, x in enumerate(pending)):
+            return None
+        return d // esize
+
+    same = all(x.batch == first.batch and x.width == first.width and x.score_stride_b == first.score_stride_b and
+               x.cum_stride == first.cum_stride and x.scale == first.scale for x in pending)
+    strides = [delta(name, 4) for name in ("attn_score", "cum_score", "b_new_slot", "b_req_idx", "b_seqlen")]
+    if same and None not in strides:
+        _lib.check(lib.svk_h2o_decode_score_update_layers(C.byref(first), len(pending), *strides, stream), lib)
+        SCORE_LAYERS_LAUNCHES["batched"] += 1
+        return
+    for a in pending:
+        _lib.check(lib.svk_h2o_decode_score_update(C.byref(a), stream), lib)
+    SCORE_LAYERS_LAUNCHES["per_layer"] += 1
+
+
 def h2o_decode_finish(mid_out, mid_out_logexpsum, B_Seqlen, O, block_seq, attn_score, scale, *, cum_score=None,
                       b_req_idx=None, b_new_slot=None):
     """flash_decode_stage2 + h2o_decode_score_update in one launch (same results)."""

@@ -24,10 +24,10 @@ def _bf(t):
     dict(B=2, L=2, budget=112, interval=16, start=100, steps=50, Hq=14, Hkv=2, D=64),
     dict(B=2, L=2, budget=112, interval=16, start=104, steps=45, Hq=7, Hkv=1, D=128),    # one TP=4 rank of Qwen2.5-7B
 ])
-@pytest.mark.parametrize("defer", ["0", "1", "auto"])
+@pytest.mark.parametrize("defer", ["0", "1", "end"])
 def test_h2o_decode_steps_match_oracle(cfg, defer, monkeypatch):
     # the score epilogue of a layer either runs in the fused finish launch ("0") or rides in the next layer's stage-1
-    # launch ("1"); "auto" picks by batch size (SparseController._defer_h2o_score)
+    # launch ("1"), or all layers of the step run in one launch after the layer loop ("end", the default)
     monkeypatch.setenv("SVK_H2O_DEFER_SCORE", defer)
     from sparse_vllm_amd.config import Config
     from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
@@ -37,6 +37,8 @@ def test_h2o_decode_steps_match_oracle(cfg, defer, monkeypatch):
                               max_num_seqs_in_gpu=B + 2, num_kvcache_slots=B * (budget + interval) + 37,
                               h2o_decode_budget=budget, h2o_decode_eviction_interval=interval,
                               h2o_prefill_budget=2 * budget)
+    from sparse_vllm_amd.kernels import h2o_ops as _ops
+    before = dict(_ops.SCORE_LAYERS_LAUNCHES)
     drv = SparseDecodeDriver(conf)
     cm = drv.cache_manager
     cm.permute_free_slots(11)
@@ -102,3 +104,7 @@ def test_h2o_decode_steps_match_oracle(cfg, defer, monkeypatch):
             np.testing.assert_array_equal(stack[l, :p], st.free_stack[l, :p])
     assert n_bursts >= 2
     assert cm._h2o_counters["decode_eviction_bursts"] == n_bursts * B
+    if defer == "end":
+        # the layers' buffers are equally spaced slices: every step took the single all-layers launch
+        from sparse_vllm_amd.kernels import h2o_ops
+        assert h2o_ops.SCORE_LAYERS_LAUNCHES["batched"] > before["batched"] and h2o_ops.SCORE_LAYERS_LAUNCHES["per_layer"] == before["per_layer"]
