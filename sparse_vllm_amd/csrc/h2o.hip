@@ -54,46 +54,82 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
 }
 
 // All layers of a decode step in one launch (grid = (batch lane, layer)): the score half of h2o_decode_finish_kernel
-// with the layer's pointers.  The row lives in registers (one read, one write of the raw scores and of the cumulative row).
-template <int EPT>
-__global__ void __launch_bounds__(1024) h2o_decode_score_layers_kernel(const SvkH2oDecodeScoreArgs a, int64_t score_stride_layer,
-                                                                       int64_t cum_stride_layer, int64_t new_slot_stride_layer,
-                                                                       int64_t req_stride_layer, int64_t seqlen_stride_layer) {
+// with the layer's pointers.  The row lives in registers (one read, one write of the raw scores and of the cumulative
+// row).  256 threads x 16-byte accesses: eight workgroups per CU keep 8 x 256 x 2 x E4 loads in flight (with 1024 scalar
+// threads per row two workgroups fit a CU and the 3584 rows of a B=128 step took 77 us = 3.1 TB/s).
+template <int E4, bool VEC>
+__global__ void __launch_bounds__(256) h2o_decode_score_layers_kernel(const SvkH2oDecodeScoreArgs a, int64_t score_stride_layer,
+                                                                      int64_t cum_stride_layer, int64_t new_slot_stride_layer,
+                                                                      int64_t req_stride_layer, int64_t seqlen_stride_layer) {
   __shared__ float red[16];
   const int b = blockIdx.x;
   const int64_t l = blockIdx.y;
   float* x = a.attn_score + l * score_stride_layer + (int64_t)b * a.score_stride_b;
-  const int W = a.width;
+  const int W = a.width;                  // VEC: a multiple of 4 and every row 16-byte aligned (launcher)
   float* cum = nullptr;
   int len = 0;
   if (a.cum_score != nullptr && !(a.b_new_slot != nullptr && a.b_new_slot[l * new_slot_stride_layer + b] < 0)) {   // padded graph lanes
     cum = a.cum_score + l * cum_stride_layer + (int64_t)a.b_req_idx[l * req_stride_layer + b] * a.cum_stride;
     len = a.b_seqlen[l * seqlen_stride_layer + b];
   }
-  float v[EPT], c[EPT];
+  float v[E4][4], c[E4][4];
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int t = threadIdx.x + i * 1024;
-    v[i] = t < W ? mul_rn(x[t], a.scale) : -INFINITY;
-    c[i] = (cum != nullptr && t < len - 1) ? cum[t] : 0.f;
-    mx = fmaxf(mx, v[i]);
+  for (int i = 0; i < E4; ++i) {
+    const int t = (threadIdx.x + i * 256) * 4;
+    if constexpr (VEC) {
+      float4 xv = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), cv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < W) xv = *reinterpret_cast<const float4*>(x + t);
+      if (cum != nullptr && t < len - 1) cv = *reinterpret_cast<const float4*>(cum + t);   // (elements >= len - 1 are not used)
+      v[i][0] = t < W ? mul_rn(xv.x, a.scale) : -INFINITY; v[i][1] = t < W ? mul_rn(xv.y, a.scale) : -INFINITY;
+      v[i][2] = t < W ? mul_rn(xv.z, a.scale) : -INFINITY; v[i][3] = t < W ? mul_rn(xv.w, a.scale) : -INFINITY;
+      c[i][0] = cv.x; c[i][1] = cv.y; c[i][2] = cv.z; c[i][3] = cv.w;
+    } else {
+      // same element -> thread mapping and summation order with scalar accesses (any width / alignment: the eager path
+      // sizes the rows to the current maximum length): bit-identical to the 16-byte form
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][e] = t + e < W ? mul_rn(x[t + e], a.scale) : -INFINITY;
+        c[i][e] = (cum != nullptr && t + e < len - 1) ? cum[t + e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, v[i][e]);
   }
   mx = block_allmax(mx, red);
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    v[i] = expf(v[i] - mx);          // exp(-inf) = 0 for the padding lanes
-    sum += v[i];
-  }
+  for (int i = 0; i < E4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[i][e] = expf(v[i][e] - mx);          // exp(-inf) = 0 for the padding lanes
+      sum += v[i][e];
+    }
   sum = block_allsum(sum, red);
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int t = threadIdx.x + i * 1024;
+  for (int i = 0; i < E4; ++i) {
+    const int t = (threadIdx.x + i * 256) * 4;
     if (t < W) {
-      const float p = v[i] / sum;
-      x[t] = p;
-      if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : c[i] + p;   // pad(prev, 1) + p
+      float p[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p[e] = v[i][e] / sum;
+      if constexpr (VEC) {
+        *reinterpret_cast<float4*>(x + t) = make_float4(p[0], p[1], p[2], p[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (t + e < W) x[t + e] = p[e];
+      }
+      if (cum != nullptr && t < len) {
+        // pad(prev, 1) + p: positions < len - 1 add, position len - 1 starts at p, positions >= len stay untouched
+        if (VEC && t + 3 < len - 1) {
+          *reinterpret_cast<float4*>(cum + t) = make_float4(c[i][0] + p[0], c[i][1] + p[1], c[i][2] + p[2], c[i][3] + p[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (t + e < len) cum[t + e] = (t + e == len - 1) ? p[e] : c[i][e] + p[e];
+        }
+      }
     }
   }
 }
@@ -358,6 +394,10 @@ extern "C" int svk_h2o_decode_score_update_layers(const SvkH2oDecodeScoreArgs* f
   SVK_REQUIRE(first->cum_score == nullptr || (first->b_req_idx != nullptr && first->b_seqlen != nullptr), SVK_ERR_VALUE,
               "svk_h2o_decode_score_update_layers: cum_score needs b_req_idx and b_seqlen");
   if (first->batch <= 0 || n_layers == 0) return SVK_OK;
+  const bool vec_ok = first->width % 4 == 0 && first->score_stride_b % 4 == 0 && score_stride_layer % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(first->attn_score) & 15) == 0 &&
+                      (first->cum_score == nullptr || (first->cum_stride % 4 == 0 && cum_stride_layer % 4 == 0 &&
+                                                       (reinterpret_cast<uintptr_t>(first->cum_score) & 15) == 0));
   if (first->width > 1024 * 32) {      // rows that do not fit the register-resident form: layer by layer
     for (int l = 0; l < n_layers; ++l) {
       SvkH2oDecodeScoreArgs a = *first;
@@ -373,12 +413,20 @@ extern "C" int svk_h2o_decode_score_update_layers(const SvkH2oDecodeScoreArgs* f
   }
   dim3 grid(first->batch, n_layers);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int ept = (first->width + 1023) / 1024;
-#define SVK_SCORE_LAYERS(EPT_) \
-  hipLaunchKernelGGL((h2o_decode_score_layers_kernel<EPT_>), grid, dim3(1024), 0, s, *first, score_stride_layer, cum_stride_layer, new_slot_stride_layer, req_stride_layer, seqlen_stride_layer)
-  if (ept <= 2) SVK_SCORE_LAYERS(2);
-  else if (ept <= 5) SVK_SCORE_LAYERS(5);
-  else if (ept <= 16) SVK_SCORE_LAYERS(16);
+  const int e4 = ((first->width + 3) / 4 + 255) / 256;
+#define SVK_SCORE_LAYERS(E4_)                                                                                              \
+  do {                                                                                                                     \
+    if (vec_ok)                                                                                                            \
+      hipLaunchKernelGGL((h2o_decode_score_layers_kernel<E4_, true>), grid, dim3(256), 0, s, *first, score_stride_layer,   \
+                         cum_stride_layer, new_slot_stride_layer, req_stride_layer, seqlen_stride_layer);                  \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((h2o_decode_score_layers_kernel<E4_, false>), grid, dim3(256), 0, s, *first, score_stride_layer,  \
+                         cum_stride_layer, new_slot_stride_layer, req_stride_layer, seqlen_stride_layer);                  \
+  } while (0)
+  if (e4 <= 2) SVK_SCORE_LAYERS(2);
+  else if (e4 <= 5) SVK_SCORE_LAYERS(5);
+  else if (e4 <= 8) SVK_SCORE_LAYERS(8);
+  else if (e4 <= 16) SVK_SCORE_LAYERS(16);
   else SVK_SCORE_LAYERS(32);
 #undef SVK_SCORE_LAYERS
   return check_launch("svk_h2o_decode_score_update_layers");
