@@ -452,6 +452,31 @@ int svk_quest_decode_alloc(const SvkQuestDecodeAllocArgs* a, svk_stream_t stream
 #define SVK_DTYPE_BF16 1
 #define SVK_DTYPE_F16 2
 
+/* Slot bookkeeping of one DeltaKV decode step in ONE launch (engine/cache_manager/deltakv_base.py:2038-2154
+ * `prepare_decode_static`: the reference issues four indexed scatters and five buffer fills, each with its own host
+ * upload): every real lane b < batch gets one new raw slot in the full-layer pool and one in the sparse-layer pool at
+ * position cur_len of its row; the graph-stable metadata buffers are written for all graph_batch lanes (padded lanes
+ * mirror lane 0 with slot -1, like h2o.py:419-424).  `meta` is the step's host data as one upload:
+ * [5, meta_stride] int32 = row, cur_len, full_slot, sparse_slot, compressed_len of lanes [0, batch). */
+typedef struct SvkDeltakvDecodeAllocArgs {
+  const int32_t* meta;
+  int64_t meta_stride;
+  int32_t* full_slots_map;        /* [rows, full_map_stride]   <- full_slot at [row, cur_len]   */
+  int64_t full_map_stride;
+  int32_t* full_slot_to_pos;      /* [full slots]              <- cur_len at [full_slot]        */
+  int32_t* sparse_raw_slots_map;  /* [rows, sparse_map_stride] <- sparse_slot at [row, cur_len] */
+  int64_t sparse_map_stride;
+  int32_t* sparse_slot_to_pos;    /* [sparse slots]            <- cur_len at [sparse_slot]      */
+  int32_t* context_lens;          /* [graph_batch] cur_len + 1                                   */
+  int32_t* req_indices;           /* [graph_batch] row                                           */
+  int32_t* slot_mapping;          /* [graph_batch] full_slot   (-1 on padded lanes)              */
+  int32_t* sparse_slot_mapping;   /* [graph_batch] sparse_slot (-1 on padded lanes)              */
+  int32_t* compressed_lens;       /* [graph_batch]                                               */
+  int32_t batch;
+  int32_t graph_batch;
+} SvkDeltakvDecodeAllocArgs;
+int svk_deltakv_decode_alloc(const SvkDeltakvDecodeAllocArgs* a, svk_stream_t stream);
+
 /* Sparse-layer view + reconstruct work list of one decode step:
  *   row b = [sink raw slots | for j < min(clen,K): temp slot if the selected compressed position has a
  *            latent else its raw slot | up to max_buffer recent raw slots], padding = first sink slot;

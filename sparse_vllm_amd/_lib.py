@@ -146,6 +146,13 @@ class SvkPrefillScoreArgs(C.Structure):
                 ("num_recent_tokens", _i32), ("score_mode", _i32)]
 
 
+class SvkDeltakvDecodeAllocArgs(C.Structure):
+    _fields_ = [("meta", _p), ("meta_stride", C.c_int64), ("full_slots_map", _p), ("full_map_stride", C.c_int64),
+                ("full_slot_to_pos", _p), ("sparse_raw_slots_map", _p), ("sparse_map_stride", C.c_int64),
+                ("sparse_slot_to_pos", _p), ("context_lens", _p), ("req_indices", _p), ("slot_mapping", _p),
+                ("sparse_slot_mapping", _p), ("compressed_lens", _p), ("batch", C.c_int32), ("graph_batch", C.c_int32)]
+
+
 class SvkDeltakvPlanArgs(C.Structure):
     _fields_ = [("raw_slots_map", _p), ("latent_slots_map", _p), ("active_compressed", _p), ("req_indices", _p),
                 ("context_lens", _p), ("compressed_lens", _p), ("temp_slots", _p), ("active_slots_out", _p),
@@ -269,6 +276,7 @@ ENTRY_POINTS = {
     "svk_decode_alloc_slots": ([C.POINTER(SvkDecodeAllocArgs), _p], C.c_int),
     "svk_prefill_score_workspace_bytes": ([_i32, _i32, _i32, _i32, _i32], C.c_int64),
     "svk_prefill_score": ([C.POINTER(SvkPrefillScoreArgs), _p], C.c_int),
+    "svk_deltakv_decode_alloc": ([C.POINTER(SvkDeltakvDecodeAllocArgs), _p], C.c_int),
     "svk_deltakv_static_decode_plan": ([C.POINTER(SvkDeltakvPlanArgs), _p], C.c_int),
     "svk_deltakv_reconstruct_writeback": ([C.POINTER(SvkDeltakvReconstructArgs), _p], C.c_int),
     "svk_dequantize_grouped": ([C.POINTER(SvkDequantGroupedArgs), _p], C.c_int),

@@ -551,8 +551,43 @@ int topk_plan_chunks(int n, int k) {
   return chunk <= 32768 ? chunks : 0;                            // chunk stage: 128 KiB of keys, no sort buffer
 }
 
+__global__ void __launch_bounds__(256) deltakv_decode_alloc_kernel(const SvkDeltakvDecodeAllocArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.graph_batch) return;
+  const int src = b < a.batch ? b : 0;               // padded graph lanes mirror lane 0
+  const int row = a.meta[src], cur = a.meta[a.meta_stride + src];
+  const int clen = a.meta[4 * a.meta_stride + src];
+  int fs = -1, ss = -1;
+  if (b < a.batch) {
+    fs = a.meta[2 * a.meta_stride + b];
+    ss = a.meta[3 * a.meta_stride + b];
+    a.full_slots_map[(int64_t)row * a.full_map_stride + cur] = fs;
+    a.full_slot_to_pos[fs] = cur;
+    a.sparse_raw_slots_map[(int64_t)row * a.sparse_map_stride + cur] = ss;
+    a.sparse_slot_to_pos[ss] = cur;
+  }
+  a.context_lens[b] = cur + 1;
+  a.req_indices[b] = row;
+  a.slot_mapping[b] = fs;
+  a.sparse_slot_mapping[b] = ss;
+  a.compressed_lens[b] = clen;
+}
+
 }  // namespace
 }  // namespace svk
+
+extern "C" int svk_deltakv_decode_alloc(const SvkDeltakvDecodeAllocArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->meta != nullptr, SVK_ERR_VALUE, "svk_deltakv_decode_alloc: null args");
+  SVK_REQUIRE(a->batch > 0, SVK_ERR_VALUE, "Static DeltaKV decode requires a non-empty real decode batch.");
+  SVK_REQUIRE(a->graph_batch >= a->batch, SVK_ERR_VALUE,
+              "Static DeltaKV decode graph batch is smaller than the real decode batch: graph=%d, real=%d.", a->graph_batch, a->batch);
+  SVK_REQUIRE(a->meta_stride >= a->batch, SVK_ERR_VALUE, "svk_deltakv_decode_alloc: meta_stride %lld < batch %d",
+              (long long)a->meta_stride, a->batch);
+  hipLaunchKernelGGL(deltakv_decode_alloc_kernel, dim3((a->graph_batch + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_deltakv_decode_alloc");
+}
 
 extern "C" int svk_deltakv_static_decode_plan(const SvkDeltakvPlanArgs* a, svk_stream_t stream) {
   using namespace svk;

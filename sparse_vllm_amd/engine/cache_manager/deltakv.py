@@ -516,27 +516,20 @@ class DeltaKVCacheManager(CacheManager):
             slot_mapping = own_slot_mapping if slot_mapping is None else slot_mapping
             context_lens = own_ctx if context_lens is None else context_lens
             req_indices = own_req if req_indices is None else req_indices
-            rows_gpu = torch.from_numpy(rows).to(d)
-            cols_gpu = torch.from_numpy(cur.astype(np.int64)).to(d)
-            fs_gpu, ss_gpu = torch.from_numpy(full_slots).to(d), torch.from_numpy(sparse_slots).to(d)
-            self.full_layer_slots_map[rows_gpu, cols_gpu] = fs_gpu
-            self.full_layer_slot_to_pos[fs_gpu.long()] = cols_gpu.to(torch.int32)
-            self.sparse_layer_raw_slots_map[rows_gpu, cols_gpu] = ss_gpu
-            self.deltakv_slot_to_pos[ss_gpu.long()] = cols_gpu.to(torch.int32)
+            # the step's host data as ONE upload, the four map scatters and five buffer fills as ONE launch
+            # (svk_deltakv_decode_alloc; the reference issues them one by one, each with its own small upload: ~0.45 ms
+            # of host-driven copies per step in front of a 2.1 ms graph replay)
+            clens = self.row_deltakv_compressed_lens[rows]
+            meta = np.stack([rows, cur, full_slots, sparse_slots, clens]).astype(np.int32)
+            meta_gpu = torch.from_numpy(meta).to(d, non_blocking=True)
             self.row_seq_lens[rows] += 1
             real_lens = self.row_seq_lens[rows]
-            clens = self.row_deltakv_compressed_lens[rows]
-
-            def fill(dst, vals, pad):
-                dst[:B].copy_(torch.from_numpy(np.asarray(vals, dtype=np.int32)).to(d))
-                if GB > B:
-                    dst[B:].fill_(int(pad))
-
-            fill(context_lens, real_lens, real_lens[0])
-            fill(req_indices, rows, rows[0])
-            fill(slot_mapping, full_slots, -1)
-            fill(sparse_mapping, sparse_slots, -1)
-            fill(compressed, clens, clens[0])
+            dk.deltakv_decode_alloc(meta_gpu, batch=B, full_slots_map=self.full_layer_slots_map,
+                                    full_slot_to_pos=self.full_layer_slot_to_pos,
+                                    sparse_raw_slots_map=self.sparse_layer_raw_slots_map,
+                                    sparse_slot_to_pos=self.deltakv_slot_to_pos, context_lens=context_lens,
+                                    req_indices=req_indices, slot_mapping=slot_mapping, sparse_slot_mapping=sparse_mapping,
+                                    compressed_lens=compressed)
             self._deltakv_decode_static_slot_mapping = sparse_mapping
             self._deltakv_decode_static_compressed_lens = compressed
             cap = self._decode_static_max_context_len
@@ -654,8 +647,9 @@ class DeltaKVCacheManager(CacheManager):
         self._deltakv_decode_static_active_pos = active_pos
         return active_slots, local_req, new_context_lens, no_free, recon_pos, recon_latent, recon_out_slot
 
-    def _load_residual(self, l_idx: int, recon_latent: torch.Tensor) -> torch.Tensor:
-        """deltakv_less_memory.py:2841-2848: latent gather -> (int4 dequant) -> compress_up (library GEMMs)."""
+    def _load_residual(self, l_idx: int, recon_latent: torch.Tensor, bufs=None) -> torch.Tensor:
+        """deltakv_less_memory.py:2841-2848: latent gather -> (int4 dequant) -> compress_up (library GEMMs).
+        `bufs` = (hidden, delta) caller-owned outputs of the two Linear layers (look-ahead on the side stream)."""
         if int(self.config.kv_quant_bits or 0) == 4:
             cache = self.deltakv_latent_cache[l_idx]
             up = self.compress_up[l_idx]
@@ -665,14 +659,87 @@ class DeltaKVCacheManager(CacheManager):
                 lin1, lin2 = fused
                 h = dk.dequant_linear_act(cache, self.deltakv_latent_scales[l_idx], self.deltakv_latent_mins[l_idx],
                                           self._quant_group_size(), lin1.weight, lin1.bias, activation="gelu",
-                                          row_index=recon_latent)
-                return torch.nn.functional.linear(h, lin2.weight, lin2.bias)
+                                          row_index=recon_latent, out=None if bufs is None else bufs[0])
+                if bufs is None or lin2.bias is None:
+                    return torch.nn.functional.linear(h, lin2.weight, lin2.bias)
+                return torch.addmm(lin2.bias, h, lin2.weight.t(), out=bufs[1])
             # gather + dequant in one launch (row_index = recon_latent, -1 entries read latent 0 and are never written back)
             residual = dk.dequantize_grouped(cache, self.deltakv_latent_scales[l_idx], self.deltakv_latent_mins[l_idx],
                                              self._quant_group_size(), int(cache.shape[-1]) * 8, 4, row_index=recon_latent)
         else:
             residual = self.deltakv_latent_cache[l_idx, recon_latent.clamp_min(0).long()]
         return self.compress_up[l_idx](residual)
+
+    def _recon_lookahead_buffers(self, l_idx: int, n: int):
+        """Caller-owned (hidden, delta) buffers of one sparse layer for the look-ahead reconstruction, or None when the
+        layer's compress_up is not the fused two-Linear form."""
+        if int(self.config.kv_quant_bits or 0) != 4:
+            return None
+        fused = self._fused_up_parts(self.compress_up[l_idx], self.deltakv_latent_cache[l_idx])
+        if fused is None or fused[1].bias is None:
+            return None
+        store = self.__dict__.setdefault("_recon_bufs", {})
+        cur = store.get(l_idx)
+        hid, out = int(fused[0].weight.shape[0]), int(fused[1].weight.shape[0])
+        if cur is None or cur[0].shape[0] < n:
+            cur = (torch.empty((n, hid), dtype=torch.bfloat16, device=self.device),
+                   torch.empty((n, out), dtype=torch.bfloat16, device=self.device))
+            store[l_idx] = cur
+        return cur[0][:n], cur[1][:n]
+
+    def _reconstruct_layer(self, l_idx: int, recon_pos, recon_latent, recon_out_slot, bufs=None):
+        k_cache, v_cache = self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx]
+        with profiler.record("deltakv_less_memory_reconstruct_load_residual"):
+            kv_delta = self._load_residual(l_idx, recon_latent, bufs)
+        with profiler.record("deltakv_less_memory_reconstruct_writeback"):
+            # fathers = latent_to_full_slots[l, recon_latent.clamp_min(0)].clamp_min(0), resolved in-kernel
+            dk.deltakv_reconstruct_writeback_grouped_heads(
+                kv_delta=kv_delta, father_slots=self.deltakv_latent_to_full_slots[l_idx], father_index=recon_latent,
+                slot_to_pos=self.deltakv_slot_to_pos,
+                out_slots=recon_out_slot, out_pos=recon_pos, cos_sin=self.cos_sin_cache, k_cache=k_cache,
+                v_cache=v_cache, k_norm_weight=None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx],
+                k_norm_eps=float(self.deltakv_k_norm_eps), raw_k_cache=True, store_raw_k=False)
+
+    @staticmethod
+    def _recon_lookahead_enabled() -> bool:
+        import os
+        return os.environ.get("SVK_DELTAKV_RECON_AHEAD", "1") == "1"
+
+    def _group_sparse_layers(self, layer_idx: int) -> list[int]:
+        """The sparse layers that share the plan of `layer_idx`: the run of sparse layers it starts, up to the next
+        full-attention layer."""
+        out, l = [], int(layer_idx)
+        while l < self.num_layers and l in self.deltakv_layer_to_idx:
+            out.append(l)
+            l += 1
+        return out
+
+    def _reconstruct_group_ahead(self, layer_idx: int, recon_pos, recon_latent, recon_out_slot) -> bool:
+        """MI355X: the residual load and reconstruction of a sparse layer depend on the plan of its observation group and
+        on the layer's own caches, not on the step's activations - so all layers of the group are issued NOW, back to
+        back on a side stream (three launches, ~43 us per layer at 2048 tokens), while the main stream walks the layers
+        (store, view, attention: ~25 us per layer here, plus the dense model in a real engine) and only waits for the
+        layer's event before it builds the view.  Per step of the 256 k configuration: 2.67 -> see DESIGN.md 4.8."""
+        layers = self._group_sparse_layers(layer_idx)
+        n = int(recon_latent.numel())
+        bufs = {l: self._recon_lookahead_buffers(self.deltakv_layer_to_idx[l], n) for l in layers}
+        if len(layers) < 2 or any(b is None for b in bufs.values()):
+            return False
+        side = self.__dict__.get("_recon_stream")
+        if side is None:
+            side = self._recon_stream = torch.cuda.Stream(device=self.device)
+            self._recon_events = {}
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)                       # the plan (and everything before it) is complete for the side stream
+        with torch.cuda.stream(side):
+            for l in layers:
+                self._reconstruct_layer(self.deltakv_layer_to_idx[l], recon_pos, recon_latent, recon_out_slot, bufs[l])
+                ev = self._recon_events.get(l)
+                if ev is None:
+                    ev = self._recon_events[l] = torch.cuda.Event()
+                ev.record(side)
+        self._recon_ahead = {l: True for l in layers}
+        return True
 
     @staticmethod
     def _fused_up_parts(up, cache):
@@ -712,21 +779,22 @@ class DeltaKVCacheManager(CacheManager):
         """deltakv_less_memory.py:4032-4143 (static decode branch)."""
         del context_lens, chunk_lens, return_reconstruct_temp_slots
         with profiler.record("deltakv_less_memory_reconstruct_total"):
+            plan_before = self._deltakv_view_cache_value
             active_slots, local_req, new_context_lens, temp_slots, recon_pos, recon_latent, recon_out_slot = \
                 self._deltakv_build_view_and_plan_reconstruct(layer_idx, active_compressed_indices, req_indices)
+            fresh_plan = self._deltakv_view_cache_value is not plan_before
             l_idx = self.deltakv_layer_to_idx[layer_idx]
-            k_cache, v_cache = self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx]
             if recon_latent.numel() > 0:
-                with profiler.record("deltakv_less_memory_reconstruct_load_residual"):
-                    kv_delta = self._load_residual(l_idx, recon_latent)
-                with profiler.record("deltakv_less_memory_reconstruct_writeback"):
-                    # fathers = latent_to_full_slots[l, recon_latent.clamp_min(0)].clamp_min(0), resolved in-kernel
-                    dk.deltakv_reconstruct_writeback_grouped_heads(
-                        kv_delta=kv_delta, father_slots=self.deltakv_latent_to_full_slots[l_idx], father_index=recon_latent,
-                        slot_to_pos=self.deltakv_slot_to_pos,
-                        out_slots=recon_out_slot, out_pos=recon_pos, cos_sin=self.cos_sin_cache, k_cache=k_cache,
-                        v_cache=v_cache, k_norm_weight=None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx],
-                        k_norm_eps=float(self.deltakv_k_norm_eps), raw_k_cache=True, store_raw_k=False)
+                ahead = self.__dict__.get("_recon_ahead") or {}
+                if fresh_plan:
+                    ahead = self._recon_ahead = {}
+                    if self._recon_lookahead_enabled():
+                        self._reconstruct_group_ahead(layer_idx, recon_pos, recon_latent, recon_out_slot)
+                        ahead = self._recon_ahead
+                if ahead.pop(int(layer_idx), False):
+                    torch.cuda.current_stream().wait_event(self._recon_events[int(layer_idx)])
+                else:
+                    self._reconstruct_layer(l_idx, recon_pos, recon_latent, recon_out_slot)
             # static decode: the post-RoPE slots of this layer are exactly the reconstruct scratch slots the plan put
             # into the view, so the attention view identifies them positionally (no per-layer mask maintenance;
             # `_set_postrope_slots` remains for callers that want the reference's mask)

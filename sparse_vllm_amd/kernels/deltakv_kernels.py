@@ -190,7 +190,31 @@ def dequantize_grouped(packed, scale, mn, group_size: int, output_dim: int, bits
     return out
 
 
-def dequant_linear_act(packed, scale, mn, group_size: int, weight, bias=None, *, activation: str = "gelu", row_index=None):
+def deltakv_decode_alloc(meta, *, batch: int, full_slots_map, full_slot_to_pos, sparse_raw_slots_map, sparse_slot_to_pos,
+                         context_lens, req_indices, slot_mapping, sparse_slot_mapping, compressed_lens):
+    """Slot bookkeeping of one DeltaKV decode step (deltakv_base.py:2038-2154 `prepare_decode_static`, device half) in
+    one launch: `meta` [5, >= batch] int32 on the device = row, cur_len, full_slot, sparse_slot, compressed_len per real
+    lane; the five graph-stable buffers are written for all their lanes (padded lanes mirror lane 0, slots -1)."""
+    gb = int(context_lens.numel())
+    assert meta.dtype == torch.int32 and meta.dim() == 2 and meta.shape[0] == 5 and meta.stride(1) == 1 and meta.shape[1] >= batch
+    for t in (full_slots_map, full_slot_to_pos, sparse_raw_slots_map, sparse_slot_to_pos, context_lens, req_indices,
+              slot_mapping, sparse_slot_mapping, compressed_lens):
+        assert t.dtype == torch.int32 and t.stride(-1) == 1
+    for t in (req_indices, slot_mapping, sparse_slot_mapping, compressed_lens):
+        assert int(t.numel()) >= gb
+    lib = _lib.load()
+    a = _lib.SvkDeltakvDecodeAllocArgs(
+        meta=_lib.ptr(meta), meta_stride=meta.stride(0), full_slots_map=_lib.ptr(full_slots_map),
+        full_map_stride=full_slots_map.stride(0), full_slot_to_pos=_lib.ptr(full_slot_to_pos),
+        sparse_raw_slots_map=_lib.ptr(sparse_raw_slots_map), sparse_map_stride=sparse_raw_slots_map.stride(0),
+        sparse_slot_to_pos=_lib.ptr(sparse_slot_to_pos), context_lens=_lib.ptr(context_lens), req_indices=_lib.ptr(req_indices),
+        slot_mapping=_lib.ptr(slot_mapping), sparse_slot_mapping=_lib.ptr(sparse_slot_mapping),
+        compressed_lens=_lib.ptr(compressed_lens), batch=int(batch), graph_batch=gb)
+    _lib.check(lib.svk_deltakv_decode_alloc(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+def dequant_linear_act(packed, scale, mn, group_size: int, weight, bias=None, *, activation: str = "gelu", row_index=None,
+                       out=None):
     """`act(F.linear(dequant_int4(packed[row_index]), weight, bias))` as one MFMA launch (MI355X fusion of the residual
     load's dequantisation with the first Linear (+ erf-GELU) of `compress_up`; `_load_residual`,
     deltakv_less_memory.py:2841-2848, utils/compressor.py:69-73).  bf16 weights and output, int4 codes."""
@@ -217,7 +241,10 @@ def dequant_linear_act(packed, scale, mn, group_size: int, weight, bias=None, *,
     if row_index is not None:
         assert row_index.dtype == torch.int32 and row_index.is_contiguous()
     n = src_rows if row_index is None else int(row_index.numel())
-    out = torch.empty((n, N), device=packed.device, dtype=torch.bfloat16)
+    if out is None:
+        out = torch.empty((n, N), device=packed.device, dtype=torch.bfloat16)
+    else:       # caller-owned buffer (work issued ahead on a side stream must not borrow from the caching allocator)
+        assert out.dtype == torch.bfloat16 and tuple(out.shape) == (n, N) and out.stride(1) == 1
     lib = _lib.load()
     a = _lib.SvkDequantLinearArgs(packed=_lib.ptr(packed), scale=_lib.ptr(scale), mn=_lib.ptr(mn), row_index=_lib.ptr(row_index),
                                   weight=_lib.ptr(weight), bias=_lib.ptr(bias), out=_lib.ptr(out),

@@ -352,3 +352,47 @@ def test_topk_sorted_desc_equals_stable_argsort(n, k, kind):
     idx = topk_sorted_desc(t(x), k).cpu().numpy()
     ref = np.argsort(-x, axis=1, kind="stable")[:, :k]
     np.testing.assert_array_equal(idx, ref)
+
+
+def test_deltakv_decode_alloc_matches_numpy():
+    """svk_deltakv_decode_alloc (deltakv_base.py:2038-2154, device half): four map scatters + five metadata buffers of a
+    decode step, padded graph lanes mirroring lane 0 with slot -1."""
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    rng = np.random.default_rng(5)
+    d = torch.device("cuda:0")
+    rows_n, width, n_full, n_sparse, B, GB = 7, 50, 90, 120, 3, 5
+    full_map = rng.integers(0, n_full, (rows_n, width)).astype(np.int32)
+    sparse_map = rng.integers(-1, n_sparse, (rows_n, width)).astype(np.int32)
+    full_pos = rng.integers(-1, width, n_full).astype(np.int32)
+    sparse_pos = rng.integers(-1, width, n_sparse).astype(np.int32)
+    rows = np.array([4, 0, 6], np.int32)
+    cur = np.array([17, 3, 49], np.int32)
+    fs = np.array([11, 80, 5], np.int32)
+    ss = np.array([100, 7, 64], np.int32)
+    cl = np.array([9, 0, 32], np.int32)
+    meta = torch.from_numpy(np.stack([rows, cur, fs, ss, cl])).to(d)
+    t = lambda x: torch.from_numpy(x.copy()).to(d)
+    g_full_map, g_sparse_map, g_full_pos, g_sparse_pos = t(full_map), t(sparse_map), t(full_pos), t(sparse_pos)
+    outs = [torch.full((GB,), 777, dtype=torch.int32, device=d) for _ in range(5)]
+    dk.deltakv_decode_alloc(meta, batch=B, full_slots_map=g_full_map, full_slot_to_pos=g_full_pos,
+                            sparse_raw_slots_map=g_sparse_map, sparse_slot_to_pos=g_sparse_pos, context_lens=outs[0],
+                            req_indices=outs[1], slot_mapping=outs[2], sparse_slot_mapping=outs[3], compressed_lens=outs[4])
+    torch.cuda.synchronize()
+    full_map[rows, cur] = fs
+    sparse_map[rows, cur] = ss
+    full_pos[fs] = cur
+    sparse_pos[ss] = cur
+    np.testing.assert_array_equal(g_full_map.cpu().numpy(), full_map)
+    np.testing.assert_array_equal(g_sparse_map.cpu().numpy(), sparse_map)
+    np.testing.assert_array_equal(g_full_pos.cpu().numpy(), full_pos)
+    np.testing.assert_array_equal(g_sparse_pos.cpu().numpy(), sparse_pos)
+    pad = GB - B
+    np.testing.assert_array_equal(outs[0].cpu().numpy(), np.concatenate([cur + 1, [cur[0] + 1] * pad]))
+    np.testing.assert_array_equal(outs[1].cpu().numpy(), np.concatenate([rows, [rows[0]] * pad]))
+    np.testing.assert_array_equal(outs[2].cpu().numpy(), np.concatenate([fs, [-1] * pad]))
+    np.testing.assert_array_equal(outs[3].cpu().numpy(), np.concatenate([ss, [-1] * pad]))
+    np.testing.assert_array_equal(outs[4].cpu().numpy(), np.concatenate([cl, [cl[0]] * pad]))
+    with pytest.raises(ValueError, match="graph batch is smaller"):
+        dk.deltakv_decode_alloc(meta, batch=B, full_slots_map=g_full_map, full_slot_to_pos=g_full_pos,
+                                sparse_raw_slots_map=g_sparse_map, sparse_slot_to_pos=g_sparse_pos, context_lens=outs[0][:2],
+                                req_indices=outs[1], slot_mapping=outs[2], sparse_slot_mapping=outs[3], compressed_lens=outs[4])
