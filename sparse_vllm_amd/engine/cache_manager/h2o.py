@@ -276,6 +276,12 @@ class H2OCacheManager(SnapKVCacheManager):
         periodic_trigger = budget + self.h2o_decode_eviction_interval
         under_pressure = self.num_free_slots <= 0
         trigger = budget + 1 if under_pressure else periodic_trigger
+        if not under_pressure:
+            # the common step evicts nothing: one numpy gather over all (layer, sequence) lengths decides it (the loop
+            # below is 28 x B Python iterations per decode step)
+            kv = self.decode_kv_lens_all_layers(seqs)
+            if kv is not None and bool((kv == kv[0]).all()) and not bool((kv[0] >= trigger).any()):
+                return layer_indices, {}
         seq_by_id = {int(s.seq_id): s for s in seqs}
         candidate_ids = list(seq_ids)
         if under_pressure:

@@ -230,6 +230,16 @@ class SnapKVCacheManager(CacheManager):
     def pop_prefill_attention_score(self, layer_idx: int, seq):
         return self._prefill_attn_score_accumulators.pop((int(layer_idx), int(seq.seq_id)), None)
 
+    def decode_kv_lens_all_layers(self, seqs):
+        """[KV layers, len(seqs)] physical row lengths as one numpy gather, for the decode sequences whose row matrix
+        `prepare_decode_static` cached this step (None otherwise): per-step policy checks need no Python loop over
+        layers x sequences."""
+        cached = getattr(self, "_decode_static_rows", None)
+        if cached is None or cached[0][0] != tuple(s.seq_id for s in seqs):
+            return None
+        _, rows_2d, _, kv_idx = cached[:4]
+        return self._row_seq_lens_all[kv_idx[:, None], rows_2d]
+
     def decode_kv_lens_for_layer(self, layer_idx: int, seqs) -> list[int]:
         """snapkv.py:1516-1527."""
         return [int(self.row_seq_lens[layer_idx][self._row_of(layer_idx, s)]) for s in seqs]
