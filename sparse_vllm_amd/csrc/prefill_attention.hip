@@ -309,7 +309,12 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
       qt = j * (8 / ny) + xcd / ny;
     }
   }
-  const int head = kvh * G + w;
+  // G compute waves (wave = query head) + for G <= 7 one helper wave that issues all of the workgroup's DMA: it sits on
+  // the SIMD that holds a single compute wave, and the compute waves' instruction streams lose the ~0.3 us per tile of
+  // slot-id reads, address arithmetic and DMA issue
+  const bool has_helper = (int)(blockDim.x >> 6) > G;
+  const bool helper = has_helper && w == G;
+  const int head = kvh * G + min(w, G - 1);
   const int lq = lane & 31, half = lane >> 5;
   const int pc = a.b_prompt_cache_len[b];
   const int q_len = a.b_seq_len[b] - pc;
@@ -399,14 +404,16 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
       pa_dma4x16(src, dst);
     }
   };
+  const int g_first = has_helper ? (helper ? 0 : 8) : widx, g_step = has_helper ? 1 : G;
   auto issue_tile = [&](int t) {
-    for (int g = widx; g < 8; g += G) {
+    for (int g = g_first; g < 8; g += g_step) {
       if (g < 4) issue_group(t, g, std::false_type{}); else issue_group(t, g, std::true_type{});
     }
   };
   // slot ids of tile t: 64 x 4 bytes by LDS-DMA as well (wave 0), straight into the id buffer t & 1 - no register in flight
+  const int ids_wave = has_helper ? G : 0;
   auto issue_ids = [&](int t) {
-    if (w == 0) {
+    if (w == ids_wave) {
       const int32_t* p = row + min(t * kKV2 + lane, kv_end - 1);
       uint32_t keep;
       const uint32_t dst = __builtin_amdgcn_readfirstlane(
@@ -447,6 +454,18 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   //      block j (only when some row's maximum moved) sits between C(j-1) and C(j).  Tile t+1 must have landed before
   //      A(2t+2) in step 2t+1 and tile t-1 is read last by C(2t-1) in step 2t: the workgroup barrier of tile t sits
   //      between those two steps and the DMA of tile t+2 is issued right behind it - a ring of three tile buffers.
+  if (helper) {
+    // one barrier per tile like the compute waves: behind barrier t, tile t+1 has landed (this wave's DMA drained) and
+    // tile t-1 is dead, so tile t+2 and the ids of tile t+3 go out
+    for (int t = 0; t < ntiles; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 2 < ntiles) issue_tile(t + 2);
+      if (t + 3 < ntiles) issue_ids(t + 3);
+    }
+    __syncthreads();
+    return;
+  }
   uint32_t ob_prev = 2 * kBuf, ob_cur = 0, ob_next = kBuf;          // ring offsets of tiles t-1, t, t+1
   f32x16_t s_a, s_b;                                                 // S of the even / odd block of a tile
   {
@@ -658,8 +677,10 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(context_attention_kernel_v2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
-    if (off32) hipLaunchKernelGGL((context_attention_kernel_v2<true>), grid, block, shm2, s, *a);
-    else hipLaunchKernelGGL((context_attention_kernel_v2<false>), grid, block, shm2, s, *a);
+    static const int use_helper = getenv("SVK_PREFILL_ATTN_HELPER") ? atoi(getenv("SVK_PREFILL_ATTN_HELPER")) : 1;
+    const dim3 block2(64 * (G + ((G <= 7 && use_helper) ? 1 : 0)));
+    if (off32) hipLaunchKernelGGL((context_attention_kernel_v2<true>), grid, block2, shm2, s, *a);
+    else hipLaunchKernelGGL((context_attention_kernel_v2<false>), grid, block2, shm2, s, *a);
     return check_launch("svk_context_attention_fwd");
   }
   if (a->head_dim == 128) {
