@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 5
+#define SVK_ABI_VERSION 6
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -537,6 +537,14 @@ typedef struct SvkDeltakvReconstructArgs {
   int64_t father_table_stride;
 } SvkDeltakvReconstructArgs;
 int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs* a, svk_stream_t stream);
+/* The dense-delta decode form for `n_batch` layers in one launch (same plan: out_slots / out_pos / father_index shared;
+ * delta, the father table, the K / V caches and the k-norm weight advance by their per-layer element strides). */
+typedef struct SvkDeltakvReconstructBatch {
+  int32_t n_batch;
+  int64_t delta_stride_batch, father_table_stride_batch, kv_cache_stride_batch, k_norm_stride_batch;
+} SvkDeltakvReconstructBatch;
+int svk_deltakv_reconstruct_writeback_batched(const SvkDeltakvReconstructArgs* first, const SvkDeltakvReconstructBatch* b,
+                                              svk_stream_t stream);
 
 /* out[r, f] = code(r, f) * scale[r, f/group] + mn[r, f/group]; codes are `bits`-wide fields packed
  * LSB-first into int32.  Replaces triton_dequantize_2d_int4_grouped (kernels/triton/quant.py:160-216) and
@@ -573,6 +581,14 @@ typedef struct SvkDequantLinearArgs {
   int32_t activation;       /* 0 = none, 1 = erf-GELU                              */
 } SvkDequantLinearArgs;
 int svk_dequant_linear_act(const SvkDequantLinearArgs* a, svk_stream_t stream);
+/* The same for `n_batch` layers in one launch: `first` describes layer 0, layer z adds z * (the element stride of the
+ * field's tensor between consecutive layers); row_index is shared.  (DeltaKV sparse layers of one observation group:
+ * their residual loads depend on the group's plan only, deltakv_less_memory.py:2841-2848 per layer.) */
+typedef struct SvkDequantLinearBatch {
+  int32_t n_batch;
+  int64_t packed_stride_batch, scale_stride_batch, weight_stride_batch, bias_stride_batch, out_stride_batch;
+} SvkDequantLinearBatch;
+int svk_dequant_linear_act_batched(const SvkDequantLinearArgs* first, const SvkDequantLinearBatch* b, svk_stream_t stream);
 
 /* Attention-facing contiguous copy of a DeltaKV sparse layer's active slots: entry n = b*width + w takes slot
  * active_slots[b, w] (clamped into [0, num_slots)); V is copied; K is copied when postrope_mask[slot] != 0,

@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 5
+SVK_ABI_VERSION = 6
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -144,6 +144,16 @@ class SvkPrefillScoreArgs(C.Structure):
                 ("n_ranges", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
                 ("max_query_len", _i32), ("score_cols", _i32), ("candidate_start", _i32),
                 ("num_recent_tokens", _i32), ("score_mode", _i32)]
+
+
+class SvkDequantLinearBatch(C.Structure):
+    _fields_ = [("n_batch", C.c_int32), ("packed_stride_batch", C.c_int64), ("scale_stride_batch", C.c_int64),
+                ("weight_stride_batch", C.c_int64), ("bias_stride_batch", C.c_int64), ("out_stride_batch", C.c_int64)]
+
+
+class SvkDeltakvReconstructBatch(C.Structure):
+    _fields_ = [("n_batch", C.c_int32), ("delta_stride_batch", C.c_int64), ("father_table_stride_batch", C.c_int64),
+                ("kv_cache_stride_batch", C.c_int64), ("k_norm_stride_batch", C.c_int64)]
 
 
 class SvkDeltakvDecodeAllocArgs(C.Structure):
@@ -279,8 +289,10 @@ ENTRY_POINTS = {
     "svk_deltakv_decode_alloc": ([C.POINTER(SvkDeltakvDecodeAllocArgs), _p], C.c_int),
     "svk_deltakv_static_decode_plan": ([C.POINTER(SvkDeltakvPlanArgs), _p], C.c_int),
     "svk_deltakv_reconstruct_writeback": ([C.POINTER(SvkDeltakvReconstructArgs), _p], C.c_int),
+    "svk_deltakv_reconstruct_writeback_batched": ([C.POINTER(SvkDeltakvReconstructArgs), C.POINTER(SvkDeltakvReconstructBatch), _p], C.c_int),
     "svk_dequantize_grouped": ([C.POINTER(SvkDequantGroupedArgs), _p], C.c_int),
     "svk_dequant_linear_act": ([C.POINTER(SvkDequantLinearArgs), _p], C.c_int),
+    "svk_dequant_linear_act_batched": ([C.POINTER(SvkDequantLinearArgs), C.POINTER(SvkDequantLinearBatch), _p], C.c_int),
     "svk_deltakv_token_scores": ([C.POINTER(SvkDeltakvTokenScoresArgs), _p], C.c_int),
     "svk_deltakv_token_scores_chunks": ([_i32], C.c_int),
     "svk_topk_sorted_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),

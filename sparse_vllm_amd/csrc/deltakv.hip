@@ -192,7 +192,17 @@ __global__ void __launch_bounds__(256) deltakv_reconstruct_kernel(const SvkDelta
 // row is fetched as 16-byte pieces (4 loads per father per lane instead of 32 two-byte ones).  Element arithmetic and
 // order are those of the scalar kernel above; only the k-norm sum of squares is reduced in a different order.
 template <int D>
-__global__ void __launch_bounds__(256) deltakv_reconstruct_vec_kernel(const SvkDeltakvReconstructArgs a) {
+__global__ void __launch_bounds__(256) deltakv_reconstruct_vec_kernel(const SvkDeltakvReconstructArgs a_in,
+                                                                      const SvkDeltakvReconstructBatch lb) {
+  SvkDeltakvReconstructArgs a = a_in;
+  if (gridDim.y > 1) {                  // layer y of a batched launch (dense bf16 delta): per-layer tensors advance
+    const int64_t z = blockIdx.y;
+    a.delta = reinterpret_cast<const uint16_t*>(a.delta) + z * lb.delta_stride_batch;
+    if (a.father_table != nullptr) a.father_table += z * lb.father_table_stride_batch;
+    a.k_cache += z * lb.kv_cache_stride_batch;
+    a.v_cache += z * lb.kv_cache_stride_batch;
+    if (a.k_norm_weight != nullptr) a.k_norm_weight += z * lb.k_norm_stride_batch;
+  }
   constexpr int HD2 = D / 2, LPH = HD2 / 8;
   const int H = a.num_kv_heads;
   const int lanes_per_entry = LPH * H;
@@ -614,8 +624,9 @@ extern "C" int svk_dequantize_grouped(const SvkDequantGroupedArgs* a, svk_stream
   return check_launch("svk_dequantize_grouped");
 }
 
-extern "C" int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs* a, svk_stream_t stream) {
-  using namespace svk;
+namespace svk {
+namespace {
+int launch_reconstruct(const SvkDeltakvReconstructArgs* a, const SvkDeltakvReconstructBatch& lb, svk_stream_t stream) {
   SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_deltakv_reconstruct_writeback: null args");
   SVK_REQUIRE(a->head_dim % 2 == 0 && a->head_dim > 0, SVK_ERR_LAYOUT, "head_dim must be even");
   SVK_REQUIRE(a->delta_bits == 0 || a->delta_bits == 2 || a->delta_bits == 4 || a->delta_bits == 8, SVK_ERR_VALUE,
@@ -637,17 +648,35 @@ extern "C" int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs
       reinterpret_cast<uintptr_t>(a->delta) % 16 == 0 && reinterpret_cast<uintptr_t>(a->cos_sin) % 16 == 0) {
     const int lpe = (a->head_dim / 16) * a->num_kv_heads;
     const int epb2 = 256 / lpe;
-    const dim3 grid((a->n + epb2 - 1) / epb2), block(256);
-    if (a->head_dim == 128) hipLaunchKernelGGL(deltakv_reconstruct_vec_kernel<128>, grid, block, 0, static_cast<hipStream_t>(stream), *a);
-    else hipLaunchKernelGGL(deltakv_reconstruct_vec_kernel<64>, grid, block, 0, static_cast<hipStream_t>(stream), *a);
+    const dim3 grid((a->n + epb2 - 1) / epb2, lb.n_batch), block(256);
+    if (a->head_dim == 128) hipLaunchKernelGGL(deltakv_reconstruct_vec_kernel<128>, grid, block, 0, static_cast<hipStream_t>(stream), *a, lb);
+    else hipLaunchKernelGGL(deltakv_reconstruct_vec_kernel<64>, grid, block, 0, static_cast<hipStream_t>(stream), *a, lb);
     return check_launch("svk_deltakv_reconstruct_writeback");
   }
+  SVK_REQUIRE(lb.n_batch == 1, SVK_ERR_LAYOUT, "svk_deltakv_reconstruct_writeback_batched: only the dense bf16 16-byte form is batched");
   int threads = per_entry;
   if (threads < 256) threads = (256 / per_entry) * per_entry;
   const int epb = threads / per_entry;
   hipLaunchKernelGGL(deltakv_reconstruct_kernel, dim3((a->n + epb - 1) / epb), dim3(threads), sizeof(float) * threads,
                      static_cast<hipStream_t>(stream), *a);
   return check_launch("svk_deltakv_reconstruct_writeback");
+}
+}  // namespace
+}  // namespace svk
+
+extern "C" int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs* a, svk_stream_t stream) {
+  SvkDeltakvReconstructBatch one = {};
+  one.n_batch = 1;
+  return svk::launch_reconstruct(a, one, stream);
+}
+
+extern "C" int svk_deltakv_reconstruct_writeback_batched(const SvkDeltakvReconstructArgs* first, const SvkDeltakvReconstructBatch* b,
+                                                         svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(b != nullptr && b->n_batch >= 1 && b->n_batch <= 65535, SVK_ERR_VALUE, "svk_deltakv_reconstruct_writeback_batched: bad batch description");
+  SVK_REQUIRE(b->n_batch == 1 || (b->delta_stride_batch % 8 == 0 && b->kv_cache_stride_batch % 8 == 0), SVK_ERR_LAYOUT,
+              "svk_deltakv_reconstruct_writeback_batched: per-layer strides must keep 16-byte alignment");
+  return launch_reconstruct(first, *b, stream);
 }
 
 extern "C" int svk_deltakv_token_scores_chunks(int32_t length) {

@@ -34,8 +34,19 @@ __device__ __forceinline__ float load_param(const void* p, int64_t i, int dtype)
 }
 
 template <bool GELU, int KT>
-__global__ void __launch_bounds__(256) dequant_linear_act_kernel(const SvkDequantLinearArgs a) {
+__global__ void __launch_bounds__(256) dequant_linear_act_kernel(const SvkDequantLinearArgs a_in, const SvkDequantLinearBatch lb) {
   extern __shared__ __attribute__((aligned(16))) uint16_t xs[];      // [kBM][K + 8] bf16
+  SvkDequantLinearArgs a = a_in;
+  if (gridDim.z > 1) {                  // layer z of a batched launch: every per-layer tensor advances by its stride
+    const int64_t z = blockIdx.z;
+    a.packed += z * lb.packed_stride_batch;
+    const int64_t es = a.scale_dtype == SVK_DTYPE_F32 ? 4 : 2;
+    a.scale = reinterpret_cast<const char*>(a.scale) + z * lb.scale_stride_batch * es;
+    a.mn = reinterpret_cast<const char*>(a.mn) + z * lb.scale_stride_batch * es;
+    a.weight += z * lb.weight_stride_batch;
+    if (a.bias != nullptr) a.bias += z * lb.bias_stride_batch;
+    a.out += z * lb.out_stride_batch;
+  }
   const int K = KT > 0 ? KT : a.k, ldx = K + 8;
   const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -219,16 +230,20 @@ __global__ void __launch_bounds__(256) dequant_linear_act_kernel(const SvkDequan
 }  // namespace
 }  // namespace svk
 
-extern "C" int svk_dequant_linear_act(const SvkDequantLinearArgs* a, svk_stream_t stream) {
-  using namespace svk;
+namespace svk {
+namespace {
+int launch_dequant_linear_act(const SvkDequantLinearArgs* a, const SvkDequantLinearBatch& lb, hipStream_t s, const char* who) {
   SVK_REQUIRE(a != nullptr && a->packed != nullptr && a->scale != nullptr && a->mn != nullptr && a->weight != nullptr && a->out != nullptr,
-              SVK_ERR_VALUE, "svk_dequant_linear_act: null args");
-  SVK_REQUIRE(a->k > 0 && a->k % 32 == 0 && a->k <= 512, SVK_ERR_LAYOUT, "svk_dequant_linear_act: K = %d must be a multiple of 32, <= 512", a->k);
+              SVK_ERR_VALUE, "%s: null args", who);
+  SVK_REQUIRE(a->k > 0 && a->k % 32 == 0 && a->k <= 512, SVK_ERR_LAYOUT, "%s: K = %d must be a multiple of 32, <= 512", who, a->k);
   SVK_REQUIRE(a->group_size > 0 && a->group_size % 8 == 0 && a->k % a->group_size == 0, SVK_ERR_VALUE,
               "dequantization requires output_dim divisible by group_size, got output_dim=%d, group_size=%d.", a->k, a->group_size);
   SVK_REQUIRE(a->n > 0 && (a->weight_stride % 8) == 0 && (reinterpret_cast<uintptr_t>(a->weight) % 16) == 0, SVK_ERR_LAYOUT,
-              "svk_dequant_linear_act: weight rows must be 16-byte aligned");
-  SVK_REQUIRE(a->activation == 0 || a->activation == 1, SVK_ERR_VALUE, "svk_dequant_linear_act: activation %d (0 none, 1 erf-GELU)", a->activation);
+              "%s: weight rows must be 16-byte aligned", who);
+  SVK_REQUIRE(a->activation == 0 || a->activation == 1, SVK_ERR_VALUE, "%s: activation %d (0 none, 1 erf-GELU)", who, a->activation);
+  SVK_REQUIRE(lb.n_batch >= 1 && lb.n_batch <= 65535, SVK_ERR_VALUE, "%s: n_batch %d out of range", who, lb.n_batch);
+  SVK_REQUIRE(lb.n_batch == 1 || (lb.weight_stride_batch % 8 == 0 && lb.packed_stride_batch % 4 == 0), SVK_ERR_LAYOUT,
+              "%s: per-layer strides must keep 16-byte alignment", who);
   if (a->rows <= 0) return SVK_OK;
   // the staged A tile, reused for the transposed output tile of the epilogue (K = 32 needs the larger of the two)
   const size_t shm = sizeof(uint16_t) * kBM * (size_t)((a->k > kBN ? a->k : kBN) + 8);
@@ -240,15 +255,28 @@ extern "C" int svk_dequant_linear_act(const SvkDequantLinearArgs* a, svk_stream_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dequant_linear_act_kernel<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     attr_set = true;
   }
-  const dim3 grid((a->n + kBN - 1) / kBN, (a->rows + kBM - 1) / kBM), block(256);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((a->n + kBN - 1) / kBN, (a->rows + kBM - 1) / kBM, lb.n_batch), block(256);
   if (a->k == 256 && (a->packed_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(a->packed) % 16) == 0) {
     // the latent width of the published compressors: fully unrolled
-    if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_kernel<true, 256>), grid, block, shm, s, *a);
-    else hipLaunchKernelGGL((dequant_linear_act_kernel<false, 256>), grid, block, shm, s, *a);
+    if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_kernel<true, 256>), grid, block, shm, s, *a, lb);
+    else hipLaunchKernelGGL((dequant_linear_act_kernel<false, 256>), grid, block, shm, s, *a, lb);
   } else {
-    if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_kernel<true, 0>), grid, block, shm, s, *a);
-    else hipLaunchKernelGGL((dequant_linear_act_kernel<false, 0>), grid, block, shm, s, *a);
+    if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_kernel<true, 0>), grid, block, shm, s, *a, lb);
+    else hipLaunchKernelGGL((dequant_linear_act_kernel<false, 0>), grid, block, shm, s, *a, lb);
   }
-  return check_launch("svk_dequant_linear_act");
+  return check_launch(who);
+}
+}  // namespace
+}  // namespace svk
+
+extern "C" int svk_dequant_linear_act(const SvkDequantLinearArgs* a, svk_stream_t stream) {
+  SvkDequantLinearBatch one = {};
+  one.n_batch = 1;
+  return svk::launch_dequant_linear_act(a, one, static_cast<hipStream_t>(stream), "svk_dequant_linear_act");
+}
+
+extern "C" int svk_dequant_linear_act_batched(const SvkDequantLinearArgs* first, const SvkDequantLinearBatch* b, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(b != nullptr, SVK_ERR_VALUE, "svk_dequant_linear_act_batched: null batch description");
+  return launch_dequant_linear_act(first, *b, static_cast<hipStream_t>(stream), "svk_dequant_linear_act_batched");
 }

@@ -67,7 +67,7 @@ def deltakv_static_decode_plan(*, raw_slots_map, latent_slots_map, active_compre
 
 
 def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
-                 v_cache, bits, group_size, k_norm_weight, k_norm_eps, raw_k_cache, store_raw_k, father_index=None):
+                 v_cache, bits, group_size, k_norm_weight, k_norm_eps, raw_k_cache, store_raw_k, father_index=None, batch=None):
     assert k_cache.dtype == torch.bfloat16 and k_cache.stride() == v_cache.stride() and k_cache.stride(-1) == 1
     assert father_slots.dim() == 2 and father_slots.dtype == torch.int32 and father_slots.stride(1) == 1
     if father_index is not None:      # father_slots is the [latents, K] table, indexed in-kernel
@@ -91,7 +91,32 @@ def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, o
         scale_dtype=0 if scale is None else _dt(scale), cos_dtype=_dt(cos_sin), raw_k_cache=int(bool(raw_k_cache)),
         store_raw_k=int(bool(store_raw_k)), father_table=_lib.ptr(father_slots) if father_index is not None else None,
         father_index=_lib.ptr(father_index), father_table_stride=father_slots.stride(0))
+    if batch is not None:
+        _lib.check(lib.svk_deltakv_reconstruct_writeback_batched(C.byref(a), C.byref(batch), _lib.current_stream_handle()), lib)
+        return
     _lib.check(lib.svk_deltakv_reconstruct_writeback(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+@torch.no_grad()
+def deltakv_reconstruct_writeback_layers(kv_delta, father_table, father_index, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
+                                         v_cache, *, k_norm_weight=None, k_norm_eps: float = 1e-6, raw_k_cache: bool = False,
+                                         store_raw_k: bool = False):
+    """`deltakv_reconstruct_writeback_grouped_heads` for several layers that share one plan, in ONE launch: kv_delta
+    [n_layers, N, 2*Hkv*D] bf16, father_table [n_layers, latents, K], k_cache / v_cache [n_layers, slots, Hkv, D],
+    k_norm_weight None or [n_layers, D] f32; father_index / out_slots / out_pos / slot_to_pos are the plan's."""
+    nl = int(kv_delta.shape[0])
+    assert kv_delta.dim() == 3 and kv_delta.dtype == torch.bfloat16 and kv_delta.stride(2) == 1
+    assert father_table.dim() == 3 and father_table.shape[0] == nl and k_cache.dim() == 4 and k_cache.shape[0] == nl
+    assert k_cache.stride() == v_cache.stride()
+    if k_norm_weight is not None:
+        assert k_norm_weight.dim() == 2 and k_norm_weight.shape[0] == nl and k_norm_weight.dtype == torch.float32 and k_norm_weight.is_contiguous()
+    batch = _lib.SvkDeltakvReconstructBatch(
+        n_batch=nl, delta_stride_batch=kv_delta.stride(0), father_table_stride_batch=father_table.stride(0),
+        kv_cache_stride_batch=k_cache.stride(0), k_norm_stride_batch=0 if k_norm_weight is None else k_norm_weight.stride(0))
+    _reconstruct(delta=kv_delta[0], scale=None, mn=None, latent_slots=None, father_slots=father_table[0],
+                 slot_to_pos=slot_to_pos, out_slots=out_slots, out_pos=out_pos, cos_sin=cos_sin, k_cache=k_cache[0],
+                 v_cache=v_cache[0], bits=0, group_size=0, k_norm_weight=None if k_norm_weight is None else k_norm_weight[0],
+                 k_norm_eps=k_norm_eps, raw_k_cache=raw_k_cache, store_raw_k=store_raw_k, father_index=father_index, batch=batch)
 
 
 @torch.no_grad()
@@ -214,10 +239,24 @@ def deltakv_decode_alloc(meta, *, batch: int, full_slots_map, full_slot_to_pos, 
 
 
 def dequant_linear_act(packed, scale, mn, group_size: int, weight, bias=None, *, activation: str = "gelu", row_index=None,
-                       out=None):
+                       out=None, layers: bool = False):
     """`act(F.linear(dequant_int4(packed[row_index]), weight, bias))` as one MFMA launch (MI355X fusion of the residual
     load's dequantisation with the first Linear (+ erf-GELU) of `compress_up`; `_load_residual`,
     deltakv_less_memory.py:2841-2848, utils/compressor.py:69-73).  bf16 weights and output, int4 codes."""
+    batch = None
+    if layers:
+        # several layers in one launch: packed / scale / mn [n_layers, rows, ...], weight [n_layers, N, K], bias
+        # [n_layers, N], out [n_layers, n, N]; row_index is shared
+        assert packed.dim() == 3 and scale.dim() == 3 and mn.dim() == 3 and weight.dim() == 3 and out is not None and out.dim() == 3
+        nl = int(packed.shape[0])
+        assert scale.shape[0] == nl and weight.shape[0] == nl and out.shape[0] == nl and (bias is None or (bias.dim() == 2 and bias.shape[0] == nl))
+        assert scale.stride() == mn.stride()
+        batch = _lib.SvkDequantLinearBatch(n_batch=nl, packed_stride_batch=packed.stride(0), scale_stride_batch=scale.stride(0),
+                                           weight_stride_batch=weight.stride(0), bias_stride_batch=0 if bias is None else bias.stride(0),
+                                           out_stride_batch=out.stride(0))
+        out_all = out
+        packed, scale, mn, weight, out = packed[0], scale[0], mn[0], weight[0], out[0]
+        bias = None if bias is None else bias[0]
     if packed.dim() != 2 or scale.dim() != 2 or mn.dim() != 2:
         raise ValueError("2D dequantization expects rank-2 packed/scale/min tensors, "
                          f"got packed={tuple(packed.shape)}, scale={tuple(scale.shape)}, mn={tuple(mn.shape)}.")
@@ -251,6 +290,9 @@ def dequant_linear_act(packed, scale, mn, group_size: int, weight, bias=None, *,
                                   packed_stride=packed.stride(0), scale_stride=scale.stride(0), weight_stride=weight.stride(0),
                                   out_stride=out.stride(0), rows=n, k=K, n=N, group_size=group_size, scale_dtype=_dt(scale),
                                   activation=1 if activation == "gelu" else 0)
+    if batch is not None:
+        _lib.check(lib.svk_dequant_linear_act_batched(C.byref(a), C.byref(batch), _lib.current_stream_handle()), lib)
+        return out_all
     _lib.check(lib.svk_dequant_linear_act(C.byref(a), _lib.current_stream_handle()), lib)
     return out
 

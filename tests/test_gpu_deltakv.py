@@ -396,3 +396,43 @@ def test_deltakv_decode_alloc_matches_numpy():
         dk.deltakv_decode_alloc(meta, batch=B, full_slots_map=g_full_map, full_slot_to_pos=g_full_pos,
                                 sparse_raw_slots_map=g_sparse_map, sparse_slot_to_pos=g_sparse_pos, context_lens=outs[0][:2],
                                 req_indices=outs[1], slot_mapping=outs[2], sparse_slot_mapping=outs[3], compressed_lens=outs[4])
+
+
+def test_layer_batched_residual_and_reconstruct_equal_per_layer_launches():
+    """svk_dequant_linear_act_batched / svk_deltakv_reconstruct_writeback_batched: several layers that share one plan in
+    one launch each - bit-identical to the per-layer launches."""
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    torch.manual_seed(11)
+    d = torch.device("cuda:0")
+    nl, latents, K, hid, n, Hkv, D, kf, slots = 3, 300, 256, 384, 200, 4, 128, 4, 700
+    packed = torch.randint(-2**31, 2**31 - 1, (nl, latents, K // 8), dtype=torch.int32, device=d)
+    scale = (torch.rand(nl, latents, K // 32, device=d) * 0.1 + 0.01).bfloat16()
+    mn = (torch.randn(nl, latents, K // 32, device=d) * 0.2).bfloat16()
+    w1 = (torch.randn(nl, hid, K, device=d) * 0.05).bfloat16()
+    b1 = (torch.randn(nl, hid, device=d) * 0.1).bfloat16()
+    row_index = torch.randint(-1, latents, (n,), dtype=torch.int32, device=d)
+    out_b = torch.zeros(nl, n, hid, dtype=torch.bfloat16, device=d)
+    dk.dequant_linear_act(packed, scale, mn, 32, w1, b1, activation="gelu", row_index=row_index, out=out_b, layers=True)
+    for l in range(nl):
+        ref = dk.dequant_linear_act(packed[l], scale[l], mn[l], 32, w1[l], b1[l], activation="gelu", row_index=row_index)
+        assert torch.equal(ref.view(torch.int16), out_b[l].view(torch.int16))
+
+    delta = (torch.randn(nl, n, 2 * Hkv * D, device=d) * 0.1).bfloat16()
+    table = torch.randint(-1, slots // 2, (nl, latents, kf), dtype=torch.int32, device=d)
+    slot_to_pos = torch.randint(0, 500, (slots,), dtype=torch.int32, device=d)
+    out_slots = (slots // 2 + torch.randperm(slots // 2, device=d)[:n]).to(torch.int32)
+    out_slots[::17] = -1
+    out_pos = torch.randint(0, 500, (n,), dtype=torch.int32, device=d)
+    cos_sin = torch.randn(512, D, device=d)
+    base_k = (torch.randn(nl, slots, Hkv, D, device=d) * 0.3).bfloat16()
+    base_v = (torch.randn(nl, slots, Hkv, D, device=d) * 0.3).bfloat16()
+    kb, vb = base_k.clone(), base_v.clone()
+    dk.deltakv_reconstruct_writeback_layers(delta, table, row_index, slot_to_pos, out_slots, out_pos, cos_sin, kb, vb,
+                                            raw_k_cache=True, store_raw_k=False)
+    for l in range(nl):
+        kr, vr = base_k[l].clone(), base_v[l].clone()
+        dk.deltakv_reconstruct_writeback_grouped_heads(kv_delta=delta[l], father_slots=table[l], father_index=row_index,
+                                                       slot_to_pos=slot_to_pos, out_slots=out_slots, out_pos=out_pos,
+                                                       cos_sin=cos_sin, k_cache=kr, v_cache=vr, raw_k_cache=True, store_raw_k=False)
+        assert torch.equal(kr.view(torch.int16), kb[l].view(torch.int16))
+        assert torch.equal(vr.view(torch.int16), vb[l].view(torch.int16))
