@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 6
+#define SVK_ABI_VERSION 7
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -599,8 +599,8 @@ typedef struct SvkDeltakvMaterializeArgs {
   const int32_t* active_slots;     /* [batch, width] (active_stride)                          */
   const int32_t* slot_to_pos;      /* [num_slots]                                             */
   const uint8_t* postrope_mask;    /* NULL or [num_slots] bool                                */
-  const uint16_t* k_cache;         /* [num_slots, Hkv, D] bf16 (kv_slot_stride/kv_head_stride) */
-  const uint16_t* v_cache;
+  uint16_t* k_cache;               /* [num_slots, Hkv, D] bf16 (kv_slot_stride/kv_head_stride); written only with new_slots */
+  uint16_t* v_cache;
   uint16_t* out_k;                 /* [>= batch*width, Hkv, D] bf16 (out_slot_stride/out_head_stride) */
   uint16_t* out_v;
   const void* cos_sin;             /* [max_pos, D]: cos | sin halves (cos_dtype)              */
@@ -613,6 +613,14 @@ typedef struct SvkDeltakvMaterializeArgs {
   const int32_t* temp_slots;       /* NULL or [batch, temp_count] (temp_stride)               */
   int64_t temp_stride;
   int32_t temp_offset, temp_count;
+  /* MI355X: this step's raw store (save_raw_kv_if_needed -> store_kvcache, deltakv_less_memory.py:1269-1281) riding
+   * in the same launch.  With new_slots != NULL row b's new token (new_k/new_v[b], pre-RoPE key) is written to
+   * cache slot new_slots[b] (skipped when < 0), and a view entry (b, w) whose slot equals new_slots[b] takes its
+   * data from new_k/new_v[b] instead of the cache, so the result equals store-then-materialise. */
+  const uint16_t* new_k;           /* NULL or [batch, Hkv, D] bf16 (new_token_stride/new_head_stride) */
+  const uint16_t* new_v;
+  const int32_t* new_slots;        /* NULL or [batch]                                         */
+  int64_t new_token_stride, new_head_stride;
 } SvkDeltakvMaterializeArgs;
 int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeArgs* a, svk_stream_t stream);
 

@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 6
+SVK_ABI_VERSION = 7
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -219,7 +219,8 @@ class SvkDeltakvMaterializeArgs(C.Structure):
                                     "out_head_stride", "cos_stride")] + \
                [("k_norm_eps", _f32)] + \
                [(n, _i32) for n in ("batch", "width", "num_slots", "num_kv_heads", "head_dim", "cos_dtype")] + \
-               [("temp_slots", _p), ("temp_stride", _i64), ("temp_offset", _i32), ("temp_count", _i32)]
+               [("temp_slots", _p), ("temp_stride", _i64), ("temp_offset", _i32), ("temp_count", _i32)] + \
+               [("new_k", _p), ("new_v", _p), ("new_slots", _p), ("new_token_stride", _i64), ("new_head_stride", _i64)]
 
 
 class SvkContextAttentionArgs(C.Structure):

@@ -47,6 +47,19 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
   uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1, rk1 = v1, rk2 = v1;
   int pos = 0;
   bool copy = false;
+  if (a.new_slots != nullptr && tl < tokens_per_block && n >= total && n - total < a.batch) {
+    // the blocks behind the view: this step's raw rows into the cache (what store_kvcache did in a launch of its own)
+    const int b = (int)(n - total);
+    const int slot = a.new_slots[b];
+    if (slot >= 0 && slot < a.num_slots) {
+      const int64_t src = (int64_t)b * a.new_token_stride + (int64_t)h * a.new_head_stride + p;
+      const int64_t dst = (int64_t)slot * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
+      *reinterpret_cast<uint4*>(a.k_cache + dst) = *reinterpret_cast<const uint4*>(a.new_k + src);
+      *reinterpret_cast<uint4*>(a.k_cache + dst + HD2) = *reinterpret_cast<const uint4*>(a.new_k + src + HD2);
+      *reinterpret_cast<uint4*>(a.v_cache + dst) = *reinterpret_cast<const uint4*>(a.new_v + src);
+      *reinterpret_cast<uint4*>(a.v_cache + dst + HD2) = *reinterpret_cast<const uint4*>(a.new_v + src + HD2);
+    }
+  }
   if (live) {
     const int b = (int)(n / a.width), w = (int)(n % a.width);
     const int slot = a.active_slots[(int64_t)b * a.active_stride + w];
@@ -58,11 +71,18 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
       const int j = w - a.temp_offset;
       copy = valid && j >= 0 && j < a.temp_count && a.temp_slots[(int64_t)b * a.temp_stride + j] == slot;
     }
-    const int64_t base = (int64_t)safe * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
-    rk1 = *reinterpret_cast<const uint4*>(a.k_cache + base);
-    rk2 = *reinterpret_cast<const uint4*>(a.k_cache + base + HD2);
-    v1 = *reinterpret_cast<const uint4*>(a.v_cache + base);
-    v2 = *reinterpret_cast<const uint4*>(a.v_cache + base + HD2);
+    const uint16_t* ks = a.k_cache;
+    const uint16_t* vs = a.v_cache;
+    int64_t base = (int64_t)safe * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
+    if (a.new_slots != nullptr && valid && slot == a.new_slots[b]) {   // the row the store blocks are writing right now
+      ks = a.new_k;
+      vs = a.new_v;
+      base = (int64_t)b * a.new_token_stride + (int64_t)h * a.new_head_stride + p;
+    }
+    rk1 = *reinterpret_cast<const uint4*>(ks + base);
+    rk2 = *reinterpret_cast<const uint4*>(ks + base + HD2);
+    v1 = *reinterpret_cast<const uint4*>(vs + base);
+    v2 = *reinterpret_cast<const uint4*>(vs + base + HD2);
   }
   unpack8(rk1, k1);
   unpack8(rk2, k2);
@@ -116,10 +136,18 @@ extern "C" int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeAr
   SVK_REQUIRE(a->kv_slot_stride % 8 == 0 && a->kv_head_stride % 8 == 0 && a->out_slot_stride % 8 == 0 && a->out_head_stride % 8 == 0,
               SVK_ERR_LAYOUT, "svk_deltakv_materialize_sparse_view: K/V strides must keep 16-byte alignment");
   const int64_t total = (int64_t)a->batch * a->width;
-  if (total <= 0) return SVK_OK;
+  const bool store = a->new_slots != nullptr;
+  if (store) {
+    SVK_REQUIRE(a->new_k != nullptr && a->new_v != nullptr, SVK_ERR_VALUE,
+                "svk_deltakv_materialize_sparse_view: new_slots needs new_k and new_v");
+    SVK_REQUIRE(a->new_token_stride % 8 == 0 && a->new_head_stride % 8 == 0, SVK_ERR_LAYOUT,
+                "svk_deltakv_materialize_sparse_view: new_k/new_v strides must keep 16-byte alignment");
+  }
+  const int64_t entries = total + (store ? a->batch : 0);          // the store rows ride behind the view entries
+  if (entries <= 0) return SVK_OK;
   const int lpt = (a->head_dim / 16) * a->num_kv_heads;
   const int tpb = 256 / lpt;
-  const unsigned grid = (unsigned)((total + tpb - 1) / tpb);
+  const unsigned grid = (unsigned)((entries + tpb - 1) / tpb);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (a->head_dim == 128) hipLaunchKernelGGL(materialize_kernel<128>, dim3(grid), dim3(256), 0, s, *a);
   else hipLaunchKernelGGL(materialize_kernel<64>, dim3(grid), dim3(256), 0, s, *a);

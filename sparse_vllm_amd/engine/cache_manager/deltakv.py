@@ -154,6 +154,7 @@ class DeltaKVCacheManager(CacheManager):
         self._deltakv_decode_static_compressed_lens = None
         self._deltakv_decode_static_slot_mapping = None
         self._deltakv_decode_static_active_pos = None
+        self._pending_raw_store: dict[int, tuple] = {}   # layer -> (k, v) whose store rides in the materialise launch
 
     # ------------------------------------------------------------------ configuration helpers
     def _full_layer_kivi_enabled(self) -> bool:
@@ -315,7 +316,30 @@ class DeltaKVCacheManager(CacheManager):
 
     def save_raw_kv_if_needed(self, layer_idx: int, k: torch.Tensor, v: torch.Tensor):
         """deltakv_less_memory.py:1269-1281: sparse layers keep the *pre-RoPE* key."""
-        if self._stores_sparse_raw_kv(layer_idx):
+        if not self._stores_sparse_raw_kv(layer_idx):
+            return
+        if self._raw_store_rides_in_view(k):
+            # MI355X: one launch less on the per-layer chain of a decode step -- the materialise launch of this layer
+            # (get_layer_compute_view) writes the row and reads it from k/v directly
+            self._pending_raw_store[layer_idx] = (k, v)
+            return
+        super().save_rope_kv_if_needed(layer_idx, k, v)
+
+    def _raw_store_rides_in_view(self, k: torch.Tensor) -> bool:
+        if os.environ.get("SVK_DELTAKV_FUSE_RAW_STORE", "1") == "0" or get_context().is_prefill:
+            return False
+        mapping = self.deltakv_layer_batch_states.slot_mapping
+        return (mapping is not None and mapping is self._deltakv_decode_static_slot_mapping and k.dim() == 3
+                and int(k.shape[0]) == int(mapping.numel()))
+
+    def on_forward_end(self, seqs, is_prefill: bool):
+        self._flush_pending_raw_stores()
+        return super().on_forward_end(seqs, is_prefill)
+
+    def _flush_pending_raw_stores(self):
+        """Rows whose layer never reached get_layer_compute_view in this step (none in the decode driver's flow)."""
+        while self._pending_raw_store:
+            layer_idx, (k, v) = self._pending_raw_store.popitem()
             super().save_rope_kv_if_needed(layer_idx, k, v)
 
     def save_rope_kv_if_needed(self, layer_idx: int, k: torch.Tensor, v: torch.Tensor):
@@ -888,6 +912,13 @@ class DeltaKVCacheManager(CacheManager):
         if total == 0:
             return k_out, v_out, local_active, local_req, context_lens
         l_idx = self.deltakv_layer_to_idx[layer_idx]
+        new_k = new_v = new_slots = None
+        pending = self._pending_raw_store.pop(layer_idx, None)
+        if pending is not None:
+            new_k, new_v = pending
+            new_slots = self.deltakv_layer_batch_states.slot_mapping
+            if int(new_slots.numel()) != B:
+                raise RuntimeError(f"DeltaKV fused raw store: {int(new_slots.numel())} slots for a view of {B} rows")
         with profiler.record("deltakv_materialize_sparse_view"):
             k_max = W - int(self.config.num_sink_tokens) - self._deltakv_decode_static_max_buffer()
             dk.deltakv_materialize_sparse_view(
@@ -896,7 +927,8 @@ class DeltaKVCacheManager(CacheManager):
                 self.cos_sin_cache,
                 k_norm_weight=None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx],
                 k_norm_eps=float(self.deltakv_k_norm_eps),
-                temp_slots=self._ensure_decode_static_temp_slots(B, k_max), temp_offset=int(self.config.num_sink_tokens))
+                temp_slots=self._ensure_decode_static_temp_slots(B, k_max), temp_offset=int(self.config.num_sink_tokens),
+                new_k=new_k, new_v=new_v, new_slots=new_slots)
         return k_out, v_out, local_active, local_req, context_lens
 
     def build_decode_compute_view(self, layer_idx: int, q: torch.Tensor, selection: SparseSelection, *, num_heads: int,
@@ -1016,6 +1048,7 @@ class DeltaKVCacheManager(CacheManager):
         with profiler.record("deltakv_less_memory_evict_total"):
             if not self.deltakv_layer_ids:
                 return
+            self._flush_pending_raw_stores()
             d = self.device
             sink, recent = int(self.config.num_sink_tokens), int(self.config.num_recent_tokens)
             step = self._deltakv_base_cluster_step()

@@ -345,10 +345,13 @@ def topk_sorted_desc(scores, k: int, *, valid_len=None, masked_value: float = -1
 @torch.no_grad()
 def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, postrope_mask, k_cache, v_cache, out_k, out_v,
                                     cos_sin, *, k_norm_weight=None, k_norm_eps: float = 1e-6, block_tokens: int = 16,
-                                    temp_slots=None, temp_offset: int = 0):
+                                    temp_slots=None, temp_offset: int = 0, new_k=None, new_v=None, new_slots=None):
     """Reference wrapper deltakv_kernels.py:3489-3585 (same arguments; `block_tokens` is a Triton tile knob).
-    Extension: `temp_slots` [B, K] + `temp_offset` replace the mask in static decode (an entry in columns
-    [temp_offset, temp_offset + K) is post-RoPE iff its slot is this step's reconstruct scratch slot)."""
+    Extensions: `temp_slots` [B, K] + `temp_offset` replace the mask in static decode (an entry in columns
+    [temp_offset, temp_offset + K) is post-RoPE iff its slot is this step's reconstruct scratch slot);
+    `new_k`/`new_v` [B, Hkv, D] + `new_slots` [B] carry this step's raw store in the same launch (row b's new token
+    goes to cache slot new_slots[b]; the view reads it from new_k/new_v), equal to store_kvcache followed by the
+    plain call."""
     for t in (active_slots, context_lens, slot_to_pos, k_cache, v_cache, out_k, out_v, cos_sin):
         assert t.is_cuda
     assert active_slots.dim() == 2
@@ -393,6 +396,13 @@ def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, pos
         num_kv_heads=num_kv_heads, head_dim=head_dim, cos_dtype=_dt(cos_sin), temp_slots=_lib.ptr(temp_slots),
         temp_stride=0 if temp_slots is None else temp_slots.stride(0), temp_offset=int(temp_offset),
         temp_count=0 if temp_slots is None else int(temp_slots.shape[1]))
+    if new_slots is not None:
+        assert new_k is not None and new_v is not None and new_k.shape == new_v.shape and new_k.stride() == new_v.stride()
+        assert new_k.dtype == torch.bfloat16 and new_v.dtype == torch.bfloat16 and new_k.stride(-1) == 1
+        assert tuple(new_k.shape) == (batch, num_kv_heads, head_dim)
+        assert new_slots.dtype == torch.int32 and new_slots.is_contiguous() and new_slots.numel() == batch
+        a.new_k, a.new_v, a.new_slots = _lib.ptr(new_k), _lib.ptr(new_v), _lib.ptr(new_slots)
+        a.new_token_stride, a.new_head_stride = new_k.stride(0), new_k.stride(1)
     _lib.check(lib.svk_deltakv_materialize_sparse_view(C.byref(a), _lib.current_stream_handle()), lib)
 
 

@@ -302,6 +302,55 @@ def test_fused_static_decode_variants_match_unfused():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("cfg", [dict(B=3, Hkv=4, D=128, W=61, knorm=False), dict(B=5, Hkv=1, D=128, W=40, knorm=True),
+                                 dict(B=2, Hkv=2, D=64, W=33, knorm=False), dict(B=130, Hkv=4, D=128, W=9, knorm=True)])
+def test_materialize_with_riding_raw_store_equals_store_then_materialize(cfg):
+    """`new_k/new_v/new_slots`: the step's raw store in the materialise launch == store_kvcache, then the plain call
+    (view and cache bit-identical); rows with slot -1 store nothing, and a new slot outside the view is still stored."""
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    from sparse_vllm_amd.kernels import store_kvcache
+    B, Hkv, D, W = cfg["B"], cfg["Hkv"], cfg["D"], cfg["W"]
+    S, P = 600 + max(100, 2 * B), 900
+    g = torch.Generator().manual_seed(B * 131 + W)
+    rng = np.random.default_rng(B + W)
+    kc = torch.randn((S, Hkv, D), generator=g).to(torch.bfloat16).to(dev())
+    vc = torch.randn((S, Hkv, D), generator=g).to(torch.bfloat16).to(dev())
+    nk = torch.randn((B, Hkv, D), generator=g).to(torch.bfloat16).to(dev())
+    nv = torch.randn((B, Hkv, D), generator=g).to(torch.bfloat16).to(dev())
+    s2p = torch.from_numpy(rng.integers(0, P, S).astype(np.int32)).to(dev())
+    inv = 1.0 / (1e6 ** (np.arange(D // 2) / (D // 2)))
+    ang = np.arange(P)[:, None] * inv[None, :]
+    cos_sin = t(np.concatenate((np.cos(ang), np.sin(ang)), axis=1).astype(np.float32))
+    new_slots = rng.choice(np.arange(600, S), B, replace=False).astype(np.int32)
+    active = rng.integers(0, 600, (B, W)).astype(np.int32)
+    active[:, W - 1] = new_slots                 # the new token closes the view's raw tail
+    active[0, W - 1] = 5                         # ... except row 0: its new slot is not in the view at all
+    if B > 2:
+        new_slots[2] = -1                        # a padded lane stores nothing
+        active[2, W - 1] = -1
+    active[B - 1, 3] = -1
+    knw = torch.rand(D, generator=g).add(0.5).to(dev()) if cfg["knorm"] else None
+    temp = torch.from_numpy(active[:, 2:5].copy()).to(dev())
+    temp[:, 1] = 599
+    lens = torch.full((B,), W, dtype=torch.int32, device=dev())
+    res = []
+    for fused in (False, True):
+        k2, v2 = kc.clone(), vc.clone()
+        ok = torch.zeros((B * W, Hkv, D), dtype=torch.bfloat16, device=dev())
+        ov = torch.zeros_like(ok)
+        kw = dict(k_norm_weight=knw, temp_slots=temp, temp_offset=2)
+        if fused:
+            kw.update(new_k=nk, new_v=nv, new_slots=t(new_slots))
+        else:
+            store_kvcache(nk, nv, k2, v2, t(new_slots))
+        dk.deltakv_materialize_sparse_view(t(active), lens, s2p, None, k2, v2, ok, ov, cos_sin, **kw)
+        torch.cuda.synchronize()
+        res.append((ok, ov, k2, v2))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert not torch.equal(res[1][2], kc)
+
+
 @pytest.mark.parametrize("shape", [dict(rows=300, src=157, K=256, N=2048), dict(rows=129, src=129, K=64, N=200),
                                    dict(rows=5, src=9, K=512, N=136), dict(rows=260, src=33, K=32, N=128)])
 @pytest.mark.parametrize("act", ["gelu", "none"])
