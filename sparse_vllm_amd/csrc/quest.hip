@@ -3,6 +3,19 @@
 // HBM-bound scans of the [pages, Hkv, D] min/max metadata (1/16 of the K bytes each).
 
 #include "svk_common.hpp"
+// Developer build (make EXTRA=-DSVK_QV_TIMING, then tools/qv_timing.py): s_memrealtime stamps (100 MHz) of workgroup 0 of
+// quest_build_view_kernel: 0 entry, 1 keys staged, 8.. after each radix pass, 2 threshold known, 3 pages emitted, 4 view written.
+#ifdef SVK_QV_TIMING
+__device__ unsigned long long g_qv_stamps[16];
+#define SVK_SEL_STAMP(i)                                                                                    \
+  do {                                                                                                      \
+    __syncthreads();                                                                                        \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_qv_stamps[i] = __builtin_amdgcn_s_memrealtime();             \
+  } while (0)
+extern "C" int svk_debug_quest_view_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qv_stamps), sizeof(g_qv_stamps));
+}
+#endif
 #include "svk_select.hpp"
 
 namespace svk {
@@ -140,6 +153,9 @@ __global__ void __launch_bounds__(512) quest_score_pages_kernel(const SvkQuestSc
 // top-k + packed view, one workgroup per batch lane
 // ------------------------------------------------------------------------------------
 
+// CH > 0: thread t holds the keys of per = ceil(n_prev / blockDim) <= CH consecutive pages in registers for the whole select;
+// CH == 0: keys in LDS (`lds_keys`) or re-read from memory on every sweep.
+template <int CH>
 __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBuildViewArgs a, int lds_keys) {
   __shared__ SelectScratch scratch;
   extern __shared__ int sel_pages[];          // [prev_budget] selected logical pages, ascending
@@ -153,16 +169,39 @@ __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBu
   const int32_t* ptab = a.page_table + (int64_t)row * a.page_table_stride;
   if (tid == 0) a.local_req[b] = b;
   const bool dense = !a.is_long_text && (len <= a.token_budget || num_pages <= a.page_budget_base);
+  SVK_SEL_STAMP(0);
   if (dense) {
     for (int i = tid; i < a.max_keep; i += nt) packed[i] = ttab[i];
     if (tid == 0) a.local_lens[b] = len;
     return;
   }
   const float* sc = a.page_scores + (int64_t)b * a.score_stride;
-  if (lds_keys) {
+  if constexpr (CH > 0) {
+    // one round trip for the thread's CH scores (16-byte loads when the row allows), then no memory in the select
+    constexpr int C = CH > 0 ? CH : 4;
+    const int per = (a.n_prev + nt - 1) / nt;
+    const int base = tid * per;
+    float v[C];
+    if ((per & 3) == 0 && (reinterpret_cast<uintptr_t>(sc) & 15u) == 0u && base + per <= a.n_prev) {
+#pragma unroll
+      for (int j = 0; j < C; j += 4) {
+        if (j < per) {
+          const float4 f = *reinterpret_cast<const float4*>(sc + base + j);
+          v[j] = f.x; v[j + 1] = f.y; v[j + 2] = f.z; v[j + 3] = f.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < C; ++j) v[j] = j < per && base + j < a.n_prev ? sc[base + j] : 0.f;
+    }
+    uint32_t key[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) key[j] = desc_key(v[j]);
+    block_select_topk_ordered_owned<C>(key, per, a.n_prev, a.prev_budget, scratch,
+                                       [&](int pos, int idx) { sel_pages[pos] = idx; });
+  } else if (lds_keys) {
+    // keys staged in LDS (8 scores per thread and trip with the loads first, the select's OR / AND sweep folded in)
     uint32_t* keys = reinterpret_cast<uint32_t*>(sel_pages + a.prev_budget);
-    // staging: 8 scores per thread and trip with the loads first (one round trip instead of one per element), the
-    // select's OR / AND sweep folded in
     select_bits_begin(scratch);
     uint32_t o_bits = 0u, a_bits = 0xffffffffu;
     for (int i0 = 0; i0 < a.n_prev; i0 += 8 * nt) {
@@ -191,6 +230,7 @@ __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBu
     block_select_topk_ordered(sc, a.n_prev, a.prev_budget, scratch, [&](int pos, int idx) { sel_pages[pos] = idx; });
   }
   __syncthreads();
+  SVK_SEL_STAMP(3);
   const int sparse_keep = (a.prev_budget + 1) * ps;
   for (int i0 = 0; i0 < sparse_keep; i0 += 8 * nt) {          // page-table gathers of 8 entries per thread in flight together
     int slot[8];
@@ -209,6 +249,7 @@ __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBu
   if (!a.is_long_text)
     for (int i = sparse_keep + tid; i < a.max_keep; i += nt) packed[i] = ttab[i];
   if (tid == 0) a.local_lens[b] = a.prev_budget * ps + (len - (num_pages - 1) * ps);
+  SVK_SEL_STAMP(4);
 }
 
 __global__ void __launch_bounds__(256) quest_decode_alloc_kernel(const SvkQuestDecodeAllocArgs a) {
@@ -288,17 +329,27 @@ extern "C" int svk_quest_build_view(const SvkQuestBuildViewArgs* a, svk_stream_t
   SVK_REQUIRE(a->max_keep >= (a->prev_budget + 1) * a->page_size || a->is_long_text, SVK_ERR_VALUE,
               "svk_quest_build_view: max_keep %d smaller than the sparse view", a->max_keep);
   if (a->batch <= 0) return SVK_OK;
-  // page-score keys are staged in LDS (one coalesced read, five LDS sweeps) whenever the row fits
+  // page-score keys live in registers (up to 32 per thread); longer rows stage them in LDS whenever the row fits
   size_t shm = sizeof(int) * a->prev_budget;
   const int lds_keys = (shm + sizeof(uint32_t) * (size_t)a->n_prev) <= 128 * 1024;
   if (lds_keys) shm += sizeof(uint32_t) * (size_t)a->n_prev;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quest_build_view_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quest_build_view_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     attr_set = true;
   }
-  hipLaunchKernelGGL(quest_build_view_kernel, dim3(a->batch), dim3(a->n_prev > 2048 ? 1024 : 256), shm,
-                     static_cast<hipStream_t>(stream), *a, lds_keys);
+  static const bool no_owned = [] { const char* e = getenv("SVK_QUEST_VIEW_VARIANT"); return e != nullptr && e[0] == '1'; }();
+  const int nt = a->n_prev > 2048 ? 1024 : 256;
+  const int per_thread = (a->n_prev + nt - 1) / nt;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t shm_owned = sizeof(int) * a->prev_budget;
+  if (no_owned || per_thread > 32) hipLaunchKernelGGL(quest_build_view_kernel<0>, dim3(a->batch), dim3(nt), shm, s, *a, lds_keys);
+  else if (per_thread <= 4) hipLaunchKernelGGL(quest_build_view_kernel<4>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
+  else if (per_thread <= 8) hipLaunchKernelGGL(quest_build_view_kernel<8>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
+  else if (per_thread <= 12) hipLaunchKernelGGL(quest_build_view_kernel<12>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
+  else if (per_thread <= 16) hipLaunchKernelGGL(quest_build_view_kernel<16>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
+  else if (per_thread <= 24) hipLaunchKernelGGL(quest_build_view_kernel<24>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
+  else hipLaunchKernelGGL(quest_build_view_kernel<32>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
   return check_launch("svk_quest_build_view");
 }
 

@@ -4,6 +4,10 @@
 
 #include "svk_common.hpp"
 
+#ifndef SVK_SEL_STAMP
+#define SVK_SEL_STAMP(i)      // developer timing hook (quest.hip, -DSVK_QV_TIMING)
+#endif
+
 namespace svk {
 
 // ------------------------------------------------------------------------------------
@@ -116,36 +120,15 @@ __device__ __forceinline__ void select_bits_add(SelectScratch& S, uint32_t o, ui
   if ((threadIdx.x & 63) == 0) { atomicOr(&S.or_bits, o); atomicAnd(&S.and_bits, an); }
 }
 
-template <typename KeyAt, typename Emit>
-__device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int n, int k, SelectScratch& S, Emit emit,
-                                                               bool bits_ready = false) {
+// The radix passes of the select: digits of up to 8 bits from bit `top` down to bit `low`; keys whose bits above the
+// current digit differ from `prefix` are out of the race.  In: prefix = the decided / shared bits, kk = rank wanted
+// among the keys still in the race (1-based).  Out: prefix = the kk-th key, kk = how many keys equal to it are taken.
+// `sweep(shift, dmask, himask, prefix)` adds every key still in the race to S.hist (hist_add_aggregated, all lanes of
+// a wave together).  All threads of the block call.
+template <typename Sweep>
+__device__ __forceinline__ void select_radix_passes_sweep(Sweep sweep, SelectScratch& S, uint32_t& prefix, int& kk, int top,
+                                                          int low) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  uint32_t prefix = 0;
-  int kk = k;
-  // bytes shared by every key (bf16-valued scores: the two low bytes; probabilities: most of the top byte) are
-  // found with one atomic-free sweep and skip their radix pass
-  // (callers that stage the keys themselves fold this sweep into their staging loop: `select_bits_begin` before,
-  //  `select_bits_add` with each thread's OR / AND, then `bits_ready` = true)
-  if (!bits_ready) {
-    select_bits_begin(S);
-    uint32_t o = 0u, an = 0xffffffffu;
-    for (int i = tid; i < n; i += nt) {
-      const uint32_t key = key_at(i);
-      o |= key;
-      an &= key;
-    }
-    select_bits_add(S, o, an);
-    __syncthreads();
-  }
-  const uint32_t all_and = S.and_bits;
-  const uint32_t varying = S.or_bits ^ all_and;              // bit positions on which the keys differ
-  // 8-bit digits are laid from the highest varying bit down to the lowest one (not on byte boundaries): the first
-  // digit then spreads over the bins even when the keys share their leading bits (probabilities share sign and the
-  // upper exponent bits and would pile into a handful of bins - serialised LDS atomics), and digits made of shared
-  // bits only are never histogrammed (bf16-valued scores: 2 passes instead of 4)
-  prefix = all_and;                                           // shared bits are those of every key, the k-th too
-  int top = varying ? 31 - __builtin_clz(varying) : -1;       // highest bit still undecided
-  const int low = varying ? __builtin_ctz(varying) : 0;
   while (top >= low) {
     const int shift = max(top - 7, 0);
     const int width = top - shift + 1;
@@ -155,13 +138,7 @@ __device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int
     top = shift - 1;
     for (int i = tid; i < 256; i += nt) S.hist[i] = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += nt) {                        // all threads iterate together (wave-wide ballots inside)
-      const int i = c0 + tid;
-      uint32_t key = 0u;
-      const bool in = i < n;
-      if (in) key = key_at(i);
-      hist_add_aggregated(S.hist, (key >> shift) & dmask, in && (key & himask) == (prefix & himask));
-    }
+    sweep(shift, dmask, himask, prefix);
     __syncthreads();
     if (tid < 64) {
       int c[4];
@@ -191,20 +168,31 @@ __device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int
     prefix = S.prefix;
     kk = S.k;
     __syncthreads();
+    SVK_SEL_STAMP(8 + (31 - shift) / 8);
   }
-  const uint32_t T = prefix;   // threshold key
-  const int take_eq = kk;      // elements equal to T that are taken, lowest index first
-  // ordered emit: thread t owns the contiguous index range [t*chunk, (t+1)*chunk) (odd chunk: conflict-free LDS
-  // strides), so ONE block scan of (#keys < T, #keys == T) gives every element its rank among the selected
-  const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
-  const int chunk = ((n + nt - 1) / nt) | 1;
-  const int i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
-  int n_lt = 0, n_eq = 0;
-  for (int i = i0; i < i1; ++i) {
-    const uint32_t key = key_at(i);
-    n_lt += key < T;
-    n_eq += key == T;
-  }
+  SVK_SEL_STAMP(2);
+}
+
+// sweep over key_at(tid), key_at(tid + nt), ...
+template <typename KeyAt>
+__device__ __forceinline__ void select_radix_passes(KeyAt key_at, int n, SelectScratch& S, uint32_t& prefix, int& kk, int top,
+                                                    int low) {
+  select_radix_passes_sweep([&](int shift, uint32_t dmask, uint32_t himask, uint32_t pfx) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int c0 = 0; c0 < n; c0 += nt) {                        // all threads iterate together (wave-wide ballots inside)
+      const int i = c0 + tid;
+      uint32_t key = 0u;
+      const bool in = i < n;
+      if (in) key = key_at(i);
+      hist_add_aggregated(S.hist, (key >> shift) & dmask, in && (key & himask) == (pfx & himask));
+    }
+  }, S, prefix, kk, top, low);
+}
+
+// Block scan behind the ordered emit: (n_lt, n_eq) = this thread's counts over the contiguous index range it owns ->
+// the counts of all lower-numbered threads.
+__device__ __forceinline__ void select_emit_offsets(int n_lt, int n_eq, SelectScratch& S, int& lt_before, int& eq_before) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int il = n_lt, ie = n_eq;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -214,9 +202,27 @@ __device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int
   __syncthreads();
   if (lane == 63) { S.wsum[w] = il; S.wsum2[w] = ie; }
   __syncthreads();
-  int lt_before = il - n_lt, eq_before = ie - n_eq;
+  lt_before = il - n_lt;
+  eq_before = ie - n_eq;
   for (int j = 0; j < w; ++j) { lt_before += S.wsum[j]; eq_before += S.wsum2[j]; }
-  (void)nw;
+}
+
+// ordered emit over key_at(0..n): T = threshold key, take_eq = elements equal to T that are taken, lowest index first
+template <typename KeyAt, typename Emit>
+__device__ __forceinline__ void select_ordered_emit(KeyAt key_at, int n, uint32_t T, int take_eq, SelectScratch& S, Emit emit) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // ordered emit: thread t owns the contiguous index range [t*chunk, (t+1)*chunk) (odd chunk: conflict-free LDS
+  // strides), so ONE block scan of (#keys < T, #keys == T) gives every element its rank among the selected
+  const int chunk = ((n + nt - 1) / nt) | 1;
+  const int i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
+  int n_lt = 0, n_eq = 0;
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t key = key_at(i);
+    n_lt += key < T;
+    n_eq += key == T;
+  }
+  int lt_before, eq_before;
+  select_emit_offsets(n_lt, n_eq, S, lt_before, eq_before);
   // selected-before = (all < T before) + (equal-to-T before that are taken)
   for (int i = i0; i < i1; ++i) {
     const uint32_t key = key_at(i);
@@ -225,6 +231,87 @@ __device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int
     lt_before += lt;
     eq_before += eq;
   }
+}
+
+
+// The select with the keys in registers: thread t owns the `per` (<= CH, the same for all threads) consecutive indices
+// from t * per (key[j] = key of index t * per + j; indices >= n are ignored whatever their key), so neither the passes
+// nor the emit read memory.
+template <int CH, typename Emit>
+__device__ __forceinline__ void block_select_topk_ordered_owned(const uint32_t (&key)[CH], int per, int n, int k,
+                                                                SelectScratch& S, Emit emit) {
+  const int base = threadIdx.x * per;
+  select_bits_begin(S);
+  uint32_t o = 0u, an = 0xffffffffu;
+#pragma unroll
+  for (int j = 0; j < CH; ++j)
+    if (j < per && base + j < n) { o |= key[j]; an &= key[j]; }
+  select_bits_add(S, o, an);
+  __syncthreads();
+  SVK_SEL_STAMP(1);
+  const uint32_t all_and = S.and_bits;
+  const uint32_t varying = S.or_bits ^ all_and;
+  uint32_t prefix = all_and;
+  int kk = k;
+  select_radix_passes_sweep([&](int shift, uint32_t dmask, uint32_t himask, uint32_t pfx) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (j < per) hist_add_aggregated(S.hist, (key[j] >> shift) & dmask, base + j < n && (key[j] & himask) == (pfx & himask));
+  }, S, prefix, kk, varying ? 31 - __builtin_clz(varying) : -1, varying ? __builtin_ctz(varying) : 0);
+  const uint32_t T = prefix;
+  int n_lt = 0, n_eq = 0;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const bool in = j < per && base + j < n;
+    n_lt += in && key[j] < T;
+    n_eq += in && key[j] == T;
+  }
+  int lt_before, eq_before;
+  select_emit_offsets(n_lt, n_eq, S, lt_before, eq_before);
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    if (j < per) {
+      const bool in = base + j < n;
+      const bool lt = in && key[j] < T, eq = in && key[j] == T;
+      if (lt || (eq && eq_before < kk)) emit(lt_before + min(eq_before, kk), base + j);
+      lt_before += lt;
+      eq_before += eq;
+    }
+  }
+}
+
+template <typename KeyAt, typename Emit>
+__device__ __forceinline__ void block_select_topk_ordered_keys(KeyAt key_at, int n, int k, SelectScratch& S, Emit emit,
+                                                               bool bits_ready = false) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  uint32_t prefix = 0;
+  int kk = k;
+  // bytes shared by every key (bf16-valued scores: the two low bytes; probabilities: most of the top byte) are
+  // found with one atomic-free sweep and skip their radix pass
+  // (callers that stage the keys themselves fold this sweep into their staging loop: `select_bits_begin` before,
+  //  `select_bits_add` with each thread's OR / AND, then `bits_ready` = true)
+  if (!bits_ready) {
+    select_bits_begin(S);
+    uint32_t o = 0u, an = 0xffffffffu;
+    for (int i = tid; i < n; i += nt) {
+      const uint32_t key = key_at(i);
+      o |= key;
+      an &= key;
+    }
+    select_bits_add(S, o, an);
+    __syncthreads();
+  }
+  const uint32_t all_and = S.and_bits;
+  const uint32_t varying = S.or_bits ^ all_and;              // bit positions on which the keys differ
+  // 8-bit digits are laid from the highest varying bit down to the lowest one (not on byte boundaries): the first
+  // digit then spreads over the bins even when the keys share their leading bits (probabilities share sign and the
+  // upper exponent bits and would pile into a handful of bins - serialised LDS atomics), and digits made of shared
+  // bits only are never histogrammed (bf16-valued scores: 2 passes instead of 4)
+  prefix = all_and;                                           // shared bits are those of every key, the k-th too
+  const int top = varying ? 31 - __builtin_clz(varying) : -1;       // highest bit still undecided
+  const int low = varying ? __builtin_ctz(varying) : 0;
+  select_radix_passes(key_at, n, S, prefix, kk, top, low);
+  select_ordered_emit(key_at, n, prefix, kk, S, emit);
 }
 
 // `score_at(i)` form (callers that mask or remap scores on the fly)

@@ -93,6 +93,58 @@ def test_score_pages_and_view_golden(golden):
         np.testing.assert_array_equal(ll.cpu().numpy(), g[f"{tag}_lens"])
 
 
+@pytest.mark.parametrize("dist", ["normal", "normal_bf16", "uniform_one_binade", "narrow", "all_equal", "two_values",
+                                  "with_neg_inf", "tiny_probabilities"])
+@pytest.mark.parametrize("shape", [dict(n_prev=8191, prev_budget=291), dict(n_prev=2047, prev_budget=255),
+                                   dict(n_prev=20000, prev_budget=1023), dict(n_prev=700, prev_budget=699)])
+def test_build_view_selection_exact_over_score_distributions(dist, shape):
+    """The page top-k of `svk_quest_build_view` == the first prev_budget entries of a stable descending argsort, as a
+    set written in ascending page order, for score rows that drive the select through each of its routes: a handful
+    of candidates in the k-th score's leading-bits bin (counted), hundreds (radix passes over the candidate list),
+    more than the list holds (radix passes over all keys), all keys equal (no pass at all)."""
+    from sparse_vllm_amd.kernels.quest_ops import build_view
+    n_prev, prev_budget = shape["n_prev"], shape["prev_budget"]
+    page, B = 16, 3
+    rng = np.random.default_rng(n_prev + len(dist))
+    if dist == "normal":
+        sc = rng.standard_normal((B, n_prev)).astype(np.float32) * 3
+    elif dist == "normal_bf16":
+        sc = bf16_round(rng.standard_normal((B, n_prev)).astype(np.float32) * 3)
+    elif dist == "uniform_one_binade":
+        sc = (1.0 + rng.random((B, n_prev))).astype(np.float32)
+    elif dist == "narrow":
+        sc = (1.0 + rng.random((B, n_prev)) * 2.0 ** -14).astype(np.float32)
+    elif dist == "all_equal":
+        sc = np.full((B, n_prev), 0.25, dtype=np.float32)
+    elif dist == "two_values":
+        sc = rng.choice(np.array([1.5, -2.0], dtype=np.float32), (B, n_prev))
+    elif dist == "with_neg_inf":
+        sc = bf16_round(rng.standard_normal((B, n_prev)).astype(np.float32))
+        sc[:, n_prev - n_prev // 3:] = -np.inf
+        sc[1, prev_budget // 2:] = -np.inf
+    else:
+        sc = (rng.random((B, n_prev)) ** 8 * 1e-3).astype(np.float32)
+    n_pages = n_prev + 1
+    ptab = np.stack([rng.permutation(n_pages * B)[:n_pages] for _ in range(B)]).astype(np.int32)
+    d = dev()
+    lens = np.full(B, n_pages * page - 5, dtype=np.int32)
+    keep = (prev_budget + 1) * page
+    packed = torch.zeros((B, keep), dtype=torch.int32, device=d)
+    ll = torch.zeros((B,), dtype=torch.int32, device=d)
+    lr = torch.zeros((B,), dtype=torch.int32, device=d)
+    ttab = torch.zeros((B, 16), dtype=torch.int32, device=d)
+    build_view(torch.from_numpy(sc).to(d), torch.from_numpy(ptab).to(d), ttab, torch.arange(B, dtype=torch.int32, device=d),
+               torch.from_numpy(lens).to(d), packed, ll, lr, page_size=page, n_prev=n_prev, prev_budget=prev_budget,
+               token_budget=prev_budget * page + page, page_budget_base=prev_budget + 1, max_keep=keep, is_long_text=True)
+    got = packed.cpu().numpy()
+    for b in range(B):
+        order = np.sort(np.argsort(-sc[b], kind="stable")[:prev_budget])
+        exp_pages = np.concatenate((ptab[b, order], ptab[b, n_pages - 1:n_pages]))
+        exp = (exp_pages[:, None].astype(np.int64) * page + np.arange(page)[None, :]).reshape(-1)
+        np.testing.assert_array_equal(got[b], exp)
+    np.testing.assert_array_equal(ll.cpu().numpy(), prev_budget * page + (lens - n_prev * page))
+
+
 def test_quest_scores_qwen7b_shape_vs_oracle():
     from sparse_vllm_amd.kernels.quest_ops import page_minmax, score_pages
     rng = np.random.default_rng(4)
