@@ -36,6 +36,19 @@ __device__ __forceinline__ float block_allsum(float x, float* red) {
   return r;
 }
 
+// inclusive prefix sum over the 64 lanes on the DPP network (a __shfl_up scan is six ds_bpermute round trips through the
+// LDS crossbar): Hillis-Steele inside each row of 16 lanes (sources outside the row read as 0), then the row totals
+// ripple with the two row broadcasts
+__device__ __forceinline__ int wave_incl_scan_add(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);    // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
 // exclusive prefix count of a 1-bit flag over the block, plus the block total
 __device__ __forceinline__ int block_excl_count(bool flag, int* wsum, int& total) {
   const unsigned long long bal = __ballot(flag);
@@ -145,12 +158,7 @@ __device__ __forceinline__ void select_radix_passes_sweep(Sweep sweep, SelectScr
       int local = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { c[j] = S.hist[tid * 4 + j]; local += c[j]; }
-      int incl = local;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (tid >= o) incl += v;
-      }
+      const int incl = wave_incl_scan_add(local);
       const int excl = incl - local;
       if (kk > excl && kk <= incl) {
         int run = excl;
@@ -193,12 +201,7 @@ __device__ __forceinline__ void select_radix_passes(KeyAt key_at, int n, SelectS
 // the counts of all lower-numbered threads.
 __device__ __forceinline__ void select_emit_offsets(int n_lt, int n_eq, SelectScratch& S, int& lt_before, int& eq_before) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  int il = n_lt, ie = n_eq;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(il, o, 64), u = __shfl_up(ie, o, 64);
-    if (lane >= o) { il += v; ie += u; }
-  }
+  const int il = wave_incl_scan_add(n_lt), ie = wave_incl_scan_add(n_eq);
   __syncthreads();
   if (lane == 63) { S.wsum[w] = il; S.wsum2[w] = ie; }
   __syncthreads();
