@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=128, help="sequences per GPU (a 288 GB MI355X holds far more 4224-token "
-                    "rows than this; 64 = the round-1 default, see profiles/ for 64 / 128 / 256)")
+    ap.add_argument("--batch", type=int, default=256, help="sequences per GPU (a 288 GB MI355X holds far more 4224-token "
+                    "rows than this; 256 rows = one unsplit stage-1 workgroup per CU; "
+                    "64 = the round-1 default, see profiles/ for 64 / 128 / 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of hipGraph replay")

@@ -2,7 +2,7 @@
 """profiles/stage1_traffic.json from the two PMC passes of tools/refresh_profiles.sh (FETCH_SIZE, WRITE_SIZE; separate
 rocprofv3 runs over tools/kbench.py): HBM bytes per stage-1 launch, with the gfx950 FETCH_SIZE correction of the
 micro-architecture guide.  bench.py reports the figure as roofline.traffic when its workload matches `batch`.
-  python tools/make_traffic_json.py profiles/r02 128 2112 4224"""
+  python tools/make_traffic_json.py profiles/r02 256 4224 4224"""
 import csv
 import json
 import os

@@ -19,8 +19,8 @@ timeout 600 python3 "$R/bench.py" < /dev/null > "$O/bench_stdout.log" 2> "$O/ben
 stats bench_kernel_stats.csv python3 "$R/bench.py" --steps 128 --warmup 8 --no-cpu-baseline
 grep '^{' "$O/_bench_kernel_stats.log" | tail -1 > "$O/bench_line_profiled.json"
 for b in 1 8 32; do timeout 300 python3 "$R/bench.py" --batch $b --no-cpu-baseline --no-kernel-events < /dev/null 2>/dev/null | tail -1 >> "$O/bench_small_batches.jsonl"; done
-# the roofline leg at the neighbouring batch sizes (the default is 128)
-for b in 64 256; do timeout 400 python3 "$R/bench.py" --batch $b --no-cpu-baseline < /dev/null 2>/dev/null | tail -1 >> "$O/bench_other_batches.jsonl"; done
+# the roofline leg at the neighbouring batch sizes (the default is 256)
+for b in 64 128 512; do timeout 400 python3 "$R/bench.py" --batch $b --no-cpu-baseline < /dev/null 2>/dev/null | tail -1 >> "$O/bench_other_batches.jsonl"; done
 # other configurations
 timeout 600 python3 "$R/tools/pathbench.py" --graph < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_graph.jsonl"
 timeout 600 python3 "$R/tools/pathbench.py" < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_eager.jsonl"
@@ -32,10 +32,10 @@ timeout 300 python3 "$R/tools/kbench_kivi.py" --sink 0 --tail 0 < /dev/null 2>/d
 timeout 300 python3 "$R/tools/kbench_prefill.py" < /dev/null 2>/dev/null | grep prefill > "$O/paths/kbench_prefill.txt"
 timeout 300 python3 "$R/tools/kbench_prefill_score.py" < /dev/null 2>/dev/null | grep prefill_score > "$O/paths/kbench_prefill_score.txt"
 stats paths/prefill_h2o_kernel_stats.csv python3 "$R/tools/prefillbench.py"
-timeout 300 python3 "$R/tools/kbench.py" --batches 64,128 --block-seqs 1056,2112 --modes 2 --layers 6 < /dev/null 2>/dev/null | tail -6 > "$O/kbench_stage1.txt"
+timeout 300 python3 "$R/tools/kbench.py" --batches 128,256 --block-seqs 2112,4224 --modes 2 --layers 6 < /dev/null 2>/dev/null | tail -6 > "$O/kbench_stage1.txt"
 # HBM traffic of stage 1: separate counter passes, nothing else traced
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $ctr --output-format csv -d "$O/_pmc_$ctr" -- python3 "$R/tools/kbench.py" --batches 128 --block-seqs 2112 --modes 2 --iters 3 < /dev/null > "$O/_pmc_$ctr.log" 2>&1
+  timeout 400 rocprofv3 --pmc $ctr --output-format csv -d "$O/_pmc_$ctr" -- python3 "$R/tools/kbench.py" --batches 256 --block-seqs 4224 --modes 2 --iters 3 < /dev/null > "$O/_pmc_$ctr.log" 2>&1
   f=$(find "$O/_pmc_$ctr" -type f -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$O/kbench_pmc_$ctr.csv"
 done
