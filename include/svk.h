@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 7
+#define SVK_ABI_VERSION 8
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -131,6 +131,13 @@ typedef struct SvkFlashDecodeStage1Args {
   const uint16_t* new_v;
   const int32_t* slot_mapping;   /* [B] */
   int64_t new_stride_b, new_stride_h;
+  /* Optional direct output: when the grid has ONE block per sequence (max_len_in_batch <= block_seq) the stage-2 merge
+   * (flash_decoding_stage2.py:8-46) of that single partial is the identity followed by the bf16 rounding, so with
+   * direct_o != NULL the kernel writes bf16(acc / l) to direct_o[b, head, :] itself - bit-identical to stage 1 +
+   * stage 2 - and leaves mid_o untouched (mid_lse is still written); a row without tokens gets zeros.  The stage-2
+   * launch of the layer disappears.  Stage-1 variant 3 only. */
+  uint16_t* direct_o;            /* NULL or [B, Hq, D] bf16 */
+  int64_t direct_stride_b, direct_stride_h;
 } SvkFlashDecodeStage1Args;
 int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_stream_t stream);
 

@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 7
+SVK_ABI_VERSION = 8
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -55,7 +55,8 @@ class SvkFlashDecodeStage1Args(C.Structure):
                 ("score_stride_h", _i64),
                 ("batch", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
                 ("max_len_in_batch", _i32), ("block_seq", _i32), ("score_mode", _i32),
-                ("new_k", _p), ("new_v", _p), ("slot_mapping", _p), ("new_stride_b", _i64), ("new_stride_h", _i64)]
+                ("new_k", _p), ("new_v", _p), ("slot_mapping", _p), ("new_stride_b", _i64), ("new_stride_h", _i64),
+                ("direct_o", _p), ("direct_stride_b", _i64), ("direct_stride_h", _i64)]
 
 
 class SvkFlashDecodeStage2Args(C.Structure):

@@ -892,10 +892,15 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a, const SvkH2oDecodeScor
   float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)blk * a.mid_o_stride_s;
   float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + blk;
 
+  uint16_t* direct_o = a.direct_o == nullptr ? nullptr : a.direct_o + (int64_t)b * a.direct_stride_b;
   if (end <= start) {
     for (int h = 0; h < G; ++h) {
-      float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h;
-      for (int d = lane; d < D; d += 64) o[d] = 0.f;
+      if (direct_o != nullptr) {
+        for (int d = lane; d < D; d += 64) direct_o[(int64_t)(w * G + h) * a.direct_stride_h + d] = 0;
+      } else {
+        float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h;
+        for (int d = lane; d < D; d += 64) o[d] = 0.f;
+      }
       if (lane == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = -INFINITY;
     }
     if constexpr (FUSED) fused_row_finish<D>(a, fs, fo, fo_stride_b, fo_stride_h, tickets, b, lds);
@@ -1138,9 +1143,19 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a, const SvkH2oDecodeScor
       if (h < G) {
         if (n_e == 0) mid_lse[(int64_t)(w * G + h) * a.mid_lse_stride_h] = m[r] + __logf(l[r]);
         if (n_e < DW) {
-          float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h + (n_e % DW) * 8;
-          *reinterpret_cast<float4*>(o) = make_float4(acc[0][r] / l[r], acc[1][r] / l[r], acc[2][r] / l[r], acc[3][r] / l[r]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4][r] / l[r], acc[5][r] / l[r], acc[6][r] / l[r], acc[7][r] / l[r]);
+          if (direct_o != nullptr) {
+            // the single partial of the row IS the output: stage 2 would weight it by exp(lse - lse) = 1 and round
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              pk[e] = f32_to_bf16_bits(acc[2 * e][r] / l[r]) | (f32_to_bf16_bits(acc[2 * e + 1][r] / l[r]) << 16);
+            *reinterpret_cast<uint4*>(direct_o + (int64_t)(w * G + h) * a.direct_stride_h + (n_e % DW) * 8) =
+                make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          } else {
+            float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h + (n_e % DW) * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(acc[0][r] / l[r], acc[1][r] / l[r], acc[2][r] / l[r], acc[3][r] / l[r]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4][r] / l[r], acc[5][r] / l[r], acc[6][r] / l[r], acc[7][r] / l[r]);
+          }
         }
       }
     }
@@ -1385,6 +1400,13 @@ static int validate_stage1(const SvkFlashDecodeStage1Args* a, const char* who) {
                     (reinterpret_cast<uintptr_t>(a->new_v) % 16) == 0,
                 SVK_ERR_LAYOUT, "%s: new_k/new_v rows must be 16-byte aligned", who);
     SVK_REQUIRE(stage1_variant() >= 3, SVK_ERR_VALUE, "%s: the fused store is only built into stage-1 variants 3 and 4", who);
+  }
+  if (a->direct_o != nullptr) {
+    SVK_REQUIRE(a->max_len_in_batch <= a->block_seq, SVK_ERR_VALUE,
+                "%s: direct_o needs one block per sequence (max_len_in_batch %d > block_seq %d)", who, a->max_len_in_batch, a->block_seq);
+    SVK_REQUIRE(stage1_variant() == 3, SVK_ERR_VALUE, "%s: direct_o is only built into stage-1 variant 3", who);
+    SVK_REQUIRE((a->direct_stride_b % 8) == 0 && (a->direct_stride_h % 8) == 0 && (reinterpret_cast<uintptr_t>(a->direct_o) % 16) == 0,
+                SVK_ERR_LAYOUT, "%s: direct_o rows must be 16-byte aligned", who);
   }
   return SVK_OK;
 }

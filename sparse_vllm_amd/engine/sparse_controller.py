@@ -270,10 +270,18 @@ class SparseController:
         """"fused" | "stage1" | "end" (see __init__)."""
         return {"0": "fused", "1": "stage1"}.get(self._defer_h2o_mode, "end")
 
-    def fused_decode_finish(self, layer_idx: int, mid_o, mid_lse, context_lens, o, block_seq) -> bool:
+    def decode_direct_out_allowed(self, layer_idx: int, batch_size: int) -> bool:
+        """May stage 1 write the layer's output itself when one block covers the rows (no stage 2)?  Not when this
+        controller wants stage 2 and the score epilogue as one launch (`SVK_H2O_DEFER_SCORE=0`)."""
+        if self.sparse_method != "h2o" or get_context().is_prefill or self._h2o_score_stream_enabled:
+            return True
+        return self._h2o_score_mode(int(batch_size)) != "fused"
+
+    def fused_decode_finish(self, layer_idx: int, mid_o, mid_lse, context_lens, o, block_seq, merged: bool = False) -> bool:
         """MI355X fusion hook called by the attention backend instead of `flash_decode_stage2`:
         for H2O decode, stage 2 and this layer's `on_layer_attention_end` score epilogue run as
-        one launch (svk_h2o_decode_finish).  Returns False when there is nothing to fuse."""
+        one launch (svk_h2o_decode_finish).  Returns False when there is nothing to fuse.  `merged`: stage 1 already
+        wrote `o` (single-block launch), only the score bookkeeping is left."""
         if self.sparse_method != "h2o" or get_context().is_prefill or self._h2o_score_stream_enabled:
             return False
         s = self.layer_batch_sparse_states[layer_idx]
@@ -287,7 +295,8 @@ class SparseController:
             from ..kernels.gqa_flash_decoding_stage1 import h2o_score_args
             if mode == "stage1":
                 self.flush_deferred_score()          # at most one layer is ever pending
-            flash_decode_stage2(mid_o, mid_lse, context_lens, o, block_seq)
+            if not merged:
+                flash_decode_stage2(mid_o, mid_lse, context_lens, o, block_seq)
             new_slots = self._h2o_new_slots(layer_idx)
             entry = (h2o_score_args(s.attn_score, self.attn_softmax_scale, cum_score=cum, b_req_idx=s.req_indices,
                                     b_seqlen=context_lens, b_new_slot=new_slots),
@@ -298,6 +307,8 @@ class SparseController:
                 self._pending_scores.append(entry)
             self._layer_score_finished[layer_idx] = True
             return True
+        if merged:
+            raise RuntimeError("H2O fused finish needs the stage-1 partials (decode_direct_out_allowed was not consulted)")
         h2o_ops.h2o_decode_finish(mid_o, mid_lse, context_lens, o, block_seq, s.attn_score, self.attn_softmax_scale,
                                   cum_score=cum, b_req_idx=s.req_indices, b_new_slot=self._h2o_new_slots(layer_idx))
         self._layer_score_finished[layer_idx] = True

@@ -10,6 +10,7 @@ existing call sites (layers/attention_backend.py:284-349) keep working.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -32,8 +33,14 @@ def _assert_supported_layout(q, k, v, req_to_tokens, b_req_idx, b_seqlen, mid_ou
         f"mid_out_logsumexp block dimension must be contiguous, got stride={mid_out_logsumexp.stride()}.")
 
 
+def direct_out_supported(max_len_in_batch, block_seq) -> bool:
+    """True when stage 1 may write the attention output itself (`direct_out=`): one block per sequence, default kernel."""
+    return (int(max_len_in_batch) <= int(block_seq) and os.environ.get("SVK_STAGE1_VARIANT", "3") == "3"
+            and os.environ.get("SVK_DECODE_DIRECT_OUT", "1") != "0")
+
+
 def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                 attn_score, block_seq, new_kv=None):
+                 attn_score, block_seq, new_kv=None, direct_out=None):
     Lq, Lk = q.shape[-1], k.shape[-1]
     assert Lq == Lk
     assert Lk in {16, 32, 64, 128, 256}
@@ -66,6 +73,10 @@ def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, 
         assert slot_mapping.dtype == torch.int32 and slot_mapping.is_contiguous() and slot_mapping.numel() >= batch
         store = dict(new_k=_lib.ptr(new_k), new_v=_lib.ptr(new_v), slot_mapping=_lib.ptr(slot_mapping),
                      new_stride_b=new_k.stride(0), new_stride_h=new_k.stride(1))
+    if direct_out is not None:
+        # MI355X: a single-block launch writes bf16(acc / l) itself; the stage-2 launch disappears (include/svk.h)
+        assert direct_out.dtype == torch.bfloat16 and direct_out.shape == q.shape and direct_out.stride(-1) == 1
+        store.update(direct_o=_lib.ptr(direct_out), direct_stride_b=direct_out.stride(0), direct_stride_h=direct_out.stride(1))
     return _lib.SvkFlashDecodeStage1Args(
         q=_lib.ptr(q), k_cache=_lib.ptr(k), v_cache=_lib.ptr(v), req_to_tokens=_lib.ptr(Req_to_tokens),
         b_req_idx=_lib.ptr(B_req_idx), b_seqlen=_lib.ptr(B_Seqlen), mid_o=_lib.ptr(mid_out),
@@ -94,9 +105,9 @@ def h2o_score_args(attn_score, scale, *, cum_score=None, b_req_idx=None, b_seqle
 
 
 def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv=None, deferred_score=None):
+            attn_score, block_seq, new_kv=None, deferred_score=None, direct_out=None):
     a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                     attn_score, block_seq, new_kv)
+                     attn_score, block_seq, new_kv, direct_out)
     lib = _lib.load()
     if deferred_score is not None:
         _lib.check(lib.svk_flash_decode_stage1_deferred(C.byref(a), C.byref(deferred_score), _lib.current_stream_handle()), lib)
@@ -137,16 +148,19 @@ def h2o_decode_fused(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_bat
 
 @torch.no_grad()
 def flash_decode_stage1(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
-                        mid_out_logsumexp, block_seq, block_n=16, num_warps=2, num_stages=2, *, new_kv=None):
-    """`new_kv=(new_k, new_v, slot_mapping)` (MI355X extension): store this step's K/V rows inside the launch."""
+                        mid_out_logsumexp, block_seq, block_n=16, num_warps=2, num_stages=2, *, new_kv=None, direct_out=None):
+    """`new_kv=(new_k, new_v, slot_mapping)` (MI355X extension): store this step's K/V rows inside the launch.
+    `direct_out` [B, Hq, D] bf16 (MI355X extension, see `direct_out_supported`): the launch writes the attention output
+    itself and no stage 2 is needed."""
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp, None,
-            block_seq, new_kv)
+            block_seq, new_kv, direct_out=direct_out)
 
 
 @torch.no_grad()
 def flash_decode_stage1_with_score(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
-                                   mid_out_logsumexp, attn_score, block_seq, *, new_kv=None, deferred_score=None):
+                                   mid_out_logsumexp, attn_score, block_seq, *, new_kv=None, deferred_score=None,
+                                   direct_out=None):
     """`deferred_score` (MI355X extension, `h2o_score_args(...)` of the PREVIOUS layer): its score epilogue runs inside
-    this launch (svk_flash_decode_stage1_deferred)."""
+    this launch (svk_flash_decode_stage1_deferred).  `direct_out`: as in `flash_decode_stage1`."""
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv, deferred_score)
+            attn_score, block_seq, new_kv, deferred_score, direct_out=direct_out)

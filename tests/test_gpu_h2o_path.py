@@ -511,6 +511,71 @@ def test_decode_with_fused_store_equals_store_then_decode(shape, mode):
         np.testing.assert_array_equal(x[:B - 1], y[:B - 1])
 
 
+@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("shape", [
+    dict(B=3, Hq=28, Hkv=4, D=128, lens=[4224, 4100, 17], block_seq=4224),
+    dict(B=5, Hq=14, Hkv=2, D=64, lens=[1, 16, 33, 256, 300], block_seq=304),
+    dict(B=2, Hq=8, Hkv=8, D=128, lens=[512, 511], block_seq=512),
+    dict(B=4, Hq=7, Hkv=1, D=128, lens=[700, 0, 64, 1], block_seq=704),
+])
+def test_single_block_decode_writes_output_itself(shape, mode):
+    """`direct_out`: with one block per sequence the stage-1 launch writes the attention output (the stage-2 merge of
+    a single partial is the identity + bf16 rounding).  Output, lse and scores bit-identical to stage 1 + stage 2,
+    with and without the fused store; more than one block per row is refused."""
+    import os
+    from sparse_vllm_amd.kernels import flash_decode_stage1, flash_decode_stage1_with_score, flash_decode_stage2
+    from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import direct_out_supported
+    if os.environ.get("SVK_STAGE1_VARIANT", "3") != "3":
+        pytest.skip("direct output is built into the default stage-1 kernel only")
+    B, Hq, Hkv, D, lens, block_seq = (shape[k] for k in ("B", "Hq", "Hkv", "D", "lens", "block_seq"))
+    q, k, v, req, bidx, blen = _rand_case(77 + mode, B, Hq, Hkv, D, [max(n, 1) for n in lens], block_seq)
+    blen = np.array(lens, dtype=np.int32)
+    max_len = int(max(lens))
+    assert direct_out_supported(max_len, block_seq) and not direct_out_supported(block_seq + 1, block_seq)
+    tq, tk, tv = to_bf16(q), to_bf16(k), to_bf16(v)
+    treq, tb, tl = (torch.from_numpy(x).to(dev()) for x in (req, bidx, blen))
+    rng = np.random.default_rng(6)
+    nk, nv = (to_bf16(bf16_round((rng.standard_normal((B, Hkv, D)) * 0.3).astype(np.float32))) for _ in range(2))
+    sm = torch.from_numpy(np.array([req[bidx[b], max(blen[b], 1) - 1] for b in range(B)], dtype=np.int32)).to(dev())
+
+    def run(direct, store):
+        kc, vc = tk.clone(), tv.clone()
+        mid = torch.full((B, Hq, 1, D), 7.0, dtype=torch.float32, device=dev())
+        lse = torch.full((B, Hq, 1), 7.0, dtype=torch.float32, device=dev())
+        o = torch.full((B, Hq, D), 3.0, dtype=torch.bfloat16, device=dev())
+        score = None
+        if mode == 2:
+            score = torch.full((B, max_len), -1e20, dtype=torch.float32, device=dev())
+        elif mode == 3:
+            score = torch.full((B, Hq, max_len), -1e20, dtype=torch.float32, device=dev())
+        kw = dict(new_kv=(nk, nv, sm) if store else None, direct_out=o if direct else None)
+        if score is not None:
+            flash_decode_stage1_with_score(tq, kc, vc, treq, tb, tl, max_len, mid, lse, score, block_seq, **kw)
+        else:
+            flash_decode_stage1(tq, kc, vc, treq, tb, tl, max_len, mid, lse, block_seq, **kw)
+        if not direct:
+            flash_decode_stage2(mid, lse, tl, o, block_seq)
+        else:
+            assert float(mid.min()) == 7.0                      # the partials were not written
+        torch.cuda.synchronize()
+        return o, lse, score
+
+    for store in (False, True):
+        (o1, l1, s1), (o2, l2, s2) = run(False, store), run(True, store)
+        live = torch.from_numpy(blen > 0).to(dev())             # an empty row: NaN from the merge, zeros from the direct write
+        assert torch.equal(o1[live].view(torch.int16), o2[live].view(torch.int16))
+        assert torch.equal(l1, l2)
+        if s1 is not None:
+            assert torch.equal(s1, s2)
+        if not bool(live.all()):
+            assert float(o2[~live].float().abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        mid = torch.zeros((B, Hq, 2, D), dtype=torch.float32, device=dev())
+        lse = torch.zeros((B, Hq, 2), dtype=torch.float32, device=dev())
+        flash_decode_stage1(tq, tk, tv, treq, tb, tl, max_len, mid, lse, -(-(-(-max_len // 2)) // 16) * 16,
+                            direct_out=torch.empty((B, Hq, D), dtype=torch.bfloat16, device=dev()))
+
+
 @pytest.mark.parametrize("case", [dict(B=1, Hq=28, D=128, nblk=64, block_seq=66), dict(B=3, Hq=28, D=128, nblk=700, block_seq=256),
                                   dict(B=2, Hq=14, D=64, nblk=33, block_seq=128), dict(B=4, Hq=8, D=128, nblk=3, block_seq=2048, cap=1025)])
 def test_split_kv_merge_many_partials_vs_float64(case):

@@ -13,3 +13,4 @@ run SVK_FUSE_DECODE_STORE=0 "h2o or decode or streamingllm or quest or vanilla"
 run SVK_DELTAKV_RECON_AHEAD=0 "deltakv"
 run SVK_DELTAKV_FUSE_RAW_STORE=0 "deltakv"
 run SVK_QUEST_VIEW_VARIANT=1 "quest"
+run SVK_DECODE_DIRECT_OUT=0 "h2o or decode or streamingllm or fuzz or full_size"
