@@ -525,8 +525,8 @@ def test_single_block_decode_writes_output_itself(shape, mode):
     import os
     from sparse_vllm_amd.kernels import flash_decode_stage1, flash_decode_stage1_with_score, flash_decode_stage2
     from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import direct_out_supported
-    if os.environ.get("SVK_STAGE1_VARIANT", "3") != "3":
-        pytest.skip("direct output is built into the default stage-1 kernel only")
+    if os.environ.get("SVK_STAGE1_VARIANT", "3") != "3" or os.environ.get("SVK_DECODE_DIRECT_OUT", "1") == "0":
+        pytest.skip("direct output is built into the default stage-1 kernel only (and switched off by SVK_DECODE_DIRECT_OUT=0)")
     B, Hq, Hkv, D, lens, block_seq = (shape[k] for k in ("B", "Hq", "Hkv", "D", "lens", "block_seq"))
     q, k, v, req, bidx, blen = _rand_case(77 + mode, B, Hq, Hkv, D, [max(n, 1) for n in lens], block_seq)
     blen = np.array(lens, dtype=np.int32)
