@@ -55,11 +55,16 @@ class Mi355xDecodeLaunchProvider(DecodeAttentionLaunchProvider):
       B=64: 1056 -> 83.8 us, 528 -> 85.5, 352 -> 86.4, 272 -> 92.7, 192 -> 101.2, 2112 -> 118.8
       B=32:  528 -> 45.7 us, 272 -> 47.6, 176 -> 46.6        B=16: 352 -> 26.8 us, 272 -> 27.2, 528 -> 33.1
     Fewer, longer blocks amortise the per-block prologue / epilogue and the stage-2 partials as long as every CU
-    still owns a workgroup.  So: the largest 16-aligned BLOCK_SEQ that still yields >= one block per CU."""
+    still owns a workgroup.  So: the largest 16-aligned BLOCK_SEQ that still yields >= one block per CU - and, for the
+    1- and 2-KV-head ranks of a tensor-parallel model (a workgroup is then one or two waves), >= one wave per SIMD:
+      Hq/Hkv = 7/1, B=256: 4224 -> 178.9 us (3.1 TB/s), 2112 -> 112.6, 1056 -> 97.9 (5.7 TB/s); B=64: 1056 -> 51.3, 272 -> 30.1
+      Hq/Hkv = 14/2, B=256: 4224 -> 208.2 us, 2112 -> 186.4 (6.0 TB/s)"""
     name = "mi355x_hip"
     priority = 100
     RESIDENT_WORKGROUPS = 256       # one workgroup per CU
+    RESIDENT_WAVES = 1024           # one wave per SIMD
     MIN_BLOCK_SEQ = 64
+    wants_kv_heads = True           # PreparedDecodeAttentionLaunchOp passes the spec's num_kv_heads
 
     def supports(self, spec, caps):
         if caps.platform != PlatformEnum.ROCM:
@@ -74,22 +79,27 @@ class Mi355xDecodeLaunchProvider(DecodeAttentionLaunchProvider):
             return SupportResult.no("1..8 KV heads per rank")
         return SupportResult.yes()
 
-    def launch_config(self, *, block_seq, max_context_len, requires_attention_scores, batch_size=None):
+    def launch_config(self, *, block_seq, max_context_len, requires_attention_scores, batch_size=None, num_kv_heads=None):
         b = max(1, int(batch_size or 1))
         length = max(1, int(max_context_len))
-        nblk = max(1, -(-self.RESIDENT_WORKGROUPS // b))                 # blocks per sequence wanted
+        hkv = max(1, int(num_kv_heads or 4))                             # waves per workgroup
+        groups = max(self.RESIDENT_WORKGROUPS, -(-self.RESIDENT_WAVES // hkv))
+        nblk = max(1, -(-groups // b))                                   # blocks per sequence wanted
         bs = -(-length // nblk)                                          # tokens per block
         bs = max(self.MIN_BLOCK_SEQ, -(-bs // 16) * 16)
         return bs, 16, 4
 
 
 class PreparedDecodeAttentionLaunchOp:
-    def __init__(self, provider: DecodeAttentionLaunchProvider):
+    def __init__(self, provider: DecodeAttentionLaunchProvider, spec: DecodeAttentionLaunchSpec | None = None):
         self.provider = provider
+        self.spec = spec
 
     def launch_config(self, **kw):
+        if self.spec is not None and getattr(self.provider, "wants_kv_heads", False):
+            kw.setdefault("num_kv_heads", int(self.spec.num_kv_heads))
         return self.provider.launch_config(**kw)
 
 
 def prepare_decode_launch_op(spec: DecodeAttentionLaunchSpec, caps: DeviceCaps) -> PreparedDecodeAttentionLaunchOp:
-    return PreparedDecodeAttentionLaunchOp(OpResolver(DECODE_LAUNCH_REGISTRY).resolve(spec, caps))
+    return PreparedDecodeAttentionLaunchOp(OpResolver(DECODE_LAUNCH_REGISTRY).resolve(spec, caps), spec)

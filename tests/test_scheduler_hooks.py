@@ -80,3 +80,28 @@ def test_base_capacity_hooks_defaults():
     assert m.prompt_admission_cost(seqs[0]) == 26 and m.prompt_admission_costs(seqs[1]) == {"slots": 9}
     assert m.prefill_step_free_slots() == 37 == m.decode_step_free_slots_for(seqs[0])
     assert m.prefill_step_reservation_cost(seqs[0], 5) == 5 and m.decode_step_reservation_cost(seqs[0]) == 1
+
+
+def test_mi355x_decode_launch_geometry():
+    """`Mi355xDecodeLaunchProvider` (the reference's DecodeAttentionLaunchProvider pattern, operators/decode_attention.py:
+    13-158): the largest 16-aligned BLOCK_SEQ that keeps one workgroup per CU and - for 1- and 2-KV-head tensor-parallel
+    ranks, whose workgroups are one or two waves - one wave per SIMD; the default provider keeps the caller's value."""
+    from sparse_vllm_amd.operators.decode_attention import DecodeAttentionLaunchSpec, prepare_decode_launch_op
+    from sparse_vllm_amd.operators.registry import DeviceCaps, PlatformEnum
+    caps = DeviceCaps(platform=PlatformEnum.ROCM, arch="gfx950", num_cus=256)
+    def cfg(hq, hkv, batch, length):
+        op = prepare_decode_launch_op(DecodeAttentionLaunchSpec(num_heads=hq, num_kv_heads=hkv, head_dim=128), caps)
+        return op.launch_config(block_seq=256, max_context_len=length, requires_attention_scores=True, batch_size=batch)[0]
+    assert cfg(28, 4, 256, 4224) == 4224           # one block per sequence: stage 1 writes the output itself
+    assert cfg(28, 4, 128, 4224) == 2112
+    assert cfg(28, 4, 64, 4224) == 1056
+    assert cfg(28, 4, 1, 4224) == 64               # floor: MIN_BLOCK_SEQ
+    assert cfg(32, 8, 256, 4224) == 4224           # 8 waves per workgroup: still one workgroup per CU
+    assert cfg(14, 2, 256, 4224) == 2112           # two waves per workgroup -> 512 workgroups
+    assert cfg(7, 1, 256, 4224) == 1056            # one wave per workgroup -> 1024 workgroups
+    assert cfg(7, 1, 64, 4224) == 272
+    for hkv in (1, 2, 4, 8):
+        assert cfg(8 * hkv // hkv * hkv if hkv > 1 else 7, hkv, 16, 8192) % 16 == 0
+    other = DeviceCaps(platform=PlatformEnum.ROCM, arch="gfx942", num_cus=304)
+    op = prepare_decode_launch_op(DecodeAttentionLaunchSpec(num_heads=28, num_kv_heads=4, head_dim=128), other)
+    assert op.launch_config(block_seq=256, max_context_len=4224, requires_attention_scores=False, batch_size=256) == (256, 16, 2)

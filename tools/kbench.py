@@ -22,9 +22,11 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--modes", default="2,0")
     ap.add_argument("--layers", type=int, default=6, help="distinct K/V sets cycled through (defeats the 256 MB MALL)")
+    ap.add_argument("--heads", default="28,4", help="query heads, KV heads of the rank (7,1 = one TP=4 rank of Qwen2.5-7B)")
     args = ap.parse_args()
     d = torch.device("cuda:0")
-    Hq, Hkv, D, L = 28, 4, 128, args.len
+    Hq, Hkv = (int(x) for x in args.heads.split(","))
+    D, L = 128, args.len
     torch.manual_seed(20260625)
     for B in [int(x) for x in args.batches.split(",")]:
         slots = B * L + 4096
