@@ -24,9 +24,11 @@ def main():
     ap.add_argument("--score", action="store_true")
     ap.add_argument("--sink", type=int, default=8)
     ap.add_argument("--tail", type=int, default=48)
+    ap.add_argument("--heads", default="28,4", help="query heads, KV heads of the rank (7,1 = one TP=4 rank of Qwen2.5-7B)")
     args = ap.parse_args()
     d = torch.device("cuda:0")
-    Hq, Hkv, D, G, sink, tail = 28, 4, 128, 32, args.sink, args.tail
+    Hq, Hkv = (int(x) for x in args.heads.split(","))
+    D, G, sink, tail = 128, 32, args.sink, args.tail
     torch.manual_seed(1)
     for B in [int(x) for x in args.batches.split(",")]:
         L = args.ctx
