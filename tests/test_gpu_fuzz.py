@@ -68,6 +68,19 @@ def test_fuzz_decode_stage1(seed):
         flash_decode_stage1_with_score(tb(q), tb(k), tb(v), ti(table), ti(rows), ti(lens), max_len, mid, lse, score, block_seq)
     o = torch.empty((B, Hq, D), dtype=torch.bfloat16, device=dev())
     flash_decode_stage2(mid, lse, ti(lens), o, block_seq)
+    from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import direct_out_supported
+    if nblk == 1 and direct_out_supported(max_len, block_seq):
+        # single-block launch: stage 1 writes the output itself, bit-identical to the two launches above
+        o2 = torch.empty_like(o)
+        lse2 = torch.full_like(lse, 7.0)
+        if score is None:
+            flash_decode_stage1(tb(q), tb(k), tb(v), ti(table), ti(rows), ti(lens), max_len, mid, lse2, block_seq, direct_out=o2)
+        else:
+            score2 = torch.full_like(score, -1e20)
+            flash_decode_stage1_with_score(tb(q), tb(k), tb(v), ti(table), ti(rows), ti(lens), max_len, mid, lse2, score2,
+                                           block_seq, direct_out=o2)
+            assert torch.equal(score2, score)
+        assert torch.equal(o2.view(torch.int16), o.view(torch.int16)) and torch.equal(lse2, lse)
     torch.cuda.synchronize()
     mid_ref, lse_ref = oda.flash_decode_stage1(q, k, v, table, rows, lens, max_len, block_seq, attn_score=score_ref)
     o_ref = oda.flash_decode_stage2(mid_ref, lse_ref, lens, block_seq)
