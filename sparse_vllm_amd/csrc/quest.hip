@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBu
 #pragma unroll
     for (int j = 0; j < C; ++j) key[j] = desc_key(v[j]);
     block_select_topk_ordered_owned<C>(key, per, a.n_prev, a.prev_budget, scratch,
-                                       [&](int pos, int idx) { sel_pages[pos] = idx; });
+                                       [&](int pos, int idx, uint32_t) { sel_pages[pos] = idx; });
   } else if (lds_keys) {
     // keys staged in LDS (8 scores per thread and trip with the loads first, the select's OR / AND sweep folded in)
     uint32_t* keys = reinterpret_cast<uint32_t*>(sel_pages + a.prev_budget);

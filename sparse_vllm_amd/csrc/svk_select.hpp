@@ -239,7 +239,7 @@ __device__ __forceinline__ void select_ordered_emit(KeyAt key_at, int n, uint32_
 
 // The select with the keys in registers: thread t owns the `per` (<= CH, the same for all threads) consecutive indices
 // from t * per (key[j] = key of index t * per + j; indices >= n are ignored whatever their key), so neither the passes
-// nor the emit read memory.
+// nor the emit read memory; `emit(pos, idx, key)`.
 template <int CH, typename Emit>
 __device__ __forceinline__ void block_select_topk_ordered_owned(const uint32_t (&key)[CH], int per, int n, int k,
                                                                 SelectScratch& S, Emit emit) {
@@ -276,7 +276,7 @@ __device__ __forceinline__ void block_select_topk_ordered_owned(const uint32_t (
     if (j < per) {
       const bool in = base + j < n;
       const bool lt = in && key[j] < T, eq = in && key[j] == T;
-      if (lt || (eq && eq_before < kk)) emit(lt_before + min(eq_before, kk), base + j);
+      if (lt || (eq && eq_before < kk)) emit(lt_before + min(eq_before, kk), base + j, key[j]);
       lt_before += lt;
       eq_before += eq;
     }
