@@ -248,3 +248,74 @@ def decode_softmax_token_scores(raw_scores, *, sink: int, compressed_lens, scale
         p = e / e.sum(axis=1, keepdims=True, dtype=np.float32)
         out[b, :c] = p.max(axis=0)
     return out
+
+
+def token_scores_full(raw_scores, *, candidate_start: int, candidate_lens, scale: float, model_dtype: str = "bfloat16"):
+    """sparse_controller.py:255-299 exactly as the caller sees it: [B, H, L] raw logits -> [B, L] token scores.
+    Candidates are positions [candidate_start, candidate_start + len): logits * scale, per-head softmax over the
+    candidates, max over heads, cast to the model dtype (bf16 / fp16 checkpoints; fp32 stays), every other
+    position = finfo(dtype).min.  Returned as float32 holding the dtype's values."""
+    raw = np.asarray(raw_scores, np.float32)
+    B, H, L = raw.shape
+    cs = int(candidate_start)
+    fill = {"bfloat16": np.float32(-3.3895313892515355e38), "float32": np.finfo(np.float32).min}[model_dtype]
+    out = np.full((B, L), fill, np.float32)
+    lens = np.clip(np.asarray(candidate_lens, np.int64), 0, L - cs)
+    for b in range(B):
+        c = int(lens[b])
+        if c <= 0:
+            continue
+        x = raw[b, :, cs:cs + c] * np.float32(scale)
+        x = x - x.max(axis=1, keepdims=True)
+        e = np.exp(x, dtype=np.float32)
+        p = (e / e.sum(axis=1, keepdims=True, dtype=np.float32)).max(axis=0)
+        out[b, cs:cs + c] = bf16_round(p) if model_dtype == "bfloat16" else p
+    return out
+
+
+def dynamic_topk_keys(token_scores, *, sink: int, compressed_lens, tiebreak: bool = False, model_dtype: str = "bfloat16"):
+    """The keys the reference's topk ranks (sparse_controller.py:1784-1811): token_scores[:, sink:] with
+    positions >= compressed_len set to -1e10 (stored in the score tensor's dtype: bf16 holds -9.999221e9); with the
+    deterministic tie-break, `float(s) + max(|s|, 1) * (pos / n * 1e-6)` first (fp32 op by op, so LATER positions
+    win among equal scores), masked again with the fp32 -1e10."""
+    s = np.asarray(token_scores, np.float32)[:, sink:].copy()
+    n = s.shape[1]
+    mask = np.arange(n)[None, :] >= np.asarray(compressed_lens, np.int64)[:, None]
+    s[mask] = bf16_round(np.float32(-1e10)) if model_dtype == "bfloat16" else np.float32(-1e10)
+    if tiebreak and s.size:
+        pos = np.arange(n, dtype=np.float32) / np.float32(max(1, n))
+        key = (pos * np.float32(1.0e-6))[None, :]
+        s = s + np.maximum(np.abs(s), np.float32(1.0)) * key
+        s[mask] = np.float32(-1e10)
+    return s
+
+
+def dynamic_topk_indices(token_scores, *, sink: int, compressed_lens, keep: int, tiebreak: bool = False,
+                         model_dtype: str = "bfloat16"):
+    """topk(min(keep, n), sorted=True) over `dynamic_topk_keys` -> int32 [B, k] relative to `sink`; equal keys in
+    ascending position (torch leaves that order unspecified — compare with `check_sorted_topk`)."""
+    keys = dynamic_topk_keys(token_scores, sink=sink, compressed_lens=compressed_lens, tiebreak=tiebreak,
+                             model_dtype=model_dtype)
+    k = min(int(keep), keys.shape[1])
+    if k <= 0:
+        return np.zeros((keys.shape[0], 0), np.int32)
+    return np.stack([np.argsort(-keys[b], kind="stable")[:k] for b in range(keys.shape[0])]).astype(np.int32)
+
+
+def check_sorted_topk(keys_row: np.ndarray, got: np.ndarray, ref: np.ndarray) -> bool:
+    """Two sorted top-k results over the same key row agree up to topk's freedom: the same key at every rank,
+    distinct indices, and the same index set for every key value strictly above the last rank's (indices that
+    share a key may be permuted among themselves, and at the last key value either may hold any of the tied
+    positions).  Returns True when the index arrays are identical."""
+    got, ref = np.asarray(got).reshape(-1), np.asarray(ref).reshape(-1)
+    assert got.shape == ref.shape
+    assert np.unique(got).size == got.size, "duplicate indices"
+    np.testing.assert_array_equal(keys_row[got], keys_row[ref])
+    if np.array_equal(got, ref):
+        return True
+    if got.size:
+        last = keys_row[ref[-1]]
+        above_g = np.sort(got[keys_row[got] > last])
+        above_r = np.sort(ref[keys_row[ref] > last])
+        np.testing.assert_array_equal(above_g, above_r)
+    return False

@@ -272,6 +272,7 @@ class SvkKiviDecodeStage1Args(C.Structure):
 ENTRY_POINTS = {
     "svk_abi_version": ([], C.c_int),
     "svk_last_error": ([], C.c_char_p),
+    "svk_build_flags": ([], C.c_int),
     "svk_store_kvcache": ([C.POINTER(SvkStoreKvcacheArgs), _p], C.c_int),
     "svk_copy_slots": ([C.POINTER(SvkCopySlotsArgs), _p], C.c_int),
     "svk_flash_decode_stage1": ([C.POINTER(SvkFlashDecodeStage1Args), _p], C.c_int),

@@ -48,6 +48,9 @@ _LEGACY_RUNTIME_KEYS = {
     "full_attn_layers": "full_attention_layers",
     "k_neighbors": "deltakv_neighbor_count",
     "deltakv_k_neighbors": "deltakv_neighbor_count",
+    "seq_chunk_size": "removed; use deltakv_neighbor_count for cluster reference top-k",
+    "compressor_token_group_size": "removed; use deltakv_neighbor_count for cluster reference top-k",
+    "ref_mode": "removed; cluster_e2e_big always uses cluster-derived references",
     "cluster_ratio": "deltakv_center_ratio",
     "kv_compressed_size": "deltakv_latent_dim",
     "kv_quant_bits": "deltakv_latent_quant_bits",
@@ -55,6 +58,9 @@ _LEGACY_RUNTIME_KEYS = {
     "chunk_prefill_size": "engine_prefill_chunk_size",
     "model_prefill_chunk_size": "engine_prefill_chunk_size",
     "sparsevllm_prefill_chunk_size": "engine_prefill_chunk_size",
+    "chunk_prefill_accel_omnikv": "removed; OmniKV prefill routing is runtime-owned",
+    "deltakv_visual_compress_only": "visual_token_prune_only",
+    "deltakv_visual_keep_ratio": "visual_token_keep_ratio",
 }
 
 
@@ -116,7 +122,7 @@ class Config:
     quest_skip_layers: int = 2
     snapkv_window_size: int = 32
     snapkv_num_full_layers: int = 0
-    snapkv_pooling_kernel_size: int = 0
+    pool_kernel_size: int = 1            # configs/groups.py:129 (max_pool1d over the SnapKV middle scores)
     sparse_prefill_score_mode: str = "probability"
     sparse_attn_score_dtype: str = "float32"
     h2o_decode_budget: int = 4096

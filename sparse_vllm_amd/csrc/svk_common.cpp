@@ -19,3 +19,15 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int svk_abi_version(void) { return SVK_ABI_VERSION; }
 extern "C" const char* svk_last_error(void) { return svk::g_err; }
+// Developer-build switches compiled into this library (bit 0: -DSVK_PA_TIMING, bit 1: -DSVK_QV_TIMING); the timing tools
+// under tools/ refuse to run against a product build (0).
+extern "C" int svk_build_flags(void) {
+  int f = 0;
+#ifdef SVK_PA_TIMING
+  f |= 1;
+#endif
+#ifdef SVK_QV_TIMING
+  f |= 2;
+#endif
+  return f;
+}

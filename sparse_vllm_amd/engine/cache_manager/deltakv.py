@@ -333,8 +333,31 @@ class DeltaKVCacheManager(CacheManager):
                 and int(k.shape[0]) == int(mapping.numel()))
 
     def on_forward_end(self, seqs, is_prefill: bool):
+        self._join_recon_stream()
         self._flush_pending_raw_stores()
         return super().on_forward_end(seqs, is_prefill)
+
+    def check_prefill_attention_view(self, layer_idx: int):
+        """The prompt-side attention of DeltaKV runs over a reconstructed, RoPE-rotated staging view
+        (deltakv_base.py:936-972 `build_prefill_compute_view` -> `deltakv_reconstruct(chunk_lens=...)` and the prefill
+        staging caches), which is outside this build ("prefill staging ... OOS").  The plain slot
+        table is NOT that view: sparse layers hold pre-RoPE keys, evicted positions map to slot -1 and the KIVI prefix
+        of the full layers is int4 - so refuse instead of computing attention over the wrong bytes."""
+        raise NotImplementedError(
+            "DeltaKV prefill attention needs the reconstructed prefill compute view, which this build does not have; "
+            "prefill_chunk(..., outputs=None) runs the store / compression side of the prompt only "
+            f"(layer={int(layer_idx)}).")
+
+    def _join_recon_stream(self):
+        """Look-ahead reconstructions that no layer waited for (a layer of the group left early, an empty view, an
+        exception between layers) are still in flight on the side stream: join it before anything mutates the caches
+        it reads (`deltakv_evict`, the next step) - also what lets a hipGraph capture end with no unjoined branch."""
+        ahead = self.__dict__.get("_recon_ahead")
+        side = self.__dict__.get("_recon_stream")
+        if ahead and side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        if ahead:
+            self._recon_ahead = {}
 
     def _flush_pending_raw_stores(self):
         """Rows whose layer never reached get_layer_compute_view in this step (none in the decode driver's flow)."""
@@ -790,16 +813,18 @@ class DeltaKVCacheManager(CacheManager):
     def _stacked_up_weights(self):
         """(W1 [Ls, hid, K], b1 [Ls, hid], W2 [Ls, out, hid], b2 [Ls, out]) of the sparse layers' compress_up modules as
         stacked copies (rebuilt after `load_compressor_state`), or None when a layer is not the fused two-Linear form."""
+        parts = [self._fused_up_parts(self.compress_up[i], self.deltakv_latent_cache[i]) for i in range(len(self.compress_up))]
+        if any(p is None or p[0].bias is None or p[1].bias is None for p in parts) or int(self.config.kv_quant_bits or 0) != 4:
+            return None
+        # keyed on the parameters' storage and version counters: load_state_dict / .to() / in-place checkpoint loads
+        # rebuild the stacked copies, so this path can never run on weights the per-layer path no longer has
+        key = tuple((t.data_ptr(), t._version) for p in parts for t in (p[0].weight, p[0].bias, p[1].weight, p[1].bias))
         st = self.__dict__.get("_up_stack")
-        if st is None:
-            parts = [self._fused_up_parts(self.compress_up[i], self.deltakv_latent_cache[i]) for i in range(len(self.compress_up))]
-            if any(p is None or p[0].bias is None or p[1].bias is None for p in parts) or int(self.config.kv_quant_bits or 0) != 4:
-                st = False
-            else:
-                st = (torch.stack([p[0].weight.detach() for p in parts]).contiguous(), torch.stack([p[0].bias.detach() for p in parts]).contiguous(),
-                      torch.stack([p[1].weight.detach() for p in parts]).contiguous(), torch.stack([p[1].bias.detach() for p in parts]).contiguous())
+        if st is None or st[0] != key:
+            st = (key, (torch.stack([p[0].weight.detach() for p in parts]).contiguous(), torch.stack([p[0].bias.detach() for p in parts]).contiguous(),
+                        torch.stack([p[1].weight.detach() for p in parts]).contiguous(), torch.stack([p[1].bias.detach() for p in parts]).contiguous()))
             self._up_stack = st
-        return st or None
+        return st[1]
 
     def _reconstruct_layers_batched(self, l_idxs, stack, recon_pos, recon_latent, recon_out_slot):
         """Residual load + reconstruction of consecutive sparse layers `l_idxs` (same plan) in three launches."""
@@ -1048,6 +1073,7 @@ class DeltaKVCacheManager(CacheManager):
         with profiler.record("deltakv_less_memory_evict_total"):
             if not self.deltakv_layer_ids:
                 return
+            self._join_recon_stream()
             self._flush_pending_raw_stores()
             d = self.device
             sink, recent = int(self.config.num_sink_tokens), int(self.config.num_recent_tokens)

@@ -35,6 +35,19 @@ class LayerBatchSparseState:
     deltakv_free_temp_slots: bool = False
 
 
+def _env_bool(name: str, default: bool) -> bool:
+    """sparse_controller.py:18-33."""
+    value = os.environ.get(name)
+    if value is None:
+        return bool(default)
+    value = value.strip().lower()
+    if value in ("1", "true", "yes", "on"):
+        return True
+    if value in ("0", "false", "no", "off"):
+        return False
+    raise ValueError(f"{name} must be one of 1/0, true/false, yes/no, or on/off; got {value!r}.")
+
+
 class SparseController:
     def __init__(self, config, cache_manager):
         self.config = config
@@ -75,6 +88,8 @@ class SparseController:
         self._pending_scores: list = []      # (SvkH2oDecodeScoreArgs, keep-alive tensors) of this step's layers ("end")
         self._deferred_score = None          # (SvkH2oDecodeScoreArgs, keep-alive tensors)
         self.is_deltakv_family = self.sparse_method == "deltakv"
+        # sparse_controller.py:70-73
+        self.dynamic_deltakv_topk_tiebreak = _env_bool("SPARSEVLLM_DELTAKV_DETERMINISTIC_TOPK_TIEBREAK", False)
         self.obs_layer_ids = list(getattr(config, "obs_layer_ids", None) or [])
         self.full_attn_layers = list(getattr(config, "full_attn_layers", None) or [])
         self._decode_attn_score_buffers: dict[int, torch.Tensor] = {}
@@ -412,13 +427,22 @@ class SparseController:
 
     def _update_dynamic_omnikv_indices(self, obs_layer_idx: int, target_layers):
         """sparse_controller.py:1755-1822, :1951-1959 (DeltaKV decode): mask beyond the compressed length with -1e10,
-        `topk(k_max, sorted=True)`; ties resolve to the lower position (the reference's optional deterministic
-        tie-break :1797-1811 has the same order)."""
+        `topk(k_max, sorted=True)`.  torch leaves the order among equal scores unspecified (the reference notes that
+        graph replay and eager disagree, :1803-1806); here equal scores rank by ascending position.  With
+        SPARSEVLLM_DELTAKV_DETERMINISTIC_TOPK_TIEBREAK=1 the reference's position key is added first, op by op in fp32
+        (:1797-1811: `s + max(|s|, 1) * (pos / n * 1e-6)` — later positions win, and scores below ~1e-4 are
+        re-ranked by it), so that mode is bit-identical up to keys that still tie after the fp32 add."""
         obs = self.layer_batch_sparse_states[obs_layer_idx]
         token_scores = obs.attn_score
         search_scores = token_scores[:, self.num_sink:]
         rel_hist_lens = self.cache_manager.get_compressed_lens(obs.req_indices)
         k_max = min(int(self.decode_keep_tokens), int(search_scores.size(1)))
+        if self.dynamic_deltakv_topk_tiebreak and search_scores.numel() > 0:
+            n = int(search_scores.size(1))
+            pos_key = torch.arange(n, device=search_scores.device, dtype=torch.float32) / max(1, n)
+            masked = torch.arange(n, device=search_scores.device) >= rel_hist_lens.to(search_scores.device).unsqueeze(1)
+            base = search_scores.float().masked_fill(masked, -1e10)
+            search_scores = base + base.abs().clamp_min(1.0) * (pos_key.unsqueeze(0) * 1.0e-6)
         if k_max > 0:
             topk_indices = deltakv_kernels.topk_sorted_desc(search_scores, k_max, valid_len=rel_hist_lens,
                                                             masked_value=-1e10)
@@ -482,7 +506,7 @@ class SparseController:
                     raise RuntimeError("SnapKV/PyramidKV prefill eviction requires prefill attention scores. "
                                        f"method={self.sparse_method} layer={layer_idx} seq_id={seq.seq_id}")
                 keep = self._snapkv_select_indices(seq_scores[:kv_len], kv_len, budget,
-                                                   pool_kernel_size=int(getattr(self.config, "snapkv_pooling_kernel_size", 1) or 1))
+                                                   pool_kernel_size=int(getattr(self.config, "pool_kernel_size", 1) or 1))
                 cm.free_part_slots(layer_idx, seq, keep, keep_indices_sorted=True)
 
     @torch.no_grad()
@@ -516,8 +540,15 @@ class SparseController:
                     with profiler.record("snapkv_decode_select"):
                         keep = self._snapkv_select_indices_batch(scores.index_select(0, idx)[:, :kv_len].contiguous(),
                                                                  kv_len, budget)
-                    key = (tuple(int(s.seq_id) for _, s in group), tuple(keep.shape))
-                    pending.setdefault(key, []).append((layer_idx, [s for _, s in group], keep))
+                    group_seqs = [s for _, s in group]
+                    if len(group) == 1:
+                        # a lone row is compacted at once, batched groups after the layer loop (:1173-1182 vs
+                        # :1209-1223): that order fixes the layer's free-stack contents
+                        with profiler.record("snapkv_decode_compact"):
+                            cm.free_part_slots_batch_layers([layer_idx], group_seqs, keep[None], keep_indices_sorted=True)
+                        continue
+                    key = (tuple(int(s.seq_id) for s in group_seqs), tuple(keep.shape))
+                    pending.setdefault(key, []).append((layer_idx, group_seqs, keep))
             for entries in pending.values():
                 layers = [e[0] for e in entries]
                 with profiler.record("snapkv_decode_compact_layers"):

@@ -118,6 +118,9 @@ class Attention(torch.nn.Module):
             # queries over the sequence's physical row (cached prefix + the chunk just stored)
             if context.cu_seqlens_q is None or context.cu_seqlens_q.numel() <= 1:
                 return torch.empty_like(q)
+            guard = getattr(cache_manager, "check_prefill_attention_view", None)
+            if guard is not None:
+                guard(layer_idx)          # managers whose prompt view is not the plain slot table refuse here
             st = cache_manager.get_layer_batch_states(layer_idx)
             k_cache, v_cache = cache_manager.get_layer_kv_cache(layer_idx)
             b_start_loc = context.cu_seqlens_q[:-1].to(torch.int32)

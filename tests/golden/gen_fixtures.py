@@ -913,6 +913,380 @@ def gen_decode_alloc():
     save("decode_alloc", **out)
 
 
+# ----------------------------------------------------------------------------------
+# SnapKV / StreamingLLM selection (torch on CPU) - SparseController functions
+# ----------------------------------------------------------------------------------
+
+def _make_controller(*, sink, recent, keep, method="snapkv", cache_manager=None, num_layers=1,
+                     model_dtype=torch.bfloat16, head_dim=128):
+    """Hand-built SparseController (no engine): the attribute set the selection functions read
+    (engine/sparse_controller.py:59-152)."""
+    from sparsevllm.engine.sparse_controller import LayerBatchSparseState, SparseController
+    c = object.__new__(SparseController)
+    c.sparse_method = method
+    c.is_deltakv_family = method.startswith("deltakv")
+    c.device = torch.device("cpu")
+    c.num_sink, c.num_recent, c.decode_keep_tokens = int(sink), int(recent), int(keep)
+    c.num_layers = num_layers
+    c.config = SimpleNamespace(hf_config=SimpleNamespace(torch_dtype=model_dtype, num_hidden_layers=num_layers),
+                               pyramid_layer_ratios=None, snapkv_num_full_layers=0, pool_kernel_size=1,
+                               runtime_layout=None, decode_cuda_graph=False)
+    c.cache_manager = cache_manager
+    c.attn_softmax_scale = float(head_dim) ** -0.5
+    c.snapkv_decode_score_dtype = torch.float32
+    c.layer_batch_sparse_states = {i: LayerBatchSparseState() for i in range(num_layers)}
+    c.dynamic_deltakv_topk_tiebreak = False
+    c.debug_dynamic_selection = {}
+    c.debug_dynamic_selection_detail = False
+    c.validate_runtime_invariants = False
+    return c
+
+
+def _pooled(scores, sink, recent_start, pool):
+    import torch.nn.functional as F
+    mid = scores[sink:recent_start]
+    if pool > 1:
+        mid = F.max_pool1d(mid[None, None, :], kernel_size=pool, padding=pool // 2, stride=1)[0, 0]
+    return mid
+
+
+def gen_snapkv_select():
+    """SparseController._snapkv_select_indices{,_batch} (sparse_controller.py:1670-1747) with pool_kernel_size 1 and
+    > 1, _streamingllm_select_indices (:1661-1668), _snapkv_decode_trigger_len (:2050-2054), _get_layer_budget."""
+    out = {}
+    cases = [
+        # name, kv_len, sink, recent, keep(top), pool, batch, want a tie-free threshold?
+        ("a", 90, 4, 8, 20, 1, 3, True),
+        ("b", 300, 64, 32, 100, 1, 2, True),
+        ("c", 200, 4, 16, 40, 5, 3, True),       # pooled, seed searched so the k-th / (k+1)-th pooled values differ
+        ("d", 200, 4, 16, 40, 7, 2, False),      # pooled, ties at the threshold (the reference's pick is recorded)
+        ("e", 64, 8, 8, 60, 1, 2, True),         # num_topk > middle length -> clamp
+        ("f", 40, 30, 12, 0, 1, 2, True),        # recent_start <= sink -> sink ++ recent only (budget 42 > kv_len is
+                                                  # not allowed; use keep=0 with kv_len>budget handled below)
+        ("g", 5000, 64, 512, 1024, 1, 2, True),
+        ("h", 4300, 64, 512, 1024, 5, 1, True),
+    ]
+    names = []
+    for name, kv_len, sink, recent, keep, pool, batch, tie_free in cases:
+        budget = sink + keep + recent
+        if kv_len <= budget:
+            continue
+        c = _make_controller(sink=sink, recent=recent, keep=keep)
+        recent_start = kv_len - recent
+        num_topk = min(keep, max(0, recent_start - sink))
+        seed = 100
+        while True:
+            g = torch.Generator().manual_seed(seed)
+            scores = torch.rand(batch, kv_len + 3, generator=g)           # wider than kv_len like the decode buffer
+            ok = True
+            if num_topk > 0 and recent_start > sink:
+                for b in range(batch):
+                    mid = _pooled(scores[b, :kv_len], sink, recent_start, pool)
+                    srt = torch.sort(mid, descending=True).values
+                    tied = num_topk < mid.numel() and bool(srt[num_topk - 1] == srt[num_topk])
+                    ok &= (not tied) if tie_free else True
+                if not tie_free:
+                    mid = _pooled(scores[0, :kv_len], sink, recent_start, pool)
+                    srt = torch.sort(mid, descending=True).values
+                    ok = num_topk < mid.numel() and bool(srt[num_topk - 1] == srt[num_topk])
+            if ok:
+                break
+            seed += 1
+        keep_b = c._snapkv_select_indices_batch(scores[:, :kv_len], kv_len, budget, pool_kernel_size=pool)
+        keep_s = torch.stack([c._snapkv_select_indices(scores[b, :kv_len], kv_len, budget, pool_kernel_size=pool)
+                              for b in range(batch)])
+        out[f"{name}_scores"] = scores.numpy()
+        out[f"{name}_cfg"] = np.array([kv_len, sink, recent, keep, pool, budget, int(tie_free)], dtype=np.int64)
+        out[f"{name}_keep_batch"] = keep_b.numpy().astype(np.int64)
+        out[f"{name}_keep_scalar"] = keep_s.numpy().astype(np.int64)
+        names.append(name)
+    out["names"] = np.array(names)
+    # trigger lengths / budgets / StreamingLLM keep sets
+    trig = []
+    for sink, recent, keep in [(4, 8, 20), (64, 512, 4096), (0, 0, 7), (64, 32, 100)]:
+        c = _make_controller(sink=sink, recent=recent, keep=keep)
+        budget = c._get_layer_budget(0, is_prefill=False)
+        trig.append([sink, recent, keep, budget, c._snapkv_decode_trigger_len(budget)])
+    out["trigger"] = np.array(trig, dtype=np.int64)
+    sl = []
+    for sink, recent, kv_len in [(4, 16, 50), (64, 512, 1152), (4, 16, 10), (4, 16, 3), (0, 8, 20), (8, 0, 20)]:
+        c = _make_controller(sink=sink, recent=recent, keep=0, method="streamingllm")
+        idx = c._streamingllm_select_indices(kv_len).numpy().astype(np.int64)
+        out[f"sl_{sink}_{recent}_{kv_len}"] = idx
+        sl.append([sink, recent, kv_len, c._get_streamingllm_budget() or -1])
+    out["sl_cases"] = np.array(sl, dtype=np.int64)
+    save("snapkv_select", **out)
+
+
+def _make_snapkv_manager(lengths_by_layer, *, cap, nslots, sink, recent, keep, window, heads, dim, slot_seed=11,
+                         mode="probability"):
+    m = _make_manager(lengths_by_layer, cap=cap, nslots=nslots, heads=heads, dim=dim, slot_seed=slot_seed,
+                      cls_name="SnapKVCacheManager")
+    m.config.vllm_sparse_method = "snapkv"
+    m.config.num_sink_tokens, m.config.num_recent_tokens, m.config.decode_keep_tokens = sink, recent, keep
+    m.config.snapkv_window_size = window
+    m.config.sparse_prefill_score_mode = mode
+    m.config.sparse_attn_score_dtype = "float32"
+    m.config.pool_kernel_size = 1
+    m._prefill_attn_score_accumulators = {}
+    m.kv_layer_index = lambda layer: int(layer)
+    return m
+
+
+def gen_snapkv_e2e():
+    """The SnapKV prompt path of the reference end to end on CPU: collect_prefill_attention_score
+    (snapkv.py:1216-1304; the real prefill_score_fwd under the Triton interpreter, candidate_start = sink,
+    num_recent = recent, elementwise-max accumulator :1017-1044,:1299-1303) -> _snapkv_prefill_eviction
+    (sparse_controller.py:1059-1102) -> free_part_slots; then _snapkv_decode_eviction (:1104-1223) on a
+    decode-time score buffer (single-row and batched groups, fused batch-layers compaction)."""
+    from sparsevllm.engine.cache_manager.base import AttentionViewMeta, ExplicitKVPayload, PrefillComputeView
+    from sparsevllm.engine.cache_manager.snapkv import SnapKVCacheManager
+    from sparsevllm.utils.context import set_context
+
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    # ---------------- prefill: two prompts in one final chunk, one of them under budget (not scored, not evicted)
+    L, Hq, Hkv, D = 2, 4, 2, 64
+    prompts = (90, 30, 77)
+    tot = sum(prompts)
+    q = bf16f(torch.randn(L, tot, Hq, D, generator=g) * 0.5)
+    kc = bf16f(torch.randn(L, 256, Hkv, D, generator=g) * 0.5)
+    out["p_q"] = bits(q)
+    out["p_k"] = bits(kc)
+    for tag, mode, pool in (("pf", "probability", 1), ("pl", "logits", 1), ("pp", "probability", 5)):
+        sink, recent, keep, window = 4, 8, 20, 8
+        budget = sink + keep + recent
+        m = _make_snapkv_manager([[n for n in prompts]] * L, cap=128, nslots=256, sink=sink, recent=recent, keep=keep,
+                                 window=window, heads=Hkv, dim=D, mode=mode)
+        m.config.pool_kernel_size = pool
+        c = _make_controller(sink=sink, recent=recent, keep=keep, cache_manager=m, num_layers=L)
+        c.config.pool_kernel_size = pool
+        seqs = [SimpleNamespace(seq_id=i, num_prompt_tokens=n, num_prefilled_tokens=0, current_chunk_size=n,
+                                is_last_chunk_prefill=True, chain_status="", is_recompute_replay=False,
+                                chain_reused_tokens=0) for i, n in enumerate(prompts)]
+        set_context(True, seqs=seqs)
+        starts = torch.tensor(np.concatenate(([0], np.cumsum(prompts)[:-1])), dtype=torch.int32)
+        chunk_lens = torch.tensor(prompts, dtype=torch.int32)
+        m._prefill_context_lens_cpu_by_layer = {l: tuple(prompts) for l in range(L)}
+        _put(out, f"{tag}_before", _state(m))
+        out[f"{tag}_cfg"] = np.array([sink, recent, keep, window, budget, 1 if mode == "logits" else 0, pool], dtype=np.int64)
+        out[f"{tag}_prompts"] = np.array(prompts, dtype=np.int64)
+        for l in range(L):
+            meta = AttentionViewMeta(active_slots=m.buffer_req_to_token_slots[l],
+                                     req_indices=torch.arange(len(prompts), dtype=torch.int32),
+                                     context_lens=torch.tensor(prompts, dtype=torch.int32), max_context_len=max(prompts))
+            view = PrefillComputeView(meta=meta, payload=ExplicitKVPayload(k_cache=kc[l], v_cache=kc[l]))
+            SnapKVCacheManager.collect_prefill_attention_score(m, l, q[l], view, b_start_loc=starts, chunk_lens=chunk_lens)
+            for i in range(len(prompts)):
+                acc = m._prefill_attn_score_accumulators.get((l, i))
+                if acc is not None:
+                    out[f"{tag}_acc_{l}_{i}"] = acc.numpy().copy()
+        out[f"{tag}_scored"] = np.array(sorted(k_[1] for k_ in m._prefill_attn_score_accumulators if k_[0] == 0), dtype=np.int64)
+        c._snapkv_prefill_eviction(seqs)
+        _put(out, f"{tag}_after", _state(m))
+    # ---------------- accumulator across a recompute replay: a second collect on the same prompt keeps the max
+    # (num_prefilled_tokens != 0 keeps the accumulator; == 0 resets it)
+    # pinned through _get_prefill_attention_score_accumulator directly
+    m = _make_snapkv_manager([[10]], cap=16, nslots=32, sink=1, recent=1, keep=2, window=2, heads=1, dim=4)
+    for mode in ("probability", "logits"):
+        m.config.sparse_prefill_score_mode = mode
+        m._prefill_attn_score_accumulators = {}
+        seq = SimpleNamespace(seq_id=0, num_prefilled_tokens=0)
+        a0 = m._get_prefill_attention_score_accumulator(0, seq, prompt_len=10, device=torch.device("cpu"))
+        out[f"acc_init_{mode}"] = a0.numpy().copy()
+        s1 = torch.rand(10, generator=g) - 0.5
+        torch.maximum(a0, s1, out=a0)
+        seq.num_prefilled_tokens = 4
+        a1 = m._get_prefill_attention_score_accumulator(0, seq, prompt_len=10, device=torch.device("cpu"))
+        s2 = torch.rand(10, generator=g) - 0.5
+        torch.maximum(a1, s2, out=a1)
+        out[f"acc_steps_{mode}"] = np.stack([s1.numpy(), s2.numpy()])
+        out[f"acc_final_{mode}"] = a1.numpy().copy()
+        seq.num_prefilled_tokens = 0
+        a2 = m._get_prefill_attention_score_accumulator(0, seq, prompt_len=10, device=torch.device("cpu"))
+        out[f"acc_reset_{mode}"] = a2.numpy().copy()
+
+    # ---------------- decode re-eviction
+    sink, recent, keep = 4, 8, 20
+    budget = sink + keep + recent                 # 32, trigger 40
+    for tag, lens in (("dg", (40, 40, 33, 40)), ("ds", (41, 35, 40, 12)), ("dn", (39, 38, 33, 12)),
+                      ("dm", (40, 41, 40, 12)), ("dq", (41, 40, 40, 41))):
+        L = 3
+        m = _make_snapkv_manager([list(lens)] * L, cap=64, nslots=300, sink=sink, recent=recent, keep=keep, window=8,
+                                 heads=2, dim=4)
+        m.decode_kv_lens_for_layer = lambda layer_idx, seqs_, _m=m: [int(_m.row_seq_lens[layer_idx][s.seq_id]) for s in seqs_]
+        c = _make_controller(sink=sink, recent=recent, keep=keep, cache_manager=m, num_layers=L)
+        seqs = [SimpleNamespace(seq_id=i) for i in range(len(lens))]
+        set_context(False, seqs=seqs)
+        _put(out, f"{tag}_before", _state(m))
+        for l in range(L):
+            st = c.layer_batch_sparse_states[l]
+            st.attn_score = torch.rand(len(lens), max(lens), generator=g)
+            st.max_context_len = max(lens)
+            st.context_lens = torch.tensor(lens, dtype=torch.int32)
+            out[f"{tag}_score_{l}"] = st.attn_score.numpy().copy()
+        c._snapkv_decode_eviction(seqs)
+        _put(out, f"{tag}_after", _state(m))
+        out[f"{tag}_cfg"] = np.array([sink, recent, keep, budget, c._snapkv_decode_trigger_len(budget)], dtype=np.int64)
+    save("snapkv_e2e", **out)
+
+
+# ----------------------------------------------------------------------------------
+# DeltaKV observation-layer token scores + sorted top-k (torch on CPU)
+# ----------------------------------------------------------------------------------
+
+def gen_deltakv_topk():
+    """SparseController._decode_softmax_token_scores (sparse_controller.py:255-299) and the decode branch of
+    _update_dynamic_omnikv_indices (:1755-1822, :1951-1959): masked topk(sorted=True) with and without the
+    deterministic tie-break key (:1797-1811)."""
+    from sparsevllm.utils.context import set_context
+    out = {}
+    g = torch.Generator().manual_seed(4242)
+    cases = [
+        # name, B, H, L, sink, recent, keep, compressed lens, model dtype
+        ("a", 3, 28, 700, 8, 16, 128, (600, 130, 40), torch.bfloat16),
+        ("b", 2, 8, 300, 4, 8, 64, (280, 0), torch.float32),
+        ("c", 2, 28, 5000, 8, 128, 2048, (4800, 2050), torch.bfloat16),
+        ("d", 2, 4, 200, 8, 16, 512, (150, 100), torch.bfloat16),         # keep > candidates
+        # (a float16 model dtype cannot run this path in the reference: masked_fill_(-1e10) overflows c10::Half)
+    ]
+    names = []
+    for name, B, H, L, sink, recent, keep, clens, mdt in cases:
+        raw = bf16f(torch.randn(B, H, L, generator=g) * 6.0)
+        clen_t = torch.tensor(clens, dtype=torch.int32)
+        cm = SimpleNamespace(get_compressed_lens=lambda req, _c=clen_t: _c.clone())
+        res = {}
+        for tb in (False, True):
+            c = _make_controller(sink=sink, recent=recent, keep=keep, method="deltakv-triton-v4", cache_manager=cm,
+                                 num_layers=3, model_dtype=mdt)
+            c.dynamic_deltakv_topk_tiebreak = tb
+            set_context(False, is_long_text=True)
+            ts = c._decode_softmax_token_scores(raw.clone(), candidate_start=sink, candidate_lens=clen_t)
+            st = c.layer_batch_sparse_states[0]
+            st.attn_score = ts.clone()
+            st.context_lens = torch.tensor([sink + cl + recent for cl in clens], dtype=torch.int32)
+            st.req_indices = torch.arange(B, dtype=torch.int32)
+            c._update_dynamic_omnikv_indices(0, [1, 2])
+            res[tb] = (ts, c.layer_batch_sparse_states[1].active_compressed_indices,
+                       st.attn_score.clone())
+            assert c.layer_batch_sparse_states[2].active_compressed_indices is res[tb][1]
+            assert c.layer_batch_sparse_states[2].deltakv_free_temp_slots and not c.layer_batch_sparse_states[1].deltakv_free_temp_slots
+        ts = res[False][0]
+        out[f"{name}_raw"] = bits(raw)
+        out[f"{name}_cfg"] = np.array([sink, recent, keep, {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[mdt]], dtype=np.int64)
+        out[f"{name}_clens"] = np.array(clens, dtype=np.int64)
+        out[f"{name}_token_scores"] = ts.float().numpy()
+        out[f"{name}_topk"] = res[False][1].numpy()
+        out[f"{name}_topk_tiebreak"] = res[True][1].numpy()
+        # the masked search scores the reference's topk saw (the obs state's buffer is masked in place)
+        out[f"{name}_search_masked"] = res[False][2][:, sink:].float().numpy()
+        names.append(name)
+    out["names"] = np.array(names)
+    save("deltakv_topk", **out)
+
+
+# ----------------------------------------------------------------------------------
+# method surface (pure Python tables)
+# ----------------------------------------------------------------------------------
+
+def _call(fn, *a, **k):
+    try:
+        return {"ok": fn(*a, **k)}
+    except Exception as e:          # the exception class and text are part of the surface
+        return {"err": type(e).__name__, "msg": str(e)}
+
+
+def gen_method_surface():
+    """method_registry.py (aliases, policies, contracts, compatibility) and configs/runtime_params.py
+    (public aliases, legacy-name rejection) as a JSON table of inputs -> outputs / error texts."""
+    import json
+    from sparsevllm import method_registry as mr
+    from sparsevllm.configs.runtime_params import normalize_runtime_params
+    from sparsevllm.distributed.topology import ParallelTopology
+
+    names = [None, "", " H2O ", "vanilla", "Vanilla", "attention-sink", "attention_sink", "r-kv", "r_kv", "skip-kv", "skip_kv",
+             "deltakv", "deltakv-less-memory", "deltakv_less_memory", "deltakv-less-memory-cudagraph",
+             "deltakv_less_memory_cudagraph", "streamingllm", "snapkv", "h2o", "pyramidkv", "omnikv", "quest", "rkv",
+             "skipkv", "nope", "deltakv-triton-v4", 7]
+    policies = [None, "", "auto", "AUTO", "all_chunked", " long_bs1full_short_batch ", "bogus"]
+    out = {"names": [n if n is None or isinstance(n, str) else {"int": n} for n in names], "policies": policies}
+    rows = []
+    compat_tables = {}
+    for n in names:
+        row = {
+            "normalize": _call(mr.normalize_sparse_method, n),
+            "default_policy": _call(mr.get_default_prefill_schedule_policy, n),
+            "resolve": [_call(mr.resolve_prefill_schedule_policy, n, p) for p in policies],
+            "is_deltakv": _call(mr.is_deltakv_method, n),
+            "graph": _call(mr.is_decode_cuda_graph_supported, n),
+            "tp_graph": _call(mr.is_tp_decode_cuda_graph_supported, n),
+        }
+        c = _call(mr.sparse_prefill_attention_contract, n)
+        if "ok" in c:
+            c = {"ok": [c["ok"].main_score_kind.name, c["ok"].score_collection.name]}
+        row["contract"] = c
+        compat = []
+        for model_type in ("qwen2", "Llama", "qwen3_moe", "mystery"):
+            for graph in (False, True):
+                for prefix in (False, True):
+                    r = _call(mr.validate_model_runtime_compatibility, model_type=model_type, sparse_method=n,
+                              topology=ParallelTopology(1, 1, 1), decode_cuda_graph=graph, enable_prefix_caching=prefix)
+                    if "ok" in r:
+                        lists = [sorted(r["ok"].sparse_methods), sorted(r["ok"].prefix_cache_methods),
+                                 sorted(r["ok"].decode_cuda_graph_methods)]
+                        key = json.dumps(lists)
+                        if key not in compat_tables:
+                            compat_tables[key] = f"T{len(compat_tables)}"
+                        r = {"ok": compat_tables[key]}
+                    compat.append([model_type, graph, prefix, r])
+        row["compat"] = compat
+        rows.append(row)
+    out["rows"] = rows
+    out["compat_tables"] = {v: json.loads(k) for k, v in compat_tables.items()}
+    out["tables"] = {
+        "METHOD_ALIASES": {("<None>" if k is None else k): v for k, v in mr.METHOD_ALIASES.items()},
+        "CANONICAL_SPARSE_METHODS": sorted(mr.CANONICAL_SPARSE_METHODS),
+        "SUPPORTED_SPARSE_METHODS": sorted(mr.SUPPORTED_SPARSE_METHODS),
+        "SUPPORTED_SPARSE_METHOD_ALIASES": sorted(mr.SUPPORTED_SPARSE_METHOD_ALIASES),
+        "PREFIX_CACHE_SUPPORTED_METHODS": sorted(mr.PREFIX_CACHE_SUPPORTED_METHODS),
+        "DECODE_CUDA_GRAPH_SUPPORTED_METHODS": sorted(mr.DECODE_CUDA_GRAPH_SUPPORTED_METHODS),
+        "TP_DECODE_CUDA_GRAPH_SUPPORTED_METHODS": sorted(mr.TP_DECODE_CUDA_GRAPH_SUPPORTED_METHODS),
+        "PREFILL_POLICY_BY_METHOD": dict(mr.PREFILL_POLICY_BY_METHOD),
+        "SUPPORTED_PREFILL_POLICIES": sorted(mr.SUPPORTED_PREFILL_POLICIES),
+    }
+    kw_cases = [
+        {},
+        {"sparse_method": "h2o", "h2o_decode_budget": 4096},
+        {"sparse_method": "vanilla"},
+        {"sparse_method": "attention-sink", "sink_keep_tokens": 4, "recent_keep_tokens": 16},
+        {"sparse_method": "deltakv", "deltakv_checkpoint_path": "/x", "deltakv_center_ratio": 0.03, "deltakv_latent_dim": 256,
+         "deltakv_latent_quant_bits": 4, "deltakv_latent_quant_group_size": 32, "deltakv_neighbor_count": 4,
+         "full_attention_layers": "0,1,2", "engine_prefill_chunk_size": 8192},
+        {"sparse_method": "quest", "decode_keep_tokens": 0.5},
+        {"sparse_method": "quest", "decode_keep_tokens": 4096, "quest_chunk_size": 16},
+        {"sink_keep_tokens": 4, "num_sink_tokens": 4},
+        {"vllm_sparse_method": "h2o"},
+        {"num_top_tokens": 3, "chunk_prefill_size": 5},
+        {"seq_chunk_size": 1},
+        {"deltakv_visual_keep_ratio": 0.5, "ref_mode": "x"},
+        {"quest_token_budget": 100},
+        {"k_neighbors": 4, "cluster_ratio": 0.1, "kv_quant_bits": 4},
+    ]
+    res = []
+    for kw in kw_cases:
+        r = _call(normalize_runtime_params, dict(kw), backend="sparsevllm")
+        if "ok" in r:
+            r = {"ok": r["ok"].infer_config}
+        res.append([kw, r])
+    # (every alias target is itself a legacy key, so the "conflicting alias" branch of _set_alias is unreachable from
+    # the public API: the legacy-name rejection fires first - see the {"sink_keep_tokens", "num_sink_tokens"} case)
+    out["runtime_params"] = res
+    path = os.path.join(HERE, "method_surface.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 GROUPS = {
     "decode_alloc": gen_decode_alloc,
     "decode": gen_decode,
@@ -928,6 +1302,10 @@ GROUPS = {
     "deltakv_view": gen_deltakv_view,
     "deltakv_compress": gen_deltakv_compress,
     "prefill_attention": gen_prefill_attention,
+    "snapkv_select": gen_snapkv_select,
+    "snapkv_e2e": gen_snapkv_e2e,
+    "deltakv_topk": gen_deltakv_topk,
+    "method_surface": gen_method_surface,
 }
 
 

@@ -150,3 +150,18 @@ def test_chunked_prompt_reaches_the_same_compressed_length_and_frees_every_slot(
     for s in seqs:
         cm.free_seq(s.seq_id)
     assert cm.free_slot_stats() == free0
+
+
+def test_prefill_attention_over_the_raw_slot_table_is_refused():
+    """DeltaKV's prompt attention runs over a reconstructed staging view in the reference (deltakv_base.py:936-972),
+    which this build does not have; the plain slot table holds pre-RoPE keys / slot -1 holes, so asking for outputs
+    must fail loudly instead of reading the wrong bytes."""
+    from sparse_vllm_amd.engine.sequence import Sequence
+    drv = _driver(4, True, 256)
+    seq = Sequence(num_prompt_tokens=40)
+    seq.current_chunk_size = 40
+    g = torch.Generator().manual_seed(1)
+    mk = lambda h: (torch.randn(4, 40, h, 64, generator=g) * 0.5).to(torch.bfloat16).to(drv.device)
+    q, k, v = mk(8), mk(2), mk(2)
+    with pytest.raises(NotImplementedError, match="reconstructed prefill compute view"):
+        drv.prefill_chunk([seq], q, k, v, outputs=torch.zeros_like(q))

@@ -145,3 +145,67 @@ def test_decode_split_invariance_and_fused_store_full_size():
     np.testing.assert_array_equal(sa, sb)
     np.testing.assert_array_equal(oa, ob)
     assert torch.equal(ka, kb) and torch.equal(va, vb)
+
+
+def test_h2o_headline_batch_256_single_block_direct_out_matches_split_path():
+    """bench.py's default launch shape: B = 256 sequences, the launch provider gives every sequence ONE 4224-token
+    block, stage 1 writes the bf16 output itself (`direct_o`, no stage-2 launch), the score epilogue of all layers
+    runs once after the layer loop ('end') and the layer loop is a hipGraph.  Against the same step sequence run
+    through the reference-shaped split path (BLOCK_SEQ 256 -> 17 partials per row + flash_decode_stage2, eager):
+    slot tables / free stacks / lengths bit-identical across a burst, cumulative scores equal within the
+    accumulation-order noise of 132 steps, outputs within the attention tolerance; plus slot conservation and the
+    4096 -> 4223 -> 4096 walk at full batch."""
+    import os
+    from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import direct_out_supported
+    B, L, steps = 256, 4, 132
+    assert os.environ.get("SVK_H2O_DEFER_SCORE", "end") == "end" and os.environ.get("SVK_DECODE_DIRECT_OUT", "1") == "1"
+    results = []
+    for headline in (True, False):
+        from sparse_vllm_amd.config import Config
+        from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+        kw = dict(QWEN)
+        kw["num_hidden_layers"] = L
+        conf = Config.from_kwargs(sparse_method="h2o", h2o_decode_budget=4096, h2o_decode_eviction_interval=128,
+                                  h2o_prefill_budget=8192, max_model_len=4224 + 64, max_num_seqs_in_gpu=B,
+                                  num_kvcache_slots=B * 4224 + 4096, **kw)
+        drv = SparseDecodeDriver(conf, use_launch_provider=headline)
+        cm = drv.cache_manager
+        cm.permute_free_slots(1)
+        drv.admit_resident_rows(B, 4096, logical_len=131072, seed=5, device_rng=True)
+        if headline:
+            drv.enable_decode_graph()
+            bs, _, _ = drv.attn.decode_launch_op.launch_config(block_seq=256, max_context_len=4224,
+                                                               requires_attention_scores=True, batch_size=B)
+            assert bs == 4224 and direct_out_supported(4224, bs)
+            assert drv.sparse_controller.decode_direct_out_allowed(0, B)
+        else:
+            assert drv.attn.decode_launch_op is None and not direct_out_supported(4224, 256)
+        q, k, v = drv.random_step_inputs(seed=2)
+        o = torch.zeros((L, B, 28, 128), dtype=torch.bfloat16, device=drv.device)
+        lens_seen, first_o = [], None
+        for i in range(steps):
+            drv.step(q, k, v, outputs=o)
+            lens_seen.append(int(drv.row_len()[0]))
+            if i == 2:
+                torch.cuda.synchronize()
+                first_o = o.float().cpu().numpy().copy()
+            if i in (0, 126, 127):
+                torch.cuda.synchronize()
+                _check_slot_partition(cm, B)
+        torch.cuda.synchronize()
+        assert lens_seen[0] == 4097 and max(lens_seen) == 4223 and lens_seen[127] == 4096 and lens_seen[-1] == 4096 + steps - 128
+        results.append(dict(o=o.float().cpu().numpy().copy(), first_o=first_o, score=cm.h2o_score_tensor.cpu().numpy().copy(),
+                            table=cm.buffer_req_to_token_slots_tensor.cpu().numpy().copy(),
+                            stack=cm.free_slots_stack_tensor.cpu().numpy().copy(), lens=np.stack(cm.row_seq_lens).copy(),
+                            ptr=list(cm._num_free_slots)))
+        del drv, cm, q, k, v, o
+        torch.cuda.empty_cache()
+    a, b = results
+    np.testing.assert_array_equal(a["lens"], b["lens"])
+    assert a["ptr"] == b["ptr"]
+    np.testing.assert_array_equal(a["table"], b["table"])                 # same tokens evicted: selection is stable
+    for l in range(L):
+        np.testing.assert_array_equal(a["stack"][l, : a["ptr"][l]], b["stack"][l, : b["ptr"][l]])
+    np.testing.assert_allclose(a["first_o"], b["first_o"], rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(a["o"], b["o"], rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(a["score"], b["score"], rtol=1e-4, atol=1e-6)

@@ -25,6 +25,9 @@ print("table mode", mode)
 z = torch.zeros(1, dtype=torch.int32, device=d); seq = torch.tensor([L], dtype=torch.int32, device=d); pcl = torch.tensor([pc], dtype=torch.int32, device=d)
 orig = cf._lib.load
 lib = _lib.load()
+if not (lib.svk_build_flags() & 1):
+    raise SystemExit("pa_timing.py needs a developer build: make -C sparse_vllm_amd/csrc EXTRA=-DSVK_PA_TIMING "
+                     "(in a product build bit 30 of max_input_len is part of the length: ~33 M empty workgroups)")
 real = lib.svk_context_attention_fwd
 class Hook:
     def __call__(self, a, s):

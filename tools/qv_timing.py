@@ -13,6 +13,8 @@ import torch
 from sparse_vllm_amd import _lib
 from sparse_vllm_amd.kernels import quest_ops
 
+if not (_lib.load().svk_build_flags() & 2):
+    raise SystemExit("qv_timing.py needs a developer build: make -C sparse_vllm_amd/csrc EXTRA=-DSVK_QV_TIMING")
 ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 budget = int(sys.argv[3]) if len(sys.argv) > 3 else 4672

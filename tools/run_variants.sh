@@ -1,5 +1,5 @@
 set -u
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -2
 run() { echo "== $1"; env $1 python -m pytest tests/ -x -q -m gpu -k "$2" 2>&1 | tail -1; }
 run SVK_STAGE1_VARIANT=4 "h2o or decode or stage1 or large or fuzz"
