@@ -47,23 +47,38 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of hipGraph replay")
     ap.add_argument("--event-steps", type=int, default=8, help="eager steps timed per launch for the roofline leg")
+    ap.add_argument("--max-model-len", type=int, default=131072, help="row stride of the slot table / score tensor")
+    ap.add_argument("--no-paths", action="store_true", help="skip the other configurations' decode-step timings")
+    ap.add_argument("--path-steps", type=int, default=24)
     return ap.parse_args()
 
 
-def cpu_baseline(seed: int = 20260625):
-    """Oracle (numpy restatement of the reference) on a bounded sample: 2 sequences x 28 layers
-    x 16 decode steps at row length 4160 (the mean of the 4096..4224 cycle) + one burst
-    selection over the 56 (layer, sequence) rows amortised over the 128-step interval."""
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def _cpu_worker(job):
+    """One host core: the numpy oracle on ONE sequence x 28 layers x `steps` decode steps at row length 4160 (the mean of
+    the 4096..4224 cycle), then one burst selection over the sequence's 28 rows.  -> (seconds of steps, seconds of burst)"""
+    seed, steps = job
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:      # pragma: no cover
+        pass
     from oracle import bf16_round
     from oracle import decode_attention as oda
     from oracle import h2o as oh
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
-    except Exception:      # pragma: no cover
-        limiter = None
     rng = np.random.default_rng(seed)
-    B, Hq, Hkv, D, Lrow, layers, steps = 2, 28, 4, 128, 4160, 28, 16
+    B, Hq, Hkv, D, Lrow, layers = 1, 28, 4, 128, 4160, 28
     slots = B * 4224 + 64
     k = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.3).astype(np.float32))
     v = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.3).astype(np.float32))
@@ -84,15 +99,54 @@ def cpu_baseline(seed: int = 20260625):
     s = rng.random((layers * B, 4224)).astype(np.float32)
     t0 = time.perf_counter()
     oh.select_h2o_indices_batch(s, budget=4096, recent_ratio=0.5)
-    t_burst = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
-    per_step = t_steps / steps + t_burst / 128.0
+    return t_steps, time.perf_counter() - t0
+
+
+def _usable_cores() -> int:
+    """Cores this process may actually run on: the affinity mask, capped by the cgroup CPU quota (a container can see 256
+    CPUs in os.cpu_count() and own far fewer)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:      # pragma: no cover
+        n = int(os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], parts[1]
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = f.read().split()[0]
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / float(period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def cpu_baseline(seed: int = 20260625, steps: int = 4, workers: int | None = None):
+    """The oracle (numpy restatement of the reference) on ALL host cores: one worker process per core, one sequence per
+    worker (the path shards by sequence on the CPU exactly as on the GPUs), 28 layers x `steps` decode steps each, plus
+    one burst selection per sequence amortised over the 128-step interval.  Must run before this process touches the
+    GPU (the workers are forked)."""
+    import multiprocessing as mp
+    cores = int(workers) if workers else _usable_cores()
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(seed + i, steps) for i in range(cores)], chunksize=1)
+    wall = time.perf_counter() - t0
+    # every worker decodes its sequence concurrently: a step of the whole batch takes as long as the slowest worker's
+    per_step = max(r[0] for r in res) / steps + max(r[1] for r in res) / 128.0
     return {
-        "value": B / per_step, "unit": "tokens/s", "cores": 1, "kind": "port",
-        "sample": f"numpy oracle, {B} seqs x {layers} layers x {steps} decode steps at row length {Lrow} "
-                  f"(+1 burst selection over {layers * B} rows / 128 steps), {t_steps + t_burst:.1f} s of CPU work, "
-                  f"{os.cpu_count()} host cores present, 1 thread used",
+        "value": cores / per_step, "unit": "tokens/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+        "cpus_visible": int(os.cpu_count() or 0),
+        "sample": f"numpy oracle, {cores} worker processes (one per usable host core) x 1 sequence x 28 layers x {steps} decode "
+                  f"steps at row length 4160 (+1 burst selection over each sequence's 28 rows / 128 steps); slowest worker "
+                  f"{max(r[0] for r in res):.1f} s of steps, {wall:.1f} s wall incl. process start; single worker alone: "
+                  f"{steps / min(r[0] for r in res):.2f} tokens/s",
     }
 
 
@@ -121,6 +175,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     n_gpus = world if use_dist else 1
     device = f"cuda:{local_rank}"
+    # the CPU leg forks one worker per host core, so it runs before this process creates a GPU context
+    cpu = cpu_baseline() if (rank == 0 and n_gpus == 1 and not args.no_cpu_baseline) else None
 
     from sparse_vllm_amd.config import Config
     from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
@@ -130,7 +186,7 @@ def main():
     budget, interval = 4096, 128
     conf = Config.from_kwargs(
         sparse_method="h2o", num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4, head_dim=128,
-        max_model_len=131072 if B <= 128 else 8192, max_num_seqs_in_gpu=B, num_kvcache_slots=B * (budget + interval) + 4096,
+        max_model_len=int(args.max_model_len), max_num_seqs_in_gpu=B, num_kvcache_slots=B * (budget + interval) + 4096,
         h2o_decode_budget=budget, h2o_decode_eviction_interval=interval, h2o_prefill_budget=8192,
         engine_prefill_chunk_size=8192, device=device)
     drv = SparseDecodeDriver(conf)
@@ -213,11 +269,30 @@ def main():
     for _ in range(warmup):
         drv.step(q, k, v)
     barrier()
+    bursts0 = int(cm._h2o_counters["decode_eviction_bursts"])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         drv.step(q, k, v)
     barrier()
     elapsed = time.perf_counter() - t0
+    bursts_in_window = (int(cm._h2o_counters["decode_eviction_bursts"]) - bursts0) // B
+    # ---- the burst on its own: run on to the next eviction step, time the plain steps before it and the step that carries
+    # the burst (select + compact over all 28 layers x B rows); every sequence pays it once per `interval` steps
+    burst = None
+    if not args.no_graph:
+        plain = []
+        for _ in range(2 * interval + 2):
+            n0 = int(cm._h2o_counters["decode_eviction_bursts"])
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            drv.step(q, k, v)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - ts) * 1e3
+            if int(cm._h2o_counters["decode_eviction_bursts"]) > n0:
+                base = float(np.median(plain[-16:])) if plain else float("nan")
+                burst = {"ms": dt - base, "step_ms_with_burst": dt, "plain_step_ms": base, "per_steps": interval}
+                break
+            plain.append(dt)
     if not args.no_kernel_events:
         # roofline leg: the same workload continues for a few eagerly launched steps
         drv.config.decode_cuda_graph = False
@@ -242,8 +317,15 @@ def main():
                         "eviction every 128 steps; dense model layers not included",
             "seqs_per_gpu": B, "global_batch": n_gpus * B, "launch": "eager" if args.no_graph else "hipGraph replay", "resident_row_len": "4096..4224", "layers": 28,
             "heads": "28q/4kv x 128", "parallelism": f"replicas x{n_gpus} (sequence-sharded, no collective)",
+            "max_model_len": int(args.max_model_len), "logical_context": 131072,
+            "bursts_in_timed_window": int(bursts_in_window),
         },
     }
+    if burst is not None:
+        # what the timed window would read with exactly one burst per `interval` steps, whatever K the driver chose
+        plain_ms = (elapsed * 1e3 - bursts_in_window * burst["ms"]) / args.steps
+        burst["value_amortised"] = n_gpus * B / ((plain_ms + burst["ms"] / interval) * 1e-3)
+        out["burst"] = burst
     if events:
         ms_total = sum(e[0] for e in events)
         n_launch = sum(e[1] for e in events)
@@ -261,6 +343,8 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "traffic_source": "profiles/stage1_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/kbench.py "
+                              "at this batch (builder-run, not re-measured in this process)",
             "kernel": "decode_stage1_kernel_v3<128,7,HEADMAX,nt,off32> (scored GQA split-KV decode)",
             "launches_timed": n_launch, "avg_launch_us": ms_total * 1e3 / n_launch,
             "timing": (f"{args.event_steps} eagerly launched steps continue the timed region; after each step's layer "
@@ -268,8 +352,24 @@ def main():
                        "data and state between one pair of HIP events on the launch stream"),
             "algorithmic_bytes_per_launch": bytes_total / n_launch,
         }
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    if rank == 0 and n_gpus == 1 and not args.no_paths:
+        # the other configurations of BASELINE.json (and the B=64 H2O point of SURVEY 8(d)) as decode-step timings of the
+        # same build, a few seconds each: hipGraph replay, synthetic resident state (tools/pathbench.py)
+        attn_mod.flash_decode_stage1_with_score = orig
+        del drv, cm, q, k, v
+        scratch.clear()
+        record["calls"].clear()
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pathbench
+        out["paths"] = []
+        for name in ("h2o_b64", "streamingllm", "quest", "deltakv"):
+            try:
+                out["paths"].append(pathbench.measure(name, steps=args.path_steps, warmup=4, graph=True))
+            except Exception as e:      # a failing side leg must not lose the headline line
+                out["paths"].append({"config": name, "error": f"{type(e).__name__}: {e}"})
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -36,6 +36,7 @@ def flash_decode_stage1(
     block_n: int = 16,
     attn_score: np.ndarray | None = None,   # [B, W] (2-D, max-reduced in place) or [B, Hq, W]
     p_dtype_bf16: bool = True,
+    token_valid: np.ndarray | None = None,  # [B, max_len] bool: tokens a caller's view excludes (KIVI maps, see oracle/kivi.py)
 ):
     """Returns (mid_o [B,Hq,nblk,D] f32, mid_lse [B,Hq,nblk] f32).
 
@@ -65,6 +66,9 @@ def flash_decode_stage1(
                  + np.arange(tiles)[None, :, None] * block_n
                  + np.arange(block_n)[None, None, :])
         valid = t_idx < L                                  # masks both seq end and block end
+        if token_valid is not None:
+            tv = np.asarray(token_valid[b], dtype=bool)
+            valid = valid & tv[np.minimum(t_idx, tv.shape[0] - 1)]
         safe_t = np.where(valid, t_idx, 0)
         safe_t = np.minimum(safe_t, row.shape[0] - 1)
         slots = np.where(valid, row[safe_t], 0).astype(np.int64)   # other=0 (:254-255)

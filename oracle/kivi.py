@@ -20,10 +20,13 @@ from .decode_attention import flash_decode_stage1
 def dequant_tokens(row: int, length: int, raw_k, raw_v, raw_slots_map, kivi_block_slots_map, kivi_block_start_pos,
                    key_packed, key_scales, key_mins, value_packed, value_scales, value_mins, group_size: int,
                    round_bf16: bool):
-    """-> K, V [length, Hkv, D] f32 for the tokens of one row."""
+    """-> K, V [length, Hkv, D] f32 for the tokens of one row, valid [length] bool.  A token is valid when it is raw
+    (raw_slots_map >= 0) or maps to a KIVI block that contains its position (deltakv_kernels.py:806-823); every other
+    token is excluded from the softmax and gets no score (`slot_valid`, :823, :853-866)."""
     Hkv, D = raw_k.shape[1], raw_k.shape[2]
     K = np.zeros((length, Hkv, D), np.float32)
     V = np.zeros((length, Hkv, D), np.float32)
+    valid = np.ones((length,), bool)
     kp = key_packed.view(np.uint32).astype(np.int64)
     vp = value_packed.view(np.uint32).astype(np.int64)
     d = np.arange(D)
@@ -33,8 +36,10 @@ def dequant_tokens(row: int, length: int, raw_k, raw_v, raw_slots_map, kivi_bloc
             K[t], V[t] = raw_k[rs], raw_v[rs]
             continue
         b = int(kivi_block_slots_map[row, t])
-        lt = t - int(kivi_block_start_pos[b])
-        assert b >= 0 and 0 <= lt < group_size, "token is neither raw nor inside its KIVI block"
+        lt = t - int(kivi_block_start_pos[max(b, 0)])
+        if b < 0 or not 0 <= lt < group_size:
+            valid[t] = False
+            continue
         kq = ((kp[b, :, :, lt // 8] >> ((lt % 8) * 4)) & 15).astype(np.float32)            # [Hkv, D]
         kk = kq * key_scales[b].astype(np.float32) + key_mins[b].astype(np.float32)
         vq = ((vp[b, :, lt, :][:, d // 8] >> ((d % 8) * 4)[None, :]) & 15).astype(np.float32)
@@ -42,7 +47,7 @@ def dequant_tokens(row: int, length: int, raw_k, raw_v, raw_slots_map, kivi_bloc
             value_mins[b, :, lt, :][:, d // group_size].astype(np.float32)
         K[t] = bf16_round(kk) if round_bf16 else kk
         V[t] = bf16_round(vv) if round_bf16 else vv
-    return K, V
+    return K, V, valid
 
 
 def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_block_slots_map, kivi_block_start_pos,
@@ -57,14 +62,16 @@ def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_
     Kp = np.zeros((max(tot, 1), Hkv, D), np.float32)
     Vp = np.zeros_like(Kp)
     table = np.zeros((B, int(max_len_in_batch)), np.int32)
+    token_valid = np.ones((B, int(max_len_in_batch)), bool)
     off = 0
     for b in range(B):
         n = int(lens[b])
-        K, V = dequant_tokens(int(req_indices[b]), n, raw_k, raw_v, raw_slots_map, kivi_block_slots_map,
+        K, V, token_valid[b, :n] = dequant_tokens(int(req_indices[b]), n, raw_k, raw_v, raw_slots_map, kivi_block_slots_map,
                               kivi_block_start_pos, key_packed, key_scales, key_mins, value_packed, value_scales,
                               value_mins, group_size, round_bf16)
         Kp[off: off + n], Vp[off: off + n] = K, V
         table[b, :n] = np.arange(off, off + n)
         off += n
     return flash_decode_stage1(q, Kp, Vp, table, np.arange(B, dtype=np.int32), lens, int(max_len_in_batch), block_seq,
-                               attn_score=attn_score, p_dtype_bf16=p_dtype_bf16)
+                               attn_score=attn_score, p_dtype_bf16=p_dtype_bf16,
+                               token_valid=None if token_valid.all() else token_valid)

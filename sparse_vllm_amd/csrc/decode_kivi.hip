@@ -296,12 +296,52 @@ __device__ __forceinline__ float nibble_f32(uint32_t lo, uint32_t hi) {
   return (I & 1) ? cvt_ubyte<I / 2>(hi) : cvt_ubyte<I / 2>(lo);
 }
 
-template <int D, int G, bool KF32>
+
+// The 8 int4 codes of a packed word as floats n * 2^-9, two per instruction: an fp8 (e4m3) byte 0x0n IS n * 2^-9 - its
+// denormals and first binade form one linear ramp (tools/probe_fp8cvt.hip) - so v_cvt_pk_f32_fp8 on the nibble-masked
+// word converts two codes at once, exactly.  x[0] = (n0, n2), x[1] = (n4, n6), x[2] = (n1, n3), x[3] = (n5, n7);
+// multiplying by 512 * scale (an exact power-of-two prescale) rounds exactly like code * scale.
+__device__ __forceinline__ void nibbles_fp8(uint32_t w, f32x2_t (&x)[4]) {
+  const uint32_t lo = w & 0x0f0f0f0fu, hi = (w >> 4) & 0x0f0f0f0fu;
+  x[0] = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false);
+  x[1] = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+  x[2] = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false);
+  x[3] = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+}
+// value of nibble I in the layout above
+template <int I>
+__device__ __forceinline__ float nib_of(const f32x2_t (&x)[4]) {
+  return x[(I & 1) * 2 + (I >> 2)][(I >> 1) & 1];
+}
+__device__ __forceinline__ f32x2_t pk_mul_rn(f32x2_t x, f32x2_t y) {
+#pragma clang fp contract(off)
+  return x * y;
+}
+__device__ __forceinline__ f32x2_t pk_add_rn(f32x2_t x, f32x2_t y) {
+#pragma clang fp contract(off)
+  return x + y;
+}
+
+// WIDE (D = 128): tiles made of four whole, consecutive KIVI blocks fetch their codes with 16-byte-per-lane loads (1 KiB
+// per instruction, 8 instructions for the tile's K codes and 8 for its V codes instead of 32 + 32 four-byte ones) into
+// registers one half-tile ahead, lay them down in a per-wave LDS buffer (K and V take turns in the same 9 KiB) and read
+// the operand words back with conflict-free ds_read_b32.  Workgroup ranges are shifted to block boundaries so that the
+// tiles of a regular row ARE whole blocks.  Everything else (raw tokens, ragged ends, irregular maps) takes the
+// narrow paths below unchanged.
+constexpr int kKBlkStride = 2048 + 16;          // K codes of a block-head in LDS: [128 channels][16 B] + 16 B (bank skew)
+constexpr int kVBlkStride = 2048 + 4 * 64;      // V codes: [32 tokens][64 B], 64 B of skew after every 8 tokens
+constexpr int kKParStride = 512 + 16;           // per-channel K scales (or mins) of a block-head: 128 floats + 16 B (bank skew)
+constexpr int kKParOff = 4 * kKBlkStride;       // Q.K^T phase: [K codes of 4 blocks | K scales of 4 blocks | K mins of 4 blocks]
+constexpr int kXBufBytes = kKParOff + 8 * kKParStride;     // 12480 (the P.V phase uses the first 4 * kVBlkStride = 9216)
+
+template <int D, int G, bool KF32, bool WIDE = false>
 __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviDecodeStage1Args a) {
   constexpr int NC = D / 32, JQ = (G + 3) / 4, DW = D / 8, NG = D / 32;
   constexpr int kT = 128, GS = 32;
-  // per-wave LDS: P tile [16][128] bf16 (4 KiB) | V scales [NG][128] bf16 | V mins [NG][128] bf16
-  constexpr int P_BYTES = 16 * kT * 2, VS_BYTES = NG * kT * 2, WAVE_BYTES = P_BYTES + 2 * VS_BYTES;
+  static_assert(!WIDE || D == 128, "the wide path is written for head_dim 128");
+  // per-wave LDS: P tile [16][128] bf16 (4 KiB) | V scales [NG][128] bf16 | V mins [NG][128] bf16 | (WIDE) code buffer
+  constexpr int PST = kT + 8;            // P tile row stride in bf16: 272 B, so the 16 rows of an A-operand read hit 16 bank groups
+  constexpr int P_BYTES = 16 * PST * 2, VS_BYTES = NG * kT * 2, WAVE_BYTES = P_BYTES + 2 * VS_BYTES + (WIDE ? kXBufBytes : 0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -314,9 +354,28 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
   uint16_t* Pl = reinterpret_cast<uint16_t*>(wl);
   uint16_t* Vs = reinterpret_cast<uint16_t*>(wl + P_BYTES);
   uint16_t* Vm = reinterpret_cast<uint16_t*>(wl + P_BYTES + VS_BYTES);
+  unsigned char* xbuf = wl + P_BYTES + 2 * VS_BYTES;          // WIDE only
   const int len = a.context_lens[b];
-  const int start = blk * a.block_seq;
-  const int end = min(len, start + a.block_seq);
+  const int row = a.req_indices[b];
+  const int32_t* raw_map = a.raw_slots_map + (int64_t)row * a.map_stride;
+  const int32_t* blk_map = a.kivi_block_slots_map + (int64_t)row * a.map_stride;
+  int start = blk * a.block_seq;
+  int end_nominal = start + a.block_seq;
+  if constexpr (WIDE) {
+    // range i = [i*BS + f(i*BS), (i+1)*BS + f((i+1)*BS)), f(p) = distance from p to the next block boundary (0 for raw
+    // tokens, boundaries and positions outside the row): still a partition of the row, position-indexed outputs and the
+    // merged result do not depend on where the cuts are
+    // both cuts at once and without branches: two loads deep instead of six
+    const int lm = max(len - 1, 0);
+    const int q0 = min(max(start, 0), lm), q1 = min(max(end_nominal, 0), lm);
+    const int r0 = raw_map[q0], r1 = raw_map[q1], b0 = blk_map[q0], b1 = blk_map[q1];
+    const int lt0 = start - a.kivi_block_start_pos[max(b0, 0)], lt1 = end_nominal - a.kivi_block_start_pos[max(b1, 0)];
+    const bool in0 = start > 0 && start < len && r0 < 0 && b0 >= 0 && lt0 > 0 && lt0 < GS;
+    const bool in1 = end_nominal > 0 && end_nominal < len && r1 < 0 && b1 >= 0 && lt1 > 0 && lt1 < GS;
+    start += in0 ? GS - lt0 : 0;
+    end_nominal += in1 ? GS - lt1 : 0;
+  }
+  const int end = min(len, end_nominal);
   float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)blk * a.mid_o_stride_s;
   float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + blk;
   if (end <= start) {
@@ -339,9 +398,6 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       qa[c] = __builtin_bit_cast(bf16x8_t, t);
     }
   }
-  const int row = a.req_indices[b];
-  const int32_t* raw_map = a.raw_slots_map + (int64_t)row * a.map_stride;
-  const int32_t* blk_map = a.kivi_block_slots_map + (int64_t)row * a.map_stride;
   const float sm_scale = rsqrtf((float)D);
   const bool score_vec = a.attn_score != nullptr && (a.score_stride_b % 4) == 0 && (a.score_stride_h % 4) == 0 &&
                          (reinterpret_cast<uintptr_t>(a.attn_score) % 16) == 0 && (start % 8) == 0;
@@ -352,11 +408,12 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  int lim = end;          // the narrow paths stop here (the row / range end, or the next block boundary in WIDE mode)
   // K fragment of one token (generic path): 8 channels c*32 + kc*8.. of token t, raw or dequantised
   auto token_k = [&](int t, uint4 (&kr)[NC]) -> bool {
 #pragma unroll
     for (int c = 0; c < NC; ++c) kr[c] = make_uint4(0, 0, 0, 0);
-    if (t >= end) return false;
+    if (t >= lim) return false;
     const int rs = raw_map[t];
     if (rs >= 0) {
       const uint16_t* kp = a.raw_k + (int64_t)rs * a.raw_slot_stride + (int64_t)w * a.raw_head_stride + kc * 8;
@@ -396,7 +453,7 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
   };
   // V row segment of one token (generic path): 8 head dims dg*8.. as packed bf16; zero when invalid
   auto token_v = [&](int t) -> uint4 {
-    if (t >= end) return make_uint4(0, 0, 0, 0);
+    if (t >= lim) return make_uint4(0, 0, 0, 0);
     const int rs = raw_map[t];
     if (rs >= 0) return *reinterpret_cast<const uint4*>(a.raw_v + (int64_t)rs * a.raw_slot_stride + (int64_t)w * a.raw_head_stride + dg * 8);
     const int bs = blk_map[t];
@@ -415,6 +472,65 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     return make_uint4(o[0], o[1], o[2], o[3]);
   };
 
+  // ---- shared middle of a tile pass: raw scores out, online softmax over the tile, P (bf16) -> LDS, rescale of O
+  auto softmax_tile = [&](f32x4_t (&s)[8], unsigned tvmask, int t0) __attribute__((always_inline)) {
+    // ---- raw scores (observation layers): 8 consecutive tokens per head per lane -> two 16-byte stores when the
+  //      score rows keep 16-byte alignment (t0 and 8n are multiples of 8)
+  if (a.attn_score != nullptr && kc < JQ) {
+    const bool vec = score_vec && tvmask == 0xffu;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = kc * 4 + r;
+      if (h < G) {
+        float* dst = a.attn_score + (int64_t)b * a.score_stride_b + (int64_t)(w * G + h) * a.score_stride_h + t0 + 8 * n;
+        if (vec) {
+          *reinterpret_cast<float4*>(dst) = make_float4(s[0][r], s[1][r], s[2][r], s[3][r]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(s[4][r], s[5][r], s[6][r], s[7][r]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if ((tvmask >> i) & 1u) dst[i] = s[i][r];
+        }
+      }
+    }
+  }
+  // ---- online softmax over the tile; P (bf16) -> LDS [head][token]
+  float alpha[4];
+  bool rescale = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool hv = (kc * 4 + r < G);
+    float x[8], tmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x[i] = (hv && ((tvmask >> i) & 1u)) ? s[i][r] * sm_scale : -INFINITY;
+      tmax = fmaxf(tmax, x[i]);
+    }
+    tmax = row16_allmax(tmax);
+    const float nm = fmaxf(m[r], tmax);
+    float psum = 0.f;
+    uint32_t pw[4] = {0u, 0u, 0u, 0u};
+    alpha[r] = 1.f;
+    if (hv && nm > -INFINITY) {
+      alpha[r] = __expf(m[r] - nm);
+      float p[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { p[i] = __expf(x[i] - nm); psum += p[i]; }
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) pw[e2] = pack_bf16(p[2 * e2], p[2 * e2 + 1]);
+      rescale |= (nm != m[r]);
+      m[r] = nm;
+    }
+    l[r] = l[r] * alpha[r] + row16_allsum(psum);
+    if (kc < JQ) *reinterpret_cast<uint4*>(Pl + (kc * 4 + r) * PST + 8 * n) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+  }
+  if (__any(rescale)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][r] *= alpha[r];
+  }
+  };
   // A tile is processed in passes over disjoint token subsets (the online softmax does not care how the tokens are
   // partitioned): MODE_FAST = the groups that are 8 aligned tokens of one KIVI block (word loads; lanes of other groups
   // masked), MODE_RAW = the groups made of raw bf16 rows (slot ids staged in LDS, straight-line vector loads),
@@ -430,16 +546,16 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     if (lane < 16) {
       const int tg = t0 + lane * 8;
       c.gfast = false;
-      c.gempty = tg >= end;
+      c.gempty = tg >= lim;
       int rm[8], bm[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { rm[e] = raw_map[min(tg + e, end - 1)]; bm[e] = blk_map[min(tg + e, end - 1)]; }
+      for (int e = 0; e < 8; ++e) { rm[e] = raw_map[min(tg + e, lim - 1)]; bm[e] = blk_map[min(tg + e, lim - 1)]; }
       if (!c.gempty) {
         c.graw = true;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) c.graw = c.graw && (tg + e >= end || rm[e] >= 0);
+        for (int e = 0; e < 8; ++e) c.graw = c.graw && (tg + e >= lim || rm[e] >= 0);
       }
-      if (tg + 8 <= end) {
+      if (tg + 8 <= lim) {
         const int b0 = bm[0];
         bool ok = b0 >= 0;
 #pragma unroll
@@ -470,11 +586,11 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     if constexpr (!HOT) {
       if (mode == MODE_RAW) {
         const int t = t0 + 2 * lane;
-        const int s0 = raw_map[min(t, end - 1)], s1 = raw_map[min(t + 1, end - 1)];
-        // -1 = not part of this pass (past the end, or not a raw row)
+        const int s0 = raw_map[min(t, lim - 1)], s1 = raw_map[min(t + 1, lim - 1)];
+        // -1 = not part of this pass (past the lim, or not a raw row)
         const bool mine = __shfl((int)cls.graw, lane >> 2, 64) != 0;
-        slot_lds[2 * lane] = (mine && t < end) ? s0 : -1;
-        slot_lds[2 * lane + 1] = (mine && t + 1 < end) ? s1 : -1;
+        slot_lds[2 * lane] = (mine && t < lim) ? s0 : -1;
+        slot_lds[2 * lane + 1] = (mine && t + 1 < lim) ? s1 : -1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -593,62 +709,7 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
           s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, kr[c]), s[i], 0, 0, 0);
       }
     }
-    // ---- raw scores (observation layers): 8 consecutive tokens per head per lane -> two 16-byte stores when the
-    //      score rows keep 16-byte alignment (t0 and 8n are multiples of 8)
-    if (a.attn_score != nullptr && kc < JQ) {
-      const bool vec = score_vec && tvmask == 0xffu;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int h = kc * 4 + r;
-        if (h < G) {
-          float* dst = a.attn_score + (int64_t)b * a.score_stride_b + (int64_t)(w * G + h) * a.score_stride_h + t0 + 8 * n;
-          if (vec) {
-            *reinterpret_cast<float4*>(dst) = make_float4(s[0][r], s[1][r], s[2][r], s[3][r]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(s[4][r], s[5][r], s[6][r], s[7][r]);
-          } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-              if ((tvmask >> i) & 1u) dst[i] = s[i][r];
-          }
-        }
-      }
-    }
-    // ---- online softmax over the tile; P (bf16) -> LDS [head][token]
-    float alpha[4];
-    bool rescale = false;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool hv = (kc * 4 + r < G);
-      float x[8], tmax = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        x[i] = (hv && ((tvmask >> i) & 1u)) ? s[i][r] * sm_scale : -INFINITY;
-        tmax = fmaxf(tmax, x[i]);
-      }
-      tmax = row16_allmax(tmax);
-      const float nm = fmaxf(m[r], tmax);
-      float psum = 0.f;
-      uint32_t pw[4] = {0u, 0u, 0u, 0u};
-      alpha[r] = 1.f;
-      if (hv && nm > -INFINITY) {
-        alpha[r] = __expf(m[r] - nm);
-        float p[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { p[i] = __expf(x[i] - nm); psum += p[i]; }
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) pw[e2] = pack_bf16(p[2 * e2], p[2 * e2 + 1]);
-        rescale |= (nm != m[r]);
-        m[r] = nm;
-      }
-      l[r] = l[r] * alpha[r] + row16_allsum(psum);
-      if (kc < JQ) *reinterpret_cast<uint4*>(Pl + (kc * 4 + r) * kT + 8 * n) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-    }
-    if (__any(rescale)) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][r] *= alpha[r];
-    }
+    softmax_tile(s, tvmask, t0);
     // ---- V scales / mins of the tile -> LDS [group][token] (fast tiles): lane l covers tokens 2l, 2l+1
     if (fast) {
       // memory order: token 2l: groups 0..NG-1, token 2l+1: groups 0..NG-1 (2 bf16 per word)
@@ -668,7 +729,7 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     // ---- P.V: 4 blocks of 32 tokens, 8 MFMAs each (head dims dg*8 + i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint4 pa = *reinterpret_cast<const uint4*>(Pl + n * kT + 32 * j + kc * 8);       // A: head n, tokens 32j + kc*8..
+      const uint4 pa = *reinterpret_cast<const uint4*>(Pl + n * PST + 32 * j + kc * 8);       // A: head n, tokens 32j + kc*8..
       const bf16x8_t pfrag = __builtin_bit_cast(bf16x8_t, pa);
       if (fast) {
         if (j + 1 < 4) issue_v(j + 1, vq[(j + 1) & 1]);
@@ -730,8 +791,253 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     __builtin_amdgcn_wave_barrier();
     }   // pass
   };
-  // driver: general tiles until an all-fast tile shows up, then the hot loop until one is not, and so on
-  {
+
+  // ------------------------------------------------------------------------------------------------------------
+  // WIDE: runs of tiles made of four whole consecutive KIVI blocks
+  // ------------------------------------------------------------------------------------------------------------
+  struct Cls4 { bool ok; int bj; };      // bj: block slot of the 32-token block this lane's two tokens sit in (lane >> 4)
+  // "tile [t, t+128) is four whole consecutive blocks" in three steps, so that inside a wide run no step waits for a
+  // load it has just issued: the maps (lane l: tokens t+2l, t+2l+1) - one phase later the partial verdict and the
+  // dependent block-start load - one phase later the verdict
+  struct Maps4 { bool inside; int r0, r1, b0, b1; };
+  struct Pend4 { bool okp; int bj, bst; };
+  auto maps4 = [&](int t) -> Maps4 {
+    // no branch around the loads (a tile that does not fit reads clamped positions and is rejected by `inside`): a
+    // branch would end the basic block and pull the first use of the values - and its in-order wait - up to here
+    Maps4 mp{t + kT <= end, 0, 0, 0, 0};
+    const int p = min(t + 2 * lane, end - 2);
+    mp.r0 = raw_map[p]; mp.r1 = raw_map[p + 1]; mp.b0 = blk_map[p]; mp.b1 = blk_map[p + 1];
+    return mp;
+  };
+  auto pend4 = [&](const Maps4& mp) -> Pend4 {
+    Pend4 pd{false, 0, 0};
+    pd.bj = __shfl(mp.b0, lane & 48, 64);
+    pd.okp = mp.inside && mp.r0 < 0 && mp.r1 < 0 && mp.b0 == pd.bj && mp.b1 == pd.bj && pd.bj >= 0;
+    pd.bst = a.kivi_block_start_pos[max(pd.bj, 0)];
+    return pd;
+  };
+  auto verdict4 = [&](const Pend4& pd, int t) -> Cls4 {
+    return Cls4{(bool)__all(pd.okp && pd.bst == t + 32 * (lane >> 4)), pd.bj};
+  };
+  auto classify4 = [&](int t) -> Cls4 { return verdict4(pend4(maps4(t)), t); };
+  [[maybe_unused]] auto wide_run = [&](int& t0, Cls4 cls) __attribute__((always_inline)) {
+    if constexpr (WIDE) {
+    // LDS addresses of this lane's operand words
+    // K row d of a block sits at position 16*(d>>4) + 8*((d&7)>>2) + 4*((d>>3)&1) + (d&3): rows d and d+8 (the two
+    // k-chunks of a 32-lane half) are 64 B apart, so a ds_read_b32 of the half touches 32 different banks
+    const unsigned char* kl = xbuf + (n >> 2) * kKBlkStride + (16 * (kc >> 1) + 4 * (kc & 1)) * 16 + (n & 3) * 4;   // + c*512 + (8*(e>>2) + (e&3))*16
+    const unsigned char* vl = xbuf + kc * 8 * 64 + kc * 64 + n * 4;                             // + j*kVBlkStride + e*64
+    // (the store addresses are recomputed from a fresh lane id where they are used: six address registers held across
+    // the loop were the difference between no spill and spills whose scratch reloads drain the prefetched loads)
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+    u32x4_t st[8];                                                     // one half-tile of codes in flight
+    u32x4_t sp[4];                                                     // K scales (lanes 0..31) / mins (32..63) of the 4 blocks
+    static_assert(KF32, "the wide path stages fp32 per-channel key parameters");
+    const unsigned char* kpl = xbuf + kKParOff + (n >> 2) * kKParStride + kc * 8 * 4;         // + c*128 (+ 4*kKParStride: mins)
+    auto issue_k = [&](const Cls4& c) {
+      // parameters first: loads return in order and the Q.K^T phase needs them with the very first chunk
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int bs = __builtin_amdgcn_readlane(c.bj, 16 * j);
+        const float* base = reinterpret_cast<const float*>(lane < 32 ? a.key_scales : a.key_mins) + ((int64_t)bs * Hkv + w) * D;
+        sp[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(base) + (lane & 31));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int bs = __builtin_amdgcn_readlane(c.bj, 16 * (j >> 1));
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(a.key_packed + (((int64_t)bs * Hkv + w) * D + (j & 1) * 64) * (GS / 8)) + lane;
+        st[j] = __builtin_nontemporal_load(src);
+      }
+    };
+    auto issue_v = [&](const Cls4& c) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int bs = __builtin_amdgcn_readlane(c.bj, 16 * (j >> 1));
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(a.value_packed + (((int64_t)bs * Hkv + w) * GS + (j & 1) * 16) * DW) + lane;
+        st[j] = __builtin_nontemporal_load(src);
+      }
+    };
+    auto put_k = [&]() {
+      const int ln = lane_id_fresh();
+      // K row d of a block sits at position 16*(d>>4) + 8*((d&7)>>2) + 4*((d>>3)&1) + (d&3) (see kl above)
+      unsigned char* kst = xbuf + (16 * (ln >> 4) + 8 * ((ln & 7) >> 2) + 4 * ((ln >> 3) & 1) + (ln & 3)) * 16;   // + (j>>1)*kKBlkStride + (j&1)*1024
+      unsigned char* kpst = xbuf + kKParOff + (ln >> 5) * 4 * kKParStride + (ln & 31) * 16;                          // + j*kKParStride
+      const float kpmul = ln < 32 ? 512.0f : 1.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // scales go down premultiplied by 2^9 (exact), the factor that turns an fp8-converted code n * 2^-9 back into n
+        typedef __attribute__((ext_vector_type(4))) float f4_t;
+        const f4_t v = __builtin_bit_cast(f4_t, sp[j]) * kpmul;
+        *reinterpret_cast<f4_t*>(kpst + j * kKParStride) = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4_t*>(kst + (j >> 1) * kKBlkStride + (j & 1) * 1024) = st[j];
+    };
+    auto put_v = [&]() {
+      // instruction j: tokens (j & 1) * 16 + (lane >> 2) of block j >> 1; the 64-byte skew after every 8 tokens is in vst
+      const int ln = lane_id_fresh();
+      unsigned char* vst = xbuf + (ln >> 2) * 64 + (ln >> 5) * 64 + (ln & 3) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4_t*>(vst + (j >> 1) * kVBlkStride + (j & 1) * (16 * 64 + 128)) = st[j];
+    };
+    auto lds_sync = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    issue_k(cls);
+    Cls4 nxt = classify4(t0 + kT);
+    put_k();
+    lds_sync();
+    while (true) {
+      // ---------------- Q.K^T of the tile: codes and per-channel scales / mins from LDS
+      // in flight under this phase: the tile's V codes from the start; its V scale / min rows (lane l: tokens 2l, 2l+1)
+      // from the third chunk and the maps of the tile after next from the last one (requested as late as their first
+      // use allows: every register held across the whole phase is one the dequantisation cannot have)
+      uint32_t vsw[NG], vmw[NG];
+      issue_v(cls);
+      Maps4 mp2{false, 0, 0, 0, 0};
+      f32x4_t s[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (c == NC - 2) {
+          const int vb = __shfl(cls.bj, lane & 48, 64);
+          const int64_t tb = (((int64_t)vb * Hkv + w) * GS + ((2 * lane) & 31)) * NG;
+          const uint4 s4 = *reinterpret_cast<const uint4*>(a.value_scales + tb), m4 = *reinterpret_cast<const uint4*>(a.value_mins + tb);
+          vsw[0] = s4.x; vsw[1] = s4.y; vsw[2] = s4.z; vsw[3] = s4.w; vmw[0] = m4.x; vmw[1] = m4.y; vmw[2] = m4.z; vmw[3] = m4.w;
+        }
+        if (c == NC - 1) mp2 = maps4(t0 + 2 * kT);
+        float sc[8], mn[8];
+        {
+          const float4 s0 = *reinterpret_cast<const float4*>(kpl + c * 128), s1 = *reinterpret_cast<const float4*>(kpl + c * 128 + 16);
+          const float4 m0 = *reinterpret_cast<const float4*>(kpl + 4 * kKParStride + c * 128);
+          const float4 m1 = *reinterpret_cast<const float4*>(kpl + 4 * kKParStride + c * 128 + 16);
+          sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+          mn[0] = m0.x; mn[1] = m0.y; mn[2] = m0.z; mn[3] = m0.w; mn[4] = m1.x; mn[5] = m1.y; mn[6] = m1.z; mn[7] = m1.w;
+        }
+        // channel pairs (2*e2, 2*e2+1): 16 codes -> the e2-th operand word of all 8 MFMAs (token 8n+i takes nibble i)
+        uint32_t kf[8][4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          f32x2_t y0[4], y1[4];
+          nibbles_fp8(*reinterpret_cast<const uint32_t*>(kl + c * 512 + (8 * ((2 * e2) >> 2) + ((2 * e2) & 3)) * 16), y0);
+          nibbles_fp8(*reinterpret_cast<const uint32_t*>(kl + c * 512 + (8 * ((2 * e2 + 1) >> 2) + ((2 * e2 + 1) & 3)) * 16), y1);
+          const float s0 = sc[2 * e2], s1 = sc[2 * e2 + 1];             // already x 2^9
+          const f32x2_t sv0 = {s0, s0}, mv0 = {mn[2 * e2], mn[2 * e2]}, sv1 = {s1, s1}, mv1 = {mn[2 * e2 + 1], mn[2 * e2 + 1]};
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            y0[k4] = pk_add_rn(pk_mul_rn(y0[k4], sv0), mv0);
+            y1[k4] = pk_add_rn(pk_mul_rn(y1[k4], sv1), mv1);
+          }
+          kf[0][e2] = pack_bf16(nib_of<0>(y0), nib_of<0>(y1)); kf[1][e2] = pack_bf16(nib_of<1>(y0), nib_of<1>(y1));
+          kf[2][e2] = pack_bf16(nib_of<2>(y0), nib_of<2>(y1)); kf[3][e2] = pack_bf16(nib_of<3>(y0), nib_of<3>(y1));
+          kf[4][e2] = pack_bf16(nib_of<4>(y0), nib_of<4>(y1)); kf[5][e2] = pack_bf16(nib_of<5>(y0), nib_of<5>(y1));
+          kf[6][e2] = pack_bf16(nib_of<6>(y0), nib_of<6>(y1)); kf[7][e2] = pack_bf16(nib_of<7>(y0), nib_of<7>(y1));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], __builtin_bit_cast(bf16x8_t, make_uint4(kf[i][0], kf[i][1], kf[i][2], kf[i][3])), s[i], 0, 0, 0);
+      }
+      softmax_tile(s, 0xffu, t0);
+      // ---------------- the code buffer changes hands: K words are all read, V codes go down
+      lds_sync();
+      put_v();
+      // V scales / mins -> LDS [group][token]: memory order is token 2l: groups 0..3, token 2l+1: groups 0..3, so
+      // group g of both tokens is one v_perm and one dword store
+      {
+        uint32_t* vs32 = reinterpret_cast<uint32_t*>(Vs);
+        uint32_t* vm32 = reinterpret_cast<uint32_t*>(Vm);
+        vs32[0 * (kT / 2) + lane] = __builtin_amdgcn_perm(vsw[2], vsw[0], 0x05040100u);
+        vs32[1 * (kT / 2) + lane] = __builtin_amdgcn_perm(vsw[2], vsw[0], 0x07060302u);
+        vs32[2 * (kT / 2) + lane] = __builtin_amdgcn_perm(vsw[3], vsw[1], 0x05040100u);
+        vs32[3 * (kT / 2) + lane] = __builtin_amdgcn_perm(vsw[3], vsw[1], 0x07060302u);
+        vm32[0 * (kT / 2) + lane] = __builtin_amdgcn_perm(vmw[2], vmw[0], 0x05040100u);
+        vm32[1 * (kT / 2) + lane] = __builtin_amdgcn_perm(vmw[2], vmw[0], 0x07060302u);
+        vm32[2 * (kT / 2) + lane] = __builtin_amdgcn_perm(vmw[3], vmw[1], 0x05040100u);
+        vm32[3 * (kT / 2) + lane] = __builtin_amdgcn_perm(vmw[3], vmw[1], 0x07060302u);
+      }
+      const Pend4 pd2 = pend4(mp2);                            // (before the conditional loads: its wait stays a counted one)
+      if (nxt.ok) issue_k(nxt);                                // next tile's K codes and parameters travel under P.V
+      lds_sync();
+      // ---------------- P.V: 4 blocks of 32 tokens, 8 MFMAs each (head dims dg*8 + i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 pa = *reinterpret_cast<const uint4*>(Pl + n * PST + 32 * j + kc * 8);
+        const bf16x8_t pfrag = __builtin_bit_cast(bf16x8_t, pa);
+        const uint4 s8 = *reinterpret_cast<const uint4*>(Vs + (dg / 4) * kT + 32 * j + kc * 8);
+        const uint4 m8 = *reinterpret_cast<const uint4*>(Vm + (dg / 4) * kT + 32 * j + kc * 8);
+        const uint32_t s8w[4] = {s8.x, s8.y, s8.z, s8.w}, m8w[4] = {m8.x, m8.y, m8.z, m8.w};
+        // token pairs (2*e2, 2*e2+1) of the block's k-chunk: 16 codes -> the e2-th operand word of all 8 MFMAs (head dim
+        // dg*8 + i takes nibble i).  bf16 scale x 4-bit code is exact in fp32, so the fused multiply-add equals the
+        // reference's separately rounded multiply and add bit for bit.
+        uint32_t vf[8][4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          f32x2_t y0[4], y1[4];
+          nibbles_fp8(*reinterpret_cast<const uint32_t*>(vl + j * kVBlkStride + (2 * e2) * 64), y0);
+          nibbles_fp8(*reinterpret_cast<const uint32_t*>(vl + j * kVBlkStride + (2 * e2 + 1) * 64), y1);
+          const float s0 = bf16_lo(s8w[e2]) * 512.0f, s1 = bf16_hi(s8w[e2]) * 512.0f;
+          const float m0 = bf16_lo(m8w[e2]), m1 = bf16_hi(m8w[e2]);
+          const f32x2_t sv0 = {s0, s0}, mv0 = {m0, m0}, sv1 = {s1, s1}, mv1 = {m1, m1};
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            y0[k4] = __builtin_elementwise_fma(y0[k4], sv0, mv0);
+            y1[k4] = __builtin_elementwise_fma(y1[k4], sv1, mv1);
+          }
+          vf[0][e2] = pack_bf16(nib_of<0>(y0), nib_of<0>(y1)); vf[1][e2] = pack_bf16(nib_of<1>(y0), nib_of<1>(y1));
+          vf[2][e2] = pack_bf16(nib_of<2>(y0), nib_of<2>(y1)); vf[3][e2] = pack_bf16(nib_of<3>(y0), nib_of<3>(y1));
+          vf[4][e2] = pack_bf16(nib_of<4>(y0), nib_of<4>(y1)); vf[5][e2] = pack_bf16(nib_of<5>(y0), nib_of<5>(y1));
+          vf[6][e2] = pack_bf16(nib_of<6>(y0), nib_of<6>(y1)); vf[7][e2] = pack_bf16(nib_of<7>(y0), nib_of<7>(y1));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag, __builtin_bit_cast(bf16x8_t, make_uint4(vf[i][0], vf[i][1], vf[i][2], vf[i][3])), acc[i], 0, 0, 0);
+      }
+      t0 += kT;
+      lds_sync();                                              // V words all read
+      if (!nxt.ok) break;
+      put_k();
+      lds_sync();
+      cls = nxt;
+      nxt = verdict4(pd2, t0 + kT);
+    }
+    }
+  };
+  // driver
+  if constexpr (WIDE) {
+    // wide runs wherever four whole blocks start at t0; a narrow tile otherwise, cut at the next block start so that the
+    // tiles after it are on the block grid (the sink tile of a row: 8 raw tokens, then blocks)
+    auto next_block_start = [&](int t0) -> int {
+      int first = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int p = t0 + 1 + 2 * lane + k;
+        bool is_start = false;
+        if (p < end && raw_map[p] < 0) {
+          const int bs = blk_map[p];
+          is_start = bs >= 0 && a.kivi_block_start_pos[bs] == p;
+        }
+        const unsigned long long mask = __ballot(is_start);
+        if (mask) first = min(first, t0 + 1 + 2 * (int)__builtin_ctzll(mask) + k);
+      }
+      return first;
+    };
+    int t0 = start;
+    while (t0 < end) {
+      const Cls4 c4 = classify4(t0);
+      if (c4.ok) { wide_run(t0, c4); continue; }
+      const int nb = next_block_start(t0);
+      lim = (nb < t0 + kT && nb + kT <= end) ? nb : end;
+      const Cls cls = classify(t0);
+      if (__all(cls.gfast)) tile_body(std::true_type{}, t0, cls);
+      else tile_body(std::false_type{}, t0, cls);
+      t0 = min(t0 + kT, lim);
+      lim = end;
+    }
+  } else {
+    // general tiles until an all-fast tile shows up, then the hot loop until one is not, and so on
     int t0 = start;
     Cls cls = classify(t0);
     while (t0 < end) {
@@ -1172,15 +1478,24 @@ kivi_stage1_tile128_pf_kernel(const SvkKiviDecodeStage1Args a) {
   }
 }
 
+// developer builds (make EXTRA=-DSVK_DEV_G7) instantiate the Qwen2.5-7B group size only: 1/8 of the compile time
+#ifdef SVK_DEV_G7
+#define SVK_ALL_G_CASES SVK_CASE(7)
+#else
+#define SVK_ALL_G_CASES SVK_CASE(1) SVK_CASE(2) SVK_CASE(3) SVK_CASE(4) SVK_CASE(5) SVK_CASE(6) SVK_CASE(7) SVK_CASE(8)
+#endif
+
 template <int D>
 int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
   const int G = a.num_q_heads / a.num_kv_heads;
   const int nblk = (a.max_len_in_batch + a.block_seq - 1) / a.block_seq;
   dim3 grid(nblk, a.batch), block(64 * a.num_kv_heads);
   const size_t shm = sizeof(float) * a.num_kv_heads * (kTile * (((G + 3) / 4) * 4) + 16);
-  // 2 = register-staged 128-token tiles (default); 3 = LDS-DMA staged pipeline (decode_kivi_lds.hip): measured slower so far
-  // (582 vs 353 us at B=4 x 256k: 256 VGPRs + 50 KiB LDS leave 6 waves/CU and the waits did not shrink), opt-in for A/B runs
-  static const int variant = getenv("SVK_KIVI_VARIANT") ? atoi(getenv("SVK_KIVI_VARIANT")) : 2;
+  // 5 (default) = 128-token tiles whose whole-block tiles take 16-byte loads through a per-wave LDS buffer (head_dim 128,
+  // <= 4 KV heads, fp32 key parameters, block_seq a multiple of 128; anything else falls through to 2);
+  // 2 = register-staged 128-token tiles with 4-byte code loads (round 2's default); 3 = LDS-DMA staged pipeline
+  // (decode_kivi_lds.hip); 4 = whole-tile register prefetch - kept for A/B runs
+  static const int variant = getenv("SVK_KIVI_VARIANT") ? atoi(getenv("SVK_KIVI_VARIANT")) : 5;
   if (a.group_size == 32 && variant == 3) return launch_kivi_lds(a, s);
   if (a.group_size == 32 && variant == 4 && a.num_kv_heads <= 4 && a.block_seq % 128 == 0) {
     // whole-tile prefetch, one wave per SIMD (see kivi_stage1_tile128_pf_kernel)
@@ -1191,7 +1506,7 @@ int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
     if (a.key_param_dtype == SVK_DTYPE_F32) hipLaunchKernelGGL((kivi_stage1_tile128_pf_kernel<D, G_, true>), grid, block, shm_pf, s, a); \
     else hipLaunchKernelGGL((kivi_stage1_tile128_pf_kernel<D, G_, false>), grid, block, shm_pf, s, a);         \
     break;
-      SVK_CASE(1) SVK_CASE(2) SVK_CASE(3) SVK_CASE(4) SVK_CASE(5) SVK_CASE(6) SVK_CASE(7) SVK_CASE(8)
+      SVK_ALL_G_CASES
 #undef SVK_CASE
       default:
         set_error("svk_kivi_decode_stage1: GQA group size %d unsupported (1..8)", G);
@@ -1199,16 +1514,39 @@ int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
     }
     return check_launch("svk_kivi_decode_stage1");
   }
+  if constexpr (D == 128) {
+    if (a.group_size == 32 && variant == 5 && a.num_kv_heads <= 4 && a.block_seq % 128 == 0 && a.key_param_dtype == SVK_DTYPE_F32) {
+      // 128-token tiles, whole-block tiles fetched with 16-byte loads through a per-wave LDS buffer (72.75 KiB per
+      // workgroup of 4 KV heads: two workgroups per CU)
+      const size_t shm_w = (size_t)a.num_kv_heads * (16 * 136 * 2 + 2 * (D / 32) * 128 * 2 + kXBufBytes);
+      switch (G) {
+#define SVK_CASE(G_)                                                                                          \
+  case G_: {                                                                                                  \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&kivi_stage1_tile128_kernel<D, G_, true, true>), \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (16 * 136 * 2 + 2 * (D / 32) * 128 * 2 + kXBufBytes)) == hipSuccess; \
+    (void)attr_ok;                                                                                            \
+    hipLaunchKernelGGL((kivi_stage1_tile128_kernel<D, G_, true, true>), grid, block, shm_w, s, a);           \
+    break;                                                                                                    \
+  }
+        SVK_ALL_G_CASES
+#undef SVK_CASE
+        default:
+          set_error("svk_kivi_decode_stage1: GQA group size %d unsupported (1..8)", G);
+          return SVK_ERR_LAYOUT;
+      }
+      return check_launch("svk_kivi_decode_stage1");
+    }
+  }
   if (a.group_size == 32) {
     // 128-token tiles, both products on the matrix cores
-    const size_t shm_t = (size_t)a.num_kv_heads * (16 * 128 * 2 + 2 * (D / 32) * 128 * 2);
+    const size_t shm_t = (size_t)a.num_kv_heads * (16 * 136 * 2 + 2 * (D / 32) * 128 * 2);
     switch (G) {
 #define SVK_CASE(G_)                                                                                          \
   case G_:                                                                                                    \
     if (a.key_param_dtype == SVK_DTYPE_F32) hipLaunchKernelGGL((kivi_stage1_tile128_kernel<D, G_, true>), grid, block, shm_t, s, a); \
     else hipLaunchKernelGGL((kivi_stage1_tile128_kernel<D, G_, false>), grid, block, shm_t, s, a);            \
     break;
-      SVK_CASE(1) SVK_CASE(2) SVK_CASE(3) SVK_CASE(4) SVK_CASE(5) SVK_CASE(6) SVK_CASE(7) SVK_CASE(8)
+      SVK_ALL_G_CASES
 #undef SVK_CASE
       default:
         set_error("svk_kivi_decode_stage1: GQA group size %d unsupported (1..8)", G);
@@ -1222,7 +1560,7 @@ int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
     if (a.key_param_dtype == SVK_DTYPE_F32) hipLaunchKernelGGL((kivi_stage1_kernel<D, G_, true>), grid, block, shm, s, a); \
     else hipLaunchKernelGGL((kivi_stage1_kernel<D, G_, false>), grid, block, shm, s, a);                  \
     break;
-    SVK_CASE(1) SVK_CASE(2) SVK_CASE(3) SVK_CASE(4) SVK_CASE(5) SVK_CASE(6) SVK_CASE(7) SVK_CASE(8)
+    SVK_ALL_G_CASES
 #undef SVK_CASE
     default:
       set_error("svk_kivi_decode_stage1: GQA group size %d unsupported (1..8)", G);

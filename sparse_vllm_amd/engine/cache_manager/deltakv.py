@@ -373,11 +373,23 @@ class DeltaKVCacheManager(CacheManager):
     def get_decode_block_seq(self, layer_idx: int, default: int) -> int:
         if self._full_layer_kivi_enabled() and layer_idx in self.full_layer_to_idx:
             bs = int(self.config.full_layer_kivi_decode_block_seq or default)
-            if os.environ.get("SVK_KIVI_BLOCK_SEQ", "") == "auto":
+            mode = os.environ.get("SVK_KIVI_BLOCK_SEQ", "wide")
+            if mode == "auto":
                 # MI355X launch geometry for the whole-tile-prefetch kernel: one round of <= 256 workgroups
                 # (one per CU), 128-token tiles
                 rows = max(1, int(self.config.max_num_seqs_in_gpu))
                 per_row = max(1, 256 // rows)
+                bs = max(bs, -(-(-(-int(self.max_model_len) // per_row)) // 128) * 128)
+            elif mode == "wide" and os.environ.get("SVK_KIVI_VARIANT", "5") == "5":
+                # MI355X launch geometry of the default (whole-block, wide-load) kernel: a workgroup pays ~15 us of
+                # prologue (boundary / classification / first-tile loads), so ranges are as long as still fills the
+                # chip: two workgroups per CU when that leaves >= 8 tiles per workgroup, else one
+                # (tools/kbench_kivi.py: 1 x 256k: 1024 -> 72.7 us, 512 -> 79.4, 256 -> 85.2; 4 x 256k: 2048 -> 180.9
+                # us, 1024 -> 191.7, 512 -> 204.7, 256 -> 232.2)
+                rows = max(1, int(self.config.max_num_seqs_in_gpu))
+                tokens = rows * int(self.max_model_len)
+                wgs = 512 if tokens >= 512 * 1024 else 256
+                per_row = max(1, wgs // rows)
                 bs = max(bs, -(-(-(-int(self.max_model_len) // per_row)) // 128) * 128)
             return bs
         return super().get_decode_block_seq(layer_idx, default)

@@ -189,6 +189,40 @@ def test_kivi_stage1_tile_passes(sink, raw_tail, lens, block_seq):
     compare(got, ref, lens, block_seq)
 
 
+@pytest.mark.parametrize("block_seq", [128, 256, 1024])
+def test_kivi_stage1_irregular_maps(block_seq):
+    """The maps are per token (deltakv_kernels.py:806-828): a raw token in the middle of a quantised run, a block whose
+    recorded start is shifted (tokens in front of it fall outside and are skipped, :821-823), a block that is only half
+    mapped, blocks out of position order.  The wide whole-block path must reject exactly those tiles and the narrow
+    paths must give the oracle's result - scores position by position, merged outputs."""
+    rng = np.random.default_rng(block_seq)
+    Hq, Hkv, D, G = 28, 4, 128, 32
+    lens = [1500, 1100, 700]
+    B = len(lens)
+    bits, maps, max_len = make_case(rng, B=B, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=lens, rows=B + 1, raw_tail=40, sink=8, key_f32=True)
+    raw_map, blk_map, blk_start = maps["raw_map"], maps["blk_map"], maps["blk_start"]
+    r0, r1, r2 = (int(x) for x in maps["req"])
+    spare_raw = int(raw_map.max()) - 3                    # make_case leaves 7 unused raw slots at the top
+    # row 0: a raw token inside block 5 of the row, and block 9 recorded 3 tokens late
+    p = 8 + 5 * G + 11
+    raw_map[r0, p] = spare_raw
+    blk_map[r0, p] = -1
+    blk_start[blk_map[r0, 8 + 9 * G]] += 3
+    # row 1: the second half of block 3 unmapped (neither raw nor quantised: invalid tokens), blocks 12 and 13 swapped
+    blk_map[r1, 8 + 3 * G + 16: 8 + 4 * G] = -1
+    a, b_ = int(blk_map[r1, 8 + 12 * G]), int(blk_map[r1, 8 + 13 * G])
+    blk_map[r1, 8 + 12 * G: 8 + 13 * G] = b_
+    blk_map[r1, 8 + 13 * G: 8 + 14 * G] = a
+    blk_start[a], blk_start[b_] = blk_start[b_], blk_start[a]
+    # row 2 stays regular
+    shape = (B, Hq, max_len)
+    got = run_gpu(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
+    ref = run_oracle(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
+    compare(got, ref, lens, block_seq)
+    # skipped tokens keep the score buffer's fill value in both
+    assert (got[2][0, :, 8 + 9 * G: 8 + 9 * G + 3] == np.float32(-1e20)).all()
+
+
 def test_kivi_stage1_all_raw_matches_plain_stage1():
     """With no KIVI block the kernel is the ordinary slot-table decode: compare with svk_flash_decode_stage1.
     The two kernels tile the row differently (128 vs 32 tokens per online-softmax step), so P is rounded to bf16

@@ -2,8 +2,8 @@
 """KIVI-int4 full-layer decode stage 1 micro-benchmark (development tool, GPU only).
 
     python tools/kbench_kivi.py [--batches 1,4] [--ctx 262152] [--block-seqs 256,512] [--iters 20]
-Algorithmic bytes per token: 4 KV heads x (64 B K codes + 64 B V codes + 32 B fp32 per-channel K scale/min
-+ 16 B bf16 per-token V scale/min) + 8 B of slot maps = 712 B.
+Algorithmic bytes per token: KV heads x (64 B K codes + 64 B V codes + 32 B fp32 per-channel K scale/min
++ 16 B bf16 per-token V scale/min) + 8 B of slot maps = 712 B with 4 KV heads (184 B for a one-KV-head TP rank).
 """
 import argparse
 import os
@@ -80,7 +80,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.iters
-            byts = B * L * (712 + (4 * Hq if args.score else 0))
+            # per token: Hkv x (64 B K codes + 64 B V codes + 32 B K scale/min + 16 B V scale/min) + 8 B of slot maps
+            byts = B * L * (Hkv * 176 + 8 + (4 * Hq if args.score else 0))
             print(f"kivi stage1 B={B} L={L} block_seq={bs:5d} score={int(args.score)}: {us:9.1f} us  {byts / us / 1e6:7.3f} TB/s "
                   f"({byts / us / 1e6 / 8.0 * 100:5.1f}% of 8 TB/s)", flush=True)
 

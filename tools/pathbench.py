@@ -66,6 +66,69 @@ def build(name: str):
     raise SystemExit(f"unknown config {name}")
 
 
+def algorithmic_bytes_per_step(name: str, info: dict, mean_row_len: float | None = None) -> float:
+    """HBM bytes one decode step of the configuration has to move (SURVEY.md section 8(d) per-unit figures x units):
+    K + V rows of the attended tokens (2 KiB per token-layer) + slot ids (+ the fp32 score for H2O), Quest's page
+    metadata scan (128 B per context token and sparse layer), DeltaKV's father gathers / latents / scratch writes and the
+    712 B per token of a KIVI-int4 full layer."""
+    B, L = info["batch"], 28
+    if name in ("h2o", "h2o_b64"):
+        return B * L * float(mean_row_len) * 2056
+    if name == "streamingllm":
+        return B * L * float(mean_row_len) * 2052
+    if name == "vanilla":
+        return B * L * float(info["context"]) * 2052
+    if name == "quest":
+        ctx, budget = info["context"], info["token_budget"]
+        return B * ((L - 2) * (ctx * 128 + budget * 2056) + 2 * ctx * 2052)
+    if name in ("deltakv", "deltakv_raw"):
+        ctx, nfull = info["context"], info["full_layers"]
+        keep, K, view = 2048, 4, 8 + 2048 + 256
+        sparse = keep * (K * 2048 + 160 + 2048) + view * 2052
+        full = ctx * (712 if info["kivi"] else 2052)
+        return B * ((L - nfull) * sparse + nfull * full)
+    raise ValueError(name)
+
+
+def build_h2o(B: int):
+    budget, interval = 4096, 128
+    cfg = Config.from_kwargs(sparse_method="h2o", max_model_len=131072, max_num_seqs_in_gpu=B,
+                             num_kvcache_slots=B * (budget + interval) + 4096, h2o_decode_budget=budget,
+                             h2o_decode_eviction_interval=interval, h2o_prefill_budget=8192, **QWEN)
+    drv = SparseDecodeDriver(cfg)
+    drv.cache_manager.permute_free_slots(1)
+    drv.admit_resident_rows(B, budget, logical_len=131072, seed=0, device_rng=True)
+    return drv, dict(batch=B, context=131072, resident=budget)
+
+
+def measure(name: str, *, steps: int = 32, warmup: int = 4, graph: bool = True) -> dict:
+    """Build the configuration, run `warmup` + `steps` decode steps of its sparse path, -> one result dict."""
+    t0 = time.perf_counter()
+    drv, info = build_h2o(64) if name == "h2o_b64" else build(name)
+    q, k, v = drv.random_step_inputs(seed=1)
+    if graph:
+        drv.enable_decode_graph()
+    torch.cuda.synchronize()
+    setup = time.perf_counter() - t0
+    for _ in range(max(warmup, 3 if graph else 0)):          # the graph is captured in the first steps
+        drv.step(q, k, v)
+    torch.cuda.synchronize()
+    lens = []
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        drv.step(q, k, v)
+        lens.append(float(drv.row_len()[0]))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) * 1e3 / steps
+    nbytes = algorithmic_bytes_per_step(name, info, mean_row_len=sum(lens) / len(lens))
+    res = dict(config=name, ms_per_step=round(ms, 4), tokens_per_s=round(info["batch"] / ms * 1e3, 1),
+               algorithmic_mb_per_step=round(nbytes / 1e6, 1), roofline_frac=round(nbytes / (ms * 1e-3) / 8.0e12, 4),
+               graph=bool(graph), steps=steps, setup_s=round(setup, 1), **info)
+    del drv, q, k, v
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="streamingllm,quest,deltakv_raw,deltakv,vanilla")
@@ -74,25 +137,7 @@ def main():
     ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
     for name in args.configs.split(","):
-        t0 = time.perf_counter()
-        drv, info = build(name)
-        q, k, v = drv.random_step_inputs(seed=1)
-        if args.graph:
-            drv.enable_decode_graph()
-        torch.cuda.synchronize()
-        setup = time.perf_counter() - t0
-        for _ in range(args.warmup):
-            drv.step(q, k, v)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            drv.step(q, k, v)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t1) * 1e3 / args.steps
-        print(json.dumps(dict(config=name, ms_per_step=round(ms, 4), tokens_per_s=round(info["batch"] / ms * 1e3, 1),
-                              graph=bool(args.graph), steps=args.steps, setup_s=round(setup, 1), **info)), flush=True)
-        del drv, q, k, v
-        torch.cuda.empty_cache()
+        print(json.dumps(measure(name, steps=args.steps, warmup=args.warmup, graph=args.graph)), flush=True)
 
 
 if __name__ == "__main__":

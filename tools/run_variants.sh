@@ -9,6 +9,7 @@ run SVK_PREFILL_ATTN_VARIANT=1 "prefill or context or large"
 run SVK_PREFILL_ATTN_HELPER=0 "prefill or context or large"
 run SVK_PREFILL_SCORE_VARIANT=1 "prefill_score or snapkv or h2o"
 run SVK_KIVI_VARIANT=4 "kivi or deltakv"
+run SVK_KIVI_VARIANT=2 "kivi or deltakv"
 run SVK_FUSE_DECODE_STORE=0 "h2o or decode or streamingllm or quest or vanilla"
 run SVK_DELTAKV_RECON_AHEAD=0 "deltakv"
 run SVK_DELTAKV_FUSE_RAW_STORE=0 "deltakv"
