@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 8
+#define SVK_ABI_VERSION 9
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -357,7 +357,15 @@ typedef struct SvkPrefillScoreArgs {
   int32_t score_cols;                 /* columns of attn_score = longest candidate range           */
   int32_t candidate_start, num_recent_tokens;
   int32_t score_mode;                 /* SVK_PREFILL_SCORE_*                                       */
+  /* MI355X: softmax statistics of the window's query rows that svk_context_attention_fwd of the same chunk left behind
+   * (`score_row_stats` there): probability mode then runs its final pass only - Q.K^T once instead of twice, one launch
+   * instead of three; attn_score must have been cleared (`score_clear` there).  Only when every causal key is a
+   * candidate (candidate_start = 0, num_recent_tokens = 0: H2O), range i <-> sequence i, head_dim 128.  NULL = compute
+   * the statistics here (the reference's three-launch form). */
+  const float* row_stats;
 } SvkPrefillScoreArgs;
+/* columns of one (sequence, head) in `row_stats`: the window padded as the scoring kernel tiles it */
+int32_t svk_prefill_score_window_pad(int32_t num_q_heads, int32_t num_kv_heads, int32_t max_query_len);
 int64_t svk_prefill_score_workspace_bytes(int32_t n_ranges, int32_t num_q_heads, int32_t num_kv_heads,
                                           int32_t max_query_len, int32_t score_cols);
 int svk_prefill_score(const SvkPrefillScoreArgs* a, svk_stream_t stream);
@@ -656,6 +664,18 @@ typedef struct SvkContextAttentionArgs {
   int64_t q_stride_t, q_stride_h, kv_slot_stride, kv_head_stride, o_stride_t, o_stride_h, req_stride;
   int32_t batch, num_q_heads, num_kv_heads, head_dim, max_input_len;
   int64_t kv_num_slots;          /* slots in k_cache / v_cache (0 = unknown): < 4 GiB tensors get 32-bit row offsets */
+  /* MI355X, optional (NULL = off; head_dim 128 kernel only): the attention already owns what prefill_score_fwd's first
+   * two launches compute - the final softmax statistics of every query row - so the rows of a score window
+   * [score_q_start[b], b_seq_len[b]) leave them behind for svk_prefill_score(row_stats=...):
+   *   score_row_stats[((b * Hkv + kvh) * G + g) * score_wpad + (pos - score_q_start[b])] = m * D^-0.5 * log2 e + log2 l
+   * (base-2 domain: p = 2^(s * D^-0.5 * log2 e - stat)), pos = absolute position of the query row in the sequence.
+   * `score_clear` [batch, score_clear_stride] f32: the first score_clear_cols columns of every row are zeroed (the
+   * state the final scoring pass publishes into by atomic max). */
+  float* score_row_stats;
+  const int32_t* score_q_start;  /* [B] absolute position of the window's first query row (< 0: no window)          */
+  float* score_clear;
+  int64_t score_clear_stride;
+  int32_t score_wpad, score_clear_cols;
 } SvkContextAttentionArgs;
 int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_stream_t stream);
 

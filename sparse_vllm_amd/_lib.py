@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 8
+SVK_ABI_VERSION = 9
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -144,7 +144,7 @@ class SvkPrefillScoreArgs(C.Structure):
                 ("req_stride", _i64), ("score_stride", _i64),
                 ("n_ranges", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
                 ("max_query_len", _i32), ("score_cols", _i32), ("candidate_start", _i32),
-                ("num_recent_tokens", _i32), ("score_mode", _i32)]
+                ("num_recent_tokens", _i32), ("score_mode", _i32), ("_pad", _i32), ("row_stats", _p)]
 
 
 class SvkDequantLinearBatch(C.Structure):
@@ -230,7 +230,8 @@ class SvkContextAttentionArgs(C.Structure):
                [(n, _i64) for n in ("q_stride_t", "q_stride_h", "kv_slot_stride", "kv_head_stride", "o_stride_t", "o_stride_h",
                                     "req_stride")] + \
                [(n, _i32) for n in ("batch", "num_q_heads", "num_kv_heads", "head_dim", "max_input_len")] + \
-               [("_pad", _i32), ("kv_num_slots", _i64)]
+               [("_pad", _i32), ("kv_num_slots", _i64), ("score_row_stats", _p), ("score_q_start", _p), ("score_clear", _p),
+                ("score_clear_stride", _i64), ("score_wpad", _i32), ("score_clear_cols", _i32)]
 
 
 class SvkQuantPackArgs(C.Structure):
@@ -288,6 +289,7 @@ ENTRY_POINTS = {
     "svk_compact_rows": ([C.POINTER(SvkCompactRowsArgs), _p], C.c_int),
     "svk_decode_alloc_slots": ([C.POINTER(SvkDecodeAllocArgs), _p], C.c_int),
     "svk_prefill_score_workspace_bytes": ([_i32, _i32, _i32, _i32, _i32], C.c_int64),
+    "svk_prefill_score_window_pad": ([_i32, _i32, _i32], C.c_int32),
     "svk_prefill_score": ([C.POINTER(SvkPrefillScoreArgs), _p], C.c_int),
     "svk_deltakv_decode_alloc": ([C.POINTER(SvkDeltakvDecodeAllocArgs), _p], C.c_int),
     "svk_deltakv_static_decode_plan": ([C.POINTER(SvkDeltakvPlanArgs), _p], C.c_int),

@@ -617,6 +617,20 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   PA_TIMING_END();
   // ---- epilogue: row sums across the two halves, 1/l into register-row layout, outputs through LDS as whole rows
   l_part += lane_xor32(l_part);
+  if (a.score_row_stats != nullptr && half == 0) {
+    // the score window's rows leave their final softmax statistics behind for the token-score pass (svk.h): the base-2
+    // exponent constant of the row, m * c + log2 l (any reference point m gives the same sum)
+    const int qs = a.score_q_start[b];
+    const int r = pc + qrow - qs;
+    if (qs >= 0 && r >= 0 && r < a.score_wpad && qrow < q_len)
+      a.score_row_stats[((int64_t)(b * a.num_kv_heads + kvh) * G + w) * a.score_wpad + r] =
+          m_run * sm_scale + __builtin_amdgcn_logf(l_part);
+  }
+  if (a.score_clear != nullptr && kvh == 0 && m0 + kQTile >= q_len) {
+    // one workgroup per sequence (the tile that holds the chunk's last rows, KV head 0) zeroes the sequence's score row
+    float* dst = a.score_clear + (int64_t)b * a.score_clear_stride;
+    for (int c = threadIdx.x; c < a.score_clear_cols; c += G * 64) dst[c] = 0.f;
+  }
   if (half == 0) fac[lq] = 1.0f / l_part;            // (the loop's last barrier retired the tiles: staging may reuse them)
   uint16_t* ost = reinterpret_cast<uint16_t*>(lds_raw + (size_t)w * (kQTile * D * 2));     // [32 rows][128] bf16 per wave
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -662,6 +676,11 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
                   (a->kv_slot_stride % 8) == 0 && (a->kv_head_stride % 8) == 0,
               SVK_ERR_LAYOUT, "svk_context_attention_fwd: q/k/v/o strides must keep 16-byte alignment");
   if (a->batch <= 0 || a->max_input_len <= 0) return SVK_OK;
+  static const int variant0 = getenv("SVK_PREFILL_ATTN_VARIANT") ? atoi(getenv("SVK_PREFILL_ATTN_VARIANT")) : 2;
+  SVK_REQUIRE((a->score_row_stats == nullptr && a->score_clear == nullptr) || (a->head_dim == 128 && variant0 == 2), SVK_ERR_LAYOUT,
+              "svk_context_attention_fwd: score statistics are produced by the head_dim 128 kernel only");
+  SVK_REQUIRE(a->score_row_stats == nullptr || (a->score_q_start != nullptr && a->score_wpad > 0), SVK_ERR_VALUE,
+              "svk_context_attention_fwd: score_row_stats needs score_q_start and score_wpad");
   dim3 grid(((a->max_input_len & kPaLenMask) + kQTile - 1) / kQTile, a->num_kv_heads, a->batch), block(64 * G);
   const size_t shm = (size_t)G * (kQTile * kPRowP * 2 + 256);
   hipStream_t s = static_cast<hipStream_t>(stream);

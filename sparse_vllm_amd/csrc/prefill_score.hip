@@ -568,6 +568,13 @@ inline int prefill_score_variant() {
 }  // namespace
 }  // namespace svk
 
+extern "C" int32_t svk_prefill_score_window_pad(int32_t num_q_heads, int32_t num_kv_heads, int32_t max_query_len) {
+  using namespace svk;
+  if (num_kv_heads <= 0 || max_query_len <= 0) return 0;
+  const Tiling t = make_tiling(1, num_q_heads, num_kv_heads, max_query_len, 1, SVK_PREFILL_SCORE_PROBABILITY);
+  return make_tiling2(t, 1, num_kv_heads, 1).Wpad32;
+}
+
 extern "C" int64_t svk_prefill_score_workspace_bytes(int32_t n_ranges, int32_t num_q_heads, int32_t num_kv_heads,
                                                      int32_t max_query_len, int32_t score_cols) {
   using namespace svk;
@@ -591,12 +598,18 @@ extern "C" int svk_prefill_score(const SvkPrefillScoreArgs* a, svk_stream_t stre
   if (a->score_mode == SVK_PREFILL_SCORE_PROBABILITY) {
     SVK_REQUIRE(std::max(16, next_pow2(a->max_query_len)) <= 128, SVK_ERR_VALUE,
                 "probability prefill score query range is too large for this kernel: %d > 128", a->max_query_len);
-    SVK_REQUIRE(a->workspace != nullptr, SVK_ERR_VALUE, "svk_prefill_score: probability mode needs a workspace");
+    SVK_REQUIRE(a->workspace != nullptr || a->row_stats != nullptr, SVK_ERR_VALUE, "svk_prefill_score: probability mode needs a workspace");
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Tiling t = make_tiling(a->n_ranges, a->num_q_heads, a->num_kv_heads, a->max_query_len, a->score_cols, a->score_mode);
   const bool logits = a->score_mode == SVK_PREFILL_SCORE_LOGITS;
   const bool v2 = a->head_dim == 128 && t.G <= 8 && t.Wpad <= 128 && prefill_score_variant() == 2;
+  if (a->row_stats != nullptr) {
+    SVK_REQUIRE(!logits && v2, SVK_ERR_LAYOUT, "svk_prefill_score: row_stats serve the head_dim 128 probability kernel only");
+    SVK_REQUIRE(a->candidate_start == 0 && a->num_recent_tokens == 0 && a->batch_indices == nullptr, SVK_ERR_VALUE,
+                "svk_prefill_score: row_stats are the attention's statistics over ALL causal keys: candidate_start = 0, "
+                "num_recent_tokens = 0 and range i <-> sequence i are required");
+  }
   if (logits || !v2)      // (the v2 probability path clears the row inside its first pass)
     hipLaunchKernelGGL(fill_rows_kernel, dim3(std::min(64, (a->score_cols + 255) / 256), a->n_ranges), dim3(256), 0, s,
                        a->attn_score, a->score_stride, a->score_cols, logits ? -INFINITY : 0.f);
@@ -607,6 +620,10 @@ extern "C" int svk_prefill_score(const SvkPrefillScoreArgs* a, svk_stream_t stre
     if (logits) {
       hipLaunchKernelGGL((prefill_score_kernel_v2<2>), grid2, block2, shm, s, *a, t.G, u.Wpad32, t.q_limit, u.NKB, nullptr, nullptr,
                          nullptr);
+    } else if (a->row_stats != nullptr) {
+      // the chunk's attention launch left the window rows' statistics and a cleared score row: final pass only
+      hipLaunchKernelGGL((prefill_score_kernel_v2<1>), grid2, block2, shm, s, *a, t.G, u.Wpad32, t.q_limit, u.NKB, nullptr, nullptr,
+                         a->row_stats);
     } else {
       const int64_t part2 = u.groups * u.NKB * u.ROWS, glob2 = u.groups * u.ROWS;
       float* pm2 = a->workspace;

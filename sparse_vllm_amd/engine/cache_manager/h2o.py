@@ -235,6 +235,56 @@ class H2OCacheManager(SnapKVCacheManager):
             ranges.append((b, seq, cache_len, start, context_len))
         return ranges
 
+    def _prefill_score_meta_tensors(self, ranges, d):
+        """(cache_lens, starts, ends) int32 on the device; rows are uniform across layers: one upload per chunk, not per
+        layer (the reference caches the same tensors, snapkv.py:1155-1214 `_cached_prefill_score_metadata_tensors`)."""
+        key = tuple((r[2], r[3], r[4]) for r in ranges)
+        cached = getattr(self, "_prefill_score_meta", None)
+        if cached is None or cached[0] != key or cached[1].device != d:
+            meta = torch.tensor([[r[2] for r in ranges], [r[3] for r in ranges], [r[4] for r in ranges]], dtype=torch.int32, device=d)
+            cached = (key, meta)
+            self._prefill_score_meta = cached
+        return key, cached[1][0], cached[1][1], cached[1][2]
+
+    def prefill_attention_score_request(self, layer_idx: int, q: torch.Tensor):
+        """MI355X: asked by the prefill attention of `layer_idx` right before its launch.  In the probability mode the
+        H2O score of a key is built from softmax rows over ALL causal keys (candidate_start = 0, num_recent = 0) - the
+        very statistics the attention computes - so the launch leaves the window rows' statistics behind and zeroes the
+        step-score rows; `collect_prefill_attention_score` then needs one scoring pass instead of three launches (Q.K^T
+        of the window once instead of twice).  -> `score_stats` of kernels.context_attention_fwd, or None."""
+        from ...utils.context import get_context
+        self._fused_prefill_stats = None
+        enabled = self.__dict__.get("_prefill_fuse_enabled")
+        if enabled is None:
+            import os
+            enabled = self._prefill_fuse_enabled = (
+                self.config.sparse_prefill_score_mode == "probability" and self.head_dim == 128
+                and self.num_heads // self.num_kv_heads <= 8 and os.environ.get("SVK_PREFILL_SCORE_FUSE", "1") == "1"
+                and os.environ.get("SVK_PREFILL_ATTN_VARIANT", "2") == "2" and os.environ.get("SVK_PREFILL_SCORE_VARIANT", "2") == "2")
+            self._prefill_wpad = {}
+        seqs = getattr(get_context(), "seqs", None)
+        if not enabled or seqs is None:
+            return None
+        ranges = self.prefill_score_ranges(layer_idx, seqs)
+        if not ranges:
+            return None
+        max_q = max(r[4] - r[3] for r in ranges)
+        if max_q <= 0 or max_q > 128:
+            return None
+        d = q.device
+        key, _cache_lens, starts, _ends = self._prefill_score_meta_tensors(ranges, d)
+        wpad = self._prefill_wpad.get(max_q)
+        if wpad is None:
+            from ...kernels.prefill_score import prefill_score_window_pad
+            wpad = self._prefill_wpad[max_q] = prefill_score_window_pad(self.num_heads, self.num_kv_heads, max_q)
+        n = len(seqs) * self.num_heads * wpad
+        buf = getattr(self, "_prefill_stats_buf", None)
+        if buf is None or buf.numel() < n or buf.device != d:
+            buf = self._prefill_stats_buf = torch.zeros((n,), dtype=torch.float32, device=d)
+        step = torch.empty((len(seqs), max(r[4] for r in ranges)), dtype=torch.float32, device=d)
+        self._fused_prefill_stats = (int(layer_idx), key, buf, step)
+        return buf, starts, wpad, step
+
     @torch.no_grad()
     def collect_prefill_attention_score(self, layer_idx: int, q: torch.Tensor, seqs, *, b_start_loc: torch.Tensor):
         """cum[:len] = expand(prev, len) + W_eff * step_score (logits mode: softmax of the vector first)."""
@@ -242,20 +292,19 @@ class H2OCacheManager(SnapKVCacheManager):
         if not ranges:
             return None
         d = q.device
-        # rows are uniform across layers: one upload per chunk, not per layer (the reference caches the same tensors,
-        # snapkv.py:1155-1214 `_cached_prefill_score_metadata_tensors`)
-        key = tuple((r[2], r[3], r[4]) for r in ranges)
-        cached = getattr(self, "_prefill_score_meta", None)
-        if cached is None or cached[0] != key or cached[1].device != d:
-            meta = torch.tensor([[r[2] for r in ranges], [r[3] for r in ranges], [r[4] for r in ranges]], dtype=torch.int32, device=d)
-            cached = (key, meta)
-            self._prefill_score_meta = cached
-        cache_lens, starts, ends = cached[1][0], cached[1][1], cached[1][2]
+        key, cache_lens, starts, ends = self._prefill_score_meta_tensors(ranges, d)
         max_ctx = max(r[4] for r in ranges)
-        step = torch.empty((len(seqs), max_ctx), dtype=torch.float32, device=d)
+        fused, self._fused_prefill_stats = getattr(self, "_fused_prefill_stats", None), None
         k_cache, _ = self.get_layer_kv_cache(layer_idx)
-        self._run_prefill_score(q, k_cache, step, layer_idx, b_start_loc, cache_lens, max(r[4] - r[3] for r in ranges),
-                                starts, ends, candidate_start=0, num_recent_tokens=0)
+        if fused is not None and fused[0] == int(layer_idx) and fused[1] == key:
+            # the attention launch of this layer and chunk left the statistics and the cleared rows: final pass only
+            step = fused[3]
+            self._run_prefill_score(q, k_cache, step, layer_idx, b_start_loc, cache_lens, max(r[4] - r[3] for r in ranges),
+                                    starts, ends, candidate_start=0, num_recent_tokens=0, row_stats=fused[2])
+        else:
+            step = torch.empty((len(seqs), max_ctx), dtype=torch.float32, device=d)
+            self._run_prefill_score(q, k_cache, step, layer_idx, b_start_loc, cache_lens, max(r[4] - r[3] for r in ranges),
+                                    starts, ends, candidate_start=0, num_recent_tokens=0)
         kv = self.kv_layer_index(layer_idx)
         for b, seq, cache_len, start, end in ranges:
             row = self.seq_id_to_row[layer_idx][int(seq.seq_id)]

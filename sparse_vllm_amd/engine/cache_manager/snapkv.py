@@ -181,7 +181,8 @@ class SnapKVCacheManager(CacheManager):
         return float("-inf") if getattr(self.config, "sparse_prefill_score_mode", "probability") == "logits" else 0.0
 
     def _run_prefill_score(self, q, k_cache, step_score, layer_idx, b_start_loc, b_prompt_cache_len, max_score_len,
-                           score_starts, score_ends, *, candidate_start: int, num_recent_tokens: int, batch_indices=None):
+                           score_starts, score_ends, *, candidate_start: int, num_recent_tokens: int, batch_indices=None,
+                           row_stats=None):
         """snapkv.py:1050-1085 -> svk_prefill_score."""
         from ...kernels.prefill_score import PrefillScoreWorkspace, prefill_score_fwd
         if self._prefill_score_workspace is None:
@@ -191,7 +192,7 @@ class SnapKVCacheManager(CacheManager):
                           int(max_score_len), self.get_layer_buffer_req_to_token_slots(layer_idx), score_starts, score_ends,
                           candidate_start=candidate_start, num_recent_tokens=num_recent_tokens,
                           score_mode=self.config.sparse_prefill_score_mode, workspace=self._prefill_score_workspace,
-                          batch_indices=batch_indices)
+                          batch_indices=batch_indices, row_stats=row_stats)
 
     @torch.no_grad()
     def collect_prefill_attention_score(self, layer_idx: int, q: torch.Tensor, seqs, *, b_start_loc: torch.Tensor):

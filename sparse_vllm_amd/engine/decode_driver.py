@@ -251,6 +251,7 @@ class SparseDecodeDriver:
             cu = torch.tensor(np.concatenate(([0], np.cumsum(lens))).astype(np.int32), device=self.device)
         ctx = set_context(True, cu_seqlens_q=cu, cache_manager=cm, sparse_controller=sc)
         ctx.max_chunk_len = max(int(s.current_chunk_size) for s in seqs)
+        ctx.seqs = seqs
         sc.prepare_forward(seqs, True)
         collect = getattr(cm, "collect_prefill_attention_score", None)
         save_raw = getattr(cm, "save_raw_kv_if_needed", None)

@@ -17,7 +17,10 @@ from .. import _lib
 
 @torch.no_grad()
 def context_attention_fwd(q, k, v, o, b_req_idx, b_start_loc, b_seq_len, b_prompt_cache_len, max_input_len,
-                          req_to_token_indexs, attn_score=None):
+                          req_to_token_indexs, attn_score=None, *, score_stats=None):
+    """`score_stats` (MI355X extension) = (row_stats f32 [B * Hq * wpad], q_start int32 [B], wpad, score_rows f32 [B, cols] or
+    None): the rows of the score window [q_start[b], b_seq_len[b]) leave their final softmax statistics in `row_stats`
+    for `prefill_score_fwd(row_stats=...)`, and `score_rows` is zeroed - see include/svk.h."""
     if attn_score is not None:
         raise NotImplementedError("prefill attention with fused score collection is outside this build (SURVEY 8(f).1)")
     Lq, Lk, Lv = q.shape[-1], k.shape[-1], v.shape[-1]
@@ -38,4 +41,12 @@ def context_attention_fwd(q, k, v, o, b_req_idx, b_start_loc, b_seq_len, b_promp
         kv_slot_stride=k.stride(0), kv_head_stride=k.stride(1), o_stride_t=o.stride(0), o_stride_h=o.stride(1),
         req_stride=req_to_token_indexs.stride(0), batch=int(b_seq_len.shape[0]), num_q_heads=int(q.shape[1]),
         num_kv_heads=int(k.shape[1]), head_dim=int(Lk), max_input_len=int(max_input_len), kv_num_slots=int(k.shape[0]))
+    if score_stats is not None:
+        row_stats, q_start, wpad, score_rows = score_stats
+        assert row_stats.dtype == torch.float32 and row_stats.is_contiguous() and q_start.dtype == torch.int32
+        assert row_stats.numel() >= int(b_seq_len.shape[0]) * int(q.shape[1]) * int(wpad)
+        a.score_row_stats, a.score_q_start, a.score_wpad = _lib.ptr(row_stats), _lib.ptr(q_start), int(wpad)
+        if score_rows is not None:
+            assert score_rows.dtype == torch.float32 and score_rows.stride(1) == 1 and score_rows.shape[0] >= b_seq_len.shape[0]
+            a.score_clear, a.score_clear_stride, a.score_clear_cols = _lib.ptr(score_rows), score_rows.stride(0), int(score_rows.shape[1])
     _lib.check(lib.svk_context_attention_fwd(C.byref(a), _lib.current_stream_handle()), lib)

@@ -27,7 +27,11 @@ class PrefillScoreWorkspace:
 def prefill_score_fwd(q, k, attn_score, b_req_idx, b_start_loc, b_seq_len, b_prompt_cache_len, max_query_len,
                       req_to_token_indexs, score_q_start, score_q_end, *, candidate_start: int = 0,
                       num_recent_tokens: int = 0, score_mode: str = "probability",
-                      workspace: PrefillScoreWorkspace | None = None, batch_indices: torch.Tensor | None = None):
+                      workspace: PrefillScoreWorkspace | None = None, batch_indices: torch.Tensor | None = None,
+                      row_stats: torch.Tensor | None = None):
+    """`row_stats` (MI355X extension): the window rows' softmax statistics that `context_attention_fwd(score_stats=...)`
+    of the same chunk left behind; the probability mode then runs its final pass only (attn_score must be the tensor that
+    launch cleared)."""
     head_dim = q.shape[-1]
     assert k.shape[-1] == head_dim
     assert q.dtype == k.dtype
@@ -59,7 +63,9 @@ def prefill_score_fwd(q, k, attn_score, b_req_idx, b_start_loc, b_seq_len, b_pro
     mode = _lib.SVK_PREFILL_SCORE_LOGITS if score_mode == "logits" else _lib.SVK_PREFILL_SCORE_PROBABILITY
     lib = _lib.load()
     ws = None
-    if mode == _lib.SVK_PREFILL_SCORE_PROBABILITY:
+    if row_stats is not None:
+        assert row_stats.dtype == torch.float32 and row_stats.is_contiguous()
+    if mode == _lib.SVK_PREFILL_SCORE_PROBABILITY and row_stats is None:
         nbytes = lib.svk_prefill_score_workspace_bytes(batch, head, kv_head, int(max_query_len), int(attn_score.shape[1]))
         workspace = PrefillScoreWorkspace() if workspace is None else workspace
         ws = workspace.reserve(nbytes, q.device)
@@ -72,5 +78,10 @@ def prefill_score_fwd(q, k, attn_score, b_req_idx, b_start_loc, b_seq_len, b_pro
         req_stride=req_to_token_indexs.stride(0), score_stride=attn_score.stride(0), n_ranges=batch,
         num_q_heads=head, num_kv_heads=kv_head, head_dim=head_dim, max_query_len=int(max_query_len),
         score_cols=int(attn_score.shape[1]), candidate_start=int(candidate_start),
-        num_recent_tokens=int(num_recent_tokens), score_mode=mode)
+        num_recent_tokens=int(num_recent_tokens), score_mode=mode, row_stats=_lib.ptr(row_stats))
     _lib.check(lib.svk_prefill_score(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+def prefill_score_window_pad(num_q_heads: int, num_kv_heads: int, max_query_len: int) -> int:
+    """Columns per (sequence, head) of a `row_stats` tensor: the score window padded the way the kernel tiles it."""
+    return int(_lib.load().svk_prefill_score_window_pad(int(num_q_heads), int(num_kv_heads), int(max_query_len)))

@@ -131,10 +131,14 @@ class Attention(torch.nn.Module):
                                    f"layer={layer_idx} context_lens_shape={tuple(b_seq_len.shape)} "
                                    f"chunk_lens_shape={tuple(chunk_lens.shape)} q_shape={tuple(q.shape)}")
             o = torch.empty_like(q)
+            # MI355X: a manager whose prefill token scores use the attention's own softmax statistics (H2O, probability
+            # mode) asks the launch to leave them behind; its collect_prefill_attention_score then runs one scoring pass
+            request = getattr(cache_manager, "prefill_attention_score_request", None)
+            score_stats = request(layer_idx, q) if request is not None else None
             with profiler.record("prefill_attention"):
                 context_attention_fwd(q, k_cache, v_cache, o, st.req_indices, b_start_loc, b_seq_len, b_seq_len - chunk_lens,
                                       int(context.max_chunk_len or q.shape[0]),
-                                      cache_manager.get_layer_buffer_req_to_token_slots(layer_idx))
+                                      cache_manager.get_layer_buffer_req_to_token_slots(layer_idx), score_stats=score_stats)
             return o
         temp_slots = None
         # this step's K/V rows: stored here (explicit launch), or inside the stage-1 launch when the manager allows it

@@ -19,6 +19,7 @@ class Context:
     decode_mid_o_logexpsum: torch.Tensor | None = None
     is_long_text: bool = False
     max_chunk_len: int | None = None       # host-known longest chunk of a prefill step (avoids a device sync)
+    seqs: Any = None                       # the step's sequences (utils/context.py:11 `seqs`)
 
 
 _CONTEXT = Context()

@@ -121,3 +121,71 @@ def test_prefill_score_validation():
         prefill_score_fwd(q, k, sc, z, z, z, z, 200, req, z, z)
     with pytest.raises(ValueError, match="one row per score range"):
         prefill_score_fwd(q, k, torch.zeros(2, 8, device=d), z, z, z, z, 4, req, z, z)
+
+
+@pytest.mark.parametrize("cfg", [
+    # Hq, Hkv, [(cache, chunk)], window
+    (28, 4, [(3000, 1096)], 128),                     # an H2O chunk: window 128, GQA 7
+    (28, 4, [(500, 700), (0, 333), (64, 40)], 128),   # ragged batch, a chunk shorter than the window
+    (32, 8, [(100, 300), (700, 65)], 48),             # Llama heads, a window that is not a power of two
+    (28, 4, [(0, 20)], 16),
+])
+def test_prefill_score_from_attention_statistics(cfg):
+    """MI355X fusion: context_attention_fwd(score_stats=...) leaves the score window's softmax statistics and a cleared
+    score row, prefill_score_fwd(row_stats=...) runs its final pass only.  Same scores as the stand-alone three-launch
+    form (the row statistics are the same sums in another order: rtol 1e-4) and as the oracle (tolerance of this file)."""
+    from sparse_vllm_amd.kernels.context_flashattention_nopad import context_attention_fwd
+    from sparse_vllm_amd.kernels.prefill_score import prefill_score_fwd, prefill_score_window_pad
+    Hq, Hkv, seqs_cfg, window = cfg
+    D = 128
+    rng = np.random.default_rng(Hq + window)
+    nb = len(seqs_cfg)
+    ctx = [c + n for c, n in seqs_cfg]
+    slots = sum(ctx) + 50
+    d = dev()
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(d)
+    k = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.5).astype(np.float32))
+    v = bf16_round((rng.standard_normal((slots, Hkv, D)) * 0.5).astype(np.float32))
+    total_q = sum(n for _, n in seqs_cfg)
+    q = bf16_round((rng.standard_normal((total_q, Hq, D)) * 0.5).astype(np.float32))
+    cap = max(ctx) + 7
+    req = np.zeros((nb + 1, cap), np.int32)
+    perm = rng.permutation(slots).astype(np.int32)
+    rows, off = list(range(nb, 0, -1)), 0
+    for i, L in enumerate(ctx):
+        req[rows[i], :L] = perm[off: off + L]
+        off += L
+    b_req = np.array(rows, np.int32)
+    b_start = np.concatenate(([0], np.cumsum([n for _, n in seqs_cfg])[:-1])).astype(np.int32)
+    b_seq = np.array(ctx, np.int32)
+    b_cache = np.array([c for c, _ in seqs_cfg], np.int32)
+    qe = b_seq.copy()
+    qs = np.array([max(L - window, c) for L, (c, n) in zip(ctx, seqs_cfg)], np.int32)
+    max_q = int((qe - qs).max())
+    tq, tk, tv = to_bf16(q), to_bf16(k), to_bf16(v)
+    # stand-alone
+    ref3 = torch.full((nb, max(ctx)), 7.0, dtype=torch.float32, device=d)
+    prefill_score_fwd(tq, tk, ref3, t(b_req), t(b_start), t(b_seq), t(b_cache), max_q, t(req), t(qs), t(qe))
+    # fused: attention leaves the statistics
+    wpad = prefill_score_window_pad(Hq, Hkv, max_q)
+    stats = torch.full((nb * Hq * wpad,), float("nan"), dtype=torch.float32, device=d)
+    got = torch.full((nb, max(ctx)), 7.0, dtype=torch.float32, device=d)
+    o = torch.empty_like(tq)
+    context_attention_fwd(tq, tk, tv, o, t(b_req), t(b_start), t(b_seq), t(b_cache), max(n for _, n in seqs_cfg), t(req),
+                          score_stats=(stats, t(qs), wpad, got))
+    torch.cuda.synchronize()
+    assert not got.any()                                                        # cleared by the attention launch
+    st = stats.view(nb, Hq, wpad).cpu().numpy()
+    for i in range(nb):
+        assert np.isfinite(st[i, :, : qe[i] - qs[i]]).all() and np.isnan(st[i, :, qe[i] - qs[i]:]).all()
+    prefill_score_fwd(tq, tk, got, t(b_req), t(b_start), t(b_seq), t(b_cache), max_q, t(req), t(qs), t(qe), row_stats=stats)
+    torch.cuda.synchronize()
+    a, b = got.cpu().numpy(), ref3.cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-8)
+    out = np.empty_like(b)
+    ops.prefill_score_fwd(q, k, out, b_req, b_start, b_seq, b_cache, max_q, req, qs, qe)
+    compare(a, out, False)
+    # the statistics only stand for softmax rows over all causal keys
+    with pytest.raises(ValueError, match="candidate_start = 0"):
+        prefill_score_fwd(tq, tk, got, t(b_req), t(b_start), t(b_seq), t(b_cache), max_q, t(req), t(qs), t(qe),
+                          candidate_start=4, row_stats=stats)
