@@ -676,8 +676,22 @@ typedef struct SvkContextAttentionArgs {
   float* score_clear;
   int64_t score_clear_stride;
   int32_t score_wpad, score_clear_cols;
+  /* The reference's score-collecting forms (context_flashattention_nopad.py:82-240, `attn_score=` of
+   * context_attention_fwd; what its OmniKV / DeltaKV observation layers receive in prefill), optional (NULL = off):
+   *   attn_score_dim 3: attn_score[b, h, t] += sum over the chunk's query rows r with cache_len + r >= t of q[r, h] . k[t]
+   *                     (raw logits, _fwd_kernel_with_score :127-132)
+   *   attn_score_dim 2: attn_score[b, t] = max(attn_score[b, t], max over heads h and over the 128-row query blocks Q of
+   *                     (sum over r in Q, cache_len + r >= t of q[r, h] . k[t]) / chunk_len)   (_with_score_2d :205-212)
+   * for t < b_seq_len[b].  Computed beside the attention launch from per-block suffix sums of the query rows
+   * (`score_workspace`, svk_context_attention_score_workspace_bytes(tokens, Hq, D) bytes), fp32. */
+  float* attn_score;
+  float* score_workspace;
+  int64_t attn_score_stride_b, attn_score_stride_h;
+  int32_t attn_score_dim;        /* 2 or 3                                                                          */
+  int32_t attn_score_cols;       /* columns of attn_score (>= the longest b_seq_len)                               */
 } SvkContextAttentionArgs;
 int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_stream_t stream);
+int64_t svk_context_attention_score_workspace_bytes(int64_t tokens, int32_t num_q_heads, int32_t head_dim);
 
 /* ---- DeltaKV compression side -------------------------------------------------------------- */
 

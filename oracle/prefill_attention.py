@@ -74,3 +74,36 @@ def context_attention_dense(q, k, v, b_req_idx, b_start_loc, b_seq_len, b_prompt
             p = np.exp(s)
             o[start: start + n_q, h] = (p / p.sum(axis=1, keepdims=True)) @ vv
     return o
+
+
+def context_attention_scores(q, k, b_req_idx, b_start_loc, b_seq_len, b_prompt_cache_len, req_to_tokens, attn_score, *,
+                             block_m: int = 128):
+    """The score-collecting forms of context_attention_fwd (context_flashattention_nopad.py:82-240), in place on
+    `attn_score`:
+      3-D [B, Hq, L]: += sum over the chunk's query rows r with cache_len + r >= t of q[r, h] . k[t]   (:127-132, atomic_add)
+      2-D [B, L]:     = max(old, max over heads and over the BLOCK_M-row query blocks of the block's masked sum / chunk_len)
+                      (:205-212, atomic_max; BLOCK_M = 128, :246)
+    for the keys t < b_seq_len[b]; raw logits (no D^-0.5), fp32."""
+    Hq, D = q.shape[1], q.shape[2]
+    G = Hq // k.shape[1]
+    for b in range(len(b_seq_len)):
+        pc, L = int(b_prompt_cache_len[b]), int(b_seq_len[b])
+        chunk = L - pc
+        if chunk <= 0:
+            continue
+        row = req_to_tokens[int(b_req_idx[b])]
+        kk = k[row[:L].astype(np.int64)].astype(np.float32)                       # [L, Hkv, D]
+        qq = q[int(b_start_loc[b]): int(b_start_loc[b]) + chunk].astype(np.float32)   # [chunk, Hq, D]
+        kh = np.repeat(kk, G, axis=1)                                             # [L, Hq, D]
+        qk = np.einsum("rhd,thd->hrt", qq, kh, dtype=np.float32)                  # [Hq, chunk, L]
+        mask = (np.arange(chunk)[:, None] + pc) >= np.arange(L)[None, :]
+        qk = np.where(mask[None], qk, np.float32(0))
+        for r0 in range(0, chunk, block_m):
+            r1 = min(r0 + block_m, chunk)
+            end = min(r0 + block_m + pc, L)                                       # block_end_loc
+            part = qk[:, r0:r1, :end].sum(axis=1, dtype=np.float32)               # [Hq, end]
+            if attn_score.ndim == 3:
+                attn_score[b, :, :end] += part
+            else:
+                attn_score[b, :end] = np.maximum(attn_score[b, :end], (part / np.float32(chunk)).max(axis=0))
+    return attn_score

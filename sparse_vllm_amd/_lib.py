@@ -231,7 +231,9 @@ class SvkContextAttentionArgs(C.Structure):
                                     "req_stride")] + \
                [(n, _i32) for n in ("batch", "num_q_heads", "num_kv_heads", "head_dim", "max_input_len")] + \
                [("_pad", _i32), ("kv_num_slots", _i64), ("score_row_stats", _p), ("score_q_start", _p), ("score_clear", _p),
-                ("score_clear_stride", _i64), ("score_wpad", _i32), ("score_clear_cols", _i32)]
+                ("score_clear_stride", _i64), ("score_wpad", _i32), ("score_clear_cols", _i32),
+                ("attn_score", _p), ("score_workspace", _p), ("attn_score_stride_b", _i64), ("attn_score_stride_h", _i64),
+                ("attn_score_dim", _i32), ("attn_score_cols", _i32)]
 
 
 class SvkQuantPackArgs(C.Structure):
@@ -304,6 +306,7 @@ ENTRY_POINTS = {
     "svk_topk_sorted_desc": ([C.POINTER(SvkTopkSortedArgs), _p, _p], C.c_int),
     "svk_deltakv_materialize_sparse_view": ([C.POINTER(SvkDeltakvMaterializeArgs), _p], C.c_int),
     "svk_context_attention_fwd": ([C.POINTER(SvkContextAttentionArgs), _p], C.c_int),
+    "svk_context_attention_score_workspace_bytes": ([_i64, _i32, _i32], C.c_int64),
     "svk_quantize_pack_grouped": ([C.POINTER(SvkQuantPackArgs), _p], C.c_int),
     "svk_kivi_store_blocks": ([C.POINTER(SvkKiviStoreArgs), _p], C.c_int),
     "svk_cluster_topk": ([C.POINTER(SvkClusterTopkArgs), _p], C.c_int),

@@ -661,6 +661,91 @@ __global__ void __launch_bounds__(512) context_attention_kernel_v2(const SvkCont
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The reference's score-collecting forms of context_attention_fwd (context_flashattention_nopad.py:82-240).  Both are
+// sums of RAW logits over query rows, so they factor through the query rows' suffix sums:
+//   sum_{r in Q, r >= r0} q[r, h] . k[t] = (sum_{r in Q, r >= r0} q[r, h]) . k[t]
+// Kernel A writes, for every 128-row query block Q (the reference's BLOCK_M), the within-block suffix sums of the bf16
+// query rows in fp32; kernel B walks the blocks that see key t and takes one 128-dim dot per (head, block).
+// ------------------------------------------------------------------------------------------------
+constexpr int kScoreBlockM = 128;
+
+__global__ void __launch_bounds__(256) ctx_q_block_suffix_kernel(const SvkContextAttentionArgs a) {
+  const int b = blockIdx.z, qb = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int cols = a.num_q_heads * a.head_dim;
+  const int chunk = a.b_seq_len[b] - a.b_prompt_cache_len[b];
+  const int r0 = qb * kScoreBlockM, r1 = min(r0 + kScoreBlockM, chunk);
+  if (col >= cols || r0 >= r1) return;
+  const int h = col / a.head_dim, d = col - h * a.head_dim;
+  const int64_t t0 = a.b_start_loc[b];
+  float run = 0.f;
+  for (int r = r1 - 1; r >= r0; --r) {
+    run += bf16_lo((uint32_t)a.q[(t0 + r) * a.q_stride_t + (int64_t)h * a.q_stride_h + d]);
+    a.score_workspace[(t0 + r) * cols + col] = run;
+  }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(64) ctx_attn_score_kernel(const SvkContextAttentionArgs a) {
+  __shared__ __attribute__((aligned(16))) float ksh[8 * 256];           // k[t] of every KV head, fp32
+  const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+  const int pc = a.b_prompt_cache_len[b];
+  const int len = a.b_seq_len[b];
+  const int chunk = len - pc;
+  if (t >= len || chunk <= 0) return;
+  const int D = a.head_dim, Hkv = a.num_kv_heads, Hq = a.num_q_heads, G = Hq / Hkv;
+  const int64_t slot = a.req_to_tokens[(int64_t)a.b_req_idx[b] * a.req_stride + t];
+  for (int i = lane; i < Hkv * D; i += 64) {
+    const int kh = i / D, d = i - kh * D;
+    ksh[i] = bf16_lo((uint32_t)a.k_cache[slot * a.kv_slot_stride + (int64_t)kh * a.kv_head_stride + d]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int h = lane;
+  const int64_t t0 = a.b_start_loc[b];
+  const int cols = Hq * D;
+  // query block Q (rows [Q*128, ..)) visits key t iff t < min(Q*128 + 128, chunk) + pc; its first row that sees t
+  const int rmin = max(t - pc, 0);
+  const int nblk = (chunk + kScoreBlockM - 1) / kScoreBlockM;
+  float total = 0.f, best = -INFINITY;
+  if (h < Hq) {
+    const float* kv = ksh + (h / G) * D;
+    for (int qb = rmin / kScoreBlockM; qb < nblk; ++qb) {
+      const int r0 = max(qb * kScoreBlockM, rmin);
+      const float* qs = a.score_workspace + (t0 + r0) * cols + (int64_t)h * D;
+      float acc = 0.f;
+      for (int d = 0; d < D; d += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(qs + d), y = *reinterpret_cast<const float4*>(kv + d);
+        acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+      }
+      total += acc;
+      best = fmaxf(best, acc / (float)chunk);
+    }
+  }
+  if (DIM == 3) {
+    if (h < Hq) a.attn_score[(int64_t)b * a.attn_score_stride_b + (int64_t)h * a.attn_score_stride_h + t] += total;
+  } else {
+    best = wave_allmax(best);
+    if (lane == 0) {
+      float* dst = a.attn_score + (int64_t)b * a.attn_score_stride_b + t;
+      *dst = fmaxf(*dst, best);
+    }
+  }
+}
+
+int launch_attn_scores(const SvkContextAttentionArgs& a, hipStream_t s) {
+  const int cols = a.num_q_heads * a.head_dim;
+  const int nblk = ((a.max_input_len & kPaLenMask) + kScoreBlockM - 1) / kScoreBlockM;
+  hipLaunchKernelGGL(ctx_q_block_suffix_kernel, dim3((cols + 255) / 256, nblk, a.batch), dim3(256), 0, s, a);
+  // (keys per sequence: up to the longest context; rows past a sequence's length return at once)
+  const dim3 grid((unsigned)a.attn_score_cols, a.batch);
+  if (a.attn_score_dim == 3) hipLaunchKernelGGL(ctx_attn_score_kernel<3>, grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(ctx_attn_score_kernel<2>, grid, dim3(64), 0, s, a);
+  return check_launch("svk_context_attention_fwd (scores)");
+}
 }  // namespace
 }  // namespace svk
 
@@ -676,6 +761,14 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
                   (a->kv_slot_stride % 8) == 0 && (a->kv_head_stride % 8) == 0,
               SVK_ERR_LAYOUT, "svk_context_attention_fwd: q/k/v/o strides must keep 16-byte alignment");
   if (a->batch <= 0 || a->max_input_len <= 0) return SVK_OK;
+  if (a->attn_score != nullptr) {
+    SVK_REQUIRE(a->attn_score_dim == 2 || a->attn_score_dim == 3, SVK_ERR_VALUE,
+                "svk_context_attention_fwd: attn_score must be rank 2 or 3, got %d", a->attn_score_dim);
+    SVK_REQUIRE(a->score_workspace != nullptr && a->attn_score_cols > 0, SVK_ERR_VALUE,
+                "svk_context_attention_fwd: attn_score needs score_workspace and attn_score_cols");
+    SVK_REQUIRE(a->num_q_heads <= 64 && a->num_kv_heads <= 8 && a->head_dim <= 256 && a->head_dim % 4 == 0, SVK_ERR_LAYOUT,
+                "svk_context_attention_fwd: score collection supports <= 64 query heads, <= 8 KV heads");
+  }
   static const int variant0 = getenv("SVK_PREFILL_ATTN_VARIANT") ? atoi(getenv("SVK_PREFILL_ATTN_VARIANT")) : 2;
   SVK_REQUIRE((a->score_row_stats == nullptr && a->score_clear == nullptr) || (a->head_dim == 128 && variant0 == 2), SVK_ERR_LAYOUT,
               "svk_context_attention_fwd: score statistics are produced by the head_dim 128 kernel only");
@@ -700,6 +793,7 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
     const dim3 block2(64 * (G + ((G <= 7 && use_helper) ? 1 : 0)));
     if (off32) hipLaunchKernelGGL((context_attention_kernel_v2<true>), grid, block2, shm2, s, *a);
     else hipLaunchKernelGGL((context_attention_kernel_v2<false>), grid, block2, shm2, s, *a);
+    if (a->attn_score != nullptr) return launch_attn_scores(*a, s);
     return check_launch("svk_context_attention_fwd");
   }
   if (a->head_dim == 128) {
@@ -709,5 +803,11 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
     if (off32) hipLaunchKernelGGL((context_attention_kernel<64, true>), grid, block, shm, s, *a);
     else hipLaunchKernelGGL((context_attention_kernel<64, false>), grid, block, shm, s, *a);
   }
+  if (a->attn_score != nullptr) return launch_attn_scores(*a, s);
   return check_launch("svk_context_attention_fwd");
+}
+
+extern "C" int64_t svk_context_attention_score_workspace_bytes(int64_t tokens, int32_t num_q_heads, int32_t head_dim) {
+  if (tokens <= 0 || num_q_heads <= 0 || head_dim <= 0) return 0;
+  return tokens * (int64_t)num_q_heads * head_dim * (int64_t)sizeof(float);
 }

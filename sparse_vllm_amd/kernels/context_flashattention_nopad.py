@@ -1,9 +1,10 @@
 """Chunked-prefill causal attention over the paged slot table on gfx950.
 
 Mirror of the reference's kernels/triton/context_flashattention_nopad.py `context_attention_fwd` (:242-302): same
-argument order and layout asserts.  The score-collecting variants (`attn_score` 2-D / 3-D, used by the reference's
-OmniKV / DeltaKV prefill observation layers) are not part of this build; H2O / SnapKV prefill scores come from
-`prefill_score_fwd`.
+argument order and layout asserts, including the score-collecting forms (`attn_score` 3-D: per-head sums of the raw
+logits over the chunk's query rows, :82-160; 2-D: head / query-block maximum of their means, :163-240) that the
+reference's sparse controller hands to observation layers in prefill (sparse_controller.py:355-364).  H2O / SnapKV
+prefill scores come from `prefill_score_fwd`.
 """
 
 from __future__ import annotations
@@ -14,6 +15,8 @@ import torch
 
 from .. import _lib
 
+_SCORE_WS: dict = {}          # device -> fp32 workspace of the score-collecting forms (query suffix sums)
+
 
 @torch.no_grad()
 def context_attention_fwd(q, k, v, o, b_req_idx, b_start_loc, b_seq_len, b_prompt_cache_len, max_input_len,
@@ -21,8 +24,6 @@ def context_attention_fwd(q, k, v, o, b_req_idx, b_start_loc, b_seq_len, b_promp
     """`score_stats` (MI355X extension) = (row_stats f32 [B * Hq * wpad], q_start int32 [B], wpad, score_rows f32 [B, cols] or
     None): the rows of the score window [q_start[b], b_seq_len[b]) leave their final softmax statistics in `row_stats`
     for `prefill_score_fwd(row_stats=...)`, and `score_rows` is zeroed - see include/svk.h."""
-    if attn_score is not None:
-        raise NotImplementedError("prefill attention with fused score collection is outside this build (SURVEY 8(f).1)")
     Lq, Lk, Lv = q.shape[-1], k.shape[-1], v.shape[-1]
     assert Lq == Lk and Lk == Lv
     assert Lk in {16, 32, 64, 128, 256}
@@ -41,6 +42,21 @@ def context_attention_fwd(q, k, v, o, b_req_idx, b_start_loc, b_seq_len, b_promp
         kv_slot_stride=k.stride(0), kv_head_stride=k.stride(1), o_stride_t=o.stride(0), o_stride_h=o.stride(1),
         req_stride=req_to_token_indexs.stride(0), batch=int(b_seq_len.shape[0]), num_q_heads=int(q.shape[1]),
         num_kv_heads=int(k.shape[1]), head_dim=int(Lk), max_input_len=int(max_input_len), kv_num_slots=int(k.shape[0]))
+    if attn_score is not None:
+        if attn_score.dim() not in (2, 3):
+            raise ValueError(f"attn_score must be [batch, heads, len] or [batch, len], got {tuple(attn_score.shape)}.")
+        assert attn_score.dtype == torch.float32 and attn_score.stride(-1) == 1, "score collection accumulates in fp32"
+        assert attn_score.shape[0] >= b_seq_len.shape[0]
+        if attn_score.dim() == 3:
+            assert attn_score.shape[1] == q.shape[1]
+        nbytes = int(lib.svk_context_attention_score_workspace_bytes(int(q.shape[0]), int(q.shape[1]), int(Lq)))
+        ws = _SCORE_WS.get(q.device)
+        if ws is None or ws.numel() * 4 < nbytes:
+            ws = _SCORE_WS[q.device] = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=q.device)
+        a.attn_score, a.score_workspace = _lib.ptr(attn_score), _lib.ptr(ws)
+        a.attn_score_stride_b = attn_score.stride(0)
+        a.attn_score_stride_h = attn_score.stride(1) if attn_score.dim() == 3 else 0
+        a.attn_score_dim, a.attn_score_cols = int(attn_score.dim()), int(attn_score.shape[-1])
     if score_stats is not None:
         row_stats, q_start, wpad, score_rows = score_stats
         assert row_stats.dtype == torch.float32 and row_stats.is_contiguous() and q_start.dtype == torch.int32

@@ -798,8 +798,30 @@ def gen_prefill_attention():
     pcl = torch.tensor(pc, dtype=torch.int32)
     o = torch.zeros(T, Hq, D)
     context_attention_fwd(q, kc, vc, o, req, start, seq_len, pcl, max(chunk), table)
-    save("prefill_attention", q=bits(q), k=bits(kc), v=bits(vc), table=table.numpy(), req=req.numpy(), start=start.numpy(),
-         seq_len=seq_len.numpy(), pcl=pcl.numpy(), o=o.numpy())
+    out = dict(q=bits(q), k=bits(kc), v=bits(vc), table=table.numpy(), req=req.numpy(), start=start.numpy(),
+               seq_len=seq_len.numpy(), pcl=pcl.numpy(), o=o.numpy())
+    # the score-collecting forms (`attn_score=`, :82-240): chunks longer than one 128-row query block
+    chunk2, pc2 = [150, 40, 129], [11, 0, 70]
+    T2 = sum(chunk2)
+    q2 = bf16f(torch.randn(T2, Hq, D, generator=g) * 0.5)
+    k2 = bf16f(torch.randn(400, Hkv, D, generator=g) * 0.5)
+    table2 = torch.randperm(400, generator=g)[: 3 * 130].to(torch.int32).view(3, 130)      # (row width < a context: see lens)
+    table2 = torch.cat([table2, torch.randperm(400, generator=g)[: 3 * 100].to(torch.int32).view(3, 100)], dim=1)
+    req2 = torch.tensor([1, 2, 0], dtype=torch.int32)
+    start2 = torch.tensor([0, chunk2[0], chunk2[0] + chunk2[1]], dtype=torch.int32)
+    seq2 = torch.tensor([c + p_ for c, p_ in zip(chunk2, pc2)], dtype=torch.int32)
+    pcl2 = torch.tensor(pc2, dtype=torch.int32)
+    L2 = int(seq2.max())
+    s3 = torch.zeros(3, Hq, L2)
+    o3 = torch.zeros(T2, Hq, D)
+    context_attention_fwd(q2, k2, k2, o3, req2, start2, seq2, pcl2, max(chunk2), table2, attn_score=s3)
+    s2 = torch.full((3, L2), -1.0e20)
+    o2 = torch.zeros(T2, Hq, D)
+    context_attention_fwd(q2, k2, k2, o2, req2, start2, seq2, pcl2, max(chunk2), table2, attn_score=s2)
+    assert torch.equal(o2, o3)
+    out.update(s_q=bits(q2), s_k=bits(k2), s_table=table2.numpy(), s_req=req2.numpy(), s_start=start2.numpy(),
+               s_seq_len=seq2.numpy(), s_pcl=pcl2.numpy(), s_score3=s3.numpy(), s_score2=s2.numpy())
+    save("prefill_attention", **out)
 
 
 def gen_h2o_capacity():
