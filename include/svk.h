@@ -295,6 +295,40 @@ typedef struct SvkCompactRowsArgs {
 } SvkCompactRowsArgs;
 int svk_compact_rows(const SvkCompactRowsArgs* a, svk_stream_t stream);
 
+/* Device-resident decode bookkeeping of the H2O path (the reference keeps row lengths and
+ * free-stack pointers in host numpy / Python lists and uploads the step's metadata, h2o.py:256-476, and decides the
+ * burst on the host, h2o.py:1498-1625).  Row lengths `row_len[l, row]` and stack pointers `free_ptr[l]` live on the
+ * device; a decode step is then two calls that need no host value of the step and can sit in one hipGraph together with
+ * the layer loop:
+ *   svk_h2o_device_step_begin  the allocation of svk_decode_alloc_slots from the device state: lane b of layer l takes
+ *                              free_stack[l, free_ptr[l] - B + b], appends it to its row, fills slot_mapping /
+ *                              context_lens / req_indices (padded graph lanes: slot -1, lane 0's metadata), then
+ *                              row_len += 1 and free_ptr[l] -= B;
+ *   svk_h2o_device_burst       every (layer, lane) whose row has reached `trigger_len` runs svk_h2o_select_indices on
+ *                              its cumulative score row and svk_compact_rows on its slot-table / score row (dropped
+ *                              slots go to the free stack in lane order, exactly where the host-driven burst puts
+ *                              them), then row_len = budget and free_ptr[l] += dropped; rows below the trigger return
+ *                              at once (three launches, microseconds when nothing triggers).
+ * Rows are uniform across layers (H2O's invariant, h2o.py:256-271). */
+typedef struct SvkH2oDeviceStepArgs {
+  int32_t* slot_table;         /* [L, rows, table_stride_row]                         */
+  int32_t* free_stack;         /* [L, stack_stride]                                   */
+  float* scores;               /* [L, rows, score_stride_row] cumulative H2O scores   */
+  int32_t* row_len;            /* [L, rows_total] device-resident row lengths         */
+  int64_t* free_ptr;           /* [L] device-resident free-stack pointers             */
+  const int32_t* row_ids;      /* [batch] physical row of every decode lane           */
+  int32_t* slot_mapping;       /* [L, out_stride] out (begin)                         */
+  int32_t* context_lens;       /* [L, out_stride] out (begin)                         */
+  int32_t* req_indices;        /* [L, out_stride] out (begin)                         */
+  int64_t* keep;               /* [L, batch, budget] scratch (burst)                  */
+  int64_t table_stride_layer, table_stride_row, stack_stride;
+  int64_t score_stride_layer, score_stride_row, out_stride;
+  int32_t n_layers, rows_total, batch, graph_batch;
+  int32_t budget, recent_count, trigger_len, _pad;
+} SvkH2oDeviceStepArgs;
+int svk_h2o_device_step_begin(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);
+int svk_h2o_device_burst(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);
+
 /* Decode slot allocation for all layers at once: lane b of layer l takes
  * free_stack[l, free_ptr - B + b], writes it at slot_table[l, row[b], cur_len[b]] and
  * into slot_mapping[l, b]; context_lens[l, b] = cur_len[b] + 1; req_indices[l, b] = row[b].

@@ -106,6 +106,15 @@ class SvkDecodeAllocArgs(C.Structure):
                 ("n_layers", _i32), ("batch", _i32), ("graph_batch", _i32)]
 
 
+class SvkH2oDeviceStepArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("slot_table", "free_stack", "scores", "row_len", "free_ptr", "row_ids", "slot_mapping",
+                                  "context_lens", "req_indices", "keep")] + \
+               [(n, _i64) for n in ("table_stride_layer", "table_stride_row", "stack_stride", "score_stride_layer",
+                                    "score_stride_row", "out_stride")] + \
+               [(n, _i32) for n in ("n_layers", "rows_total", "batch", "graph_batch", "budget", "recent_count",
+                                    "trigger_len", "_pad")]
+
+
 class SvkQuestPageMinmaxArgs(C.Structure):
     _fields_ = [("k_cache", _p), ("metadata", _p), ("page_slots", _p),
                 ("k_layer_stride", _i64), ("meta_kind_stride", _i64), ("meta_layer_stride", _i64),
@@ -290,6 +299,8 @@ ENTRY_POINTS = {
     "svk_select_prefix_topk_suffix": ([C.POINTER(SvkSelectTopkArgs), _p], C.c_int),
     "svk_compact_rows": ([C.POINTER(SvkCompactRowsArgs), _p], C.c_int),
     "svk_decode_alloc_slots": ([C.POINTER(SvkDecodeAllocArgs), _p], C.c_int),
+    "svk_h2o_device_step_begin": ([C.POINTER(SvkH2oDeviceStepArgs), _p], C.c_int),
+    "svk_h2o_device_burst": ([C.POINTER(SvkH2oDeviceStepArgs), _p], C.c_int),
     "svk_prefill_score_workspace_bytes": ([_i32, _i32, _i32, _i32, _i32], C.c_int64),
     "svk_prefill_score_window_pad": ([_i32, _i32, _i32], C.c_int32),
     "svk_prefill_score": ([C.POINTER(SvkPrefillScoreArgs), _p], C.c_int),

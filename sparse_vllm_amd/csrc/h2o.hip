@@ -237,25 +237,26 @@ __global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDec
 // exact H2O selection
 // ------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) h2o_select_kernel(const SvkH2oSelectArgs a) {
-  __shared__ SelectScratch scratch;
-  const int rowi = blockIdx.x;
-  const float* sc = a.scores + (int64_t)rowi * a.score_stride;
-  int64_t* keep = a.keep + (int64_t)rowi * a.keep_stride;
-  const int kv_len = a.kv_len, budget = a.budget;
+__device__ __forceinline__ void h2o_select_row(const float* sc, int64_t* keep, int kv_len, int budget, int recent,
+                                               SelectScratch& scratch) {
   const int tid = threadIdx.x, nt = blockDim.x;
-
   if (kv_len <= budget) {
     for (int i = tid; i < kv_len; i += nt) keep[i] = i;
     return;
   }
-  const int recent = a.recent_count;
   const int heavy = budget - recent;
   const int rs = kv_len - recent;      // recent_start; heavy < rs always holds here
   for (int i = tid; i < recent; i += nt) keep[heavy + i] = rs + i;
   if (heavy <= 0) return;
   // top-`heavy` of sc[0:rs] by (score desc, index asc), emitted in ascending index order
   block_select_topk_ordered(sc, rs, heavy, scratch, [&](int pos, int idx) { keep[pos] = idx; });
+}
+
+__global__ void __launch_bounds__(256) h2o_select_kernel(const SvkH2oSelectArgs a) {
+  __shared__ SelectScratch scratch;
+  const int rowi = blockIdx.x;
+  h2o_select_row(a.scores + (int64_t)rowi * a.score_stride, a.keep + (int64_t)rowi * a.keep_stride, a.kv_len, a.budget,
+                 a.recent_count, scratch);
 }
 
 __global__ void __launch_bounds__(256) select_topk_kernel(const SvkSelectTopkArgs a) {
@@ -279,18 +280,8 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const SvkSelectTopkArg
 // slot-table compaction
 // ------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) compact_rows_kernel(const SvkCompactRowsArgs a) {
-  const int lane_i = blockIdx.x, li = blockIdx.y;
+__device__ __forceinline__ void compact_row(int32_t* tab, int32_t* stack, float* pay, const int64_t* keep, int K, int cur) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int layer = a.layer_ids[li];
-  const int row = a.row_ids[(int64_t)li * a.n_lanes + lane_i];
-  const int K = a.keep_len, cur = a.cur_len;
-  const int64_t* keep = a.keep + ((int64_t)li * a.n_lanes + lane_i) * K;
-  int32_t* tab = a.slot_table + (int64_t)layer * a.table_stride_layer + (int64_t)row * a.table_stride_row;
-  int32_t* stack = a.free_stack + (int64_t)layer * a.stack_stride + a.free_base[li] + (int64_t)lane_i * (cur - K);
-  float* pay = a.row_payload ? a.row_payload + (int64_t)layer * a.payload_stride_layer + (int64_t)row * a.payload_stride_row
-                             : nullptr;
-
   // (A) dropped slots -> free stack, ascending position.  Position q with j = |{keep < q}|
   //     kept entries before it lands at out[q - j]   (snapkv.py:1754-1768 row-major mask order)
   for (int q = tid; q < cur; q += nt) {
@@ -325,6 +316,103 @@ __global__ void __launch_bounds__(256) compact_rows_kernel(const SvkCompactRowsA
   for (int q = K + tid; q < cur; q += nt) {
     tab[q] = 0;
     if (pay) pay[q] = 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) compact_rows_kernel(const SvkCompactRowsArgs a) {
+  const int lane_i = blockIdx.x, li = blockIdx.y;
+  const int layer = a.layer_ids[li];
+  const int row = a.row_ids[(int64_t)li * a.n_lanes + lane_i];
+  const int K = a.keep_len, cur = a.cur_len;
+  const int64_t* keep = a.keep + ((int64_t)li * a.n_lanes + lane_i) * K;
+  int32_t* tab = a.slot_table + (int64_t)layer * a.table_stride_layer + (int64_t)row * a.table_stride_row;
+  int32_t* stack = a.free_stack + (int64_t)layer * a.stack_stride + a.free_base[li] + (int64_t)lane_i * (cur - K);
+  float* pay = a.row_payload ? a.row_payload + (int64_t)layer * a.payload_stride_layer + (int64_t)row * a.payload_stride_row
+                             : nullptr;
+  compact_row(tab, stack, pay, keep, K, cur);
+}
+
+// ------------------------------------------------------------------------------------
+// device-resident decode bookkeeping (svk.h SvkH2oDeviceStepArgs)
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) h2o_device_begin_kernel(const SvkH2oDeviceStepArgs a) {
+  const int l = blockIdx.x, tid = threadIdx.x;
+  int32_t* lens = a.row_len + (int64_t)l * a.rows_total;
+  const int64_t ptr = a.free_ptr[l];
+  const int row0 = a.row_ids[0];
+  const int cur0 = lens[row0];                                         // (read before any lane of this layer writes it)
+  __syncthreads();
+  int32_t* sm = a.slot_mapping + (int64_t)l * a.out_stride;
+  int32_t* cl = a.context_lens + (int64_t)l * a.out_stride;
+  int32_t* ri = a.req_indices + (int64_t)l * a.out_stride;
+  for (int b = tid; b < a.graph_batch; b += blockDim.x) {
+    if (b >= a.batch) {                                               // padded graph lanes (h2o.py:419-424)
+      sm[b] = -1;
+      cl[b] = cur0 + 1;
+      ri[b] = row0;
+      continue;
+    }
+    const int row = a.row_ids[b];
+    const int cur = lens[row];
+    const int32_t slot = a.free_stack[(int64_t)l * a.stack_stride + ptr - a.batch + b];
+    a.slot_table[(int64_t)l * a.table_stride_layer + (int64_t)row * a.table_stride_row + cur] = slot;
+    sm[b] = slot;
+    cl[b] = cur + 1;
+    ri[b] = row;
+    lens[row] = cur + 1;
+  }
+  if (tid == 0) a.free_ptr[l] = ptr - a.batch;
+}
+
+__global__ void __launch_bounds__(256) h2o_device_select_kernel(const SvkH2oDeviceStepArgs a) {
+  __shared__ SelectScratch scratch;
+  const int b = blockIdx.x, l = blockIdx.y;
+  const int row = a.row_ids[b];
+  if (a.row_len[(int64_t)l * a.rows_total + row] != a.trigger_len) return;
+  h2o_select_row(a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row,
+                 a.keep + ((int64_t)l * a.batch + b) * a.budget, a.trigger_len, a.budget, a.recent_count, scratch);
+}
+
+__global__ void __launch_bounds__(256) h2o_device_compact_kernel(const SvkH2oDeviceStepArgs a) {
+  __shared__ int s_rank[4];
+  const int b = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+  const int32_t* lens = a.row_len + (int64_t)l * a.rows_total;
+  const int row = a.row_ids[b];
+  if (lens[row] != a.trigger_len) return;
+  // lanes in front of this one that evict too: the host-driven burst hands the lanes of a group consecutive pieces of
+  // the free stack in lane order
+  int cnt = 0;
+  for (int j = tid; j < b; j += blockDim.x) cnt += lens[a.row_ids[j]] == a.trigger_len ? 1 : 0;
+  cnt = (int)wave_allsum((float)cnt);
+  if ((tid & 63) == 0) s_rank[tid >> 6] = cnt;
+  __syncthreads();
+  const int rank = s_rank[0] + s_rank[1] + s_rank[2] + s_rank[3];
+  const int K = a.budget, cur = a.trigger_len;
+  int32_t* tab = a.slot_table + (int64_t)l * a.table_stride_layer + (int64_t)row * a.table_stride_row;
+  int32_t* stack = a.free_stack + (int64_t)l * a.stack_stride + a.free_ptr[l] + (int64_t)rank * (cur - K);
+  float* pay = a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row;
+  compact_row(tab, stack, pay, a.keep + ((int64_t)l * a.batch + b) * K, K, cur);
+}
+
+__global__ void __launch_bounds__(256) h2o_device_commit_kernel(const SvkH2oDeviceStepArgs a) {
+  __shared__ int s_cnt[4];
+  const int l = blockIdx.x, tid = threadIdx.x;
+  int32_t* lens = a.row_len + (int64_t)l * a.rows_total;
+  int cnt = 0;
+  for (int b = tid; b < a.batch; b += blockDim.x) {
+    const int row = a.row_ids[b];
+    if (lens[row] == a.trigger_len) {
+      lens[row] = a.budget;
+      ++cnt;
+    }
+  }
+  cnt = (int)wave_allsum((float)cnt);
+  if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (total > 0) a.free_ptr[l] += (int64_t)total * (a.trigger_len - a.budget);
   }
 }
 
@@ -517,4 +605,32 @@ extern "C" int svk_decode_alloc_slots(const SvkDecodeAllocArgs* a, svk_stream_t 
   hipLaunchKernelGGL(decode_alloc_kernel, dim3((a->graph_batch + 255) / 256, a->n_layers), dim3(256), 0,
                      static_cast<hipStream_t>(stream), *a);
   return check_launch("svk_decode_alloc_slots");
+}
+
+extern "C" int svk_h2o_device_step_begin(const SvkH2oDeviceStepArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->row_len != nullptr && a->free_ptr != nullptr && a->row_ids != nullptr, SVK_ERR_VALUE,
+              "svk_h2o_device_step_begin: null args");
+  SVK_REQUIRE(a->batch > 0, SVK_ERR_VALUE, "Static decode requires a non-empty real decode batch.");
+  SVK_REQUIRE(a->graph_batch >= a->batch, SVK_ERR_VALUE,
+              "Static decode graph batch is smaller than the real decode batch: graph=%d, real=%d.", a->graph_batch, a->batch);
+  if (a->n_layers <= 0) return SVK_OK;
+  hipLaunchKernelGGL(h2o_device_begin_kernel, dim3(a->n_layers), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_h2o_device_step_begin");
+}
+
+extern "C" int svk_h2o_device_burst(const SvkH2oDeviceStepArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->row_len != nullptr && a->free_ptr != nullptr && a->row_ids != nullptr && a->keep != nullptr &&
+                  a->scores != nullptr, SVK_ERR_VALUE, "svk_h2o_device_burst: null args");
+  SVK_REQUIRE(a->budget > 0 && a->trigger_len > a->budget, SVK_ERR_VALUE,
+              "svk_h2o_device_burst: trigger_len %d must exceed the budget %d", a->trigger_len, a->budget);
+  SVK_REQUIRE(a->recent_count >= 1 && a->recent_count <= a->budget, SVK_ERR_VALUE,
+              "svk_h2o_device_burst: recent_count %d out of range (budget %d)", a->recent_count, a->budget);
+  if (a->n_layers <= 0 || a->batch <= 0) return SVK_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(h2o_device_select_kernel, dim3(a->batch, a->n_layers), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(h2o_device_compact_kernel, dim3(a->batch, a->n_layers), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(h2o_device_commit_kernel, dim3(a->n_layers), dim3(256), 0, s, *a);
+  return check_launch("svk_h2o_device_burst");
 }

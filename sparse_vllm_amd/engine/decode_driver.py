@@ -203,19 +203,32 @@ class SparseDecodeDriver:
         """`after_layers()` (measurement hook) runs between the layer loop and post_forward."""
         cm, sc = self.cache_manager, self.sparse_controller
         seqs = self.seqs
+        # a manager with device-resident bookkeeping (H2O) hands its allocation and its predicated burst over as launches
+        # of the step: with the layer loop they are ONE hipGraph and the step uploads nothing
+        dev = hasattr(cm, "device_step_begin")
+        kw = {"defer_device_launch": True} if dev else {}
         if self.graph_batch_size is not None:
-            cm.prepare_decode_static(seqs, graph_batch_size=int(self.graph_batch_size))
+            cm.prepare_decode_static(seqs, graph_batch_size=int(self.graph_batch_size), **kw)
         else:
-            cm.prepare_decode_static(seqs)
-        if not getattr(self.config, "decode_cuda_graph", False):
+            cm.prepare_decode_static(seqs, **kw)
+        dev_active = dev and cm._device_step is not None
+
+        def body():
+            if dev_active:
+                cm.device_step_begin()
             self._forward_layers(q, k, v, outputs)
+            if dev_active:
+                cm.device_step_burst()
+
+        if not getattr(self.config, "decode_cuda_graph", False):
+            body()
         else:
             key = (q.data_ptr(), k.data_ptr(), v.data_ptr(), None if outputs is None else outputs.data_ptr(),
-                   tuple(s.seq_id for s in seqs))
+                   tuple(s.seq_id for s in seqs), id(cm._device_step[0]) if dev_active else None)
             if self._graph is None or self._graph_key != key:
                 if self._graph_steps_seen == 0 or self._graph_key != key:
                     # first step with these buffers runs eagerly (allocates every scratch buffer)
-                    self._forward_layers(q, k, v, outputs)
+                    body()
                     self._graph_key = key
                     self._graph_steps_seen = 1
                     self._graph = None
@@ -223,10 +236,12 @@ class SparseDecodeDriver:
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        self._forward_layers(q, k, v, outputs)
+                        body()
                     self._graph = g
                     g.replay()
             else:
+                if dev_active:
+                    cm._device_step[3] = True        # the replayed graph carries the burst launches
                 self._graph.replay()
         if after_layers is not None:
             after_layers()

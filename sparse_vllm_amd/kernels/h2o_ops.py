@@ -208,6 +208,40 @@ def decode_alloc_slots(slot_table, free_stack, layer_ids, row_ids, cur_lens, slo
     _lib.check(lib.svk_decode_alloc_slots(C.byref(a), _lib.current_stream_handle()), lib)
 
 
+def h2o_device_step_args(slot_table, free_stack, scores, row_len, free_ptr, row_ids, slot_mapping, context_lens, req_indices,
+                         keep, *, batch: int, budget: int, recent_count: int, trigger_len: int):
+    """Arguments of svk_h2o_device_step_begin / svk_h2o_device_burst (device-resident row lengths and free-stack
+    pointers, include/svk.h): built once per batch composition, every pointer in them is graph-stable."""
+    assert slot_table.dim() == 3 and slot_table.dtype == torch.int32 and slot_table.stride(2) == 1
+    assert free_stack.dim() == 2 and free_stack.dtype == torch.int32 and free_stack.stride(1) == 1
+    assert scores.dim() == 3 and scores.dtype == torch.float32 and scores.stride(2) == 1
+    assert row_len.dim() == 2 and row_len.dtype == torch.int32 and row_len.is_contiguous()
+    assert free_ptr.dtype == torch.long and free_ptr.numel() == slot_table.shape[0]
+    assert row_ids.dtype == torch.int32 and row_ids.numel() >= int(batch)
+    assert slot_mapping.dim() == 2 and slot_mapping.dtype == torch.int32 and slot_mapping.stride(1) == 1
+    assert context_lens.stride() == slot_mapping.stride() and req_indices.stride() == slot_mapping.stride()
+    assert keep.dtype == torch.long and keep.is_contiguous() and keep.numel() >= slot_table.shape[0] * int(batch) * int(budget)
+    return _lib.SvkH2oDeviceStepArgs(
+        slot_table=_lib.ptr(slot_table), free_stack=_lib.ptr(free_stack), scores=_lib.ptr(scores), row_len=_lib.ptr(row_len),
+        free_ptr=_lib.ptr(free_ptr), row_ids=_lib.ptr(row_ids), slot_mapping=_lib.ptr(slot_mapping),
+        context_lens=_lib.ptr(context_lens), req_indices=_lib.ptr(req_indices), keep=_lib.ptr(keep),
+        table_stride_layer=slot_table.stride(0), table_stride_row=slot_table.stride(1), stack_stride=free_stack.stride(0),
+        score_stride_layer=scores.stride(0), score_stride_row=scores.stride(1), out_stride=slot_mapping.stride(0),
+        n_layers=int(slot_table.shape[0]), rows_total=int(row_len.shape[1]), batch=int(batch),
+        graph_batch=int(slot_mapping.shape[1]), budget=int(budget), recent_count=int(recent_count),
+        trigger_len=int(trigger_len))
+
+
+def h2o_device_step_begin(args):
+    lib = _lib.load()
+    _lib.check(lib.svk_h2o_device_step_begin(C.byref(args), _lib.current_stream_handle()), lib)
+
+
+def h2o_device_burst(args):
+    lib = _lib.load()
+    _lib.check(lib.svk_h2o_device_burst(C.byref(args), _lib.current_stream_handle()), lib)
+
+
 def copy_slots(k_cache, v_cache, src_slots, dst_slots, workspace):
     """K/V move of H2O final-prefill dense compaction (h2o.py:1296-1329): gather all
     sources into `workspace` [2, n, Hkv, D], then scatter -> overlap safe."""

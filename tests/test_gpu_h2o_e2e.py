@@ -108,3 +108,72 @@ def test_h2o_decode_steps_match_oracle(cfg, defer, monkeypatch):
         # the layers' buffers are equally spaced slices: every step took the single all-layers launch
         from sparse_vllm_amd.kernels import h2o_ops
         assert h2o_ops.SCORE_LAYERS_LAUNCHES["batched"] > before["batched"] and h2o_ops.SCORE_LAYERS_LAUNCHES["per_layer"] == before["per_layer"]
+
+
+def _run_h2o(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False):
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    B, L, budget, interval = 4, 3, 48, 16
+    conf = Config.from_kwargs(sparse_method="h2o", num_hidden_layers=L, max_model_len=128, max_num_seqs_in_gpu=B + 1,
+                              num_kvcache_slots=B * (budget + interval) + 41, h2o_decode_budget=budget,
+                              h2o_decode_eviction_interval=interval, h2o_prefill_budget=2 * budget)
+    drv = SparseDecodeDriver(conf)
+    cm = drv.cache_manager
+    cm._device_step_enabled = device_state
+    cm.permute_free_slots(4)
+    drv.admit_resident_rows(B, budget, seed=8)
+    if ragged:
+        # two of the four rows are 5 tokens behind: bursts then hit subsets of the batch (two phases per interval)
+        for l in range(L):
+            for s in drv.seqs[:2]:
+                r = cm.seq_id_to_row[l][s.seq_id]
+                keep = torch.arange(budget - 5, device=drv.device)
+                cm.free_part_slots(l, s, keep, keep_indices_sorted=True)
+    if graph:
+        drv.enable_decode_graph()
+    q, k, v = drv.random_step_inputs(seed=3)
+    o = torch.zeros((L, B, 28, 128), dtype=torch.bfloat16, device=drv.device)
+    used_device = 0
+    for i in range(steps):
+        if sync_debug and i >= 4:
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            drv.step(q, k, v, outputs=o)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        used_device += int(cm._dev_step_cache is not None and not cm._dev_state_dirty)
+    torch.cuda.synchronize()
+    return dict(o=o.view(torch.int16).cpu().numpy().copy(), score=cm.h2o_score_tensor.cpu().numpy().copy(),
+                table=cm.buffer_req_to_token_slots_tensor.cpu().numpy().copy(), stack=cm.free_slots_stack_tensor.cpu().numpy().copy(),
+                lens=np.stack(cm.row_seq_lens).copy(), ptr=list(cm._num_free_slots), counters=dict(cm._h2o_counters),
+                dev_lens=cm._dev_row_len.cpu().numpy().copy(), dev_ptr=cm._dev_free_ptr.cpu().numpy().copy(),
+                used_device=used_device)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_device_resident_bookkeeping_equals_host_driven_steps(ragged):
+    """row lengths and free-stack pointers on the device, the allocation and the (predicated) burst as
+    launches of the step.  Against the host-driven form of the same steps across four bursts: slot tables, free stacks
+    (content and order), score rows and outputs bit-identical, eager and under hipGraph replay; the device copy of the
+    bookkeeping equals the host mirrors; rows that trigger at different steps (subsets of the batch) included."""
+    steps = 4 * 16 + 6
+    ref = _run_h2o(False, False, steps, ragged=ragged)
+    assert ref["used_device"] == 0 and ref["counters"]["decode_eviction_bursts"] >= 4 * 2
+    for graph in (False, True):
+        got = _run_h2o(True, graph, steps, ragged=ragged)
+        assert got["used_device"] >= steps - 2
+        for key in ("o", "score", "table", "lens"):
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} graph={graph}")
+        assert got["ptr"] == ref["ptr"] and got["counters"] == ref["counters"]
+        for l in range(len(ref["ptr"])):
+            np.testing.assert_array_equal(got["stack"][l, : ref["ptr"][l]], ref["stack"][l, : ref["ptr"][l]])
+        np.testing.assert_array_equal(got["dev_lens"], got["lens"])
+        np.testing.assert_array_equal(got["dev_ptr"], np.asarray(got["ptr"]))
+
+
+def test_device_resident_step_needs_no_host_sync():
+    """Under hipGraph replay a step - the burst included - is a graph launch plus numpy arithmetic on the host mirrors:
+    with torch's sync debug mode set to "error" three full eviction intervals run without a single host <-> device
+    synchronisation."""
+    got = _run_h2o(True, True, 3 * 16 + 8, sync_debug=True)
+    assert got["counters"]["decode_eviction_bursts"] == 3 * 4 and got["used_device"] >= 3 * 16
