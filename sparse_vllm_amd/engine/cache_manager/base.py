@@ -181,6 +181,19 @@ class CacheManager(ABC):
     # ------------------------------------------------------------------ scheduler capacity hooks
     # base.py:1290-1393 of the reference: what the scheduler asks a cache manager before it admits a prompt or schedules a
     # prefill chunk / decode token.  Defaults: one persistent slot per token, one shared slot budget.
+    def prefill_batched_tokens_margin(self) -> int:
+        """base.py:1243-1245: extra headroom the scheduler leaves in max_num_batched_tokens for this manager."""
+        return 0
+
+    def remaining_prefill_tokens(self, seq) -> int:
+        """base.py:1247-1253."""
+        virtual_prefilled = max(int(seq.num_prefilled_tokens), int(getattr(seq, "prefix_cache_hit_len", 0) or 0))
+        return int(seq.num_prompt_tokens - virtual_prefilled)
+
+    def min_final_prefill_chunk_size(self, seq) -> int:
+        """base.py:1326-1329."""
+        return 0
+
     def reserved_prefill_slots(self, waiting_seqs, chunk_prefill_size: int) -> int:
         """Slots still owed to prompts that are part-way through their prefill."""
         total = 0

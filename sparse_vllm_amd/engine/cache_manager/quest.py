@@ -97,6 +97,75 @@ class QuestCacheManager(CacheManager):
         after = (cur + int(size) + self.page_size - 1) // self.page_size
         return max(0, after - before)
 
+    # ---- scheduler capacity hooks in page units (quest.py:272-378, without the prefix cache - out of scope here)
+    def _ceil_to_page_slots(self, n_tokens: int) -> int:
+        n_tokens = int(n_tokens)
+        return 0 if n_tokens <= 0 else ((n_tokens + self.page_size - 1) // self.page_size) * self.page_size
+
+    def _partial_page_free_slots(self) -> int:
+        total = 0
+        for row in self.seq_id_to_row.values():
+            off = int(self.row_seq_lens[row]) % self.page_size
+            if off:
+                total += self.page_size - off
+        return total
+
+    def prefill_step_free_slots(self) -> int:
+        return int(self.num_free_slots + self._partial_page_free_slots())
+
+    def prefill_step_free_slots_for(self, seq) -> int:
+        row = self.seq_id_to_row.get(seq.seq_id)
+        partial = 0
+        if row is not None:
+            off = int(self.row_seq_lens[row]) % self.page_size
+            if off:
+                partial = self.page_size - off
+        return int(self.num_free_slots + partial)
+
+    def prefill_step_reservation_cost(self, seq, scheduled_tokens: int) -> int:
+        row = self.seq_id_to_row.get(seq.seq_id)
+        cur = 0 if row is None else int(self.row_seq_lens[row])
+        remaining, cost = int(scheduled_tokens), 0
+        off = cur % self.page_size
+        if off:
+            take = min(remaining, self.page_size - off)
+            cost += take
+            remaining -= take
+        if remaining > 0:
+            cost += self._ceil_to_page_slots(remaining)
+        return int(cost)
+
+    def decode_step_free_slots(self) -> int:
+        partial_rows = sum(1 for row in self.seq_id_to_row.values() if int(self.row_seq_lens[row]) % self.page_size)
+        return int(self._num_free_pages * self.page_size + partial_rows)
+
+    def decode_step_free_slots_for(self, seq) -> int:
+        if self._required_new_pages(seq.seq_id, 1) == 0:
+            return 1
+        return self.page_size if self._num_free_pages > 0 else 0
+
+    def decode_step_reservation_cost(self, seq) -> int:
+        return 1 if self._required_new_pages(seq.seq_id, 1) == 0 else self.page_size
+
+    def prompt_admission_free_slots(self) -> int:
+        return int(self.num_free_slots)
+
+    def prompt_admission_cost(self, seq) -> int:
+        hit = int(getattr(seq, "prefix_cache_hit_len", 0) or 0)
+        if hit > 0:
+            raise NotImplementedError("QuEST prefix-cache admission is outside this build (SURVEY.md section 2)")
+        return self._ceil_to_page_slots(int(seq.num_prompt_tokens))
+
+    def prompt_logical_reservation_cost(self, seq) -> int:
+        return int(self.prompt_admission_cost(seq))
+
+    def reserved_prefill_slots(self, waiting_seqs, chunk_prefill_size: int) -> int:
+        reserved = 0
+        for seq in waiting_seqs:
+            if 0 < seq.num_prefilled_tokens < seq.num_prompt_tokens:
+                reserved += self._ceil_to_page_slots(int(seq.num_prompt_tokens - seq.num_prefilled_tokens))
+        return reserved
+
     def _pop_pages(self, n: int) -> np.ndarray:
         """LIFO pop, newest first (quest.py:1253-1257 `[ptr-n:ptr][::-1]`)."""
         assert self._num_free_pages >= n, f"Out of QuEST KV pages: need_pages={n}, free_pages={self._num_free_pages}"

@@ -177,6 +177,26 @@ class SnapKVCacheManager(CacheManager):
                                    f"chunk_range=[{chunk_start}, {chunk_end}).")
         return rows
 
+    # ---- scheduler hooks of the SnapKV manager (snapkv.py:806-905, the branches of methods in this build)
+    def prefill_batched_tokens_margin(self) -> int:
+        return 0
+
+    def remaining_prefill_tokens(self, seq) -> int:
+        return int(seq.num_prompt_tokens - seq.num_prefilled_tokens)
+
+    def min_final_prefill_chunk_size(self, seq) -> int:
+        """snapkv.py:806-879: a prompt longer than the layer budget is scored with the last `snapkv_window_size` queries, so
+        its final chunk must hold that window."""
+        if self.config.vllm_sparse_method != "snapkv":
+            return 0
+        window = int(getattr(self.config, "snapkv_window_size", 0) or 0)
+        if window <= 0 or int(getattr(self.config, "snapkv_num_full_layers", 0) or 0) >= int(self.num_kv_layers):
+            return 0
+        budget = int(self.config.num_sink_tokens) + int(self.config.decode_keep_tokens) + int(self.config.num_recent_tokens)
+        if int(seq.num_prompt_tokens) <= budget:
+            return 0
+        return min(window, int(self.remaining_prefill_tokens(seq)))
+
     def _prefill_score_initial_value(self) -> float:
         return float("-inf") if getattr(self.config, "sparse_prefill_score_mode", "probability") == "logits" else 0.0
 

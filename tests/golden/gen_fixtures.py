@@ -1309,6 +1309,83 @@ def gen_method_surface():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+def gen_capacity_others():
+    """Scheduler capacity hooks of the SnapKV / StreamingLLM / QuEST managers (snapkv.py:761-905, streamingllm.py:24-32,
+    quest.py:272-378 without a prefix cache, base.py:1242-1397 defaults) on hand-built managers, as JSON."""
+    import json
+    from collections import deque
+    from sparsevllm.engine.cache_manager.quest import QuestCacheManager
+    from sparsevllm.engine.cache_manager.snapkv import SnapKVCacheManager
+    from sparsevllm.engine.cache_manager.streamingllm import StreamingLLMCacheManager
+    rng = np.random.default_rng(23)
+    hooks = ("prompt_admission_cost", "prompt_logical_reservation_cost", "prefill_step_free_slots_for",
+             "decode_step_free_slots_for", "decode_step_reservation_cost", "remaining_prefill_tokens",
+             "min_final_prefill_chunk_size")
+    out = []
+
+    def record(kind, m, seqs, extra):
+        waiting = deque(seqs)
+        rec = dict(kind=kind, **extra,
+                   seqs=[[int(s.seq_id), int(s.num_prompt_tokens), int(s.num_prefilled_tokens)] for s in seqs])
+        for h in hooks:
+            rec[h] = [int(getattr(m, h)(s)) for s in seqs]
+        rec["prefill_step_reservation_cost"] = [int(m.prefill_step_reservation_cost(s, 5 + 7 * i)) for i, s in enumerate(seqs)]
+        rec["prompt_admission_free_slots"] = int(m.prompt_admission_free_slots())
+        rec["prefill_step_free_slots"] = int(m.prefill_step_free_slots())
+        rec["decode_step_free_slots"] = int(m.decode_step_free_slots())
+        rec["reserved_prefill_slots"] = int(m.reserved_prefill_slots(waiting, 8))
+        rec["prompt_admission_budgets"] = {k: int(v) for k, v in m.prompt_admission_budgets(waiting, 8).items()}
+        rec["prompt_admission_costs"] = [{k: int(v) for k, v in m.prompt_admission_costs(s).items()} for s in seqs]
+        rec["prefill_batched_tokens_margin"] = int(m.prefill_batched_tokens_margin())
+        rec["prompt_admission_failure_action"] = m.prompt_admission_failure_action()
+        out.append(rec)
+
+    def mkseqs(n):
+        res = []
+        for r in range(n):
+            prompt = int(rng.integers(1, 300))
+            done = int(rng.choice([0, prompt, int(rng.integers(0, prompt + 1))]))
+            res.append(SimpleNamespace(seq_id=r, num_prompt_tokens=prompt, num_prefilled_tokens=done, prefix_cache_hit_len=0,
+                                       chain_status="", is_recompute_replay=False, chain_reused_tokens=0))
+        return res
+
+    for case in range(6):
+        B = int(rng.integers(2, 5))
+        lens = [int(x) for x in rng.integers(0, 90, B)]
+        free_ptr = int(rng.integers(0, 80))
+        sink, recent, keep, window = int(rng.choice([4, 64])), int(rng.choice([8, 32])), int(rng.choice([20, 100])), int(rng.choice([0, 8, 32]))
+        full_layers = int(rng.choice([0, 0, 2]))
+        for kind, cls in (("snapkv", SnapKVCacheManager), ("streamingllm", StreamingLLMCacheManager)):
+            m = _make_manager([lens, lens], cap=128, nslots=512, free_ptr=free_ptr, cls_name="SnapKVCacheManager")
+            m.__class__ = cls
+            m.config.vllm_sparse_method = kind
+            m.config.num_sink_tokens, m.config.num_recent_tokens, m.config.decode_keep_tokens = sink, recent, keep
+            m.config.snapkv_window_size = window
+            m.config.snapkv_num_full_layers = full_layers
+            m.config.pyramid_layer_ratios = None
+            m.kv_layer_index = lambda layer: int(layer)
+            m.kv_transformer_layer_indices = lambda: (0, 1)
+            m.chain_physical_kv_len = lambda layer, seq_id: 0
+            record(kind, m, mkseqs(B), dict(lens=lens, free=[int(x) for x in m._num_free_slots], sink=sink, recent=recent,
+                                            keep=keep, window=window, full_layers=full_layers))
+    for case in range(6):
+        B = int(rng.integers(2, 5))
+        page = int(rng.choice([4, 16]))
+        m = object.__new__(QuestCacheManager)
+        m.page_size = page
+        m.prefix_cache = None
+        m.row_seq_lens = np.asarray([int(x) for x in rng.integers(0, 100, B + 1)], dtype=np.int32)
+        m.seq_id_to_row = {r: r for r in range(B - 1)}          # the last sequence has no row yet
+        m._num_free_pages = int(rng.integers(0, 9))
+        m.config = SimpleNamespace(vllm_sparse_method="quest")
+        record("quest", m, mkseqs(B), dict(page=page, lens=[int(x) for x in m.row_seq_lens], free_pages=int(m._num_free_pages),
+                                           rows={str(k): int(v) for k, v in m.seq_id_to_row.items()}))
+    path = os.path.join(HERE, "capacity_others.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 GROUPS = {
     "decode_alloc": gen_decode_alloc,
     "decode": gen_decode,
@@ -1328,6 +1405,7 @@ GROUPS = {
     "snapkv_e2e": gen_snapkv_e2e,
     "deltakv_topk": gen_deltakv_topk,
     "method_surface": gen_method_surface,
+    "capacity_others": gen_capacity_others,
 }
 
 

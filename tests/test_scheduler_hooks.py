@@ -105,3 +105,48 @@ def test_mi355x_decode_launch_geometry():
     other = DeviceCaps(platform=PlatformEnum.ROCM, arch="gfx942", num_cus=304)
     op = prepare_decode_launch_op(DecodeAttentionLaunchSpec(num_heads=28, num_kv_heads=4, head_dim=128), other)
     assert op.launch_config(block_seq=256, max_context_len=4224, requires_attention_scores=False, batch_size=256) == (256, 16, 2)
+
+
+def test_snapkv_streamingllm_quest_capacity_hooks_match_reference():
+    """Scheduler capacity hooks of the SnapKV / StreamingLLM / QuEST managers (snapkv.py:761-905, streamingllm.py:24-32,
+    quest.py:272-378 without a prefix cache, base.py:1242-1397) against answers recorded from the reference's own hooks
+    on hand-built managers (tests/golden/gen_fixtures.py capacity_others)."""
+    import json
+    import os
+    from sparse_vllm_amd.engine.cache_manager.quest import QuestCacheManager
+    from sparse_vllm_amd.engine.cache_manager.snapkv import SnapKVCacheManager
+    from sparse_vllm_amd.engine.cache_manager.streamingllm import StreamingLLMCacheManager
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "capacity_others.json")) as f:
+        cases = json.load(f)
+    assert {c["kind"] for c in cases} == {"snapkv", "streamingllm", "quest"}
+    for c in cases:
+        seqs = [SimpleNamespace(seq_id=a, num_prompt_tokens=b, num_prefilled_tokens=d, prefix_cache_hit_len=0) for a, b, d in c["seqs"]]
+        if c["kind"] == "quest":
+            m = object.__new__(QuestCacheManager)
+            m.page_size = c["page"]
+            m.row_seq_lens = np.asarray(c["lens"], dtype=np.int32)
+            m.seq_id_to_row = {int(k): v for k, v in c["rows"].items()}
+            m._num_free_pages = c["free_pages"]
+        else:
+            m = object.__new__({"snapkv": SnapKVCacheManager, "streamingllm": StreamingLLMCacheManager}[c["kind"]])
+            m.num_layers = m.num_kv_layers = 2
+            m.config = SimpleNamespace(vllm_sparse_method=c["kind"], num_sink_tokens=c["sink"], num_recent_tokens=c["recent"],
+                                       decode_keep_tokens=c["keep"], snapkv_window_size=c["window"],
+                                       snapkv_num_full_layers=c["full_layers"])
+            m._num_free_slots = list(c["free"])
+            m.row_seq_lens = [np.asarray(c["lens"], dtype=np.int32) for _ in range(2)]
+            m.seq_id_to_row = [{r: r for r in range(len(c["lens"]))} for _ in range(2)]
+        waiting = deque(seqs)
+        for h in ("prompt_admission_cost", "prompt_logical_reservation_cost", "prefill_step_free_slots_for",
+                  "decode_step_free_slots_for", "decode_step_reservation_cost", "remaining_prefill_tokens",
+                  "min_final_prefill_chunk_size"):
+            assert [int(getattr(m, h)(s)) for s in seqs] == c[h], (c["kind"], h)
+        assert [int(m.prefill_step_reservation_cost(s, 5 + 7 * i)) for i, s in enumerate(seqs)] == c["prefill_step_reservation_cost"]
+        assert int(m.prompt_admission_free_slots()) == c["prompt_admission_free_slots"]
+        assert int(m.prefill_step_free_slots()) == c["prefill_step_free_slots"]
+        assert int(m.decode_step_free_slots()) == c["decode_step_free_slots"]
+        assert int(m.reserved_prefill_slots(waiting, 8)) == c["reserved_prefill_slots"]
+        assert {k: int(v) for k, v in m.prompt_admission_budgets(waiting, 8).items()} == c["prompt_admission_budgets"]
+        assert [{k: int(v) for k, v in m.prompt_admission_costs(s).items()} for s in seqs] == c["prompt_admission_costs"]
+        assert int(m.prefill_batched_tokens_margin()) == c["prefill_batched_tokens_margin"]
+        assert m.prompt_admission_failure_action() == c["prompt_admission_failure_action"]
