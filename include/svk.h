@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 9
+#define SVK_ABI_VERSION 10
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -154,6 +154,7 @@ typedef struct SvkFlashDecodeStage2Args {
   int64_t mid_lse_stride_b, mid_lse_stride_h;
   int64_t o_stride_b, o_stride_h;
   int32_t batch, num_q_heads, head_dim, block_seq;
+  int32_t extra_partials;        /* partials merged beyond ceil(len / block_seq) (svk_kivi_decode_stage1), normally 0 */
 } SvkFlashDecodeStage2Args;
 int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_stream_t stream);
 
@@ -826,8 +827,16 @@ typedef struct SvkKiviDecodeStage1Args {
   int64_t score_stride_b, score_stride_h;
   int32_t batch, num_q_heads, num_kv_heads, head_dim, max_len_in_batch, block_seq, group_size;
   int32_t key_param_dtype;           /* SVK_DTYPE_F32 (reference manager) or SVK_DTYPE_BF16 */
+  /* MI355X: 0, or svk_kivi_decode_stage1_extra_partials(args) when mid_o / mid_lse have that many partial slots more
+   * than ceil(max_len_in_batch / block_seq).  The launch then gives the latency-bound pieces of every row (raw sink
+   * tokens, raw residual tail, the ragged quantised piece in front of it) to extra workgroups that write the partials
+   * nblk_row .. nblk_row + extra - 1 (nblk_row = ceil(len / block_seq)); partials of regular blocks at or past nblk_row
+   * are then NOT written, and stage 2 must be told (SvkFlashDecodeStage2Args.extra_partials). */
+  int32_t extra_partials;
 } SvkKiviDecodeStage1Args;
 int svk_kivi_decode_stage1(const SvkKiviDecodeStage1Args* a, svk_stream_t stream);
+/* extra partial slots the launch described by `a` can use (its extra_partials field is ignored): 3 or 0 */
+int32_t svk_kivi_decode_stage1_extra_partials(const SvkKiviDecodeStage1Args* a);
 
 /* Observation-layer token scores for the query-aware top-k:
  *   s[b, t] = max_h softmax_{t in [start, start+len_b)} (raw[b,h,t] * scale), cast to `round_dtype`,
@@ -844,7 +853,8 @@ typedef struct SvkDeltakvTokenScoresArgs {
   int32_t round_dtype;            /* SVK_DTYPE_*: F32 = no rounding               */
 } SvkDeltakvTokenScoresArgs;
 int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_stream_t stream);
-/* number of statistics chunks the workspace must hold for score rows of `length` elements */
+/* statistics slots per (row, head) the workspace must hold for score rows of `length` elements: one per 4096-element
+ * chunk plus one for their combination */
 int svk_deltakv_token_scores_chunks(int32_t length);
 
 /* idx[r, :k] = indices of the k largest of scores[r, :n] ordered by (score desc, index asc) -

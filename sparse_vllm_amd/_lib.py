@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 9
+SVK_ABI_VERSION = 10
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -63,7 +63,7 @@ class SvkFlashDecodeStage2Args(C.Structure):
     _fields_ = [("mid_o", _p), ("mid_lse", _p), ("b_seqlen", _p), ("o", _p),
                 ("mid_o_stride_b", _i64), ("mid_o_stride_h", _i64), ("mid_o_stride_s", _i64),
                 ("mid_lse_stride_b", _i64), ("mid_lse_stride_h", _i64), ("o_stride_b", _i64), ("o_stride_h", _i64),
-                ("batch", _i32), ("num_q_heads", _i32), ("head_dim", _i32), ("block_seq", _i32)]
+                ("batch", _i32), ("num_q_heads", _i32), ("head_dim", _i32), ("block_seq", _i32), ("extra_partials", _i32)]
 
 
 class SvkH2oDecodeScoreArgs(C.Structure):
@@ -277,7 +277,7 @@ class SvkKiviDecodeStage1Args(C.Structure):
                                     "mid_o_stride_b", "mid_o_stride_h", "mid_o_stride_s", "mid_lse_stride_b",
                                     "mid_lse_stride_h", "score_stride_b", "score_stride_h")] + \
                [(n, _i32) for n in ("batch", "num_q_heads", "num_kv_heads", "head_dim", "max_len_in_batch", "block_seq",
-                                    "group_size", "key_param_dtype")]
+                                    "group_size", "key_param_dtype", "extra_partials")]
 
 
 # symbol -> (argtypes) ; every entry point declared in include/svk.h
@@ -289,6 +289,7 @@ ENTRY_POINTS = {
     "svk_copy_slots": ([C.POINTER(SvkCopySlotsArgs), _p], C.c_int),
     "svk_flash_decode_stage1": ([C.POINTER(SvkFlashDecodeStage1Args), _p], C.c_int),
     "svk_flash_decode_stage2": ([C.POINTER(SvkFlashDecodeStage2Args), _p], C.c_int),
+    "svk_kivi_decode_stage1_extra_partials": ([C.POINTER(SvkKiviDecodeStage1Args)], C.c_int32),
     "svk_fill_f32": ([_p, _i64, _f32, _p], C.c_int),
     "svk_h2o_decode_score_update": ([C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
     "svk_h2o_decode_score_update_layers": ([C.POINTER(SvkH2oDecodeScoreArgs), C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _p], C.c_int),

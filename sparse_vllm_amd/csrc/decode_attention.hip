@@ -1176,7 +1176,7 @@ decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
   const int b = blockIdx.x, h = blockIdx.y;
   const int g = threadIdx.x / LPR, d = (threadIdx.x % LPR) * 4;
   const int len = a.b_seqlen[b];
-  const int nblk = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq;
+  const int nblk = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq + a.extra_partials;
   const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h + d;
   const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
   float mx = -INFINITY;
@@ -1460,6 +1460,7 @@ extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_st
   SVK_REQUIRE(a->head_dim == 64 || a->head_dim == 128, SVK_ERR_LAYOUT,
               "svk_flash_decode_stage2: head_dim %d unsupported (64, 128)", a->head_dim);
   SVK_REQUIRE(a->block_seq > 0, SVK_ERR_VALUE, "svk_flash_decode_stage2: block_seq must be positive");
+  SVK_REQUIRE(a->extra_partials >= 0 && a->extra_partials <= 8, SVK_ERR_VALUE, "svk_flash_decode_stage2: extra_partials %d out of range", a->extra_partials);
   SVK_REQUIRE((a->mid_o_stride_h % 4) == 0 && (a->mid_o_stride_s % 4) == 0 && (a->mid_o_stride_b % 4) == 0 &&
                   (a->o_stride_b % 4) == 0 && (a->o_stride_h % 4) == 0,
               SVK_ERR_LAYOUT, "svk_flash_decode_stage2: strides must be multiples of 4 elements (16-byte partial rows)");

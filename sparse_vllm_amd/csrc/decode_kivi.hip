@@ -347,7 +347,10 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Hkv = a.num_kv_heads;
   int b, blk;
-  kivi_wg_to_range(b, blk);
+  const int n_extra = WIDE ? a.extra_partials : 0;
+  kivi_wg_to_range_extra(b, blk, n_extra);
+  const int nreg = (int)gridDim.x - n_extra;
+  const int extra_id = blk - nreg;                  // >= 0: one of the extra workgroups of the row
   const int n = lane & 15, kc = lane >> 4;          // MFMA column / k chunk; kc doubles as accumulator row group
   const int dg = n % DW;                            // V word (8 head dims) of this lane
   unsigned char* wl = lds_raw + w * WAVE_BYTES;
@@ -375,10 +378,65 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     start += in0 ? GS - lt0 : 0;
     end_nominal += in1 ? GS - lt1 : 0;
   }
-  const int end = min(len, end_nominal);
-  float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)blk * a.mid_o_stride_s;
-  float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + blk;
-  if (end <= start) {
+  int end = min(len, end_nominal);
+  // WIDE: the raw head [0, H) of a row (sink tokens), its raw tail [S, len) (the not yet quantised residual) and the
+  // ragged quantised piece [S', S) in front of the tail that does not fill a 128-token tile from H are narrow tiles:
+  // 20-25 us of dependent round trips each against 5-6 us for a wide tile, and they used to sit in the first and the
+  // last full workgroups of the row - on the critical path of a one-round launch (1 x 256 k: 73 us against 59 us for a
+  // row without them).  Every regular range is cut to [H, S').  With `extra_partials` = 3 (the caller's workspace has
+  // three more partial slots per row) the three pieces are the ranges of three extra workgroups of the row, dispatched
+  // first, which write the partials nblk_row, nblk_row + 1, nblk_row + 2; regular workgroups past the row's length then
+  // write nothing.  Without them the row's LAST regular workgroup (whose own range is the remainder len mod block_seq)
+  // adds the pieces to its online-softmax state.  Either way still a partition of the row.  H and S come from capped
+  // scans of the raw map (128 / 512 positions): wherever the cuts fall, the narrow paths handle what they find.
+  int head_end = 0, tail_start = len, ragged_start = len;
+  bool owns_ends = false;
+  int slot = blk;
+  if constexpr (WIDE) {
+    const int nblk_row = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq;
+    if (n_extra > 0) {
+      if (extra_id < 0 && blk >= nblk_row) return;            // the extra workgroups own the slots from nblk_row on
+      if (extra_id >= 0) slot = nblk_row + extra_id;
+    } else {
+      owns_ends = blk == nblk_row - 1;
+    }
+    constexpr int kHeadScan = 128, kTailScan = 512;
+    const bool need_s = owns_ends || extra_id >= 0 || end + kT > len - kTailScan;
+    const bool need_h = need_s || start < kHeadScan;
+    const int lm1 = max(len - 1, 0);
+    if (need_h) {
+      const int p0 = 2 * lane, p1 = 2 * lane + 1;
+      const bool q0 = p0 < len && raw_map[min(p0, lm1)] < 0, q1 = p1 < len && raw_map[min(p1, lm1)] < 0;
+      const unsigned long long m0 = __ballot(q0), m1 = __ballot(q1);
+      int first = min(len, kHeadScan);
+      if (m0) first = min(first, 2 * (int)__builtin_ctzll(m0));
+      if (m1) first = min(first, 2 * (int)__builtin_ctzll(m1) + 1);
+      head_end = first;
+    }
+    if (need_s) {
+      const int w0 = max(len - kTailScan, 0);
+      int last = -1;                                   // last quantised position of the window
+#pragma unroll
+      for (int e = 0; e < kTailScan / 64; ++e) {
+        const int p = w0 + e * 64 + lane;
+        const bool qz = p < len && raw_map[min(p, lm1)] < 0;
+        const unsigned long long mk = __ballot(qz);
+        if (mk) last = w0 + e * 64 + 63 - (int)__builtin_clzll(mk);
+      }
+      tail_start = max(last < 0 ? w0 : last + 1, head_end);
+      ragged_start = head_end + ((tail_start - head_end) / kT) * kT;
+    }
+    if (extra_id >= 0) {
+      start = extra_id == 0 ? 0 : (extra_id == 1 ? ragged_start : tail_start);
+      end = extra_id == 0 ? head_end : (extra_id == 1 ? tail_start : len);
+    } else {
+      start = max(start, head_end);
+      end = min(end, ragged_start);
+    }
+  }
+  float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)slot * a.mid_o_stride_s;
+  float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + slot;
+  if (end <= start && !(owns_ends && (head_end > 0 || ragged_start < len))) {
     for (int h = 0; h < G; ++h) {
       float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h;
       for (int d = lane; d < D; d += 64) o[d] = 0.f;
@@ -399,8 +457,9 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     }
   }
   const float sm_scale = rsqrtf((float)D);
-  const bool score_vec = a.attn_score != nullptr && (a.score_stride_b % 4) == 0 && (a.score_stride_h % 4) == 0 &&
-                         (reinterpret_cast<uintptr_t>(a.attn_score) % 16) == 0 && (start % 8) == 0;
+  const bool score_vec_ok = a.attn_score != nullptr && (a.score_stride_b % 4) == 0 && (a.score_stride_h % 4) == 0 &&
+                            (reinterpret_cast<uintptr_t>(a.attn_score) % 16) == 0;
+  bool score_vec = score_vec_ok && (start % 8) == 0;
   float m[4], l[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
@@ -1024,17 +1083,30 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       }
       return first;
     };
-    int t0 = start;
-    while (t0 < end) {
-      const Cls4 c4 = classify4(t0);
-      if (c4.ok) { wide_run(t0, c4); continue; }
-      const int nb = next_block_start(t0);
-      lim = (nb < t0 + kT && nb + kT <= end) ? nb : end;
-      const Cls cls = classify(t0);
-      if (__all(cls.gfast)) tile_body(std::true_type{}, t0, cls);
-      else tile_body(std::false_type{}, t0, cls);
-      t0 = min(t0 + kT, lim);
-      lim = end;
+    // up to three ranges, one copy of the loop body: the workgroup's own range, then (last workgroup of the row) the raw
+    // head and the raw tail
+    const int rs3[3] = {start, 0, ragged_start};
+    const int re3[3] = {end, owns_ends ? head_end : 0, owns_ends ? len : 0};
+#pragma nounroll
+    for (int ri = 0; ri < 3; ++ri) {
+      const int rs = rs3[ri], re = re3[ri];
+      if (re <= rs) continue;
+      start = rs;
+      end = re;
+      lim = re;
+      score_vec = score_vec_ok && (rs % 8) == 0;
+      int t0 = rs;
+      while (t0 < end) {
+        const Cls4 c4 = classify4(t0);
+        if (c4.ok) { wide_run(t0, c4); continue; }
+        const int nb = next_block_start(t0);
+        lim = (nb < t0 + kT && nb + kT <= end) ? nb : end;
+        const Cls cls = classify(t0);
+        if (__all(cls.gfast)) tile_body(std::true_type{}, t0, cls);
+        else tile_body(std::false_type{}, t0, cls);
+        t0 = min(t0 + kT, lim);
+        lim = end;
+      }
     }
   } else {
     // general tiles until an all-fast tile shows up, then the hot loop until one is not, and so on
@@ -1485,6 +1557,16 @@ kivi_stage1_tile128_pf_kernel(const SvkKiviDecodeStage1Args a) {
 #define SVK_ALL_G_CASES SVK_CASE(1) SVK_CASE(2) SVK_CASE(3) SVK_CASE(4) SVK_CASE(5) SVK_CASE(6) SVK_CASE(7) SVK_CASE(8)
 #endif
 
+inline int kivi_variant() {
+  static const int variant = getenv("SVK_KIVI_VARIANT") ? atoi(getenv("SVK_KIVI_VARIANT")) : 5;
+  return variant;
+}
+// does this launch take the wide kernel (variant 5)?
+inline bool kivi_wide_launch(const SvkKiviDecodeStage1Args& a) {
+  return a.head_dim == 128 && a.group_size == 32 && kivi_variant() == 5 && a.num_kv_heads <= 4 && a.block_seq % 128 == 0 &&
+         a.key_param_dtype == SVK_DTYPE_F32;
+}
+
 template <int D>
 int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
   const int G = a.num_q_heads / a.num_kv_heads;
@@ -1495,7 +1577,7 @@ int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
   // <= 4 KV heads, fp32 key parameters, block_seq a multiple of 128; anything else falls through to 2);
   // 2 = register-staged 128-token tiles with 4-byte code loads (round 2's default); 3 = LDS-DMA staged pipeline
   // (decode_kivi_lds.hip); 4 = whole-tile register prefetch - kept for A/B runs
-  static const int variant = getenv("SVK_KIVI_VARIANT") ? atoi(getenv("SVK_KIVI_VARIANT")) : 5;
+  const int variant = kivi_variant();
   if (a.group_size == 32 && variant == 3) return launch_kivi_lds(a, s);
   if (a.group_size == 32 && variant == 4 && a.num_kv_heads <= 4 && a.block_seq % 128 == 0) {
     // whole-tile prefetch, one wave per SIMD (see kivi_stage1_tile128_pf_kernel)
@@ -1515,10 +1597,11 @@ int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
     return check_launch("svk_kivi_decode_stage1");
   }
   if constexpr (D == 128) {
-    if (a.group_size == 32 && variant == 5 && a.num_kv_heads <= 4 && a.block_seq % 128 == 0 && a.key_param_dtype == SVK_DTYPE_F32) {
+    if (kivi_wide_launch(a)) {
       // 128-token tiles, whole-block tiles fetched with 16-byte loads through a per-wave LDS buffer (72.75 KiB per
       // workgroup of 4 KV heads: two workgroups per CU)
       const size_t shm_w = (size_t)a.num_kv_heads * (16 * 136 * 2 + 2 * (D / 32) * 128 * 2 + kXBufBytes);
+      grid.x += a.extra_partials;
       switch (G) {
 #define SVK_CASE(G_)                                                                                          \
   case G_: {                                                                                                  \
@@ -1572,9 +1655,16 @@ int dispatch(const SvkKiviDecodeStage1Args& a, hipStream_t s) {
 }  // namespace
 }  // namespace svk
 
+extern "C" int32_t svk_kivi_decode_stage1_extra_partials(const SvkKiviDecodeStage1Args* a) {
+  return (a != nullptr && svk::kivi_wide_launch(*a)) ? 3 : 0;
+}
+
 extern "C" int svk_kivi_decode_stage1(const SvkKiviDecodeStage1Args* a, svk_stream_t stream) {
   using namespace svk;
   SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_kivi_decode_stage1: null args");
+  SVK_REQUIRE(a->extra_partials == 0 || a->extra_partials == svk_kivi_decode_stage1_extra_partials(a), SVK_ERR_VALUE,
+              "svk_kivi_decode_stage1: extra_partials %d, this launch supports 0 or %d (svk_kivi_decode_stage1_extra_partials)",
+              a->extra_partials, svk_kivi_decode_stage1_extra_partials(a));
   SVK_REQUIRE(a->head_dim == 64 || a->head_dim == 128, SVK_ERR_VALUE, "Unsupported decode head_dim=%d.", a->head_dim);
   SVK_REQUIRE(a->group_size > 0 && a->head_dim % a->group_size == 0, SVK_ERR_VALUE,
               "Invalid KIVI group_size=%d for head_dim=%d.", a->group_size, a->head_dim);

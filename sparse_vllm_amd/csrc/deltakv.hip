@@ -5,6 +5,8 @@
 #include "svk_common.hpp"
 #include "svk_select.hpp"
 
+#include <string.h>
+
 namespace svk {
 namespace {
 
@@ -332,64 +334,79 @@ __global__ void __launch_bounds__(256) token_score_stats_kernel(const SvkDeltakv
   }
   sum = block_allsum(sum, red);
   if (threadIdx.x == 0) {
-    float* ws = a.workspace + (((int64_t)b * a.num_heads + h) * nchunk + c) * 2;
+    float* ws = a.workspace + (((int64_t)b * a.num_heads + h) * (nchunk + 1) + c) * 2;
     ws[0] = mx;
     ws[1] = sum;
   }
 }
 
-// one token per thread; the per-head statistics are combined by one wave per head (lane = chunk) from an LDS copy.
+// the chunk statistics of one (row, head) -> its global (max, sum) in slot `nchunk` of the same workspace row; one wave.
+// (Round 2 combined them at the top of every workgroup of the final kernel: 1024 workgroups each re-did 28 two-pass
+// wave reductions - most of that kernel's 19 us at 262 k tokens.)
+__global__ void __launch_bounds__(64) token_score_combine_kernel(const SvkDeltakvTokenScoresArgs a, int nchunk) {
+  const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  float* ws = a.workspace + ((int64_t)b * a.num_heads + h) * (nchunk + 1) * 2;
+  float mx = -INFINITY;
+  for (int c = lane; c < nchunk; c += 64) mx = fmaxf(mx, ws[2 * c]);
+  mx = wave_allmax(mx);
+  float sum = 0.f;
+  for (int c = lane; c < nchunk; c += 64) {
+    const float m = ws[2 * c];
+    if (m > -INFINITY) sum += ws[2 * c + 1] * expf(m - mx);
+  }
+  sum = wave_allsum(sum);
+  if (lane == 0) { ws[2 * nchunk] = mx; ws[2 * nchunk + 1] = sum; }
+}
+
+// two tokens per thread (256 apart), 16 heads per trip: the kernel is a latency chain per trip (loads -> exp / divide), so
+// it wants few trips with many loads in flight (28 heads: 2 trips of 32 loads)
 __global__ void __launch_bounds__(256) token_score_final_kernel(const SvkDeltakvTokenScoresArgs a, int nchunk) {
-  extern __shared__ float stats[];      // [H][2] global max / sum per head | [H][nchunk][2] staged chunk statistics
+  extern __shared__ float stats[];      // [H][2] global max / sum per head
   const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float* wsl = stats + 2 * a.num_heads;
-  {
-    // all chunk statistics of the row with one coalesced sweep (one wave per head walking global memory paid a
-    // dependent round trip per head: 14 us of the kernel's 28)
-    const float* ws = a.workspace + (int64_t)b * a.num_heads * nchunk * 2;
-    for (int i = threadIdx.x; i < a.num_heads * nchunk * 2; i += 256) wsl[i] = ws[i];
-  }
+  for (int i = threadIdx.x; i < 2 * a.num_heads; i += 256)
+    stats[i] = a.workspace[(((int64_t)b * a.num_heads + (i >> 1)) * (nchunk + 1) + nchunk) * 2 + (i & 1)];
   __syncthreads();
-  for (int h = wv; h < a.num_heads; h += 4) {
-    const float* ws = wsl + (int64_t)h * nchunk * 2;
-    float mx = -INFINITY;
-    for (int c = lane; c < nchunk; c += 64) mx = fmaxf(mx, ws[2 * c]);
-    mx = wave_allmax(mx);
-    float sum = 0.f;
-    for (int c = lane; c < nchunk; c += 64) {
-      const float m = ws[2 * c];
-      if (m > -INFINITY) sum += ws[2 * c + 1] * expf(m - mx);
-    }
-    sum = wave_allsum(sum);
-    if (lane == 0) { stats[2 * h] = mx; stats[2 * h + 1] = sum; }
-  }
-  __syncthreads();
-  // one token per thread: the precise exp + division per (token, head) make this kernel VALU-latency-bound, so it
-  // wants waves (4 per SIMD), not wide lanes; 4 heads per trip with their loads issued before the first exp
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.length) return;
   const int len = min(max(a.candidate_lens[b], 0), a.length - a.candidate_start);
-  const int rel = t - a.candidate_start;
-  float out = a.fill_value;
-  if (rel >= 0 && rel < len) {
-    const float* x = a.raw_scores + (int64_t)b * a.raw_stride_b + t;
-    float best = 0.f;
-    for (int h0 = 0; h0 < a.num_heads; h0 += 4) {
-      float xv[4];
+  const int t0 = blockIdx.x * 512 + threadIdx.x;
+  bool in[2];
+  float best[2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xv[u] = x[(int64_t)min(h0 + u, a.num_heads - 1) * a.raw_stride_h];
+  for (int u = 0; u < 2; ++u) {
+    const int rel = t0 + u * 256 - a.candidate_start;
+    in[u] = t0 + u * 256 < a.length && rel >= 0 && rel < len;
+    best[u] = 0.f;
+  }
+  const float* x = a.raw_scores + (int64_t)b * a.raw_stride_b + t0;
+  if (in[0] || in[1]) {
+    for (int h0 = 0; h0 < a.num_heads; h0 += 16) {
+      float xv[16][2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int h = min(h0 + u, a.num_heads - 1);          // a repeated last head leaves the maximum unchanged
-        best = fmaxf(best, expf(mul_rn(xv[u], a.scale) - stats[2 * h]) / stats[2 * h + 1]);
+      for (int j = 0; j < 16; ++j) {
+        const int h = min(h0 + j, a.num_heads - 1);            // a repeated last head leaves the maximum unchanged
+#pragma unroll
+        for (int u = 0; u < 2; ++u) xv[j][u] = in[u] ? x[(int64_t)h * a.raw_stride_h + u * 256] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int h = min(h0 + j, a.num_heads - 1);
+        const float mx = stats[2 * h], sum = stats[2 * h + 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) best[u] = fmaxf(best[u], expf(mul_rn(xv[j][u], a.scale) - mx) / sum);
       }
     }
-    if (a.round_dtype == SVK_DTYPE_BF16) best = bf16_round(best);
-    else if (a.round_dtype == SVK_DTYPE_F16) best = (float)(_Float16)best;
-    out = best;
   }
-  a.token_scores[(int64_t)b * a.out_stride + t] = out;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = t0 + u * 256;
+    if (t >= a.length) continue;
+    float out = a.fill_value;
+    if (in[u]) {
+      out = best[u];
+      if (a.round_dtype == SVK_DTYPE_BF16) out = bf16_round(out);
+      else if (a.round_dtype == SVK_DTYPE_F16) out = (float)(_Float16)out;
+    }
+    a.token_scores[(int64_t)b * a.out_stride + t] = out;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -526,6 +543,276 @@ __global__ void __launch_bounds__(1024) topk_merge_kernel(const SvkTopkSortedArg
   block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, total, a.k, scratch, [&](int pos, int i) {
     sorted[pos] = in[i];
   }, true);
+  __syncthreads();
+  bitonic_sort_keys(sorted, kpad);
+  for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(sorted[i] & 0xffffffffull);
+}
+
+// ------------------------------------------------------------------------------------
+// long rows (n > kTopkStage), histogram plan: four launches that every CU takes part in instead of `chunks` select
+// workgroups + one merge workgroup (262 k scores, k = 2048: 30 + 34 us -> see DESIGN.md 4.8):
+//   topk_prep_kernel     zeroes the row's histogram and leaves the OR / AND of each 4096-key chunk's valid keys
+//   topk_hist_kernel     4096 keys per workgroup -> 4096-bin histogram (LDS, then global atomics) of the 12 key bits
+//                        below the highest bit on which the valid keys differ (probabilities / bf16-valued scores
+//                        share their leading bits: a fixed top-12 window would put most of the row into one bin)
+//   topk_collect_kernel  every workgroup finds the threshold bin T (the bin that holds the k-th key) from the histogram
+//                        and writes its keys of the bins <= T in ascending index order into its own region + their count
+//   topk_final_kernel    one workgroup per row: the regions concatenated are all candidates in ascending index order
+//                        (k <= m < k + |bin T|), the usual ordered select + bitonic sort finishes
+// Entries at index >= valid_len + k are never looked at: they compare as `masked_value`, and the k masked entries in
+// front of them tie with them at lower indices.  The masked key does not widen the window: a key whose bits above the
+// window are below / above the valid keys' common prefix falls into the first / last bin (still monotone in the key).
+// ------------------------------------------------------------------------------------
+
+constexpr int kTopkHistBits = 12, kTopkHistBins = 1 << kTopkHistBits, kTopkHistChunk = 4096;
+
+__device__ __forceinline__ int topk_effective_n(const SvkTopkSortedArgs& a, int r, int& vlen) {
+  vlen = a.valid_len ? min(max(a.valid_len[r], 0), a.n) : a.n;
+  return (int)min((int64_t)a.n, (int64_t)vlen + a.k);
+}
+
+// workspace: [rows][kTopkHistBins] u32 histograms | [rows][pad4(nwg)] u32 candidate counts | [rows][pad4(2 nwg)] u32 chunk
+// OR / AND | [rows][nwg][kTopkHistChunk] u64 candidates
+struct TopkHistWs {
+  uint32_t* hist;
+  uint32_t* counts;
+  uint32_t* bits;
+  unsigned long long* cand;
+};
+__host__ __device__ __forceinline__ int64_t topk_hist_bytes(int rows, int nwg) {
+  return (int64_t)rows * ((int64_t)sizeof(uint32_t) * (kTopkHistBins + ((nwg + 3) & ~3) + ((2 * nwg + 3) & ~3)) +
+                          (int64_t)sizeof(unsigned long long) * nwg * kTopkHistChunk);
+}
+__device__ __forceinline__ TopkHistWs topk_hist_ws(void* workspace, int rows, int r, int nwg) {
+  uint32_t* base = static_cast<uint32_t*>(workspace);
+  const int cpad = (nwg + 3) & ~3, bpad = (2 * nwg + 3) & ~3;
+  TopkHistWs w;
+  w.hist = base + (int64_t)r * kTopkHistBins;
+  w.counts = base + (int64_t)rows * kTopkHistBins + (int64_t)r * cpad;
+  w.bits = base + (int64_t)rows * (kTopkHistBins + cpad) + (int64_t)r * bpad;
+  w.cand = reinterpret_cast<unsigned long long*>(base + (int64_t)rows * (kTopkHistBins + cpad + bpad)) + (int64_t)r * nwg * kTopkHistChunk;
+  return w;
+}
+
+// the bin window of a row: bin(key) for keys whose bits above the window equal `hi`
+struct TopkWindow {
+  int shift;          // lowest key bit of the window
+  uint32_t hi;        // the valid keys' common bits above the window (key >> (shift + 12)), 0 when the window reaches bit 31
+};
+__device__ __forceinline__ uint32_t topk_bin(const TopkWindow& w, uint32_t key) {
+  const int up = w.shift + kTopkHistBits;
+  const uint32_t hi = up >= 32 ? 0u : key >> up;
+  if (hi < w.hi) return 0u;
+  if (hi > w.hi) return kTopkHistBins - 1;
+  return (key >> w.shift) & (kTopkHistBins - 1);
+}
+// all threads of the workgroup call; `red` = 32 words of LDS
+__device__ __forceinline__ TopkWindow topk_window(const TopkHistWs& ws, int nwg, uint32_t* red) {
+  uint32_t o = 0u, an = 0xffffffffu;
+  for (int c = threadIdx.x; c < nwg; c += blockDim.x) { o |= ws.bits[2 * c]; an &= ws.bits[2 * c + 1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    o |= (uint32_t)__shfl_xor((int)o, off, 64);
+    an &= (uint32_t)__shfl_xor((int)an, off, 64);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) { red[2 * w] = o; red[2 * w + 1] = an; }
+  __syncthreads();
+  o = 0u; an = 0xffffffffu;
+  for (int j = 0; j < nw; ++j) { o |= red[2 * j]; an &= red[2 * j + 1]; }
+  const uint32_t varying = o ^ an;
+  TopkWindow win;
+  const int top = varying ? 31 - __builtin_clz(varying) : kTopkHistBits - 1;
+  win.shift = max(top - (kTopkHistBits - 1), 0);
+  const int up = win.shift + kTopkHistBits;
+  win.hi = up >= 32 ? 0u : an >> up;                 // above the highest varying bit every valid key equals the AND
+  return win;
+}
+
+__device__ __forceinline__ void topk_load4(const SvkTopkSortedArgs& a, int r, int i0, int vlen, uint32_t (&key)[4]) {
+  const float* sc = a.scores + (int64_t)r * a.score_stride;
+  float v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = i0 + u * 1024 + (int)threadIdx.x;
+    v[u] = i < vlen ? sc[i] : a.masked_value;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) key[u] = desc_key(v[u]);
+}
+
+__global__ void __launch_bounds__(1024) topk_prep_kernel(const SvkTopkSortedArgs a, void* workspace, int nwg) {
+  __shared__ uint32_t red[32];
+  const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  const TopkHistWs ws = topk_hist_ws(workspace, (int)gridDim.y, r, nwg);
+  const int per = (kTopkHistBins + nwg - 1) / nwg;               // this workgroup's slice of the histogram to zero
+  for (int j = tid; j < per; j += 1024)
+    if (c * per + j < kTopkHistBins) ws.hist[c * per + j] = 0u;
+  int vlen;
+  const int ne = topk_effective_n(a, r, vlen);
+  const int i0 = c * kTopkHistChunk;
+  uint32_t o = 0u, an = 0xffffffffu;
+  if (i0 < ne) {
+    uint32_t key[4];
+    topk_load4(a, r, i0, vlen, key);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 1024 + tid;
+      if (i < ne && (i < vlen || vlen == 0)) { o |= key[u]; an &= key[u]; }      // masked entries only when nothing is valid
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    o |= (uint32_t)__shfl_xor((int)o, off, 64);
+    an &= (uint32_t)__shfl_xor((int)an, off, 64);
+  }
+  if ((tid & 63) == 0) { red[2 * (tid >> 6)] = o; red[2 * (tid >> 6) + 1] = an; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int j = 1; j < 16; ++j) { o |= red[2 * j]; an &= red[2 * j + 1]; }
+    ws.bits[2 * c] = o;
+    ws.bits[2 * c + 1] = an;
+  }
+}
+
+__global__ void __launch_bounds__(1024) topk_hist_kernel(const SvkTopkSortedArgs a, void* workspace, int nwg) {
+  __shared__ int hist[kTopkHistBins];
+  __shared__ uint32_t red[32];
+  const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  int vlen;
+  const int ne = topk_effective_n(a, r, vlen);
+  const int i0 = c * kTopkHistChunk;
+  if (i0 >= ne) return;
+  const TopkHistWs ws = topk_hist_ws(workspace, (int)gridDim.y, r, nwg);
+  uint32_t key[4];
+  topk_load4(a, r, i0, vlen, key);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) hist[u * 1024 + tid] = 0;
+  const TopkWindow win = topk_window(ws, nwg, red);              // (its barriers also publish the zeroed bins)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) hist_add_aggregated(hist, topk_bin(win, key[u]), i0 + u * 1024 + tid < ne);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int n = hist[u * 1024 + tid];
+    if (n != 0) atomicAdd(&ws.hist[u * 1024 + tid], (uint32_t)n);
+  }
+}
+
+__global__ void __launch_bounds__(1024) topk_collect_kernel(const SvkTopkSortedArgs a, void* workspace, int nwg) {
+  __shared__ int wsum[16];
+  __shared__ uint32_t red[32];
+  __shared__ int s_T;
+  const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int vlen;
+  const int ne = topk_effective_n(a, r, vlen);
+  const TopkHistWs ws = topk_hist_ws(workspace, (int)gridDim.y, r, nwg);
+  const int i0 = c * kTopkHistChunk;
+  if (i0 >= ne) {
+    if (tid == 0) ws.counts[c] = 0u;
+    return;
+  }
+  uint32_t key[4];
+  topk_load4(a, r, i0, vlen, key);
+  const TopkWindow win = topk_window(ws, nwg, red);
+  // threshold bin: thread t owns bins 4t .. 4t+3
+  {
+    const uint4 h = *reinterpret_cast<const uint4*>(ws.hist + tid * 4);
+    const int cb[4] = {(int)h.x, (int)h.y, (int)h.z, (int)h.w};
+    const int local = cb[0] + cb[1] + cb[2] + cb[3];
+    const int incl_w = wave_incl_scan_add(local);
+    if (lane == 63) wsum[w] = incl_w;
+    __syncthreads();
+    int base = 0;
+    for (int j = 0; j < w; ++j) base += wsum[j];
+    const int incl = base + incl_w, excl = incl - local;
+    if (a.k > excl && a.k <= incl) {
+      int run = excl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (a.k > run && a.k <= run + cb[j]) s_T = tid * 4 + j;
+        run += cb[j];
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t T = (uint32_t)s_T;
+  unsigned long long* out = ws.cand + (int64_t)c * kTopkHistChunk;
+  int written = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = i0 + u * 1024 + tid;
+    const bool take = i < ne && topk_bin(win, key[u]) <= T;
+    int total;
+    const int rank = block_excl_count(take, wsum, total);
+    if (take) out[written + rank] = ((unsigned long long)key[u] << 32) | (unsigned)i;
+    written += total;
+  }
+  if (tid == 0) ws.counts[c] = (uint32_t)written;
+}
+
+// one workgroup per row; `lds_cap` = candidates whose keys fit the dynamic LDS next to the sort buffer and the prefix table
+__global__ void __launch_bounds__(1024) topk_final_kernel(const SvkTopkSortedArgs a, int kpad, void* workspace, int nwg, int lds_cap) {
+  __shared__ SelectScratch scratch;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  unsigned long long* sorted = reinterpret_cast<unsigned long long*>(dyn);                    // [kpad]
+  int* prefix = reinterpret_cast<int*>(dyn + sizeof(unsigned long long) * kpad);               // [nwg + 1] exclusive
+  uint32_t* keys = reinterpret_cast<uint32_t*>(prefix + ((nwg + 2) & ~1));                     // [lds_cap]
+  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const TopkHistWs ws = topk_hist_ws(workspace, (int)gridDim.x, r, nwg);
+  // exclusive prefix of the region counts: one coalesced load into LDS (a thread summing straight from memory chains
+  // a round trip per region: 20 us at 64 regions), then every thread adds up what is in front of its regions
+  int* cnt = reinterpret_cast<int*>(keys);           // the key stage is not in use yet
+  for (int c = tid; c < nwg; c += nt) cnt[c] = (int)ws.counts[c];
+  __syncthreads();
+  for (int c = tid; c <= nwg; c += nt) {
+    int run = 0;
+    for (int j = 0; j < c; ++j) run += cnt[j];
+    prefix[c] = run;
+  }
+  for (int i = tid; i < kpad; i += nt) sorted[i] = ~0ull;
+  __syncthreads();
+  const int m = prefix[nwg];
+  auto cand_at = [&](int i) {
+    int lo = 0, hi = nwg;                       // largest c with prefix[c] <= i
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (prefix[mid] <= i) lo = mid; else hi = mid;
+    }
+    return ws.cand[(int64_t)lo * kTopkHistChunk + (i - prefix[lo])];
+  };
+  if (m <= lds_cap) {
+    select_bits_begin(scratch);
+    uint32_t o_bits = 0u, a_bits = 0xffffffffu;
+    for (int j0 = 0; j0 < m; j0 += 4 * nt) {
+      unsigned long long c4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = j0 + u * nt + tid;
+        c4[u] = i < m ? cand_at(i) : ~0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = j0 + u * nt + tid;
+        if (i < m) {
+          const uint32_t key = (uint32_t)(c4[u] >> 32);
+          keys[i] = key;
+          o_bits |= key;
+          a_bits &= key;
+        }
+      }
+    }
+    select_bits_add(scratch, o_bits, a_bits);
+    __syncthreads();
+    block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, m, a.k, scratch, [&](int pos, int i) {
+      sorted[pos] = cand_at(i);
+    }, true);
+  } else {
+    block_select_topk_ordered_keys([&](int i) { return (uint32_t)(cand_at(i) >> 32); }, m, a.k, scratch, [&](int pos, int i) {
+      sorted[pos] = cand_at(i);
+    });
+  }
   __syncthreads();
   bitonic_sort_keys(sorted, kpad);
   for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(sorted[i] & 0xffffffffull);
@@ -679,8 +966,9 @@ extern "C" int svk_deltakv_reconstruct_writeback_batched(const SvkDeltakvReconst
   return launch_reconstruct(first, *b, stream);
 }
 
+// statistics slots per (row, head) of the workspace: one per 4096-element chunk + one for the combined (max, sum)
 extern "C" int svk_deltakv_token_scores_chunks(int32_t length) {
-  return length <= 0 ? 1 : (length + svk::kTokenScoreChunk - 1) / svk::kTokenScoreChunk;
+  return (length <= 0 ? 1 : (length + svk::kTokenScoreChunk - 1) / svk::kTokenScoreChunk) + 1;
 }
 
 extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_stream_t stream) {
@@ -690,23 +978,27 @@ extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_
               "candidate_start must be within score length; got %d for L=%d.", a->candidate_start, a->length);
   if (a->batch <= 0 || a->length <= 0) return SVK_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int nchunk = svk_deltakv_token_scores_chunks(a->length);
+  const int nchunk = svk_deltakv_token_scores_chunks(a->length) - 1;
   hipLaunchKernelGGL(token_score_stats_kernel, dim3(a->batch, a->num_heads, nchunk), dim3(256), 0, s, *a, nchunk);
-  const size_t final_lds = sizeof(float) * 2 * a->num_heads * (1 + nchunk);
-  SVK_REQUIRE(final_lds <= 156 * 1024, SVK_ERR_VALUE, "svk_deltakv_token_scores: %d heads x %d chunks of statistics do not fit LDS",
-              a->num_heads, nchunk);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(token_score_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(token_score_final_kernel, dim3((a->length + 255) / 256, a->batch), dim3(256), final_lds, s, *a, nchunk);
+  hipLaunchKernelGGL(token_score_combine_kernel, dim3(a->batch, a->num_heads), dim3(64), 0, s, *a, nchunk);
+  hipLaunchKernelGGL(token_score_final_kernel, dim3((a->length + 511) / 512, a->batch), dim3(256),
+                     sizeof(float) * 2 * a->num_heads, s, *a, nchunk);
   return check_launch("svk_deltakv_token_scores");
+}
+
+// 1 = histogram plan for rows longer than one LDS stage (default), 0 = per-chunk selects + merge (SVK_TOPK_PLAN=chunks)
+static bool topk_hist_plan() {
+  const char* v = getenv("SVK_TOPK_PLAN");          // read per call: a few ns, and tests flip it
+  return v == nullptr || strcmp(v, "chunks") != 0;
 }
 
 extern "C" int64_t svk_topk_sorted_workspace_bytes(int32_t rows, int32_t n, int32_t k) {
   const int chunks = svk::topk_plan_chunks(n, k);
-  return chunks > 1 ? (int64_t)sizeof(unsigned long long) * rows * chunks * k : 0;
+  const int64_t two_level = chunks > 1 ? (int64_t)sizeof(unsigned long long) * rows * chunks * k : 0;
+  if (n <= svk::kTopkStage) return two_level;
+  const int nwg = (n + svk::kTopkHistChunk - 1) / svk::kTopkHistChunk;
+  const int64_t hist = svk::topk_hist_bytes(rows, nwg);
+  return hist > two_level ? hist : two_level;
 }
 
 extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, void* workspace, svk_stream_t stream) {
@@ -725,7 +1017,22 @@ extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, void* workspace,
     attr_set = true;
   }
   const int chunks = topk_plan_chunks(a->n, a->k);
-  if (chunks == 1) {
+  if (a->n > kTopkStage && workspace != nullptr && topk_hist_plan()) {
+    const int nwg = (a->n + kTopkHistChunk - 1) / kTopkHistChunk;
+    static bool final_attr = false;
+    if (!final_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+      final_attr = true;
+    }
+    hipLaunchKernelGGL(topk_prep_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
+    hipLaunchKernelGGL(topk_hist_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
+    hipLaunchKernelGGL(topk_collect_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
+    const int prefix_ints = (nwg + 2) & ~1;
+    const int cap = kTopkStage;
+    hipLaunchKernelGGL(topk_final_kernel, dim3(a->rows), dim3(1024),
+                       sizeof(unsigned long long) * kpad + sizeof(int) * (size_t)prefix_ints + sizeof(uint32_t) * (size_t)cap, s, *a,
+                       kpad, workspace, nwg, cap);
+  } else if (chunks == 1) {
     hipLaunchKernelGGL(topk_stage_kernel, dim3(1, a->rows), dim3(a->n > 2048 ? 1024 : 256),
                        sizeof(unsigned long long) * kpad + sizeof(uint32_t) * (size_t)a->n, s, *a, kpad, a->n, 1,
                        static_cast<unsigned long long*>(nullptr));

@@ -130,4 +130,14 @@ __device__ __forceinline__ void kivi_wg_to_range(int& b, int& blk) {
   else { const int r = id - 2 * B; b = r / (nblk - 2); blk = 1 + r % (nblk - 2); }
 }
 
+// the same with `n_extra` trailing block indices per row that are dispatched before everything else (the wide KIVI
+// kernel's latency-bound raw / ragged pieces)
+__device__ __forceinline__ void kivi_wg_to_range_extra(int& b, int& blk, int n_extra) {
+  if (n_extra <= 0) { kivi_wg_to_range(b, blk); return; }
+  const int nblk = gridDim.x, B = gridDim.y, nreg = nblk - n_extra;
+  const int id = blockIdx.x + nblk * blockIdx.y;
+  if (id < B * n_extra) { b = id / n_extra; blk = nreg + id % n_extra; }
+  else { const int r = id - B * n_extra; b = r / nreg; blk = r % nreg; }
+}
+
 }  // namespace svk

@@ -833,10 +833,20 @@ class DeltaKVCacheManager(CacheManager):
         key = tuple((t.data_ptr(), t._version) for p in parts for t in (p[0].weight, p[0].bias, p[1].weight, p[1].bias))
         st = self.__dict__.get("_up_stack")
         if st is None or st[0] != key:
+            # the second Linear's bias rides in the GEMM as one more input feature: W2' = [W2 | b2 | 0 ...] against a hidden
+            # row [h | 1 | 0 ...] (kRecondPad columns, so K stays a multiple of the library's 64-wide tiles) - baddbmm would
+            # first broadcast-copy the bias into the whole [layers, n, out] output (12 us per launch at 2048 tokens)
+            w2 = torch.stack([p[1].weight.detach() for p in parts])
+            b2 = torch.stack([p[1].bias.detach() for p in parts])
+            w2p = torch.zeros((w2.shape[0], w2.shape[1], w2.shape[2] + self._RECON_PAD), dtype=w2.dtype, device=w2.device)
+            w2p[:, :, :w2.shape[2]] = w2
+            w2p[:, :, w2.shape[2]] = b2
             st = (key, (torch.stack([p[0].weight.detach() for p in parts]).contiguous(), torch.stack([p[0].bias.detach() for p in parts]).contiguous(),
-                        torch.stack([p[1].weight.detach() for p in parts]).contiguous(), torch.stack([p[1].bias.detach() for p in parts]).contiguous()))
+                        w2p.contiguous(), b2.contiguous()))
             self._up_stack = st
         return st[1]
+
+    _RECON_PAD = 64
 
     def _reconstruct_layers_batched(self, l_idxs, stack, recon_pos, recon_latent, recon_out_slot):
         """Residual load + reconstruction of consecutive sparse layers `l_idxs` (same plan) in three launches."""
@@ -845,16 +855,19 @@ class DeltaKVCacheManager(CacheManager):
         assert list(l_idxs) == list(range(l0, l1))
         k, n = l1 - l0, int(recon_latent.numel())
         store = self.__dict__.setdefault("_recon_batch_bufs", {})
-        cur = store.get("b")
-        if cur is None or cur[0].shape[0] < k or cur[0].shape[1] < n:
-            cur = (torch.empty((max(k, self._recon_sub_batch()), n, int(w1.shape[1])), dtype=torch.bfloat16, device=self.device),
-                   torch.empty((max(k, self._recon_sub_batch()), n, int(w2.shape[1])), dtype=torch.bfloat16, device=self.device))
-            store["b"] = cur
-        h, delta = cur[0][:k, :n], cur[1][:k, :n]
+        cur = store.get(n)                     # one buffer pair per token count, never freed while the side stream may use it
+        hid = int(w1.shape[1])
+        if cur is None or cur[0].shape[0] < k:
+            kb = max(k, self._recon_sub_batch())
+            hbuf = torch.zeros((kb, n, hid + self._RECON_PAD), dtype=torch.bfloat16, device=self.device)
+            hbuf[:, :, hid] = 1.0                                   # the bias feature; the kernel below writes [:, :, :hid] only
+            cur = (hbuf, torch.empty((kb, n, int(w2.shape[1])), dtype=torch.bfloat16, device=self.device))
+            store[n] = cur
+        hp, delta = cur[0][:k], cur[1][:k]
         dk.dequant_linear_act(self.deltakv_latent_cache[l0:l1], self.deltakv_latent_scales[l0:l1], self.deltakv_latent_mins[l0:l1],
                               self._quant_group_size(), w1[l0:l1], b1[l0:l1], activation="gelu", row_index=recon_latent,
-                              out=h, layers=True)
-        torch.baddbmm(b2[l0:l1, None, :], h, w2[l0:l1].transpose(1, 2), out=delta)
+                              out=hp[:, :, :hid], layers=True)
+        torch.bmm(hp, w2[l0:l1].transpose(1, 2), out=delta)
         knw = self.deltakv_k_norm_weight
         dk.deltakv_reconstruct_writeback_layers(
             delta, self.deltakv_latent_to_full_slots[l0:l1], recon_latent, self.deltakv_slot_to_pos, recon_out_slot, recon_pos,

@@ -69,6 +69,7 @@ class SparseController:
         # (139.7 us vs 93.5 + 9.3 us at B=64: one workgroup per row cannot hide the finish step's L2 round trips), so it
         # is opt-in; kept because it halves the launches for callers that are launch-bound.
         self._fused_h2o_layer = os.environ.get("SVK_H2O_FUSED_LAYER", "0") == "1"
+        self._obs_score_refill = os.environ.get("SVK_DELTAKV_SCORE_REFILL", "0") == "1"
         self._layer_score_finished = [False] * self.num_layers
         # MI355X: the per-layer H2O score epilogue (scale + softmax + accumulate) has no consumer until the step's
         # eviction check, so it may run on a side stream beside the next layers (joined in `join_side_streams`)
@@ -197,11 +198,17 @@ class SparseController:
             raise RuntimeError("Decode attention score buffer requires positive shape: "
                                f"layer={layer_idx} batch={batch_size} heads={num_heads} max_len={max_len}.")
         buf = self._decode_attn_score_buffers.get(int(layer_idx))
-        if buf is None or buf.shape[0] < batch_size or buf.shape[1] < num_heads or buf.shape[2] < max_len:
+        fresh = buf is None or buf.shape[0] < batch_size or buf.shape[1] < num_heads or buf.shape[2] < max_len
+        if fresh:
             buf = torch.empty((batch_size, num_heads, max_len), dtype=torch.float32, device=self.device)
             self._decode_attn_score_buffers[int(layer_idx)] = buf
         view = buf[:batch_size, :num_heads, :max_len]
-        h2o_ops.fill_f32(view, fill_value) if view.is_contiguous() else view.fill_(fill_value)
+        # MI355X: the per-step refill is 29 MB per observation layer at 256 k tokens and nothing reads what it writes -
+        # the attention launch overwrites every position below the row's length and `_decode_softmax_token_scores`
+        # masks by the candidate lengths (never past the length) - so only a new buffer is filled.  Positions at or
+        # beyond a row's length are then unspecified instead of -1e20; SVK_DELTAKV_SCORE_REFILL=1 restores the refill.
+        if fresh or self._obs_score_refill:
+            h2o_ops.fill_f32(view, fill_value) if view.is_contiguous() else view.fill_(fill_value)
         return view
 
     def _h2o_decode_score_width(self, layer_indices) -> int:

@@ -410,10 +410,13 @@ def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_
                                         key_packed, key_scales, key_mins, value_packed, value_scales, value_mins,
                                         req_indices, context_lens, max_len_in_batch: int, mid_out, mid_out_logsumexp,
                                         group_size: int, block_seq: int, block_n: int = 16, num_warps: int = 2,
-                                        num_stages: int = 3, attn_score=None):
+                                        num_stages: int = 3, attn_score=None, extra_partial_slots: int = 0) -> int:
     """Decode stage 1 over KIVI-int4 blocks + raw tail (reference wrapper deltakv_kernels.py:973-1142; same
     argument names and ValueErrors).  block_n / num_warps / num_stages are Triton launch knobs: validated,
-    otherwise unused (the HIP kernel tiles 32 tokens per wave)."""
+    otherwise unused (the HIP kernel tiles 32 tokens per wave).
+    MI355X: `extra_partial_slots` = partial slots of mid_out / mid_out_logsumexp beyond ceil(max_len / block_seq) the
+    launch may use for the raw / ragged pieces of every row; returns how many it used (0 or 3) - the `extra_partials`
+    stage 2 has to merge."""
     for t in (q, raw_k, raw_v, raw_slots_map, kivi_block_slots_map, kivi_block_start_pos, key_packed, key_scales,
               key_mins, value_packed, value_scales, value_mins, req_indices, context_lens, mid_out, mid_out_logsumexp):
         assert t.is_cuda
@@ -449,7 +452,7 @@ def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_
                          f"got block_n={block_n}, block_seq={block_seq}.")
     max_len_in_batch = int(max_len_in_batch)
     if max_len_in_batch <= 0:
-        return
+        return 0
     if max_len_in_batch > int(raw_slots_map.shape[1]):
         raise ValueError("Full-layer KIVI max_len_in_batch exceeds map width: "
                          f"max_len={max_len_in_batch} width={int(raw_slots_map.shape[1])}.")
@@ -493,8 +496,14 @@ def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_
         score_stride_h=attn_score.stride(1) if attn_score is not None else 0,
         batch=batch, num_q_heads=int(q.shape[1]), num_kv_heads=num_kv_heads, head_dim=head_dim,
         max_len_in_batch=max_len_in_batch, block_seq=block_seq, group_size=group_size,
-        key_param_dtype=_dt(key_scales))
+        key_param_dtype=_dt(key_scales), extra_partials=0)
+    extra = int(lib.svk_kivi_decode_stage1_extra_partials(C.byref(a))) if int(extra_partial_slots) > 0 else 0
+    nblk = (max_len_in_batch + block_seq - 1) // block_seq
+    if extra > int(extra_partial_slots) or int(mid_out.shape[2]) < nblk + extra or int(mid_out_logsumexp.shape[2]) < nblk + extra:
+        extra = 0
+    a.extra_partials = extra
     _lib.check(lib.svk_kivi_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
+    return extra
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -53,8 +53,9 @@ class HipAttentionBackend:
             md = payload.metadata
             if md is None:
                 raise RuntimeError("full_layer_kivi decode view is missing metadata.")
+            nblk = (int(max_len_in_batch) + int(block_seq) - 1) // int(block_seq)
             with profiler.record("decode_attention_stage1_kivi"):
-                full_layer_kivi_flash_decode_stage1(
+                extra = full_layer_kivi_flash_decode_stage1(
                     q=q, raw_k=payload.k_cache, raw_v=payload.v_cache, raw_slots_map=meta.active_slots,
                     kivi_block_slots_map=md["kivi_block_slots_map"], kivi_block_start_pos=md["kivi_block_start_pos"],
                     key_packed=md["key_packed"], key_scales=md["key_scales"], key_mins=md["key_mins"],
@@ -62,9 +63,10 @@ class HipAttentionBackend:
                     req_indices=meta.req_indices, context_lens=meta.context_lens, max_len_in_batch=max_len_in_batch,
                     mid_out=mid_o, mid_out_logsumexp=mid_o_logexpsum, group_size=int(md["group_size"]),
                     block_seq=block_seq, block_n=int(md.get("block_n", 16)), num_warps=int(md.get("num_warps", 2)),
-                    num_stages=int(md.get("num_stages", 3)), attn_score=meta.attn_score)
+                    num_stages=int(md.get("num_stages", 3)), attn_score=meta.attn_score,
+                    extra_partial_slots=max(0, int(mid_o.shape[2]) - nblk))
             o = torch.empty_like(q)
-            flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
+            flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq, extra_partials=extra)
             return o
         if new_kv is not None and payload.backend != "dense":
             raise RuntimeError("the fused decode store is only wired into the dense stage-1 launch")
@@ -177,6 +179,8 @@ class Attention(torch.nn.Module):
                     block_seq=block_seq, max_context_len=max_len_in_batch,
                     requires_attention_scores=decode_meta.attn_score is not None, batch_size=batch_size)
             num_seq_blocks = (max_len_in_batch + block_seq - 1) // block_seq
+            if decode_view.payload.backend == "full_layer_kivi":
+                num_seq_blocks += 3           # room for the wide KIVI launch's extra partials (raw / ragged pieces of a row)
             mid_o, mid_lse = get_decode_workspace(context, batch_size, self.num_heads, num_seq_blocks, self.head_dim,
                                                   q.device)
             finish = getattr(sparse_controller, "fused_decode_finish", None)

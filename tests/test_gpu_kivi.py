@@ -223,6 +223,78 @@ def test_kivi_stage1_irregular_maps(block_seq):
     assert (got[2][0, :, 8 + 9 * G: 8 + 9 * G + 3] == np.float32(-1e20)).all()
 
 
+def run_gpu_extra(inp_bits, maps, *, max_len, G, block_seq, score_shape=None):
+    """The launch with three spare partial slots per row + the product's stage 2 told about them: merged bf16 output."""
+    from sparse_vllm_amd.kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1
+    from sparse_vllm_amd.kernels.flash_decoding_stage2 import flash_decode_stage2
+    q = bf(inp_bits["q"])
+    B, Hq, D = q.shape
+    nblk = (max_len + block_seq - 1) // block_seq
+    mid = torch.full((B, Hq, nblk + 3, D), 7.0, dtype=torch.float32, device=dev())
+    lse = torch.full((B, Hq, nblk + 3), 7.0, dtype=torch.float32, device=dev())
+    score = None if score_shape is None else torch.full(score_shape, -1e20, dtype=torch.float32, device=dev())
+    extra = full_layer_kivi_flash_decode_stage1(
+        q=q, raw_k=bf(inp_bits["raw_k"]), raw_v=bf(inp_bits["raw_v"]), raw_slots_map=t(maps["raw_map"]),
+        kivi_block_slots_map=t(maps["blk_map"]), kivi_block_start_pos=t(maps["blk_start"]),
+        key_packed=t(inp_bits["key_packed"]), key_scales=kparam(inp_bits["key_scales"]), key_mins=kparam(inp_bits["key_mins"]),
+        value_packed=t(inp_bits["value_packed"]), value_scales=bf(inp_bits["value_scales"]),
+        value_mins=bf(inp_bits["value_mins"]), req_indices=t(maps["req"]), context_lens=t(maps["lens"]),
+        max_len_in_batch=max_len, mid_out=mid, mid_out_logsumexp=lse, group_size=G, block_seq=block_seq,
+        attn_score=score, extra_partial_slots=3)
+    o = torch.full((B, Hq, D), 7.0, dtype=torch.bfloat16, device=dev())
+    flash_decode_stage2(mid, lse, t(maps["lens"]), o, block_seq, extra_partials=extra)
+    torch.cuda.synchronize()
+    return extra, o.float().cpu().numpy(), mid.cpu().numpy(), lse.cpu().numpy(), None if score is None else score.cpu().numpy()
+
+
+@pytest.mark.parametrize("sink,raw_tail,lens,block_seq,irregular", [
+    (8, 40, [1500, 777, 136, 8], 512, False),
+    (32, 64, [1500, 1181], 256, False),
+    (0, 0, [1024, 515], 256, False),
+    (4, 21, [700, 300], 128, False),
+    (8, 200, [1000, 420], 1024, False),
+    (8, 600, [3000, 2100, 5], 1024, False),      # raw tail longer than the tail scan window
+    (8, 40, [4100, 2048 + 8 + 40, 1100], 1024, False),
+    (8, 40, [1500, 1100, 700], 256, True),
+    (200, 40, [1500, 900], 128, False),          # raw head longer than the head scan window
+])
+def test_kivi_stage1_extra_partials(sink, raw_tail, lens, block_seq, irregular):
+    """With three spare partial slots per row the wide launch hands the raw sink tokens, the raw residual tail and the
+    ragged quantised piece in front of it to extra workgroups (partials nblk_row .. nblk_row + 2) and leaves the
+    regular partials past a row's length unwritten; stage 2 merges the extras.  Same merged output (against the oracle's
+    partials merged by the oracle, bf16 output tolerance) and the same position-indexed raw scores as the plain launch."""
+    from oracle import decode_attention as oda
+    rng = np.random.default_rng(sink * 1000 + raw_tail + block_seq)
+    Hq, Hkv, D, G = 28, 4, 128, 32
+    B = len(lens)
+    bits, maps, max_len = make_case(rng, B=B, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=lens, rows=B + 1, raw_tail=raw_tail,
+                                     sink=sink, key_f32=True)
+    if irregular:
+        raw_map, blk_map, blk_start = maps["raw_map"], maps["blk_map"], maps["blk_start"]
+        r0, r1 = int(maps["req"][0]), int(maps["req"][1])
+        p = 8 + 5 * G + 11
+        raw_map[r0, p] = int(raw_map.max()) - 3
+        blk_map[r0, p] = -1
+        blk_map[r1, 8 + 3 * G + 16: 8 + 4 * G] = -1
+    shape = (B, Hq, max_len)
+    extra, o, mid, lse, score = run_gpu_extra(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
+    assert extra == 3
+    mid_r, lse_r, score_r = run_oracle(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
+    o_r = oda.flash_decode_stage2(mid_r, lse_r, np.asarray(lens, np.int32), block_seq)
+    np.testing.assert_allclose(o, bf16_round(o_r), rtol=ATTN_TOL, atol=ATTN_TOL)
+    np.testing.assert_allclose(score, score_r, rtol=1e-5, atol=1e-4)
+    # the plain launch of the same inputs: same scores bit for bit (same tiles, only their workgroup differs)
+    _, _, score_plain = run_gpu(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
+    for b, n in enumerate(lens):
+        nb_row = (n + block_seq - 1) // block_seq
+        assert np.isfinite(mid[b][:, :nb_row + 3]).all()                        # regular + extra partials written
+        assert (mid[b][:, nb_row + 3:] == 7.0).all()                            # nothing past them
+        np.testing.assert_array_equal(score[b, :, :n], score_plain[b, :, :n])
+    # launches the wide kernel does not serve take no extras (bf16 key parameters here)
+    bits16, maps16, ml16 = make_case(rng, B=1, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=[300], rows=2, raw_tail=40, sink=8, key_f32=False)
+    assert run_gpu_extra(bits16, maps16, max_len=ml16, G=G, block_seq=128)[0] == 0
+
+
 def test_kivi_stage1_all_raw_matches_plain_stage1():
     """With no KIVI block the kernel is the ordinary slot-table decode: compare with svk_flash_decode_stage1.
     The two kernels tile the row differently (128 vs 32 tokens per online-softmax step), so P is rounded to bf16

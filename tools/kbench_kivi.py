@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--block-seqs", default="256,512,1024")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--score", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="no spare partial slots: the launch without extra workgroups")
     ap.add_argument("--sink", type=int, default=8)
     ap.add_argument("--tail", type=int, default=48)
     ap.add_argument("--heads", default="28,4", help="query heads, KV heads of the rank (7,1 = one TP=4 rank of Qwen2.5-7B)")
@@ -61,15 +62,16 @@ def main():
         score = torch.empty(B, Hq, L, device=d) if args.score else None
         for bs in [int(x) for x in args.block_seqs.split(",")]:
             nblk = (L + bs - 1) // bs
-            mid = torch.empty(B, Hq, nblk, D, device=d)
-            lse = torch.empty(B, Hq, nblk, device=d)
+            spare = 0 if args.no_extra else 3
+            mid = torch.empty(B, Hq, nblk + spare, D, device=d)
+            lse = torch.empty(B, Hq, nblk + spare, device=d)
 
             def run():
                 full_layer_kivi_flash_decode_stage1(
                     q=q, raw_k=raw_k, raw_v=raw_v, raw_slots_map=raw_map, kivi_block_slots_map=blk_map,
                     kivi_block_start_pos=blk_start, key_packed=kp, key_scales=ks, key_mins=km, value_packed=vp,
                     value_scales=vs, value_mins=vm, req_indices=req, context_lens=lens, max_len_in_batch=L, mid_out=mid,
-                    mid_out_logsumexp=lse, group_size=G, block_seq=bs, attn_score=score)
+                    mid_out_logsumexp=lse, group_size=G, block_seq=bs, attn_score=score, extra_partial_slots=spare)
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
@@ -82,7 +84,7 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / args.iters
             # per token: Hkv x (64 B K codes + 64 B V codes + 32 B K scale/min + 16 B V scale/min) + 8 B of slot maps
             byts = B * L * (Hkv * 176 + 8 + (4 * Hq if args.score else 0))
-            print(f"kivi stage1 B={B} L={L} block_seq={bs:5d} score={int(args.score)}: {us:9.1f} us  {byts / us / 1e6:7.3f} TB/s "
+            print(f"kivi stage1 B={B} L={L} block_seq={bs:5d} score={int(args.score)} extra={spare}: {us:9.1f} us  {byts / us / 1e6:7.3f} TB/s "
                   f"({byts / us / 1e6 / 8.0 * 100:5.1f}% of 8 TB/s)", flush=True)
 
 
