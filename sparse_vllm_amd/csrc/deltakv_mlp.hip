@@ -250,6 +250,137 @@ __global__ void __launch_bounds__(256) dequant_linear_act_kernel(const SvkDequan
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K = 256, group 32, bf16 scales (the published compressors): 64 rows x 256 features per workgroup.  The kernel above
+// gives every 64-feature tile its own workgroup, so a launch of [3 layers, 2048 rows, 2048 features] is 1536 short
+// workgroups in three rounds, each paying the row-index -> codes round trips and dequantising the same 128 latent rows
+// 32 times over (39 us for 6.4 GFLOP).  Here the A tile is dequantised once per 256 features, the weights of the next
+// 64-feature sub-tile are fetched under the MFMAs / GELU epilogue of the current one, and the 768 workgroups of that
+// launch are resident together (43 KiB of LDS, three per CU).
+// ------------------------------------------------------------------------------------------------
+constexpr int kM2 = 64, kSub = 64, kNSub = 4, kLdx2 = 256 + 8, kLdy2 = kSub + 8;
+
+template <bool GELU>
+__global__ void __launch_bounds__(256) dequant_linear_act_k256_kernel(const SvkDequantLinearArgs a_in, const SvkDequantLinearBatch lb) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];      // [kM2][kLdx2] bf16 | 2 x [kM2][kLdy2] bf16
+  SvkDequantLinearArgs a = a_in;
+  if (gridDim.z > 1) {
+    const int64_t z = blockIdx.z;
+    a.packed += z * lb.packed_stride_batch;
+    a.scale = reinterpret_cast<const uint16_t*>(a.scale) + z * lb.scale_stride_batch;
+    a.mn = reinterpret_cast<const uint16_t*>(a.mn) + z * lb.scale_stride_batch;
+    a.weight += z * lb.weight_stride_batch;
+    if (a.bias != nullptr) a.bias += z * lb.bias_stride_batch;
+    a.out += z * lb.out_stride_batch;
+  }
+  constexpr int K = 256, KS = K / 32;
+  const int m0 = blockIdx.y * kM2, nb0 = blockIdx.x * (kSub * kNSub);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, kc = lane >> 4;
+  uint16_t* ys = xs + kM2 * kLdx2;
+  auto load_w = [&](int ns, uint4 (&wf)[KS]) {
+    const int n = min(nb0 + ns * kSub + w * 16 + fr, a.n - 1);            // clamped: features past N are never stored
+    const uint16_t* wr = a.weight + (int64_t)n * a.weight_stride + kc * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(wr + ks * 32);
+  };
+  uint4 wa[KS], wb[KS];
+  load_w(0, wa);
+  // ---- dequantise 64 rows: four threads per row, 64 codes (two groups) each
+  {
+    const int r = tid >> 2, qd = tid & 3;
+    const int row = m0 + r;
+    uint16_t* dst = xs + r * kLdx2 + qd * 64;
+    if (row < a.rows) {
+      const int64_t src = a.row_index ? max(a.row_index[row], 0) : row;
+      const int32_t* pw = a.packed + src * a.packed_stride + qd * 8;
+      const uint4 c0 = *reinterpret_cast<const uint4*>(pw), c1 = *reinterpret_cast<const uint4*>(pw + 4);
+      const uint32_t sv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.scale) + src * a.scale_stride + qd * 2);
+      const uint32_t mv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.mn) + src * a.scale_stride + qd * 2);
+      const float scs[2] = {bf16_lo(sv), bf16_hi(sv)}, mns[2] = {bf16_lo(mv), bf16_hi(mv)};
+      const uint32_t wd[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float sc = scs[u >> 2], mn = mns[u >> 2];
+        uint32_t p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float q0 = (float)((wd[u] >> (8 * e)) & 15u), q1 = (float)((wd[u] >> (8 * e + 4)) & 15u);
+          p[e] = pack2_bf16(add_rn(mul_rn(q0, sc), mn), add_rn(mul_rn(q1, sc), mn));
+        }
+        *reinterpret_cast<uint4*>(dst + u * 8) = make_uint4(p[0], p[1], p[2], p[3]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) *reinterpret_cast<uint4*>(dst + u * 8) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  __syncthreads();
+  const uint16_t* xrow = xs + fr * kLdx2 + kc * 8;
+  const bool vec_out = (a.out_stride % 8) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16) == 0;
+  auto sub_tile = [&](int ns, const uint4 (&wf)[KS]) {
+    const int n0 = nb0 + ns * kSub;
+    if (n0 >= a.n) return;                                     // (uniform over the workgroup)
+    f32x4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8_t bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xrow + j * 16 * kLdx2 + ks * 32));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[ks]), bfr[j], acc[j], 0, 0, 0);
+    }
+    // lane (token fr of tile j, features w*16 + kc*4 + r): bias, bf16 rounding of the Linear output, GELU, bf16
+    const int nl = w * 16 + kc * 4;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n0 + nl + r < a.n) bias[r] = __builtin_bit_cast(float, (uint32_t)a.bias[n0 + nl + r] << 16);
+    }
+    uint16_t* yb = ys + (ns & 1) * (kM2 * kLdy2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float y[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = bf16_round(acc[j][r] + bias[r]);
+        if (GELU) v = mul_rn(mul_rn(v, 0.5f), add_rn(1.0f, erf_fast(mul_rn(v, 0.70710678118654752440f))));
+        y[r] = v;
+      }
+      *reinterpret_cast<uint2*>(yb + (j * 16 + fr) * kLdy2 + nl) = make_uint2(pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3]));
+    }
+    __syncthreads();
+    // 64 rows x 128 B: two 16-byte segments per thread
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + u * 256;
+      const int r = c >> 3, seg = c & 7;
+      const int row = m0 + r, n = n0 + seg * 8;
+      if (row >= a.rows || n >= a.n) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(yb + r * kLdy2 + seg * 8);
+      uint16_t* o = a.out + (int64_t)row * a.out_stride + n;
+      if (vec_out && n + 8 <= a.n) {
+        *reinterpret_cast<uint4*>(o) = v;
+      } else {
+        const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+        for (int e = 0; e < 8 && n + e < a.n; ++e) o[e] = (uint16_t)(wd[e >> 1] >> ((e & 1) * 16));
+      }
+    }
+  };
+  // weights of sub-tile s+1 in flight under sub-tile s (two register sets, statically named)
+  load_w(1, wb);
+  sub_tile(0, wa);
+  load_w(2, wa);
+  sub_tile(1, wb);
+  load_w(3, wb);
+  sub_tile(2, wa);
+  sub_tile(3, wb);
+}
+
 }  // namespace
 }  // namespace svk
 
@@ -279,6 +410,17 @@ int launch_dequant_linear_act(const SvkDequantLinearArgs* a, const SvkDequantLin
     attr_set = true;
   }
   const dim3 grid((a->n + kBN - 1) / kBN, (a->rows + kBM - 1) / kBM, lb.n_batch), block(256);
+  static const bool wide_tiles = getenv("SVK_DQL_WIDE") == nullptr || atoi(getenv("SVK_DQL_WIDE")) != 0;
+  if (wide_tiles && a->k == 256 && a->group_size == 32 && a->scale_dtype == SVK_DTYPE_BF16 && (a->packed_stride % 4) == 0 &&
+      (reinterpret_cast<uintptr_t>(a->packed) % 16) == 0 && (a->scale_stride % 2) == 0 &&
+      (reinterpret_cast<uintptr_t>(a->scale) % 4) == 0 && (reinterpret_cast<uintptr_t>(a->mn) % 4) == 0 &&
+      (lb.n_batch == 1 || lb.scale_stride_batch % 2 == 0)) {
+    const dim3 grid2((a->n + kSub * kNSub - 1) / (kSub * kNSub), (a->rows + kM2 - 1) / kM2, lb.n_batch);
+    const size_t shm2 = sizeof(uint16_t) * (kM2 * kLdx2 + 2 * kM2 * kLdy2);
+    if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_k256_kernel<true>), grid2, block, shm2, s, *a, lb);
+    else hipLaunchKernelGGL((dequant_linear_act_k256_kernel<false>), grid2, block, shm2, s, *a, lb);
+    return check_launch(who);
+  }
   if (a->k == 256 && (a->packed_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(a->packed) % 16) == 0) {
     // the latent width of the published compressors: fully unrolled
     if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_kernel<true, 256>), grid, block, shm, s, *a, lb);

@@ -802,8 +802,11 @@ class DeltaKVCacheManager(CacheManager):
                 # sub-batches of `sub` consecutive layers: one dequant + Linear + GELU launch, one batched GEMM and one
                 # reconstruct launch per sub-batch instead of three launches per layer (48 -> ~28 us per layer), small
                 # enough that the main stream can start on the group's first layers while the rest is still in flight
-                for c0 in range(0, len(layers), sub):
-                    chunk = layers[c0: c0 + sub]
+                sizes, c0, ci = self._recon_sub_batches(), 0, 0
+                while c0 < len(layers):
+                    n_c = sizes[min(ci, len(sizes) - 1)]
+                    chunk = layers[c0: c0 + n_c]
+                    c0, ci = c0 + n_c, ci + 1
                     self._reconstruct_layers_batched([self.deltakv_layer_to_idx[l] for l in chunk], stack, recon_pos,
                                                      recon_latent, recon_out_slot)
                     for l in chunk:
@@ -818,9 +821,15 @@ class DeltaKVCacheManager(CacheManager):
         return ev
 
     @staticmethod
-    def _recon_sub_batch() -> int:
+    def _recon_sub_batches() -> list[int]:
+        """Layers per look-ahead launch group: "a,b,c" = a layers first, then b, then c, c, ... (the last value repeats)."""
         import os
-        return max(1, int(os.environ.get("SVK_DELTAKV_RECON_BATCH", "3")))
+        vals = [max(1, int(x)) for x in os.environ.get("SVK_DELTAKV_RECON_BATCH", "2").split(",") if x.strip()]
+        return vals or [2]
+
+    @classmethod
+    def _recon_sub_batch(cls) -> int:
+        return max(cls._recon_sub_batches())
 
     def _stacked_up_weights(self):
         """(W1 [Ls, hid, K], b1 [Ls, hid], W2 [Ls, out, hid], b2 [Ls, out]) of the sparse layers' compress_up modules as

@@ -355,7 +355,8 @@ def test_materialize_with_riding_raw_store_equals_store_then_materialize(cfg):
 
 
 @pytest.mark.parametrize("shape", [dict(rows=300, src=157, K=256, N=2048), dict(rows=129, src=129, K=64, N=200),
-                                   dict(rows=5, src=9, K=512, N=136), dict(rows=260, src=33, K=32, N=128)])
+                                   dict(rows=5, src=9, K=512, N=136), dict(rows=260, src=33, K=32, N=128),
+                                   dict(rows=70, src=50, K=256, N=204), dict(rows=64, src=64, K=256, N=520)])
 @pytest.mark.parametrize("act", ["gelu", "none"])
 def test_dequant_linear_act_matches_separate_ops(shape, act):
     """Fused residual load (int4 dequant + first Linear + erf-GELU of compress_up) against the numpy restatement of
