@@ -256,11 +256,49 @@ __device__ __forceinline__ void block_select_topk_ordered_owned(const uint32_t (
   const uint32_t varying = S.or_bits ^ all_and;
   uint32_t prefix = all_and;
   int kk = k;
-  select_radix_passes_sweep([&](int shift, uint32_t dmask, uint32_t himask, uint32_t pfx) {
+  auto sweep = [&](int shift, uint32_t dmask, uint32_t himask, uint32_t pfx) {
 #pragma unroll
     for (int j = 0; j < CH; ++j)
       if (j < per) hist_add_aggregated(S.hist, (key[j] >> shift) & dmask, base + j < n && (key[j] & himask) == (pfx & himask));
-  }, S, prefix, kk, varying ? 31 - __builtin_clz(varying) : -1, varying ? __builtin_ctz(varying) : 0);
+  };
+  const int top = varying ? 31 - __builtin_clz(varying) : -1, low = varying ? __builtin_ctz(varying) : 0;
+  if (top - low >= 8) {
+    // first digit by histogram; if the threshold bin then holds few keys (the usual case: n / 256 on average) the
+    // remaining digits are settled by ranking those keys against each other instead of three more histogram passes
+    // (each ~1.3 us of barriers for a handful of keys)
+    const int shift1 = top - 7;
+    select_radix_passes_sweep(sweep, S, prefix, kk, top, shift1);
+    const int in_bin = S.hist[(prefix >> shift1) & 0xffu];
+    __syncthreads();                                           // everyone has read the bin count: the histogram is free
+    if (in_bin <= 256) {
+      uint32_t* cand = reinterpret_cast<uint32_t*>(S.hist);
+      if (threadIdx.x == 0) S.k = 0;
+      __syncthreads();
+      const uint32_t himask = 0xffffffffu << shift1;
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (j < per && base + j < n && (key[j] & himask) == (prefix & himask)) cand[atomicAdd(&S.k, 1)] = key[j];
+      __syncthreads();
+      if ((int)threadIdx.x < in_bin) {
+        const uint32_t mine = cand[threadIdx.x];
+        int lt = 0, eq = 0;
+        for (int i = 0; i < in_bin; ++i) {
+          const uint32_t o = cand[i];
+          lt += o < mine;
+          eq += o == mine;
+        }
+        if (lt < kk && kk <= lt + eq) { S.prefix = mine; S.wsum2[0] = kk - lt; }      // equal keys write equal values
+      }
+      __syncthreads();
+      prefix = S.prefix;
+      kk = S.wsum2[0];
+      __syncthreads();
+    } else {
+      select_radix_passes_sweep(sweep, S, prefix, kk, shift1 - 1, low);
+    }
+  } else {
+    select_radix_passes_sweep(sweep, S, prefix, kk, top, low);
+  }
   const uint32_t T = prefix;
   int n_lt = 0, n_eq = 0;
 #pragma unroll
