@@ -44,7 +44,8 @@ typedef enum SvkStatus {
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
-/* Developer-build switches compiled in (bit 0: -DSVK_PA_TIMING, bit 1: -DSVK_QV_TIMING); 0 in a product build. */
+/* Developer-build switches compiled in (bit 0: -DSVK_PA_TIMING, bit 1: -DSVK_QV_TIMING, bit 2: -DSVK_KV_TIMING); 0 in a
+ * product build. */
 int svk_build_flags(void);
 
 /* ------------------------------------------------------------------------------------

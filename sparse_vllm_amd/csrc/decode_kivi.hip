@@ -9,6 +9,24 @@
 #include <type_traits>
 
 #include "svk_common.hpp"
+// Developer build (make EXTRA=-DSVK_KV_TIMING, then tools/kv_timing.py): s_memrealtime stamps (100 MHz) of wave 0 of every
+// workgroup of the wide KIVI kernel: 0 entry, 1 range known, 2 before the tile loop, 3 first K tile in LDS, 4 first tile
+// done, 5 tile loop done, 6 partials written.
+#ifdef SVK_KV_TIMING
+__device__ unsigned long long g_kv_stamps[4096 * 8];
+#define SVK_KV_STAMP(i)                                                                                                \
+  do {                                                                                                                 \
+    if (threadIdx.x == 0) {                                                                                            \
+      const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                                        \
+      if (wg_ < 4096u) g_kv_stamps[wg_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                                   \
+    }                                                                                                                  \
+  } while (0)
+extern "C" int svk_debug_kivi_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kv_stamps), sizeof(g_kv_stamps));
+}
+#else
+#define SVK_KV_STAMP(i)
+#endif
 
 namespace svk {
 int launch_kivi_lds(const SvkKiviDecodeStage1Args& a, hipStream_t s);      // decode_kivi_lds.hip
@@ -346,6 +364,7 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Hkv = a.num_kv_heads;
+  if constexpr (WIDE) SVK_KV_STAMP(0);
   int b, blk;
   const int n_extra = WIDE ? a.extra_partials : 0;
   kivi_wg_to_range_extra(b, blk, n_extra);
@@ -434,6 +453,7 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       end = min(end, ragged_start);
     }
   }
+  if constexpr (WIDE) SVK_KV_STAMP(1);
   float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)slot * a.mid_o_stride_s;
   float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + slot;
   if (end <= start && !(owns_ends && (head_end > 0 || ragged_start < len))) {
@@ -948,6 +968,8 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     Cls4 nxt = classify4(t0 + kT);
     put_k();
     lds_sync();
+    SVK_KV_STAMP(3);
+    [[maybe_unused]] bool first_tile = true;
     while (true) {
       // ---------------- Q.K^T of the tile: codes and per-channel scales / mins from LDS
       // in flight under this phase: the tile's V codes from the start; its V scale / min rows (lane l: tokens 2l, 2l+1)
@@ -1056,6 +1078,9 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       }
       t0 += kT;
       lds_sync();                                              // V words all read
+#ifdef SVK_KV_TIMING
+      if (first_tile) { SVK_KV_STAMP(4); first_tile = false; }
+#endif
       if (!nxt.ok) break;
       put_k();
       lds_sync();
@@ -1085,6 +1110,7 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     };
     // up to three ranges, one copy of the loop body: the workgroup's own range, then (last workgroup of the row) the raw
     // head and the raw tail
+    SVK_KV_STAMP(2);
     const int rs3[3] = {start, 0, ragged_start};
     const int re3[3] = {end, owns_ends ? head_end : 0, owns_ends ? len : 0};
 #pragma nounroll
@@ -1125,6 +1151,7 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       }
     }
   }
+  if constexpr (WIDE) SVK_KV_STAMP(5);
   // ---- epilogue: lane (n, kc) owns heads kc*4+r and head dims dg*8 .. +8
   if (kc < JQ) {
 #pragma unroll
@@ -1141,6 +1168,7 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       }
     }
   }
+  if constexpr (WIDE) SVK_KV_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -29,5 +29,8 @@ extern "C" int svk_build_flags(void) {
 #ifdef SVK_QV_TIMING
   f |= 2;
 #endif
+#ifdef SVK_KV_TIMING
+  f |= 4;
+#endif
   return f;
 }

@@ -388,8 +388,13 @@ class DeltaKVCacheManager(CacheManager):
                 # us, 1024 -> 191.7, 512 -> 204.7, 256 -> 232.2)
                 rows = max(1, int(self.config.max_num_seqs_in_gpu))
                 tokens = rows * int(self.max_model_len)
-                wgs = 512 if tokens >= 512 * 1024 else 256
-                per_row = max(1, wgs // rows)
+                # Two per CU: the launch must fit the 512 resident slots INCLUDING the three extra workgroups per row
+                # (raw / ragged pieces, ~50 us each) - the regular workgroups they displace start when the extras end
+                # and finish that much later (8 x 256k: block_seq 4096 = 512 + 24 workgroups 401 us, 4480 = 472 + 24
+                # 328 us; 4 x 256k: 2048 -> 208 us, 2304 -> 186 us on the same box).  One per CU: the overflow lands
+                # on a CU's second slot, nothing waits.
+                two = tokens >= 512 * 1024
+                per_row = max(1, (480 // rows - 3) if two else 256 // rows)
                 bs = max(bs, -(-(-(-int(self.max_model_len) // per_row)) // 128) * 128)
             return bs
         return super().get_decode_block_seq(layer_idx, default)
