@@ -881,7 +881,10 @@ class DeltaKVCacheManager(CacheManager):
         dk.dequant_linear_act(self.deltakv_latent_cache[l0:l1], self.deltakv_latent_scales[l0:l1], self.deltakv_latent_mins[l0:l1],
                               self._quant_group_size(), w1[l0:l1], b1[l0:l1], activation="gelu", row_index=recon_latent,
                               out=hp[:, :, :hid], layers=True)
-        torch.bmm(hp, w2[l0:l1].transpose(1, 2), out=delta)
+        if os.environ.get("SVK_DELTAKV_BIAS_COLUMN", "1") == "1":
+            torch.bmm(hp, w2[l0:l1].transpose(1, 2), out=delta)
+        else:       # A/B: the plain form, whose broadcast bias copy is a launch of its own
+            torch.baddbmm(b2[l0:l1, None, :], hp[:, :, :hid], w2[l0:l1, :, :hid].transpose(1, 2), out=delta)
         knw = self.deltakv_k_norm_weight
         dk.deltakv_reconstruct_writeback_layers(
             delta, self.deltakv_latent_to_full_slots[l0:l1], recon_latent, self.deltakv_slot_to_pos, recon_out_slot, recon_pos,
