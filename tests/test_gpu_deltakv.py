@@ -206,6 +206,45 @@ def test_sorted_topk_long_rows(n, k, rows, plan, monkeypatch):
         np.testing.assert_array_equal(idx[r], np.argsort(-s, kind="stable")[:k])
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_sorted_topk_histogram_plan_fuzz(seed):
+    """Seeded random shapes of the histogram plan (rows longer than one LDS stage): value kinds that stress the bin window -
+    a narrow band of bf16 probabilities (all keys share their leading bits), wide-range fp32 with both signs, signed
+    zeros and infinities, a constant row (every key in one bin: the memory fallback), a few distinct values - with random
+    valid lengths (shorter than k included) and masked values above and below the data.  Must equal the stable argsort."""
+    from sparse_vllm_amd.kernels.deltakv_kernels import topk_sorted_desc
+    rng = np.random.default_rng(1000 + seed)
+    rows = int(rng.integers(1, 4))
+    n = int(rng.integers(24577, 300001))
+    k = int(rng.integers(1, 4097))
+    kinds = ["band", "wide", "special", "const", "few"]
+    x = np.empty((rows, n), np.float32)
+    for r in range(rows):
+        kind = kinds[int(rng.integers(0, len(kinds)))]
+        if kind == "band":
+            x[r] = bf16_round((2.0 ** -18 * (1.0 + rng.random(n))).astype(np.float32))
+        elif kind == "wide":
+            x[r] = (rng.standard_normal(n) * 10.0 ** rng.integers(-20, 20, n)).astype(np.float32)
+        elif kind == "special":
+            x[r] = rng.standard_normal(n).astype(np.float32)
+            idx = rng.integers(0, n, 64)
+            x[r, idx[:16]] = 0.0
+            x[r, idx[16:32]] = -0.0
+            x[r, idx[32:48]] = np.inf
+            x[r, idx[48:]] = -np.inf
+        elif kind == "const":
+            x[r] = np.float32(rng.standard_normal())
+        else:
+            x[r] = rng.integers(0, 5, n).astype(np.float32) * np.float32(0.125)
+    vlen = np.array([int(rng.choice([n, rng.integers(0, n + 1), rng.integers(0, k + 1)])) for _ in range(rows)], np.int32)
+    masked = float(rng.choice([-1e10, 0.5, 3e38]))
+    idx = topk_sorted_desc(t(x), k, valid_len=t(vlen), masked_value=masked).cpu().numpy()
+    for r in range(rows):
+        s = np.where(np.arange(n) < vlen[r], x[r], np.float32(masked))
+        s = np.where(s == 0, np.float32(0.0), s)                      # -0.0 and +0.0 compare equal
+        np.testing.assert_array_equal(idx[r], np.argsort(-s, kind="stable")[:k], err_msg=f"row {r} n={n} k={k} vlen={vlen[r]}")
+
+
 def test_materialize_sparse_view_golden_and_random(golden):
     """Tolerance: one bf16 rounding of the rotated key (|x| <~ 4 -> atol 2^-7 * ... use rtol 2^-7, atol 1e-6);
     V and post-RoPE K are copies -> bit-exact."""
