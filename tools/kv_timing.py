@@ -86,3 +86,13 @@ for it in range(4):
     for label, rows in (("median workgroup", rel[sel:sel + 1]), ("slowest regular", rel[order[0]:order[0] + 1])):
         print(f"  {label:18s} " + " | ".join(f"{n} {rows[0, i]:.2f}" for i, n in enumerate(names)))
     print("  medians over workgroups: " + " | ".join(f"{n} {np.median(rel[:, i]):.2f}" for i, n in enumerate(names)))
+    if it == 3:
+        ids = np.arange(nwg)
+        print("  end by workgroup id % 8 (XCD of a round-robin dispatch): "
+              + ", ".join(f"{x}: med {np.median(rel[ids % 8 == x, 6]):.0f} max {rel[ids % 8 == x, 6].max():.0f}" for x in range(8)))
+        q = np.quantile(rel[:, 6], [0.1, 0.25, 0.5, 0.75, 0.9, 1.0])
+        print("  end quantiles 10/25/50/75/90/100 %: " + " ".join(f"{v:.0f}" for v in q))
+        per_tile = (rel[:, 5] - rel[:, 4])
+        print("  loop time after tile 1, quantiles: " + " ".join(f"{v:.0f}" for v in np.quantile(per_tile, [0.1, 0.5, 0.9, 1.0])))
+        slow = np.argsort(-rel[:, 6])[:40]
+        print("  40 slowest ids: " + " ".join(str(int(i)) for i in sorted(slow)))

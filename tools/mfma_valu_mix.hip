@@ -33,7 +33,14 @@ __global__ void __launch_bounds__(1024) mix(float* out, long long* cyc, int iter
         if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
         else if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
         else if (KIND == 2) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
-        else asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(vp[(m * N + j) % 8]) : "v"(cp1), "v"(cp2));
+        else if (KIND == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(vp[(m * N + j) % 8]) : "v"(cp1), "v"(cp2));
+        else if (KIND == 4) asm volatile("v_cvt_pk_f32_fp8 %0, %1" : "=v"(vp[(m * N + j) % 8]) : "v"(x));
+        else if (KIND == 5) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(x) : "v"(vp[(m * N + j) % 8].x), "v"(vp[(m * N + j) % 8].y));
+        else if (KIND == 6) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(vp[(m * N + j) % 8]) : "v"(cp1));
+        else if (KIND == 7) asm volatile("v_and_b32 %0, 0x0f0f0f0f, %0" : "+v"(x));
+        else if (KIND == 8) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
+        else if (KIND == 9) asm volatile("v_lshrrev_b32 %0, 4, %0" : "+v"(x));
+        else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(vp[(m * N + j) % 8]) : "v"(cp1));
       }
     }
   }
@@ -78,5 +85,15 @@ int main() {
     run<8, 3, false>("v_pk_fma", waves, out, cyc);
   }
   for (int waves : {4, 8}) { run<4, 3>("v_pk_fma", waves, out, cyc); run<8, 3>("v_pk_fma", waves, out, cyc); }
+  // instruction kinds of the int4 dequantisation (KIVI stage 1)
+  for (int waves : {4, 8, 12}) {
+    run<8, 4, false>("cvt_pk_f32_fp8", waves, out, cyc);
+    run<8, 5, false>("cvt_pk_bf16_f32", waves, out, cyc);
+    run<8, 6, false>("v_pk_mul", waves, out, cyc);
+    run<8, 10, false>("v_pk_add", waves, out, cyc);
+    run<8, 7, false>("v_and", waves, out, cyc);
+    run<8, 9, false>("v_lshrrev", waves, out, cyc);
+    run<8, 8, false>("v_perm", waves, out, cyc);
+  }
   return 0;
 }
