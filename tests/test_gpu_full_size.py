@@ -158,7 +158,9 @@ def test_h2o_headline_batch_256_single_block_direct_out_matches_split_path():
     import os
     from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import direct_out_supported
     B, L, steps = 256, 4, 132
-    assert os.environ.get("SVK_H2O_DEFER_SCORE", "end") == "end" and os.environ.get("SVK_DECODE_DIRECT_OUT", "1") == "1"
+    if (os.environ.get("SVK_H2O_DEFER_SCORE", "end") != "end" or os.environ.get("SVK_DECODE_DIRECT_OUT", "1") != "1"
+            or os.environ.get("SVK_STAGE1_VARIANT", "3") != "3"):
+        pytest.skip("the headline launch shape (single block, direct output, end-of-step epilogue) is the default configuration's")
     results = []
     for headline in (True, False):
         from sparse_vllm_amd.config import Config

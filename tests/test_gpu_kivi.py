@@ -278,7 +278,8 @@ def test_kivi_stage1_extra_partials(sink, raw_tail, lens, block_seq, irregular):
         blk_map[r1, 8 + 3 * G + 16: 8 + 4 * G] = -1
     shape = (B, Hq, max_len)
     extra, o, mid, lse, score = run_gpu_extra(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
-    assert extra == 3
+    import os
+    assert extra == (3 if os.environ.get("SVK_KIVI_VARIANT", "5") == "5" else 0)     # only the wide kernel takes extras
     mid_r, lse_r, score_r = run_oracle(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
     o_r = oda.flash_decode_stage2(mid_r, lse_r, np.asarray(lens, np.int32), block_seq)
     np.testing.assert_allclose(o, bf16_round(o_r), rtol=ATTN_TOL, atol=ATTN_TOL)
@@ -287,8 +288,9 @@ def test_kivi_stage1_extra_partials(sink, raw_tail, lens, block_seq, irregular):
     _, _, score_plain = run_gpu(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
     for b, n in enumerate(lens):
         nb_row = (n + block_seq - 1) // block_seq
-        assert np.isfinite(mid[b][:, :nb_row + 3]).all()                        # regular + extra partials written
-        assert (mid[b][:, nb_row + 3:] == 7.0).all()                            # nothing past them
+        if extra:
+            assert np.isfinite(mid[b][:, :nb_row + 3]).all()                    # regular + extra partials written
+            assert (mid[b][:, nb_row + 3:] == 7.0).all()                        # nothing past them
         np.testing.assert_array_equal(score[b, :, :n], score_plain[b, :, :n])
     # launches the wide kernel does not serve take no extras (bf16 key parameters here)
     bits16, maps16, ml16 = make_case(rng, B=1, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=[300], rows=2, raw_tail=40, sink=8, key_f32=False)

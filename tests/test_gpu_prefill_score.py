@@ -134,8 +134,11 @@ def test_prefill_score_from_attention_statistics(cfg):
     """MI355X fusion: context_attention_fwd(score_stats=...) leaves the score window's softmax statistics and a cleared
     score row, prefill_score_fwd(row_stats=...) runs its final pass only.  Same scores as the stand-alone three-launch
     form (the row statistics are the same sums in another order: rtol 1e-4) and as the oracle (tolerance of this file)."""
+    import os
     from sparse_vllm_amd.kernels.context_flashattention_nopad import context_attention_fwd
     from sparse_vllm_amd.kernels.prefill_score import prefill_score_fwd, prefill_score_window_pad
+    if os.environ.get("SVK_PREFILL_ATTN_VARIANT", "2") != "2" or os.environ.get("SVK_PREFILL_SCORE_VARIANT", "2") != "2":
+        pytest.skip("the statistics hand-over is built into the default (v2) attention and prefill_score kernels")
     Hq, Hkv, seqs_cfg, window = cfg
     D = 128
     rng = np.random.default_rng(Hq + window)
