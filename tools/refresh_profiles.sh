@@ -27,8 +27,14 @@ timeout 600 python3 "$R/tools/pathbench.py" < /dev/null 2>/dev/null | grep '^{' 
 for c in streamingllm quest deltakv_raw deltakv vanilla; do
   stats paths/${c}_kernel_stats.csv python3 "$R/tools/pathbench.py" --graph --configs $c --steps 20
 done
-timeout 300 python3 "$R/tools/kbench_kivi.py" < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi.txt"
-timeout 300 python3 "$R/tools/kbench_kivi.py" --sink 0 --tail 0 < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi_no_raw.txt"
+timeout 300 python3 "$R/tools/kbench_kivi.py" --batches 1 --block-seqs 512,1024 < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi.txt"
+timeout 300 python3 "$R/tools/kbench_kivi.py" --batches 4 --block-seqs 1024,2048,2304 < /dev/null 2>/dev/null | grep kivi >> "$O/paths/kbench_kivi.txt"
+timeout 300 python3 "$R/tools/kbench_kivi.py" --batches 8 --block-seqs 4480 < /dev/null 2>/dev/null | grep kivi >> "$O/paths/kbench_kivi.txt"
+timeout 300 python3 "$R/tools/kbench_kivi.py" --batches 1,4 --block-seqs 1024,2304 --score < /dev/null 2>/dev/null | grep kivi >> "$O/paths/kbench_kivi.txt"
+timeout 300 python3 "$R/tools/kbench_kivi.py" --batches 1,4 --block-seqs 1024,2304 --no-extra < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi_no_extra.txt"
+timeout 300 python3 "$R/tools/kbench_kivi.py" --batches 1,4 --block-seqs 1024,2304 --sink 0 --tail 0 < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi_no_raw.txt"
+timeout 300 python3 "$R/tools/kbench_quest.py" < /dev/null 2>/dev/null | grep quest > "$O/paths/kbench_quest.txt"
+timeout 300 python3 "$R/tools/kbench_quest.py" --batch 1 < /dev/null 2>/dev/null | grep quest >> "$O/paths/kbench_quest.txt"
 timeout 300 python3 "$R/tools/kbench_prefill.py" < /dev/null 2>/dev/null | grep prefill > "$O/paths/kbench_prefill.txt"
 timeout 300 python3 "$R/tools/kbench_prefill_score.py" < /dev/null 2>/dev/null | grep prefill_score > "$O/paths/kbench_prefill_score.txt"
 stats paths/prefill_h2o_kernel_stats.csv python3 "$R/tools/prefillbench.py"
@@ -40,7 +46,9 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   [ -n "$f" ] && cp "$f" "$O/kbench_pmc_$ctr.csv"
 done
 # bare access-pattern and instruction probes (built here by hipcc, see the header of each file)
-for p in probe_gather probe_kdma probe_dma_offset mfma_valu_mix; do
+# PMC passes over the KIVI stage-1 kernel (counters only)
+bash "$R/tools/pmc_kivi.sh" 5 4 2304 > "$O/pmc_kivi_v5.txt" 2>/dev/null
+for p in probe_gather probe_kdma probe_dma_offset mfma_valu_mix probe_fp8cvt probe_tr4; do
   [ -x "$R/tools/bin/$p" ] && timeout 120 "$R/tools/bin/$p" < /dev/null > "$O/$p.txt" 2>&1
 done
 rm -rf "$O"/_prof_* "$O"/_pmc_*/
