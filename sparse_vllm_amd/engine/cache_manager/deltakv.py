@@ -390,9 +390,10 @@ class DeltaKVCacheManager(CacheManager):
                 tokens = rows * int(self.max_model_len)
                 # Two per CU: the launch must fit the 512 resident slots INCLUDING the three extra workgroups per row
                 # (raw / ragged pieces, ~50 us each) - the regular workgroups they displace start when the extras end
-                # and finish that much later (8 x 256k: block_seq 4096 = 512 + 24 workgroups 401 us, 4480 = 472 + 24
-                # 328 us; 4 x 256k: 2048 -> 208 us, 2304 -> 186 us on the same box).  One per CU: the overflow lands
-                # on a CU's second slot, nothing waits.
+                # and finish that much later (4 x 256k: block_seq 2048 = 516 + 12 workgroups 182 us, 2304 = 456 + 12
+                # 170 us; 8 x 256k: 4096 -> 318 us, 4480 -> 315 us; tools/kbench_kivi.py after 0.4 s of warm-up - the
+                # first configuration timed in a process reads 10-20 % slow).  One per CU: the overflow lands on a
+                # CU's second slot, nothing waits.
                 two = tokens >= 512 * 1024
                 per_row = max(1, (480 // rows - 3) if two else 256 // rows)
                 bs = max(bs, -(-(-(-int(self.max_model_len) // per_row)) // 128) * 128)

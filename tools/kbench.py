@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--layers", type=int, default=6, help="distinct K/V sets cycled through (defeats the 256 MB MALL)")
     ap.add_argument("--heads", default="28,4", help="query heads, KV heads of the rank (7,1 = one TP=4 rank of Qwen2.5-7B)")
     args = ap.parse_args()
+    from _warm import warm
+    warm()                                  # clocks settled before the first timed configuration (tools/_warm.py)
     d = torch.device("cuda:0")
     Hq, Hkv = (int(x) for x in args.heads.split(","))
     D, L = 128, args.len

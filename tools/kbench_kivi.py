@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--block-seqs", default="256,512,1024")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--score", action="store_true")
+    ap.add_argument("--warmup-s", type=float, default=0.4, help="seconds of launches before each timed configuration")
     ap.add_argument("--no-extra", action="store_true", help="no spare partial slots: the launch without extra workgroups")
     ap.add_argument("--sink", type=int, default=8)
     ap.add_argument("--tail", type=int, default=48)
@@ -72,9 +73,16 @@ def main():
                     kivi_block_start_pos=blk_start, key_packed=kp, key_scales=ks, key_mins=km, value_packed=vp,
                     value_scales=vs, value_mins=vm, req_indices=req, context_lens=lens, max_len_in_batch=L, mid_out=mid,
                     mid_out_logsumexp=lse, group_size=G, block_seq=bs, attn_score=score, extra_partial_slots=spare)
-            for _ in range(3):
-                run()
-            torch.cuda.synchronize()
+            # warm-up by time, not by count: the first configuration timed in a process otherwise reads 10-20 % slow
+            # (clocks ramp over tens of milliseconds of sustained work; 30 launches of 200 us are not enough)
+            import time
+            t_end = time.perf_counter() + args.warmup_s
+            while True:
+                for _ in range(10):
+                    run()
+                torch.cuda.synchronize()
+                if time.perf_counter() >= t_end:
+                    break
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.iters):

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--prefixes", default="0,8192,57344")
     ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
+    from _warm import warm
+    warm()                                  # clocks settled before the first timed configuration (tools/_warm.py)
     d = torch.device("cuda:0")
     Hq, Hkv, D = 28, 4, 128
     torch.manual_seed(0)

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=8192)
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
+    from _warm import warm
+    warm()                                  # clocks settled before the first timed configuration (tools/_warm.py)
     d = torch.device("cuda:0")
     Hq, Hkv, D, W = 28, 4, 128, args.window
     torch.manual_seed(0)

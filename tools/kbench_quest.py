@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--heads", default="28,4")
     args = ap.parse_args()
+    from _warm import warm
+    warm()                                  # clocks settled before the first timed configuration (tools/_warm.py)
     d = torch.device("cuda:0")
     Hq, Hkv = (int(x) for x in args.heads.split(","))
     D, ps, B, ctx = 128, 16, args.batch, args.ctx
