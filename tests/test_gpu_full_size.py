@@ -5,7 +5,9 @@ size-independent properties - the oracle takes minutes at this size, the propert
   * linearity of the score accumulation: every step adds one softmax row (sum 1) per (layer, sequence);
   * the hipGraph replay is bit-identical to eager launches (outputs, scores, slot tables);
   * split invariance of the decode kernel: raw scores are bit-identical for any block_seq, merged outputs agree within
-    the attention tolerance, and the launch with the fused store equals store-then-launch at full size.
+    the attention tolerance, and the launch with the fused store equals store-then-launch at full size;
+  * (configs[4], one KIVI-int4 full layer at 262 152 tokens) the merged output and the raw scores do not depend on how
+    the row is cut: block_seq, extra workgroups for the raw / ragged pieces or not.
 """
 
 import numpy as np
@@ -211,3 +213,73 @@ def test_h2o_headline_batch_256_single_block_direct_out_matches_split_path():
     np.testing.assert_allclose(a["first_o"], b["first_o"], rtol=2e-2, atol=2e-2)
     np.testing.assert_allclose(a["o"], b["o"], rtol=2e-2, atol=2e-2)
     np.testing.assert_allclose(a["score"], b["score"], rtol=1e-4, atol=1e-6)
+
+
+def test_kivi_full_layer_256k_partition_invariance():
+    """BASELINE.json configs[4] size for one full-attention layer: a 262 152-token row of KIVI-int4 blocks (sink 8, 56 raw
+    tail tokens) at Qwen2.5-7B heads - the oracle needs minutes here, the properties do not need it.  Online softmax is
+    associative, so the merged output must not depend on how the row is cut: block_seq 1024 / 2304, with and without the
+    three extra workgroups per row (raw / ragged pieces), wide kernel or not; and the position-indexed raw scores of an
+    observation layer are the same numbers bit for bit in every launch.  Row 1 is shorter than the batch maximum."""
+    import os
+    from sparse_vllm_amd.kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1
+    from sparse_vllm_amd.kernels.flash_decoding_stage2 import flash_decode_stage2
+    d = torch.device("cuda:0")
+    Hq, Hkv, D, G, sink = 28, 4, 128, 32, 8
+    lens_l = [262152, 100003]
+    B, L = len(lens_l), max(lens_l)
+    gen = torch.Generator(device=d).manual_seed(7)
+    nb_rows = [(n - sink - 48) // G for n in lens_l]
+    nblocks = sum(nb_rows)
+    raw_slots = sum(n - nb * G for n, nb in zip(lens_l, nb_rows)) + 8
+    raw_k = (torch.randn(raw_slots, Hkv, D, device=d, generator=gen) * 0.3).bfloat16()
+    raw_v = (torch.randn(raw_slots, Hkv, D, device=d, generator=gen) * 0.3).bfloat16()
+    q = (torch.randn(B, Hq, D, device=d, generator=gen) * 0.3).bfloat16()
+    raw_map = torch.full((B, L + 8), -1, dtype=torch.int32, device=d)
+    blk_map = torch.full((B, L + 8), -1, dtype=torch.int32, device=d)
+    blk_start = torch.zeros(nblocks, dtype=torch.int32, device=d)
+    perm = torch.randperm(nblocks, device=d, generator=gen).to(torch.int32)
+    rp = torch.randperm(raw_slots, device=d, generator=gen).to(torch.int32)
+    ru = bu = 0
+    for b, (n, nb) in enumerate(zip(lens_l, nb_rows)):
+        raw_map[b, :sink] = rp[ru: ru + sink]; ru += sink
+        pb = perm[bu: bu + nb]; bu += nb
+        blk_map[b, sink: sink + nb * G] = pb.repeat_interleave(G)
+        blk_start[pb.long()] = torch.arange(sink, sink + nb * G, G, dtype=torch.int32, device=d)
+        n_tail = n - sink - nb * G
+        raw_map[b, sink + nb * G: n] = rp[ru: ru + n_tail]; ru += n_tail
+    ri = lambda *shape: torch.randint(-2 ** 31, 2 ** 31 - 1, shape, device=d, dtype=torch.int64, generator=gen).to(torch.int32)
+    kp, vp = ri(nblocks, Hkv, D, G // 8), ri(nblocks, Hkv, G, D // 8)
+    ks = torch.rand(nblocks, Hkv, D, device=d, generator=gen) * 0.1 + 0.02
+    km = ks * -7.5
+    vs = (torch.rand(nblocks, Hkv, G, D // G, device=d, generator=gen) * 0.1 + 0.02).bfloat16()
+    vm = (vs.float() * -7.5).bfloat16()
+    req = torch.arange(B, dtype=torch.int32, device=d)
+    lens = torch.tensor(lens_l, dtype=torch.int32, device=d)
+
+    def run(block_seq, spare):
+        nblk = (L + block_seq - 1) // block_seq
+        mid = torch.full((B, Hq, nblk + spare, D), 7.0, dtype=torch.float32, device=d)
+        lse = torch.full((B, Hq, nblk + spare), 7.0, dtype=torch.float32, device=d)
+        score = torch.full((B, Hq, L), -1e20, dtype=torch.float32, device=d)
+        extra = full_layer_kivi_flash_decode_stage1(
+            q=q, raw_k=raw_k, raw_v=raw_v, raw_slots_map=raw_map, kivi_block_slots_map=blk_map, kivi_block_start_pos=blk_start,
+            key_packed=kp, key_scales=ks, key_mins=km, value_packed=vp, value_scales=vs, value_mins=vm, req_indices=req,
+            context_lens=lens, max_len_in_batch=L, mid_out=mid, mid_out_logsumexp=lse, group_size=G, block_seq=block_seq,
+            attn_score=score, extra_partial_slots=spare)
+        o = torch.empty((B, Hq, D), dtype=torch.bfloat16, device=d)
+        flash_decode_stage2(mid, lse, lens, o, block_seq, extra_partials=extra)
+        torch.cuda.synchronize()
+        return extra, o.float(), score
+
+    wide = os.environ.get("SVK_KIVI_VARIANT", "5") == "5"
+    e0, o0, s0 = run(1024, 3)
+    assert e0 == (3 if wide else 0)
+    assert torch.isfinite(o0).all() and float(o0.abs().max()) > 0
+    for n, b in zip(lens_l, range(B)):
+        assert torch.isfinite(s0[b, :, :n]).all() and (s0[b, :, n:] == -1e20).all()      # every position below the length, nothing past it
+    for block_seq, spare in ((1024, 0), (2304, 3), (2304, 0), (4096, 3)):
+        e, o, s = run(block_seq, spare)
+        assert e == (3 if wide and spare else 0)
+        torch.testing.assert_close(o, o0, rtol=2e-2, atol=2e-3)                         # bf16 outputs of two summation orders
+        assert torch.equal(s, s0)                                                       # raw logits: no softmax, no order
