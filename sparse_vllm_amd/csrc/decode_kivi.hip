@@ -884,8 +884,9 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
     // no branch around the loads (a tile that does not fit reads clamped positions and is rejected by `inside`): a
     // branch would end the basic block and pull the first use of the values - and its in-order wait - up to here
     Maps4 mp{t + kT <= end, 0, 0, 0, 0};
-    const int p = min(t + 2 * lane, end - 2);
-    mp.r0 = raw_map[p]; mp.r1 = raw_map[p + 1]; mp.b0 = blk_map[p]; mp.b1 = blk_map[p + 1];
+    const int last = max(end - 1, 0);
+    const int p = min(t + 2 * lane, last), p1 = min(t + 2 * lane + 1, last);       // (clamped into the row whatever t is)
+    mp.r0 = raw_map[p]; mp.r1 = raw_map[p1]; mp.b0 = blk_map[p]; mp.b1 = blk_map[p1];
     return mp;
   };
   auto pend4 = [&](const Maps4& mp) -> Pend4 {
@@ -898,9 +899,14 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
   auto verdict4 = [&](const Pend4& pd, int t) -> Cls4 {
     return Cls4{(bool)__all(pd.okp && pd.bst == t + 32 * (lane >> 4)), pd.bj};
   };
-  auto classify4 = [&](int t) -> Cls4 { return verdict4(pend4(maps4(t)), t); };
-  [[maybe_unused]] auto wide_run = [&](int& t0, Cls4 cls) __attribute__((always_inline)) {
+  // Entered with the maps of the tiles at t0 and t0 + 128 on their way (`pa`, `pb`: block ids known, recorded block starts
+  // still in flight): the first tile's K codes are requested from the block ids at once and the verdicts are taken while
+  // they travel - the start of a run is three dependent round trips instead of five (in-kernel stamps: first K tile in
+  // LDS 8 us after the range is known -> 5.5).  Returns false, with nothing but a few abandoned loads done, when the tile
+  // at t0 turns out not to be four whole blocks on their recorded positions.
+  [[maybe_unused]] auto wide_run = [&](int& t0, const Pend4& pa, const Pend4& pb) __attribute__((always_inline)) -> bool {
     if constexpr (WIDE) {
+    Cls4 cls{true, pa.bj};
     // LDS addresses of this lane's operand words
     // K row d of a block sits at position 16*(d>>4) + 8*((d&7)>>2) + 4*((d>>3)&1) + (d&3): rows d and d+8 (the two
     // k-chunks of a 32-lane half) are 64 B apart, so a ds_read_b32 of the half touches 32 different banks
@@ -965,7 +971,8 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     issue_k(cls);
-    Cls4 nxt = classify4(t0 + kT);
+    if (!verdict4(pa, t0).ok) return false;
+    Cls4 nxt = verdict4(pb, t0 + kT);
     put_k();
     lds_sync();
     SVK_KV_STAMP(3);
@@ -1087,7 +1094,9 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       cls = nxt;
       nxt = verdict4(pd2, t0 + kT);
     }
+    return true;
     }
+    return false;
   };
   // driver
   if constexpr (WIDE) {
@@ -1123,8 +1132,9 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       score_vec = score_vec_ok && (rs % 8) == 0;
       int t0 = rs;
       while (t0 < end) {
-        const Cls4 c4 = classify4(t0);
-        if (c4.ok) { wide_run(t0, c4); continue; }
+        const Maps4 ma = maps4(t0), mb = maps4(t0 + kT);
+        const Pend4 pa = pend4(ma), pb = pend4(mb);
+        if (__all(pa.okp) && wide_run(t0, pa, pb)) continue;
         const int nb = next_block_start(t0);
         lim = (nb < t0 + kT && nb + kT <= end) ? nb : end;
         const Cls cls = classify(t0);
