@@ -177,3 +177,26 @@ def test_device_resident_step_needs_no_host_sync():
     synchronisation."""
     got = _run_h2o(True, True, 3 * 16 + 8, sync_debug=True)
     assert got["counters"]["decode_eviction_bursts"] == 3 * 4 and got["used_device"] >= 3 * 16
+
+
+def test_device_resident_bookkeeping_soak_forty_bursts():
+    """The same comparison over 40 eviction intervals (643 steps, ragged rows: 80 partial bursts): the device copies of the
+    bookkeeping never drift from the host mirrors, the graph-replayed device-resident run stays bit-identical to the
+    host-driven eager run (tables, free stacks, pointers, cumulative scores, outputs), and every layer's rows and free
+    stack still partition its slot pool at the end."""
+    steps = 40 * 16 + 3
+    ref = _run_h2o(False, False, steps, ragged=True)
+    got = _run_h2o(True, True, steps, ragged=True)
+    assert ref["counters"]["decode_eviction_bursts"] >= 40 * 4 - 4 and got["counters"] == ref["counters"]
+    for key in ("o", "score", "table", "lens"):
+        np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
+    assert got["ptr"] == ref["ptr"]
+    np.testing.assert_array_equal(got["dev_lens"], got["lens"])
+    np.testing.assert_array_equal(got["dev_ptr"], np.asarray(got["ptr"]))
+    n_slots = got["stack"].shape[1]
+    for l in range(len(got["ptr"])):
+        np.testing.assert_array_equal(got["stack"][l, : got["ptr"][l]], ref["stack"][l, : ref["ptr"][l]])
+        used = np.concatenate([got["table"][l, r, : got["lens"][l][r]] for r in range(got["table"].shape[1]) if got["lens"][l][r] > 0])
+        free = got["stack"][l, : got["ptr"][l]]
+        both = np.concatenate([used, free])
+        assert len(np.unique(both)) == len(both) and len(both) <= n_slots           # disjoint: no slot owned twice
