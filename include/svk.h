@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 10
+#define SVK_ABI_VERSION 11
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -834,6 +834,15 @@ typedef struct SvkKiviDecodeStage1Args {
    * nblk_row .. nblk_row + extra - 1 (nblk_row = ceil(len / block_seq)); partials of regular blocks at or past nblk_row
    * are then NOT written, and stage 2 must be told (SvkFlashDecodeStage2Args.extra_partials). */
   int32_t extra_partials;
+  /* MI355X: this step's raw store of the layer (store_kvcache of the B new rows into raw_k / raw_v at new_slots,
+   * engine/cache_manager/base.py:629-694 `_store_layer_kv`) riding in the launch, like SvkFlashDecodeStage1Args.new_k:
+   * the workgroup that owns position len - 1 of row b writes new_k/new_v[b] to raw slot new_slots[b] (skipped when < 0)
+   * before it reads the row.  Only launches svk_kivi_decode_stage1_extra_partials() reports > 0 for (the wide kernel)
+   * carry it; NULL = the caller stores.  The result equals store-then-launch. */
+  const uint16_t* new_k;             /* NULL or [B, Hkv, D] bf16 (new_stride_b / new_stride_h) */
+  const uint16_t* new_v;
+  const int32_t* new_slots;          /* [B]                                              */
+  int64_t new_stride_b, new_stride_h;
 } SvkKiviDecodeStage1Args;
 int svk_kivi_decode_stage1(const SvkKiviDecodeStage1Args* a, svk_stream_t stream);
 /* extra partial slots the launch described by `a` can use (its extra_partials field is ignored): 3 or 0 */

@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 10
+SVK_ABI_VERSION = 11
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -277,7 +277,8 @@ class SvkKiviDecodeStage1Args(C.Structure):
                                     "mid_o_stride_b", "mid_o_stride_h", "mid_o_stride_s", "mid_lse_stride_b",
                                     "mid_lse_stride_h", "score_stride_b", "score_stride_h")] + \
                [(n, _i32) for n in ("batch", "num_q_heads", "num_kv_heads", "head_dim", "max_len_in_batch", "block_seq",
-                                    "group_size", "key_param_dtype", "extra_partials")]
+                                    "group_size", "key_param_dtype", "extra_partials")] + \
+               [("new_k", _p), ("new_v", _p), ("new_slots", _p), ("new_stride_b", _i64), ("new_stride_h", _i64)]
 
 
 # symbol -> (argtypes) ; every entry point declared in include/svk.h

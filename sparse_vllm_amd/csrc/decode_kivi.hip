@@ -456,6 +456,25 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
   if constexpr (WIDE) SVK_KV_STAMP(1);
   float* mid_o = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)slot * a.mid_o_stride_s;
   float* mid_lse = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + slot;
+  if constexpr (WIDE) {
+    if (a.new_k != nullptr && len > 0 && (n_extra > 0 ? extra_id == n_extra - 1 : owns_ends)) {
+      // fused raw store: this workgroup owns position len - 1 (the newest token is a raw row, so it is in the tail range; the store does not depend on that).
+      // Wave w writes its KV head's K and V rows (2 x D/8 lanes, 16 bytes each) before any read of the slot; only this
+      // wave reads that slot's head row in this launch, so a workgroup-scope fence pair (= the store has completed) is
+      // enough, as in decode_stage1_kernel_v3.
+      const int ns = a.new_slots[b];
+      if (ns >= 0 && lane < 2 * DW) {
+        const bool is_v = lane >= DW;
+        const int seg = lane % DW;
+        const uint16_t* src = (is_v ? a.new_v : a.new_k) + (int64_t)b * a.new_stride_b + (int64_t)w * a.new_stride_h + seg * 8;
+        uint16_t* dst = const_cast<uint16_t*>(is_v ? a.raw_v : a.raw_k) + (int64_t)ns * a.raw_slot_stride +
+                        (int64_t)w * a.raw_head_stride + seg * 8;
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
   if (end <= start && !(owns_ends && (head_end > 0 || ragged_start < len))) {
     for (int h = 0; h < G; ++h) {
       float* o = mid_o + (int64_t)(w * G + h) * a.mid_o_stride_h;
@@ -1700,6 +1719,12 @@ extern "C" int32_t svk_kivi_decode_stage1_extra_partials(const SvkKiviDecodeStag
 extern "C" int svk_kivi_decode_stage1(const SvkKiviDecodeStage1Args* a, svk_stream_t stream) {
   using namespace svk;
   SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_kivi_decode_stage1: null args");
+  SVK_REQUIRE(a->new_k == nullptr || (a->new_v != nullptr && a->new_slots != nullptr && svk_kivi_decode_stage1_extra_partials(a) > 0 &&
+                                      (a->new_stride_b % 8) == 0 && (a->new_stride_h % 8) == 0 &&
+                                      (reinterpret_cast<uintptr_t>(a->new_k) % 16) == 0 && (reinterpret_cast<uintptr_t>(a->new_v) % 16) == 0 &&
+                                      (a->raw_slot_stride % 8) == 0 && (a->raw_head_stride % 8) == 0),
+              SVK_ERR_VALUE, "svk_kivi_decode_stage1: the fused raw store needs new_k, new_v, new_slots with 16-byte aligned rows and a "
+              "launch the wide kernel serves (svk_kivi_decode_stage1_extra_partials() > 0)");
   SVK_REQUIRE(a->extra_partials == 0 || a->extra_partials == svk_kivi_decode_stage1_extra_partials(a), SVK_ERR_VALUE,
               "svk_kivi_decode_stage1: extra_partials %d, this launch supports 0 or %d (svk_kivi_decode_stage1_extra_partials)",
               a->extra_partials, svk_kivi_decode_stage1_extra_partials(a));

@@ -370,6 +370,20 @@ class DeltaKVCacheManager(CacheManager):
             return None
         return super().save_rope_kv_if_needed(layer_idx, k, v)
 
+    def fused_decode_store_slots(self, layer_idx: int):
+        """MI355X: a KIVI full layer's raw store of the step (plain `store_kvcache` into the layer's raw rows, no side
+        effect) rides in its stage-1 launch when the wide kernel serves it (`SVK_DELTAKV_FUSE_FULL_STORE=0`: own launch)."""
+        if (layer_idx not in self.full_layer_to_idx or not self._full_layer_kivi_enabled() or get_context().is_prefill
+                or os.environ.get("SVK_DELTAKV_FUSE_FULL_STORE", "1") != "1"):
+            return None
+        ok = self.__dict__.get("_kivi_fused_store_ok")
+        if ok is None:
+            ok = self._kivi_fused_store_ok = dk.kivi_fused_store_supported(
+                head_dim=self.head_dim, num_kv_heads=self.num_kv_heads, group_size=self._full_layer_kivi_group_size(),
+                block_seq=self.get_decode_block_seq(layer_idx, 256), key_param_dtype=self.full_layer_kivi_key_scales.dtype)
+        mapping = self.full_layer_batch_states.slot_mapping
+        return mapping if ok and mapping is not None and mapping.dtype == torch.int32 else None
+
     def get_decode_block_seq(self, layer_idx: int, default: int) -> int:
         if self._full_layer_kivi_enabled() and layer_idx in self.full_layer_to_idx:
             bs = int(self.config.full_layer_kivi_decode_block_seq or default)

@@ -410,13 +410,15 @@ def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_
                                         key_packed, key_scales, key_mins, value_packed, value_scales, value_mins,
                                         req_indices, context_lens, max_len_in_batch: int, mid_out, mid_out_logsumexp,
                                         group_size: int, block_seq: int, block_n: int = 16, num_warps: int = 2,
-                                        num_stages: int = 3, attn_score=None, extra_partial_slots: int = 0) -> int:
+                                        num_stages: int = 3, attn_score=None, extra_partial_slots: int = 0,
+                                        new_kv=None) -> int:
     """Decode stage 1 over KIVI-int4 blocks + raw tail (reference wrapper deltakv_kernels.py:973-1142; same
     argument names and ValueErrors).  block_n / num_warps / num_stages are Triton launch knobs: validated,
     otherwise unused (the HIP kernel tiles 32 tokens per wave).
     MI355X: `extra_partial_slots` = partial slots of mid_out / mid_out_logsumexp beyond ceil(max_len / block_seq) the
     launch may use for the raw / ragged pieces of every row; returns how many it used (0 or 3) - the `extra_partials`
-    stage 2 has to merge."""
+    stage 2 has to merge.  `new_kv` = (k [B, Hkv, D], v, slots [B] int32): this step's raw store of the layer riding in
+    the launch (only when `kivi_fused_store_supported(...)`; equal to store_kvcache(k, v, raw_k, raw_v, slots) first)."""
     for t in (q, raw_k, raw_v, raw_slots_map, kivi_block_slots_map, kivi_block_start_pos, key_packed, key_scales,
               key_mins, value_packed, value_scales, value_mins, req_indices, context_lens, mid_out, mid_out_logsumexp):
         assert t.is_cuda
@@ -502,8 +504,22 @@ def full_layer_kivi_flash_decode_stage1(*, q, raw_k, raw_v, raw_slots_map, kivi_
     if extra > int(extra_partial_slots) or int(mid_out.shape[2]) < nblk + extra or int(mid_out_logsumexp.shape[2]) < nblk + extra:
         extra = 0
     a.extra_partials = extra
+    if new_kv is not None:
+        nk, nv, slots = new_kv
+        assert nk.dtype == torch.bfloat16 and nv.dtype == torch.bfloat16 and nk.stride(-1) == 1 and nk.stride() == nv.stride()
+        assert slots.dtype == torch.int32 and slots.is_contiguous() and int(slots.numel()) == batch and int(nk.shape[0]) == batch
+        a.new_k, a.new_v, a.new_slots = _lib.ptr(nk), _lib.ptr(nv), _lib.ptr(slots)
+        a.new_stride_b, a.new_stride_h = nk.stride(0), nk.stride(1)
     _lib.check(lib.svk_kivi_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
     return extra
+
+
+def kivi_fused_store_supported(*, head_dim: int, num_kv_heads: int, group_size: int, block_seq: int, key_param_dtype) -> bool:
+    """Does a launch of this shape take the wide kernel, which can carry the step's raw store (`new_kv`)?"""
+    lib = _lib.load()
+    a = _lib.SvkKiviDecodeStage1Args(head_dim=int(head_dim), num_kv_heads=int(num_kv_heads), group_size=int(group_size),
+                                     block_seq=int(block_seq), key_param_dtype=_DT[key_param_dtype])
+    return int(lib.svk_kivi_decode_stage1_extra_partials(C.byref(a))) > 0
 
 
 # ------------------------------------------------------------------------------------------------------------------

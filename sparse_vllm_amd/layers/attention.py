@@ -64,11 +64,11 @@ class HipAttentionBackend:
                     mid_out=mid_o, mid_out_logsumexp=mid_o_logexpsum, group_size=int(md["group_size"]),
                     block_seq=block_seq, block_n=int(md.get("block_n", 16)), num_warps=int(md.get("num_warps", 2)),
                     num_stages=int(md.get("num_stages", 3)), attn_score=meta.attn_score,
-                    extra_partial_slots=max(0, int(mid_o.shape[2]) - nblk))
+                    extra_partial_slots=max(0, int(mid_o.shape[2]) - nblk), new_kv=new_kv)
             o = torch.empty_like(q)
             flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq, extra_partials=extra)
             return o
-        if new_kv is not None and payload.backend != "dense":
+        if new_kv is not None and payload.backend not in ("dense", "full_layer_kivi"):
             raise RuntimeError("the fused decode store is only wired into the dense stage-1 launch")
         if (fused_layer is not None and new_kv is None and payload.backend == "dense" and meta.attn_score is not None
                 and meta.attn_score.dim() == 2):

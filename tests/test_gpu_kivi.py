@@ -297,6 +297,58 @@ def test_kivi_stage1_extra_partials(sink, raw_tail, lens, block_seq, irregular):
     assert run_gpu_extra(bits16, maps16, max_len=ml16, G=G, block_seq=128)[0] == 0
 
 
+@pytest.mark.parametrize("spare", [3, 0])
+def test_kivi_stage1_fused_raw_store_equals_store_then_launch(spare):
+    """The step's raw store of the layer inside the launch (`new_kv`): the workgroup that owns position len - 1 writes the
+    new rows before it reads them.  Against store_kvcache followed by the plain launch: raw caches, partials, scores and
+    merged outputs bit-identical, padded lanes (slot -1) untouched; with the extra workgroups and with the last-workgroup
+    form."""
+    import os
+    if os.environ.get("SVK_KIVI_VARIANT", "5") != "5":
+        pytest.skip("the fused raw store is built into the wide kernel (the default)")
+    from sparse_vllm_amd.kernels import store_kvcache
+    from sparse_vllm_amd.kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1, kivi_fused_store_supported
+    from sparse_vllm_amd.kernels.flash_decoding_stage2 import flash_decode_stage2
+    rng = np.random.default_rng(77 + spare)
+    Hq, Hkv, D, G, block_seq = 28, 4, 128, 32, 256
+    lens = [1500, 777, 136, 9]
+    B = len(lens)
+    bits, maps, max_len = make_case(rng, B=B, Hq=Hq, Hkv=Hkv, D=D, G=G, lens=lens, rows=B + 1, raw_tail=40, sink=8, key_f32=True)
+    assert kivi_fused_store_supported(head_dim=D, num_kv_heads=Hkv, group_size=G, block_seq=block_seq, key_param_dtype=torch.float32)
+    new_k = bf(f32_to_bf16_bits(rng.standard_normal((B, Hkv, D)).astype(np.float32)))
+    new_v = bf(f32_to_bf16_bits(rng.standard_normal((B, Hkv, D)).astype(np.float32)))
+    # the newest token of row b lives in raw slot raw_map[req[b], len - 1]; lane 3 is a padded graph lane (slot -1)
+    slots_np = np.array([maps["raw_map"][maps["req"][b], lens[b] - 1] for b in range(B)], np.int32)
+    slots_np[3] = -1
+    slots = t(slots_np)
+
+    def launch(fused):
+        raw_k, raw_v = bf(bits["raw_k"]), bf(bits["raw_v"])
+        if not fused:
+            store_kvcache(new_k, new_v, raw_k, raw_v, slots)
+        nblk = (max_len + block_seq - 1) // block_seq
+        mid = torch.full((B, Hq, nblk + spare, D), 7.0, dtype=torch.float32, device=dev())
+        lse = torch.full((B, Hq, nblk + spare), 7.0, dtype=torch.float32, device=dev())
+        score = torch.full((B, Hq, max_len), -1e20, dtype=torch.float32, device=dev())
+        extra = full_layer_kivi_flash_decode_stage1(
+            q=bf(bits["q"]), raw_k=raw_k, raw_v=raw_v, raw_slots_map=t(maps["raw_map"]), kivi_block_slots_map=t(maps["blk_map"]),
+            kivi_block_start_pos=t(maps["blk_start"]), key_packed=t(bits["key_packed"]), key_scales=kparam(bits["key_scales"]),
+            key_mins=kparam(bits["key_mins"]), value_packed=t(bits["value_packed"]), value_scales=bf(bits["value_scales"]),
+            value_mins=bf(bits["value_mins"]), req_indices=t(maps["req"]), context_lens=t(maps["lens"]), max_len_in_batch=max_len,
+            mid_out=mid, mid_out_logsumexp=lse, group_size=G, block_seq=block_seq, attn_score=score, extra_partial_slots=spare,
+            new_kv=(new_k, new_v, slots) if fused else None)
+        o = torch.full((B, Hq, D), 7.0, dtype=torch.bfloat16, device=dev())
+        flash_decode_stage2(mid, lse, t(maps["lens"]), o, block_seq, extra_partials=extra)
+        torch.cuda.synchronize()
+        return raw_k, raw_v, mid, lse, score, o
+
+    ref, got = launch(False), launch(True)
+    for x, y in zip(ref, got):
+        assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y)
+    # the new rows are in the cache, and they are what the launch saw (the output changes when the new value changes)
+    assert torch.equal(got[0][int(slots_np[0])], new_k[0]) and torch.equal(got[1][int(slots_np[1])], new_v[1])
+
+
 def test_kivi_stage1_all_raw_matches_plain_stage1():
     """With no KIVI block the kernel is the ordinary slot-table decode: compare with svk_flash_decode_stage1.
     The two kernels tile the row differently (128 vs 32 tokens per online-softmax step), so P is rounded to bf16
