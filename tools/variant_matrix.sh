@@ -20,3 +20,4 @@ run SVK_STAGE1_VARIANT=2
 run SVK_PREFILL_SCORE_FUSE=0 SVK_PREFILL_ATTN_VARIANT=1 SVK_PREFILL_SCORE_VARIANT=1
 run SVK_DELTAKV_RECON_AHEAD=0 SVK_DELTAKV_FUSED_UP=0 SVK_DELTAKV_FUSE_RAW_STORE=0 SVK_QUEST_VIEW_VARIANT=1
 run SVK_FUSE_DECODE_STORE=0 SVK_DECODE_DIRECT_OUT=0
+run SVK_PREFILL_ATTN_HELPER=0 SVK_DELTAKV_FUSE_FULL_STORE=0
