@@ -408,8 +408,12 @@ class DeltaKVCacheManager(CacheManager):
                 # 170 us; 8 x 256k: 4096 -> 318 us, 4480 -> 315 us; tools/kbench_kivi.py after 0.4 s of warm-up - the
                 # first configuration timed in a process reads 10-20 % slow).  One per CU: the overflow lands on a
                 # CU's second slot, nothing waits.
+                # A workgroup is Hkv waves: a tensor-parallel rank with 1 or 2 KV heads gets 4 / Hkv times the workgroups
+                # for the same waves per CU (7q/1kv, 4 x 256k: block_seq 640 -> 62 us, 1024 -> 78; 14q/2kv: 1152 -> 99 us,
+                # 2304 -> 160; profiles/r03/tp_shapes.txt).
                 two = tokens >= 512 * 1024
-                per_row = max(1, (480 // rows - 3) if two else 256 // rows)
+                scale = max(1, 4 // max(1, int(self.num_kv_heads)))
+                per_row = max(1, ((480 * scale) // rows - 3) if two else (256 * scale) // rows)
                 bs = max(bs, -(-(-(-int(self.max_model_len) // per_row)) // 128) * 128)
             return bs
         return super().get_decode_block_seq(layer_idx, default)
