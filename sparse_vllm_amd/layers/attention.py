@@ -125,9 +125,20 @@ class Attention(torch.nn.Module):
                 guard(layer_idx)          # managers whose prompt view is not the plain slot table refuse here
             st = cache_manager.get_layer_batch_states(layer_idx)
             k_cache, v_cache = cache_manager.get_layer_kv_cache(layer_idx)
-            b_start_loc = context.cu_seqlens_q[:-1].to(torch.int32)
-            chunk_lens = (context.cu_seqlens_q[1:] - context.cu_seqlens_q[:-1]).to(torch.int32)
             b_seq_len = st.context_lens
+            # derived once per chunk, not once per layer (three small launches per layer otherwise): keyed on the storage
+            # and version of the tensors they come from
+            cu = context.cu_seqlens_q
+            key = (cu.data_ptr(), cu._version, int(cu.numel()), b_seq_len.data_ptr(), b_seq_len._version)
+            cached = getattr(context, "_prefill_derived", None)
+            if cached is None or cached[0][:3] != key[:3]:
+                b_start_loc = cu[:-1].to(torch.int32)
+                chunk_lens = (cu[1:] - cu[:-1]).to(torch.int32)
+                cached = (key, b_start_loc, chunk_lens, None)
+            if cached[3] is None or cached[0] != key:
+                cached = (key, cached[1], cached[2], b_seq_len - cached[2] if b_seq_len.numel() == cached[2].numel() else None)
+            context._prefill_derived = cached
+            _, b_start_loc, chunk_lens, prompt_cache_len = cached
             if b_seq_len.numel() != chunk_lens.numel():
                 raise RuntimeError("prefill context_lens/chunk_lens batch mismatch: "
                                    f"layer={layer_idx} context_lens_shape={tuple(b_seq_len.shape)} "
@@ -138,7 +149,7 @@ class Attention(torch.nn.Module):
             request = getattr(cache_manager, "prefill_attention_score_request", None)
             score_stats = request(layer_idx, q) if request is not None else None
             with profiler.record("prefill_attention"):
-                context_attention_fwd(q, k_cache, v_cache, o, st.req_indices, b_start_loc, b_seq_len, b_seq_len - chunk_lens,
+                context_attention_fwd(q, k_cache, v_cache, o, st.req_indices, b_start_loc, b_seq_len, prompt_cache_len,
                                       int(context.max_chunk_len or q.shape[0]),
                                       cache_manager.get_layer_buffer_req_to_token_slots(layer_idx), score_stats=score_stats)
             return o
