@@ -16,7 +16,7 @@ stats() {  # stats <name> <cmd...>: kernel-trace stats csv of one command
 }
 # headline bench: plain run (the judged line) and the same command under the profiler
 timeout 600 python3 "$R/bench.py" < /dev/null > "$O/bench_stdout.log" 2> "$O/bench_stderr.log"; tail -1 "$O/bench_stdout.log" > "$O/bench_line.json"
-stats bench_kernel_stats.csv python3 "$R/bench.py" --steps 128 --warmup 8 --no-cpu-baseline
+stats bench_kernel_stats.csv python3 "$R/bench.py" --steps 128 --warmup 8 --no-cpu-baseline --no-paths     # (the other configurations launch the same kernels at other shapes: they would pollute the per-kernel averages)
 grep '^{' "$O/_bench_kernel_stats.log" | tail -1 > "$O/bench_line_profiled.json"
 for b in 1 8 32; do timeout 300 python3 "$R/bench.py" --batch $b --no-cpu-baseline --no-kernel-events < /dev/null 2>/dev/null | tail -1 >> "$O/bench_small_batches.jsonl"; done
 # the roofline leg at the neighbouring batch sizes (the default is 256)
