@@ -7,7 +7,10 @@ size-independent properties - the oracle takes minutes at this size, the propert
   * split invariance of the decode kernel: raw scores are bit-identical for any block_seq, merged outputs agree within
     the attention tolerance, and the launch with the fused store equals store-then-launch at full size;
   * (configs[4], one KIVI-int4 full layer at 262 152 tokens) the merged output and the raw scores do not depend on how
-    the row is cut: block_seq, extra workgroups for the raw / ragged pieces or not.
+    the row is cut: block_seq, extra workgroups for the raw / ragged pieces or not; the observation chain (token scores
+    against a torch fp32 restatement, sorted top-k properties under both long-row plans) at that length;
+  * (configs[3], 4 x 131 072 tokens) Quest page scores against a torch fp32 restatement and the decode view's
+    selection properties.
 """
 
 import numpy as np
@@ -283,3 +286,114 @@ def test_kivi_full_layer_256k_partition_invariance():
         assert e == (3 if wide and spare else 0)
         torch.testing.assert_close(o, o0, rtol=2e-2, atol=2e-3)                         # bf16 outputs of two summation orders
         assert torch.equal(s, s0)                                                       # raw logits: no softmax, no order
+
+
+def test_quest_selection_full_size_properties():
+    """BASELINE.json configs[3] size for one sparse layer: 4 sequences x 131 072 tokens (8191 previous pages of 16), token
+    budget 4672, Qwen2.5-7B heads.  The page scores against a plain torch fp32 restatement of the reference's two bmm's
+    with its bf16 rounding points (max over heads of bf16(bf16(q+ . max) + bf16(q- . min))), and the decode view through
+    properties that need no oracle: exactly budget - 1 previous pages + the last page per row, no page twice, every chosen
+    score >= every rejected one (ties may fall either way), slots = page slot * 16 + offset in ascending page order, rows
+    shorter than the batch maximum masked, and the two launches idempotent."""
+    from sparse_vllm_amd.kernels import quest_ops
+    d = torch.device("cuda:0")
+    Hq, Hkv, D, ps, B, budget = 28, 4, 128, 16, 4, 4672
+    lens_l = [131072, 131072 - 3, 90001, 131072 - 16 * 700]
+    ctx = max(lens_l)
+    pages = (ctx + ps - 1) // ps
+    n_prev = pages - 1
+    prev_budget = budget // ps - 1
+    gen = torch.Generator(device=d).manual_seed(11)
+    pool = pages * B + 5
+    pmax = (torch.randn(pool, Hkv, D, device=d, generator=gen) * 0.5 + 1).bfloat16()
+    pmin = (torch.randn(pool, Hkv, D, device=d, generator=gen) * 0.5 - 1).bfloat16()
+    q = (torch.randn(B, Hq, D, device=d, generator=gen) * 0.5).bfloat16()
+    ptab = torch.stack([torch.randperm(pool, device=d, generator=gen)[:pages] for _ in range(B)]).to(torch.int32)
+    ttab = torch.zeros(B, ctx, dtype=torch.int32, device=d)
+    req = torch.arange(B, dtype=torch.int32, device=d)
+    lens = torch.tensor(lens_l, dtype=torch.int32, device=d)
+    keep = (prev_budget + 1) * ps
+
+    def run():
+        scores = torch.full((B, n_prev), 7.0, dtype=torch.float32, device=d)
+        packed = torch.full((B, keep), -5, dtype=torch.int32, device=d)
+        ll = torch.zeros(B, dtype=torch.int32, device=d)
+        lr = torch.zeros(B, dtype=torch.int32, device=d)
+        quest_ops.score_pages(q, pmax, pmin, ptab, req, lens, scores, page_size=ps, n_prev=n_prev)
+        quest_ops.build_view(scores, ptab, ttab, req, lens, packed, ll, lr, page_size=ps, n_prev=n_prev, prev_budget=prev_budget,
+                             token_budget=budget, page_budget_base=budget // ps, max_keep=keep, is_long_text=True)
+        torch.cuda.synchronize()
+        return scores, packed, ll
+
+    scores, packed, ll = run()
+    scores2, packed2, ll2 = run()
+    assert torch.equal(scores, scores2) and torch.equal(packed, packed2) and torch.equal(ll, ll2)
+    G = Hq // Hkv
+    for b, n in enumerate(lens_l):
+        npages = (n + ps - 1) // ps
+        valid = min(n_prev, npages - 1)
+        slots = ptab[b, :n_prev].long()
+        mx, mn = pmax[slots].float(), pmin[slots].float()                                   # [P, Hkv, D]
+        qf = q[b].float().view(Hkv, G, D)
+        sp = torch.einsum("hgd,phd->phg", qf.clamp_min(0), mx).bfloat16().float()
+        sn = torch.einsum("hgd,phd->phg", qf.clamp_max(0), mn).bfloat16().float()
+        ref = (sp + sn).bfloat16().float().amax(dim=(1, 2))
+        got = scores[b]
+        torch.testing.assert_close(got[:valid], ref[:valid], rtol=2e-2, atol=2e-2)
+        assert float((got[:valid] != ref[:valid]).float().mean()) < 0.02             # bf16-valued: almost all land on the same value
+        assert bool(torch.isinf(got[valid:]).all()) and bool((got[valid:] < 0).all())
+        # the view
+        assert int(ll[b]) == prev_budget * ps + (n - (npages - 1) * ps)
+        row = packed[b]
+        page_of = (row // ps)[:: ps]                                                         # one entry per selected page
+        offs = (row % ps).view(-1, ps)
+        assert bool((offs == torch.arange(ps, device=d, dtype=torch.int32)).all())
+        inv = torch.full((pool,), -1, dtype=torch.long, device=d)
+        inv[ptab[b].long()] = torch.arange(pages, device=d)
+        logical = inv[page_of.long()]
+        assert bool((logical >= 0).all()) and int(logical[-1]) == npages - 1                 # the last page closes the view
+        sel = logical[:-1]
+        assert bool((sel[1:] > sel[:-1]).all()) and bool((sel < valid).all())               # ascending, unique, valid pages
+        chosen = torch.zeros(n_prev, dtype=torch.bool, device=d)
+        chosen[sel] = True
+        assert float(got[:valid][chosen[:valid]].min()) >= float(got[:valid][~chosen[:valid]].max())
+
+
+def test_deltakv_observation_chain_full_size():
+    """BASELINE.json configs[4] size for one observation layer: raw logits [1, 28 heads, 262 152 tokens] -> per-head softmax
+    over the compressed range -> max over heads, bf16-rounded (`_decode_softmax_token_scores`) -> sorted top-2048
+    (`topk(sorted=True)`).  Scores against a plain torch fp32 restatement (tolerance: one bf16 rounding of a probability,
+    rtol 2^-7); the top-k through properties: sorted by (score desc, index asc), inside the valid range, every chosen score
+    >= every rejected one, identical under both long-row plans, and equal to torch.topk as a multiset of scores."""
+    from sparse_vllm_amd.kernels.deltakv_kernels import decode_softmax_token_scores, topk_sorted_desc
+    d = torch.device("cuda:0")
+    B, H, L, sink, k = 1, 28, 262152, 8, 2048
+    gen = torch.Generator(device=d).manual_seed(5)
+    raw = torch.randn(B, H, L, device=d, generator=gen) * 6.0                              # peaky rows
+    clen = torch.tensor([L - sink - 137], dtype=torch.int32, device=d)
+    scale = 128 ** -0.5
+    got = decode_softmax_token_scores(raw, candidate_start=sink, candidate_lens=clen, scale=scale, round_dtype=torch.bfloat16)
+    n = int(clen[0])
+    x = raw[0, :, sink: sink + n].float() * scale
+    ref = torch.softmax(x, dim=-1).amax(dim=0).bfloat16().float()
+    torch.testing.assert_close(got[0, sink: sink + n], ref, rtol=2 ** -7, atol=1e-12)
+    fill = torch.finfo(torch.bfloat16).min
+    assert bool((got[0, :sink] == fill).all()) and bool((got[0, sink + n:] == fill).all())
+    import os
+    search = got[:, sink:]
+    res = {}
+    for plan in ("hist", "chunks"):
+        os.environ["SVK_TOPK_PLAN"] = plan
+        try:
+            res[plan] = topk_sorted_desc(search, k, valid_len=clen, masked_value=-1e10)
+        finally:
+            os.environ.pop("SVK_TOPK_PLAN", None)
+    assert torch.equal(res["hist"], res["chunks"])
+    idx = res["hist"][0].long()
+    assert bool((idx >= 0).all()) and bool((idx < n).all()) and len(torch.unique(idx)) == k
+    s = search[0][idx]
+    assert bool(((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (idx[:-1] < idx[1:]))).all())     # (score desc, index asc)
+    rejected = torch.ones(n, dtype=torch.bool, device=d)
+    rejected[idx] = False
+    assert float(s.min()) >= float(search[0, :n][rejected].max())
+    assert torch.equal(s, torch.topk(search[0, :n], k, sorted=True).values)
