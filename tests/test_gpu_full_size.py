@@ -10,7 +10,9 @@ size-independent properties - the oracle takes minutes at this size, the propert
     the row is cut: block_seq, extra workgroups for the raw / ragged pieces or not; the observation chain (token scores
     against a torch fp32 restatement, sorted top-k properties under both long-row plans) at that length;
   * (configs[3], 4 x 131 072 tokens) Quest page scores against a torch fp32 restatement and the decode view's
-    selection properties.
+    selection properties;
+  * (configs[1], 64 x 32 k, sink 64 + recent 512) StreamingLLM window cycles: kept slots = sink + latest, slot
+    conservation, graph replay = eager bookkeeping.
 """
 
 import numpy as np
@@ -397,3 +399,62 @@ def test_deltakv_observation_chain_full_size():
     rejected[idx] = False
     assert float(s.min()) >= float(search[0, :n][rejected].max())
     assert torch.equal(s, torch.topk(search[0, :n], k, sorted=True).values)
+
+
+def test_streamingllm_full_size_window_cycle():
+    """BASELINE.json configs[1] size: 64 sequences at 32 k context, sink 64 + recent 512 (rows of 576 ... 1151 physical
+    tokens), Qwen2.5-7B heads, 28 layers.  Over more than one eviction cycle, graph-replayed against eager: slot tables and
+    free stacks bit-identical, outputs within the attention tolerance; rows walk 576 -> trigger -> back to sink + recent and never exceed the
+    window's peak; per layer, rows and free stack partition the slot pool; the kept slots of a row are its first 64 and
+    its latest ones (the slots that were resident at positions >= len - recent before the eviction)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import pathbench
+    B, sink, recent = 64, 64, 512
+    runs = []
+    for graph in (True, False):
+        drv, _ = pathbench.build("streamingllm")
+        cm = drv.cache_manager
+        q, k, v = drv.random_step_inputs(seed=1)
+        if graph:
+            drv.enable_decode_graph()
+        o = torch.zeros((cm.num_layers, B, 28, 128), dtype=torch.bfloat16, device=drv.device)
+        lens_seen, evicted = [], 0
+        prev_tab = None
+        for step in range(700):
+            before = drv.row_len().copy()
+            if prev_tab is None or int(before[0]) >= 1100:
+                prev_tab = cm.buffer_req_to_token_slots_tensor[0, :, : int(before.max())].clone()
+            drv.step(q, k, v, outputs=o)
+            after = drv.row_len()
+            lens_seen.append(int(after.max()))
+            if int(after[0]) < int(before[0]):                      # the window closed on this step
+                evicted += 1
+                n_before = int(before[0]) + 1
+                row0 = cm.seq_id_to_row[0][drv.seqs[0].seq_id] if isinstance(cm.seq_id_to_row, list) else cm.seq_id_to_row[drv.seqs[0].seq_id]
+                now = cm.buffer_req_to_token_slots_tensor[0, row0, : int(after[0])].cpu().numpy()
+                old = prev_tab[row0].cpu().numpy()
+                assert int(after[0]) == sink + recent
+                np.testing.assert_array_equal(now[:sink], old[:sink])                          # the sink stays
+                np.testing.assert_array_equal(now[sink: sink + recent - 1], old[n_before - recent: n_before - 1])   # the latest stay
+        torch.cuda.synchronize()
+        assert evicted >= 1 and max(lens_seen) <= 1152 and min(lens_seen) >= sink + recent
+        table = cm.buffer_req_to_token_slots_tensor.cpu().numpy()
+        stack = cm.free_slots_stack_tensor.cpu().numpy()
+        ptr = list(cm._num_free_slots)
+        lens = np.stack(cm.row_seq_lens) if isinstance(cm.row_seq_lens, list) else np.asarray(cm.row_seq_lens)[None]
+        for l in range(table.shape[0]):
+            ll = lens[min(l, lens.shape[0] - 1)]
+            used = np.concatenate([table[l, r, : ll[r]] for r in range(table.shape[1]) if ll[r] > 0])
+            both = np.concatenate([used, stack[l, : ptr[l]]])
+            assert len(np.unique(both)) == len(both) == stack.shape[1], f"layer {l}: rows and free stack must partition the pool"
+        runs.append((o.float().cpu().numpy().copy(), table, [stack[l, : ptr[l]].copy() for l in range(len(ptr))]))
+        del drv, q, k, v, o
+        torch.cuda.empty_cache()
+    # (the graph pins the context capacity, so its launches split the rows differently from the eager ones: same sums in
+    #  another order - outputs to the attention tolerance, the bookkeeping bit for bit)
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=2e-2, atol=2e-2)
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    for a, b in zip(runs[0][2], runs[1][2]):
+        np.testing.assert_array_equal(a, b)
