@@ -250,6 +250,105 @@ class CacheManager(ABC):
             return None          # Quest page metadata, DeltaKV raw/KIVI stores: keep the explicit store
         return self.get_layer_batch_states(layer_idx).slot_mapping
 
+    # ------------------------------------------------------------------ per-layer compute views (base.py:696-734, :838-965)
+    def get_layer_compute_view(self, layer_idx: int, active_slots: torch.Tensor, req_indices: torch.Tensor,
+                               context_lens: torch.Tensor, selection: SparseSelection | None = None):
+        """base.py:696-709 -> (k_cache, v_cache, active_slots, req_indices, context_lens)."""
+        k_cache, v_cache = self.get_layer_compute_tensors(layer_idx)
+        return k_cache, v_cache, active_slots, req_indices, context_lens
+
+    def get_layer_compute_payload(self, layer_idx: int, active_slots: torch.Tensor, req_indices: torch.Tensor,
+                                  context_lens: torch.Tensor, selection: SparseSelection | None = None):
+        """base.py:711-734: the decode payload + logical coordinates."""
+        k_cache, v_cache, active_slots, req_indices, context_lens = self.get_layer_compute_view(
+            layer_idx, active_slots, req_indices, context_lens, selection)
+        return ExplicitKVPayload(k_cache=k_cache, v_cache=v_cache), active_slots, req_indices, context_lens
+
+    def has_prefill_staging_view(self, layer_idx: int) -> bool:
+        """base.py:1124-1126: whether this prefill layer reads a temporary staging KV view (none in this build)."""
+        return False
+
+    def get_prefill_staging_view(self, layer_idx: int):
+        """base.py:1128-1133 -> (active_slots, req_indices, context_lens, temp_slots)."""
+        raise NotImplementedError
+
+    def has_full_layer_quantized_view(self, layer_idx: int) -> bool:
+        """base.py:1135-1137."""
+        return False
+
+    def build_full_layer_quantized_view(self, layer_idx: int, req_indices: torch.Tensor, context_lens: torch.Tensor):
+        """base.py:1139-1146 -> (active_slots, local_req_indices, context_lens)."""
+        raise NotImplementedError
+
+    def _default_active_slots_for_selection(self, layer_idx: int, selection: SparseSelection) -> torch.Tensor:
+        """base.py:887-890."""
+        if selection.active_slots is not None:
+            return selection.active_slots
+        return self.get_layer_buffer_req_to_token_slots(layer_idx)
+
+    def get_prefill_compute_view(self, layer_idx: int, k_current: torch.Tensor, v_current: torch.Tensor,
+                                 selection: SparseSelection, active_slots: torch.Tensor, req_indices: torch.Tensor,
+                                 context_lens: torch.Tensor):
+        """base.py:838-856: KV tensors + logical view of the prompt-side attention (the chunk's own K/V are in the cache)."""
+        del k_current, v_current
+        return self.get_layer_compute_view(layer_idx, active_slots, req_indices, context_lens, selection)
+
+    def get_prefill_compute_payload(self, layer_idx: int, k_current: torch.Tensor, v_current: torch.Tensor,
+                                    selection: SparseSelection, active_slots: torch.Tensor, req_indices: torch.Tensor,
+                                    context_lens: torch.Tensor):
+        """base.py:858-885."""
+        k_cache, v_cache, active_slots, req_indices, context_lens = self.get_prefill_compute_view(
+            layer_idx, k_current, v_current, selection, active_slots, req_indices, context_lens)
+        return ExplicitKVPayload(k_cache=k_cache, v_cache=v_cache), active_slots, req_indices, context_lens
+
+    def build_prefill_compute_view(self, layer_idx: int, k_current: torch.Tensor, v_current: torch.Tensor,
+                                   selection: SparseSelection) -> PrefillComputeView:
+        """base.py:892-931: staging view, quantised full-layer view or the plain slot table of the selection."""
+        temp_slots = None
+        if self.has_prefill_staging_view(layer_idx):
+            active_slots, req_indices, context_lens, temp_slots = self.get_prefill_staging_view(layer_idx)
+        elif self.has_full_layer_quantized_view(layer_idx):
+            active_slots, req_indices, context_lens = self.build_full_layer_quantized_view(
+                layer_idx, selection.req_indices, selection.context_lens)
+        else:
+            active_slots = self._default_active_slots_for_selection(layer_idx, selection)
+            req_indices = selection.req_indices
+            context_lens = selection.context_lens
+        payload, active_slots, req_indices, context_lens = self.get_prefill_compute_payload(
+            layer_idx, k_current, v_current, selection, active_slots, req_indices, context_lens)
+        return PrefillComputeView(
+            meta=AttentionViewMeta(active_slots=active_slots, req_indices=req_indices, context_lens=context_lens,
+                                   attn_score=selection.attn_score, max_context_len=selection.max_context_len,
+                                   temp_slots=temp_slots),
+            payload=payload)
+
+    def collect_prefill_attention_score(self, layer_idx: int, q: torch.Tensor, view: PrefillComputeView, *,
+                                        b_start_loc: torch.Tensor, chunk_lens: torch.Tensor):
+        """base.py:933-944: optional method-owned prefill score collection after the attention output is computed."""
+        del layer_idx, q, view, b_start_loc, chunk_lens
+        return None
+
+    def record_prefill_query(self, layer_idx: int, q: torch.Tensor, view: PrefillComputeView, *,
+                             b_start_loc: torch.Tensor, chunk_lens: torch.Tensor):
+        """base.py:946-957: optional method-owned prefill query cache update."""
+        del layer_idx, q, view, b_start_loc, chunk_lens
+        return None
+
+    def before_prefill_layer_attention(self, layer_idx: int, selection: SparseSelection):
+        """base.py:959-965: hook right before a prefill layer's compute view is built (the reference forwards it to
+        its prefix-cache coordinator, which this build does not have)."""
+        del layer_idx, selection
+        return None
+
+    def defer_prefill_eviction(self) -> bool:
+        """base.py:967-969."""
+        return False
+
+    def pop_prefill_attention_score(self, layer_idx: int, seq):
+        """base.py:976-979."""
+        del layer_idx, seq
+        return None
+
     def build_decode_compute_view(self, layer_idx: int, q: torch.Tensor, selection: SparseSelection, *,
                                   num_heads: int, num_kv_heads: int) -> DecodeComputeView:
         """base.py:1162-1206: full physical row of every request."""

@@ -337,7 +337,9 @@ class DeltaKVCacheManager(CacheManager):
         self._flush_pending_raw_stores()
         return super().on_forward_end(seqs, is_prefill)
 
-    def check_prefill_attention_view(self, layer_idx: int):
+    prefill_attention_view_supported = False
+
+    def build_prefill_compute_view(self, layer_idx: int, k_current, v_current, selection):
         """The prompt-side attention of DeltaKV runs over a reconstructed, RoPE-rotated staging view
         (deltakv_base.py:936-972 `build_prefill_compute_view` -> `deltakv_reconstruct(chunk_lens=...)` and the prefill
         staging caches), which is outside this build ("prefill staging ... OOS").  The plain slot

@@ -18,6 +18,8 @@ import numpy as np
 import torch
 
 from ...kernels import h2o_ops
+from ...utils.context import get_context
+from .base import ExplicitKVPayload, PrefillComputeView
 from .snapkv import SnapKVCacheManager
 
 
@@ -266,23 +268,19 @@ class H2OCacheManager(SnapKVCacheManager):
             self._prefill_score_meta = cached
         return key, cached[1][0], cached[1][1], cached[1][2]
 
-    def prefill_attention_score_request(self, layer_idx: int, q: torch.Tensor):
-        """MI355X: asked by the prefill attention of `layer_idx` right before its launch.  In the probability mode the
-        H2O score of a key is built from softmax rows over ALL causal keys (candidate_start = 0, num_recent = 0) - the
-        very statistics the attention computes - so the launch leaves the window rows' statistics behind and zeroes the
-        step-score rows; `collect_prefill_attention_score` then needs one scoring pass instead of three launches (Q.K^T
-        of the window once instead of twice).  -> `score_stats` of kernels.context_attention_fwd, or None."""
-        from ...utils.context import get_context
-        self._fused_prefill_stats = None
+    def _prefill_statistics_request(self, layer_idx: int, seqs, d):
+        """MI355X: in the probability mode the H2O score of a key is built from softmax rows over ALL causal keys
+        (candidate_start = 0, num_recent = 0) - the very statistics the prefill attention of the layer computes - so
+        the attention launch is asked to leave the window rows' statistics behind and to zero the step-score rows;
+        `collect_prefill_attention_score` then needs one scoring pass instead of three launches (Q.K^T of the window
+        once instead of twice).  -> {"request": `score_stats` of kernels.context_attention_fwd, ...} or None."""
         enabled = self.__dict__.get("_prefill_fuse_enabled")
         if enabled is None:
             import os
             enabled = self._prefill_fuse_enabled = (
                 self.config.sparse_prefill_score_mode == "probability" and self.head_dim == 128
-                and self.num_heads // self.num_kv_heads <= 8 and os.environ.get("SVK_PREFILL_SCORE_FUSE", "1") == "1"
-                and os.environ.get("SVK_PREFILL_ATTN_VARIANT", "2") == "2" and os.environ.get("SVK_PREFILL_SCORE_VARIANT", "2") == "2")
+                and self.num_heads // self.num_kv_heads <= 8 and os.environ.get("SVK_PREFILL_SCORE_FUSE", "1") == "1")
             self._prefill_wpad = {}
-        seqs = getattr(get_context(), "seqs", None)
         if not enabled or seqs is None:
             return None
         ranges = self.prefill_score_ranges(layer_idx, seqs)
@@ -291,8 +289,7 @@ class H2OCacheManager(SnapKVCacheManager):
         max_q = max(r[4] - r[3] for r in ranges)
         if max_q <= 0 or max_q > 128:
             return None
-        d = q.device
-        key, _cache_lens, starts, _ends = self._prefill_score_meta_tensors(ranges, d)
+        key, cache_lens, starts, _ends = self._prefill_score_meta_tensors(ranges, d)
         wpad = self._prefill_wpad.get(max_q)
         if wpad is None:
             from ...kernels.prefill_score import prefill_score_window_pad
@@ -302,29 +299,74 @@ class H2OCacheManager(SnapKVCacheManager):
         if buf is None or buf.numel() < n or buf.device != d:
             buf = self._prefill_stats_buf = torch.zeros((n,), dtype=torch.float32, device=d)
         step = torch.empty((len(seqs), max(r[4] for r in ranges)), dtype=torch.float32, device=d)
-        self._fused_prefill_stats = (int(layer_idx), key, buf, step)
-        return buf, starts, wpad, step
+        # `written_for` is set by the attention backend after its launch: (q storage, q version, q shape)
+        return {"request": (buf, starts, wpad, step), "layer": int(layer_idx), "key": key, "row_stats": buf,
+                "step": step, "written_for": None, "b_prompt_cache_len": cache_lens}
+
+    def build_prefill_compute_view(self, layer_idx: int, k_current: torch.Tensor, v_current: torch.Tensor,
+                                   selection) -> PrefillComputeView:
+        """base.py:892-931 (the plain slot table of the physical row).  MI355X: the view's payload also carries the
+        request for the attention launch's softmax statistics (see `_prefill_statistics_request`) - an internal detail
+        between this manager and the HIP attention backend; a backend that ignores it gets the three-launch scoring."""
+        view = super().build_prefill_compute_view(layer_idx, k_current, v_current, selection)
+        ctx = get_context()
+        if not ctx.is_prefill or not isinstance(view.payload, ExplicitKVPayload) or not view.payload.k_cache.is_cuda:
+            return view
+        stats = self._prefill_statistics_request(layer_idx, getattr(ctx, "seqs", None), view.payload.k_cache.device)
+        if stats is None:
+            return view
+        md = dict(view.payload.metadata or {})
+        md["score_stats"] = stats
+        md["b_prompt_cache_len"] = stats["b_prompt_cache_len"]
+        payload = ExplicitKVPayload(k_cache=view.payload.k_cache, v_cache=view.payload.v_cache,
+                                    backend=view.payload.backend, metadata=md)
+        return PrefillComputeView(meta=view.meta, payload=payload)
 
     @torch.no_grad()
-    def collect_prefill_attention_score(self, layer_idx: int, q: torch.Tensor, seqs, *, b_start_loc: torch.Tensor):
-        """cum[:len] = expand(prev, len) + W_eff * step_score (logits mode: softmax of the vector first)."""
+    def collect_prefill_attention_score(self, layer_idx: int, q: torch.Tensor, view: PrefillComputeView, *,
+                                        b_start_loc: torch.Tensor, chunk_lens: torch.Tensor):
+        """h2o.py:777-894: cum[:len] = expand(prev, len) + W_eff * step_score (logits mode: softmax of the vector
+        first), the window = the last min(h2o_prefill_score_window, chunk) queries in compressed physical coordinates,
+        candidate_start = 0, num_recent = 0."""
+        ctx = get_context()
+        if not ctx.is_prefill:
+            raise RuntimeError("H2O prefill score collection was called outside prefill.")
+        seqs = getattr(ctx, "seqs", None)
+        if seqs is None:
+            raise RuntimeError("H2O prefill score collection requires current seqs in context.")
+        if int(chunk_lens.ndim) != 1 or int(chunk_lens.shape[0]) != len(seqs):
+            raise RuntimeError("H2O prefill scoring chunk-length batch mismatch: "
+                               f"shape={tuple(chunk_lens.shape)} seqs={len(seqs)}.")
         ranges = self.prefill_score_ranges(layer_idx, seqs)
         if not ranges:
             return None
+        if not isinstance(view.payload, ExplicitKVPayload):
+            raise TypeError(f"H2O prefill scoring requires ExplicitKVPayload, got {type(view.payload).__name__}.")
+        meta, payload = view.meta, view.payload
+        context_lens = tuple(int(r[4]) for r in ranges)
+        prepared = self._prefill_context_lens_cpu_by_layer.get(int(layer_idx))
+        if prepared is None and meta.context_lens.device.type == "cpu":
+            prepared = tuple(int(x) for x in meta.context_lens.tolist())
+        if prepared is None:
+            raise RuntimeError(f"H2O prefill scoring requires CPU context lengths prepared for layer={layer_idx}.")
+        if tuple(prepared) != context_lens:
+            raise RuntimeError("H2O prefill score view is not in compressed physical coordinates: "
+                               f"layer={layer_idx} view={tuple(prepared)} physical={context_lens}.")
         d = q.device
         key, cache_lens, starts, ends = self._prefill_score_meta_tensors(ranges, d)
-        max_ctx = max(r[4] for r in ranges)
-        fused, self._fused_prefill_stats = getattr(self, "_fused_prefill_stats", None), None
-        k_cache, _ = self.get_layer_kv_cache(layer_idx)
-        if fused is not None and fused[0] == int(layer_idx) and fused[1] == key:
-            # the attention launch of this layer and chunk left the statistics and the cleared rows: final pass only
-            step = fused[3]
-            self._run_prefill_score(q, k_cache, step, layer_idx, b_start_loc, cache_lens, max(r[4] - r[3] for r in ranges),
-                                    starts, ends, candidate_start=0, num_recent_tokens=0, row_stats=fused[2])
+        max_q = max(r[4] - r[3] for r in ranges)
+        stats = (payload.metadata or {}).get("score_stats")
+        if (stats is not None and stats["layer"] == int(layer_idx) and stats["key"] == key
+                and stats["written_for"] == (q.data_ptr(), q._version, tuple(q.shape))):
+            # the attention launch of this layer and chunk, on this very q, left the statistics and the cleared rows:
+            # final pass only
+            step = stats["step"]
+            self._run_prefill_score(q, payload.k_cache, step, meta, b_start_loc, cache_lens, max_q, starts, ends,
+                                    candidate_start=0, num_recent_tokens=0, row_stats=stats["row_stats"])
         else:
-            step = torch.empty((len(seqs), max_ctx), dtype=torch.float32, device=d)
-            self._run_prefill_score(q, k_cache, step, layer_idx, b_start_loc, cache_lens, max(r[4] - r[3] for r in ranges),
-                                    starts, ends, candidate_start=0, num_recent_tokens=0)
+            step = torch.empty((len(seqs), max(context_lens)), dtype=torch.float32, device=d)
+            self._run_prefill_score(q, payload.k_cache, step, meta, b_start_loc, cache_lens, max_q, starts, ends,
+                                    candidate_start=0, num_recent_tokens=0)
         kv = self.kv_layer_index(layer_idx)
         for b, seq, cache_len, start, end in ranges:
             row = self.seq_id_to_row[layer_idx][int(seq.seq_id)]

@@ -22,7 +22,9 @@ import numpy as np
 import torch
 
 from ...kernels import h2o_ops
-from .base import CacheManager, LayerBatchStates
+from ...utils.context import get_context
+from ...utils.profiler import profiler
+from .base import CacheManager, ExplicitKVPayload, LayerBatchStates, PrefillComputeView
 
 
 class SnapKVCacheManager(CacheManager):
@@ -31,6 +33,7 @@ class SnapKVCacheManager(CacheManager):
         self._uniform_decode_metadata = False
         self._prefill_attn_score_accumulators: dict[tuple[int, int], torch.Tensor] = {}
         self._prefill_score_workspace = None
+        self._prefill_context_lens_cpu_by_layer: dict[int, tuple[int, ...]] = {}
         self.allocate_kv_cache()
 
     # ------------------------------------------------------------------ allocation
@@ -139,6 +142,7 @@ class SnapKVCacheManager(CacheManager):
             st.context_lens = torch.tensor(ctx, dtype=torch.int32, device=d)
             st.req_indices = torch.tensor(rows, dtype=torch.int32, device=d)
             st.max_context_len = max(ctx) if ctx else 0
+            self._prefill_context_lens_cpu_by_layer[int(layer_idx)] = tuple(ctx)
         cu = np.concatenate(([0], np.cumsum(chunk_lens))).astype(np.int32)
         return torch.from_numpy(cu).to(d), total
 
@@ -200,51 +204,69 @@ class SnapKVCacheManager(CacheManager):
     def _prefill_score_initial_value(self) -> float:
         return float("-inf") if getattr(self.config, "sparse_prefill_score_mode", "probability") == "logits" else 0.0
 
-    def _run_prefill_score(self, q, k_cache, step_score, layer_idx, b_start_loc, b_prompt_cache_len, max_score_len,
+    def _run_prefill_score(self, q, k_cache, step_score, meta, b_start_loc, b_prompt_cache_len, max_score_len,
                            score_starts, score_ends, *, candidate_start: int, num_recent_tokens: int, batch_indices=None,
                            row_stats=None):
-        """snapkv.py:1050-1085 -> svk_prefill_score."""
+        """snapkv.py:1050-1085 -> svk_prefill_score over the view's slot table (`meta` = the AttentionViewMeta of the
+        layer's PrefillComputeView)."""
         from ...kernels.prefill_score import PrefillScoreWorkspace, prefill_score_fwd
         if self._prefill_score_workspace is None:
             self._prefill_score_workspace = PrefillScoreWorkspace()
-        st = self.layer_batch_states[layer_idx]
-        prefill_score_fwd(q, k_cache, step_score, st.req_indices, b_start_loc, st.context_lens, b_prompt_cache_len,
-                          int(max_score_len), self.get_layer_buffer_req_to_token_slots(layer_idx), score_starts, score_ends,
-                          candidate_start=candidate_start, num_recent_tokens=num_recent_tokens,
-                          score_mode=self.config.sparse_prefill_score_mode, workspace=self._prefill_score_workspace,
-                          batch_indices=batch_indices, row_stats=row_stats)
+        with profiler.record("prefill_token_score"):
+            prefill_score_fwd(q, k_cache, step_score, meta.req_indices, b_start_loc, meta.context_lens, b_prompt_cache_len,
+                              int(max_score_len), meta.active_slots, score_starts, score_ends,
+                              candidate_start=candidate_start, num_recent_tokens=num_recent_tokens,
+                              score_mode=self.config.sparse_prefill_score_mode, workspace=self._prefill_score_workspace,
+                              batch_indices=batch_indices, row_stats=row_stats)
+
+    def _get_prefill_attention_score_accumulator(self, layer_idx: int, seq, *, prompt_len: int, device):
+        """snapkv.py:1017-1044: the per-(layer, sequence) element-wise-max accumulator; a prompt that starts over
+        (num_prefilled_tokens == 0) starts from the mode's neutral value."""
+        key = (int(layer_idx), int(seq.seq_id))
+        if int(seq.num_prefilled_tokens) == 0:
+            self._prefill_attn_score_accumulators.pop(key, None)
+        acc = self._prefill_attn_score_accumulators.get(key)
+        if acc is None:
+            acc = torch.full((int(prompt_len),), self._prefill_score_initial_value(), dtype=torch.float32, device=device)
+            self._prefill_attn_score_accumulators[key] = acc
+        return acc
 
     @torch.no_grad()
-    def collect_prefill_attention_score(self, layer_idx: int, q: torch.Tensor, seqs, *, b_start_loc: torch.Tensor):
+    def collect_prefill_attention_score(self, layer_idx: int, q: torch.Tensor, view: PrefillComputeView, *,
+                                        b_start_loc: torch.Tensor, chunk_lens: torch.Tensor):
         """snapkv.py:1216-1304: score the row with the last-window queries of the final chunk
         (candidates [sink, len - recent)), max-accumulate per (layer, sequence)."""
+        ctx = get_context()
+        if not ctx.is_prefill:
+            return None
         if self.config.vllm_sparse_method != "snapkv":
             return None
+        seqs = getattr(ctx, "seqs", None)
+        if seqs is None:
+            raise RuntimeError("Prefill score collection requires current seqs in context.")
         rows = self._prefill_score_rows(layer_idx, seqs)
         if not rows:
             return None
+        if not isinstance(view.payload, ExplicitKVPayload):
+            raise TypeError(f"SnapKV prefill scoring requires ExplicitKVPayload, got {type(view.payload).__name__}.")
+        meta, payload = view.meta, view.payload
+        if int(chunk_lens.ndim) != 1 or int(chunk_lens.shape[0]) != len(seqs):
+            raise RuntimeError("SnapKV prefill scoring chunk-length batch mismatch: "
+                               f"shape={tuple(chunk_lens.shape)} seqs={len(seqs)}.")
         d = q.device
-        st = self.layer_batch_states[layer_idx]
-        ctx = [int(self.row_seq_lens[layer_idx][self.seq_id_to_row[layer_idx][s.seq_id]]) for s in seqs]
-        cache_lens = torch.tensor([c - int(s.current_chunk_size) for c, s in zip(ctx, seqs)], dtype=torch.int32, device=d)
+        ctx_lens = [int(self.row_seq_lens[layer_idx][self.seq_id_to_row[layer_idx][s.seq_id]]) for s in seqs]
+        cache_lens = torch.tensor([c - int(s.current_chunk_size) for c, s in zip(ctx_lens, seqs)], dtype=torch.int32, device=d)
         bi = torch.tensor([r[0] for r in rows], dtype=torch.int32, device=d)
         starts = torch.tensor([r[2] for r in rows], dtype=torch.int32, device=d)
         ends = torch.tensor([r[3] for r in rows], dtype=torch.int32, device=d)
-        max_ctx = max(ctx[r[0]] for r in rows)
+        max_ctx = max(ctx_lens[r[0]] for r in rows)
         step = torch.empty((len(rows), max_ctx), dtype=torch.float32, device=d)
-        k_cache, _ = self.get_layer_kv_cache(layer_idx)
-        self._run_prefill_score(q, k_cache, step, layer_idx, b_start_loc, cache_lens, max(r[3] - r[2] for r in rows),
+        self._run_prefill_score(q, payload.k_cache, step, meta, b_start_loc, cache_lens, max(r[3] - r[2] for r in rows),
                                 starts, ends, candidate_start=int(self.config.num_sink_tokens),
                                 num_recent_tokens=int(self.config.num_recent_tokens), batch_indices=bi)
         for i, (b_idx, seq, _s, _e) in enumerate(rows):
-            n = ctx[b_idx]
-            key = (int(layer_idx), int(seq.seq_id))
-            if int(seq.num_prefilled_tokens) == 0:
-                self._prefill_attn_score_accumulators.pop(key, None)
-            acc = self._prefill_attn_score_accumulators.get(key)
-            if acc is None:
-                acc = torch.full((n,), self._prefill_score_initial_value(), dtype=torch.float32, device=d)
-                self._prefill_attn_score_accumulators[key] = acc
+            n = ctx_lens[b_idx]
+            acc = self._get_prefill_attention_score_accumulator(layer_idx, seq, prompt_len=n, device=d)
             torch.maximum(acc[:n], step[i, :n], out=acc[:n])
         return None
 

@@ -254,9 +254,9 @@ class SparseDecodeDriver:
     @torch.no_grad()
     def prefill_chunk(self, seqs, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None):
         """The sparse side of one chunked-prefill step (ModelRunner.run prefill branch,
-        model_runner.py:1447-1481): allocate the chunk, store its K/V, collect the method's prefill
-        token scores with the chunk's queries, then the post-forward eviction.  With `outputs`
-        [L, tokens, Hq, D] the chunk's causal attention (context_attention_fwd) is computed too.
+        model_runner.py:1447-1481): allocate the chunk, per layer store its K/V and run `Attention.forward`
+        (causal attention of the chunk + the manager's prefill hooks, which collect the method's token scores),
+        then the post-forward eviction.  `outputs` [L, tokens, Hq, D] receives the attention outputs.
         q [L, tokens, Hq, D], k/v [L, tokens, Hkv, D]; every seq needs `current_chunk_size`."""
         cm, sc = self.cache_manager, self.sparse_controller
         out = cm._prepare_prefill(seqs)
@@ -268,17 +268,20 @@ class SparseDecodeDriver:
         ctx.max_chunk_len = max(int(s.current_chunk_size) for s in seqs)
         ctx.seqs = seqs
         sc.prepare_forward(seqs, True)
-        collect = getattr(cm, "collect_prefill_attention_score", None)
         save_raw = getattr(cm, "save_raw_kv_if_needed", None)
+        # a manager without a prompt-side attention view in this build (DeltaKV) runs the store / compression side only
+        run_attention = outputs is not None or bool(getattr(cm, "prefill_attention_view_supported", True))
         for layer_idx in range(cm.num_layers):
             ctx.now_layer_idx = layer_idx
             if save_raw is not None:          # DeltaKV sparse layers keep the pre-RoPE key
                 save_raw(layer_idx, k[layer_idx], v[layer_idx])
+            # models/qwen2.py:126-131: the model stores the chunk's K/V, then calls the attention layer, whose prefill
+            # branch runs the manager's hooks (selection, compute view, attention, score collection) in the reference's order
             cm.save_rope_kv_if_needed(layer_idx, k[layer_idx], v[layer_idx])
-            if outputs is not None:
-                outputs[layer_idx].copy_(self.attn(q[layer_idx]))
-            if collect is not None:
-                collect(layer_idx, q[layer_idx], seqs, b_start_loc=cu[:-1])
+            if run_attention:
+                o = self.attn(q[layer_idx], k[layer_idx], v[layer_idx])
+                if outputs is not None:
+                    outputs[layer_idx].copy_(o)
         sc.post_forward(seqs, True)
         cm.on_forward_end(seqs, True)
         for s in seqs:

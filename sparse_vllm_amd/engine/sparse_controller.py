@@ -246,20 +246,38 @@ class SparseController:
             self.layer_batch_sparse_states[layer_idx].attn_score = reduced[kv_idx]
 
     # ------------------------------------------------------------------ per layer
-    def get_decode_selection(self, layer_idx: int, q: torch.Tensor) -> SparseSelection:
-        """sparse_controller.py:881-910 (kind="full": attend the whole physical row)."""
+    def _build_selection(self, layer_idx: int, *, is_prefill: bool, q: torch.Tensor | None = None) -> SparseSelection:
+        """sparse_controller.py:881-935: the logical selection only; cache managers build the physical views.
+        kind="full" (attend the whole physical row) for every method of this build except DeltaKV's sparse layers."""
+        if not self._is_kv_layer(layer_idx):
+            raise RuntimeError(f"layer_idx={layer_idx} is linear_attention and has no KV sparse selection")
         s = self.layer_batch_sparse_states[layer_idx]
         if self.is_deltakv_family and layer_idx not in self.full_attn_layers:
-            # sparse_controller.py:912-935: batch-major view, K selected compressed positions (-1 padded / None = 0)
+            # :912-935: batch-major view, K selected compressed positions (-1 padded / None = 0)
+            chunk_lens = None
+            if is_prefill:
+                cu = get_context().cu_seqlens_q
+                if cu is not None and cu.numel() > 1:
+                    chunk_lens = (cu[1:] - cu[:-1]).to(torch.int32)
             return SparseSelection(kind="deltakv", req_indices=s.global_req_indices, context_lens=s.context_lens,
                                    max_context_len=s.max_context_len, attn_score=s.attn_score,
                                    active_compressed_indices=s.active_compressed_indices,
-                                   global_req_indices=s.global_req_indices, chunk_lens=None,
+                                   global_req_indices=s.global_req_indices, chunk_lens=chunk_lens,
                                    release_temp_slots=s.deltakv_free_temp_slots)
         req = s.global_req_indices if self.is_deltakv_family else s.req_indices
         return SparseSelection(kind="full", req_indices=req, context_lens=s.context_lens,
                                max_context_len=s.max_context_len, attn_score=s.attn_score,
                                global_req_indices=s.global_req_indices)
+
+    def get_prefill_selection(self, layer_idx: int) -> SparseSelection:
+        """sparse_controller.py:957-958."""
+        return self._build_selection(layer_idx, is_prefill=True)
+
+    def get_decode_selection(self, layer_idx: int, q: torch.Tensor, active_slots=None, req_indices=None,
+                             context_lens=None) -> SparseSelection:
+        """sparse_controller.py:960-969."""
+        del active_slots, req_indices, context_lens
+        return self._build_selection(layer_idx, is_prefill=False, q=q)
 
     def _h2o_new_slots(self, layer_idx: int):
         """This step's slot_mapping of the layer: -1 marks the padded lanes of a graph-sized batch, whose scores the

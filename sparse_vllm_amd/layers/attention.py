@@ -1,17 +1,24 @@
-"""Attention layer for the sparse decode path (mirror of layers/attention.py:75-257 decode
-branch and layers/attention_backend.py:217-349 `run_decode`).
+"""Attention layer of the sparse path (mirror of layers/attention.py:75-257 and of
+layers/attention_backend.py:113-153 `run_prefill`, :217-349 `run_decode`).
 
 Per-layer call order is the reference's:
-    get_decode_selection -> build_decode_compute_view -> get_decode_block_seq -> run_decode
-    -> record_decode_query -> sparse_controller.on_layer_attention_end
-    -> cache_manager.on_layer_attention_end -> release_layer_temp_slots (finally)
+    prefill (:88-161): sparse_controller.get_prefill_selection -> cache_manager.before_prefill_layer_attention
+        -> cache_manager.build_prefill_compute_view (ExplicitKVPayload or TypeError) -> [fake | run_prefill]
+        -> cache_manager.collect_prefill_attention_score(layer, q, view, b_start_loc=, chunk_lens=)
+        -> cache_manager.record_prefill_query(layer, q, view, b_start_loc=, chunk_lens=)
+    decode (:162-250): get_decode_selection -> build_decode_compute_view -> get_decode_block_seq -> run_decode
+        -> record_decode_query
+    both: sparse_controller.on_layer_attention_end -> cache_manager.on_layer_attention_end
+        -> release_layer_temp_slots (finally)
 """
 
 from __future__ import annotations
 
+import os
+
 import torch
 
-from ..engine.cache_manager.base import DecodeComputeView, ExplicitKVPayload
+from ..engine.cache_manager.base import DecodeComputeView, ExplicitKVPayload, PrefillComputeView
 from ..kernels import flash_decode_stage1, flash_decode_stage1_with_score, flash_decode_stage2
 from ..kernels.context_flashattention_nopad import context_attention_fwd
 from ..kernels.gqa_flash_decoding_stage1 import direct_out_supported
@@ -36,8 +43,120 @@ def get_decode_workspace(context, batch_size: int, num_heads: int, num_blocks: i
     return (mid_o[:batch_size, :num_heads, :num_blocks, :head_dim], mid_lse[:batch_size, :num_heads, :num_blocks])
 
 
+def _env_truthy(name: str) -> bool:
+    return os.environ.get(name, "").lower() in {"1", "true", "yes", "on"}
+
+
+def _fake_prefill_attention_enabled() -> bool:
+    """layers/attention_backend.py:25-47: SPARSEVLLM_FAKE_{PREFILL_,}ATTENTION, refused unless
+    SPARSEVLLM_ALLOW_FAKE_ATTENTION=1 (a fake output invalidates correctness and benchmark results)."""
+    enabled = _env_truthy("SPARSEVLLM_FAKE_PREFILL_ATTENTION") or _env_truthy("SPARSEVLLM_FAKE_ATTENTION")
+    if enabled and not _env_truthy("SPARSEVLLM_ALLOW_FAKE_ATTENTION"):
+        raise RuntimeError(
+            "Sparse-vLLM fake attention was requested, but it is disabled by default because it "
+            "invalidates correctness and benchmark results. Set SPARSEVLLM_ALLOW_FAKE_ATTENTION=1 "
+            "only for explicit fake-attention tests or profiling.")
+    return enabled
+
+
+def _fake_attention_output(q: torch.Tensor) -> torch.Tensor:
+    """layers/attention_backend.py:58-69."""
+    mode = os.environ.get("SPARSEVLLM_FAKE_ATTENTION_MODE", "zero").strip().lower()
+    if mode in {"zero", "zeros"}:
+        return torch.zeros_like(q)
+    if mode == "copy":
+        return q.clone()
+    if mode == "empty":
+        return torch.empty_like(q)
+    raise ValueError("SPARSEVLLM_FAKE_ATTENTION_MODE must be one of 'zero', 'copy', or 'empty', "
+                     f"got {mode!r}.")
+
+
+def _require_explicit_payload(view, *, operation: str) -> ExplicitKVPayload:
+    payload = view.payload
+    if not isinstance(payload, ExplicitKVPayload):
+        raise TypeError(f"{operation} requires ExplicitKVPayload, got {type(payload).__name__}.")
+    return payload
+
+
 class HipAttentionBackend:
-    """layers/attention_backend.py `TritonAttentionBackend.run_decode` on libsvk."""
+    """layers/attention_backend.py `TritonAttentionBackend.run_prefill / run_decode` on libsvk."""
+
+    name = "hip"
+
+    def maybe_run_fake_prefill(self, q: torch.Tensor, view: PrefillComputeView, *, chunk_lens: torch.Tensor,
+                               max_input_len: int) -> torch.Tensor | None:
+        """layers/attention_backend.py:97-111 (tests of the hook order without a GPU)."""
+        if not _fake_prefill_attention_enabled():
+            return None
+        if view.meta.attn_score is not None:
+            view.meta.attn_score.zero_()
+        return _fake_attention_output(q)
+
+    def debug_check_prefill_bounds(self, q: torch.Tensor, view: PrefillComputeView, *, chunk_lens: torch.Tensor) -> None:
+        """layers/attention_backend.py:155-215: host-side bound check of the prompt view, SVLLM_DEBUG_PREFILL_BOUNDS=1."""
+        if os.environ.get("SVLLM_DEBUG_PREFILL_BOUNDS", "0") != "1":
+            return
+        if q.is_cuda and torch.cuda.is_current_stream_capturing():
+            return
+        meta = view.meta
+        if int(chunk_lens.sum().item()) != int(q.shape[0]):
+            raise RuntimeError(f"prefill chunk_lens sum {int(chunk_lens.sum().item())} != q tokens {int(q.shape[0])}")
+        if meta.active_slots.dim() == 2 and meta.context_lens.numel() > 0:
+            if int(meta.context_lens.max().item()) > int(meta.active_slots.shape[1]):
+                raise RuntimeError("prefill context length exceeds active slot table width: "
+                                   f"context_lens_max={int(meta.context_lens.max().item())} "
+                                   f"slot_table_len={int(meta.active_slots.shape[1])}")
+            rows = int(meta.active_slots.shape[0])
+            req = meta.req_indices
+            if int(req.min().item()) < 0 or int(req.max().item()) >= rows:
+                raise RuntimeError(f"prefill req_indices out of range for {rows} slot-table rows")
+
+    def run_prefill(self, q: torch.Tensor, view: PrefillComputeView, *, b_start_loc: torch.Tensor,
+                    chunk_lens: torch.Tensor, max_input_len: int) -> torch.Tensor:
+        """layers/attention_backend.py:113-153: causal attention of the chunk's queries over [cached prefix | chunk]
+        through the view's slot table."""
+        payload = _require_explicit_payload(view, operation="HIP prefill")
+        meta = view.meta
+        b_seq_len = meta.context_lens
+        if b_seq_len.numel() != chunk_lens.numel():
+            layer_idx = getattr(get_context(), "now_layer_idx", None)
+            raise RuntimeError(
+                "prefill context_lens/chunk_lens batch mismatch: "
+                f"layer={layer_idx} context_lens_shape={tuple(b_seq_len.shape)} "
+                f"chunk_lens_shape={tuple(chunk_lens.shape)} q_shape={tuple(q.shape)} "
+                f"req_indices_shape={tuple(meta.req_indices.shape)} "
+                f"active_slots_shape={tuple(meta.active_slots.shape)}")
+        md = payload.metadata or {}
+        # b_seq_len - chunk_lens, derived once per chunk by the caller when it can (one small launch per layer otherwise)
+        b_prompt_cache_len = md.get("b_prompt_cache_len")
+        if b_prompt_cache_len is None:
+            ctx = get_context()
+            key = (b_seq_len.data_ptr(), b_seq_len._version, chunk_lens.data_ptr(), chunk_lens._version)
+            cached = getattr(ctx, "_prefill_cache_len", None)
+            if cached is None or cached[0] != key:
+                cached = ctx._prefill_cache_len = (key, b_seq_len - chunk_lens)
+            b_prompt_cache_len = cached[1]
+        self.debug_check_prefill_bounds(q, view, chunk_lens=chunk_lens)
+        if _fake_prefill_attention_enabled():
+            if meta.attn_score is not None:
+                meta.attn_score.zero_()
+            return _fake_attention_output(q)
+        o = torch.empty_like(q)
+        # the kernel's grid is ceil(max_input_len / tile) query tiles per sequence: the reference passes the longest
+        # CONTEXT (an upper bound, surplus programs exit); the host-known longest CHUNK is the tight bound
+        max_chunk = get_context().max_chunk_len
+        grid_len = int(max_input_len) if max_chunk is None else min(int(max_input_len), int(max_chunk))
+        # MI355X: a manager whose prefill token scores use the attention's own softmax statistics (H2O, probability
+        # mode) put a request into the view's payload; the launch leaves the statistics behind and says so
+        stats = md.get("score_stats")
+        with profiler.record("prefill_attention"):
+            context_attention_fwd(q, payload.k_cache, payload.v_cache, o, meta.req_indices, b_start_loc, b_seq_len,
+                                  b_prompt_cache_len, grid_len, meta.active_slots, attn_score=meta.attn_score,
+                                  score_stats=None if stats is None else stats["request"])
+        if stats is not None:
+            stats["written_for"] = (q.data_ptr(), q._version, tuple(q.shape))
+        return o
 
     def run_decode(self, q: torch.Tensor, view: DecodeComputeView, *, mid_o, mid_o_logexpsum, max_len_in_batch: int,
                    block_seq: int, num_heads: int, num_kv_heads: int, gqa_block_n: int = 16,
@@ -116,43 +235,7 @@ class Attention(torch.nn.Module):
         sparse_controller = context.sparse_controller
         layer_idx = context.now_layer_idx
         if context.is_prefill:
-            # layers/attention.py:88-140 + attention_backend.py:113-155 (`run_prefill`): causal attention of the chunk's
-            # queries over the sequence's physical row (cached prefix + the chunk just stored)
-            if context.cu_seqlens_q is None or context.cu_seqlens_q.numel() <= 1:
-                return torch.empty_like(q)
-            guard = getattr(cache_manager, "check_prefill_attention_view", None)
-            if guard is not None:
-                guard(layer_idx)          # managers whose prompt view is not the plain slot table refuse here
-            st = cache_manager.get_layer_batch_states(layer_idx)
-            k_cache, v_cache = cache_manager.get_layer_kv_cache(layer_idx)
-            b_seq_len = st.context_lens
-            # derived once per chunk, not once per layer (three small launches per layer otherwise): keyed on the storage
-            # and version of the tensors they come from
-            cu = context.cu_seqlens_q
-            key = (cu.data_ptr(), cu._version, int(cu.numel()), b_seq_len.data_ptr(), b_seq_len._version)
-            cached = getattr(context, "_prefill_derived", None)
-            if cached is None or cached[0][:3] != key[:3]:
-                b_start_loc = cu[:-1].to(torch.int32)
-                chunk_lens = (cu[1:] - cu[:-1]).to(torch.int32)
-                cached = (key, b_start_loc, chunk_lens, None)
-            if cached[3] is None or cached[0] != key:
-                cached = (key, cached[1], cached[2], b_seq_len - cached[2] if b_seq_len.numel() == cached[2].numel() else None)
-            context._prefill_derived = cached
-            _, b_start_loc, chunk_lens, prompt_cache_len = cached
-            if b_seq_len.numel() != chunk_lens.numel():
-                raise RuntimeError("prefill context_lens/chunk_lens batch mismatch: "
-                                   f"layer={layer_idx} context_lens_shape={tuple(b_seq_len.shape)} "
-                                   f"chunk_lens_shape={tuple(chunk_lens.shape)} q_shape={tuple(q.shape)}")
-            o = torch.empty_like(q)
-            # MI355X: a manager whose prefill token scores use the attention's own softmax statistics (H2O, probability
-            # mode) asks the launch to leave them behind; its collect_prefill_attention_score then runs one scoring pass
-            request = getattr(cache_manager, "prefill_attention_score_request", None)
-            score_stats = request(layer_idx, q) if request is not None else None
-            with profiler.record("prefill_attention"):
-                context_attention_fwd(q, k_cache, v_cache, o, st.req_indices, b_start_loc, b_seq_len, prompt_cache_len,
-                                      int(context.max_chunk_len or q.shape[0]),
-                                      cache_manager.get_layer_buffer_req_to_token_slots(layer_idx), score_stats=score_stats)
-            return o
+            return self._forward_prefill(context, cache_manager, sparse_controller, layer_idx, q, k, v)
         temp_slots = None
         # this step's K/V rows: stored here (explicit launch), or inside the stage-1 launch when the manager allows it
         new_kv = None
@@ -206,6 +289,59 @@ class Attention(torch.nn.Module):
                 new_kv=new_kv, take_deferred_score=getattr(sparse_controller, "take_deferred_score", None),
                 direct_ok=True if direct_allowed is None else bool(direct_allowed(layer_idx, batch_size)))
             cache_manager.record_decode_query(layer_idx, q)
+            sparse_controller.on_layer_attention_end(layer_idx)
+            cache_manager.on_layer_attention_end(layer_idx)
+            return o
+        finally:
+            if temp_slots is not None and temp_slots.numel() > 0:
+                cache_manager.release_layer_temp_slots(layer_idx, temp_slots)
+
+    def _forward_prefill(self, context, cache_manager, sparse_controller, layer_idx, q, k, v):
+        """layers/attention.py:88-161 hook for hook (the chunk's K/V were stored by the caller, models/qwen2.py:126-131)."""
+        temp_slots = None
+        try:
+            selection = sparse_controller.get_prefill_selection(layer_idx)
+            cache_manager.before_prefill_layer_attention(layer_idx, selection)
+            prefill_view = cache_manager.build_prefill_compute_view(layer_idx, k, v, selection)
+            if not isinstance(prefill_view.payload, ExplicitKVPayload):
+                raise TypeError("Attention prefill requires ExplicitKVPayload, got "
+                                f"{type(prefill_view.payload).__name__}.")
+            prefill_meta = prefill_view.meta
+            temp_slots = prefill_meta.temp_slots
+
+            if context.cu_seqlens_q is None or context.cu_seqlens_q.numel() <= 1:
+                return torch.empty_like(q)
+
+            # derived once per chunk, not once per layer (two small launches per layer otherwise): keyed on the storage
+            # and version of cu_seqlens_q
+            cu = context.cu_seqlens_q
+            key = (cu.data_ptr(), cu._version, int(cu.numel()))
+            cached = getattr(context, "_prefill_derived", None)
+            if cached is None or cached[0] != key:
+                b_start_loc = cu[:-1]
+                chunk_lens = cu[1:] - cu[:-1]
+                if cu.dtype != torch.int32:
+                    b_start_loc, chunk_lens = b_start_loc.to(torch.int32), chunk_lens.to(torch.int32)
+                cached = context._prefill_derived = (key, b_start_loc, chunk_lens)
+            _, b_start_loc, chunk_lens = cached
+            max_context_len = prefill_meta.max_context_len
+            if max_context_len is not None:
+                max_input_len = int(max_context_len)
+            elif q.is_cuda and torch.cuda.is_current_stream_capturing():
+                max_input_len = int(prefill_meta.active_slots.shape[1])
+            else:
+                max_input_len = int(prefill_meta.context_lens.max().item())
+
+            fake_output = self.attention_backend.maybe_run_fake_prefill(
+                q, prefill_view, chunk_lens=chunk_lens, max_input_len=max_input_len)
+            if fake_output is not None:
+                o = fake_output
+            else:
+                o = self.attention_backend.run_prefill(q, prefill_view, b_start_loc=b_start_loc, chunk_lens=chunk_lens,
+                                                       max_input_len=max_input_len)
+            cache_manager.collect_prefill_attention_score(layer_idx, q, prefill_view, b_start_loc=b_start_loc,
+                                                          chunk_lens=chunk_lens)
+            cache_manager.record_prefill_query(layer_idx, q, prefill_view, b_start_loc=b_start_loc, chunk_lens=chunk_lens)
             sparse_controller.on_layer_attention_end(layer_idx)
             cache_manager.on_layer_attention_end(layer_idx)
             return o

@@ -1386,6 +1386,84 @@ def gen_capacity_others():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+# ----------------------------------------------------------------------------------
+# Attention.forward prefill branch: hook order + arguments (layers/attention.py:88-161)
+# ----------------------------------------------------------------------------------
+def gen_attention_hooks():
+    """(A) The reference's `Attention.forward` prefill branch run on recording stand-ins of the cache manager / sparse
+    controller (tests/hook_trace.py - shared with the test of this build's mirror) under the reference's fake-attention
+    switches: the hook sequence, argument shapes / values, results and exception texts.  (B) The same branch over a REAL
+    hand-built H2OCacheManager for two prompt chunks x two layers with `_run_prefill_score` replaced by a deterministic
+    stand-in (as tests/test_h2o_cache_manager.py:418-448 does): what the scoring launch is asked for and the cumulative
+    H2O score rows afterwards."""
+    import json
+    sys.path.insert(0, os.path.dirname(HERE))
+    import hook_trace as ht
+    from sparsevllm.engine.cache_manager import base as rb
+    from sparsevllm.layers.attention import Attention
+    from sparsevllm.utils.context import get_context, set_context
+
+    types = SimpleNamespace(SparseSelection=rb.SparseSelection, AttentionViewMeta=rb.AttentionViewMeta,
+                            ExplicitKVPayload=rb.ExplicitKVPayload, PrefillComputeView=rb.PrefillComputeView)
+
+    def install(is_prefill, cu, cm, sc, layer, seqs=None):
+        set_context(is_prefill, cu_seqlens_q=cu, cache_manager=cm, seqs=seqs)
+        ctx = get_context()
+        ctx.sparse_controller = sc
+        ctx.now_layer_idx = layer
+
+    out = {"cases": {c["name"]: ht.run_case(c, attention_cls=Attention, types=types, install_context=install)
+                     for c in ht.CASES}}
+
+    # ---- (B)
+    F = ht.H2O_FLOW
+    L, B = F["layers"], len(F["chunks"][0])
+    m = _make_manager([[0] * B] * L, cap=96, nslots=256, budget=48, interval=16, prefill_budget=64, heads=F["kv_heads"],
+                      dim=F["dim"])
+    m.config.h2o_prefill_score_window = F["window"]
+    m._pyramidkv_prefill_staging_active = False          # PyramidKV staging (out of scope) is off: snapkv.py:533-539
+    c = _make_controller(sink=0, recent=0, keep=0, method="h2o", cache_manager=m, num_layers=L)
+    calls = []
+    m._run_prefill_score = ht.fake_prefill_score_fn(calls)
+    os.environ["SPARSEVLLM_FAKE_ATTENTION"] = "1"
+    os.environ["SPARSEVLLM_ALLOW_FAKE_ATTENTION"] = "1"
+    try:
+        attn = Attention(F["heads"], F["dim"], F["dim"] ** -0.5, F["kv_heads"])
+        done = [0] * B
+        for chunk in F["chunks"]:
+            seqs = [SimpleNamespace(seq_id=i, num_prompt_tokens=sum(ch[i] for ch in F["chunks"]), num_prefilled_tokens=done[i],
+                                    current_chunk_size=n) for i, n in enumerate(chunk)]
+            cu = torch.tensor(np.concatenate(([0], np.cumsum(chunk))), dtype=torch.int32)
+            for l in range(L):
+                for i, n in enumerate(chunk):          # the chunk is appended to the physical row (slots are irrelevant here)
+                    m.row_seq_lens[l][i] += n
+                ctx_lens = [int(m.row_seq_lens[l][i]) for i in range(B)]
+                st = c.layer_batch_sparse_states[l]
+                st.context_lens = torch.tensor(ctx_lens, dtype=torch.int32)
+                st.req_indices = torch.arange(B, dtype=torch.int32)
+                st.global_req_indices = st.req_indices
+                st.max_context_len = max(ctx_lens)
+                st.attn_score = None
+            m._prefill_context_lens_cpu_by_layer = {l: tuple(int(x) for x in m.row_seq_lens[l][:B]) for l in range(L)}
+            n_tok = int(cu[-1])
+            q = torch.zeros((n_tok, F["heads"], F["dim"]), dtype=torch.bfloat16)
+            kv = torch.zeros((n_tok, F["kv_heads"], F["dim"]), dtype=torch.bfloat16)
+            for l in range(L):
+                install(True, cu, m, c, l, seqs=seqs)
+                attn(q, kv, kv)
+            for i, n in enumerate(chunk):
+                done[i] += n
+    finally:
+        os.environ.pop("SPARSEVLLM_FAKE_ATTENTION", None)
+        os.environ.pop("SPARSEVLLM_ALLOW_FAKE_ATTENTION", None)
+    out["h2o_flow"] = {"calls": calls,
+                       "scores": {f"{l}_{i}": [float(x) for x in m._h2o_scores[(l, i)].tolist()] for l in range(L) for i in range(B)}}
+    path = os.path.join(HERE, "attention_hooks.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 GROUPS = {
     "decode_alloc": gen_decode_alloc,
     "decode": gen_decode,
@@ -1406,6 +1484,7 @@ GROUPS = {
     "deltakv_topk": gen_deltakv_topk,
     "method_surface": gen_method_surface,
     "capacity_others": gen_capacity_others,
+    "attention_hooks": gen_attention_hooks,
 }
 
 

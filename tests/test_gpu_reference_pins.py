@@ -147,14 +147,16 @@ def test_snapkv_prefill_collect_and_eviction_product_vs_reference(golden, tag):
         s.current_chunk_size = n
         seqs.append(s)
     starts = np.concatenate(([0], np.cumsum(prompts)[:-1])).astype(np.int32)
-    set_context(True, cu_seqlens_q=t(np.concatenate((starts, [sum(prompts)])).astype(np.int32)), cache_manager=cm,
-                sparse_controller=sc)
+    from sparse_vllm_amd.engine.cache_manager.base import AttentionViewMeta, ExplicitKVPayload, PrefillComputeView
+    ctx = set_context(True, cu_seqlens_q=t(np.concatenate((starts, [sum(prompts)])).astype(np.int32)), cache_manager=cm,
+                      sparse_controller=sc)
+    ctx.seqs = seqs
     for l in range(L):
-        st = cm.layer_batch_states[l]
-        st.context_lens = t(np.array(prompts, np.int32))
-        st.req_indices = t(np.arange(R, dtype=np.int32))
-        st.max_context_len = max(prompts)
-        cm.collect_prefill_attention_score(l, q[l], seqs, b_start_loc=t(starts))
+        # the reference's call (tests/golden/gen_fixtures.py `gen_snapkv_e2e`): a hand-built view of the layer's slot table
+        meta = AttentionViewMeta(active_slots=cm.buffer_req_to_token_slots[l], req_indices=t(np.arange(R, dtype=np.int32)),
+                                 context_lens=t(np.array(prompts, np.int32)), max_context_len=max(prompts))
+        view = PrefillComputeView(meta=meta, payload=ExplicitKVPayload(k_cache=cm.kv_cache[0, l], v_cache=cm.kv_cache[1, l]))
+        cm.collect_prefill_attention_score(l, q[l], view, b_start_loc=t(starts), chunk_lens=t(np.array(prompts, np.int32)))
     torch.cuda.synchronize()
     scored = sorted(k[1] for k in cm._prefill_attn_score_accumulators if k[0] == 0)
     np.testing.assert_array_equal(scored, g[f"{tag}_scored"])
