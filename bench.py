@@ -202,37 +202,15 @@ def main():
     # K/V rows, slot table, lengths and queries as the launches of the step itself.  (Bracketing each
     # launch separately measures the event markers' own system-scope cache flushes and the Python launch
     # latency, 2x the kernel time on this box.  The re-issue is idempotent for the partials and the
-    # fused store; the raw-score buffer already holds this layer's probabilities, the max-combine's
-    # traffic is the same; the previous layer's score epilogue that rides in the launch is pointed at
-    # scratch rows of the same shape.)
+    # fused store; the raw-score buffer already holds this layer's raw scores, the max-combine's
+    # traffic is the same.)
     events = []          # (total_ms, n_launches, row_len)
     record = {"on": False, "calls": []}
     orig = attn_mod.flash_decode_stage1_with_score
 
-    scratch = {}
-
-    def scratch_epilogue(d):
-        """The previous layer's score epilogue that rides in the launch, redirected to scratch rows of the same shape:
-        the re-issued launch does the same work (same reads and writes per row) without adding the probabilities to the
-        real cumulative scores a second time."""
-        from sparse_vllm_amd import _lib
-        if "raw" not in scratch:
-            scratch["raw"] = torch.zeros((int(d.batch), int(d.score_stride_b)), dtype=torch.float32, device=device)
-            scratch["cum"] = torch.zeros_like(cm.h2o_score_tensor[0])
-        e = type(d)()
-        for name, _ in d._fields_:
-            setattr(e, name, getattr(d, name))
-        e.attn_score = _lib.ptr(scratch["raw"])
-        if d.cum_score:
-            e.cum_score = _lib.ptr(scratch["cum"])
-        return e
-
     def capturing_stage1(*a, **kw):
         if record["on"]:
-            kw2 = dict(kw)
-            if kw2.get("deferred_score") is not None:
-                kw2["deferred_score"] = scratch_epilogue(kw2["deferred_score"])
-            record["calls"].append((a, kw2))
+            record["calls"].append((a, dict(kw)))
         return orig(*a, **kw)
 
     def time_captured_launches():

@@ -200,38 +200,6 @@ int svk_h2o_decode_score_update_layers(const SvkH2oDecodeScoreArgs* first, int32
                                        int64_t cum_stride_layer, int64_t new_slot_stride_layer, int64_t req_stride_layer,
                                        int64_t seqlen_stride_layer, svk_stream_t stream);
 
-/* Fused decode epilogue of one H2O layer: svk_flash_decode_stage2 and
- * svk_h2o_decode_score_update in ONE launch (independent workgroups of the same grid), i.e.
- * flash_decoding_stage2.py:49-81 + sparse_controller.py:762-767 + h2o.py:957-1038.
- * Same arguments and results as the two separate calls. */
-typedef struct SvkH2oDecodeFinishArgs {
-  SvkFlashDecodeStage2Args stage2;
-  SvkH2oDecodeScoreArgs score;
-} SvkH2oDecodeFinishArgs;
-int svk_h2o_decode_finish(const SvkH2oDecodeFinishArgs* a, svk_stream_t stream);
-
-/* svk_flash_decode_stage1 of layer l+1 with svk_h2o_decode_score_update of layer l (`prev`) in the SAME launch: the
- * score epilogue of a layer has no consumer before the step's eviction check (sparse_controller.py:1226-1282), so it
- * need not sit between two layers as a latency-bound launch of its own; B extra workgroups do it under the streaming
- * workgroups of the next layer.  Same results as the two calls (prev == NULL: plain stage 1).  Kernels that cannot
- * carry the rows (stage-1 variants other than 3) run the two launches back to back. */
-int svk_flash_decode_stage1_deferred(const SvkFlashDecodeStage1Args* a, const SvkH2oDecodeScoreArgs* prev,
-                                     svk_stream_t stream);
-
-/* One launch for a whole H2O decode layer: svk_flash_decode_stage1 (score_mode HEADMAX) + svk_h2o_decode_finish.  Every
- * workgroup of a batch lane takes a ticket after publishing its partials / token scores; the last one merges the lane's
- * split-KV partials into `o` and normalises + accumulates its token scores.  `tickets` is a caller-owned int32 [B]
- * zeroed once (the kernel resets it).  Same results as the two calls (layers/attention_backend.py:284-349 +
- * sparse_controller.py:762-767 + h2o.py:957-1038). */
-typedef struct SvkH2oDecodeFusedArgs {
-  SvkFlashDecodeStage1Args stage1;   /* score_mode must be SVK_SCORE_HEADMAX                      */
-  SvkH2oDecodeScoreArgs score;       /* attn_score / stride identical to stage1's                 */
-  uint16_t* o;                       /* [B, Hq, D] bf16                                           */
-  int64_t o_stride_b, o_stride_h;
-  int32_t* tickets;                  /* [B] int32, zero before the first launch                   */
-} SvkH2oDecodeFusedArgs;
-int svk_h2o_decode_fused(const SvkH2oDecodeFusedArgs* a, svk_stream_t stream);
-
 /* ------------------------------------------------------------------------------------
  * H2O selection + slot-table compaction
  * ---------------------------------------------------------------------------------- */

@@ -71,15 +71,6 @@ class SvkH2oDecodeScoreArgs(C.Structure):
                 ("score_stride_b", _i64), ("cum_stride", _i64), ("scale", _f32), ("batch", _i32), ("width", _i32)]
 
 
-class SvkH2oDecodeFinishArgs(C.Structure):
-    _fields_ = [("stage2", SvkFlashDecodeStage2Args), ("score", SvkH2oDecodeScoreArgs)]
-
-
-class SvkH2oDecodeFusedArgs(C.Structure):
-    _fields_ = [("stage1", SvkFlashDecodeStage1Args), ("score", SvkH2oDecodeScoreArgs), ("o", _p), ("o_stride_b", _i64),
-                ("o_stride_h", _i64), ("tickets", _p)]
-
-
 class SvkH2oSelectArgs(C.Structure):
     _fields_ = [("scores", _p), ("keep", _p), ("score_stride", _i64), ("keep_stride", _i64),
                 ("rows", _i32), ("kv_len", _i32), ("budget", _i32), ("recent_count", _i32)]
@@ -294,9 +285,6 @@ ENTRY_POINTS = {
     "svk_fill_f32": ([_p, _i64, _f32, _p], C.c_int),
     "svk_h2o_decode_score_update": ([C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
     "svk_h2o_decode_score_update_layers": ([C.POINTER(SvkH2oDecodeScoreArgs), C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _p], C.c_int),
-    "svk_h2o_decode_fused": ([C.POINTER(SvkH2oDecodeFusedArgs), _p], C.c_int),
-    "svk_h2o_decode_finish": ([C.POINTER(SvkH2oDecodeFinishArgs), _p], C.c_int),
-    "svk_flash_decode_stage1_deferred": ([C.POINTER(SvkFlashDecodeStage1Args), C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),
     "svk_h2o_select_indices": ([C.POINTER(SvkH2oSelectArgs), _p], C.c_int),
     "svk_select_prefix_topk_suffix": ([C.POINTER(SvkSelectTopkArgs), _p], C.c_int),
     "svk_compact_rows": ([C.POINTER(SvkCompactRowsArgs), _p], C.c_int),

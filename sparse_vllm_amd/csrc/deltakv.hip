@@ -505,52 +505,9 @@ __global__ void __launch_bounds__(1024) topk_stage_kernel(const SvkTopkSortedArg
   }, true);
 }
 
-// one workgroup per row over the chunks * k candidates (ascending index by construction)
-__global__ void __launch_bounds__(1024) topk_merge_kernel(const SvkTopkSortedArgs a, int kpad, int chunks,
-                                                          const unsigned long long* cand) {
-  __shared__ SelectScratch scratch;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-  unsigned long long* sorted = reinterpret_cast<unsigned long long*>(dyn);
-  uint32_t* keys = reinterpret_cast<uint32_t*>(dyn + sizeof(unsigned long long) * kpad);
-  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const int total = chunks * a.k;
-  const unsigned long long* in = cand + (int64_t)r * total;
-  select_bits_begin(scratch);
-  uint32_t o_bits = 0u, a_bits = 0xffffffffu;
-  for (int j0 = 0; j0 < total; j0 += 8 * nt) {
-    unsigned long long c8[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = j0 + u * nt + tid;
-      c8[u] = i < total ? in[i] : ~0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = j0 + u * nt + tid;
-      if (i < total) {
-        const uint32_t key = (uint32_t)(c8[u] >> 32);
-        keys[i] = key;
-        o_bits |= key;
-        a_bits &= key;
-      }
-    }
-  }
-  select_bits_add(scratch, o_bits, a_bits);
-  for (int i = tid; i < kpad; i += nt) sorted[i] = ~0ull;
-  __syncthreads();
-  // padding entries carry key 0xffffffff with index 0xffffffff: they lose every tie against real entries because
-  // real entries of equal key (there are none unless a score is the all-ones NaN pattern) come first in a chunk
-  block_select_topk_ordered_keys([keys](int i) { return keys[i]; }, total, a.k, scratch, [&](int pos, int i) {
-    sorted[pos] = in[i];
-  }, true);
-  __syncthreads();
-  bitonic_sort_keys(sorted, kpad);
-  for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(sorted[i] & 0xffffffffull);
-}
-
 // ------------------------------------------------------------------------------------
-// long rows (n > kTopkStage), histogram plan: four launches that every CU takes part in instead of `chunks` select
-// workgroups + one merge workgroup (262 k scores, k = 2048: 30 + 34 us -> see DESIGN.md 4.8):
+// long rows (n > kTopkStage), histogram plan: four launches that every CU takes part in (round 2 ran per-chunk selects
+// + one merge workgroup: 30 + 34 us at 262 k scores, k = 2048 -> DESIGN.md 4.8):
 //   topk_prep_kernel     zeroes the row's histogram and leaves the OR / AND of each 4096-key chunk's valid keys
 //   topk_hist_kernel     4096 keys per workgroup -> 4096-bin histogram (LDS, then global atomics) of the 12 key bits
 //                        below the highest bit on which the valid keys differ (probabilities / bf16-valued scores
@@ -837,17 +794,6 @@ __global__ void __launch_bounds__(1024) topk_sorted_kernel(const SvkTopkSortedAr
   for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(keys[i] & 0xffffffffull);
 }
 
-// chunks a row of n scores is split into (1 = single launch), or 0 when the two-level scheme does not fit
-int topk_plan_chunks(int n, int k) {
-  if (n <= kTopkStage) return 1;
-  const int max_chunks = kTopkStage / (k > 0 ? k : 1);          // merge stage: chunks * k keys in LDS
-  if (max_chunks < 2) return 0;
-  int chunks = (n + 16383) / 16384;
-  if (chunks > max_chunks) chunks = max_chunks;
-  const int chunk = (n + chunks - 1) / chunks;
-  return chunk <= 32768 ? chunks : 0;                            // chunk stage: 128 KiB of keys, no sort buffer
-}
-
 __global__ void __launch_bounds__(256) deltakv_decode_alloc_kernel(const SvkDeltakvDecodeAllocArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.graph_batch) return;
@@ -986,19 +932,11 @@ extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_
   return check_launch("svk_deltakv_token_scores");
 }
 
-// 1 = histogram plan for rows longer than one LDS stage (default), 0 = per-chunk selects + merge (SVK_TOPK_PLAN=chunks)
-static bool topk_hist_plan() {
-  const char* v = getenv("SVK_TOPK_PLAN");          // read per call: a few ns, and tests flip it
-  return v == nullptr || strcmp(v, "chunks") != 0;
-}
-
 extern "C" int64_t svk_topk_sorted_workspace_bytes(int32_t rows, int32_t n, int32_t k) {
-  const int chunks = svk::topk_plan_chunks(n, k);
-  const int64_t two_level = chunks > 1 ? (int64_t)sizeof(unsigned long long) * rows * chunks * k : 0;
-  if (n <= svk::kTopkStage) return two_level;
+  (void)k;
+  if (n <= svk::kTopkStage) return 0;
   const int nwg = (n + svk::kTopkHistChunk - 1) / svk::kTopkHistChunk;
-  const int64_t hist = svk::topk_hist_bytes(rows, nwg);
-  return hist > two_level ? hist : two_level;
+  return svk::topk_hist_bytes(rows, nwg);
 }
 
 extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, void* workspace, svk_stream_t stream) {
@@ -1013,11 +951,9 @@ extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, void* workspace,
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     attr_set = true;
   }
-  const int chunks = topk_plan_chunks(a->n, a->k);
-  if (a->n > kTopkStage && workspace != nullptr && topk_hist_plan()) {
+  if (a->n > kTopkStage && workspace != nullptr) {
     const int nwg = (a->n + kTopkHistChunk - 1) / kTopkHistChunk;
     static bool final_attr = false;
     if (!final_attr) {
@@ -1032,17 +968,10 @@ extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, void* workspace,
     hipLaunchKernelGGL(topk_final_kernel, dim3(a->rows), dim3(1024),
                        sizeof(unsigned long long) * kpad + sizeof(int) * (size_t)prefix_ints + sizeof(uint32_t) * (size_t)cap, s, *a,
                        kpad, workspace, nwg, cap);
-  } else if (chunks == 1) {
+  } else if (a->n <= kTopkStage) {
     hipLaunchKernelGGL(topk_stage_kernel, dim3(1, a->rows), dim3(a->n > 2048 ? 1024 : 256),
                        sizeof(unsigned long long) * kpad + sizeof(uint32_t) * (size_t)a->n, s, *a, kpad, a->n, 1,
                        static_cast<unsigned long long*>(nullptr));
-  } else if (chunks > 1 && workspace != nullptr) {
-    const int chunk = (a->n + chunks - 1) / chunks;
-    unsigned long long* cand = static_cast<unsigned long long*>(workspace);
-    hipLaunchKernelGGL(topk_stage_kernel, dim3(chunks, a->rows), dim3(1024), sizeof(uint32_t) * (size_t)chunk, s, *a, kpad,
-                       chunk, chunks, cand);
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(a->rows), dim3(1024),
-                       sizeof(unsigned long long) * kpad + sizeof(uint32_t) * (size_t)chunks * a->k, s, *a, kpad, chunks, cand);
   } else {
     hipLaunchKernelGGL(topk_sorted_kernel, dim3(a->rows), dim3((kpad >= 2048 || a->n > 8192) ? 1024 : 256),
                        sizeof(unsigned long long) * kpad, s, *a, kpad);

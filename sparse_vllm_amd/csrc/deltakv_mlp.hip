@@ -410,8 +410,7 @@ int launch_dequant_linear_act(const SvkDequantLinearArgs* a, const SvkDequantLin
     attr_set = true;
   }
   const dim3 grid((a->n + kBN - 1) / kBN, (a->rows + kBM - 1) / kBM, lb.n_batch), block(256);
-  static const bool wide_tiles = getenv("SVK_DQL_WIDE") == nullptr || atoi(getenv("SVK_DQL_WIDE")) != 0;
-  if (wide_tiles && a->k == 256 && a->group_size == 32 && a->scale_dtype == SVK_DTYPE_BF16 && (a->packed_stride % 4) == 0 &&
+  if (a->k == 256 && a->group_size == 32 && a->scale_dtype == SVK_DTYPE_BF16 && (a->packed_stride % 4) == 0 &&
       (reinterpret_cast<uintptr_t>(a->packed) % 16) == 0 && (a->scale_stride % 2) == 0 &&
       (reinterpret_cast<uintptr_t>(a->scale) % 4) == 0 && (reinterpret_cast<uintptr_t>(a->mn) % 4) == 0 &&
       (lb.n_batch == 1 || lb.scale_stride_batch % 2 == 0)) {

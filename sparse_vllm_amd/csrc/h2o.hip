@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
   }
 }
 
-// All layers of a decode step in one launch (grid = (batch lane, layer)): the score half of h2o_decode_finish_kernel
+// All layers of a decode step in one launch (grid = (batch lane, layer)): the arithmetic of h2o_decode_score_kernel
 // with the layer's pointers.  The row lives in registers (one read, one write of the raw scores and of the cumulative
 // row).  256 threads x 16-byte accesses: eight workgroups per CU keep 8 x 256 x 2 x E4 loads in flight (with 1024 scalar
 // threads per row two workgroups fit a CU and the 3584 rows of a B=128 step took 77 us = 3.1 TB/s).
@@ -132,105 +132,6 @@ __global__ void __launch_bounds__(256) h2o_decode_score_layers_kernel(const SvkH
       }
     }
   }
-}
-
-// ------------------------------------------------------------------------------------
-// fused decode epilogue: [0, B) workgroups normalise + accumulate one score row each (row kept
-// in registers: one HBM/L2 read, one write), the remaining workgroups merge the split-KV
-// partials of 16 (batch lane, q head) pairs each (one wave per pair).  1024-thread workgroups
-// keep the per-row dependency chain short (the score rows are latency-, not bandwidth-bound).
-// ------------------------------------------------------------------------------------
-
-template <int EPT, int PW>
-__global__ void __launch_bounds__(1024) h2o_decode_finish_kernel(const SvkH2oDecodeFinishArgs f) {
-  __shared__ float red[16];
-  const int B = f.score.batch;
-  if ((int)blockIdx.x < B) {
-    const SvkH2oDecodeScoreArgs& a = f.score;
-    const int b = blockIdx.x;
-    float* x = a.attn_score + (int64_t)b * a.score_stride_b;
-    const int W = a.width;
-    // the cumulative row's old values are fetched together with the raw scores, not after the two reductions
-    float* cum = nullptr;
-    int len = 0;
-    if (a.cum_score != nullptr && !(a.b_new_slot != nullptr && a.b_new_slot[b] < 0)) {   // padded graph lanes: no update
-      cum = a.cum_score + (int64_t)a.b_req_idx[b] * a.cum_stride;
-      len = a.b_seqlen[b];
-    }
-    float v[EPT], c[EPT];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int t = threadIdx.x + i * 1024;
-      v[i] = t < W ? mul_rn(x[t], a.scale) : -INFINITY;
-      c[i] = (cum != nullptr && t < len - 1) ? cum[t] : 0.f;
-      mx = fmaxf(mx, v[i]);
-    }
-    mx = block_allmax(mx, red);
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      v[i] = expf(v[i] - mx);          // exp(-inf) = 0 for the padding lanes
-      sum += v[i];
-    }
-    sum = block_allsum(sum, red);
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int t = threadIdx.x + i * 1024;
-      if (t < W) {
-        const float p = v[i] / sum;
-        x[t] = p;
-        if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : c[i] + p;   // pad(prev, 1) + p
-      }
-    }
-    return;
-  }
-  // ---- stage 2 (flash_decoding_stage2.py:19-46): PW waves per (b, h) pair, each taking every PW-th partial;
-  //      lane -> 2 (D=128) or 1 (D=64) dims.  The row maximum of the partial lse's comes first, so the weighted sum
-  //      has no exp chain between iterations and the partial loads are in flight together (small batches split a
-  //      row into 64+ partials: 27 us with the online form and one wave per pair).
-  __shared__ float s_part[16][3 * 64];
-  const SvkFlashDecodeStage2Args& a = f.stage2;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int pair = ((int)blockIdx.x - B) * (16 / PW) + wv / PW;
-  const int sub = wv % PW;
-  const bool live = pair < a.batch * a.num_q_heads;
-  const int b = live ? pair / a.num_q_heads : 0, h = live ? pair % a.num_q_heads : 0;
-  const int D = a.head_dim;
-  const int len = a.b_seqlen[b];
-  const int nblk = (!live || len <= 0) ? 0 : (len + a.block_seq - 1) / a.block_seq;
-  const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h;
-  const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
-  const int d = D == 128 ? lane * 2 : lane;
-  float mxl = -INFINITY;
-  for (int i = lane; i < nblk; i += 64) mxl = fmaxf(mxl, ml[i]);
-  mxl = wave_allmax(mxl);
-  float sum = 0.f, a0 = 0.f, a1 = 0.f;
-#pragma unroll 4
-  for (int i = sub; i < nblk; i += PW) {
-    float t0, t1 = 0.f;
-    if (D == 128) {
-      const float2 tv = *reinterpret_cast<const float2*>(mo + (int64_t)i * a.mid_o_stride_s + d);
-      t0 = tv.x; t1 = tv.y;
-    } else {
-      t0 = mo[(int64_t)i * a.mid_o_stride_s + d];
-    }
-    const float e = __expf(ml[i] - mxl);
-    a0 += e * t0;
-    a1 += e * t1;
-    sum += e;
-  }
-  if constexpr (PW > 1) {
-    s_part[wv][lane] = a0; s_part[wv][64 + lane] = a1; s_part[wv][128 + lane] = sum;
-    __syncthreads();
-    if (sub != 0) return;
-#pragma unroll
-    for (int j = 1; j < PW; ++j) { a0 += s_part[wv + j][lane]; a1 += s_part[wv + j][64 + lane]; sum += s_part[wv + j][128 + lane]; }
-  }
-  if (!live) return;
-  uint16_t* o = a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d;
-  if (D == 128) *reinterpret_cast<uint32_t*>(o) = f32_to_bf16_bits(a0 / sum) | (f32_to_bf16_bits(a1 / sum) << 16);
-  else *o = (uint16_t)f32_to_bf16_bits(a0 / sum);
 }
 
 // ------------------------------------------------------------------------------------
@@ -518,44 +419,6 @@ extern "C" int svk_h2o_decode_score_update_layers(const SvkH2oDecodeScoreArgs* f
   else SVK_SCORE_LAYERS(32);
 #undef SVK_SCORE_LAYERS
   return check_launch("svk_h2o_decode_score_update_layers");
-}
-
-extern "C" int svk_h2o_decode_finish(const SvkH2oDecodeFinishArgs* f, svk_stream_t stream) {
-  using namespace svk;
-  SVK_REQUIRE(f != nullptr && f->score.attn_score != nullptr, SVK_ERR_VALUE, "svk_h2o_decode_finish: null args");
-  const SvkFlashDecodeStage2Args& s2 = f->stage2;
-  const SvkH2oDecodeScoreArgs& sc = f->score;
-  SVK_REQUIRE(s2.head_dim == 64 || s2.head_dim == 128, SVK_ERR_LAYOUT,
-              "svk_h2o_decode_finish: head_dim %d unsupported (64, 128)", s2.head_dim);
-  SVK_REQUIRE(s2.block_seq > 0 && sc.width > 0, SVK_ERR_VALUE, "svk_h2o_decode_finish: block_seq and width must be positive");
-  SVK_REQUIRE(s2.batch == sc.batch, SVK_ERR_VALUE, "svk_h2o_decode_finish: stage2 batch %d != score batch %d", s2.batch, sc.batch);
-  SVK_REQUIRE(sc.cum_score == nullptr || (sc.b_req_idx != nullptr && sc.b_seqlen != nullptr), SVK_ERR_VALUE,
-              "svk_h2o_decode_finish: cum_score needs b_req_idx and b_seqlen");
-  if (sc.batch <= 0) return SVK_OK;
-  if (sc.width > 1024 * 32) {   // row does not fit the register-resident path: two plain launches
-    int rc = svk_flash_decode_stage2(&s2, stream);
-    if (rc != SVK_OK) return rc;
-    return svk_h2o_decode_score_update(&sc, stream);
-  }
-  const int pairs = s2.batch * s2.num_q_heads;
-  // waves per (b, h) pair: the lse row stride is the workspace's partial capacity
-  const int pw = s2.mid_lse_stride_h >= 24 ? 16 : (s2.mid_lse_stride_h >= 6 ? 4 : 1);
-  const int ppw = 16 / pw;
-  dim3 grid(sc.batch + (pairs + ppw - 1) / ppw);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int ept = (sc.width + 1023) / 1024;
-#define SVK_FINISH(EPT_)                                                                                  \
-  do {                                                                                                    \
-    if (pw == 16) hipLaunchKernelGGL((h2o_decode_finish_kernel<EPT_, 16>), grid, dim3(1024), 0, s, *f);   \
-    else if (pw == 4) hipLaunchKernelGGL((h2o_decode_finish_kernel<EPT_, 4>), grid, dim3(1024), 0, s, *f); \
-    else hipLaunchKernelGGL((h2o_decode_finish_kernel<EPT_, 1>), grid, dim3(1024), 0, s, *f);             \
-  } while (0)
-  if (ept <= 2) SVK_FINISH(2);
-  else if (ept <= 5) SVK_FINISH(5);
-  else if (ept <= 16) SVK_FINISH(16);
-  else SVK_FINISH(32);
-#undef SVK_FINISH
-  return check_launch("svk_h2o_decode_finish");
 }
 
 extern "C" int svk_h2o_select_indices(const SvkH2oSelectArgs* a, svk_stream_t stream) {

@@ -769,8 +769,7 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
     SVK_REQUIRE(a->num_q_heads <= 64 && a->num_kv_heads <= 8 && a->head_dim <= 256 && a->head_dim % 4 == 0, SVK_ERR_LAYOUT,
                 "svk_context_attention_fwd: score collection supports <= 64 query heads, <= 8 KV heads");
   }
-  static const int variant0 = getenv("SVK_PREFILL_ATTN_VARIANT") ? atoi(getenv("SVK_PREFILL_ATTN_VARIANT")) : 2;
-  SVK_REQUIRE((a->score_row_stats == nullptr && a->score_clear == nullptr) || (a->head_dim == 128 && variant0 == 2), SVK_ERR_LAYOUT,
+  SVK_REQUIRE((a->score_row_stats == nullptr && a->score_clear == nullptr) || a->head_dim == 128, SVK_ERR_LAYOUT,
               "svk_context_attention_fwd: score statistics are produced by the head_dim 128 kernel only");
   SVK_REQUIRE(a->score_row_stats == nullptr || (a->score_q_start != nullptr && a->score_wpad > 0), SVK_ERR_VALUE,
               "svk_context_attention_fwd: score_row_stats needs score_q_start and score_wpad");
@@ -778,9 +777,7 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
   const size_t shm = (size_t)G * (kQTile * kPRowP * 2 + 256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool off32 = a->kv_num_slots > 0 && (a->kv_num_slots * a->kv_slot_stride * 2) < (int64_t)0xffffffffll - 8192;
-  // SVK_PREFILL_ATTN_VARIANT=1 keeps the first kernel (every wave fetches its own K/V tile); 2 = LDS-shared tiles
-  static const int variant = getenv("SVK_PREFILL_ATTN_VARIANT") ? atoi(getenv("SVK_PREFILL_ATTN_VARIANT")) : 2;
-  if (a->head_dim == 128 && variant == 2) {
+  if (a->head_dim == 128) {   // LDS-shared K/V tiles; head_dim 64 keeps the first kernel (every wave fetches its own tile)
     const size_t tiles = 3 * 2 * kKV2 * kRowB, stage = (size_t)G * kQTile * 128 * 2;
     const size_t shm2 = (tiles > stage ? tiles : stage) + 2 * kKV2 * sizeof(int) + (size_t)G * 32 * sizeof(float);
     static bool attr = false;
@@ -789,20 +786,14 @@ extern "C" int svk_context_attention_fwd(const SvkContextAttentionArgs* a, svk_s
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(context_attention_kernel_v2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
-    static const int use_helper = getenv("SVK_PREFILL_ATTN_HELPER") ? atoi(getenv("SVK_PREFILL_ATTN_HELPER")) : 1;
-    const dim3 block2(64 * (G + ((G <= 7 && use_helper) ? 1 : 0)));
+    const dim3 block2(64 * (G + (G <= 7 ? 1 : 0)));          // GQA groups <= 7: an eighth wave only issues the tile DMA
     if (off32) hipLaunchKernelGGL((context_attention_kernel_v2<true>), grid, block2, shm2, s, *a);
     else hipLaunchKernelGGL((context_attention_kernel_v2<false>), grid, block2, shm2, s, *a);
     if (a->attn_score != nullptr) return launch_attn_scores(*a, s);
     return check_launch("svk_context_attention_fwd");
   }
-  if (a->head_dim == 128) {
-    if (off32) hipLaunchKernelGGL((context_attention_kernel<128, true>), grid, block, shm, s, *a);
-    else hipLaunchKernelGGL((context_attention_kernel<128, false>), grid, block, shm, s, *a);
-  } else {
-    if (off32) hipLaunchKernelGGL((context_attention_kernel<64, true>), grid, block, shm, s, *a);
-    else hipLaunchKernelGGL((context_attention_kernel<64, false>), grid, block, shm, s, *a);
-  }
+  if (off32) hipLaunchKernelGGL((context_attention_kernel<64, true>), grid, block, shm, s, *a);
+  else hipLaunchKernelGGL((context_attention_kernel<64, false>), grid, block, shm, s, *a);
   if (a->attn_score != nullptr) return launch_attn_scores(*a, s);
   return check_launch("svk_context_attention_fwd");
 }

@@ -561,10 +561,6 @@ inline Tiling2 make_tiling2(const Tiling& t, int n_ranges, int Hkv, int cols) {
   u.groups = (int64_t)n_ranges * Hkv;
   return u;
 }
-inline int prefill_score_variant() {
-  static const int v = getenv("SVK_PREFILL_SCORE_VARIANT") ? atoi(getenv("SVK_PREFILL_SCORE_VARIANT")) : 2;
-  return v;
-}
 }  // namespace
 }  // namespace svk
 
@@ -603,7 +599,7 @@ extern "C" int svk_prefill_score(const SvkPrefillScoreArgs* a, svk_stream_t stre
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Tiling t = make_tiling(a->n_ranges, a->num_q_heads, a->num_kv_heads, a->max_query_len, a->score_cols, a->score_mode);
   const bool logits = a->score_mode == SVK_PREFILL_SCORE_LOGITS;
-  const bool v2 = a->head_dim == 128 && t.G <= 8 && t.Wpad <= 128 && prefill_score_variant() == 2;
+  const bool v2 = a->head_dim == 128 && t.G <= 8 && t.Wpad <= 128;
   if (a->row_stats != nullptr) {
     SVK_REQUIRE(!logits && v2, SVK_ERR_LAYOUT, "svk_prefill_score: row_stats serve the head_dim 128 probability kernel only");
     SVK_REQUIRE(a->candidate_start == 0 && a->num_recent_tokens == 0 && a->batch_indices == nullptr, SVK_ERR_VALUE,

@@ -338,12 +338,11 @@ extern "C" int svk_quest_build_view(const SvkQuestBuildViewArgs* a, svk_stream_t
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quest_build_view_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     attr_set = true;
   }
-  static const bool no_owned = [] { const char* e = getenv("SVK_QUEST_VIEW_VARIANT"); return e != nullptr && e[0] == '1'; }();
   const int nt = a->n_prev > 2048 ? 1024 : 256;
   const int per_thread = (a->n_prev + nt - 1) / nt;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t shm_owned = sizeof(int) * a->prev_budget;
-  if (no_owned || per_thread > 32) hipLaunchKernelGGL(quest_build_view_kernel<0>, dim3(a->batch), dim3(nt), shm, s, *a, lds_keys);
+  if (per_thread > 32) hipLaunchKernelGGL(quest_build_view_kernel<0>, dim3(a->batch), dim3(nt), shm, s, *a, lds_keys);
   else if (per_thread <= 4) hipLaunchKernelGGL(quest_build_view_kernel<4>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
   else if (per_thread <= 8) hipLaunchKernelGGL(quest_build_view_kernel<8>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
   else if (per_thread <= 12) hipLaunchKernelGGL(quest_build_view_kernel<12>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);

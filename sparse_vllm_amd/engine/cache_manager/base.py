@@ -244,8 +244,8 @@ class CacheManager(ABC):
         """MI355X: slot_mapping of this decode step when the layer's K/V store may ride in the attention launch
         (plain slot-table managers whose store has no side effects), else None -> `save_rope_kv_if_needed`."""
         import os
-        if os.environ.get("SVK_FUSE_DECODE_STORE", "1") != "1" or os.environ.get("SVK_STAGE1_VARIANT", "3") != "3":
-            return None          # the store rides only in the default (v3) stage-1 kernel
+        if os.environ.get("SVK_FUSE_DECODE_STORE", "1") != "1":
+            return None
         if type(self).save_rope_kv_if_needed is not CacheManager.save_rope_kv_if_needed:
             return None          # Quest page metadata, DeltaKV raw/KIVI stores: keep the explicit store
         return self.get_layer_batch_states(layer_idx).slot_mapping

@@ -338,6 +338,11 @@ class DeltaKVCacheManager(CacheManager):
         return super().on_forward_end(seqs, is_prefill)
 
     prefill_attention_view_supported = False
+    # every position below a row's length is mapped on the full layers (a raw slot or a KIVI block: `_prepare_prefill`,
+    # `prepare_decode_static` and `_full_layer_kivi_evict` keep full_layer_slots_map / ..._kivi_block_slots_map a partition
+    # of [0, len)), so the observation layers' raw-score launch writes every position the score kernels read
+    # (SparseController._get_decode_attn_score_buffer)
+    decode_scores_cover_rows = True
 
     def build_prefill_compute_view(self, layer_idx: int, k_current, v_current, selection):
         """The prompt-side attention of DeltaKV runs over a reconstructed, RoPE-rotated staging view
@@ -389,14 +394,12 @@ class DeltaKVCacheManager(CacheManager):
     def get_decode_block_seq(self, layer_idx: int, default: int) -> int:
         if self._full_layer_kivi_enabled() and layer_idx in self.full_layer_to_idx:
             bs = int(self.config.full_layer_kivi_decode_block_seq or default)
-            mode = os.environ.get("SVK_KIVI_BLOCK_SEQ", "wide")
-            if mode == "auto":
-                # MI355X launch geometry for the whole-tile-prefetch kernel: one round of <= 256 workgroups
-                # (one per CU), 128-token tiles
-                rows = max(1, int(self.config.max_num_seqs_in_gpu))
-                per_row = max(1, 256 // rows)
-                bs = max(bs, -(-(-(-int(self.max_model_len) // per_row)) // 128) * 128)
-            elif mode == "wide" and os.environ.get("SVK_KIVI_VARIANT", "5") == "5":
+            wide = self.__dict__.get("_kivi_wide_ok")
+            if wide is None:          # does the wide (whole-block, 16-byte-load) kernel serve this head shape?
+                wide = self._kivi_wide_ok = dk.kivi_fused_store_supported(
+                    head_dim=self.head_dim, num_kv_heads=self.num_kv_heads, group_size=self._full_layer_kivi_group_size(),
+                    block_seq=128, key_param_dtype=self.full_layer_kivi_key_scales.dtype)
+            if wide:
                 # MI355X launch geometry of the default (whole-block, wide-load) kernel: a workgroup pays ~15 us of
                 # prologue (boundary / classification / first-tile loads), so ranges are as long as still fills the
                 # chip: two workgroups per CU when that leaves >= 8 tiles per workgroup, else one
@@ -848,10 +851,9 @@ class DeltaKVCacheManager(CacheManager):
 
     @staticmethod
     def _recon_sub_batches() -> list[int]:
-        """Layers per look-ahead launch group: "a,b,c" = a layers first, then b, then c, c, ... (the last value repeats)."""
-        import os
-        vals = [max(1, int(x)) for x in os.environ.get("SVK_DELTAKV_RECON_BATCH", "2").split(",") if x.strip()]
-        return vals or [2]
+        """Layers per look-ahead launch group (the last value repeats).  Two balances the side stream against the main
+        stream's per-layer chain (measured 1 / 2 / 3 / 4 layers -> 1.88 / 1.62 / 1.66 / 1.73 ms per 256 k step)."""
+        return [2]
 
     @classmethod
     def _recon_sub_batch(cls) -> int:
@@ -902,10 +904,7 @@ class DeltaKVCacheManager(CacheManager):
         dk.dequant_linear_act(self.deltakv_latent_cache[l0:l1], self.deltakv_latent_scales[l0:l1], self.deltakv_latent_mins[l0:l1],
                               self._quant_group_size(), w1[l0:l1], b1[l0:l1], activation="gelu", row_index=recon_latent,
                               out=hp[:, :, :hid], layers=True)
-        if os.environ.get("SVK_DELTAKV_BIAS_COLUMN", "1") == "1":
-            torch.bmm(hp, w2[l0:l1].transpose(1, 2), out=delta)
-        else:       # A/B: the plain form, whose broadcast bias copy is a launch of its own
-            torch.baddbmm(b2[l0:l1, None, :], hp[:, :, :hid], w2[l0:l1, :, :hid].transpose(1, 2), out=delta)
+        torch.bmm(hp, w2[l0:l1].transpose(1, 2), out=delta)
         knw = self.deltakv_k_norm_weight
         dk.deltakv_reconstruct_writeback_layers(
             delta, self.deltakv_latent_to_full_slots[l0:l1], recon_latent, self.deltakv_slot_to_pos, recon_out_slot, recon_pos,
@@ -917,7 +916,7 @@ class DeltaKVCacheManager(CacheManager):
     def _fused_up_parts(up, cache):
         """(Linear, Linear) of an `mlp_gelu` compress_up the fused dequant+Linear+GELU kernel can serve, else None."""
         import os
-        if os.environ.get("SVK_DELTAKV_FUSED_UP", "1") != "1" or not isinstance(up, torch.nn.Sequential) or len(up) != 3:
+        if not isinstance(up, torch.nn.Sequential) or len(up) != 3:
             return None
         lin1, act, lin2 = up[0], up[1], up[2]
         if not (isinstance(lin1, torch.nn.Linear) and isinstance(lin2, torch.nn.Linear) and isinstance(act, torch.nn.GELU)):

@@ -53,6 +53,9 @@ class H2OCacheManager(SnapKVCacheManager):
         self._dev_free_ptr = torch.zeros((self.num_kv_layers,), dtype=torch.long, device=self.device)
         self._dev_state_dirty = True
         self._dev_step_cache = None              # (key, SvkH2oDeviceStepArgs, keep-alive tensors)
+        # bumped whenever the args struct (whose device pointers a captured hipGraph bakes in by value) is rebuilt: a
+        # caller that replays a graph keys it on this, never on object identity (a freed struct's id can be reused)
+        self.device_step_generation = 0
         self._device_step = None                 # this step's (args, rows_2d, kv_idx, burst_launched) while active
 
     # ---- config views (h2o.py:55-71)
@@ -583,6 +586,9 @@ class H2OCacheManager(SnapKVCacheManager):
         budget, trigger = self.h2o_decode_budget, self.h2o_decode_budget + self.h2o_decode_eviction_interval
         key = (tuple(s.seq_id for s in seqs), rows0, tuple(layer_ids), int(graph_batch_size), budget, trigger)
         cache = self._dev_step_cache
+        sm, cl, ri = self._get_decode_static_buffers(int(graph_batch_size))
+        if cache is not None and cache[2][2].data_ptr() != sm.data_ptr():
+            cache = None          # the static step buffers were reallocated (a larger graph batch on the host path)
         if cache is None or cache[0] != key:
             rows_2d = np.array([rows0] + [[self._row_of(l, s) for s in seqs] for l in layer_ids[1:]], dtype=np.int64)
             if not bool((rows_2d == rows_2d[0]).all()) or len(layer_ids) != self.num_kv_layers:
@@ -591,12 +597,12 @@ class H2OCacheManager(SnapKVCacheManager):
             d = self.device
             rows_gpu = torch.from_numpy(rows_2d[0].astype(np.int32)).to(d)
             keep = torch.empty((len(layer_ids), B, budget), dtype=torch.long, device=d)
-            sm, cl, ri = self._get_decode_static_buffers(int(graph_batch_size))
             recent = min(max(1, int(budget * float(self.config.h2o_recent_ratio))), budget)
             args = h2o_ops.h2o_device_step_args(
                 self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor, self.h2o_score_tensor, self._dev_row_len,
                 self._dev_free_ptr, rows_gpu, sm, cl, ri, keep, batch=B, budget=budget, recent_count=recent, trigger_len=trigger)
             cache = self._dev_step_cache = (key, args, (rows_gpu, keep, sm, cl, ri), rows_2d, kv_idx)
+            self.device_step_generation += 1
         _, args, _keepalive, rows_2d, kv_idx = cache
         cur = self._row_seq_lens_all[kv_idx[:, None], rows_2d]
         ptrs = [int(self._num_free_slots[l]) for l in layer_ids]
@@ -611,7 +617,8 @@ class H2OCacheManager(SnapKVCacheManager):
 
     def _device_state_upload(self):
         self._dev_row_len.copy_(torch.from_numpy(self._row_seq_lens_all), non_blocking=False)
-        self._dev_free_ptr.copy_(torch.tensor([int(x) for x in self._num_free_slots], dtype=torch.long))
+        self._dev_free_ptr.copy_(torch.tensor([int(self._num_free_slots[int(l)]) for l in self.kv_transformer_layer_indices()],
+                                              dtype=torch.long))
         self._dev_state_dirty = False
 
     def prepare_decode_static(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,

@@ -286,8 +286,7 @@ class QuestCacheManager(CacheManager):
         newest token is always the last entry of the attention view (the last page is always attended), so the store can
         ride in the stage-1 launch like for the plain slot-table managers."""
         import os
-        if (get_context().is_prefill or os.environ.get("SVK_FUSE_DECODE_STORE", "1") != "1"
-                or os.environ.get("SVK_STAGE1_VARIANT", "3") != "3"):
+        if get_context().is_prefill or os.environ.get("SVK_FUSE_DECODE_STORE", "1") != "1":
             return None
         return self.layer_batch_state.slot_mapping
 

@@ -224,7 +224,7 @@ class SparseDecodeDriver:
             body()
         else:
             key = (q.data_ptr(), k.data_ptr(), v.data_ptr(), None if outputs is None else outputs.data_ptr(),
-                   tuple(s.seq_id for s in seqs), id(cm._device_step[0]) if dev_active else None)
+                   tuple(s.seq_id for s in seqs), int(cm.device_step_generation) if dev_active else None)
             if self._graph is None or self._graph_key != key:
                 if self._graph_steps_seen == 0 or self._graph_key != key:
                     # first step with these buffers runs eagerly (allocates every scratch buffer)

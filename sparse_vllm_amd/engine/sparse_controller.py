@@ -8,14 +8,12 @@ kernels).  Call order (fixed by ModelRunner.run, model_runner.py:1447-1481):
 
 from __future__ import annotations
 
-import ctypes as C
 import os
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 
-from .. import _lib
 from ..kernels import deltakv_kernels, h2o_ops
 from ..method_registry import normalize_sparse_method
 from ..utils.context import get_context
@@ -65,29 +63,13 @@ class SparseController:
         self.layer_batch_sparse_states = [LayerBatchSparseState() for _ in range(self.num_layers)]
         self._h2o_decode_attn_score_buffers: dict[tuple, torch.Tensor] = {}
         self._fused_h2o_accumulate = True
-        # single-launch layer (svk_h2o_decode_fused).  Measured slower than stage 1 + the 1024-thread finish kernel
-        # (139.7 us vs 93.5 + 9.3 us at B=64: one workgroup per row cannot hide the finish step's L2 round trips), so it
-        # is opt-in; kept because it halves the launches for callers that are launch-bound.
-        self._fused_h2o_layer = os.environ.get("SVK_H2O_FUSED_LAYER", "0") == "1"
-        self._obs_score_refill = os.environ.get("SVK_DELTAKV_SCORE_REFILL", "0") == "1"
-        self._layer_score_finished = [False] * self.num_layers
-        # MI355X: the per-layer H2O score epilogue (scale + softmax + accumulate) has no consumer until the step's
-        # eviction check, so it may run on a side stream beside the next layers (joined in `join_side_streams`)
-        self._h2o_score_stream_enabled = os.environ.get("SVK_H2O_SCORE_STREAM", "0") == "1"
-        self._h2o_score_stream = None
-        self._h2o_score_stream_used = False
-        # MI355X: a layer's score epilogue (scale + softmax + accumulate) rides in the NEXT layer's stage-1 launch
-        # (svk_flash_decode_stage1_deferred) instead of sitting between two layers as a latency-bound launch of its own;
-        # the last layer's is flushed at the end of the layer loop (`join_side_streams`) / before the eviction check
-        # Where a layer's H2O score epilogue (scale + softmax of the raw score row, cumulative add) runs.
-        # SVK_H2O_DEFER_SCORE = "end" (default): all layers of the step in ONE launch after the layer loop, like the
-        # reference's update_decode_attention_scores_all_layers (h2o.py:957-1038); "0": in every layer's fused finish
-        # launch; "1": as extra workgroups of the next layer's stage-1 launch.  Measured ms per step, end / fused:
-        # B=1 0.407 / 0.460, B=8 0.689 / 0.776, B=16 0.999 / 1.090, B=64 2.833 / 2.951, B=128 5.306 / 5.491 (same box
-        # per pair); riding in stage 1: B=1 0.500, B=16 1.077, B=64 2.92, B=128 5.40.
-        self._defer_h2o_mode = os.environ.get("SVK_H2O_DEFER_SCORE", "end")
-        self._pending_scores: list = []      # (SvkH2oDecodeScoreArgs, keep-alive tensors) of this step's layers ("end")
-        self._deferred_score = None          # (SvkH2oDecodeScoreArgs, keep-alive tensors)
+        # The H2O score epilogue of a layer (scale + softmax of its raw score row, cumulative add) has no consumer before
+        # the step's eviction check, so `on_layer_attention_end` only queues it and ALL layers of the step run as ONE
+        # launch after the layer loop (`flush_pending_scores`), like the reference's
+        # update_decode_attention_scores_all_layers (h2o.py:957-1038): 28 latency-bound row launches become one
+        # bandwidth-bound launch.  (Measured against the per-layer forms - inside a fused stage-2 launch, or riding in the
+        # next layer's stage-1 launch - it wins at every batch size)
+        self._pending_scores: list = []      # (SvkH2oDecodeScoreArgs, keep-alive tensors) of this step's layers
         self.is_deltakv_family = self.sparse_method == "deltakv"
         # sparse_controller.py:70-73
         self.dynamic_deltakv_topk_tiebreak = _env_bool("SPARSEVLLM_DELTAKV_DETERMINISTIC_TOPK_TIEBREAK", False)
@@ -203,11 +185,13 @@ class SparseController:
             buf = torch.empty((batch_size, num_heads, max_len), dtype=torch.float32, device=self.device)
             self._decode_attn_score_buffers[int(layer_idx)] = buf
         view = buf[:batch_size, :num_heads, :max_len]
-        # MI355X: the per-step refill is 29 MB per observation layer at 256 k tokens and nothing reads what it writes -
-        # the attention launch overwrites every position below the row's length and `_decode_softmax_token_scores`
-        # masks by the candidate lengths (never past the length) - so only a new buffer is filled.  Positions at or
-        # beyond a row's length are then unspecified instead of -1e20; SVK_DELTAKV_SCORE_REFILL=1 restores the refill.
-        if fresh or self._obs_score_refill:
+        # MI355X: the per-step refill is 29 MB per observation layer at 256 k tokens.  The attention launch overwrites
+        # every MAPPED position below a row's length and `_decode_softmax_token_scores` masks by the candidate lengths
+        # (never past the length), so a manager that guarantees every position below the length is mapped (raw slot or
+        # quantised block: `decode_scores_cover_rows`, DeltaKVCacheManager's full-layer invariant) only needs a new buffer
+        # filled; for any other manager an unmapped position would keep a previous step's value, so the reference's
+        # per-step refill stays.
+        if fresh or not bool(getattr(self.cache_manager, "decode_scores_cover_rows", False)):
             h2o_ops.fill_f32(view, fill_value) if view.is_contiguous() else view.fill_(fill_value)
         return view
 
@@ -288,84 +272,9 @@ class SparseController:
             return None
         return sm
 
-    def fused_decode_layer(self, layer_idx: int, q, k_cache, v_cache, active_slots, req_indices, context_lens, max_len_in_batch,
-                           mid_o, mid_lse, attn_score, block_seq, o) -> bool:
-        """MI355X fusion hook: the whole H2O decode layer (scored stage 1, stage 2, score normalise + cumulative
-        update) in one launch (svk_h2o_decode_fused).  Returns False when the layer is not an H2O decode layer."""
-        if self.sparse_method != "h2o" or get_context().is_prefill or not self._fused_h2o_layer:
-            return False
-        s = self.layer_batch_sparse_states[layer_idx]
-        if s.attn_score is None or s.attn_score.dim() != 2 or attn_score.data_ptr() != s.attn_score.data_ptr():
-            return False
-        cm = self.cache_manager
-        cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
-        from ..kernels.gqa_flash_decoding_stage1 import h2o_decode_fused
-        h2o_decode_fused(q, k_cache, v_cache, active_slots, req_indices, context_lens, max_len_in_batch, mid_o, mid_lse,
-                         attn_score, block_seq, o, self.attn_softmax_scale, cum_score=cum,
-                         b_new_slot=self._h2o_new_slots(layer_idx))
-        self._layer_score_finished[layer_idx] = True
-        return True
-
-    def _h2o_score_mode(self, batch: int) -> str:
-        """"fused" | "stage1" | "end" (see __init__)."""
-        return {"0": "fused", "1": "stage1"}.get(self._defer_h2o_mode, "end")
-
-    def decode_direct_out_allowed(self, layer_idx: int, batch_size: int) -> bool:
-        """May stage 1 write the layer's output itself when one block covers the rows (no stage 2)?  Not when this
-        controller wants stage 2 and the score epilogue as one launch (`SVK_H2O_DEFER_SCORE=0`)."""
-        if self.sparse_method != "h2o" or get_context().is_prefill or self._h2o_score_stream_enabled:
-            return True
-        return self._h2o_score_mode(int(batch_size)) != "fused"
-
-    def fused_decode_finish(self, layer_idx: int, mid_o, mid_lse, context_lens, o, block_seq, merged: bool = False) -> bool:
-        """MI355X fusion hook called by the attention backend instead of `flash_decode_stage2`:
-        for H2O decode, stage 2 and this layer's `on_layer_attention_end` score epilogue run as
-        one launch (svk_h2o_decode_finish).  Returns False when there is nothing to fuse.  `merged`: stage 1 already
-        wrote `o` (single-block launch), only the score bookkeeping is left."""
-        if self.sparse_method != "h2o" or get_context().is_prefill or self._h2o_score_stream_enabled:
-            return False
-        s = self.layer_batch_sparse_states[layer_idx]
-        if s.attn_score is None or s.attn_score.dim() != 2:
-            return False
-        cm = self.cache_manager
-        cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
-        mode = self._h2o_score_mode(int(context_lens.shape[0]))
-        if mode != "fused":
-            from ..kernels.flash_decoding_stage2 import flash_decode_stage2
-            from ..kernels.gqa_flash_decoding_stage1 import h2o_score_args
-            if mode == "stage1":
-                self.flush_deferred_score()          # at most one layer is ever pending
-            if not merged:
-                flash_decode_stage2(mid_o, mid_lse, context_lens, o, block_seq)
-            new_slots = self._h2o_new_slots(layer_idx)
-            entry = (h2o_score_args(s.attn_score, self.attn_softmax_scale, cum_score=cum, b_req_idx=s.req_indices,
-                                    b_seqlen=context_lens, b_new_slot=new_slots),
-                     (s.attn_score, cum, s.req_indices, context_lens, new_slots))
-            if mode == "stage1":
-                self._deferred_score = entry
-            else:
-                self._pending_scores.append(entry)
-            self._layer_score_finished[layer_idx] = True
-            return True
-        if merged:
-            raise RuntimeError("H2O fused finish needs the stage-1 partials (decode_direct_out_allowed was not consulted)")
-        h2o_ops.h2o_decode_finish(mid_o, mid_lse, context_lens, o, block_seq, s.attn_score, self.attn_softmax_scale,
-                                  cum_score=cum, b_req_idx=s.req_indices, b_new_slot=self._h2o_new_slots(layer_idx))
-        self._layer_score_finished[layer_idx] = True
-        return True
-
-    def take_deferred_score(self):
-        """The previous layer's pending score epilogue, for the stage-1 launch that is about to be issued."""
-        pending, self._deferred_score = self._deferred_score, None
-        return None if pending is None else pending[0]
-
-    def flush_deferred_score(self):
-        """Run the still pending score epilogues: the last layer's in "stage1" mode, all layers of the step in "end" mode
-        (end of the layer loop - inside the captured graph - and before anything reads the scores)."""
-        pending, self._deferred_score = self._deferred_score, None
-        if pending is not None:
-            lib = _lib.load()
-            _lib.check(lib.svk_h2o_decode_score_update(C.byref(pending[0]), _lib.current_stream_handle()), lib)
+    def flush_pending_scores(self):
+        """Run the queued score epilogues of this step's layers as one launch (end of the layer loop - inside the captured
+        graph - and before anything reads the scores)."""
         if self._pending_scores:
             batch, self._pending_scores = self._pending_scores, []
             h2o_ops.h2o_decode_score_update_layers([e[0] for e in batch])
@@ -382,36 +291,21 @@ class SparseController:
         s = self.layer_batch_sparse_states[layer_idx]
         if s.attn_score is None:
             return
-        if self._layer_score_finished[layer_idx]:      # already done inside the stage-2 launch
-            self._layer_score_finished[layer_idx] = False
-            return
         if s.attn_score.dim() != 2:
             raise RuntimeError("SnapKV-family decode attention must write a fused head-reduced [B, L] score tensor: "
                                f"layer={layer_idx} shape={tuple(s.attn_score.shape)}.")
         cm = self.cache_manager
         cum = cm.h2o_score_tensor[cm.kv_layer_index(layer_idx)] if self._fused_h2o_accumulate else None
-        if self._h2o_score_stream_enabled and s.attn_score.is_cuda:
-            if self._h2o_score_stream is None:
-                self._h2o_score_stream = torch.cuda.Stream(device=s.attn_score.device)
-            side = self._h2o_score_stream
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                h2o_ops.h2o_decode_score_update(s.attn_score, self.attn_softmax_scale, cum_score=cum,
-                                                b_req_idx=s.req_indices, b_seqlen=s.context_lens,
-                                                b_new_slot=self._h2o_new_slots(layer_idx))
-            self._h2o_score_stream_used = True
-            return
-        h2o_ops.h2o_decode_score_update(s.attn_score, self.attn_softmax_scale, cum_score=cum,
-                                        b_req_idx=s.req_indices, b_seqlen=s.context_lens,
-                                        b_new_slot=self._h2o_new_slots(layer_idx))
+        from ..kernels.gqa_flash_decoding_stage1 import h2o_score_args
+        new_slots = self._h2o_new_slots(layer_idx)
+        self._pending_scores.append(
+            (h2o_score_args(s.attn_score, self.attn_softmax_scale, cum_score=cum, b_req_idx=s.req_indices,
+                            b_seqlen=s.context_lens, b_new_slot=new_slots),
+             (s.attn_score, cum, s.req_indices, s.context_lens, new_slots)))
 
     def join_side_streams(self):
-        """Make the current stream wait for the side-stream score epilogues of this step (end of the layer loop,
-        inside graph capture when the step is captured) and issue the last layer's deferred score epilogue."""
-        self.flush_deferred_score()
-        if self._h2o_score_stream_used:
-            torch.cuda.current_stream().wait_stream(self._h2o_score_stream)
-            self._h2o_score_stream_used = False
+        """End of the layer loop (inside graph capture when the step is captured): issue the step's score epilogue."""
+        self.flush_pending_scores()
 
     # ------------------------------------------------------------------ DeltaKV query-aware top-k
     @torch.no_grad()
@@ -582,7 +476,7 @@ class SparseController:
 
     def _h2o_decode_eviction(self, seqs):
         """sparse_controller.py:1226-1282: scores are already accumulated (fused), evict."""
-        self.flush_deferred_score()
+        self.flush_pending_scores()
         with profiler.record("h2o_decode_eviction"):
             if not self._fused_h2o_accumulate:
                 layer_indices = self._h2o_kv_layer_indices()

@@ -35,8 +35,7 @@ def _assert_supported_layout(q, k, v, req_to_tokens, b_req_idx, b_seqlen, mid_ou
 
 def direct_out_supported(max_len_in_batch, block_seq) -> bool:
     """True when stage 1 may write the attention output itself (`direct_out=`): one block per sequence, default kernel."""
-    return (int(max_len_in_batch) <= int(block_seq) and os.environ.get("SVK_STAGE1_VARIANT", "3") == "3"
-            and os.environ.get("SVK_DECODE_DIRECT_OUT", "1") != "0")
+    return int(max_len_in_batch) <= int(block_seq) and os.environ.get("SVK_DECODE_DIRECT_OUT", "1") != "0"
 
 
 def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
@@ -105,45 +104,11 @@ def h2o_score_args(attn_score, scale, *, cum_score=None, b_req_idx=None, b_seqle
 
 
 def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv=None, deferred_score=None, direct_out=None):
+            attn_score, block_seq, new_kv=None, direct_out=None):
     a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
                      attn_score, block_seq, new_kv, direct_out)
     lib = _lib.load()
-    if deferred_score is not None:
-        _lib.check(lib.svk_flash_decode_stage1_deferred(C.byref(a), C.byref(deferred_score), _lib.current_stream_handle()), lib)
-        return
     _lib.check(lib.svk_flash_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
-
-
-_TICKETS: dict = {}
-
-
-@torch.no_grad()
-def h2o_decode_fused(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp, attn_score,
-                     block_seq, O, scale, *, cum_score=None, b_new_slot=None):
-    """One launch = flash_decode_stage1_with_score (2-D head-max scores) + flash_decode_stage2 + the H2O score
-    normalise / accumulate of `h2o_decode_finish` (ticketed last-workgroup epilogue).  Same results."""
-    assert attn_score is not None and attn_score.dim() == 2
-    assert O.dtype == torch.bfloat16 and O.stride(-1) == 1
-    if cum_score is not None:
-        assert cum_score.dim() == 2 and cum_score.dtype == torch.float32 and cum_score.stride(1) == 1
-    a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                     attn_score, block_seq)
-    key = (q.device, int(B_req_idx.shape[0]))
-    tickets = _TICKETS.get(key)
-    if tickets is None:
-        tickets = torch.zeros((int(B_req_idx.shape[0]),), dtype=torch.int32, device=q.device)
-        _TICKETS[key] = tickets
-    lib = _lib.load()
-    f = _lib.SvkH2oDecodeFusedArgs(
-        stage1=a,
-        score=_lib.SvkH2oDecodeScoreArgs(
-            attn_score=_lib.ptr(attn_score), cum_score=_lib.ptr(cum_score), b_req_idx=_lib.ptr(B_req_idx),
-            b_seqlen=_lib.ptr(B_Seqlen), b_new_slot=_lib.ptr(b_new_slot), score_stride_b=attn_score.stride(0),
-            cum_stride=0 if cum_score is None else cum_score.stride(0), scale=float(scale),
-            batch=attn_score.shape[0], width=attn_score.shape[1]),
-        o=_lib.ptr(O), o_stride_b=O.stride(0), o_stride_h=O.stride(1), tickets=_lib.ptr(tickets))
-    _lib.check(lib.svk_h2o_decode_fused(C.byref(f), _lib.current_stream_handle()), lib)
 
 
 @torch.no_grad()
@@ -158,9 +123,8 @@ def flash_decode_stage1(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_
 
 @torch.no_grad()
 def flash_decode_stage1_with_score(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
-                                   mid_out_logsumexp, attn_score, block_seq, *, new_kv=None, deferred_score=None,
-                                   direct_out=None):
-    """`deferred_score` (MI355X extension, `h2o_score_args(...)` of the PREVIOUS layer): its score epilogue runs inside
-    this launch (svk_flash_decode_stage1_deferred).  `direct_out`: as in `flash_decode_stage1`."""
+                                   mid_out_logsumexp, attn_score, block_seq, *, new_kv=None, direct_out=None):
+    """2-D `attn_score` [B, W]: head-max raw logits fused; 3-D [B, Hq, W]: per head.  `new_kv` / `direct_out`: as in
+    `flash_decode_stage1`."""
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv, deferred_score, direct_out=direct_out)
+            attn_score, block_seq, new_kv, direct_out=direct_out)

@@ -80,31 +80,6 @@ def h2o_decode_score_update_layers(pending) -> None:
     SCORE_LAYERS_LAUNCHES["per_layer"] += 1
 
 
-def h2o_decode_finish(mid_out, mid_out_logexpsum, B_Seqlen, O, block_seq, attn_score, scale, *, cum_score=None,
-                      b_req_idx=None, b_new_slot=None):
-    """flash_decode_stage2 + h2o_decode_score_update in one launch (same results)."""
-    assert mid_out.stride(-1) == 1 and mid_out_logexpsum.stride(-1) == 1 and O.stride(-1) == 1
-    assert O.dtype == torch.bfloat16 and mid_out.dtype == torch.float32
-    assert attn_score.dim() == 2 and attn_score.dtype == torch.float32 and attn_score.stride(1) == 1
-    if cum_score is not None:
-        assert cum_score.dim() == 2 and cum_score.dtype == torch.float32 and cum_score.stride(1) == 1
-        assert b_req_idx is not None
-    lib = _lib.load()
-    a = _lib.SvkH2oDecodeFinishArgs(
-        stage2=_lib.SvkFlashDecodeStage2Args(
-            mid_o=_lib.ptr(mid_out), mid_lse=_lib.ptr(mid_out_logexpsum), b_seqlen=_lib.ptr(B_Seqlen), o=_lib.ptr(O),
-            mid_o_stride_b=mid_out.stride(0), mid_o_stride_h=mid_out.stride(1), mid_o_stride_s=mid_out.stride(2),
-            mid_lse_stride_b=mid_out_logexpsum.stride(0), mid_lse_stride_h=mid_out_logexpsum.stride(1),
-            o_stride_b=O.stride(0), o_stride_h=O.stride(1), batch=mid_out.shape[0], num_q_heads=mid_out.shape[1],
-            head_dim=mid_out.shape[-1], block_seq=int(block_seq)),
-        score=_lib.SvkH2oDecodeScoreArgs(
-            attn_score=_lib.ptr(attn_score), cum_score=_lib.ptr(cum_score), b_req_idx=_lib.ptr(b_req_idx),
-            b_seqlen=_lib.ptr(B_Seqlen), b_new_slot=_lib.ptr(b_new_slot), score_stride_b=attn_score.stride(0),
-            cum_stride=0 if cum_score is None else cum_score.stride(0), scale=float(scale),
-            batch=attn_score.shape[0], width=attn_score.shape[1]))
-    _lib.check(lib.svk_h2o_decode_finish(C.byref(a), _lib.current_stream_handle()), lib)
-
-
 def h2o_recent_count(budget: int, recent_ratio: float, kv_len: int) -> int:
     """h2o.py:495-496 / :540-541."""
     rc = max(1, int(int(budget) * float(recent_ratio)))

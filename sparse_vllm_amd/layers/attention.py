@@ -160,8 +160,7 @@ class HipAttentionBackend:
 
     def run_decode(self, q: torch.Tensor, view: DecodeComputeView, *, mid_o, mid_o_logexpsum, max_len_in_batch: int,
                    block_seq: int, num_heads: int, num_kv_heads: int, gqa_block_n: int = 16,
-                   gqa_num_warps: int = 2, fused_finish=None, fused_layer=None, new_kv=None,
-                   take_deferred_score=None, direct_ok: bool = True) -> torch.Tensor:
+                   gqa_num_warps: int = 2, new_kv=None) -> torch.Tensor:
         payload = view.payload
         if not isinstance(payload, ExplicitKVPayload):
             raise TypeError(f"HIP decode requires ExplicitKVPayload, got {type(payload).__name__}.")
@@ -189,36 +188,23 @@ class HipAttentionBackend:
             return o
         if new_kv is not None and payload.backend not in ("dense", "full_layer_kivi"):
             raise RuntimeError("the fused decode store is only wired into the dense stage-1 launch")
-        if (fused_layer is not None and new_kv is None and payload.backend == "dense" and meta.attn_score is not None
-                and meta.attn_score.dim() == 2):
-            # MI355X: stage 1 + stage 2 + the controller's per-layer score epilogue as ONE launch
-            o = torch.empty_like(q)
-            with profiler.record(f"decode_attention_fused_{kind}"):
-                if fused_layer(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices, meta.context_lens,
-                               max_len_in_batch, mid_o, mid_o_logexpsum, meta.attn_score, block_seq, o):
-                    return o
         # MI355X: when one block covers every row of the launch the split-KV merge has nothing to merge and stage 1
         # writes the output itself (bit-identical, include/svk.h `direct_o`): no stage-2 launch for this layer
-        direct = bool(direct_ok) and payload.backend == "dense" and direct_out_supported(max_len_in_batch, block_seq)
+        direct = payload.backend == "dense" and direct_out_supported(max_len_in_batch, block_seq)
         o = torch.empty_like(q)
         direct_out = o if direct else None
         with profiler.record(f"decode_attention_stage1_{kind}"):
             if meta.attn_score is not None:
-                # a sparse controller may hand over the previous layer's score epilogue to ride in this launch
-                deferred = take_deferred_score() if take_deferred_score is not None else None
                 flash_decode_stage1_with_score(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                                meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum,
-                                               meta.attn_score, block_seq, new_kv=new_kv, deferred_score=deferred,
-                                               direct_out=direct_out)
+                                               meta.attn_score, block_seq, new_kv=new_kv, direct_out=direct_out)
             else:
                 flash_decode_stage1(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                     meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum, block_seq,
                                     gqa_block_n, gqa_num_warps, new_kv=new_kv, direct_out=direct_out)
-        with profiler.record(f"decode_attention_stage2_{kind}"):
-            # a sparse controller may fuse its per-layer score epilogue into the stage-2 launch (`direct`: o is final)
-            if fused_finish is None or not fused_finish(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq, direct):
-                if not direct:
-                    flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
+        if not direct:
+            with profiler.record(f"decode_attention_stage2_{kind}"):
+                flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
         return o
 
 
@@ -242,7 +228,7 @@ class Attention(torch.nn.Module):
         if k is not None and v is not None:
             fuse = getattr(cache_manager, "fused_decode_store_slots", None)
             slots = fuse(layer_idx) if fuse is not None else None
-            if slots is None or getattr(sparse_controller, "_fused_h2o_layer", False):
+            if slots is None:
                 cache_manager.save_rope_kv_if_needed(layer_idx, k, v)
             else:
                 new_kv = (k, v, slots)
@@ -277,17 +263,10 @@ class Attention(torch.nn.Module):
                 num_seq_blocks += 3           # room for the wide KIVI launch's extra partials (raw / ragged pieces of a row)
             mid_o, mid_lse = get_decode_workspace(context, batch_size, self.num_heads, num_seq_blocks, self.head_dim,
                                                   q.device)
-            finish = getattr(sparse_controller, "fused_decode_finish", None)
-            layer_fn = getattr(sparse_controller, "fused_decode_layer", None)
-            direct_allowed = getattr(sparse_controller, "decode_direct_out_allowed", None)
             o = self.attention_backend.run_decode(
                 q, decode_view, mid_o=mid_o, mid_o_logexpsum=mid_lse, max_len_in_batch=max_len_in_batch,
                 block_seq=block_seq, num_heads=self.num_heads, num_kv_heads=self.num_kv_heads,
-                gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps,
-                fused_finish=None if finish is None else (lambda *a, _l=layer_idx: finish(_l, *a)),
-                fused_layer=None if layer_fn is None else (lambda *a, _l=layer_idx: layer_fn(_l, *a)),
-                new_kv=new_kv, take_deferred_score=getattr(sparse_controller, "take_deferred_score", None),
-                direct_ok=True if direct_allowed is None else bool(direct_allowed(layer_idx, batch_size)))
+                gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps, new_kv=new_kv)
             cache_manager.record_decode_query(layer_idx, q)
             sparse_controller.on_layer_attention_end(layer_idx)
             cache_manager.on_layer_attention_end(layer_idx)

@@ -188,14 +188,11 @@ def test_token_scores_and_sorted_topk():
 
 @pytest.mark.parametrize("n,k,rows", [(262144, 2048, 2), (70000, 4096, 1), (40000, 300, 3), (24576, 4096, 2),
                                        (9000, 291, 4), (1_100_000, 2048, 1), (50, 50, 2)])
-@pytest.mark.parametrize("plan", ["hist", "chunks"])
-def test_sorted_topk_long_rows(n, k, rows, plan, monkeypatch):
+def test_sorted_topk_long_rows(n, k, rows):
     """Rows longer than one LDS stage take the histogram plan (12-bit histogram -> candidates of the bins up to the
-    threshold bin -> one select + sort) or, with SVK_TOPK_PLAN=chunks, per-chunk candidates + merge; shapes that fit
-    neither take the single-workgroup fallback.  bf16-valued probabilities => massive ties; result must equal the stable
+    threshold bin -> one select + sort); without a workspace the single-workgroup fallback.  bf16-valued probabilities => massive ties; result must equal the stable
     descending argsort (score desc, index asc) bit for bit, including masked tails shorter than k."""
     from sparse_vllm_amd.kernels.deltakv_kernels import topk_sorted_desc
-    monkeypatch.setenv("SVK_TOPK_PLAN", plan)
     rng = np.random.default_rng(n + k)
     x = bf16_round((rng.random((rows, n)) ** 8).astype(np.float32))
     x[0, : min(n, 5000)] = 0.25                                   # one huge tie group

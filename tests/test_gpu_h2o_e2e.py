@@ -24,11 +24,8 @@ def _bf(t):
     dict(B=2, L=2, budget=112, interval=16, start=100, steps=50, Hq=14, Hkv=2, D=64),
     dict(B=2, L=2, budget=112, interval=16, start=104, steps=45, Hq=7, Hkv=1, D=128),    # one TP=4 rank of Qwen2.5-7B
 ])
-@pytest.mark.parametrize("defer", ["0", "1", "end"])
-def test_h2o_decode_steps_match_oracle(cfg, defer, monkeypatch):
-    # the score epilogue of a layer either runs in the fused finish launch ("0") or rides in the next layer's stage-1
-    # launch ("1"), or all layers of the step run in one launch after the layer loop ("end", the default)
-    monkeypatch.setenv("SVK_H2O_DEFER_SCORE", defer)
+def test_h2o_decode_steps_match_oracle(cfg):
+    # the score epilogues of all layers of a step run in one launch after the layer loop
     from sparse_vllm_amd.config import Config
     from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
     B, L, budget, interval = cfg["B"], cfg["L"], cfg["budget"], cfg["interval"]
@@ -104,10 +101,9 @@ def test_h2o_decode_steps_match_oracle(cfg, defer, monkeypatch):
             np.testing.assert_array_equal(stack[l, :p], st.free_stack[l, :p])
     assert n_bursts >= 2
     assert cm._h2o_counters["decode_eviction_bursts"] == n_bursts * B
-    if defer == "end":
-        # the layers' buffers are equally spaced slices: every step took the single all-layers launch
-        from sparse_vllm_amd.kernels import h2o_ops
-        assert h2o_ops.SCORE_LAYERS_LAUNCHES["batched"] > before["batched"] and h2o_ops.SCORE_LAYERS_LAUNCHES["per_layer"] == before["per_layer"]
+    # the layers' buffers are equally spaced slices: every step took the single all-layers launch
+    from sparse_vllm_amd.kernels import h2o_ops
+    assert h2o_ops.SCORE_LAYERS_LAUNCHES["batched"] > before["batched"] and h2o_ops.SCORE_LAYERS_LAUNCHES["per_layer"] == before["per_layer"]
 
 
 def _run_h2o(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False):

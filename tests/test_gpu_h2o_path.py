@@ -387,73 +387,6 @@ def test_decode_alloc_slots_matches_oracle():
     np.testing.assert_array_equal(ri.cpu().numpy()[0], [5, 0, 2, 5, 5])
 
 
-def test_fused_decode_finish_equals_separate_calls():
-    """svk_h2o_decode_finish == svk_flash_decode_stage2 + svk_h2o_decode_score_update, bit for bit."""
-    from sparse_vllm_amd.kernels import flash_decode_stage2
-    from sparse_vllm_amd.kernels.h2o_ops import h2o_decode_finish, h2o_decode_score_update
-    d = dev()
-    g = torch.Generator(device="cpu").manual_seed(8)
-    for (B, Hq, D, nblk, block_seq, W, rows) in [(5, 28, 128, 9, 512, 4224, 7), (3, 14, 64, 4, 64, 200, 3),
-                                                 (2, 28, 128, 2, 4096, 8000, 2)]:
-        lens = torch.randint(1, min(W, nblk * block_seq) + 1, (B,), generator=g).to(torch.int32)
-        lens[0] = min(W, nblk * block_seq)
-        mid = torch.randn(B, Hq, nblk, D, generator=g).to(d)
-        lse = (torch.randn(B, Hq, nblk, generator=g) * 3).to(d)
-        raw = torch.full((B, W), -1e20)
-        for b in range(B):
-            raw[b, : lens[b]] = torch.randn(int(lens[b]), generator=g) * 5
-        cum = torch.rand(rows, W + 5, generator=g)
-        ridx = torch.randperm(rows, generator=g)[:B].to(torch.int32)
-        x1, c1 = raw.clone().to(d), cum.clone().to(d)
-        o1 = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=d)
-        flash_decode_stage2(mid, lse, lens.to(d), o1, block_seq)
-        h2o_decode_score_update(x1, D ** -0.5, cum_score=c1, b_req_idx=ridx.to(d), b_seqlen=lens.to(d))
-        x2, c2 = raw.clone().to(d), cum.clone().to(d)
-        o2 = torch.empty_like(o1)
-        h2o_decode_finish(mid, lse, lens.to(d), o2, block_seq, x2, D ** -0.5, cum_score=c2, b_req_idx=ridx.to(d))
-        assert torch.equal(o1, o2)
-        # the register-resident row sums in a different order than the 3-pass kernel: 1-2 ulp
-        torch.testing.assert_close(x2, x1, rtol=2e-6, atol=1e-12)
-        torch.testing.assert_close(c2, c1, rtol=2e-6, atol=1e-9)
-
-
-def test_single_launch_layer_matches_two_launches():
-    """svk_h2o_decode_fused (stage 1 + ticketed finish in one launch) == stage 1 followed by h2o_decode_finish, bit for bit
-    (same kernels bodies, same merge order), over ragged rows and repeated launches (ticket self-reset)."""
-    from sparse_vllm_amd.kernels import flash_decode_stage1_with_score
-    from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import h2o_decode_fused
-    from sparse_vllm_amd.kernels.h2o_ops import h2o_decode_finish
-    d = torch.device("cuda:0")
-    g = torch.Generator(device="cpu").manual_seed(9)
-    B, Hq, Hkv, D, W, bs, rows = 5, 28, 4, 128, 700, 128, 7
-    slots = 6000
-    kc = (torch.randn(slots, Hkv, D, generator=g) * 0.3).bfloat16().to(d)
-    vc = (torch.randn(slots, Hkv, D, generator=g) * 0.3).bfloat16().to(d)
-    q = (torch.randn(B, Hq, D, generator=g) * 0.3).bfloat16().to(d)
-    table = torch.randperm(slots, generator=g)[: rows * W].to(torch.int32).view(rows, W).to(d)
-    req = torch.tensor([3, 0, 6, 2, 5], dtype=torch.int32, device=d)
-    lens = torch.tensor([700, 1, 129, 640, 257], dtype=torch.int32, device=d)
-    nblk = (W + bs - 1) // bs
-    outs = []
-    for fused in (False, True):
-        for rep in range(2):
-            mid = torch.zeros(B, Hq, nblk, D, device=d)
-            lse = torch.zeros(B, Hq, nblk, device=d)
-            score = torch.full((B, W), -1e20, device=d)
-            cum = torch.arange(rows * W, dtype=torch.float32, device=d).view(rows, W) * 1e-3
-            o = torch.zeros(B, Hq, D, dtype=torch.bfloat16, device=d)
-            if fused:
-                h2o_decode_fused(q, kc, vc, table, req, lens, W, mid, lse, score, bs, o, D ** -0.5, cum_score=cum)
-            else:
-                flash_decode_stage1_with_score(q, kc, vc, table, req, lens, W, mid, lse, score, bs)
-                h2o_decode_finish(mid, lse, lens, o, bs, score, D ** -0.5, cum_score=cum, b_req_idx=req)
-            torch.cuda.synchronize()
-        outs.append((o.clone(), score.clone(), cum.clone()))
-    torch.testing.assert_close(outs[1][0].float(), outs[0][0].float(), rtol=2e-2, atol=2e-3)
-    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-9)
-    torch.testing.assert_close(outs[1][2], outs[0][2], rtol=1e-6, atol=1e-7)
-
-
 @pytest.mark.parametrize("mode", [0, 2, 3])
 @pytest.mark.parametrize("shape", [
     dict(B=3, Hq=28, Hkv=4, D=128, lens=[4224, 4100, 17], block_seq=1056),
@@ -466,8 +399,6 @@ def test_decode_with_fused_store_equals_store_then_decode(shape, mode):
     a lane with slot -1 (padded graph lane) stores nothing."""
     import os
     from sparse_vllm_amd.kernels import flash_decode_stage1, flash_decode_stage1_with_score, store_kvcache
-    if os.environ.get("SVK_STAGE1_VARIANT", "3") != "3":
-        pytest.skip("the fused store is built into the default stage-1 kernel only")
     B, Hq, Hkv, D, lens, block_seq = (shape[k] for k in ("B", "Hq", "Hkv", "D", "lens", "block_seq"))
     q, k, v, req, bidx, blen = _rand_case(31 + mode, B, Hq, Hkv, D, lens, block_seq)
     max_len = int(max(lens))
@@ -525,8 +456,8 @@ def test_single_block_decode_writes_output_itself(shape, mode):
     import os
     from sparse_vllm_amd.kernels import flash_decode_stage1, flash_decode_stage1_with_score, flash_decode_stage2
     from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import direct_out_supported
-    if os.environ.get("SVK_STAGE1_VARIANT", "3") != "3" or os.environ.get("SVK_DECODE_DIRECT_OUT", "1") == "0":
-        pytest.skip("direct output is built into the default stage-1 kernel only (and switched off by SVK_DECODE_DIRECT_OUT=0)")
+    if os.environ.get("SVK_DECODE_DIRECT_OUT", "1") == "0":
+        pytest.skip("direct output switched off by SVK_DECODE_DIRECT_OUT=0")
     B, Hq, Hkv, D, lens, block_seq = (shape[k] for k in ("B", "Hq", "Hkv", "D", "lens", "block_seq"))
     q, k, v, req, bidx, blen = _rand_case(77 + mode, B, Hq, Hkv, D, [max(n, 1) for n in lens], block_seq)
     blen = np.array(lens, dtype=np.int32)
@@ -579,11 +510,9 @@ def test_single_block_decode_writes_output_itself(shape, mode):
 @pytest.mark.parametrize("case", [dict(B=1, Hq=28, D=128, nblk=64, block_seq=66), dict(B=3, Hq=28, D=128, nblk=700, block_seq=256),
                                   dict(B=2, Hq=14, D=64, nblk=33, block_seq=128), dict(B=4, Hq=8, D=128, nblk=3, block_seq=2048, cap=1025)])
 def test_split_kv_merge_many_partials_vs_float64(case):
-    """Stage-2 merge (max-first form; 256- or 1024-thread workgroups by workspace capacity) and the merge inside
-    svk_h2o_decode_finish (1 / 4 / 16 waves per (lane, head)) against a float64 log-sum-exp merge: bf16 outputs within
-    one bf16 ulp of the exact result, ragged partial counts per lane."""
+    """Stage-2 merge (max-first form; 256- or 1024-thread workgroups by workspace capacity) against a float64
+    log-sum-exp merge: bf16 outputs within one bf16 ulp of the exact result, ragged partial counts per lane."""
     from sparse_vllm_amd.kernels import flash_decode_stage2
-    from sparse_vllm_amd.kernels.h2o_ops import h2o_decode_finish
     B, Hq, D, nblk, block_seq = (case[k] for k in ("B", "Hq", "D", "nblk", "block_seq"))
     cap = case.get("cap", nblk)
     d = dev()
@@ -599,11 +528,5 @@ def test_split_kv_merge_many_partials_vs_float64(case):
         ref[b] = (w[:, :, None] * mid[b, :, :n].double().numpy()).sum(axis=1) / w.sum(axis=1, keepdims=True)
     o1 = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=d)
     flash_decode_stage2(mid.to(d), lse.to(d), lens.to(d), o1, block_seq)
-    W = nblk * block_seq
-    raw = torch.zeros((B, min(W, 8192)), device=d)
-    o2 = torch.empty_like(o1)
-    h2o_decode_finish(mid.to(d), lse.to(d), lens.to(d), o2, block_seq, raw, D ** -0.5)
     torch.cuda.synchronize()
-    for o in (o1, o2):
-        got = o.float().cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=1e-3)
+    np.testing.assert_allclose(o1.float().cpu().numpy(), ref, rtol=2 ** -7, atol=1e-3)

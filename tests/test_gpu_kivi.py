@@ -278,8 +278,7 @@ def test_kivi_stage1_extra_partials(sink, raw_tail, lens, block_seq, irregular):
         blk_map[r1, 8 + 3 * G + 16: 8 + 4 * G] = -1
     shape = (B, Hq, max_len)
     extra, o, mid, lse, score = run_gpu_extra(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
-    import os
-    assert extra == (3 if os.environ.get("SVK_KIVI_VARIANT", "5") == "5" else 0)     # only the wide kernel takes extras
+    assert extra == 3                                                           # this launch takes the wide kernel
     mid_r, lse_r, score_r = run_oracle(bits, maps, max_len=max_len, G=G, block_seq=block_seq, score_shape=shape)
     o_r = oda.flash_decode_stage2(mid_r, lse_r, np.asarray(lens, np.int32), block_seq)
     np.testing.assert_allclose(o, bf16_round(o_r), rtol=ATTN_TOL, atol=ATTN_TOL)
@@ -303,9 +302,6 @@ def test_kivi_stage1_fused_raw_store_equals_store_then_launch(spare):
     new rows before it reads them.  Against store_kvcache followed by the plain launch: raw caches, partials, scores and
     merged outputs bit-identical, padded lanes (slot -1) untouched; with the extra workgroups and with the last-workgroup
     form."""
-    import os
-    if os.environ.get("SVK_KIVI_VARIANT", "5") != "5":
-        pytest.skip("the fused raw store is built into the wide kernel (the default)")
     from sparse_vllm_amd.kernels import store_kvcache
     from sparse_vllm_amd.kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1, kivi_fused_store_supported
     from sparse_vllm_amd.kernels.flash_decoding_stage2 import flash_decode_stage2

@@ -137,8 +137,6 @@ def test_prefill_score_from_attention_statistics(cfg):
     import os
     from sparse_vllm_amd.kernels.context_flashattention_nopad import context_attention_fwd
     from sparse_vllm_amd.kernels.prefill_score import prefill_score_fwd, prefill_score_window_pad
-    if os.environ.get("SVK_PREFILL_ATTN_VARIANT", "2") != "2" or os.environ.get("SVK_PREFILL_SCORE_VARIANT", "2") != "2":
-        pytest.skip("the statistics hand-over is built into the default (v2) attention and prefill_score kernels")
     Hq, Hkv, seqs_cfg, window = cfg
     D = 128
     rng = np.random.default_rng(Hq + window)

@@ -1,10 +1,9 @@
 #!/bin/bash
-# PMC passes over the KIVI stage-1 kernel (developer tool): tools/pmc_kivi.sh [variant] [batch] [block_seq]
+# PMC passes over the KIVI stage-1 kernel (developer tool): tools/pmc_kivi.sh [batch] [block_seq]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-V=${1:-5}; B=${2:-4}; BS=${3:-2048}
+B=${1:-4}; BS=${2:-2048}
 O=$R/gpurun_out/pmc_kivi
 mkdir -p "$O"; cd /tmp; export TMPDIR=/tmp
-export SVK_KIVI_VARIANT=$V
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU" \
