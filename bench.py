@@ -337,7 +337,6 @@ def main():
         # same build, a few seconds each: hipGraph replay, synthetic resident state (tools/pathbench.py)
         attn_mod.flash_decode_stage1_with_score = orig
         del drv, cm, q, k, v
-        scratch.clear()
         record["calls"].clear()
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -182,7 +182,6 @@ def test_h2o_headline_batch_256_single_block_direct_out_matches_split_path():
             bs, _, _ = drv.attn.decode_launch_op.launch_config(block_seq=256, max_context_len=4224,
                                                                requires_attention_scores=True, batch_size=B)
             assert bs == 4224 and direct_out_supported(4224, bs)
-            assert drv.sparse_controller.decode_direct_out_allowed(0, B)
         else:
             assert drv.attn.decode_launch_op is None and not direct_out_supported(4224, 256)
         q, k, v = drv.random_step_inputs(seed=2)
