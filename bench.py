@@ -50,7 +50,35 @@ def parse():
     ap.add_argument("--max-model-len", type=int, default=131072, help="row stride of the slot table / score tensor")
     ap.add_argument("--no-paths", action="store_true", help="skip the other configurations' decode-step timings")
     ap.add_argument("--path-steps", type=int, default=24)
+    ap.add_argument("--stub-driver", action="store_true",
+                    help="tests only: a stand-in decode driver that never touches a GPU (gloo ranks, a step = a fixed sleep of "
+                         "rank + 1 ms) so that the launch / rendezvous / aggregation plumbing of --gpus N runs on CPU")
     return ap.parse_args()
+
+
+class _StubDriver:
+    """`--stub-driver`: the interface of SparseDecodeDriver that main() uses, with no device behind it."""
+
+    def __init__(self, batch: int, rank: int, interval: int):
+        from types import SimpleNamespace
+        self.B, self.rank, self.interval, self.steps_done = int(batch), int(rank), int(interval), 0
+        self.cache_manager = SimpleNamespace(_h2o_counters={"decode_eviction_bursts": 0}, permute_free_slots=lambda seed: None)
+        self.config = SimpleNamespace(decode_cuda_graph=False)
+
+    def admit_resident_rows(self, *a, **kw):
+        return None
+
+    def random_step_inputs(self, seed: int = 0):
+        return None, None, None
+
+    def enable_decode_graph(self):
+        self.config.decode_cuda_graph = True
+
+    def step(self, q, k, v, outputs=None, *, after_layers=None):
+        time.sleep(1e-3 * (self.rank + 1))
+        self.steps_done += 1
+        if self.steps_done % self.interval == 0:
+            self.cache_manager._h2o_counters["decode_eviction_bursts"] += self.B
 
 
 def _cpu_model() -> str:
@@ -169,12 +197,18 @@ def main():
     if args.gpus != world:
         print(f"[bench] --gpus {args.gpus} does not match WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    stub = bool(args.stub_driver)
+    if stub:
+        args.no_cpu_baseline = args.no_kernel_events = args.no_paths = True
     if use_dist:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if stub:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     n_gpus = world if use_dist else 1
-    device = f"cuda:{local_rank}"
+    device = "cpu" if stub else f"cuda:{local_rank}"
     # the CPU leg forks one worker per host core, so it runs before this process creates a GPU context
     cpu = cpu_baseline() if (rank == 0 and n_gpus == 1 and not args.no_cpu_baseline) else None
 
@@ -189,7 +223,7 @@ def main():
         max_model_len=int(args.max_model_len), max_num_seqs_in_gpu=B, num_kvcache_slots=B * (budget + interval) + 4096,
         h2o_decode_budget=budget, h2o_decode_eviction_interval=interval, h2o_prefill_budget=8192,
         engine_prefill_chunk_size=8192, device=device)
-    drv = SparseDecodeDriver(conf)
+    drv = _StubDriver(B, rank, interval) if stub else SparseDecodeDriver(conf)
     cm = drv.cache_manager
     cm.permute_free_slots(20260625 + rank)
     drv.admit_resident_rows(B, budget, logical_len=131072, seed=20260625 + rank, device_rng=True)
@@ -231,10 +265,12 @@ def main():
         attn_mod.flash_decode_stage1_with_score = capturing_stage1
 
     def barrier():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     if not args.no_graph:
         drv.enable_decode_graph()
@@ -257,7 +293,7 @@ def main():
     # ---- the burst on its own: run on to the next eviction step, time the plain steps before it and the step that carries
     # the burst (select + compact over all 28 layers x B rows); every sequence pays it once per `interval` steps
     burst = None
-    if not args.no_graph:
+    if not args.no_graph and not stub:
         plain = []
         for _ in range(2 * interval + 2):
             n0 = int(cm._h2o_counters["decode_eviction_bursts"])
@@ -274,7 +310,6 @@ def main():
     if not args.no_kernel_events:
         # roofline leg: the same workload continues for a few eagerly launched steps
         drv.config.decode_cuda_graph = False
-        drv.sparse_controller._fused_h2o_layer = False
         def after_layers():
             record["on"] = False
             time_captured_launches()

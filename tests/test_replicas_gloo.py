@@ -50,3 +50,41 @@ def test_single_process_is_identity():
     assert shard_sequences(4, 0, 1) == [0, 1, 2, 3]
     with pytest.raises(ValueError):
         shard_sequences(4, 2, 2)
+
+
+def test_bench_spawn_path_two_ranks_on_cpu():
+    """`bench.py --gpus 2` started without a launcher spawns `torch.distributed.run` itself (one rank per GPU on a real
+    node); with `--stub-driver` the same code path runs here on two gloo ranks whose step is a sleep of rank + 1 ms, so the
+    launch, the rendezvous on 127.0.0.1, the barrier-bracketed timed region and the aggregation (SUM of tokens, MAX of time)
+    are exercised end to end and the one JSON line rank 0 prints is checked."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    steps, batch = 6, 5
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1",
+                          "--batch", str(batch), "--stub-driver"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout                         # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["config"]["seqs_per_gpu"] == batch and out["config"]["global_batch"] == 2 * batch
+    assert "replicas x2" in out["config"]["parallelism"]
+    # MAX over ranks: rank 1 sleeps 2 ms per step; SUM of tokens: 2 * batch * steps
+    assert out["ms_per_step"] >= 2.0
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * steps - 2 * batch * steps) < 1e-6 * 2 * batch * steps
+    assert "roofline" not in out and "cpu_baseline" not in out  # N > 1: neither leg runs
+
+
+def test_bench_refuses_mismatched_world_size():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-driver"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert res.returncode == 2 and "does not match WORLD_SIZE" in res.stderr
