@@ -344,20 +344,27 @@ def main():
         n_launch = sum(e[1] for e in events)
         bytes_total = float(sum(e[1] * B * e[2] * (2 * 4 * 128 * 2 + 4 + 4) for e in events))
         achieved = bytes_total / (ms_total * 1e-3)
-        traffic = None
+        traffic = traffic_meas = None
         pmc = os.path.join(ROOT, "profiles", "stage1_traffic.json")
+        mean_len = float(sum(e[1] * e[2] for e in events)) / n_launch
         if os.path.exists(pmc):
             try:
                 tr = json.load(open(pmc))
-                # measured per launch at one batch size (tools/make_traffic_json.py): reported for that workload only
-                traffic = tr.get("hbm_bytes_per_launch") if int(tr.get("batch", 64)) == B else None
+                # measured per launch at one batch size and row length (tools/make_traffic_json.py): reported for that batch
+                # only, and SCALED to the mean row length of the launches timed here (traffic is proportional to the rows'
+                # tokens: K + V + slot id + score per token), so that it compares like for like with
+                # algorithmic_bytes_per_launch; the measured pair stays beside it
+                if int(tr.get("batch", 64)) == B:
+                    traffic_meas = {"hbm_bytes_per_launch": tr.get("hbm_bytes_per_launch"), "row_len": tr.get("row_len"),
+                                    "algorithmic_bytes_per_launch": tr.get("algorithmic_bytes_per_launch")}
+                    traffic = float(tr["hbm_bytes_per_launch"]) * mean_len / float(tr["row_len"])
             except Exception:
-                traffic = None
+                traffic = traffic_meas = None
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_measured": traffic_meas, "mean_row_len": mean_len,
             "traffic_source": "profiles/stage1_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/kbench.py "
-                              "at this batch (builder-run, not re-measured in this process)",
+                              "at this batch (builder-run, not re-measured in this process), scaled by mean_row_len / its row_len",
             "kernel": "decode_stage1_kernel_v3<128,7,HEADMAX,nt,off32> (scored GQA split-KV decode)",
             "launches_timed": n_launch, "avg_launch_us": ms_total * 1e3 / n_launch,
             "timing": (f"{args.event_steps} eagerly launched steps continue the timed region; after each step's layer "
@@ -377,7 +384,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import pathbench
         out["paths"] = []
-        for name in ("h2o_b64", "streamingllm", "quest", "deltakv"):
+        for name in ("h2o_b64", "h2o_b8", "h2o_b1", "streamingllm", "quest", "quest_b8", "deltakv"):
             try:
                 out["paths"].append(pathbench.measure(name, steps=args.path_steps, warmup=4, graph=True))
             except Exception as e:      # a failing side leg must not lose the headline line

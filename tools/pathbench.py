@@ -9,6 +9,7 @@ BASELINE.json "other configs" (SURVEY section 8(d)), Qwen2.5-7B shapes, syntheti
   deltakv       256k context, sink 8 / recent 128 / keep 2048, K=4, latent 256 int4, 6 KIVI-int4 full layers, B=1
   deltakv_raw   same with raw bf16 full layers at 64k context
   vanilla       8k context dense decode, B=16
+  h2o_b<N>      the headline configuration at N sequences; quest_b8 / deltakv_b4: the B=8 / B=4 points of SURVEY 8(d)
 One JSON line per configuration: ms per decode step of the sparse path (all layers, no dense model).
 """
 import argparse
@@ -34,17 +35,17 @@ def build(name: str):
         drv.cache_manager.permute_free_slots(1)
         drv.admit_resident_rows(64, 576, logical_len=32768, seed=0, device_rng=True)
         return drv, dict(batch=64, context=32768, resident=576)
-    if name == "quest":
-        B, ctx = 4, 131072
+    if name in ("quest", "quest_b8"):
+        B, ctx = (8 if name == "quest_b8" else 4), 131072
         cfg = Config.from_kwargs(sparse_method="quest", sink_keep_tokens=64, decode_keep_tokens=4096, recent_keep_tokens=512,
                                  max_model_len=ctx + 256, max_num_seqs_in_gpu=B, num_kvcache_slots=B * (ctx + 256), **QWEN)
         drv = SparseDecodeDriver(cfg)
         drv.cache_manager.permute_free_pages(1)
         drv.admit_resident_rows(B, ctx, seed=0, device_rng=True)
         return drv, dict(batch=B, context=ctx, token_budget=cfg.quest_token_budget)
-    if name in ("deltakv", "deltakv_raw"):
-        kivi = name == "deltakv"
-        B, ctx = 1, 8 + 128 * (2048 if kivi else 512)     # tail == recent: room for `recent` decode steps
+    if name in ("deltakv", "deltakv_raw", "deltakv_b4"):
+        kivi = name != "deltakv_raw"
+        B, ctx = (4 if name == "deltakv_b4" else 1), 8 + 128 * (2048 if kivi else 512)     # tail == recent: room for `recent` decode steps
         cfg = Config.from_kwargs(sparse_method="deltakv", full_attention_layers="0,1,2,8,18,27" if kivi else "0,1,2,8,18",
                                  sink_keep_tokens=8, recent_keep_tokens=128, decode_keep_tokens=2048, deltakv_neighbor_count=4,
                                  deltakv_latent_dim=256, deltakv_latent_quant_bits=4, deltakv_latent_quant_group_size=32,
@@ -72,16 +73,16 @@ def algorithmic_bytes_per_step(name: str, info: dict, mean_row_len: float | None
     metadata scan (128 B per context token and sparse layer), DeltaKV's father gathers / latents / scratch writes and the
     712 B per token of a KIVI-int4 full layer."""
     B, L = info["batch"], 28
-    if name in ("h2o", "h2o_b64"):
+    if name.startswith("h2o"):
         return B * L * float(mean_row_len) * 2056
     if name == "streamingllm":
         return B * L * float(mean_row_len) * 2052
     if name == "vanilla":
         return B * L * float(info["context"]) * 2052
-    if name == "quest":
+    if name in ("quest", "quest_b8"):
         ctx, budget = info["context"], info["token_budget"]
         return B * ((L - 2) * (ctx * 128 + budget * 2056) + 2 * ctx * 2052)
-    if name in ("deltakv", "deltakv_raw"):
+    if name in ("deltakv", "deltakv_raw", "deltakv_b4"):
         ctx, nfull = info["context"], info["full_layers"]
         keep, K, view = 2048, 4, 8 + 2048 + 256
         sparse = keep * (K * 2048 + 160 + 2048) + view * 2052
@@ -101,10 +102,109 @@ def build_h2o(B: int):
     return drv, dict(batch=B, context=131072, resident=budget)
 
 
-def measure(name: str, *, steps: int = 32, warmup: int = 4, graph: bool = True) -> dict:
-    """Build the configuration, run `warmup` + `steps` decode steps of its sparse path, -> one result dict."""
+# ---------------------------------------------------------------------------------------------------------------------
+# kernel-level figures of a path: the launches of its main kernels, recorded during ONE eagerly launched step and
+# re-issued - between the step's layer loop and its post_forward, on the step's own data - as a hipGraph of back-to-back
+# launches per kernel, replayed between one pair of HIP events (the recorded Python arguments keep every tensor alive;
+# all of these launches are idempotent).
+# ---------------------------------------------------------------------------------------------------------------------
+KV_TOKEN_BYTES = 2 * 4 * 128 * 2          # K + V row of one token, Qwen2.5-7B heads, bf16
+
+
+def _lens_sum(t) -> float:
+    return float(t.sum().item())
+
+
+def _kernel_specs(name: str):
+    """-> [(label, module, attribute, group(args, kw) -> suffix, bytes(args, kw) -> algorithmic bytes of the launch)]"""
+    import sparse_vllm_amd.layers.attention as attn_mod
+    specs = [
+        ("decode_stage1_kernel_v3 (scored, svk_flash_decode_stage1)", attn_mod, "flash_decode_stage1_with_score",
+         lambda a, kw: "", lambda a, kw: _lens_sum(a[5]) * (KV_TOKEN_BYTES + 8)),
+        ("decode_stage1_kernel_v3 (svk_flash_decode_stage1)", attn_mod, "flash_decode_stage1",
+         lambda a, kw: " dense rows" if int(a[6]) > 8192 else "", lambda a, kw: _lens_sum(a[5]) * (KV_TOKEN_BYTES + 4)),
+        ("kivi_stage1_tile128_kernel (svk_kivi_decode_stage1)", attn_mod, "full_layer_kivi_flash_decode_stage1",
+         lambda a, kw: "", lambda a, kw: _lens_sum(kw["context_lens"]) * 712),
+    ]
+    if name.startswith("quest"):
+        from sparse_vllm_amd.engine.cache_manager import quest as qmod
+        # the manager calls quest_ops.<fn>: patch the functions on the module object it imported
+        specs += [
+            ("quest_score_pages_kernel (svk_quest_score_pages)", qmod.quest_ops, "score_pages", lambda a, kw: "",
+             lambda a, kw: float(a[0].shape[0]) * int(kw["n_prev"]) * 2 * a[1].shape[1] * a[1].shape[2] * 2),
+            ("quest_build_view_kernel (svk_quest_build_view)", qmod.quest_ops, "build_view", lambda a, kw: "",
+             lambda a, kw: float(a[5].shape[0]) * (int(kw["n_prev"]) * 4 + int(kw["max_keep"]) * 4)),
+        ]
+    return specs
+
+
+def kernel_timings(drv, q, k, v, name: str, *, replays: int = 5) -> list[dict]:
+    specs = _kernel_specs(name)
+    calls: dict[str, list] = {}
+    recording = {"on": False}
+    saved = []
+    for label, mod, attr, group, nbytes in specs:
+        orig = getattr(mod, attr)
+
+        def wrapper(*a, _orig=orig, _label=label, _group=group, _nbytes=nbytes, **kw):
+            if recording["on"]:
+                calls.setdefault(_label + _group(a, kw), []).append((_orig, a, dict(kw), _nbytes))
+            return _orig(*a, **kw)
+
+        saved.append((mod, attr, orig))
+        setattr(mod, attr, wrapper)
+    results: list[dict] = []
+
+    def after_layers():
+        recording["on"] = False
+        for label, lst in calls.items():
+            nb = sum(f(a, kw) for _o, a, kw, f in lst) / len(lst)
+            torch.cuda.synchronize()
+            for orig, a, kw, _f in lst:          # once eagerly: first-use allocations of the wrappers happen outside the capture
+                orig(*a, **kw)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for orig, a, kw, _f in lst:
+                    orig(*a, **kw)
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(replays):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (replays * len(lst))
+            results.append(dict(kernel=label, launches_per_step=len(lst), kernel_us=round(us, 2),
+                                algorithmic_mb_per_launch=round(nb / 1e6, 3), frac=round(nb / (us * 1e-6) / 8.0e12, 4)))
+            del g
+        calls.clear()
+
+    try:
+        was_graph = bool(getattr(drv.config, "decode_cuda_graph", False))
+        drv.config.decode_cuda_graph = False
+        recording["on"] = True
+        drv.step(q, k, v, after_layers=after_layers)
+        torch.cuda.synchronize()
+        drv.config.decode_cuda_graph = was_graph
+    finally:
+        for mod, attr, orig in saved:
+            setattr(mod, attr, orig)
+    return sorted(results, key=lambda r: -r["kernel_us"] * r["launches_per_step"])
+
+
+def measure(name: str, *, steps: int = 32, warmup: int = 4, graph: bool = True, kernels: bool = True) -> dict:
+    """Build the configuration, run `warmup` + `steps` decode steps of its sparse path, -> one result dict.
+    StreamingLLM is timed over at least one whole window cycle (rows walk 576 -> 1151 -> 576: 576 steps), so that the
+    figure is the cycle mean and not wherever in the cycle a short window happens to sit."""
     t0 = time.perf_counter()
-    drv, info = build_h2o(64) if name == "h2o_b64" else build(name)
+    if name.startswith("h2o_b"):
+        drv, info = build_h2o(int(name[5:]))
+    else:
+        drv, info = build(name)
+    if name == "streamingllm":
+        steps = max(int(steps), 576)
     q, k, v = drv.random_step_inputs(seed=1)
     if graph:
         drv.enable_decode_graph()
@@ -120,10 +220,19 @@ def measure(name: str, *, steps: int = 32, warmup: int = 4, graph: bool = True) 
         lens.append(float(drv.row_len()[0]))
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t1) * 1e3 / steps
-    nbytes = algorithmic_bytes_per_step(name, info, mean_row_len=sum(lens) / len(lens))
+    mean_len = sum(lens) / len(lens)
+    nbytes = algorithmic_bytes_per_step(name, info, mean_row_len=mean_len)
     res = dict(config=name, ms_per_step=round(ms, 4), tokens_per_s=round(info["batch"] / ms * 1e3, 1),
                algorithmic_mb_per_step=round(nbytes / 1e6, 1), roofline_frac=round(nbytes / (ms * 1e-3) / 8.0e12, 4),
-               graph=bool(graph), steps=steps, setup_s=round(setup, 1), **info)
+               mean_row_len=round(mean_len, 1), graph=bool(graph), steps=steps, setup_s=round(setup, 1), **info)
+    if kernels:
+        try:
+            ks = kernel_timings(drv, q, k, v, name)
+            res["kernels"] = ks
+            if ks:
+                res["dominant_kernel"], res["kernel_us"], res["kernel_frac"] = ks[0]["kernel"], ks[0]["kernel_us"], ks[0]["frac"]
+        except Exception as e:      # a failing side leg must not lose the step timing
+            res["kernels_error"] = f"{type(e).__name__}: {e}"
     del drv, q, k, v
     torch.cuda.empty_cache()
     return res
