@@ -673,6 +673,40 @@ def gen_kivi():
                value_mins=bits(value_mins), req=req.numpy(), lens=clens.numpy(),
                cfg=np.array([G, block_seq, max(lens)], dtype=np.int64), mid_o=mid.numpy(), mid_lse=lse.numpy(),
                score=score.numpy())
+    # ---- one LONG row (8259 tokens, one KV head, 7 query heads of 128 dims) so that the decode kernel is pinned by the
+    # reference above toy size; the inputs come from a seed shared with the tests (tests/golden_inputs.py), only the
+    # reference's partials and raw scores are stored
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import golden_inputs
+    d = golden_inputs.kivi_long_row_inputs()
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    q, raw_k, raw_v = T(d["q"]), T(d["raw_k"]), T(d["raw_v"])
+    raw_map, blk_map, blk_start = T(d["raw_map"]), T(d["blk_map"]), T(d["blk_start"])
+    key_packed, value_packed = T(d["key_packed"]), T(d["value_packed"])
+    key_scales, key_mins, value_scales, value_mins = T(d["key_scales"]), T(d["key_mins"]), T(d["value_scales"]), T(d["value_mins"])
+    req, clens = T(d["req"]), T(d["lens"])
+    Hq, Hkv, D, G, length = d["Hq"], d["Hkv"], d["D"], d["G"], d["length"]
+    block_seq = 1024
+    nblk = (length + block_seq - 1) // block_seq
+    mid = torch.zeros(1, Hq, nblk, D); lse = torch.zeros(1, Hq, nblk)
+    score = torch.full((1, Hq, length), -1e20)
+    dk._full_layer_kivi_flash_decode_stage1_kernel[(1, Hkv, nblk)](
+        q, raw_k, raw_v, raw_map, blk_map, blk_start, key_packed, key_scales, key_mins, value_packed, value_scales,
+        value_mins, req, clens, mid, lse, score,
+        q.stride(0), q.stride(1), q.stride(2), raw_k.stride(0), raw_k.stride(1), raw_k.stride(2),
+        raw_v.stride(0), raw_v.stride(1), raw_v.stride(2), raw_map.stride(0), raw_map.stride(1),
+        blk_map.stride(0), blk_map.stride(1),
+        key_packed.stride(0), key_packed.stride(1), key_packed.stride(2), key_packed.stride(3),
+        key_scales.stride(0), key_scales.stride(1), key_scales.stride(2),
+        value_packed.stride(0), value_packed.stride(1), value_packed.stride(2), value_packed.stride(3),
+        value_scales.stride(0), value_scales.stride(1), value_scales.stride(2), value_scales.stride(3),
+        mid.stride(0), mid.stride(1), mid.stride(2), mid.stride(3), lse.stride(0), lse.stride(1), lse.stride(2),
+        score.stride(0), score.stride(1), score.stride(2),
+        sm_scale=1.0 / (D ** 0.5), gqa_group_size=Hq // Hkv, Q_HEAD_NUM=16, BLOCK_SEQ=block_seq, BLOCK_DMODEL=D,
+        BLOCK_N=16, GROUP_SIZE=G, FEAT_PER_INT=8, QUANT_MASK=15, STORE_SCORE=True)
+    out.update(long_cfg=np.array([G, block_seq, length], dtype=np.int64), long_mid_o=mid.numpy(), long_mid_lse=lse.numpy(),
+               long_score=score.numpy())
     save("kivi", **out)
 
 
@@ -776,6 +810,18 @@ def gen_deltakv_compress():
     out.update(cc_cache_k=bits(m.deltakv_full_kv_cache[0, 0].float()), cc_cache_v=bits(m.deltakv_full_kv_cache[1, 0].float()),
                cc_kv=bits(kv[0].float()), cc_existing=existing.numpy(), cc_rel=rel.numpy().astype(np.int32),
                cc_topk=topk.numpy(), cc_base=bits(base[0].float()), cc_k=np.array([3], dtype=np.int64))
+    # ---- the same through IRREGULAR centre positions (BASELINE configs[4] is "dynamic-stride": explicit positions instead
+    # of range(0, n, step); the reference's own kernel test uses these six, tests/test_deltakv_less_memory_kernel.py:129-160)
+    m.config = SimpleNamespace(deltakv_k_neighbors=4, cluster_metric="l2", deltakv_cluster_gather_chunk_size=16384)
+    n = 37
+    kv = (torch.randn(1, n, 2 * Hkv * D, generator=g) * 0.5).to(torch.bfloat16)
+    existing = torch.tensor([7, 22, 61], dtype=torch.int32)
+    rel = torch.tensor([0, 5, 11, 18, 27, 35], dtype=torch.long)
+    topk, base = m._cluster_compress(layer_idx=1, kv_states=kv, existing_center_slots=existing, cluster_step=10,
+                                     new_center_rel=rel, validate_centers=False)
+    out.update(ci_cache_k=out["cc_cache_k"], ci_cache_v=out["cc_cache_v"], ci_kv=bits(kv[0].float()), ci_existing=existing.numpy(),
+               ci_rel=rel.numpy().astype(np.int32), ci_topk=topk.numpy(), ci_base=bits(base[0].float()),
+               ci_k=np.array([4], dtype=np.int64))
     save("deltakv_compress", **out)
 
 

@@ -85,9 +85,14 @@ def test_kivi_store_blocks_vs_oracle(H, D, G, key_f32):
     assert np.isfinite(deq).all()
 
 
-def test_cluster_topk_and_gather_mean(golden):
+@pytest.mark.parametrize("tag", ["cc", "ci"])
+def test_cluster_topk_and_gather_mean(golden, tag):
+    """`cc`: regular centre stride; `ci`: irregular centre positions [0, 5, 11, 18, 27, 35] through the reference's
+    `_cluster_compress` (dynamic-stride form of BASELINE configs[4])."""
     from sparse_vllm_amd.kernels.deltakv_kernels import cluster_topk, gather_mean_fathers
-    g = golden("deltakv_compress")
+    g0 = golden("deltakv_compress")
+    g = {k_[3:]: g0[k_] for k_ in g0.files if k_.startswith(tag + "_")}
+    g = {"cc_" + k_: v_ for k_, v_ in g.items()}
     k = int(g["cc_k"][0])
     ck, cv = bf16_bits_to_f32(g["cc_cache_k"]), bf16_bits_to_f32(g["cc_cache_v"])
     cache = np.concatenate((ck.reshape(64, -1), cv.reshape(64, -1)), axis=1)

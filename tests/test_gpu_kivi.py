@@ -108,6 +108,54 @@ def test_kivi_stage1_golden(golden):
             g["lens"], block_seq)
 
 
+@pytest.mark.parametrize("block_seq,spare", [(1024, 0), (1024, 3), (2048, 3), (256, 0)])
+def test_kivi_stage1_long_row_golden(golden, block_seq, spare):
+    """The reference's kernel on one 8259-token row (tests/golden/kivi.npz `long_*`, inputs from the shared seed): merged
+    output against the merge of the reference's partials, raw scores position by position - with the reference's
+    block_seq and with others (any partition of the row merges to the same output), with and without the extra
+    workgroups; this shape (head_dim 128, one KV head, fp32 key parameters) takes the wide kernel."""
+    import golden_inputs
+    from oracle import decode_attention as oda
+    from sparse_vllm_amd.kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1
+    from sparse_vllm_amd.kernels.flash_decoding_stage2 import flash_decode_stage2
+    g = golden("kivi")
+    G, ref_block_seq, length = (int(x) for x in g["long_cfg"])
+    d = golden_inputs.kivi_long_row_inputs()
+    f2b = f32_to_bf16_bits
+    q = bf(f2b(d["q"]))
+    nblk = (length + block_seq - 1) // block_seq
+    mid = torch.full((1, d["Hq"], nblk + spare, d["D"]), 7.0, dtype=torch.float32, device=dev())
+    lse = torch.full((1, d["Hq"], nblk + spare), 7.0, dtype=torch.float32, device=dev())
+    score = torch.full((1, d["Hq"], length), -1e20, dtype=torch.float32, device=dev())
+    lens = t(d["lens"])
+    extra = full_layer_kivi_flash_decode_stage1(
+        q=q, raw_k=bf(f2b(d["raw_k"])), raw_v=bf(f2b(d["raw_v"])), raw_slots_map=t(d["raw_map"]),
+        kivi_block_slots_map=t(d["blk_map"]), kivi_block_start_pos=t(d["blk_start"]), key_packed=t(d["key_packed"]),
+        key_scales=t(d["key_scales"]), key_mins=t(d["key_mins"]), value_packed=t(d["value_packed"]),
+        value_scales=bf(f2b(d["value_scales"])), value_mins=bf(f2b(d["value_mins"])), req_indices=t(d["req"]), context_lens=lens,
+        max_len_in_batch=length, mid_out=mid, mid_out_logsumexp=lse, group_size=G, block_seq=block_seq, attn_score=score,
+        extra_partial_slots=spare)
+    assert extra == (3 if spare and block_seq % 128 == 0 else 0)
+    o = torch.empty((1, d["Hq"], d["D"]), dtype=torch.bfloat16, device=dev())
+    flash_decode_stage2(mid, lse, lens, o, block_seq, extra_partials=extra)
+    torch.cuda.synchronize()
+    o_ref = oda.flash_decode_stage2(g["long_mid_o"], g["long_mid_lse"], d["lens"], ref_block_seq)
+    # the interpreter run keeps the dequantised K / V in fp32 (no `.to(q.dtype)` rounding): the fixture tolerance of
+    # test_kivi_stage1_golden
+    np.testing.assert_allclose(o.float().cpu().numpy(), o_ref, rtol=ATTN_TOL, atol=ATTN_TOL)
+    np.testing.assert_allclose(score.cpu().numpy(), g["long_score"], rtol=2e-2, atol=5e-2)
+    # and the oracle with the real bf16 data flow: tight
+    sc_o = np.full(g["long_score"].shape, -1e20, np.float32)
+    mid_o, lse_o = ok.full_layer_kivi_flash_decode_stage1(
+        q=d["q"], raw_k=d["raw_k"], raw_v=d["raw_v"], raw_slots_map=d["raw_map"], kivi_block_slots_map=d["blk_map"],
+        kivi_block_start_pos=d["blk_start"], key_packed=d["key_packed"], key_scales=d["key_scales"], key_mins=d["key_mins"],
+        value_packed=d["value_packed"], value_scales=d["value_scales"], value_mins=d["value_mins"], req_indices=d["req"],
+        context_lens=d["lens"], max_len_in_batch=length, group_size=G, block_seq=ref_block_seq, attn_score=sc_o)
+    np.testing.assert_allclose(score.cpu().numpy(), sc_o, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(o.float().cpu().numpy(), bf16_round(oda.flash_decode_stage2(mid_o, lse_o, d["lens"], ref_block_seq)),
+                               rtol=ATTN_TOL, atol=ATTN_TOL)
+
+
 def make_case(rng, *, B, Hq, Hkv, D, G, lens, rows, raw_tail, sink, key_f32=False):
     """Rows = [sink raw tokens | KIVI blocks of G tokens | raw tail]; block slots and raw slots scattered."""
     f2b = f32_to_bf16_bits
