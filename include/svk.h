@@ -279,7 +279,13 @@ int svk_compact_rows(const SvkCompactRowsArgs* a, svk_stream_t stream);
  *                              slots go to the free stack in lane order, exactly where the host-driven burst puts
  *                              them), then row_len = budget and free_ptr[l] += dropped; rows below the trigger return
  *                              at once (three launches, microseconds when nothing triggers).
- * Rows are uniform across layers (H2O's invariant, h2o.py:256-271). */
+ * Rows are uniform across layers (H2O's invariant, h2o.py:256-271).
+ * The same two calls serve StreamingLLM (round 4): select_mode SVK_DEVICE_SELECT_WINDOW keeps the sink
+ * [0, budget - recent_count) and the recent_count newest positions of a row that reached trigger_len = 2 * (sink + recent)
+ * (SparseController._streamingllm_decode_eviction, sparse_controller.py:1558-1668 -> free_prefix_recent_slots_batch_layers,
+ * snapkv.py:1805-1896); `scores` may then be NULL (no payload rows to compact). */
+#define SVK_DEVICE_SELECT_H2O 0
+#define SVK_DEVICE_SELECT_WINDOW 1
 typedef struct SvkH2oDeviceStepArgs {
   int32_t* slot_table;         /* [L, rows, table_stride_row]                         */
   int32_t* free_stack;         /* [L, stack_stride]                                   */
@@ -294,7 +300,8 @@ typedef struct SvkH2oDeviceStepArgs {
   int64_t table_stride_layer, table_stride_row, stack_stride;
   int64_t score_stride_layer, score_stride_row, out_stride;
   int32_t n_layers, rows_total, batch, graph_batch;
-  int32_t budget, recent_count, trigger_len, _pad;
+  int32_t budget, recent_count, trigger_len;
+  int32_t select_mode;         /* SVK_DEVICE_SELECT_H2O (0) | SVK_DEVICE_SELECT_WINDOW (1)  */
 } SvkH2oDeviceStepArgs;
 int svk_h2o_device_step_begin(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);
 int svk_h2o_device_burst(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);

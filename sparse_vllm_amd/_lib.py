@@ -103,7 +103,7 @@ class SvkH2oDeviceStepArgs(C.Structure):
                [(n, _i64) for n in ("table_stride_layer", "table_stride_row", "stack_stride", "score_stride_layer",
                                     "score_stride_row", "out_stride")] + \
                [(n, _i32) for n in ("n_layers", "rows_total", "batch", "graph_batch", "budget", "recent_count",
-                                    "trigger_len", "_pad")]
+                                    "trigger_len", "select_mode")]
 
 
 class SvkQuestPageMinmaxArgs(C.Structure):

@@ -271,8 +271,15 @@ __global__ void __launch_bounds__(256) h2o_device_select_kernel(const SvkH2oDevi
   const int b = blockIdx.x, l = blockIdx.y;
   const int row = a.row_ids[b];
   if (a.row_len[(int64_t)l * a.rows_total + row] != a.trigger_len) return;
-  h2o_select_row(a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row,
-                 a.keep + ((int64_t)l * a.batch + b) * a.budget, a.trigger_len, a.budget, a.recent_count, scratch);
+  int64_t* keep = a.keep + ((int64_t)l * a.batch + b) * a.budget;
+  if (a.select_mode == SVK_DEVICE_SELECT_WINDOW) {
+    // sink + recent window (StreamingLLM, sparse_controller.py:1661-1668): [0, budget - recent) ++ [len - recent, len)
+    const int prefix = a.budget - a.recent_count;
+    for (int i = threadIdx.x; i < a.budget; i += blockDim.x) keep[i] = i < prefix ? i : a.trigger_len - a.budget + i;
+    return;
+  }
+  h2o_select_row(a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row, keep, a.trigger_len,
+                 a.budget, a.recent_count, scratch);
 }
 
 __global__ void __launch_bounds__(256) h2o_device_compact_kernel(const SvkH2oDeviceStepArgs a) {
@@ -292,7 +299,7 @@ __global__ void __launch_bounds__(256) h2o_device_compact_kernel(const SvkH2oDev
   const int K = a.budget, cur = a.trigger_len;
   int32_t* tab = a.slot_table + (int64_t)l * a.table_stride_layer + (int64_t)row * a.table_stride_row;
   int32_t* stack = a.free_stack + (int64_t)l * a.stack_stride + a.free_ptr[l] + (int64_t)rank * (cur - K);
-  float* pay = a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row;
+  float* pay = a.scores ? a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row : nullptr;
   compact_row(tab, stack, pay, a.keep + ((int64_t)l * a.batch + b) * K, K, cur);
 }
 
@@ -484,8 +491,12 @@ extern "C" int svk_h2o_device_step_begin(const SvkH2oDeviceStepArgs* a, svk_stre
 
 extern "C" int svk_h2o_device_burst(const SvkH2oDeviceStepArgs* a, svk_stream_t stream) {
   using namespace svk;
-  SVK_REQUIRE(a != nullptr && a->row_len != nullptr && a->free_ptr != nullptr && a->row_ids != nullptr && a->keep != nullptr &&
-                  a->scores != nullptr, SVK_ERR_VALUE, "svk_h2o_device_burst: null args");
+  SVK_REQUIRE(a != nullptr && a->row_len != nullptr && a->free_ptr != nullptr && a->row_ids != nullptr && a->keep != nullptr,
+              SVK_ERR_VALUE, "svk_h2o_device_burst: null args");
+  SVK_REQUIRE(a->select_mode == SVK_DEVICE_SELECT_H2O || a->select_mode == SVK_DEVICE_SELECT_WINDOW, SVK_ERR_VALUE,
+              "svk_h2o_device_burst: bad select_mode %d", a->select_mode);
+  SVK_REQUIRE(a->select_mode != SVK_DEVICE_SELECT_H2O || a->scores != nullptr, SVK_ERR_VALUE,
+              "svk_h2o_device_burst: the heavy-hitter selection needs the cumulative score tensor");
   SVK_REQUIRE(a->budget > 0 && a->trigger_len > a->budget, SVK_ERR_VALUE,
               "svk_h2o_device_burst: trigger_len %d must exceed the budget %d", a->trigger_len, a->budget);
   SVK_REQUIRE(a->recent_count >= 1 && a->recent_count <= a->budget, SVK_ERR_VALUE,

@@ -43,22 +43,7 @@ class H2OCacheManager(SnapKVCacheManager):
         self._h2o_final_prefill_workspace: torch.Tensor | None = None
         self.h2o_score_tensor = torch.zeros(
             (self.num_kv_layers, self.max_buffer_rows, self.max_model_len), dtype=torch.float32, device=self.device)
-        # MI355X: device-resident decode bookkeeping.  Row lengths and free-stack pointers also live on the
-        # device, a decode step allocates from them and runs the periodic burst behind a device-side test, so the step -
-        # burst included - is one hipGraph and uploads nothing.  The host keeps its numpy mirrors in lock-step by the same
-        # (deterministic) arithmetic; any host-driven change of rows or pointers marks the device copy stale.
-        import os
-        self._device_step_enabled = os.environ.get("SVK_H2O_DEVICE_STATE", "1") == "1"
-        self._dev_row_len = torch.zeros((self.num_kv_layers, self.max_buffer_rows), dtype=torch.int32, device=self.device)
-        self._dev_free_ptr = torch.zeros((self.num_kv_layers,), dtype=torch.long, device=self.device)
-        self._dev_state_dirty = True
-        self._dev_step_cache = None              # (key, SvkH2oDeviceStepArgs, keep-alive tensors)
-        # bumped whenever the args struct (whose device pointers a captured hipGraph bakes in by value) is rebuilt: a
-        # caller that replays a graph keys it on this, never on object identity (a freed struct's id can be reused)
-        self.device_step_generation = 0
-        self._device_step = None                 # this step's (args, rows_2d, kv_idx, burst_launched) while active
 
-    # ---- config views (h2o.py:55-71)
     @property
     def h2o_decode_budget(self) -> int:
         return int(self.config.h2o_decode_budget)
@@ -187,15 +172,6 @@ class H2OCacheManager(SnapKVCacheManager):
         if scores.dim() != 1:
             raise ValueError(f"H2O scores must be 1D, got shape={tuple(scores.shape)}.")
         return h2o_ops.select_h2o_indices_batch(scores.unsqueeze(0), budget=budget, recent_ratio=recent_ratio)[0]
-
-    # ---- host-driven changes of rows / pointers leave the device-resident copy stale
-    def _allocate(self, layer_idx: int, seq_id: int, size: int):
-        self._dev_state_dirty = True
-        return super()._allocate(layer_idx, seq_id, size)
-
-    def _compact(self, layer_indices, rows_2d, keep, cur_len):
-        self._dev_state_dirty = True
-        return super()._compact(layer_indices, rows_2d, keep, cur_len)
 
     # ---- score rows
     def _row_payload_tensor(self):
@@ -572,131 +548,25 @@ class H2OCacheManager(SnapKVCacheManager):
         self._uniform_decode_metadata = False
         self._dev_state_dirty = True
 
-    # ---- device-resident decode step (include/svk.h SvkH2oDeviceStepArgs)
-    def _device_step_plan(self, seqs, graph_batch_size: int):
-        """-> (args, rows_2d, kv_idx) when this decode step can run from the device-resident state: uniform rows / lengths /
-        pointers across the KV layers (H2O's invariant), room in the rows and - after the allocation - still free slots
-        (at zero the reference switches to the slot-pressure trigger, h2o.py:1506-1524: that step takes the host path)."""
-        if not self._device_step_enabled or not seqs:
-            return None
-        layer_ids = [int(l) for l in self.kv_transformer_layer_indices()]
-        first = layer_ids[0]
-        B = len(seqs)
-        rows0 = tuple(self._row_of(first, s) for s in seqs)
-        budget, trigger = self.h2o_decode_budget, self.h2o_decode_budget + self.h2o_decode_eviction_interval
-        key = (tuple(s.seq_id for s in seqs), rows0, tuple(layer_ids), int(graph_batch_size), budget, trigger)
-        cache = self._dev_step_cache
-        sm, cl, ri = self._get_decode_static_buffers(int(graph_batch_size))
-        if cache is not None and cache[2][2].data_ptr() != sm.data_ptr():
-            cache = None          # the static step buffers were reallocated (a larger graph batch on the host path)
-        if cache is None or cache[0] != key:
-            rows_2d = np.array([rows0] + [[self._row_of(l, s) for s in seqs] for l in layer_ids[1:]], dtype=np.int64)
-            if not bool((rows_2d == rows_2d[0]).all()) or len(layer_ids) != self.num_kv_layers:
-                return None
-            kv_idx = np.array([self.kv_layer_index(l) for l in layer_ids], dtype=np.int64)
-            d = self.device
-            rows_gpu = torch.from_numpy(rows_2d[0].astype(np.int32)).to(d)
-            keep = torch.empty((len(layer_ids), B, budget), dtype=torch.long, device=d)
-            recent = min(max(1, int(budget * float(self.config.h2o_recent_ratio))), budget)
-            args = h2o_ops.h2o_device_step_args(
-                self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor, self.h2o_score_tensor, self._dev_row_len,
-                self._dev_free_ptr, rows_gpu, sm, cl, ri, keep, batch=B, budget=budget, recent_count=recent, trigger_len=trigger)
-            cache = self._dev_step_cache = (key, args, (rows_gpu, keep, sm, cl, ri), rows_2d, kv_idx)
-            self.device_step_generation += 1
-        _, args, _keepalive, rows_2d, kv_idx = cache
-        cur = self._row_seq_lens_all[kv_idx[:, None], rows_2d]
-        ptrs = [int(self._num_free_slots[l]) for l in layer_ids]
-        if not bool((cur == cur[0]).all()) or any(p != ptrs[0] for p in ptrs[1:]):
-            return None
-        max_cur = int(cur.max())
-        static_cap = self._decode_static_max_context_len
-        if (max_cur + 1 > self.max_model_len or max_cur >= trigger or ptrs[0] - B <= 0
-                or (static_cap is not None and max_cur + 1 > int(static_cap))):
-            return None
-        return args, rows_2d, kv_idx
+    # ---- device-resident decode step: the machinery lives in SnapKVCacheManager (shared with StreamingLLM); H2O's part
+    def _device_step_params(self):
+        """-> (budget, trigger_len, recent_count, select_mode, score tensor) of the predicated burst (h2o.py:1498-1630)."""
+        budget = self.h2o_decode_budget
+        recent = min(max(1, int(budget * float(self.config.h2o_recent_ratio))), budget)
+        return budget, budget + self.h2o_decode_eviction_interval, recent, 0, self.h2o_score_tensor
 
-    def _device_state_upload(self):
-        self._dev_row_len.copy_(torch.from_numpy(self._row_seq_lens_all), non_blocking=False)
-        self._dev_free_ptr.copy_(torch.tensor([int(self._num_free_slots[int(l)]) for l in self.kv_transformer_layer_indices()],
-                                              dtype=torch.long))
-        self._dev_state_dirty = False
-
-    def prepare_decode_static(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,
-                              req_indices=None, *, graph_batch_size: int | None = None, defer_device_launch: bool = False):
-        """h2o.py:256-476.  With the device-resident state the allocation is `svk_h2o_device_step_begin` (launched here,
-        or by the caller inside its hipGraph when `defer_device_launch`), nothing is uploaded; otherwise the host-driven
-        form of the SnapKV manager."""
-        real = len(seqs)
-        gbs = int(graph_batch_size or (input_ids.numel() if input_ids is not None else real))
-        plan = self._device_step_plan(seqs, gbs) if real > 0 and real <= gbs else None
-        self._device_step = None
-        if plan is None:
-            self._dev_state_dirty = True
-            return super().prepare_decode_static(seqs, input_ids, positions, slot_mapping, context_lens, req_indices,
-                                                 graph_batch_size=graph_batch_size)
-        args, rows_2d, kv_idx = plan
-        if self._dev_state_dirty:
-            self._device_state_upload()
-        cur0 = self._row_seq_lens_all[kv_idx[0], rows_2d[0]]
-        # the host mirrors move by the arithmetic the kernel applies to the device copy
-        self._row_seq_lens_all[kv_idx[:, None], rows_2d] += 1
-        for l in self.kv_transformer_layer_indices():
-            self._num_free_slots[int(l)] -= real
-        self._decode_static_rows = ((tuple(s.seq_id for s in seqs),), rows_2d, True, kv_idx)
-        sm, cl, ri = self._get_decode_static_buffers(gbs)
-        static_cap = self._decode_static_max_context_len
-        for i, l in enumerate(self.kv_transformer_layer_indices()):
-            st = self.layer_batch_states[l]
-            st.slot_mapping, st.context_lens, st.req_indices = sm[i], cl[i], ri[i]
-            st.max_context_len = int(static_cap) if static_cap is not None else int(cur0.max()) + 1
-        self._device_step = [args, rows_2d, kv_idx, False]
-        if not defer_device_launch:
-            h2o_ops.h2o_device_step_begin(args)
-        if slot_mapping is not None:
-            slot_mapping.copy_(sm[0])
-            context_lens.copy_(cl[0])
-            req_indices.copy_(ri[0])
-        return input_ids, positions, None
-
-    def device_step_begin(self):
-        """The step's allocation launch, for a caller that took `defer_device_launch` (inside its hipGraph)."""
-        if self._device_step is not None:
-            h2o_ops.h2o_device_step_begin(self._device_step[0])
-
-    def device_step_burst(self):
-        """The step's predicated burst launches (select + compact + commit), inside the caller's hipGraph."""
-        if self._device_step is not None:
-            h2o_ops.h2o_device_burst(self._device_step[0])
-            self._device_step[3] = True
+    def _on_device_burst(self, seqs, n_rows: int, n_layers: int, dropped_per_row: int) -> None:
+        self._h2o_counters["decode_eviction_bursts"] += n_rows
+        self._h2o_counters["decode_evictions"] += n_rows * n_layers
+        self._h2o_counters["dropped_tokens"] += dropped_per_row * n_rows * n_layers
 
     def _device_step_finish(self, seqs) -> None:
-        """Host half of a device-resident step's burst: launch it if the caller has not, and move the mirrors and
-        counters (no device value is read)."""
-        args, rows_2d, kv_idx, launched = self._device_step
-        self._device_step = None
-        if not launched:
-            h2o_ops.h2o_device_burst(args)
         self._h2o_active_decode_seq_ids.update(int(s.seq_id) for s in seqs)
-        budget, trigger = self.h2o_decode_budget, self.h2o_decode_budget + self.h2o_decode_eviction_interval
-        lens = self._row_seq_lens_all[kv_idx[0], rows_2d[0]]
-        hit = lens == trigger
-        n = int(hit.sum())
-        if n == 0:
-            return
-        L = len(kv_idx)
-        self._row_seq_lens_all[kv_idx[:, None], rows_2d[:, hit]] = budget
-        for l in self.kv_transformer_layer_indices():
-            self._num_free_slots[int(l)] += n * (trigger - budget)
-        self._uniform_decode_metadata = False
-        self._h2o_counters["decode_eviction_bursts"] += n
-        self._h2o_counters["decode_evictions"] += n * L
-        self._h2o_counters["dropped_tokens"] += (trigger - budget) * n * L
+        super()._device_step_finish(seqs)
 
     # ---- lifecycle
     def free_seq(self, seq_id: int):
         self._h2o_active_decode_seq_ids.discard(int(seq_id))
-        self._dev_state_dirty = True
-        self._dev_step_cache = None
         super().free_seq(int(seq_id))
 
     def reset_after_warmup(self) -> None:

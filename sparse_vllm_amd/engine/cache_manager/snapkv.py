@@ -35,6 +35,17 @@ class SnapKVCacheManager(CacheManager):
         self._prefill_score_workspace = None
         self._prefill_context_lens_cpu_by_layer: dict[int, tuple[int, ...]] = {}
         self.allocate_kv_cache()
+        # device-resident decode bookkeeping (see `_device_step_params`); SVK_H2O_DEVICE_STATE=0: host-driven steps
+        import os
+        self._device_step_enabled = os.environ.get("SVK_H2O_DEVICE_STATE", "1") == "1"
+        self._dev_row_len = torch.zeros((self.num_kv_layers, self.max_buffer_rows), dtype=torch.int32, device=self.device)
+        self._dev_free_ptr = torch.zeros((self.num_kv_layers,), dtype=torch.long, device=self.device)
+        self._dev_state_dirty = True
+        self._dev_step_cache = None              # (key, SvkH2oDeviceStepArgs, keep-alive tensors)
+        # bumped whenever the args struct (whose device pointers a captured hipGraph bakes in by value) is rebuilt: a
+        # caller that replays a graph keys it on this, never on object identity (a freed struct's id can be reused)
+        self.device_step_generation = 0
+        self._device_step = None                 # this step's [args, rows_2d, kv_idx, burst_launched] while active
 
     # ------------------------------------------------------------------ allocation
     def _resolve_num_slots(self) -> int:
@@ -110,6 +121,7 @@ class SnapKVCacheManager(CacheManager):
     # ------------------------------------------------------------------ prefill-side allocation
     def _allocate(self, layer_idx: int, seq_id: int, size: int) -> torch.Tensor:
         """snapkv.py:1319-1340: LIFO pop of stack[ptr-size:ptr] appended to the row."""
+        self._dev_state_dirty = True              # host-driven change of rows / pointers: the device copy is stale
         assert self._num_free_slots[layer_idx] >= size, (
             f"Out of KV cache slots: need {size}, free {self._num_free_slots[layer_idx]}")
         row = self._get_free_row(layer_idx, seq_id)
@@ -298,8 +310,8 @@ class SnapKVCacheManager(CacheManager):
             self._decode_static_buffers = buf
         return tuple(t[:, :graph_batch_size] for t in buf)
 
-    def prepare_decode_static(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,
-                              req_indices=None, *, graph_batch_size: int | None = None):
+    def _prepare_decode_static_host(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,
+                                    req_indices=None, *, graph_batch_size: int | None = None):
         """Device-side decode step preparation for all layers in ONE launch
         (h2o.py:256-476 / snapkv.py:2961): every layer pops the window
         [ptr-B, ptr) of its free stack, lane b's slot is appended to row b."""
@@ -373,6 +385,136 @@ class SnapKVCacheManager(CacheManager):
             req_indices.copy_(ri[0])
         return input_ids, positions, None
 
+    # ------------------------------------------------------------------ device-resident decode step
+    # include/svk.h SvkH2oDeviceStepArgs.  Row lengths and free-stack pointers also live on the device, a decode step
+    # allocates from them and runs the method's periodic eviction behind a device-side test, so the step - eviction
+    # included - is one hipGraph and uploads nothing.  The host keeps its numpy mirrors in lock-step by the same
+    # (deterministic) arithmetic; any host-driven change of rows or pointers marks the device copy stale.  A subclass
+    # opts in by returning its parameters from `_device_step_params` (H2O: heavy hitters every `interval` tokens;
+    # StreamingLLM: sink + recent window at 2 x (sink + recent)).
+    def _device_step_params(self):
+        """-> (budget, trigger_len, recent_count, select_mode, score tensor or None), or None: host-driven steps."""
+        return None
+
+    def _on_device_burst(self, seqs, n_rows: int, n_layers: int, dropped_per_row: int) -> None:
+        """Counters of a subclass when `n_rows` sequences were evicted on every layer by the in-graph burst."""
+        return None
+
+    def _device_step_plan(self, seqs, graph_batch_size: int):
+        """-> (args, rows_2d, kv_idx) when this decode step can run from the device-resident state: uniform rows / lengths /
+        pointers across the KV layers (H2O's invariant), room in the rows and - after the allocation - still free slots
+        (at zero the reference switches to the slot-pressure trigger, h2o.py:1506-1524: that step takes the host path)."""
+        params = self._device_step_params() if self._device_step_enabled and seqs else None
+        if params is None:
+            return None
+        budget, trigger, recent, select_mode, score_tensor = params
+        layer_ids = [int(l) for l in self.kv_transformer_layer_indices()]
+        first = layer_ids[0]
+        B = len(seqs)
+        rows0 = tuple(self._row_of(first, s) for s in seqs)
+        key = (tuple(s.seq_id for s in seqs), rows0, tuple(layer_ids), int(graph_batch_size), budget, trigger, recent, select_mode)
+        cache = self._dev_step_cache
+        sm, cl, ri = self._get_decode_static_buffers(int(graph_batch_size))
+        if cache is not None and cache[2][2].data_ptr() != sm.data_ptr():
+            cache = None          # the static step buffers were reallocated (a larger graph batch on the host path)
+        if cache is None or cache[0] != key:
+            rows_2d = np.array([rows0] + [[self._row_of(l, s) for s in seqs] for l in layer_ids[1:]], dtype=np.int64)
+            if not bool((rows_2d == rows_2d[0]).all()) or len(layer_ids) != self.num_kv_layers:
+                return None
+            kv_idx = np.array([self.kv_layer_index(l) for l in layer_ids], dtype=np.int64)
+            d = self.device
+            rows_gpu = torch.from_numpy(rows_2d[0].astype(np.int32)).to(d)
+            keep = torch.empty((len(layer_ids), B, budget), dtype=torch.long, device=d)
+            args = h2o_ops.h2o_device_step_args(
+                self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor, score_tensor, self._dev_row_len,
+                self._dev_free_ptr, rows_gpu, sm, cl, ri, keep, batch=B, budget=budget, recent_count=recent, trigger_len=trigger,
+                select_mode=select_mode)
+            cache = self._dev_step_cache = (key, args, (rows_gpu, keep, sm, cl, ri), rows_2d, kv_idx)
+            self.device_step_generation += 1
+        _, args, _keepalive, rows_2d, kv_idx = cache
+        cur = self._row_seq_lens_all[kv_idx[:, None], rows_2d]
+        ptrs = [int(self._num_free_slots[l]) for l in layer_ids]
+        if not bool((cur == cur[0]).all()) or any(p != ptrs[0] for p in ptrs[1:]):
+            return None
+        max_cur = int(cur.max())
+        static_cap = self._decode_static_max_context_len
+        if (max_cur + 1 > self.max_model_len or max_cur >= trigger or ptrs[0] - B <= 0
+                or (static_cap is not None and max_cur + 1 > int(static_cap))):
+            return None
+        return args, rows_2d, kv_idx
+
+    def _device_state_upload(self):
+        self._dev_row_len.copy_(torch.from_numpy(self._row_seq_lens_all), non_blocking=False)
+        self._dev_free_ptr.copy_(torch.tensor([int(self._num_free_slots[int(l)]) for l in self.kv_transformer_layer_indices()],
+                                              dtype=torch.long))
+        self._dev_state_dirty = False
+
+    def prepare_decode_static(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,
+                              req_indices=None, *, graph_batch_size: int | None = None, defer_device_launch: bool = False):
+        """h2o.py:256-476 / snapkv.py:2961.  With the device-resident state the allocation is `svk_h2o_device_step_begin`
+        (launched here, or by the caller inside its hipGraph when `defer_device_launch`), nothing is uploaded; otherwise the
+        host-driven form (`_prepare_decode_static_host`)."""
+        real = len(seqs)
+        gbs = int(graph_batch_size or (input_ids.numel() if input_ids is not None else real))
+        plan = self._device_step_plan(seqs, gbs) if real > 0 and real <= gbs else None
+        self._device_step = None
+        if plan is None:
+            self._dev_state_dirty = True
+            return self._prepare_decode_static_host(seqs, input_ids, positions, slot_mapping, context_lens, req_indices,
+                                                    graph_batch_size=graph_batch_size)
+        args, rows_2d, kv_idx = plan
+        if self._dev_state_dirty:
+            self._device_state_upload()
+        cur0 = self._row_seq_lens_all[kv_idx[0], rows_2d[0]]
+        # the host mirrors move by the arithmetic the kernel applies to the device copy
+        self._row_seq_lens_all[kv_idx[:, None], rows_2d] += 1
+        for l in self.kv_transformer_layer_indices():
+            self._num_free_slots[int(l)] -= real
+        self._decode_static_rows = ((tuple(s.seq_id for s in seqs),), rows_2d, True, kv_idx)
+        sm, cl, ri = self._get_decode_static_buffers(gbs)
+        static_cap = self._decode_static_max_context_len
+        for i, l in enumerate(self.kv_transformer_layer_indices()):
+            st = self.layer_batch_states[l]
+            st.slot_mapping, st.context_lens, st.req_indices = sm[i], cl[i], ri[i]
+            st.max_context_len = int(static_cap) if static_cap is not None else int(cur0.max()) + 1
+        self._device_step = [args, rows_2d, kv_idx, False]
+        if not defer_device_launch:
+            h2o_ops.h2o_device_step_begin(args)
+        if slot_mapping is not None:
+            slot_mapping.copy_(sm[0])
+            context_lens.copy_(cl[0])
+            req_indices.copy_(ri[0])
+        return input_ids, positions, None
+
+    def device_step_begin(self):
+        """The step's allocation launch, for a caller that took `defer_device_launch` (inside its hipGraph)."""
+        if self._device_step is not None:
+            h2o_ops.h2o_device_step_begin(self._device_step[0])
+
+    def device_step_burst(self):
+        """The step's predicated burst launches (select + compact + commit), inside the caller's hipGraph."""
+        if self._device_step is not None:
+            h2o_ops.h2o_device_burst(self._device_step[0])
+            self._device_step[3] = True
+
+    def _device_step_finish(self, seqs) -> None:
+        """Host half of a device-resident step's burst: launch it if the caller has not, and move the mirrors and
+        counters (no device value is read)."""
+        args, rows_2d, kv_idx, launched = self._device_step
+        self._device_step = None
+        if not launched:
+            h2o_ops.h2o_device_burst(args)
+        budget, trigger = int(args.budget), int(args.trigger_len)
+        lens = self._row_seq_lens_all[kv_idx[0], rows_2d[0]]
+        hit = lens == trigger
+        n = int(hit.sum())
+        if n == 0:
+            return
+        self._row_seq_lens_all[kv_idx[:, None], rows_2d[:, hit]] = budget
+        for l in self.kv_transformer_layer_indices():
+            self._num_free_slots[int(l)] += n * (trigger - budget)
+        self._on_device_burst(seqs, n, len(kv_idx), trigger - budget)
+
     def _supports_nonuniform_decode_layers(self) -> bool:
         """SnapKV-family rows may differ across layers (full layers, per-layer budgets); H2O overrides this to False:
         its decode path needs aligned rows (h2o.py:256-271)."""
@@ -385,6 +527,8 @@ class SnapKVCacheManager(CacheManager):
     def free_seq(self, seq_id: int):
         """snapkv.py:1489-1514."""
         self._decode_static_rows = None
+        self._dev_state_dirty = True
+        self._dev_step_cache = None
         for layer_idx in self.kv_transformer_layer_indices():
             row = self.seq_id_to_row[layer_idx].pop(seq_id, None)
             if row is None:
@@ -408,6 +552,7 @@ class SnapKVCacheManager(CacheManager):
 
     def _compact(self, layer_indices, rows_2d: np.ndarray, keep: torch.Tensor, cur_len: int):
         """Uniform-length fused compaction through svk_compact_rows."""
+        self._dev_state_dirty = True
         d = self.device
         n_layers, n_lanes, keep_len = keep.shape
         drop = cur_len - keep_len

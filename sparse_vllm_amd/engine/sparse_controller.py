@@ -544,5 +544,11 @@ class SparseController:
         budget = self._get_streamingllm_budget()
         if budget is None:
             return
+        cm = self.cache_manager
+        if getattr(cm, "_device_step", None) is not None:
+            # device-resident step: the window eviction is the predicated burst of the step's launches (inside the graph);
+            # the host only advances its mirrors
+            cm._device_step_finish(seqs)
+            return
         with profiler.record("streamingllm_decode_eviction"):
             self._streamingllm_evict(seqs, trigger_len=int(2.0 * budget), budget=budget, only_final_prefill=False)
