@@ -472,6 +472,36 @@ typedef struct SvkQuestDecodeAllocArgs {
 } SvkQuestDecodeAllocArgs;
 int svk_quest_decode_alloc(const SvkQuestDecodeAllocArgs* a, svk_stream_t stream);
 
+/* Device-resident Quest decode bookkeeping (the reference pops pages from a host stack and
+ * uploads rows / lengths / new pages every step, quest.py:1279-1360, :1542-1605, and scans for completed pages on the
+ * host after the step, :1718-1771).  Row lengths `row_len[rows]`, the LIFO page stack `free_pages[pages]` and its pointer
+ * `free_page_ptr[1]` live on the device:
+ *   svk_quest_device_step_begin  svk_quest_decode_alloc from the device state: the k-th lane (in lane order) whose row
+ *                                starts a new page takes free_pages[ptr - 1 - k] (the order of `_pop_pages`,
+ *                                `[ptr-n:ptr][::-1]`), then row_len += 1 and ptr -= n;
+ *   svk_quest_device_step_end    predicated svk_quest_page_minmax: every lane whose row has just completed a page
+ *                                (row_len % page_size == 0) refreshes that page's min / max rows on all layers
+ *                                (`on_forward_end`); other lanes return at once.
+ * Neither needs a host value of the step; both can sit in the step's hipGraph. */
+typedef struct SvkQuestDeviceStepArgs {
+  int32_t* page_table;           /* [rows, page_table_stride]                              */
+  int32_t* token_table;          /* [rows, token_table_stride]                             */
+  int32_t* row_len;              /* [rows] device-resident row lengths                     */
+  int32_t* free_pages;           /* [pages] device-resident LIFO page stack                */
+  int32_t* free_page_ptr;        /* [1]                                                    */
+  const int32_t* row_ids;        /* [B]                                                    */
+  int32_t* slot_mapping;         /* [graph_batch] (lanes >= B get -1)                      */
+  int32_t* context_lens;         /* [graph_batch]                                          */
+  int32_t* req_indices;          /* [graph_batch]                                          */
+  const uint16_t* k_cache;       /* end: [L, slots, Hkv * D] bf16 keys (layer 0)           */
+  uint16_t* metadata;            /* end: max rows of layer 0; min rows at + meta_kind_stride */
+  int64_t page_table_stride, token_table_stride;
+  int64_t k_layer_stride, meta_kind_stride, meta_layer_stride;
+  int32_t batch, graph_batch, page_size, n_layers, row_elems, _pad;
+} SvkQuestDeviceStepArgs;
+int svk_quest_device_step_begin(const SvkQuestDeviceStepArgs* a, svk_stream_t stream);
+int svk_quest_device_step_end(const SvkQuestDeviceStepArgs* a, svk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * DeltaKV: compressed-KV decode
  * ---------------------------------------------------------------------------------- */

@@ -106,6 +106,14 @@ class SvkH2oDeviceStepArgs(C.Structure):
                                     "trigger_len", "select_mode")]
 
 
+class SvkQuestDeviceStepArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("page_table", "token_table", "row_len", "free_pages", "free_page_ptr", "row_ids", "slot_mapping",
+                                  "context_lens", "req_indices", "k_cache", "metadata")] + \
+               [(n, _i64) for n in ("page_table_stride", "token_table_stride", "k_layer_stride", "meta_kind_stride",
+                                    "meta_layer_stride")] + \
+               [(n, _i32) for n in ("batch", "graph_batch", "page_size", "n_layers", "row_elems", "_pad")]
+
+
 class SvkQuestPageMinmaxArgs(C.Structure):
     _fields_ = [("k_cache", _p), ("metadata", _p), ("page_slots", _p),
                 ("k_layer_stride", _i64), ("meta_kind_stride", _i64), ("meta_layer_stride", _i64),
@@ -317,6 +325,8 @@ ENTRY_POINTS = {
     "svk_quest_score_pages": ([C.POINTER(SvkQuestScorePagesArgs), _p], C.c_int),
     "svk_quest_build_view": ([C.POINTER(SvkQuestBuildViewArgs), _p], C.c_int),
     "svk_quest_decode_alloc": ([C.POINTER(SvkQuestDecodeAllocArgs), _p], C.c_int),
+    "svk_quest_device_step_begin": ([C.POINTER(SvkQuestDeviceStepArgs), _p], C.c_int),
+    "svk_quest_device_step_end": ([C.POINTER(SvkQuestDeviceStepArgs), _p], C.c_int),
 }
 
 _lib = None

@@ -278,6 +278,85 @@ __global__ void __launch_bounds__(256) quest_decode_alloc_kernel(const SvkQuestD
   a.req_indices[b] = row;
 }
 
+// ------------------------------------------------------------------------------------
+// device-resident decode bookkeeping (svk.h SvkQuestDeviceStepArgs)
+// ------------------------------------------------------------------------------------
+
+// one workgroup: lane b of the batch.  Lanes whose row starts a new page are ranked in lane order (ballot + wave sums)
+__global__ void __launch_bounds__(256) quest_device_begin_kernel(const SvkQuestDeviceStepArgs a) {
+  __shared__ int s_wave[4], s_cur0, s_row0;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ptr = *a.free_page_ptr;
+  if (tid == 0) { s_row0 = a.row_ids[0]; s_cur0 = a.row_len[a.row_ids[0]]; }
+  int base = 0;                                       // new pages taken by the lanes of earlier rounds
+  for (int b0 = 0; b0 < a.graph_batch; b0 += blockDim.x) {
+    const int b = b0 + tid;
+    const bool real = b < a.batch;
+    const int row = real ? a.row_ids[b] : 0;
+    const int cur = real ? a.row_len[row] : 0;
+    const bool need = real && (cur % a.page_size) == 0;
+    const unsigned long long bal = __ballot(need);
+    __syncthreads();                                  // (also orders s_cur0 / s_row0 and the previous round's s_wave reads)
+    if (lane == 0) s_wave[w] = __popcll(bal);
+    __syncthreads();
+    int before = base + __popcll(bal & ((1ull << lane) - 1ull));
+    int total = 0;
+    for (int i = 0; i < 4; ++i) {
+      if (i < w) before += s_wave[i];
+      total += s_wave[i];
+    }
+    base += total;
+    if (b < a.graph_batch) {
+      if (!real) {                                    // padded graph lanes (quest_decode_alloc_kernel)
+        a.slot_mapping[b] = -1;
+        a.context_lens[b] = s_cur0 + 1;
+        a.req_indices[b] = s_row0;
+      } else {
+        const int page = cur / a.page_size, off = cur - page * a.page_size;
+        int32_t* ptab = a.page_table + (int64_t)row * a.page_table_stride;
+        int page_slot;
+        if (need) {
+          page_slot = a.free_pages[ptr - 1 - before];
+          ptab[page] = page_slot;
+        } else {
+          page_slot = ptab[page];
+        }
+        const int slot = page_slot * a.page_size + off;
+        a.token_table[(int64_t)row * a.token_table_stride + cur] = slot;
+        a.slot_mapping[b] = slot;
+        a.context_lens[b] = cur + 1;
+        a.req_indices[b] = row;
+      }
+    }
+  }
+  __syncthreads();                                    // every lane has read its length / the pointer
+  for (int b = tid; b < a.batch; b += blockDim.x) a.row_len[a.row_ids[b]] += 1;
+  if (tid == 0) *a.free_page_ptr = ptr - base;
+}
+
+// grid (lane, layer): the page a lane's row has just completed, if any
+__global__ void __launch_bounds__(128) quest_device_end_kernel(const SvkQuestDeviceStepArgs a, int chunks_per_row) {
+  const int b = blockIdx.x, layer = blockIdx.y;
+  const int row = a.row_ids[b];
+  const int n = a.row_len[row];
+  if (n <= 0 || (n % a.page_size) != 0) return;
+  const int64_t page = a.page_table[(int64_t)row * a.page_table_stride + n / a.page_size - 1];
+  const uint16_t* k = a.k_cache + (int64_t)layer * a.k_layer_stride + page * a.page_size * (int64_t)a.row_elems;
+  uint16_t* mx = a.metadata + (int64_t)layer * a.meta_layer_stride + page * (int64_t)a.row_elems;
+  uint16_t* mn = mx + a.meta_kind_stride;
+  for (int ch = threadIdx.x; ch < chunks_per_row; ch += blockDim.x) {
+    uint4 hi = *reinterpret_cast<const uint4*>(k + ch * 8);
+    uint4 lo = hi;
+    for (int t = 1; t < a.page_size; ++t) {
+      const uint4 v = *reinterpret_cast<const uint4*>(k + (int64_t)t * a.row_elems + ch * 8);
+      hi.x = bf16x2_max(hi.x, v.x); hi.y = bf16x2_max(hi.y, v.y); hi.z = bf16x2_max(hi.z, v.z); hi.w = bf16x2_max(hi.w, v.w);
+      lo.x = bf16x2_min(lo.x, v.x); lo.y = bf16x2_min(lo.y, v.y); lo.z = bf16x2_min(lo.z, v.z); lo.w = bf16x2_min(lo.w, v.w);
+    }
+    *reinterpret_cast<uint4*>(mx + ch * 8) = hi;
+    *reinterpret_cast<uint4*>(mn + ch * 8) = lo;
+  }
+}
+
 template <int D>
 int dispatch_score(const SvkQuestScorePagesArgs& a, hipStream_t s) {
   const int G = a.num_q_heads / a.num_kv_heads;
@@ -361,4 +440,29 @@ extern "C" int svk_quest_decode_alloc(const SvkQuestDecodeAllocArgs* a, svk_stre
   hipLaunchKernelGGL(quest_decode_alloc_kernel, dim3((a->graph_batch + 255) / 256), dim3(256), 0,
                      static_cast<hipStream_t>(stream), *a);
   return check_launch("svk_quest_decode_alloc");
+}
+
+extern "C" int svk_quest_device_step_begin(const SvkQuestDeviceStepArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->row_len != nullptr && a->free_pages != nullptr && a->free_page_ptr != nullptr && a->row_ids != nullptr,
+              SVK_ERR_VALUE, "svk_quest_device_step_begin: null args");
+  SVK_REQUIRE(a->batch > 0, SVK_ERR_VALUE, "Static decode requires a non-empty real decode batch.");
+  SVK_REQUIRE(a->graph_batch >= a->batch, SVK_ERR_VALUE,
+              "Static decode graph batch is smaller than the real decode batch: graph=%d, real=%d.", a->graph_batch, a->batch);
+  SVK_REQUIRE(a->page_size > 0, SVK_ERR_VALUE, "quest_chunk_size must be > 0");
+  hipLaunchKernelGGL(quest_device_begin_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_quest_device_step_begin");
+}
+
+extern "C" int svk_quest_device_step_end(const SvkQuestDeviceStepArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->row_len != nullptr && a->row_ids != nullptr && a->k_cache != nullptr && a->metadata != nullptr,
+              SVK_ERR_VALUE, "svk_quest_device_step_end: null args");
+  SVK_REQUIRE(a->row_elems > 0 && a->row_elems % 8 == 0, SVK_ERR_LAYOUT, "svk_quest_device_step_end: row_elems %d must be a multiple of 8", a->row_elems);
+  SVK_REQUIRE(a->page_size > 0, SVK_ERR_VALUE, "quest_chunk_size must be > 0");
+  if (a->batch <= 0 || a->n_layers <= 0) return SVK_OK;
+  const int cpr = a->row_elems / 8;
+  hipLaunchKernelGGL(quest_device_end_kernel, dim3(a->batch, a->n_layers), dim3(cpr >= 128 ? 128 : 64), 0,
+                     static_cast<hipStream_t>(stream), *a, cpr);
+  return check_launch("svk_quest_device_step_end");
 }

@@ -43,6 +43,20 @@ class QuestCacheManager(CacheManager):
         self._static = None
         self._view_bufs: dict[tuple, tuple] = {}
         self._prefill_completed_pages: torch.Tensor | None = None
+        # MI355X: device-resident decode bookkeeping.  Row lengths, the page stack and its pointer also live
+        # on the device; a decode step allocates from them (`svk_quest_device_step_begin`) and refreshes the min / max rows
+        # of the pages it completes behind a device-side test (`svk_quest_device_step_end`), so the step is one hipGraph and
+        # uploads nothing.  The host keeps its numpy mirrors in lock-step by the same (deterministic) arithmetic; any
+        # host-driven change (prefill allocation, free_seq) marks the device copy stale.  SVK_H2O_DEVICE_STATE=0: host-driven.
+        import os
+        self._device_step_enabled = os.environ.get("SVK_H2O_DEVICE_STATE", "1") == "1"
+        self._dev_row_len = torch.zeros((self.max_buffer_rows,), dtype=torch.int32, device=d)
+        self._dev_free_pages = torch.zeros((self.num_pages,), dtype=torch.int32, device=d)
+        self._dev_free_page_ptr = torch.zeros((1,), dtype=torch.int32, device=d)
+        self._dev_state_dirty = True
+        self._dev_step_cache = None
+        self.device_step_generation = 0
+        self._device_step = None                 # this step's [args, end_launched] while the device-resident step is active
 
     # ------------------------------------------------------------------ allocation
     def allocate_kv_cache(self):
@@ -65,6 +79,7 @@ class QuestCacheManager(CacheManager):
 
     def permute_free_pages(self, seed: int):
         assert self._num_free_pages == self.num_pages
+        self._dev_state_dirty = True
         self.free_pages_cpu_stack = np.random.default_rng(seed).permutation(self.num_pages).astype(np.int32)
 
     def get_layer_batch_states(self, layer_idx: int) -> LayerBatchStates:
@@ -177,6 +192,7 @@ class QuestCacheManager(CacheManager):
     @torch.no_grad()
     def _allocate(self, seq_id: int, size: int) -> torch.Tensor:
         """quest.py:1227-1277 (prefill append of `size` tokens)."""
+        self._dev_state_dirty = True
         size = int(size)
         needed = self._required_new_pages(seq_id, size)
         row = self._get_free_row(seq_id)
@@ -216,10 +232,18 @@ class QuestCacheManager(CacheManager):
         st.max_context_len = max(ctx) if ctx else 0
         self._prefill_completed_pages = torch.tensor(completed, dtype=torch.long, device=d) if completed else None
 
+    def _device_state_upload(self):
+        self._dev_row_len.copy_(torch.from_numpy(self.row_seq_lens))
+        self._dev_free_pages.copy_(torch.from_numpy(self.free_pages_cpu_stack))
+        self._dev_free_page_ptr.fill_(int(self._num_free_pages))
+        self._dev_state_dirty = False
+
     @torch.no_grad()
     def prepare_decode_static(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,
-                              req_indices=None, *, graph_batch_size: int | None = None):
-        """quest.py:1542-1605 + _allocate_batch :1279-1360."""
+                              req_indices=None, *, graph_batch_size: int | None = None, defer_device_launch: bool = False):
+        """quest.py:1542-1605 + _allocate_batch :1279-1360.  With the device-resident state the allocation is
+        `svk_quest_device_step_begin` (launched here, or by the caller inside its hipGraph when `defer_device_launch`) and
+        nothing is uploaded; the host pops the same pages from its mirror of the stack."""
         with profiler.record("cache_prepare_decode"):
             B = len(seqs)
             if B <= 0:
@@ -232,21 +256,45 @@ class QuestCacheManager(CacheManager):
             if int(cur.max()) + 1 > self.max_model_len:
                 raise RuntimeError(f"KV row length exceeds max_model_len in QuEST _allocate_batch: max_cur_len={int(cur.max())} "
                                    f"max_model_len={self.max_model_len}")
+            d = self.device
+            caller_buffers = slot_mapping is not None
+            if slot_mapping is None:
+                if self._static is None or self._static[0].numel() < GB:
+                    self._static = tuple(torch.zeros((GB,), dtype=torch.int32, device=d) for _ in range(3))
+                    self._dev_step_cache = None
+                slot_mapping, context_lens, req_indices = (t[:GB] for t in self._static)
+            self._device_step = None
+            use_device = self._device_step_enabled and not caller_buffers
+            if use_device:
+                # the device copy must be current BEFORE the host mirror moves
+                if self._dev_state_dirty:
+                    self._device_state_upload()
+                key = (tuple(int(r) for r in rows), GB, slot_mapping.data_ptr())
+                cache = self._dev_step_cache
+                if cache is None or cache[0] != key:
+                    rows_gpu = torch.from_numpy(rows.astype(np.int32)).to(d)
+                    args = quest_ops.device_step_args(
+                        self.buffer_req_to_page_slots, self.buffer_req_to_token_slots, self._dev_row_len, self._dev_free_pages,
+                        self._dev_free_page_ptr, rows_gpu, slot_mapping, context_lens, req_indices, self.kv_cache,
+                        self.metadata_cache, batch=B, page_size=self.page_size)
+                    cache = self._dev_step_cache = (key, args, (rows_gpu, slot_mapping, context_lens, req_indices))
+                    self.device_step_generation += 1
+                self._device_step = [cache[1], False]
             need = np.nonzero(cur % self.page_size == 0)[0]
             new_pages = np.full((B,), -1, dtype=np.int32)
             if need.size:
                 pages = self._pop_pages(int(need.size))
                 new_pages[need] = pages
                 self.buffer_req_to_page_slots_cpu[rows[need], cur[need] // self.page_size] = pages
-            d = self.device
-            if slot_mapping is None:
-                if self._static is None or self._static[0].numel() < GB:
-                    self._static = tuple(torch.zeros((GB,), dtype=torch.int32, device=d) for _ in range(3))
-                slot_mapping, context_lens, req_indices = (t[:GB] for t in self._static)
-            quest_ops.decode_alloc(self.buffer_req_to_page_slots, self.buffer_req_to_token_slots,
-                                   torch.from_numpy(rows.astype(np.int32)).to(d), torch.from_numpy(cur.astype(np.int32)).to(d),
-                                   torch.from_numpy(new_pages).to(d), slot_mapping, context_lens, req_indices,
-                                   batch=B, page_size=self.page_size)
+            if use_device:
+                if not defer_device_launch:
+                    quest_ops.device_step_begin(self._device_step[0])
+            else:
+                self._dev_state_dirty = True
+                quest_ops.decode_alloc(self.buffer_req_to_page_slots, self.buffer_req_to_token_slots,
+                                       torch.from_numpy(rows.astype(np.int32)).to(d), torch.from_numpy(cur.astype(np.int32)).to(d),
+                                       torch.from_numpy(new_pages).to(d), slot_mapping, context_lens, req_indices,
+                                       batch=B, page_size=self.page_size)
             self.row_seq_lens[rows] += 1
             st = self.layer_batch_state
             st.slot_mapping, st.context_lens, st.req_indices = slot_mapping, context_lens, req_indices
@@ -254,11 +302,30 @@ class QuestCacheManager(CacheManager):
             st.max_context_len = int(cap) if cap is not None else int(cur.max()) + 1
             return input_ids, positions, None
 
+    def device_step_begin(self):
+        """The step's allocation launch, for a caller that took `defer_device_launch` (inside its hipGraph)."""
+        if self._device_step is not None:
+            quest_ops.device_step_begin(self._device_step[0])
+
+    def device_step_mark_launched(self):
+        """A replayed hipGraph carried this step's launches."""
+        if self._device_step is not None:
+            self._device_step[1] = True
+
+    def device_step_burst(self):
+        """The step's predicated page min / max refresh (after the layer loop: the completed pages' keys are stored),
+        inside the caller's hipGraph."""
+        if self._device_step is not None:
+            quest_ops.device_step_end(self._device_step[0])
+            self._device_step[1] = True
+
     def _prepare_decode(self, seqs):
         return self.prepare_decode_static(seqs)
 
     def free_seq(self, seq_id: int):
         """quest.py:1379-1420."""
+        self._dev_state_dirty = True
+        self._dev_step_cache = None
         row = self.seq_id_to_row.pop(seq_id, None)
         if row is None:
             raise ValueError(f"free_seq: unknown seq_id={seq_id}")
@@ -305,6 +372,13 @@ class QuestCacheManager(CacheManager):
     def on_forward_end(self, seqs, is_prefill: bool):
         """quest.py:1718-1771: pages completed by this decode step, all layers in one launch."""
         if is_prefill or not seqs:
+            return
+        if self._device_step is not None:
+            # device-resident step: the refresh is the predicated launch of the step (issued here if the caller has not)
+            args, launched = self._device_step
+            self._device_step = None
+            if not launched:
+                quest_ops.device_step_end(args)
             return
         pages = []
         for s in seqs:

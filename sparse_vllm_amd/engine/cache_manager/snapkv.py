@@ -497,6 +497,11 @@ class SnapKVCacheManager(CacheManager):
             h2o_ops.h2o_device_burst(self._device_step[0])
             self._device_step[3] = True
 
+    def device_step_mark_launched(self):
+        """A replayed hipGraph carried this step's launches."""
+        if self._device_step is not None:
+            self._device_step[3] = True
+
     def _device_step_finish(self, seqs) -> None:
         """Host half of a device-resident step's burst: launch it if the caller has not, and move the mirrors and
         counters (no device value is read)."""

@@ -241,7 +241,7 @@ class SparseDecodeDriver:
                     g.replay()
             else:
                 if dev_active:
-                    cm._device_step[3] = True        # the replayed graph carries the burst launches
+                    cm.device_step_mark_launched()   # the replayed graph carries the burst launches
                 self._graph.replay()
         if after_layers is not None:
             after_layers()

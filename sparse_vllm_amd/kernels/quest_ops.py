@@ -70,3 +70,33 @@ def decode_alloc(page_table, token_table, row_ids, cur_lens, new_page_slots, slo
         page_table_stride=page_table.stride(0), token_table_stride=token_table.stride(0),
         batch=int(batch), graph_batch=slot_mapping.numel(), page_size=int(page_size))
     _lib.check(lib.svk_quest_decode_alloc(C.byref(a), _lib.current_stream_handle()), lib)
+
+
+def device_step_args(page_table, token_table, row_len, free_pages, free_page_ptr, row_ids, slot_mapping, context_lens,
+                     req_indices, kv_cache, metadata_cache, *, batch: int, page_size: int):
+    """Arguments of svk_quest_device_step_begin / _end (device-resident row lengths and page stack, include/svk.h): built
+    once per batch composition, every pointer in them is graph-stable."""
+    assert page_table.dtype == torch.int32 and token_table.dtype == torch.int32 and page_table.stride(1) == 1
+    assert row_len.dtype == torch.int32 and row_len.is_contiguous() and free_pages.dtype == torch.int32 and free_pages.is_contiguous()
+    assert free_page_ptr.dtype == torch.int32 and free_page_ptr.numel() == 1 and row_ids.dtype == torch.int32
+    assert kv_cache.dim() == 5 and metadata_cache.dim() == 5 and kv_cache.dtype == torch.bfloat16
+    k, meta = kv_cache[0], metadata_cache
+    assert k[0].is_contiguous() and meta[0, 0].is_contiguous()
+    return _lib.SvkQuestDeviceStepArgs(
+        page_table=_lib.ptr(page_table), token_table=_lib.ptr(token_table), row_len=_lib.ptr(row_len),
+        free_pages=_lib.ptr(free_pages), free_page_ptr=_lib.ptr(free_page_ptr), row_ids=_lib.ptr(row_ids),
+        slot_mapping=_lib.ptr(slot_mapping), context_lens=_lib.ptr(context_lens), req_indices=_lib.ptr(req_indices),
+        k_cache=_lib.ptr(k[0]), metadata=_lib.ptr(meta[0, 0]), page_table_stride=page_table.stride(0),
+        token_table_stride=token_table.stride(0), k_layer_stride=k.stride(0), meta_kind_stride=meta.stride(0),
+        meta_layer_stride=meta.stride(1), batch=int(batch), graph_batch=int(slot_mapping.numel()), page_size=int(page_size),
+        n_layers=int(k.shape[0]), row_elems=int(k.shape[2] * k.shape[3]))
+
+
+def device_step_begin(args):
+    lib = _lib.load()
+    _lib.check(lib.svk_quest_device_step_begin(C.byref(args), _lib.current_stream_handle()), lib)
+
+
+def device_step_end(args):
+    lib = _lib.load()
+    _lib.check(lib.svk_quest_device_step_end(C.byref(args), _lib.current_stream_handle()), lib)

@@ -241,3 +241,72 @@ def test_quest_decode_steps_match_oracle():
                 mid, lse = oda.flash_decode_stage1(qn[l], kc[l], vc[l], packed, lreq, llens, int(packed.shape[1]), 64)
                 o = oda.flash_decode_stage2(mid, lse, llens, 64)
             np.testing.assert_allclose(outs[l].float().cpu().numpy(), bf16_round(o), rtol=3e-2, atol=3e-2)
+
+
+def _run_quest(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False):
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    B, L = 4, 3
+    conf = Config.from_kwargs(sparse_method="quest", num_hidden_layers=L, max_model_len=1024, max_num_seqs_in_gpu=B,
+                              num_kvcache_slots=B * 1024 + 160, sink_keep_tokens=16, recent_keep_tokens=16,
+                              decode_keep_tokens=96, quest_skip_layers=1)
+    drv = SparseDecodeDriver(conf)
+    cm = drv.cache_manager
+    cm._device_step_enabled = device_state
+    cm.permute_free_pages(5)
+    drv.admit_resident_rows(B, 500, seed=9)
+    if ragged:
+        # rows of different phase inside their pages: new pages / completed pages hit subsets of the batch
+        for i, s in enumerate(drv.seqs):
+            if i:
+                cm._allocate(s.seq_id, 3 * i + 1)
+    if graph:
+        drv.enable_decode_graph()
+    q, k, v = drv.random_step_inputs(seed=3)
+    o = torch.zeros((L, B, 28, 128), dtype=torch.bfloat16, device=drv.device)
+    used_device = 0
+    for i in range(steps):
+        if sync_debug and i >= 4:
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            drv.step(q, k, v, outputs=o)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        used_device += int(cm._dev_step_cache is not None and not cm._dev_state_dirty)
+    torch.cuda.synchronize()
+    return dict(o=o.view(torch.int16).cpu().numpy().copy(), ttab=cm.buffer_req_to_token_slots.cpu().numpy().copy(),
+                ptab=cm.buffer_req_to_page_slots.cpu().numpy().copy(), ptab_cpu=cm.buffer_req_to_page_slots_cpu.copy(),
+                md=cm.metadata_cache.view(torch.int16).cpu().numpy().copy(), lens=cm.row_seq_lens.copy(),
+                nfree=int(cm._num_free_pages), stack=cm.free_pages_cpu_stack.copy(),
+                dev_lens=cm._dev_row_len.cpu().numpy().copy(), dev_stack=cm._dev_free_pages.cpu().numpy().copy(),
+                dev_ptr=int(cm._dev_free_page_ptr.item()), used_device=used_device)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_quest_device_resident_steps_equal_host_driven_steps(ragged):
+    """SURVEY 8(f).2 for Quest: row lengths and the page stack on the device, the allocation
+    (`svk_quest_device_step_begin`) and the predicated min / max refresh of completed pages (`svk_quest_device_step_end`) as
+    launches of the step.  Against the host-driven steps (host page pops + uploads, host scan for completed pages) over
+    >= 3 page boundaries: token / page tables, metadata, lengths and outputs bit-identical, eager and under hipGraph
+    replay; the device copies equal the host mirrors; rows that cross page boundaries at different steps included."""
+    steps = 3 * 16 + 7
+    ref = _run_quest(False, False, steps, ragged=ragged)
+    assert ref["used_device"] == 0
+    for graph in (False, True):
+        got = _run_quest(True, graph, steps, ragged=ragged)
+        assert got["used_device"] >= steps - 2
+        for key in ("o", "ttab", "ptab", "md", "lens", "ptab_cpu"):
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} graph={graph}")
+        assert got["nfree"] == ref["nfree"]
+        np.testing.assert_array_equal(got["stack"][: got["nfree"]], ref["stack"][: ref["nfree"]])
+        np.testing.assert_array_equal(got["dev_lens"], got["lens"])
+        assert got["dev_ptr"] == got["nfree"]
+        np.testing.assert_array_equal(got["dev_stack"][: got["nfree"]], got["stack"][: got["nfree"]])
+        np.testing.assert_array_equal(got["ptab"], got["ptab_cpu"])
+
+
+def test_quest_device_resident_step_needs_no_host_sync():
+    """Three page boundaries under hipGraph replay with torch's sync debug mode "error": no host <-> device
+    synchronisation, no upload."""
+    got = _run_quest(True, True, 3 * 16 + 8, sync_debug=True)
+    assert got["used_device"] >= 3 * 16
