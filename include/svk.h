@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 11
+#define SVK_ABI_VERSION 12
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -283,9 +283,15 @@ int svk_compact_rows(const SvkCompactRowsArgs* a, svk_stream_t stream);
  * The same two calls serve StreamingLLM (round 4): select_mode SVK_DEVICE_SELECT_WINDOW keeps the sink
  * [0, budget - recent_count) and the recent_count newest positions of a row that reached trigger_len = 2 * (sink + recent)
  * (SparseController._streamingllm_decode_eviction, sparse_controller.py:1558-1668 -> free_prefix_recent_slots_batch_layers,
- * snapkv.py:1805-1896); `scores` may then be NULL (no payload rows to compact). */
+ * snapkv.py:1805-1896); `scores` may then be NULL (no payload rows to compact).
+ * select_mode SVK_DEVICE_SELECT_SNAPKV: SnapKV's decode re-eviction (SparseController._snapkv_decode_eviction,
+ * sparse_controller.py:1104-1223): a row that reached trigger_len = 2 x decode_keep keeps its prefix_count sink tokens, the
+ * top (budget - prefix_count - recent_count) middle tokens by THIS STEP's head-max raw scores and its recent_count newest
+ * tokens; `scores` is then the step's scratch [L, graph lanes, width] indexed by batch lane (score_stride_row = lane stride),
+ * nothing of it is compacted. */
 #define SVK_DEVICE_SELECT_H2O 0
 #define SVK_DEVICE_SELECT_WINDOW 1
+#define SVK_DEVICE_SELECT_SNAPKV 2
 typedef struct SvkH2oDeviceStepArgs {
   int32_t* slot_table;         /* [L, rows, table_stride_row]                         */
   int32_t* free_stack;         /* [L, stack_stride]                                   */
@@ -301,7 +307,8 @@ typedef struct SvkH2oDeviceStepArgs {
   int64_t score_stride_layer, score_stride_row, out_stride;
   int32_t n_layers, rows_total, batch, graph_batch;
   int32_t budget, recent_count, trigger_len;
-  int32_t select_mode;         /* SVK_DEVICE_SELECT_H2O (0) | SVK_DEVICE_SELECT_WINDOW (1)  */
+  int32_t select_mode;         /* SVK_DEVICE_SELECT_H2O (0) | _WINDOW (1) | _SNAPKV (2)       */
+  int32_t prefix_count, _pad;  /* SNAPKV: sink tokens always kept                            */
 } SvkH2oDeviceStepArgs;
 int svk_h2o_device_step_begin(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);
 int svk_h2o_device_burst(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);

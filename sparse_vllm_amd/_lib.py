@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 11
+SVK_ABI_VERSION = 12
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -103,7 +103,7 @@ class SvkH2oDeviceStepArgs(C.Structure):
                [(n, _i64) for n in ("table_stride_layer", "table_stride_row", "stack_stride", "score_stride_layer",
                                     "score_stride_row", "out_stride")] + \
                [(n, _i32) for n in ("n_layers", "rows_total", "batch", "graph_batch", "budget", "recent_count",
-                                    "trigger_len", "select_mode")]
+                                    "trigger_len", "select_mode", "prefix_count", "_pad")]
 
 
 class SvkQuestDeviceStepArgs(C.Structure):

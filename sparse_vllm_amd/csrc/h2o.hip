@@ -272,6 +272,19 @@ __global__ void __launch_bounds__(256) h2o_device_select_kernel(const SvkH2oDevi
   const int row = a.row_ids[b];
   if (a.row_len[(int64_t)l * a.rows_total + row] != a.trigger_len) return;
   int64_t* keep = a.keep + ((int64_t)l * a.batch + b) * a.budget;
+  if (a.select_mode == SVK_DEVICE_SELECT_SNAPKV) {
+    // sink ++ top-k of the middle by this step's head-max raw scores (lane-indexed rows) ++ recent
+    // (SparseController._snapkv_select_indices_batch, sparse_controller.py:1670-1747), ascending
+    const float* sc = a.scores + (int64_t)l * a.score_stride_layer + (int64_t)b * a.score_stride_row;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int prefix = a.prefix_count, suffix = a.recent_count, topk = a.budget - prefix - suffix;
+    const int mid = a.trigger_len - suffix - prefix;
+    for (int i = tid; i < prefix; i += nt) keep[i] = i;
+    for (int i = tid; i < suffix; i += nt) keep[prefix + topk + i] = a.trigger_len - suffix + i;
+    if (topk <= 0) return;
+    block_select_topk_ordered(sc + prefix, mid, topk, scratch, [&](int pos, int idx) { keep[prefix + pos] = prefix + idx; });
+    return;
+  }
   if (a.select_mode == SVK_DEVICE_SELECT_WINDOW) {
     // sink + recent window (StreamingLLM, sparse_controller.py:1661-1668): [0, budget - recent) ++ [len - recent, len)
     const int prefix = a.budget - a.recent_count;
@@ -299,7 +312,9 @@ __global__ void __launch_bounds__(256) h2o_device_compact_kernel(const SvkH2oDev
   const int K = a.budget, cur = a.trigger_len;
   int32_t* tab = a.slot_table + (int64_t)l * a.table_stride_layer + (int64_t)row * a.table_stride_row;
   int32_t* stack = a.free_stack + (int64_t)l * a.stack_stride + a.free_ptr[l] + (int64_t)rank * (cur - K);
-  float* pay = a.scores ? a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row : nullptr;
+  // (SnapKV's scores are this step's lane-indexed scratch rows, not a payload that lives with the slot table)
+  float* pay = (a.scores && a.select_mode == SVK_DEVICE_SELECT_H2O)
+                   ? a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row : nullptr;
   compact_row(tab, stack, pay, a.keep + ((int64_t)l * a.batch + b) * K, K, cur);
 }
 
@@ -493,10 +508,14 @@ extern "C" int svk_h2o_device_burst(const SvkH2oDeviceStepArgs* a, svk_stream_t 
   using namespace svk;
   SVK_REQUIRE(a != nullptr && a->row_len != nullptr && a->free_ptr != nullptr && a->row_ids != nullptr && a->keep != nullptr,
               SVK_ERR_VALUE, "svk_h2o_device_burst: null args");
-  SVK_REQUIRE(a->select_mode == SVK_DEVICE_SELECT_H2O || a->select_mode == SVK_DEVICE_SELECT_WINDOW, SVK_ERR_VALUE,
-              "svk_h2o_device_burst: bad select_mode %d", a->select_mode);
-  SVK_REQUIRE(a->select_mode != SVK_DEVICE_SELECT_H2O || a->scores != nullptr, SVK_ERR_VALUE,
-              "svk_h2o_device_burst: the heavy-hitter selection needs the cumulative score tensor");
+  SVK_REQUIRE(a->select_mode == SVK_DEVICE_SELECT_H2O || a->select_mode == SVK_DEVICE_SELECT_WINDOW ||
+                  a->select_mode == SVK_DEVICE_SELECT_SNAPKV, SVK_ERR_VALUE, "svk_h2o_device_burst: bad select_mode %d", a->select_mode);
+  SVK_REQUIRE(a->select_mode == SVK_DEVICE_SELECT_WINDOW || a->scores != nullptr, SVK_ERR_VALUE,
+              "svk_h2o_device_burst: score-based selections need the score tensor");
+  SVK_REQUIRE(a->select_mode != SVK_DEVICE_SELECT_SNAPKV ||
+                  (a->prefix_count >= 0 && a->prefix_count + a->recent_count <= a->budget &&
+                   a->budget - a->prefix_count - a->recent_count <= a->trigger_len - a->prefix_count - a->recent_count), SVK_ERR_VALUE,
+              "svk_h2o_device_burst: sink %d + recent %d do not fit the budget %d", a->prefix_count, a->recent_count, a->budget);
   SVK_REQUIRE(a->budget > 0 && a->trigger_len > a->budget, SVK_ERR_VALUE,
               "svk_h2o_device_burst: trigger_len %d must exceed the budget %d", a->trigger_len, a->budget);
   SVK_REQUIRE(a->recent_count >= 1 && a->recent_count <= a->budget, SVK_ERR_VALUE,

@@ -549,11 +549,11 @@ class H2OCacheManager(SnapKVCacheManager):
         self._dev_state_dirty = True
 
     # ---- device-resident decode step: the machinery lives in SnapKVCacheManager (shared with StreamingLLM); H2O's part
-    def _device_step_params(self):
-        """-> (budget, trigger_len, recent_count, select_mode, score tensor) of the predicated burst (h2o.py:1498-1630)."""
+    def _device_step_params(self, graph_batch_size: int):
+        """-> (budget, trigger_len, recent_count, select_mode, score tensor, prefix) of the predicated burst (h2o.py:1498-1630)."""
         budget = self.h2o_decode_budget
         recent = min(max(1, int(budget * float(self.config.h2o_recent_ratio))), budget)
-        return budget, budget + self.h2o_decode_eviction_interval, recent, 0, self.h2o_score_tensor
+        return budget, budget + self.h2o_decode_eviction_interval, recent, 0, self.h2o_score_tensor, 0
 
     def _on_device_burst(self, seqs, n_rows: int, n_layers: int, dropped_per_row: int) -> None:
         self._h2o_counters["decode_eviction_bursts"] += n_rows

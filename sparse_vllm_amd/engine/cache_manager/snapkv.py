@@ -392,9 +392,27 @@ class SnapKVCacheManager(CacheManager):
     # (deterministic) arithmetic; any host-driven change of rows or pointers marks the device copy stale.  A subclass
     # opts in by returning its parameters from `_device_step_params` (H2O: heavy hitters every `interval` tokens;
     # StreamingLLM: sink + recent window at 2 x (sink + recent)).
-    def _device_step_params(self):
-        """-> (budget, trigger_len, recent_count, select_mode, score tensor or None), or None: host-driven steps."""
-        return None
+    def _device_step_params(self, graph_batch_size: int):
+        """-> (budget, trigger_len, recent_count, select_mode, score tensor or None, prefix_count), or None: host-driven
+        steps.  Here: SnapKV's decode re-eviction (sparse_controller.py:1104-1223) - a row that reached 2 x decode_keep
+        tokens keeps sink ++ top-k of the middle by this step's head-max scores ++ recent - when every layer evicts
+        (snapkv_num_full_layers == 0) and no pooling is configured; the scores are the step's scratch rows
+        `snapkv_decode_score_tensor` [L, lanes, width], which the controller hands to the attention launches."""
+        cfg = self.config
+        if cfg.vllm_sparse_method != "snapkv" or int(getattr(cfg, "snapkv_num_full_layers", 0) or 0) > 0:
+            return None
+        if int(getattr(cfg, "pool_kernel_size", 1) or 1) > 1:
+            return None
+        sink, keep, recent = int(cfg.num_sink_tokens), int(cfg.decode_keep_tokens), int(cfg.num_recent_tokens)
+        budget, trigger = sink + keep + recent, int(2.0 * keep)
+        if keep <= 0 or trigger <= budget or trigger > self.max_model_len:
+            return None
+        width = max(trigger, int(self._decode_static_max_context_len or 0))
+        buf = self.__dict__.get("snapkv_decode_score_tensor")
+        if buf is None or buf.shape[1] < int(graph_batch_size) or buf.shape[2] < width:
+            buf = self.snapkv_decode_score_tensor = torch.empty((self.num_kv_layers, int(graph_batch_size), width),
+                                                                dtype=torch.float32, device=self.device)
+        return budget, trigger, recent, 2, buf, sink
 
     def _on_device_burst(self, seqs, n_rows: int, n_layers: int, dropped_per_row: int) -> None:
         """Counters of a subclass when `n_rows` sequences were evicted on every layer by the in-graph burst."""
@@ -404,15 +422,16 @@ class SnapKVCacheManager(CacheManager):
         """-> (args, rows_2d, kv_idx) when this decode step can run from the device-resident state: uniform rows / lengths /
         pointers across the KV layers (H2O's invariant), room in the rows and - after the allocation - still free slots
         (at zero the reference switches to the slot-pressure trigger, h2o.py:1506-1524: that step takes the host path)."""
-        params = self._device_step_params() if self._device_step_enabled and seqs else None
+        params = self._device_step_params(int(graph_batch_size)) if self._device_step_enabled and seqs else None
         if params is None:
             return None
-        budget, trigger, recent, select_mode, score_tensor = params
+        budget, trigger, recent, select_mode, score_tensor, prefix = params
         layer_ids = [int(l) for l in self.kv_transformer_layer_indices()]
         first = layer_ids[0]
         B = len(seqs)
         rows0 = tuple(self._row_of(first, s) for s in seqs)
-        key = (tuple(s.seq_id for s in seqs), rows0, tuple(layer_ids), int(graph_batch_size), budget, trigger, recent, select_mode)
+        key = (tuple(s.seq_id for s in seqs), rows0, tuple(layer_ids), int(graph_batch_size), budget, trigger, recent, select_mode,
+               prefix, 0 if score_tensor is None else score_tensor.data_ptr())
         cache = self._dev_step_cache
         sm, cl, ri = self._get_decode_static_buffers(int(graph_batch_size))
         if cache is not None and cache[2][2].data_ptr() != sm.data_ptr():
@@ -428,7 +447,7 @@ class SnapKVCacheManager(CacheManager):
             args = h2o_ops.h2o_device_step_args(
                 self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor, score_tensor, self._dev_row_len,
                 self._dev_free_ptr, rows_gpu, sm, cl, ri, keep, batch=B, budget=budget, recent_count=recent, trigger_len=trigger,
-                select_mode=select_mode)
+                select_mode=select_mode, prefix_count=prefix)
             cache = self._dev_step_cache = (key, args, (rows_gpu, keep, sm, cl, ri), rows_2d, kv_idx)
             self.device_step_generation += 1
         _, args, _keepalive, rows_2d, kv_idx = cache

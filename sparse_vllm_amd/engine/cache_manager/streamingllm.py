@@ -18,7 +18,7 @@ class StreamingLLMCacheManager(SnapKVCacheManager):
     def _window(self) -> int:
         return int(self.config.num_recent_tokens)
 
-    def _device_step_params(self):
+    def _device_step_params(self, graph_batch_size: int):
         """MI355X: the decode-time window eviction - keep [0, sink) and the `recent` newest tokens of a row
         that holds 2 x (sink + recent) (sparse_controller.py:1558-1668, snapkv.py:1805-1896) - as the predicated burst of
         the device-resident step: same slot tables, free stacks and lengths as the host-driven steps, bit for bit
@@ -27,7 +27,7 @@ class StreamingLLMCacheManager(SnapKVCacheManager):
         budget = sink + recent
         if recent <= 0 or budget <= 0:
             return None
-        return budget, 2 * budget, recent, 1, None
+        return budget, 2 * budget, recent, 1, None, sink
 
     def _on_device_burst(self, seqs, n_rows: int, n_layers: int, dropped_per_row: int) -> None:
         self._uniform_decode_metadata = True          # the window moved on every layer alike

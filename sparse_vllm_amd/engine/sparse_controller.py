@@ -166,7 +166,16 @@ class SparseController:
                     fill_value=-1e20)
         if not is_prefill and self.sparse_method == "h2o":
             self._prepare_h2o_decode_attn_score_buffer(seqs)
-        if not is_prefill and self.sparse_method == "snapkv":
+        if not is_prefill and self.sparse_method == "snapkv" and getattr(self.cache_manager, "_device_step", None) is not None:
+            # device-resident step: the re-eviction is decided on the device, so every layer collects the
+            # head-max scores every step (what the reference does under its CUDA graphs) into the manager's [L, lanes, W]
+            # scratch, one fill for all layers
+            buf = self.cache_manager.snapkv_decode_score_tensor
+            h2o_ops.fill_f32(buf, -1e20)
+            for layer_idx in range(self.num_layers):
+                s = self.layer_batch_sparse_states[layer_idx]
+                s.attn_score = buf[self.cache_manager.kv_layer_index(layer_idx), : int(s.context_lens.numel())]
+        elif not is_prefill and self.sparse_method == "snapkv":
             for layer_idx in range(self.num_layers):
                 if self._needs_attn_score(layer_idx, False, seqs):
                     s = self.layer_batch_sparse_states[layer_idx]
@@ -433,6 +442,11 @@ class SparseController:
         """sparse_controller.py:1104-1223: when a row reaches 2 x top budget, re-select on this step's
         head-max raw decode scores; equal-length rows are compacted across layers in one launch."""
         cm = self.cache_manager
+        if getattr(cm, "_device_step", None) is not None:
+            # device-resident step: the re-eviction was the predicated burst of the step's launches; the host only advances
+            # its mirrors
+            cm._device_step_finish(seqs)
+            return
         with profiler.record("snapkv_decode_eviction"):
             pending: dict[tuple, list] = {}
             for layer_idx in range(self.num_layers):

@@ -184,13 +184,15 @@ def decode_alloc_slots(slot_table, free_stack, layer_ids, row_ids, cur_lens, slo
 
 
 def h2o_device_step_args(slot_table, free_stack, scores, row_len, free_ptr, row_ids, slot_mapping, context_lens, req_indices,
-                         keep, *, batch: int, budget: int, recent_count: int, trigger_len: int, select_mode: int = 0):
+                         keep, *, batch: int, budget: int, recent_count: int, trigger_len: int, select_mode: int = 0,
+                         prefix_count: int = 0):
     """Arguments of svk_h2o_device_step_begin / svk_h2o_device_burst (device-resident row lengths and free-stack
     pointers, include/svk.h): built once per batch composition, every pointer in them is graph-stable.
-    `select_mode` 0 = H2O heavy hitters over `scores` [L, rows, cap]; 1 = sink + recent window (`scores` may be None)."""
+    `select_mode` 0 = H2O heavy hitters over `scores` [L, rows, cap]; 1 = sink + recent window (`scores` may be None);
+    2 = SnapKV sink ++ top-k ++ recent over this step's lane-indexed `scores` [L, lanes, width] (`prefix_count` = sink)."""
     assert slot_table.dim() == 3 and slot_table.dtype == torch.int32 and slot_table.stride(2) == 1
     assert free_stack.dim() == 2 and free_stack.dtype == torch.int32 and free_stack.stride(1) == 1
-    assert int(select_mode) in (0, 1) and (scores is not None or int(select_mode) == 1)
+    assert int(select_mode) in (0, 1, 2) and (scores is not None or int(select_mode) == 1)
     assert scores is None or (scores.dim() == 3 and scores.dtype == torch.float32 and scores.stride(2) == 1)
     assert row_len.dim() == 2 and row_len.dtype == torch.int32 and row_len.is_contiguous()
     assert free_ptr.dtype == torch.long and free_ptr.numel() == slot_table.shape[0]
@@ -207,7 +209,7 @@ def h2o_device_step_args(slot_table, free_stack, scores, row_len, free_ptr, row_
         out_stride=slot_mapping.stride(0),
         n_layers=int(slot_table.shape[0]), rows_total=int(row_len.shape[1]), batch=int(batch),
         graph_batch=int(slot_mapping.shape[1]), budget=int(budget), recent_count=int(recent_count),
-        trigger_len=int(trigger_len), select_mode=int(select_mode))
+        trigger_len=int(trigger_len), select_mode=int(select_mode), prefix_count=int(prefix_count))
 
 
 def h2o_device_step_begin(args):

@@ -106,12 +106,12 @@ def test_h2o_decode_steps_match_oracle(cfg):
     assert h2o_ops.SCORE_LAYERS_LAUNCHES["batched"] > before["batched"] and h2o_ops.SCORE_LAYERS_LAUNCHES["per_layer"] == before["per_layer"]
 
 
-def _run_h2o(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False):
+def _run_h2o(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False, slots: int | None = None):
     from sparse_vllm_amd.config import Config
     from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
     B, L, budget, interval = 4, 3, 48, 16
     conf = Config.from_kwargs(sparse_method="h2o", num_hidden_layers=L, max_model_len=128, max_num_seqs_in_gpu=B + 1,
-                              num_kvcache_slots=B * (budget + interval) + 41, h2o_decode_budget=budget,
+                              num_kvcache_slots=slots or (B * (budget + interval) + 41), h2o_decode_budget=budget,
                               h2o_decode_eviction_interval=interval, h2o_prefill_budget=2 * budget)
     drv = SparseDecodeDriver(conf)
     cm = drv.cache_manager
@@ -196,3 +196,24 @@ def test_device_resident_bookkeeping_soak_forty_bursts():
         free = got["stack"][l, : got["ptr"][l]]
         both = np.concatenate([used, free])
         assert len(np.unique(both)) == len(both) and len(both) <= n_slots           # disjoint: no slot owned twice
+
+
+def test_h2o_slot_pressure_fallback_under_graph_replay():
+    """A pool so tight that the free stack runs dry before the rows reach budget + interval: the reference then lowers the
+    trigger to budget + 1 (h2o.py:1506-1524).  Those steps leave the device-resident path (its plan refuses a step that
+    would empty the stack) and run host-driven, also when the caller replays hipGraphs: the driver drops its graph, runs
+    the step eagerly and re-captures.  Against the host-driven eager run: tables, free stacks, scores, outputs and counters
+    bit-identical over several pressure bursts; both runs did evict under pressure (more bursts than the periodic rule
+    alone would give)."""
+    B, budget, interval, steps = 4, 48, 16, 60
+    slots = B * budget + 2 * B                     # two steps of head-room, then the stack is empty: pressure
+    ref = _run_h2o(False, False, steps, slots=slots)
+    periodic_only = (steps // interval) * B
+    assert ref["counters"]["decode_eviction_bursts"] > periodic_only
+    for device_state in (True, False):
+        got = _run_h2o(device_state, True, steps, slots=slots)
+        for key in ("o", "score", "table", "lens"):
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} device_state={device_state}")
+        assert got["ptr"] == ref["ptr"] and got["counters"] == ref["counters"]
+        for l in range(len(ref["ptr"])):
+            np.testing.assert_array_equal(got["stack"][l, : ref["ptr"][l]], ref["stack"][l, : ref["ptr"][l]])

@@ -322,3 +322,66 @@ def test_deltakv_token_scores_and_topk_product_vs_reference(golden, monkeypatch)
             np.testing.assert_array_equal(got, mine)                       # == the oracle, bit for bit
             for b in range(B):
                 od.check_sorted_topk(keys[b], got[b], ref_idx[b])            # == the reference up to topk's tie freedom
+
+
+# ------------------------------------------------------------------------------------------------ SnapKV device-resident steps
+def _run_snapkv_decode(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False):
+    sink, recent, keep = 4, 8, 20
+    budget = sink + keep + recent                  # 32, re-eviction at 2 * keep = 40
+    B, L = 4, 3
+    drv = _driver(sparse_method="snapkv", num_hidden_layers=L, max_model_len=64, max_num_seqs_in_gpu=B + 1,
+                  num_kvcache_slots=B * 40 + 29, sink_keep_tokens=sink, recent_keep_tokens=recent, decode_keep_tokens=keep)
+    cm = drv.cache_manager
+    cm._device_step_enabled = device_state
+    cm.permute_free_slots(4)
+    drv.admit_resident_rows(B, budget + 2, logical_len=60, seed=8)
+    if ragged:
+        for l in range(L):
+            for s in drv.seqs[:2]:
+                cm.free_part_slots(l, s, torch.arange(budget - 3, device=drv.device), keep_indices_sorted=True)
+    if graph:
+        drv.enable_decode_graph()
+    o = torch.zeros((L, B, 28, 128), dtype=torch.bfloat16, device=drv.device)
+    used_device = 0
+    for i in range(steps):
+        q, k, v = drv.random_step_inputs(seed=100 + i % 3) if not graph else drv.random_step_inputs(seed=100)
+        if sync_debug and i >= 4:
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            drv.step(q, k, v, outputs=o)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        used_device += int(cm._dev_step_cache is not None and not cm._dev_state_dirty)
+    torch.cuda.synchronize()
+    return dict(o=o.view(torch.int16).cpu().numpy().copy(), table=cm.buffer_req_to_token_slots_tensor.cpu().numpy().copy(),
+                stack=cm.free_slots_stack_tensor.cpu().numpy().copy(), lens=np.stack(cm.row_seq_lens).copy(),
+                ptr=list(cm._num_free_slots), dev_lens=cm._dev_row_len.cpu().numpy().copy(),
+                dev_ptr=cm._dev_free_ptr.cpu().numpy().copy(), used_device=used_device)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_snapkv_device_resident_steps_equal_host_driven_steps(ragged):
+    """SURVEY 8(f).2 for SnapKV: the decode re-eviction (sink ++ top-k of this step's head-max scores ++ recent at
+    2 x decode_keep, sparse_controller.py:1104-1223) as the predicated burst of the device-resident step
+    (`SVK_DEVICE_SELECT_SNAPKV`).  Against the host-driven steps over >= 3 re-evictions with the same step inputs: slot
+    tables, free stacks (content and order), lengths and outputs bit-identical, eager and under hipGraph replay; device
+    copies of the bookkeeping equal the host mirrors; rows that trigger at different steps included."""
+    steps = 4 * 8 + 3
+    ref = _run_snapkv_decode(False, False, steps, ragged=ragged)
+    assert ref["used_device"] == 0 and int(ref["lens"].max()) < 40
+    for graph in (False, True):
+        base = ref if not graph else _run_snapkv_decode(False, True, steps, ragged=ragged)
+        got = _run_snapkv_decode(True, graph, steps, ragged=ragged)
+        assert got["used_device"] >= steps - 2
+        for key in ("o", "table", "lens"):
+            np.testing.assert_array_equal(got[key], base[key], err_msg=f"{key} graph={graph}")
+        assert got["ptr"] == base["ptr"]
+        for l in range(len(base["ptr"])):
+            np.testing.assert_array_equal(got["stack"][l, : base["ptr"][l]], base["stack"][l, : base["ptr"][l]])
+        np.testing.assert_array_equal(got["dev_lens"], got["lens"])
+        np.testing.assert_array_equal(got["dev_ptr"], np.asarray(got["ptr"]))
+
+
+def test_snapkv_device_resident_step_needs_no_host_sync():
+    got = _run_snapkv_decode(True, True, 3 * 8 + 6, sync_debug=True)
+    assert got["used_device"] >= 3 * 8
