@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 12
+#define SVK_ABI_VERSION 13
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -141,6 +141,11 @@ typedef struct SvkFlashDecodeStage1Args {
    * launch of the layer disappears.  Stage-1 variant 3 only. */
   uint16_t* direct_o;            /* NULL or [B, Hq, D] bf16 */
   int64_t direct_stride_b, direct_stride_h;
+  /* 2-D (head-max) scores only: 1 = store the launch's score of every position < b_seqlen[b] instead of max-combining it
+   * with what attn_score holds - the caller then needs no -1e20 pre-fill of the buffer (every position below the length is
+   * written exactly once per launch, by one owner thread) and masks the positions at or beyond the length itself
+   * (SvkH2oDecodeScoreArgs.mask_by_len).  0 = the reference's max-combine contract. */
+  int32_t score_overwrite, _pad0;
 } SvkFlashDecodeStage1Args;
 int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_stream_t stream);
 
@@ -188,6 +193,9 @@ typedef struct SvkH2oDecodeScoreArgs {
   float scale;              /* head_dim ** -0.5                                          */
   int32_t batch;
   int32_t width;
+  int32_t mask_by_len;      /* 1: positions >= b_seqlen[b] count as -1e20 whatever the buffer holds there (the step's raw
+                             * scores were stored with score_overwrite, no pre-fill); needs b_seqlen                 */
+  int32_t _pad0;
 } SvkH2oDecodeScoreArgs;
 int svk_h2o_decode_score_update(const SvkH2oDecodeScoreArgs* a, svk_stream_t stream);
 /* The same for `n_layers` layers in ONE launch (engine/cache_manager/h2o.py:957-1038
@@ -309,6 +317,8 @@ typedef struct SvkH2oDeviceStepArgs {
   int32_t budget, recent_count, trigger_len;
   int32_t select_mode;         /* SVK_DEVICE_SELECT_H2O (0) | _WINDOW (1) | _SNAPKV (2)       */
   int32_t prefix_count, _pad;  /* SNAPKV: sink tokens always kept                            */
+  int32_t* tickets;            /* NULL (burst = three launches) or [L] int32, zero before the first launch: the burst runs as
+                                * ONE launch whose last workgroup per layer commits the layer and resets its ticket      */
 } SvkH2oDeviceStepArgs;
 int svk_h2o_device_step_begin(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);
 int svk_h2o_device_burst(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);

@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 12
+SVK_ABI_VERSION = 13
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -56,7 +56,7 @@ class SvkFlashDecodeStage1Args(C.Structure):
                 ("batch", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
                 ("max_len_in_batch", _i32), ("block_seq", _i32), ("score_mode", _i32),
                 ("new_k", _p), ("new_v", _p), ("slot_mapping", _p), ("new_stride_b", _i64), ("new_stride_h", _i64),
-                ("direct_o", _p), ("direct_stride_b", _i64), ("direct_stride_h", _i64)]
+                ("direct_o", _p), ("direct_stride_b", _i64), ("direct_stride_h", _i64), ("score_overwrite", _i32), ("_pad0", _i32)]
 
 
 class SvkFlashDecodeStage2Args(C.Structure):
@@ -68,7 +68,8 @@ class SvkFlashDecodeStage2Args(C.Structure):
 
 class SvkH2oDecodeScoreArgs(C.Structure):
     _fields_ = [("attn_score", _p), ("cum_score", _p), ("b_req_idx", _p), ("b_seqlen", _p), ("b_new_slot", _p),
-                ("score_stride_b", _i64), ("cum_stride", _i64), ("scale", _f32), ("batch", _i32), ("width", _i32)]
+                ("score_stride_b", _i64), ("cum_stride", _i64), ("scale", _f32), ("batch", _i32), ("width", _i32),
+                ("mask_by_len", _i32), ("_pad0", _i32)]
 
 
 class SvkH2oSelectArgs(C.Structure):
@@ -103,7 +104,7 @@ class SvkH2oDeviceStepArgs(C.Structure):
                [(n, _i64) for n in ("table_stride_layer", "table_stride_row", "stack_stride", "score_stride_layer",
                                     "score_stride_row", "out_stride")] + \
                [(n, _i32) for n in ("n_layers", "rows_total", "batch", "graph_batch", "budget", "recent_count",
-                                    "trigger_len", "select_mode", "prefix_count", "_pad")]
+                                    "trigger_len", "select_mode", "prefix_count", "_pad")] + [("tickets", _p)]
 
 
 class SvkQuestDeviceStepArgs(C.Structure):

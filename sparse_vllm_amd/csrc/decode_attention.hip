@@ -330,7 +330,7 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
       for (uint32_t t = threadIdx.x; t < (uint32_t)(c1 - c0); t += blockDim.x) {
         float mx = -INFINITY;
         for (int j = 0; j < SP; ++j) mx = fmaxf(mx, spart[t * SP + j]);
-        dst[t] = fmaxf(dst[t], mx);
+        dst[t] = a.score_overwrite ? mx : fmaxf(dst[t], mx);
       }
       __syncthreads();
       c0 = t0 + kTileTokens;

@@ -33,12 +33,14 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
   const int b = blockIdx.x;
   float* x = a.attn_score + (int64_t)b * a.score_stride_b;
   const int W = a.width;
+  const int vlen = a.mask_by_len ? a.b_seqlen[b] : W;      // positions >= vlen read as the -1e20 fill (SvkH2oDecodeScoreArgs)
+  auto raw = [&](int t) { return t < vlen ? x[t] : -1e20f; };
   float mx = -INFINITY;
   // __fmul_rn keeps `x * scale` a separately rounded product like torch's mul_ (no fma contraction)
-  for (int t = threadIdx.x; t < W; t += blockDim.x) mx = fmaxf(mx, mul_rn(x[t], a.scale));
+  for (int t = threadIdx.x; t < W; t += blockDim.x) mx = fmaxf(mx, mul_rn(raw(t), a.scale));
   mx = block_allmax(mx, red);
   float sum = 0.f;
-  for (int t = threadIdx.x; t < W; t += blockDim.x) sum += expf(mul_rn(x[t], a.scale) - mx);
+  for (int t = threadIdx.x; t < W; t += blockDim.x) sum += expf(mul_rn(raw(t), a.scale) - mx);
   sum = block_allsum(sum, red);
   float* cum = nullptr;
   int len = 0;
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(1024) h2o_decode_score_kernel(const SvkH2oDeco
     len = a.b_seqlen[b];
   }
   for (int t = threadIdx.x; t < W; t += blockDim.x) {
-    const float p = expf(mul_rn(x[t], a.scale) - mx) / sum;
+    const float p = expf(mul_rn(raw(t), a.scale) - mx) / sum;
     x[t] = p;
     if (cum != nullptr && t < len) cum[t] = (t == len - 1) ? p : cum[t] + p;   // pad(prev, 1) + p
   }
@@ -72,6 +74,9 @@ __global__ void __launch_bounds__(256) h2o_decode_score_layers_kernel(const SvkH
     cum = a.cum_score + l * cum_stride_layer + (int64_t)a.b_req_idx[l * req_stride_layer + b] * a.cum_stride;
     len = a.b_seqlen[l * seqlen_stride_layer + b];
   }
+  // mask_by_len: the raw scores were stored without a -1e20 pre-fill; positions at or beyond the row's length read as the
+  // fill value whatever the buffer holds (bit-identical to the pre-filled form)
+  const int vlen = a.mask_by_len ? a.b_seqlen[l * seqlen_stride_layer + b] : W;
   float v[E4][4], c[E4][4];
   float mx = -INFINITY;
 #pragma unroll
@@ -80,6 +85,10 @@ __global__ void __launch_bounds__(256) h2o_decode_score_layers_kernel(const SvkH
     if constexpr (VEC) {
       float4 xv = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), cv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (t < W) xv = *reinterpret_cast<const float4*>(x + t);
+      if (t + 0 >= vlen) xv.x = -1e20f;
+      if (t + 1 >= vlen) xv.y = -1e20f;
+      if (t + 2 >= vlen) xv.z = -1e20f;
+      if (t + 3 >= vlen) xv.w = -1e20f;
       if (cum != nullptr && t < len - 1) cv = *reinterpret_cast<const float4*>(cum + t);   // (elements >= len - 1 are not used)
       v[i][0] = t < W ? mul_rn(xv.x, a.scale) : -INFINITY; v[i][1] = t < W ? mul_rn(xv.y, a.scale) : -INFINITY;
       v[i][2] = t < W ? mul_rn(xv.z, a.scale) : -INFINITY; v[i][3] = t < W ? mul_rn(xv.w, a.scale) : -INFINITY;
@@ -89,7 +98,7 @@ __global__ void __launch_bounds__(256) h2o_decode_score_layers_kernel(const SvkH
       // sizes the rows to the current maximum length): bit-identical to the 16-byte form
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[i][e] = t + e < W ? mul_rn(x[t + e], a.scale) : -INFINITY;
+        v[i][e] = t + e < W ? mul_rn(t + e < vlen ? x[t + e] : -1e20f, a.scale) : -INFINITY;
         c[i][e] = (cum != nullptr && t + e < len - 1) ? cum[t + e] : 0.f;
       }
     }
@@ -339,6 +348,75 @@ __global__ void __launch_bounds__(256) h2o_device_commit_kernel(const SvkH2oDevi
   }
 }
 
+// The three burst phases in ONE launch (round 4; grid = (lane, layer) like the select / compact kernels): a workgroup
+// whose row fired selects and compacts it exactly as above - the rank among the fired lanes and the layer's stack pointer
+// are read before anything of the layer changes - and every workgroup of the layer, fired or not, then takes a ticket; the
+// last one to arrive has seen all of them finish, so it alone commits the layer (row_len of the fired rows, free_ptr) and
+// resets the ticket.  Nothing crosses between workgroups except the ticket count: no fence, no hand-over of data.  Two
+// graph nodes less per decode step (the launch is the step's burst in 127 steps out of 128: a row-length test and a ticket).
+__global__ void __launch_bounds__(256) h2o_device_burst_kernel(const SvkH2oDeviceStepArgs a) {
+  __shared__ SelectScratch scratch;
+  __shared__ int s_rank[4], s_last;
+  const int b = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+  int32_t* lens = a.row_len + (int64_t)l * a.rows_total;
+  const int row = a.row_ids[b];
+  const bool fired = lens[row] == a.trigger_len;
+  if (fired) {
+    int64_t* keep = a.keep + ((int64_t)l * a.batch + b) * a.budget;
+    if (a.select_mode == SVK_DEVICE_SELECT_SNAPKV) {
+      const float* sc = a.scores + (int64_t)l * a.score_stride_layer + (int64_t)b * a.score_stride_row;
+      const int nt = blockDim.x;
+      const int prefix = a.prefix_count, suffix = a.recent_count, topk = a.budget - prefix - suffix;
+      const int mid = a.trigger_len - suffix - prefix;
+      for (int i = tid; i < prefix; i += nt) keep[i] = i;
+      for (int i = tid; i < suffix; i += nt) keep[prefix + topk + i] = a.trigger_len - suffix + i;
+      if (topk > 0)
+        block_select_topk_ordered(sc + prefix, mid, topk, scratch, [&](int pos, int idx) { keep[prefix + pos] = prefix + idx; });
+    } else if (a.select_mode == SVK_DEVICE_SELECT_WINDOW) {
+      const int prefix = a.budget - a.recent_count;
+      for (int i = tid; i < a.budget; i += blockDim.x) keep[i] = i < prefix ? i : a.trigger_len - a.budget + i;
+    } else {
+      h2o_select_row(a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row, keep, a.trigger_len,
+                     a.budget, a.recent_count, scratch);
+    }
+    __syncthreads();                                  // the row's keep list is complete (this workgroup wrote all of it)
+    int cnt = 0;
+    for (int j = tid; j < b; j += blockDim.x) cnt += lens[a.row_ids[j]] == a.trigger_len ? 1 : 0;
+    cnt = (int)wave_allsum((float)cnt);
+    if ((tid & 63) == 0) s_rank[tid >> 6] = cnt;
+    __syncthreads();
+    const int rank = s_rank[0] + s_rank[1] + s_rank[2] + s_rank[3];
+    const int K = a.budget, cur = a.trigger_len;
+    int32_t* tab = a.slot_table + (int64_t)l * a.table_stride_layer + (int64_t)row * a.table_stride_row;
+    int32_t* stack = a.free_stack + (int64_t)l * a.stack_stride + a.free_ptr[l] + (int64_t)rank * (cur - K);
+    float* pay = (a.scores && a.select_mode == SVK_DEVICE_SELECT_H2O)
+                     ? a.scores + (int64_t)l * a.score_stride_layer + (int64_t)row * a.score_stride_row : nullptr;
+    compact_row(tab, stack, pay, keep, K, cur);
+  }
+  __syncthreads();                                    // every thread of this workgroup has done its reads of lens / free_ptr
+  if (tid == 0) s_last = atomicAdd(&a.tickets[l], 1) == a.batch - 1;
+  __syncthreads();
+  if (!s_last) return;
+  // the layer's last workgroup: all others have finished (their tickets are in), nobody reads lens / free_ptr any more
+  int cnt = 0;
+  for (int j = tid; j < a.batch; j += blockDim.x) {
+    const int r = a.row_ids[j];
+    if (lens[r] == a.trigger_len) {
+      lens[r] = a.budget;
+      ++cnt;
+    }
+  }
+  cnt = (int)wave_allsum((float)cnt);
+  __syncthreads();
+  if ((tid & 63) == 0) s_rank[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    const int total = s_rank[0] + s_rank[1] + s_rank[2] + s_rank[3];
+    if (total > 0) a.free_ptr[l] += (int64_t)total * (a.trigger_len - a.budget);
+    a.tickets[l] = 0;                                 // self-cleaning for the next launch
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // decode slot allocation (all layers)
 // ------------------------------------------------------------------------------------
@@ -402,6 +480,7 @@ extern "C" int svk_h2o_decode_score_update_layers(const SvkH2oDecodeScoreArgs* f
   using namespace svk;
   SVK_REQUIRE(first != nullptr && first->attn_score != nullptr, SVK_ERR_VALUE, "svk_h2o_decode_score_update_layers: null args");
   SVK_REQUIRE(first->width > 0 && n_layers >= 0, SVK_ERR_VALUE, "svk_h2o_decode_score_update_layers: bad shape");
+  SVK_REQUIRE(!first->mask_by_len || first->b_seqlen != nullptr, SVK_ERR_VALUE, "svk_h2o_decode_score_update_layers: mask_by_len needs b_seqlen");
   SVK_REQUIRE(first->cum_score == nullptr || (first->b_req_idx != nullptr && first->b_seqlen != nullptr), SVK_ERR_VALUE,
               "svk_h2o_decode_score_update_layers: cum_score needs b_req_idx and b_seqlen");
   if (first->batch <= 0 || n_layers == 0) return SVK_OK;
@@ -522,6 +601,10 @@ extern "C" int svk_h2o_device_burst(const SvkH2oDeviceStepArgs* a, svk_stream_t 
               "svk_h2o_device_burst: recent_count %d out of range (budget %d)", a->recent_count, a->budget);
   if (a->n_layers <= 0 || a->batch <= 0) return SVK_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a->tickets != nullptr) {     // one launch: select + compact + ticketed commit
+    hipLaunchKernelGGL(h2o_device_burst_kernel, dim3(a->batch, a->n_layers), dim3(256), 0, s, *a);
+    return check_launch("svk_h2o_device_burst");
+  }
   hipLaunchKernelGGL(h2o_device_select_kernel, dim3(a->batch, a->n_layers), dim3(256), 0, s, *a);
   hipLaunchKernelGGL(h2o_device_compact_kernel, dim3(a->batch, a->n_layers), dim3(256), 0, s, *a);
   hipLaunchKernelGGL(h2o_device_commit_kernel, dim3(a->n_layers), dim3(256), 0, s, *a);

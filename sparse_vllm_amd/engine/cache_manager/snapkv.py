@@ -40,6 +40,7 @@ class SnapKVCacheManager(CacheManager):
         self._device_step_enabled = os.environ.get("SVK_H2O_DEVICE_STATE", "1") == "1"
         self._dev_row_len = torch.zeros((self.num_kv_layers, self.max_buffer_rows), dtype=torch.int32, device=self.device)
         self._dev_free_ptr = torch.zeros((self.num_kv_layers,), dtype=torch.long, device=self.device)
+        self._dev_burst_tickets = torch.zeros((self.num_kv_layers,), dtype=torch.int32, device=self.device)
         self._dev_state_dirty = True
         self._dev_step_cache = None              # (key, SvkH2oDeviceStepArgs, keep-alive tensors)
         # bumped whenever the args struct (whose device pointers a captured hipGraph bakes in by value) is rebuilt: a
@@ -447,7 +448,7 @@ class SnapKVCacheManager(CacheManager):
             args = h2o_ops.h2o_device_step_args(
                 self.buffer_req_to_token_slots_tensor, self.free_slots_stack_tensor, score_tensor, self._dev_row_len,
                 self._dev_free_ptr, rows_gpu, sm, cl, ri, keep, batch=B, budget=budget, recent_count=recent, trigger_len=trigger,
-                select_mode=select_mode, prefix_count=prefix)
+                select_mode=select_mode, prefix_count=prefix, tickets=self._dev_burst_tickets)
             cache = self._dev_step_cache = (key, args, (rows_gpu, keep, sm, cl, ri), rows_2d, kv_idx)
             self.device_step_generation += 1
         _, args, _keepalive, rows_2d, kv_idx = cache

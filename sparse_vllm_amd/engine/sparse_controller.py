@@ -70,6 +70,12 @@ class SparseController:
         # bandwidth-bound launch.  (Measured against the per-layer forms - inside a fused stage-2 launch, or riding in the
         # next layer's stage-1 launch - it wins at every batch size)
         self._pending_scores: list = []      # (SvkH2oDecodeScoreArgs, keep-alive tensors) of this step's layers
+        # MI355X: the H2O raw-score scratch [L, B, W] is not pre-filled with -1e20 every step (the reference's
+        # `view.fill_(-1e20)`, sparse_controller.py:427-461): stage 1 STORES the head-max score of every position below a
+        # row's length (one owner thread per position, `score_overwrite`) and the score epilogue treats the positions at or
+        # beyond the length as -1e20 (`mask_by_len`) - bit-identical results, one launch and B x W x 4 bytes less per
+        # layer and step.  SVK_H2O_SCORE_PREFILL=1 restores the reference's fill + max-combine.
+        self.decode_scores_overwrite = (self.sparse_method == "h2o" and os.environ.get("SVK_H2O_SCORE_PREFILL", "0") != "1")
         self.is_deltakv_family = self.sparse_method == "deltakv"
         # sparse_controller.py:70-73
         self.dynamic_deltakv_topk_tiebreak = _env_bool("SPARSEVLLM_DELTAKV_DETERMINISTIC_TOPK_TIEBREAK", False)
@@ -225,7 +231,8 @@ class SparseController:
         if buf is None:
             buf = torch.empty(key, dtype=self.snapkv_decode_score_dtype, device=self.device)
             self._h2o_decode_attn_score_buffers[key] = buf
-        h2o_ops.fill_f32(buf, -1e20)
+        if not self.decode_scores_overwrite:
+            h2o_ops.fill_f32(buf, -1e20)
         return buf
 
     def _prepare_h2o_decode_attn_score_buffer(self, seqs):
@@ -309,7 +316,7 @@ class SparseController:
         new_slots = self._h2o_new_slots(layer_idx)
         self._pending_scores.append(
             (h2o_score_args(s.attn_score, self.attn_softmax_scale, cum_score=cum, b_req_idx=s.req_indices,
-                            b_seqlen=s.context_lens, b_new_slot=new_slots),
+                            b_seqlen=s.context_lens, b_new_slot=new_slots, mask_by_len=self.decode_scores_overwrite),
              (s.attn_score, cum, s.req_indices, s.context_lens, new_slots)))
 
     def join_side_streams(self):

@@ -39,7 +39,7 @@ def direct_out_supported(max_len_in_batch, block_seq) -> bool:
 
 
 def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                 attn_score, block_seq, new_kv=None, direct_out=None):
+                 attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False):
     Lq, Lk = q.shape[-1], k.shape[-1]
     assert Lq == Lk
     assert Lk in {16, 32, 64, 128, 256}
@@ -87,11 +87,14 @@ def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, 
         mid_lse_stride_b=mid_out_logsumexp.stride(0), mid_lse_stride_h=mid_out_logsumexp.stride(1),
         score_stride_b=ss_b, score_stride_h=ss_h,
         batch=batch, num_q_heads=q.shape[1], num_kv_heads=kv_head_num, head_dim=Lk,
-        max_len_in_batch=int(max_len_in_batch), block_seq=int(block_seq), score_mode=mode, **store)
+        max_len_in_batch=int(max_len_in_batch), block_seq=int(block_seq), score_mode=mode,
+        score_overwrite=int(bool(score_overwrite) and mode == _lib.SVK_SCORE_HEADMAX), **store)
 
 
-def h2o_score_args(attn_score, scale, *, cum_score=None, b_req_idx=None, b_seqlen=None, b_new_slot=None):
-    """SvkH2oDecodeScoreArgs of one layer's score epilogue (what `h2o_ops.h2o_decode_score_update` would launch)."""
+def h2o_score_args(attn_score, scale, *, cum_score=None, b_req_idx=None, b_seqlen=None, b_new_slot=None, mask_by_len=False):
+    """SvkH2oDecodeScoreArgs of one layer's score epilogue (what `h2o_ops.h2o_decode_score_update` would launch).
+    `mask_by_len`: the raw scores were stored with `score_overwrite` into a buffer that was NOT pre-filled with -1e20."""
+    assert not mask_by_len or b_seqlen is not None
     assert attn_score.dim() == 2 and attn_score.dtype == torch.float32 and attn_score.stride(1) == 1
     if cum_score is not None:
         assert cum_score.dim() == 2 and cum_score.dtype == torch.float32 and cum_score.stride(1) == 1
@@ -100,13 +103,13 @@ def h2o_score_args(attn_score, scale, *, cum_score=None, b_req_idx=None, b_seqle
         attn_score=_lib.ptr(attn_score), cum_score=_lib.ptr(cum_score), b_req_idx=_lib.ptr(b_req_idx),
         b_seqlen=_lib.ptr(b_seqlen), b_new_slot=_lib.ptr(b_new_slot), score_stride_b=attn_score.stride(0),
         cum_stride=0 if cum_score is None else cum_score.stride(0), scale=float(scale),
-        batch=attn_score.shape[0], width=attn_score.shape[1])
+        batch=attn_score.shape[0], width=attn_score.shape[1], mask_by_len=int(bool(mask_by_len)))
 
 
 def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv=None, direct_out=None):
+            attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False):
     a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                     attn_score, block_seq, new_kv, direct_out)
+                     attn_score, block_seq, new_kv, direct_out, score_overwrite)
     lib = _lib.load()
     _lib.check(lib.svk_flash_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
 
@@ -123,8 +126,10 @@ def flash_decode_stage1(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_
 
 @torch.no_grad()
 def flash_decode_stage1_with_score(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
-                                   mid_out_logsumexp, attn_score, block_seq, *, new_kv=None, direct_out=None):
+                                   mid_out_logsumexp, attn_score, block_seq, *, new_kv=None, direct_out=None,
+                                   score_overwrite=False):
     """2-D `attn_score` [B, W]: head-max raw logits fused; 3-D [B, Hq, W]: per head.  `new_kv` / `direct_out`: as in
-    `flash_decode_stage1`."""
+    `flash_decode_stage1`.  `score_overwrite` (MI355X extension, 2-D scores): store instead of max-combine - the caller
+    skips the -1e20 pre-fill and masks positions beyond the lengths itself (include/svk.h)."""
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv, direct_out=direct_out)
+            attn_score, block_seq, new_kv, direct_out=direct_out, score_overwrite=score_overwrite)

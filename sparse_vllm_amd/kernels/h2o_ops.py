@@ -69,7 +69,8 @@ def h2o_decode_score_update_layers(pending) -> None:
         return d // esize
 
     same = all(x.batch == first.batch and x.width == first.width and x.score_stride_b == first.score_stride_b and
-               x.cum_stride == first.cum_stride and x.scale == first.scale for x in pending)
+               x.cum_stride == first.cum_stride and x.scale == first.scale and x.mask_by_len == first.mask_by_len
+               for x in pending)
     strides = [delta(name, 4) for name in ("attn_score", "cum_score", "b_new_slot", "b_req_idx", "b_seqlen")]
     if same and None not in strides:
         _lib.check(lib.svk_h2o_decode_score_update_layers(C.byref(first), len(pending), *strides, stream), lib)
@@ -185,11 +186,13 @@ def decode_alloc_slots(slot_table, free_stack, layer_ids, row_ids, cur_lens, slo
 
 def h2o_device_step_args(slot_table, free_stack, scores, row_len, free_ptr, row_ids, slot_mapping, context_lens, req_indices,
                          keep, *, batch: int, budget: int, recent_count: int, trigger_len: int, select_mode: int = 0,
-                         prefix_count: int = 0):
+                         prefix_count: int = 0, tickets=None):
     """Arguments of svk_h2o_device_step_begin / svk_h2o_device_burst (device-resident row lengths and free-stack
     pointers, include/svk.h): built once per batch composition, every pointer in them is graph-stable.
     `select_mode` 0 = H2O heavy hitters over `scores` [L, rows, cap]; 1 = sink + recent window (`scores` may be None);
-    2 = SnapKV sink ++ top-k ++ recent over this step's lane-indexed `scores` [L, lanes, width] (`prefix_count` = sink)."""
+    2 = SnapKV sink ++ top-k ++ recent over this step's lane-indexed `scores` [L, lanes, width] (`prefix_count` = sink).
+    `tickets` int32 [L] (zeroed once): the burst runs as one launch instead of three."""
+    assert tickets is None or (tickets.dtype == torch.int32 and tickets.numel() >= slot_table.shape[0])
     assert slot_table.dim() == 3 and slot_table.dtype == torch.int32 and slot_table.stride(2) == 1
     assert free_stack.dim() == 2 and free_stack.dtype == torch.int32 and free_stack.stride(1) == 1
     assert int(select_mode) in (0, 1, 2) and (scores is not None or int(select_mode) == 1)
@@ -209,7 +212,7 @@ def h2o_device_step_args(slot_table, free_stack, scores, row_len, free_ptr, row_
         out_stride=slot_mapping.stride(0),
         n_layers=int(slot_table.shape[0]), rows_total=int(row_len.shape[1]), batch=int(batch),
         graph_batch=int(slot_mapping.shape[1]), budget=int(budget), recent_count=int(recent_count),
-        trigger_len=int(trigger_len), select_mode=int(select_mode), prefix_count=int(prefix_count))
+        trigger_len=int(trigger_len), select_mode=int(select_mode), prefix_count=int(prefix_count), tickets=_lib.ptr(tickets))
 
 
 def h2o_device_step_begin(args):

@@ -160,7 +160,7 @@ class HipAttentionBackend:
 
     def run_decode(self, q: torch.Tensor, view: DecodeComputeView, *, mid_o, mid_o_logexpsum, max_len_in_batch: int,
                    block_seq: int, num_heads: int, num_kv_heads: int, gqa_block_n: int = 16,
-                   gqa_num_warps: int = 2, new_kv=None) -> torch.Tensor:
+                   gqa_num_warps: int = 2, new_kv=None, score_overwrite: bool = False) -> torch.Tensor:
         payload = view.payload
         if not isinstance(payload, ExplicitKVPayload):
             raise TypeError(f"HIP decode requires ExplicitKVPayload, got {type(payload).__name__}.")
@@ -197,7 +197,8 @@ class HipAttentionBackend:
             if meta.attn_score is not None:
                 flash_decode_stage1_with_score(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                                meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum,
-                                               meta.attn_score, block_seq, new_kv=new_kv, direct_out=direct_out)
+                                               meta.attn_score, block_seq, new_kv=new_kv, direct_out=direct_out,
+                                               score_overwrite=score_overwrite)
             else:
                 flash_decode_stage1(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                     meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum, block_seq,
@@ -266,7 +267,8 @@ class Attention(torch.nn.Module):
             o = self.attention_backend.run_decode(
                 q, decode_view, mid_o=mid_o, mid_o_logexpsum=mid_lse, max_len_in_batch=max_len_in_batch,
                 block_seq=block_seq, num_heads=self.num_heads, num_kv_heads=self.num_kv_heads,
-                gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps, new_kv=new_kv)
+                gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps, new_kv=new_kv,
+                score_overwrite=bool(getattr(sparse_controller, "decode_scores_overwrite", False)))
             cache_manager.record_decode_query(layer_idx, q)
             sparse_controller.on_layer_attention_end(layer_idx)
             cache_manager.on_layer_attention_end(layer_idx)

@@ -82,9 +82,6 @@ class Mi355xDecodeLaunchProvider(DecodeAttentionLaunchProvider):
         return SupportResult.yes()
 
     def launch_config(self, *, block_seq, max_context_len, requires_attention_scores, batch_size=None, num_kv_heads=None):
-        forced = os.environ.get("SVK_DECODE_BLOCK_SEQ")                   # developer override for A/B runs
-        if forced:
-            return max(16, (int(forced) // 16) * 16), 16, 4
         b = max(1, int(batch_size or 1))
         length = max(1, int(max_context_len))
         hkv = max(1, int(num_kv_heads or 4))                             # waves per workgroup

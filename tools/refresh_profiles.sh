@@ -24,7 +24,7 @@ for b in 64 128 512; do timeout 400 python3 "$R/bench.py" --batch $b --no-cpu-ba
 # other configurations
 timeout 600 python3 "$R/tools/pathbench.py" --graph < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_graph.jsonl"
 timeout 600 python3 "$R/tools/pathbench.py" < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_eager.jsonl"
-for c in streamingllm quest deltakv_raw deltakv vanilla; do
+for c in streamingllm quest quest_b8 deltakv_raw deltakv vanilla h2o_b1; do
   stats paths/${c}_kernel_stats.csv python3 "$R/tools/pathbench.py" --graph --configs $c --steps 20
 done
 timeout 300 python3 "$R/tools/kbench_kivi.py" --batches 1 --block-seqs 512,1024 < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi.txt"
@@ -47,7 +47,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 # bare access-pattern and instruction probes (built here by hipcc, see the header of each file)
 # PMC passes over the KIVI stage-1 kernel (counters only)
-bash "$R/tools/pmc_kivi.sh" 5 4 2304 > "$O/pmc_kivi_v5.txt" 2>/dev/null
+bash "$R/tools/pmc_kivi.sh" 4 2304 > "$O/pmc_kivi.txt" 2>/dev/null
 for p in probe_gather probe_kdma probe_dma_offset mfma_valu_mix probe_fp8cvt probe_tr4; do
   [ -x "$R/tools/bin/$p" ] && timeout 120 "$R/tools/bin/$p" < /dev/null > "$O/$p.txt" 2>&1
 done
