@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 13
+#define SVK_ABI_VERSION 14
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -145,7 +145,12 @@ typedef struct SvkFlashDecodeStage1Args {
    * with what attn_score holds - the caller then needs no -1e20 pre-fill of the buffer (every position below the length is
    * written exactly once per launch, by one owner thread) and masks the positions at or beyond the length itself
    * (SvkH2oDecodeScoreArgs.mask_by_len).  0 = the reference's max-combine contract. */
-  int32_t score_overwrite, _pad0;
+  int32_t score_overwrite;
+  /* MI355X: > 0 = req_to_tokens is a table of PAGE slots and position t of a row lives in token slot
+   * req_to_tokens[row, t / slot_page_size] * slot_page_size + t % slot_page_size (paged caches whose token slots are
+   * page_slot * page_size + offset, e.g. Quest: the decode view is then 1 / page_size of the entries).  0 = token slots,
+   * the reference's contract.  Must be a power of two. */
+  int32_t slot_page_size;
 } SvkFlashDecodeStage1Args;
 int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_stream_t stream);
 
@@ -467,6 +472,11 @@ typedef struct SvkQuestBuildViewArgs {
   int32_t page_budget_base;
   int32_t max_keep;             /* columns of packed_slots that are defined                */
   int32_t is_long_text;
+  /* MI355X (optional): 1 = packed_slots receives PAGE slots (prev_budget selected pages + the last page; dense rows:
+   * their first ceil(max_keep / page_size) pages) for svk_flash_decode_stage1's `slot_page_size` addressing - 1/page_size
+   * of the view's entries.  0 = the reference-shaped token-slot view. */
+  int32_t emit_page_slots;
+  int32_t _pad0;
 } SvkQuestBuildViewArgs;
 int svk_quest_build_view(const SvkQuestBuildViewArgs* a, svk_stream_t stream);
 

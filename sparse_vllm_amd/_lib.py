@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 13
+SVK_ABI_VERSION = 14
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -56,7 +56,7 @@ class SvkFlashDecodeStage1Args(C.Structure):
                 ("batch", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
                 ("max_len_in_batch", _i32), ("block_seq", _i32), ("score_mode", _i32),
                 ("new_k", _p), ("new_v", _p), ("slot_mapping", _p), ("new_stride_b", _i64), ("new_stride_h", _i64),
-                ("direct_o", _p), ("direct_stride_b", _i64), ("direct_stride_h", _i64), ("score_overwrite", _i32), ("_pad0", _i32)]
+                ("direct_o", _p), ("direct_stride_b", _i64), ("direct_stride_h", _i64), ("score_overwrite", _i32), ("slot_page_size", _i32)]
 
 
 class SvkFlashDecodeStage2Args(C.Structure):
@@ -135,7 +135,8 @@ class SvkQuestBuildViewArgs(C.Structure):
                 ("score_stride", _i64), ("page_table_stride", _i64), ("token_table_stride", _i64),
                 ("packed_stride", _i64),
                 ("batch", _i32), ("page_size", _i32), ("n_prev", _i32), ("prev_budget", _i32),
-                ("token_budget", _i32), ("page_budget_base", _i32), ("max_keep", _i32), ("is_long_text", _i32)]
+                ("token_budget", _i32), ("page_budget_base", _i32), ("max_keep", _i32), ("is_long_text", _i32),
+                ("emit_page_slots", _i32), ("_pad0", _i32)]
 
 
 class SvkQuestDecodeAllocArgs(C.Structure):

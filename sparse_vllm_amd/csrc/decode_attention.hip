@@ -157,7 +157,13 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
   // slot ids of one 32-token tile: lanes 0..31 fetch row[t0 + lane] (one coalesced 128 B read)
   // (index clamped to the last valid token: always a legal, branch-free load - a conditional
   //  load would make the compiler's vmcnt bookkeeping conservative for the whole tile body)
-  auto fetch_slots = [&](int t0) -> int { return row[(uint32_t)min(t0 + (lane_id_fresh() & 31), end - 1)]; };
+  // (slot_page_size > 0, a power of two: `row` holds page slots, token slot = page slot * size + offset in the page)
+  const int page_shift = a.slot_page_size > 0 ? __builtin_ctz((unsigned)a.slot_page_size) : 0;
+  const uint32_t page_mask = (uint32_t)max(a.slot_page_size, 1) - 1u;
+  auto fetch_slots = [&](int t0) -> int {
+    const uint32_t t = (uint32_t)min(t0 + (lane_id_fresh() & 31), end - 1);
+    return (row[t >> page_shift] << page_shift) + (int)(t & page_mask);
+  };
   auto wave_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -480,6 +486,8 @@ static int validate_stage1(const SvkFlashDecodeStage1Args* a, const char* who) {
               a->num_q_heads, a->num_kv_heads);
   SVK_REQUIRE(a->score_mode == SVK_SCORE_NONE || a->score_mode == SVK_SCORE_HEADMAX || a->score_mode == SVK_SCORE_PERHEAD,
               SVK_ERR_VALUE, "%s: bad score_mode %d", who, a->score_mode);
+  SVK_REQUIRE(a->slot_page_size >= 0 && (a->slot_page_size & (a->slot_page_size - 1)) == 0, SVK_ERR_VALUE,
+              "%s: slot_page_size %d must be 0 or a power of two", who, a->slot_page_size);
   SVK_REQUIRE(a->score_mode == SVK_SCORE_NONE || a->attn_score != nullptr, SVK_ERR_VALUE, "%s: score_mode %d needs attn_score", who,
               a->score_mode);
   SVK_REQUIRE((a->kv_slot_stride % 8) == 0 && (a->kv_head_stride % 8) == 0 && (a->q_stride_h % 8) == 0 && (a->q_stride_b % 8) == 0,

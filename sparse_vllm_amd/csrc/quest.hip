@@ -158,30 +158,18 @@ __global__ void __launch_bounds__(512) quest_score_pages_kernel(const SvkQuestSc
 template <int CH>
 __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBuildViewArgs a, int lds_keys) {
   __shared__ SelectScratch scratch;
-  extern __shared__ int sel_pages[];          // [prev_budget] selected logical pages, ascending
+  extern __shared__ __attribute__((aligned(16))) int sel_pages[];          // [prev_budget] selected logical pages, ascending
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const int len = a.context_lens[b];
-  const int row = a.req_indices[b];
-  const int ps = a.page_size;
-  const int num_pages = max(1, (len + ps - 1) / ps);
-  int32_t* packed = a.packed_slots + (int64_t)b * a.packed_stride;
-  const int32_t* ttab = a.token_table + (int64_t)row * a.token_table_stride;
-  const int32_t* ptab = a.page_table + (int64_t)row * a.page_table_stride;
-  if (tid == 0) a.local_req[b] = b;
-  const bool dense = !a.is_long_text && (len <= a.token_budget || num_pages <= a.page_budget_base);
-  SVK_SEL_STAMP(0);
-  if (dense) {
-    for (int i = tid; i < a.max_keep; i += nt) packed[i] = ttab[i];
-    if (tid == 0) a.local_lens[b] = len;
-    return;
-  }
   const float* sc = a.page_scores + (int64_t)b * a.score_stride;
+  constexpr int C = CH > 0 ? CH : 4;
+  // pages per thread, rounded up to a multiple of 4: every thread's range starts 16-byte aligned (vector loads of the
+  // scores and page slots for any row length; the last threads own nothing)
+  [[maybe_unused]] const int per = ((a.n_prev + nt - 1) / nt + 3) & ~3;
+  [[maybe_unused]] const int base = tid * per;
+  [[maybe_unused]] float v[C];
   if constexpr (CH > 0) {
-    // one round trip for the thread's CH scores (16-byte loads when the row allows), then no memory in the select
-    constexpr int C = CH > 0 ? CH : 4;
-    const int per = (a.n_prev + nt - 1) / nt;
-    const int base = tid * per;
-    float v[C];
+    // the thread's scores first (16-byte loads when the row allows): they do not depend on the row's length or table row,
+    // so their round trip overlaps those loads; then no memory in the select
     if ((per & 3) == 0 && (reinterpret_cast<uintptr_t>(sc) & 15u) == 0u && base + per <= a.n_prev) {
 #pragma unroll
       for (int j = 0; j < C; j += 4) {
@@ -194,11 +182,80 @@ __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBu
 #pragma unroll
       for (int j = 0; j < C; ++j) v[j] = j < per && base + j < a.n_prev ? sc[base + j] : 0.f;
     }
+  }
+  const int len = a.context_lens[b];
+  const int row = a.req_indices[b];
+  const int ps = a.page_size;
+  const int num_pages = max(1, (len + ps - 1) / ps);
+  int32_t* packed = a.packed_slots + (int64_t)b * a.packed_stride;
+  const int32_t* ttab = a.token_table + (int64_t)row * a.token_table_stride;
+  const int32_t* ptab = a.page_table + (int64_t)row * a.page_table_stride;
+  if (tid == 0) a.local_req[b] = b;
+  const bool dense = !a.is_long_text && (len <= a.token_budget || num_pages <= a.page_budget_base);
+  SVK_SEL_STAMP(0);
+  if (dense) {
+    if (a.emit_page_slots) {
+      for (int j = tid; j < (a.max_keep + ps - 1) / ps; j += nt) packed[j] = j < num_pages ? max(ptab[j], 0) : 0;
+    } else {
+      for (int i = tid; i < a.max_keep; i += nt) packed[i] = ttab[i];
+    }
+    if (tid == 0) a.local_lens[b] = len;
+    return;
+  }
+  if constexpr (CH > 0) {
+    // the page slots of the thread's own pages, in flight during the select: a selected page is then written straight
+    // from the emit (no list of selected pages, no gather pass behind a barrier)
+    int pslot[C];
+    if ((per & 3) == 0 && (reinterpret_cast<uintptr_t>(ptab) & 15u) == 0u && base + per <= a.n_prev) {
+#pragma unroll
+      for (int j = 0; j < C; j += 4) {
+        if (j < per) {
+          const int4 t = *reinterpret_cast<const int4*>(ptab + base + j);
+          pslot[j] = t.x; pslot[j + 1] = t.y; pslot[j + 2] = t.z; pslot[j + 3] = t.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < C; ++j) pslot[j] = j < per && base + j < a.n_prev ? ptab[base + j] : 0;
+    }
+    const int last_slot = max(ptab[num_pages - 1], 0);
     uint32_t key[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) key[j] = desc_key(v[j]);
-    block_select_topk_ordered_owned<C>(key, per, a.n_prev, a.prev_budget, scratch,
-                                       [&](int pos, int idx, uint32_t) { sel_pages[pos] = idx; });
+    // (lds_keys == 2: 128 KB of LDS for the select's 16-bit histogram)
+    uint32_t* hist16 = lds_keys == 2 ? reinterpret_cast<uint32_t*>(sel_pages) : nullptr;
+    // page-slot view: written straight from the emit.  Token-slot view: the selected pages' slots go to LDS and the block
+    // writes the page_size x longer view together, coalesced (16-byte stores from the few scattered emitting lanes
+    // measured 5 us for 292 pages)
+    int* sel_slots = sel_pages + (lds_keys == 2 ? 32768 : 0);
+    uint32_t T;
+    int take_eq;
+    select_owned_threshold<C>(key, per, a.n_prev, a.prev_budget, scratch, T, take_eq, hist16);
+    // (pin the page-slot loads between the two halves of the select: they have had the threshold search to land; left
+    //  alone, the compiler sinks each one into the emit branch that uses it - up to `per` dependent round trips)
+#pragma unroll
+    for (int j = 0; j < C; ++j) asm volatile("" : "+v"(pslot[j]));
+    select_owned_emit<C>(key, per, a.n_prev, T, take_eq, scratch, [&](int pos, int, uint32_t, int j) {
+      if (a.emit_page_slots) packed[pos] = max(pslot[j], 0);
+      else sel_slots[pos] = max(pslot[j], 0);
+    });
+    SVK_SEL_STAMP(3);
+    if (tid == 0) a.local_lens[b] = a.prev_budget * ps + (len - (num_pages - 1) * ps);
+    if (a.emit_page_slots) {
+      if (tid == 0) packed[a.prev_budget] = last_slot;
+      for (int j = a.prev_budget + 1 + tid; j < (a.max_keep + ps - 1) / ps; j += nt) packed[j] = 0;
+    } else {
+      __syncthreads();
+      const int sparse_keep = (a.prev_budget + 1) * ps;
+      for (int i = tid; i < sparse_keep; i += nt) {
+        const int j = i / ps;
+        packed[i] = (j < a.prev_budget ? sel_slots[j] : last_slot) * ps + (i - j * ps);
+      }
+      if (!a.is_long_text)
+        for (int i = sparse_keep + tid; i < a.max_keep; i += nt) packed[i] = ttab[i];
+    }
+    SVK_SEL_STAMP(4);
+    return;
   } else if (lds_keys) {
     // keys staged in LDS (8 scores per thread and trip with the loads first, the select's OR / AND sweep folded in)
     uint32_t* keys = reinterpret_cast<uint32_t*>(sel_pages + a.prev_budget);
@@ -231,6 +288,13 @@ __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBu
   }
   __syncthreads();
   SVK_SEL_STAMP(3);
+  if (tid == 0) a.local_lens[b] = a.prev_budget * ps + (len - (num_pages - 1) * ps);
+  if (a.emit_page_slots) {
+    for (int j = tid; j < (a.max_keep + ps - 1) / ps; j += nt)
+      packed[j] = j <= a.prev_budget ? max(ptab[j < a.prev_budget ? sel_pages[j] : num_pages - 1], 0) : 0;
+    SVK_SEL_STAMP(4);
+    return;
+  }
   const int sparse_keep = (a.prev_budget + 1) * ps;
   for (int i0 = 0; i0 < sparse_keep; i0 += 8 * nt) {          // page-table gathers of 8 entries per thread in flight together
     int slot[8];
@@ -248,7 +312,6 @@ __global__ void __launch_bounds__(1024) quest_build_view_kernel(const SvkQuestBu
   }
   if (!a.is_long_text)
     for (int i = sparse_keep + tid; i < a.max_keep; i += nt) packed[i] = ttab[i];
-  if (tid == 0) a.local_lens[b] = a.prev_budget * ps + (len - (num_pages - 1) * ps);
   SVK_SEL_STAMP(4);
 }
 
@@ -414,20 +477,28 @@ extern "C" int svk_quest_build_view(const SvkQuestBuildViewArgs* a, svk_stream_t
   if (lds_keys) shm += sizeof(uint32_t) * (size_t)a->n_prev;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quest_build_view_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    const void* fns[] = {reinterpret_cast<const void*>(quest_build_view_kernel<0>), reinterpret_cast<const void*>(quest_build_view_kernel<4>),
+                         reinterpret_cast<const void*>(quest_build_view_kernel<8>), reinterpret_cast<const void*>(quest_build_view_kernel<12>),
+                         reinterpret_cast<const void*>(quest_build_view_kernel<16>), reinterpret_cast<const void*>(quest_build_view_kernel<24>),
+                         reinterpret_cast<const void*>(quest_build_view_kernel<32>)};
+    for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     attr_set = true;
   }
   const int nt = a->n_prev > 2048 ? 1024 : 256;
-  const int per_thread = (a->n_prev + nt - 1) / nt;
+  const int per_thread = ((a->n_prev + nt - 1) / nt + 3) & ~3;           // (the kernel's `per`)
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t shm_owned = sizeof(int) * a->prev_budget;
+  // keys in registers; rows of the 1024-thread form also get 128 KB of LDS for the select's 16-bit histogram
+  const size_t sel_bytes = a->emit_page_slots ? 0 : sizeof(int) * (size_t)a->prev_budget;
+  const bool h16 = nt == 1024 && 128 * 1024 + sel_bytes <= 156 * 1024;
+  const size_t shm_owned = (h16 ? 128 * 1024 : 0) + sel_bytes;
+  const int mode = h16 ? 2 : 0;
   if (per_thread > 32) hipLaunchKernelGGL(quest_build_view_kernel<0>, dim3(a->batch), dim3(nt), shm, s, *a, lds_keys);
-  else if (per_thread <= 4) hipLaunchKernelGGL(quest_build_view_kernel<4>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
-  else if (per_thread <= 8) hipLaunchKernelGGL(quest_build_view_kernel<8>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
-  else if (per_thread <= 12) hipLaunchKernelGGL(quest_build_view_kernel<12>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
-  else if (per_thread <= 16) hipLaunchKernelGGL(quest_build_view_kernel<16>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
-  else if (per_thread <= 24) hipLaunchKernelGGL(quest_build_view_kernel<24>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
-  else hipLaunchKernelGGL(quest_build_view_kernel<32>, dim3(a->batch), dim3(nt), shm_owned, s, *a, 0);
+  else if (per_thread <= 4) hipLaunchKernelGGL(quest_build_view_kernel<4>, dim3(a->batch), dim3(nt), shm_owned, s, *a, mode);
+  else if (per_thread <= 8) hipLaunchKernelGGL(quest_build_view_kernel<8>, dim3(a->batch), dim3(nt), shm_owned, s, *a, mode);
+  else if (per_thread <= 12) hipLaunchKernelGGL(quest_build_view_kernel<12>, dim3(a->batch), dim3(nt), shm_owned, s, *a, mode);
+  else if (per_thread <= 16) hipLaunchKernelGGL(quest_build_view_kernel<16>, dim3(a->batch), dim3(nt), shm_owned, s, *a, mode);
+  else if (per_thread <= 24) hipLaunchKernelGGL(quest_build_view_kernel<24>, dim3(a->batch), dim3(nt), shm_owned, s, *a, mode);
+  else hipLaunchKernelGGL(quest_build_view_kernel<32>, dim3(a->batch), dim3(nt), shm_owned, s, *a, mode);
   return check_launch("svk_quest_build_view");
 }
 

@@ -68,11 +68,14 @@ __device__ __forceinline__ int block_excl_count(bool flag, int* wsum, int& total
 }
 
 // Descending-order key: smaller key == larger score; -0.0 and +0.0 compare equal like
-// torch's comparison-based stable sort.
+// torch's comparison-based stable sort.  Sign-magnitude -> offset binary by ADDING / SUBTRACTING the magnitude
+// (0x80000000 +- |f|) rather than by complementing the negatives: the order is the same, and bits that are zero in
+// every magnitude stay shared by all keys - bf16-valued scores of mixed sign keep their 16 low key bits equal
+// (complementing turns them into 0x0000 / 0xffff), so the select sees 16 varying bits and runs 2 digit passes, not 4.
 __device__ __forceinline__ uint32_t desc_key(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u << 1) == 0u) u = 0u;                                   // canonical +0
-  const uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  const uint32_t mag = u & 0x7fffffffu;                         // (-0.0 -> +0.0: both map to 0x80000000)
+  const uint32_t asc = (u & 0x80000000u) ? 0x80000000u - mag : 0x80000000u + mag;
   return ~asc;
 }
 
@@ -81,7 +84,7 @@ struct SelectScratch {
   int hist[256];
   int wsum[16], wsum2[16];
   uint32_t prefix;
-  int k;
+  int k, total;
   uint32_t or_bits, and_bits;      // OR / AND of all keys: key bytes every element shares need no radix pass
 };
 
@@ -116,6 +119,29 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, boo
   if (active) atomicAdd(&hist[bin], 1);
 }
 
+// The same for a histogram of 16-bit digits held as two 16-bit counts per LDS word (65 536 bins in 128 KB).  Bins 2p and
+// 2p + 1 are the halves of word (p & 31) * 1024 + (p >> 5): the 32 words of the 64-bin segment s = p >> 5 lie 1024 words
+// apart, so thread s of a 1024-thread block sums its segment with conflict-free reads.  Counts must stay below 65 536.
+__device__ __forceinline__ int hist16_word(uint32_t bin) { return (int)(((bin >> 1) & 31u) * 1024u + (bin >> 6)); }
+__device__ __forceinline__ void hist16_add_aggregated(uint32_t* hist16, uint32_t bin, bool active) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp((int)~bin, (int)bin, 0x111, 0xf, 0xf, false);   // row_shr:1
+  if (__popcll(__ballot(active && nb == bin)) >= 16) {
+    unsigned long long todo = __ballot(active);
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      if (todo == 0ull) break;
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t lb = (uint32_t)__shfl((int)bin, leader, 64);
+      const unsigned long long same = __ballot(active && bin == lb) & todo;
+      if (lane == leader) atomicAdd(&hist16[hist16_word(lb)], (uint32_t)__popcll(same) << ((lb & 1u) * 16u));
+      todo &= ~same;
+    }
+    active = (todo >> lane) & 1ull;
+  }
+  if (active) atomicAdd(&hist16[hist16_word(bin)], 1u << ((bin & 1u) * 16u));
+}
+
 // Core on descending-order keys `key_at(i)` (smaller key = better; callers stage keys in LDS when the row fits, so the
 // sweeps do not pay a dependent global-load latency each).
 // OR / AND of all keys, accumulated in the scratch (workgroup-wide): begin (includes a barrier), add per thread, then a
@@ -131,6 +157,39 @@ __device__ __forceinline__ void select_bits_add(SelectScratch& S, uint32_t o, ui
     an &= (uint32_t)__shfl_xor((int)an, off, 64);
   }
   if ((threadIdx.x & 63) == 0) { atomicOr(&S.or_bits, o); atomicAnd(&S.and_bits, an); }
+}
+
+// The bin of S.hist[0:256) that holds the kk-th key (1-based) of a digit at `shift`: prefix |= bin << shift, kk = the rank
+// wanted inside that bin; returns the histogram's total.  The histogram is complete (a barrier behind the caller's
+// adds); all threads call; on return every thread has read the result and S.hist is still intact.
+__device__ __forceinline__ int select_find_bin(SelectScratch& S, uint32_t& prefix, int& kk, int shift) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    int c[4];
+    int local = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c[j] = S.hist[tid * 4 + j]; local += c[j]; }
+    const int incl = wave_incl_scan_add(local);
+    const int excl = incl - local;
+    if (kk > excl && kk <= incl) {
+      int run = excl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kk > run && kk <= run + c[j]) {
+          S.prefix = prefix | ((uint32_t)(tid * 4 + j) << shift);
+          S.k = kk - run;
+        }
+        run += c[j];
+      }
+    }
+    if (tid == 63) S.total = incl;
+  }
+  __syncthreads();
+  prefix = S.prefix;
+  kk = S.k;
+  const int total = S.total;
+  __syncthreads();
+  return total;
 }
 
 // The radix passes of the select: digits of up to 8 bits from bit `top` down to bit `low`; keys whose bits above the
@@ -153,29 +212,7 @@ __device__ __forceinline__ void select_radix_passes_sweep(Sweep sweep, SelectScr
     __syncthreads();
     sweep(shift, dmask, himask, prefix);
     __syncthreads();
-    if (tid < 64) {
-      int c[4];
-      int local = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { c[j] = S.hist[tid * 4 + j]; local += c[j]; }
-      const int incl = wave_incl_scan_add(local);
-      const int excl = incl - local;
-      if (kk > excl && kk <= incl) {
-        int run = excl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (kk > run && kk <= run + c[j]) {
-            S.prefix = prefix | ((uint32_t)(tid * 4 + j) << shift);
-            S.k = kk - run;
-          }
-          run += c[j];
-        }
-      }
-    }
-    __syncthreads();
-    prefix = S.prefix;
-    kk = S.k;
-    __syncthreads();
+    select_find_bin(S, prefix, kk, shift);
     SVK_SEL_STAMP(8 + (31 - shift) / 8);
   }
   SVK_SEL_STAMP(2);
@@ -240,10 +277,18 @@ __device__ __forceinline__ void select_ordered_emit(KeyAt key_at, int n, uint32_
 // The select with the keys in registers: thread t owns the `per` (<= CH, the same for all threads) consecutive indices
 // from t * per (key[j] = key of index t * per + j; indices >= n are ignored whatever their key), so neither the passes
 // nor the emit read memory; `emit(pos, idx, key)`.
-template <int CH, typename Emit>
-__device__ __forceinline__ void block_select_topk_ordered_owned(const uint32_t (&key)[CH], int per, int n, int k,
-                                                                SelectScratch& S, Emit emit) {
+// (threshold half: T = the k-th key, kk = how many keys equal to T are taken)
+// `hist16` (optional): 32 768 words of LDS, blockDim.x == 1024.  Keys that differ in their 16 high bits only (bf16-valued
+// scores: Quest page scores) are then counted by that whole 16-bit digit in ONE pass of LDS atomics spread over thousands
+// of bins, and the threshold is read off a block scan of the 1024 segment sums + a wave scan of the segment's 64 bins -
+// instead of a pass per 8-bit digit whose first digit (sign + 7 exponent bits) piles a row's keys onto a handful of
+// bins (8191 keys: ~4 us for that pass alone, ~1.5 us for the next).
+template <int CH>
+__device__ __forceinline__ void select_owned_threshold(const uint32_t (&key)[CH], int per, int n, int k, SelectScratch& S,
+                                                       uint32_t& T_out, int& kk_out, uint32_t* hist16 = nullptr) {
   const int base = threadIdx.x * per;
+  if (hist16 != nullptr)                                        // (cleared under the barriers of the OR / AND reduction)
+    for (int i = threadIdx.x * 4; i < 32768; i += blockDim.x * 4) *reinterpret_cast<uint4*>(hist16 + i) = make_uint4(0u, 0u, 0u, 0u);
   select_bits_begin(S);
   uint32_t o = 0u, an = 0xffffffffu;
 #pragma unroll
@@ -256,6 +301,40 @@ __device__ __forceinline__ void block_select_topk_ordered_owned(const uint32_t (
   const uint32_t varying = S.or_bits ^ all_and;
   uint32_t prefix = all_and;
   int kk = k;
+  if (hist16 != nullptr && varying != 0u && (varying & 0xffffu) == 0u && n < 65536 && blockDim.x == 1024) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = 16;
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (j < per) hist16_add_aggregated(hist16, key[j] >> 16, base + j < n);
+    __syncthreads();
+    SVK_SEL_STAMP(8);
+    int local = 0;                                              // thread t sums segment t (bins [64 t, 64 t + 64))
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const uint32_t c = hist16[j * 1024 + tid];
+      local += (int)(c & 0xffffu) + (int)(c >> 16);
+    }
+    const int incl = wave_incl_scan_add(local);
+    if (lane == 63) S.wsum[w] = incl;
+    __syncthreads();
+    int excl = incl - local;
+    for (int j = 0; j < nw; ++j) excl += j < w ? S.wsum[j] : 0;
+    if (kk > excl && kk <= excl + local) { S.wsum2[0] = tid; S.wsum2[1] = kk - excl; }     // the kk-th key lies in this segment
+    __syncthreads();
+    if (w == 0) {                                               // its 64 bins, one per lane
+      const int seg = S.wsum2[0], k2 = S.wsum2[1];
+      const uint32_t c = hist16[(lane >> 1) * 1024 + seg];
+      const int cnt = (lane & 1) ? (int)(c >> 16) : (int)(c & 0xffffu);
+      const int inc = wave_incl_scan_add(cnt);
+      if (k2 > inc - cnt && k2 <= inc) { S.prefix = (uint32_t)(seg * 64 + lane); S.k = k2 - (inc - cnt); }
+    }
+    __syncthreads();
+    T_out = (S.prefix << 16) | (all_and & 0xffffu);
+    kk_out = S.k;
+    __syncthreads();
+    SVK_SEL_STAMP(2);
+    return;
+  }
   auto sweep = [&](int shift, uint32_t dmask, uint32_t himask, uint32_t pfx) {
 #pragma unroll
     for (int j = 0; j < CH; ++j)
@@ -299,7 +378,16 @@ __device__ __forceinline__ void block_select_topk_ordered_owned(const uint32_t (
   } else {
     select_radix_passes_sweep(sweep, S, prefix, kk, top, low);
   }
-  const uint32_t T = prefix;
+  T_out = prefix;
+  kk_out = kk;
+}
+
+// (emit half: the keys < T and the first kk keys == T, `emit(pos, idx, key, j)` with pos = rank in ascending index order
+//  and j = the key's register index, a constant after unrolling)
+template <int CH, typename Emit>
+__device__ __forceinline__ void select_owned_emit(const uint32_t (&key)[CH], int per, int n, uint32_t T, int kk,
+                                                  SelectScratch& S, Emit emit) {
+  const int base = threadIdx.x * per;
   int n_lt = 0, n_eq = 0;
 #pragma unroll
   for (int j = 0; j < CH; ++j) {
@@ -314,11 +402,20 @@ __device__ __forceinline__ void block_select_topk_ordered_owned(const uint32_t (
     if (j < per) {
       const bool in = base + j < n;
       const bool lt = in && key[j] < T, eq = in && key[j] == T;
-      if (lt || (eq && eq_before < kk)) emit(lt_before + min(eq_before, kk), base + j, key[j]);
+      if (lt || (eq && eq_before < kk)) emit(lt_before + min(eq_before, kk), base + j, key[j], j);
       lt_before += lt;
       eq_before += eq;
     }
   }
+}
+
+template <int CH, typename Emit>
+__device__ __forceinline__ void block_select_topk_ordered_owned(const uint32_t (&key)[CH], int per, int n, int k,
+                                                                SelectScratch& S, Emit emit, uint32_t* hist16 = nullptr) {
+  uint32_t T;
+  int kk;
+  select_owned_threshold<CH>(key, per, n, k, S, T, kk, hist16);
+  select_owned_emit<CH>(key, per, n, T, kk, S, emit);
 }
 
 template <typename KeyAt, typename Emit>

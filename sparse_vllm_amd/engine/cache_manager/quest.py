@@ -57,6 +57,10 @@ class QuestCacheManager(CacheManager):
         self._dev_step_cache = None
         self.device_step_generation = 0
         self._device_step = None                 # this step's [args, end_launched] while the device-resident step is active
+        # MI355X: the decode view is written as page slots (293 instead of 4672 entries per row) and the attention launch
+        # addresses it by page (`slot_page_size`): the attended tokens and their order are unchanged
+        # (tests/test_gpu_quest.py); False = the reference-shaped token-slot view.
+        self.page_slot_view = (self.page_size & (self.page_size - 1)) == 0
 
     # ------------------------------------------------------------------ allocation
     def allocate_kv_cache(self):
@@ -402,16 +406,17 @@ class QuestCacheManager(CacheManager):
         buf = self._view_bufs.get(key)
         if buf is None:
             d = self.device
-            buf = (torch.empty((batch, n_prev), dtype=torch.float32, device=d),
-                   torch.zeros((batch, keep), dtype=torch.int32, device=d),
+            # (rows of 16-byte multiples: the view kernel reads the scores, and writes the view, with vector accesses)
+            buf = (torch.empty((batch, (n_prev + 3) // 4 * 4), dtype=torch.float32, device=d)[:, :n_prev],
+                   torch.zeros((batch, (keep + 3) // 4 * 4), dtype=torch.int32, device=d)[:, :keep],
                    torch.empty((batch,), dtype=torch.int32, device=d), torch.empty((batch,), dtype=torch.int32, device=d))
             self._view_bufs[key] = buf
         return buf
 
     @torch.no_grad()
     def build_decode_view(self, layer_idx: int, q: torch.Tensor, active_slots: torch.Tensor, req_indices: torch.Tensor,
-                          context_lens: torch.Tensor, *, num_heads: int, num_kv_heads: int):
-        """quest.py:1804-1913."""
+                          context_lens: torch.Tensor, *, num_heads: int, num_kv_heads: int, page_slots: bool = False):
+        """quest.py:1804-1913.  `page_slots`: the packed view holds page slots (its first ceil(keep / page_size) columns)."""
         if layer_idx < self.config.quest_skip_layers:
             return active_slots, req_indices, context_lens
         token_budget = int(self.config.quest_token_budget)
@@ -442,17 +447,22 @@ class QuestCacheManager(CacheManager):
             quest_ops.build_view(scores, self.buffer_req_to_page_slots, self.buffer_req_to_token_slots, req_indices,
                                  context_lens, packed, lens, lreq, page_size=self.page_size, n_prev=max_pages - 1,
                                  prev_budget=prev_budget, token_budget=token_budget, page_budget_base=page_budget_base,
-                                 max_keep=keep, is_long_text=is_long_text)
+                                 max_keep=keep, is_long_text=is_long_text, emit_page_slots=page_slots)
             return packed, lreq, lens
 
     def build_decode_compute_view(self, layer_idx: int, q: torch.Tensor, selection, *, num_heads: int, num_kv_heads: int):
         """base.py:1162-1206 with the Quest view hook."""
         k_cache, v_cache = self.get_layer_compute_tensors(layer_idx)
+        paged = bool(self.page_slot_view and q.is_cuda)
         slots, req, lens = self.build_decode_view(layer_idx, q, self.buffer_req_to_token_slots, selection.req_indices,
-                                                  selection.context_lens, num_heads=num_heads, num_kv_heads=num_kv_heads)
+                                                  selection.context_lens, num_heads=num_heads, num_kv_heads=num_kv_heads,
+                                                  page_slots=paged)
         max_ctx = selection.max_context_len
+        metadata = None
         if slots is not self.buffer_req_to_token_slots:
-            max_ctx = int(slots.shape[1])
+            max_ctx = int(slots.shape[1])          # the view's width in tokens, whichever way its slots are written
+            if paged:
+                metadata = {"slot_page_size": self.page_size}
         meta = AttentionViewMeta(active_slots=slots, req_indices=req, context_lens=lens, max_context_len=max_ctx,
                                  attn_score=selection.attn_score)
-        return DecodeComputeView(meta=meta, payload=ExplicitKVPayload(k_cache=k_cache, v_cache=v_cache))
+        return DecodeComputeView(meta=meta, payload=ExplicitKVPayload(k_cache=k_cache, v_cache=v_cache, metadata=metadata))

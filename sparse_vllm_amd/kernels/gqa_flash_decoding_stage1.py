@@ -39,7 +39,7 @@ def direct_out_supported(max_len_in_batch, block_seq) -> bool:
 
 
 def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                 attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False):
+                 attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False, slot_page_size=0):
     Lq, Lk = q.shape[-1], k.shape[-1]
     assert Lq == Lk
     assert Lk in {16, 32, 64, 128, 256}
@@ -88,7 +88,8 @@ def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, 
         score_stride_b=ss_b, score_stride_h=ss_h,
         batch=batch, num_q_heads=q.shape[1], num_kv_heads=kv_head_num, head_dim=Lk,
         max_len_in_batch=int(max_len_in_batch), block_seq=int(block_seq), score_mode=mode,
-        score_overwrite=int(bool(score_overwrite) and mode == _lib.SVK_SCORE_HEADMAX), **store)
+        score_overwrite=int(bool(score_overwrite) and mode == _lib.SVK_SCORE_HEADMAX), slot_page_size=int(slot_page_size),
+        **store)
 
 
 def h2o_score_args(attn_score, scale, *, cum_score=None, b_req_idx=None, b_seqlen=None, b_new_slot=None, mask_by_len=False):
@@ -107,21 +108,23 @@ def h2o_score_args(attn_score, scale, *, cum_score=None, b_req_idx=None, b_seqle
 
 
 def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False):
+            attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False, slot_page_size=0):
     a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                     attn_score, block_seq, new_kv, direct_out, score_overwrite)
+                     attn_score, block_seq, new_kv, direct_out, score_overwrite, slot_page_size)
     lib = _lib.load()
     _lib.check(lib.svk_flash_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
 
 
 @torch.no_grad()
 def flash_decode_stage1(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
-                        mid_out_logsumexp, block_seq, block_n=16, num_warps=2, num_stages=2, *, new_kv=None, direct_out=None):
+                        mid_out_logsumexp, block_seq, block_n=16, num_warps=2, num_stages=2, *, new_kv=None, direct_out=None,
+                        slot_page_size=0):
     """`new_kv=(new_k, new_v, slot_mapping)` (MI355X extension): store this step's K/V rows inside the launch.
     `direct_out` [B, Hq, D] bf16 (MI355X extension, see `direct_out_supported`): the launch writes the attention output
-    itself and no stage 2 is needed."""
+    itself and no stage 2 is needed.  `slot_page_size` (MI355X extension): Req_to_tokens holds page slots of that many
+    tokens (include/svk.h)."""
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp, None,
-            block_seq, new_kv, direct_out=direct_out)
+            block_seq, new_kv, direct_out=direct_out, slot_page_size=slot_page_size)
 
 
 @torch.no_grad()

@@ -46,7 +46,9 @@ def score_pages(q, page_max, page_min, page_table, req_indices, context_lens, pa
 
 def build_view(page_scores, page_table, token_table, req_indices, context_lens, packed_slots, local_lens, local_req, *,
                page_size: int, n_prev: int, prev_budget: int, token_budget: int, page_budget_base: int, max_keep: int,
-               is_long_text: bool):
+               is_long_text: bool, emit_page_slots: bool = False):
+    """`emit_page_slots` (MI355X): the view is written as page slots (`flash_decode_stage1(..., slot_page_size=page_size)`
+    reads it)."""
     assert packed_slots.dtype == torch.int32 and packed_slots.stride(1) == 1
     lib = _lib.load()
     a = _lib.SvkQuestBuildViewArgs(
@@ -56,7 +58,7 @@ def build_view(page_scores, page_table, token_table, req_indices, context_lens, 
         page_table_stride=page_table.stride(0), token_table_stride=token_table.stride(0),
         packed_stride=packed_slots.stride(0), batch=packed_slots.shape[0], page_size=int(page_size), n_prev=int(n_prev),
         prev_budget=int(prev_budget), token_budget=int(token_budget), page_budget_base=int(page_budget_base),
-        max_keep=int(max_keep), is_long_text=int(bool(is_long_text)))
+        max_keep=int(max_keep), is_long_text=int(bool(is_long_text)), emit_page_slots=int(bool(emit_page_slots)))
     _lib.check(lib.svk_quest_build_view(C.byref(a), _lib.current_stream_handle()), lib)
 
 

@@ -202,7 +202,8 @@ class HipAttentionBackend:
             else:
                 flash_decode_stage1(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                     meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum, block_seq,
-                                    gqa_block_n, gqa_num_warps, new_kv=new_kv, direct_out=direct_out)
+                                    gqa_block_n, gqa_num_warps, new_kv=new_kv, direct_out=direct_out,
+                                    slot_page_size=int((payload.metadata or {}).get("slot_page_size", 0)))
         if not direct:
             with profiler.record(f"decode_attention_stage2_{kind}"):
                 flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)

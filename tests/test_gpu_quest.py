@@ -243,7 +243,98 @@ def test_quest_decode_steps_match_oracle():
             np.testing.assert_allclose(outs[l].float().cpu().numpy(), bf16_round(o), rtol=3e-2, atol=3e-2)
 
 
-def _run_quest(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False):
+@pytest.mark.parametrize("dist", ["normal_bf16", "normal", "all_equal", "with_neg_inf"])
+@pytest.mark.parametrize("shape", [dict(n_prev=8191, prev_budget=291), dict(n_prev=2047, prev_budget=255),
+                                   dict(n_prev=700, prev_budget=699), dict(n_prev=40000, prev_budget=300)])
+def test_page_slot_view_equals_token_slot_view(dist, shape):
+    """`SvkQuestBuildViewArgs.emit_page_slots`: the view written as page slots, expanded to page_slot * 16 + offset, is the
+    token-slot view - rows that are sparse, sparse with a short last page, and dense (short)."""
+    from sparse_vllm_amd.kernels.quest_ops import build_view
+    n_prev, kb = shape["n_prev"], shape["prev_budget"]
+    page, B = 16, 4
+    rng = np.random.default_rng(n_prev * 3 + len(dist))
+    if dist == "normal_bf16":
+        sc = bf16_round(rng.standard_normal((B, n_prev)).astype(np.float32) * 3)
+    elif dist == "normal":
+        sc = rng.standard_normal((B, n_prev)).astype(np.float32) * 3
+    elif dist == "all_equal":
+        sc = np.full((B, n_prev), 0.25, dtype=np.float32)
+    else:
+        sc = bf16_round(rng.standard_normal((B, n_prev)).astype(np.float32))
+        sc[:, n_prev - n_prev // 3:] = -np.inf
+        sc[1, max(kb, n_prev // 2):] = -np.inf
+    n_pages = n_prev + 1
+    ptab = np.stack([rng.permutation(n_pages * B)[:n_pages] for _ in range(B)]).astype(np.int32)
+    ttab = (ptab[:, :, None].astype(np.int64) * page + np.arange(page)[None, None, :]).reshape(B, -1).astype(np.int32)
+    lens = np.array([n_pages * page, n_pages * page - 9, n_pages * page - 15, min(n_pages, kb) * page - 3], dtype=np.int32)
+    token_budget, base = (kb + 1) * page, kb + 1
+    keep = (kb + 1) * page
+    d = dev()
+    t_sc, t_pt, t_tt = torch.from_numpy(sc).to(d), torch.from_numpy(ptab).to(d), torch.from_numpy(ttab).to(d)
+    req, t_len = torch.arange(B, dtype=torch.int32, device=d), torch.from_numpy(lens).to(d)
+
+    def run(emit_pages):
+        packed = torch.full((B, keep), -7, dtype=torch.int32, device=d)
+        ll = torch.zeros((B,), dtype=torch.int32, device=d)
+        lr = torch.zeros((B,), dtype=torch.int32, device=d)
+        build_view(t_sc, t_pt, t_tt, req, t_len, packed, ll, lr, page_size=page, n_prev=n_prev, prev_budget=kb,
+                   token_budget=token_budget, page_budget_base=base, max_keep=keep, is_long_text=False,
+                   emit_page_slots=emit_pages)
+        torch.cuda.synchronize()
+        return packed.cpu().numpy(), ll.cpu().numpy()
+
+    ref, ref_lens = run(False)
+    assert ref_lens[3] == lens[3] and (ref_lens[:3] < lens[:3]).all()          # row 3 is dense, the others sparse
+    got, got_lens = run(True)
+    np.testing.assert_array_equal(got_lens, ref_lens)
+    for b in range(B):
+        n = int(ref_lens[b])
+        n_pg = (n + page - 1) // page
+        tok = (got[b, :n_pg, None].astype(np.int64) * page + np.arange(page)[None, :]).reshape(-1)[:n]
+        np.testing.assert_array_equal(tok, ref[b, :n])
+
+
+@pytest.mark.parametrize("cfg", [dict(D=128, Hq=28, Hkv=4, block_seq=256, scored=False),
+                                 dict(D=64, Hq=16, Hkv=8, block_seq=128, scored=False),
+                                 dict(D=128, Hq=32, Hkv=8, block_seq=256, scored=True)])
+def test_stage1_page_slot_addressing_equals_token_slots(cfg):
+    """`SvkFlashDecodeStage1Args.slot_page_size`: the launch over a table of page slots == the launch over the token slots
+    page_slot * 16 + offset, bit for bit (partials, log-sum-exps, decode scores), ragged lengths."""
+    from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import _launch
+    D, Hq, Hkv, bs = cfg["D"], cfg["Hq"], cfg["Hkv"], cfg["block_seq"]
+    page, B, n_pages = 16, 4, 300
+    rng = np.random.default_rng(D + Hq)
+    d = dev()
+    ptab = rng.permutation(B * n_pages + 5)[: B * n_pages].reshape(B, n_pages).astype(np.int32)
+    ttab = (ptab[:, :, None].astype(np.int64) * page + np.arange(page)[None, None, :]).reshape(B, -1).astype(np.int32)
+    lens = np.array([n_pages * page, n_pages * page - 13, 17, 1], dtype=np.int32)
+    slots = (B * n_pages + 5) * page
+    kc = torch.randn((slots, Hkv, D), device=d).to(torch.bfloat16)
+    vc = torch.randn((slots, Hkv, D), device=d).to(torch.bfloat16)
+    q = torch.randn((B, Hq, D), device=d).to(torch.bfloat16)
+    req = torch.tensor([2, 0, 3, 1], dtype=torch.int32, device=d)
+    t_len = torch.from_numpy(lens).to(d)
+    L = n_pages * page
+    nblk = (L + bs - 1) // bs
+    outs = []
+    for tab, sps in ((ttab, 0), (ptab, page)):
+        rows = np.zeros_like(tab)
+        rows[req.cpu().numpy()] = tab
+        mid = torch.full((B, Hq, nblk, D), 3.0, dtype=torch.float32, device=d)
+        lse = torch.full((B, Hq, nblk), 3.0, dtype=torch.float32, device=d)
+        score = torch.full((B, L), -1e20, dtype=torch.float32, device=d) if cfg["scored"] else None
+        _launch(q, kc, vc, torch.from_numpy(rows).to(d), req, t_len, L, mid, lse, score, bs, None, slot_page_size=sps)
+        torch.cuda.synchronize()
+        outs.append((mid.view(torch.int32).cpu().numpy(), lse.view(torch.int32).cpu().numpy(),
+                     None if score is None else score.view(torch.int32).cpu().numpy()))
+    np.testing.assert_array_equal(outs[1][0], outs[0][0])
+    np.testing.assert_array_equal(outs[1][1], outs[0][1])
+    if cfg["scored"]:
+        np.testing.assert_array_equal(outs[1][2], outs[0][2])
+
+
+def _run_quest(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False,
+               reference_shaped: bool = False):
     from sparse_vllm_amd.config import Config
     from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
     B, L = 4, 3
@@ -253,6 +344,8 @@ def _run_quest(device_state: bool, graph: bool, steps: int, *, ragged: bool = Fa
     drv = SparseDecodeDriver(conf)
     cm = drv.cache_manager
     cm._device_step_enabled = device_state
+    if reference_shaped:
+        cm.page_slot_view = False
     cm.permute_free_pages(5)
     drv.admit_resident_rows(B, 500, seed=9)
     if ragged:
@@ -303,6 +396,17 @@ def test_quest_device_resident_steps_equal_host_driven_steps(ragged):
         assert got["dev_ptr"] == got["nfree"]
         np.testing.assert_array_equal(got["dev_stack"][: got["nfree"]], got["stack"][: got["nfree"]])
         np.testing.assert_array_equal(got["ptab"], got["ptab_cpu"])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_quest_steps_with_page_slot_view_equal_reference_shaped_steps(graph):
+    """QuestCacheManager.page_slot_view (view written as page slots, attention addressed by page): the same outputs, tables
+    and metadata as with the reference-shaped token-slot view, eager and under replay."""
+    steps = 2 * 16 + 5
+    ref = _run_quest(True, graph, steps, ragged=True, reference_shaped=True)
+    got = _run_quest(True, graph, steps, ragged=True)
+    for key in ("o", "ttab", "ptab", "md", "lens"):
+        np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
 
 
 def test_quest_device_resident_step_needs_no_host_sync():

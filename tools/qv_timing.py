@@ -19,6 +19,7 @@ ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 budget = int(sys.argv[3]) if len(sys.argv) > 3 else 4672
 mode = sys.argv[4] if len(sys.argv) > 4 else "normal"
+paged = len(sys.argv) > 5 and sys.argv[5] == "paged"
 ps = 16
 d = torch.device("cuda:0")
 pages = ctx // ps
@@ -40,13 +41,13 @@ lib = _lib.load()
 out = (C.c_ulonglong * 16)()
 for it in range(4):
     quest_ops.build_view(scores, ptab, ttab, req, lens, packed, ll, lr, page_size=ps, n_prev=n_prev, prev_budget=prev_budget,
-                         token_budget=budget, page_budget_base=budget // ps, max_keep=keep, is_long_text=True)
+                         token_budget=budget, page_budget_base=budget // ps, max_keep=keep, is_long_text=True, emit_page_slots=paged)
     torch.cuda.synchronize()
     lib.svk_debug_quest_view_stamps(out)
     t = list(out)
-    names = [(1, "stage keys + first digit"), (5, "bin scan + candidates"), (8, "pass b31.."), (9, "pass b23.."),
+    names = [(1, "stage keys + shared bits"), (5, "bin scan + candidates"), (8, "pass b31.. / 16-bit histogram"), (9, "pass b23.."),
              (10, "pass b15.."), (11, "pass b7.."), (2, "threshold"),
-             (3, "ordered emit"), (4, "page gather + view")]
+             (3, "ordered emit (+ view, keys in registers)"), (4, "page gather + view / tail")]
     prev, line = t[0], []
     for i, nm in names:
         if t[i] > prev:
