@@ -849,11 +849,13 @@ class DeltaKVCacheManager(CacheManager):
             ev = self._recon_events[layer_idx] = torch.cuda.Event()
         return ev
 
-    @staticmethod
-    def _recon_sub_batches() -> list[int]:
+    _RECON_SUB_BATCHES = [2]
+
+    @classmethod
+    def _recon_sub_batches(cls) -> list[int]:
         """Layers per look-ahead launch group (the last value repeats).  Two balances the side stream against the main
         stream's per-layer chain (measured 1 / 2 / 3 / 4 layers -> 1.88 / 1.62 / 1.66 / 1.73 ms per 256 k step)."""
-        return [2]
+        return list(cls._RECON_SUB_BATCHES)
 
     @classmethod
     def _recon_sub_batch(cls) -> int:
@@ -884,6 +886,7 @@ class DeltaKVCacheManager(CacheManager):
         return st[1]
 
     _RECON_PAD = 64
+    _RECON_GEMM_ROWS = 4096
 
     def _reconstruct_layers_batched(self, l_idxs, stack, recon_pos, recon_latent, recon_out_slot):
         """Residual load + reconstruction of consecutive sparse layers `l_idxs` (same plan) in three launches."""
@@ -895,6 +898,9 @@ class DeltaKVCacheManager(CacheManager):
         cur = store.get(n)                     # one buffer pair per token count, never freed while the side stream may use it
         hid = int(w1.shape[1])
         if cur is None or cur[0].shape[0] < k:
+            if len(store) >= 4:                   # a handful of token counts at most (batch compositions come and go)
+                torch.cuda.current_stream().synchronize()
+                store.clear()
             kb = max(k, self._recon_sub_batch())
             hbuf = torch.zeros((kb, n, hid + self._RECON_PAD), dtype=torch.bfloat16, device=self.device)
             hbuf[:, :, hid] = 1.0                                   # the bias feature; the kernel below writes [:, :, :hid] only
@@ -904,7 +910,11 @@ class DeltaKVCacheManager(CacheManager):
         dk.dequant_linear_act(self.deltakv_latent_cache[l0:l1], self.deltakv_latent_scales[l0:l1], self.deltakv_latent_mins[l0:l1],
                               self._quant_group_size(), w1[l0:l1], b1[l0:l1], activation="gelu", row_index=recon_latent,
                               out=hp[:, :, :hid], layers=True)
-        torch.bmm(hp, w2[l0:l1].transpose(1, 2), out=delta)
+        # (row chunks: this image's hipBLASLt faults inside the batched bf16 GEMM at 8192 rows - plain
+        #  torch.bmm([2, 8192, 2112] x [2, 2112, 1024]), tools/probe_bmm2.py; 4096 rows and the per-layer mm are fine)
+        for c0 in range(0, n, self._RECON_GEMM_ROWS):
+            c1 = min(n, c0 + self._RECON_GEMM_ROWS)
+            torch.bmm(hp[:, c0:c1], w2[l0:l1].transpose(1, 2), out=delta[:, c0:c1])
         knw = self.deltakv_k_norm_weight
         dk.deltakv_reconstruct_writeback_layers(
             delta, self.deltakv_latent_to_full_slots[l0:l1], recon_latent, self.deltakv_slot_to_pos, recon_out_slot, recon_pos,

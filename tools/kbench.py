@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--modes", default="2,0")
     ap.add_argument("--layers", type=int, default=6, help="distinct K/V sets cycled through (defeats the 256 MB MALL)")
+    ap.add_argument("--graph-pair", action="store_true", help="time stage 1 + stage 2 of one layer, back to back in a hipGraph "
+                    "(small batches: eager launches are CPU-bound)")
     ap.add_argument("--heads", default="28,4", help="query heads, KV heads of the rank (7,1 = one TP=4 rank of Qwen2.5-7B)")
     args = ap.parse_args()
     from _warm import warm
@@ -47,6 +49,29 @@ def main():
             lse = torch.empty(B, Hq, nblk, device=d)
             score = torch.full((B, L), -1e20, device=d)
             o = torch.empty_like(q)
+            if args.graph_pair:
+                def pair():
+                    kc, vc = kcs[it[0] % args.layers], vcs[it[0] % args.layers]
+                    it[0] += 1
+                    flash_decode_stage1(q, kc, vc, req, bidx, blen, L, mid, lse, bs)
+                    flash_decode_stage2(mid, lse, blen, o, bs)
+                pair()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(args.iters):
+                        pair()
+                g.replay()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                print(f"stage1+stage2 (graph) B={B:3d} L={L} block_seq={bs:4d} nblk={nblk}: "
+                      f"{e0.elapsed_time(e1) * 1e3 / (5 * args.iters):8.2f} us", flush=True)
+                continue
             for mode in [int(x) for x in args.modes.split(",")]:
                 def run():
                     kc, vc = kcs[it[0] % args.layers], vcs[it[0] % args.layers]

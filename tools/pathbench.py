@@ -244,7 +244,11 @@ def main():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--recon-sub-batches", default="", help="developer: DeltaKV look-ahead layers per launch group, e.g. 1,2,3")
     args = ap.parse_args()
+    if args.recon_sub_batches:
+        from sparse_vllm_amd.engine.cache_manager.deltakv import DeltaKVCacheManager
+        DeltaKVCacheManager._RECON_SUB_BATCHES = [int(x) for x in args.recon_sub_batches.split(",")]
     for name in args.configs.split(","):
         print(json.dumps(measure(name, steps=args.steps, warmup=args.warmup, graph=args.graph)), flush=True)
 
