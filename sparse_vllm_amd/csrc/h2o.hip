@@ -349,19 +349,22 @@ __global__ void __launch_bounds__(256) h2o_device_commit_kernel(const SvkH2oDevi
 }
 
 // The three burst phases in ONE launch (round 4; grid = (lane, layer) like the select / compact kernels): a workgroup
-// whose row fired selects and compacts it exactly as above - the rank among the fired lanes and the layer's stack pointer
-// are read before anything of the layer changes - and every workgroup of the layer, fired or not, then takes a ticket; the
-// last one to arrive has seen all of them finish, so it alone commits the layer (row_len of the fired rows, free_ptr) and
-// resets the ticket.  Nothing crosses between workgroups except the ticket count: no fence, no hand-over of data.  Two
-// graph nodes less per decode step (the launch is the step's burst in 127 steps out of 128: a row-length test and a ticket).
+// whose row fired selects and compacts it exactly as above - its rank among the fired lanes, their number and the layer's
+// stack pointer are read before anything of the layer changes - and then takes a ticket; the last of the layer's FIRED
+// workgroups to arrive has seen the others finish, so it alone commits the layer (row_len of the fired rows, free_ptr) and
+// resets the ticket.  A workgroup whose row did not fire returns on its first load and touches no ticket (with every
+// workgroup taking one, the idle launch of 127 steps out of 128 cost 79 us at B=256: 256 same-address device-scope
+// atomics per layer, ~300 ns each).  Nothing crosses between workgroups except the ticket count: no fence, no hand-over
+// of data.  Two graph nodes less per decode step.
 __global__ void __launch_bounds__(256) h2o_device_burst_kernel(const SvkH2oDeviceStepArgs a) {
   __shared__ SelectScratch scratch;
-  __shared__ int s_rank[4], s_last;
+  __shared__ int s_rank[4], s_all[4], s_last;
   const int b = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+  int n_fired = 0;
   int32_t* lens = a.row_len + (int64_t)l * a.rows_total;
   const int row = a.row_ids[b];
-  const bool fired = lens[row] == a.trigger_len;
-  if (fired) {
+  if (lens[row] != a.trigger_len) return;
+  {
     int64_t* keep = a.keep + ((int64_t)l * a.batch + b) * a.budget;
     if (a.select_mode == SVK_DEVICE_SELECT_SNAPKV) {
       const float* sc = a.scores + (int64_t)l * a.score_stride_layer + (int64_t)b * a.score_stride_row;
@@ -380,12 +383,18 @@ __global__ void __launch_bounds__(256) h2o_device_burst_kernel(const SvkH2oDevic
                      a.budget, a.recent_count, scratch);
     }
     __syncthreads();                                  // the row's keep list is complete (this workgroup wrote all of it)
-    int cnt = 0;
-    for (int j = tid; j < b; j += blockDim.x) cnt += lens[a.row_ids[j]] == a.trigger_len ? 1 : 0;
+    int cnt = 0, all = 0;
+    for (int j = tid; j < a.batch; j += blockDim.x) {
+      const int f = lens[a.row_ids[j]] == a.trigger_len ? 1 : 0;
+      cnt += j < b ? f : 0;
+      all += f;
+    }
     cnt = (int)wave_allsum((float)cnt);
-    if ((tid & 63) == 0) s_rank[tid >> 6] = cnt;
+    all = (int)wave_allsum((float)all);
+    if ((tid & 63) == 0) { s_rank[tid >> 6] = cnt; s_all[tid >> 6] = all; }
     __syncthreads();
     const int rank = s_rank[0] + s_rank[1] + s_rank[2] + s_rank[3];
+    n_fired = s_all[0] + s_all[1] + s_all[2] + s_all[3];
     const int K = a.budget, cur = a.trigger_len;
     int32_t* tab = a.slot_table + (int64_t)l * a.table_stride_layer + (int64_t)row * a.table_stride_row;
     int32_t* stack = a.free_stack + (int64_t)l * a.stack_stride + a.free_ptr[l] + (int64_t)rank * (cur - K);
@@ -394,10 +403,10 @@ __global__ void __launch_bounds__(256) h2o_device_burst_kernel(const SvkH2oDevic
     compact_row(tab, stack, pay, keep, K, cur);
   }
   __syncthreads();                                    // every thread of this workgroup has done its reads of lens / free_ptr
-  if (tid == 0) s_last = atomicAdd(&a.tickets[l], 1) == a.batch - 1;
+  if (tid == 0) s_last = atomicAdd(&a.tickets[l], 1) == n_fired - 1;
   __syncthreads();
   if (!s_last) return;
-  // the layer's last workgroup: all others have finished (their tickets are in), nobody reads lens / free_ptr any more
+  // the layer's last fired workgroup: the others have finished (their tickets are in), nobody reads lens / free_ptr any more
   int cnt = 0;
   for (int j = tid; j < a.batch; j += blockDim.x) {
     const int r = a.row_ids[j];
