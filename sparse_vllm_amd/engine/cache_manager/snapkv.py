@@ -309,6 +309,10 @@ class SnapKVCacheManager(CacheManager):
             L = self.num_layers
             buf = tuple(torch.zeros((L, graph_batch_size), dtype=torch.int32, device=d) for _ in range(3))
             self._decode_static_buffers = buf
+            # the cached device-step arguments hold views of the old buffers: rebuild them (and, through the generation
+            # counter, the caller's hipGraph) before the next device-resident step
+            self._dev_step_cache = None
+            self._dev_state_dirty = True
         return tuple(t[:, :graph_batch_size] for t in buf)
 
     def _prepare_decode_static_host(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,
