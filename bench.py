@@ -384,7 +384,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import pathbench
         out["paths"] = []
-        for name in ("h2o_b64", "h2o_b8", "h2o_b1", "streamingllm", "quest", "quest_b8", "deltakv", "deltakv_b4"):
+        for name in ("h2o_b64", "h2o_b8", "h2o_b1", "streamingllm", "streamingllm_b1", "quest", "quest_b8", "quest_b1", "deltakv",
+                     "deltakv_b4"):
             try:
                 out["paths"].append(pathbench.measure(name, steps=args.path_steps, warmup=4, graph=True))
             except Exception as e:      # a failing side leg must not lose the headline line

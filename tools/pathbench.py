@@ -9,7 +9,8 @@ BASELINE.json "other configs" (SURVEY section 8(d)), Qwen2.5-7B shapes, syntheti
   deltakv       256k context, sink 8 / recent 128 / keep 2048, K=4, latent 256 int4, 6 KIVI-int4 full layers, B=1
   deltakv_raw   same with raw bf16 full layers at 64k context
   vanilla       8k context dense decode, B=16
-  h2o_b<N>      the headline configuration at N sequences; quest_b8 / deltakv_b4: the B=8 / B=4 points of SURVEY 8(d)
+  h2o_b<N>      the headline configuration at N sequences; quest_b<N> / streamingllm_b<N> / deltakv_b4: the other batch
+                points of SURVEY 8(d)
 One JSON line per configuration: ms per decode step of the sparse path (all layers, no dense model).
 """
 import argparse
@@ -28,15 +29,16 @@ QWEN = dict(num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4,
 
 
 def build(name: str):
-    if name == "streamingllm":
+    if name.startswith("streamingllm"):
+        B = int(name.split("_b")[1]) if "_b" in name else 64
         cfg = Config.from_kwargs(sparse_method="streamingllm", sink_keep_tokens=64, recent_keep_tokens=512,
-                                 max_model_len=2048, max_num_seqs_in_gpu=64, num_kvcache_slots=64 * 1160 + 64, **QWEN)
+                                 max_model_len=2048, max_num_seqs_in_gpu=B, num_kvcache_slots=B * 1160 + 64, **QWEN)
         drv = SparseDecodeDriver(cfg)
         drv.cache_manager.permute_free_slots(1)
-        drv.admit_resident_rows(64, 576, logical_len=32768, seed=0, device_rng=True)
-        return drv, dict(batch=64, context=32768, resident=576)
-    if name in ("quest", "quest_b8"):
-        B, ctx = (8 if name == "quest_b8" else 4), 131072
+        drv.admit_resident_rows(B, 576, logical_len=32768, seed=0, device_rng=True)
+        return drv, dict(batch=B, context=32768, resident=576)
+    if name.startswith("quest"):
+        B, ctx = (int(name.split("_b")[1]) if "_b" in name else 4), 131072
         cfg = Config.from_kwargs(sparse_method="quest", sink_keep_tokens=64, decode_keep_tokens=4096, recent_keep_tokens=512,
                                  max_model_len=ctx + 256, max_num_seqs_in_gpu=B, num_kvcache_slots=B * (ctx + 256), **QWEN)
         drv = SparseDecodeDriver(cfg)
@@ -75,11 +77,11 @@ def algorithmic_bytes_per_step(name: str, info: dict, mean_row_len: float | None
     B, L = info["batch"], 28
     if name.startswith("h2o"):
         return B * L * float(mean_row_len) * 2056
-    if name == "streamingllm":
+    if name.startswith("streamingllm"):
         return B * L * float(mean_row_len) * 2052
     if name == "vanilla":
         return B * L * float(info["context"]) * 2052
-    if name in ("quest", "quest_b8"):
+    if name.startswith("quest"):
         ctx, budget = info["context"], info["token_budget"]
         return B * ((L - 2) * (ctx * 128 + budget * 2056) + 2 * ctx * 2052)
     if name in ("deltakv", "deltakv_raw", "deltakv_b4"):
@@ -203,7 +205,7 @@ def measure(name: str, *, steps: int = 32, warmup: int = 4, graph: bool = True, 
         drv, info = build_h2o(int(name[5:]))
     else:
         drv, info = build(name)
-    if name == "streamingllm":
+    if name.startswith("streamingllm"):
         steps = max(int(steps), 576)
     q, k, v = drv.random_step_inputs(seed=1)
     if graph:
