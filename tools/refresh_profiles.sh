@@ -24,6 +24,7 @@ for b in 64 128 512; do timeout 400 python3 "$R/bench.py" --batch $b --no-cpu-ba
 # other configurations
 timeout 600 python3 "$R/tools/pathbench.py" --graph < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_graph.jsonl"
 timeout 600 python3 "$R/tools/pathbench.py" < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_eager.jsonl"
+timeout 900 python3 "$R/tools/pathbench.py" --graph --configs h2o_b64,h2o_b8,h2o_b1,streamingllm_b1,quest_b1,quest_b8,deltakv_b4 < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_points.jsonl"
 for c in streamingllm quest quest_b8 deltakv_raw deltakv deltakv_b4 vanilla h2o_b1; do
   stats paths/${c}_kernel_stats.csv python3 "$R/tools/pathbench.py" --graph --configs $c --steps 20
 done
