@@ -155,8 +155,15 @@ class DeltaKVCacheManager(CacheManager):
         self._deltakv_decode_static_slot_mapping = None
         self._deltakv_decode_static_active_pos = None
         self._pending_raw_store: dict[int, tuple] = {}   # layer -> (k, v) whose store rides in the materialise launch
+        self._reset_prefill_staging()
 
     # ------------------------------------------------------------------ configuration helpers
+    def _reset_prefill_staging(self):
+        self._deltakv_prefill_staging_active = False
+        self._deltakv_prefill_staging_active_slots = None
+        self._deltakv_prefill_staging_req_indices = None
+        self._deltakv_prefill_staging_context_lens = None
+
     def _full_layer_kivi_enabled(self) -> bool:
         return bool(self.config.enable_full_layer_kivi_quant) and int(self.config.full_layer_kv_quant_bits or 0) == 4
 
@@ -335,24 +342,58 @@ class DeltaKVCacheManager(CacheManager):
     def on_forward_end(self, seqs, is_prefill: bool):
         self._join_recon_stream()
         self._flush_pending_raw_stores()
+        self._reset_prefill_staging()
         return super().on_forward_end(seqs, is_prefill)
 
-    prefill_attention_view_supported = False
     # every position below a row's length is mapped on the full layers (a raw slot or a KIVI block: `_prepare_prefill`,
     # `prepare_decode_static` and `_full_layer_kivi_evict` keep full_layer_slots_map / ..._kivi_block_slots_map a partition
     # of [0, len)), so the observation layers' raw-score launch writes every position the score kernels read
     # (SparseController._get_decode_attn_score_buffer)
     decode_scores_cover_rows = True
 
+    # ------------------------------------------------------------------ prompt-side attention view
+    @property
+    def prefill_attention_view_supported(self) -> bool:
+        """Whether THIS prefill step has a prompt-side attention view: first-prefill steps do (below), continuation
+        chunks do not (their sparse layers would need the reconstructed view, deltakv_base.py:936-972)."""
+        return bool(self._deltakv_prefill_staging_active)
+
+    def has_prefill_staging_view(self, layer_idx: int) -> bool:
+        """deltakv_base.py:1020-1024."""
+        return bool(self._deltakv_prefill_staging_active and layer_idx in self.deltakv_layer_to_idx)
+
+    def get_prefill_staging_view(self, layer_idx: int):
+        """deltakv_base.py:1026-1037 -> (active_slots, req_indices, context_lens, temp_slots)."""
+        if not self.has_prefill_staging_view(layer_idx):
+            raise NotImplementedError("DeltaKV prefill staging view is not active for this layer.")
+        return (self._deltakv_prefill_staging_active_slots, self._deltakv_prefill_staging_req_indices,
+                self._deltakv_prefill_staging_context_lens, None)
+
+    def get_prefill_compute_view(self, layer_idx: int, k_current, v_current, selection, active_slots, req_indices,
+                                 context_lens):
+        """deltakv_base.py:904-934.  A first-prefill step attends the chunk's own post-RoPE K/V (`k_current`,
+        `v_current`: the staging view's slots are positions in the step's token order); the full layers of such a step
+        hold the whole row raw (no KIVI block exists before the chunk-end eviction), so their slot table is the view."""
+        if self.has_prefill_staging_view(layer_idx):
+            return k_current, v_current, active_slots, req_indices, context_lens
+        if layer_idx in self.full_layer_to_idx and self._deltakv_prefill_staging_active:
+            k_cache, v_cache = self.get_layer_kv_cache(layer_idx)
+            return k_cache, v_cache, active_slots, req_indices, context_lens
+        raise NotImplementedError
+
     def build_prefill_compute_view(self, layer_idx: int, k_current, v_current, selection):
-        """The prompt-side attention of DeltaKV runs over a reconstructed, RoPE-rotated staging view
-        (deltakv_base.py:936-972 `build_prefill_compute_view` -> `deltakv_reconstruct(chunk_lens=...)` and the prefill
-        staging caches), which is outside this build ("prefill staging ... OOS").  The plain slot
-        table is NOT that view: sparse layers hold pre-RoPE keys, evicted positions map to slot -1 and the KIVI prefix
-        of the full layers is int4 - so refuse instead of computing attention over the wrong bytes."""
+        """deltakv_base.py:936-972.  Built here: the FIRST prefill step of a prompt (every row starts at length 0 -
+        the reference's "full prefill" staging, deltakv_base.py:1852-1993: the sparse layers attend the step's own K/V
+        through a staging slot view, the pre-RoPE rows go to the raw slots for the chunk-end compression).  Not built:
+        continuation chunks, whose sparse layers attend a reconstructed, RoPE-rotated view
+        (`deltakv_reconstruct(chunk_lens=...)`; SURVEY.md section 2 marks it out of scope) and whose full layers have an
+        int4 KIVI prefix - the plain slot table is NOT that view (pre-RoPE keys, slot -1 holes), so those are refused
+        instead of computing attention over the wrong bytes."""
+        if self._deltakv_prefill_staging_active:
+            return super().build_prefill_compute_view(layer_idx, k_current, v_current, selection)
         raise NotImplementedError(
-            "DeltaKV prefill attention needs the reconstructed prefill compute view, which this build does not have; "
-            "prefill_chunk(..., outputs=None) runs the store / compression side of the prompt only "
+            "DeltaKV prefill attention of a continuation chunk needs the reconstructed prefill compute view, which this "
+            "build does not have; prefill_chunk(..., outputs=None) runs the store / compression side of the chunk only "
             f"(layer={int(layer_idx)}).")
 
     def _join_recon_stream(self):
@@ -434,12 +475,15 @@ class DeltaKVCacheManager(CacheManager):
         that left the residual window - the prompt's compressed state is produced by the same operators as in decode.
         -> (cu_seqlens_q int32 [B + 1], total tokens)"""
         self._deltakv_reset_view_cache()
+        self._reset_prefill_staging()
         d = self.device
         chunk_lens = [int(s.current_chunk_size) for s in seqs]
         rows, ctx, full_parts, sparse_parts = [], [], [], []
+        first_prefill = True
         for s, n in zip(seqs, chunk_lens):
             row = self._get_free_row(s.seq_id)
             cur = int(self.row_seq_lens[row])
+            first_prefill = first_prefill and cur == 0
             if n <= 0:
                 raise ValueError(f"DeltaKV prefill chunk must be positive, got {n} for seq_id={s.seq_id}.")
             if cur + n > self.max_model_len:
@@ -466,6 +510,16 @@ class DeltaKVCacheManager(CacheManager):
         self._deltakv_decode_static_slot_mapping = None
         self._deltakv_decode_static_compressed_lens = None
         cu = np.concatenate(([0], np.cumsum(chunk_lens))).astype(np.int32)
+        if first_prefill and seqs:
+            # deltakv_base.py:1965-1993: the staging view of a first-prefill step - row b's positions are the tokens
+            # [cu[b], cu[b + 1]) of the step, -1 beyond its chunk
+            table = np.full((len(seqs), max(chunk_lens)), -1, dtype=np.int32)
+            for b, n in enumerate(chunk_lens):
+                table[b, :n] = np.arange(cu[b], cu[b] + n, dtype=np.int32)
+            self._deltakv_prefill_staging_active = True
+            self._deltakv_prefill_staging_active_slots = torch.from_numpy(table).to(d)
+            self._deltakv_prefill_staging_req_indices = torch.arange(len(seqs), dtype=torch.int32, device=d)
+            self._deltakv_prefill_staging_context_lens = context_lens
         return torch.from_numpy(cu).to(d), int(sum(chunk_lens))
 
     def _prepare_decode(self, seqs):
@@ -577,6 +631,7 @@ class DeltaKVCacheManager(CacheManager):
         """deltakv_base.py:2038-2154: one new raw slot per row in each pool, graph-stable metadata buffers."""
         with profiler.record("cache_prepare_decode"):
             self._deltakv_reset_view_cache()
+            self._reset_prefill_staging()
             B = len(seqs)
             if B <= 0:
                 raise ValueError("Static DeltaKV decode requires a non-empty real decode batch.")

@@ -252,12 +252,14 @@ class SparseDecodeDriver:
 
     # ------------------------------------------------------------------ one prefill chunk
     @torch.no_grad()
-    def prefill_chunk(self, seqs, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None):
+    def prefill_chunk(self, seqs, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None,
+                      *, k_raw: torch.Tensor | None = None):
         """The sparse side of one chunked-prefill step (ModelRunner.run prefill branch,
         model_runner.py:1447-1481): allocate the chunk, per layer store its K/V and run `Attention.forward`
         (causal attention of the chunk + the manager's prefill hooks, which collect the method's token scores),
         then the post-forward eviction.  `outputs` [L, tokens, Hq, D] receives the attention outputs.
-        q [L, tokens, Hq, D], k/v [L, tokens, Hkv, D]; every seq needs `current_chunk_size`."""
+        q [L, tokens, Hq, D], k/v [L, tokens, Hkv, D]; every seq needs `current_chunk_size`.  `k_raw` [L, tokens, Hkv, D]:
+        the pre-RoPE keys a model hands to `save_raw_kv_if_needed` (models/qwen2.py:118-125; default: `k`)."""
         cm, sc = self.cache_manager, self.sparse_controller
         out = cm._prepare_prefill(seqs)
         cu = out[0] if isinstance(out, tuple) else None
@@ -269,12 +271,13 @@ class SparseDecodeDriver:
         ctx.seqs = seqs
         sc.prepare_forward(seqs, True)
         save_raw = getattr(cm, "save_raw_kv_if_needed", None)
-        # a manager without a prompt-side attention view in this build (DeltaKV) runs the store / compression side only
+        # a step without a prompt-side attention view in this build (a DeltaKV continuation chunk) runs the store /
+        # compression side only
         run_attention = outputs is not None or bool(getattr(cm, "prefill_attention_view_supported", True))
         for layer_idx in range(cm.num_layers):
             ctx.now_layer_idx = layer_idx
             if save_raw is not None:          # DeltaKV sparse layers keep the pre-RoPE key
-                save_raw(layer_idx, k[layer_idx], v[layer_idx])
+                save_raw(layer_idx, (k if k_raw is None else k_raw)[layer_idx], v[layer_idx])
             # models/qwen2.py:126-131: the model stores the chunk's K/V, then calls the attention layer, whose prefill
             # branch runs the manager's hooks (selection, compute view, attention, score collection) in the reference's order
             cm.save_rope_kv_if_needed(layer_idx, k[layer_idx], v[layer_idx])

@@ -152,16 +152,86 @@ def test_chunked_prompt_reaches_the_same_compressed_length_and_frees_every_slot(
     assert cm.free_slot_stats() == free0
 
 
-def test_prefill_attention_over_the_raw_slot_table_is_refused():
-    """DeltaKV's prompt attention runs over a reconstructed staging view in the reference (deltakv_base.py:936-972),
-    which this build does not have; the plain slot table holds pre-RoPE keys / slot -1 holes, so asking for outputs
-    must fail loudly instead of reading the wrong bytes."""
+def _compressed_state(cm):
+    """Everything the compression side of a prompt leaves behind (slot ids included: same pools, same seeds)."""
+    keys = ("sparse_layer_raw_slots_map", "sparse_layer_latent_slots_map", "full_layer_slots_map", "deltakv_latent_cache",
+            "deltakv_latent_scales", "deltakv_latent_mins", "deltakv_latent_to_full_slots", "deltakv_full_kv_cache",
+            "full_kv_cache", "full_layer_kivi_key_packed", "full_layer_kivi_value_packed", "full_layer_kivi_block_slots_map")
+    out = {}
+    for k in keys:
+        t = getattr(cm, k, None)
+        if isinstance(t, torch.Tensor):
+            out[k] = (t.view(torch.int16) if t.dtype == torch.bfloat16 else t).cpu().numpy().copy()
+    out["lens"] = cm.row_seq_lens.copy()
+    out["clens"] = cm.row_deltakv_compressed_lens.copy()
+    return out
+
+
+@pytest.mark.parametrize("bits,kivi", [(4, True), (0, False)])
+def test_first_prefill_step_attends_the_chunk_through_the_staging_view(bits, kivi):
+    """deltakv_base.py:936-972 / :1852-1993 ("full prefill" staging): in the first prefill step of a prompt the sparse layers
+    attend the step's own post-RoPE K/V through the staging slot view and the full layers their raw rows; the pre-RoPE
+    keys go to the raw slots and the chunk end compresses them.  Two prompts of different lengths in one step: outputs of
+    every layer against the float64 causal attention of the oracle (rtol = atol = 2e-2, the reference's bar), and the
+    compressed state bit-identical to the store-only run of the same prompts (the attention touches nothing)."""
+    from oracle import prefill_attention as opa
+    from sparse_vllm_amd.engine.sequence import Sequence
+    L, Hq, Hkv, D = 4, 8, 2, 64
+    lens = [4 + 8 * 9 + 5, 37]
+    n = sum(lens)
+    g = torch.Generator().manual_seed(21)
+    mk = lambda h: (torch.randn(L, n, h, D, generator=g) * 0.5).to(torch.bfloat16)
+    q, k_rope, k_raw, v = mk(Hq), mk(Hkv), mk(Hkv), mk(Hkv)
+    states = []
+    for with_outputs in (True, False):
+        drv = _driver(bits, kivi, 256)
+        cm = drv.cache_manager
+        cm.permute_free_slots(5)
+        seqs = []
+        for m in lens:
+            s = Sequence(num_prompt_tokens=m)
+            s.current_chunk_size = m
+            seqs.append(s)
+        dev_ = lambda t: t.to(drv.device)
+        out = torch.zeros((L, n, Hq, D), dtype=torch.bfloat16, device=drv.device) if with_outputs else None
+        drv.prefill_chunk(seqs, dev_(q), dev_(k_rope), dev_(v), outputs=out, k_raw=dev_(k_raw))
+        torch.cuda.synchronize()
+        assert not cm.prefill_attention_view_supported           # the staging view lives for one step
+        states.append(_compressed_state(cm))
+        if with_outputs:
+            cu = np.concatenate(([0], np.cumsum(lens)))
+            table = np.full((2, max(lens)), -1, dtype=np.int64)
+            for b, m in enumerate(lens):
+                table[b, :m] = np.arange(cu[b], cu[b] + m)
+            for l in range(L):
+                ref = opa.context_attention_dense(f32(q[l]), f32(k_rope[l]), f32(v[l]), np.arange(2), cu[:2], np.array(lens),
+                                                  np.zeros(2, np.int64), table)
+                np.testing.assert_allclose(f32(out[l]), ref, rtol=2e-2, atol=2e-2, err_msg=f"layer {l}")
+            row = cm.seq_id_to_row[seqs[0].seq_id]
+            assert int(cm.row_deltakv_compressed_lens[row]) == 64       # ... and the chunk end still compressed the prompt
+    for key in states[0]:
+        np.testing.assert_array_equal(states[0][key], states[1][key], err_msg=key)
+
+
+def test_prefill_attention_of_a_continuation_chunk_is_refused():
+    """A continuation chunk's sparse layers attend a reconstructed, RoPE-rotated view in the reference
+    (deltakv_base.py:936-972 -> deltakv_reconstruct(chunk_lens=...)), which this build does not have; the plain slot table
+    holds pre-RoPE keys / slot -1 holes, so asking for its outputs must fail loudly instead of reading the wrong bytes.
+    The first chunk of the same prompt does have a view (the staging view above)."""
     from sparse_vllm_amd.engine.sequence import Sequence
     drv = _driver(4, True, 256)
-    seq = Sequence(num_prompt_tokens=40)
+    seq = Sequence(num_prompt_tokens=80)
     seq.current_chunk_size = 40
     g = torch.Generator().manual_seed(1)
     mk = lambda h: (torch.randn(4, 40, h, 64, generator=g) * 0.5).to(torch.bfloat16).to(drv.device)
     q, k, v = mk(8), mk(2), mk(2)
+    drv.prefill_chunk([seq], q, k, v, outputs=torch.zeros_like(q))
+    seq.current_chunk_size = 40
     with pytest.raises(NotImplementedError, match="reconstructed prefill compute view"):
         drv.prefill_chunk([seq], q, k, v, outputs=torch.zeros_like(q))
+    drv2 = _driver(4, True, 256)
+    seq2 = Sequence(num_prompt_tokens=80)
+    seq2.current_chunk_size = 40
+    drv2.prefill_chunk([seq2], q, k, v)                      # store-only: fine
+    seq2.current_chunk_size = 40
+    drv2.prefill_chunk([seq2], q, k, v)
