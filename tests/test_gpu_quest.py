@@ -96,7 +96,8 @@ def test_score_pages_and_view_golden(golden):
 @pytest.mark.parametrize("dist", ["normal", "normal_bf16", "uniform_one_binade", "narrow", "all_equal", "two_values",
                                   "with_neg_inf", "tiny_probabilities"])
 @pytest.mark.parametrize("shape", [dict(n_prev=8191, prev_budget=291), dict(n_prev=2047, prev_budget=255),
-                                   dict(n_prev=20000, prev_budget=1023), dict(n_prev=700, prev_budget=699)])
+                                   dict(n_prev=20000, prev_budget=1023), dict(n_prev=700, prev_budget=699),
+                                   dict(n_prev=8193, prev_budget=291), dict(n_prev=32768, prev_budget=4000)])
 def test_build_view_selection_exact_over_score_distributions(dist, shape):
     """The page top-k of `svk_quest_build_view` == the first prev_budget entries of a stable descending argsort, as a
     set written in ascending page order, for score rows that drive the select through each of its routes: a handful
