@@ -280,15 +280,17 @@ __device__ __forceinline__ void select_ordered_emit(KeyAt key_at, int n, uint32_
 // (threshold half: T = the k-th key, kk = how many keys equal to T are taken)
 // `hist16` (optional): 32 768 words of LDS, blockDim.x == 1024.  Keys that differ in their 16 high bits only (bf16-valued
 // scores: Quest page scores) are then counted by that whole 16-bit digit in ONE pass of LDS atomics spread over thousands
-// of bins, and the threshold is read off a block scan of the 1024 segment sums + a wave scan of the segment's 64 bins -
+// of bins, and the threshold is read off a block scan of the 1024 segment sums + a wave scan of the
+// segment's 64 bins -
 // instead of a pass per 8-bit digit whose first digit (sign + 7 exponent bits) piles a row's keys onto a handful of
 // bins (8191 keys: ~4 us for that pass alone, ~1.5 us for the next).
 template <int CH>
 __device__ __forceinline__ void select_owned_threshold(const uint32_t (&key)[CH], int per, int n, int k, SelectScratch& S,
                                                        uint32_t& T_out, int& kk_out, uint32_t* hist16 = nullptr) {
   const int base = threadIdx.x * per;
-  if (hist16 != nullptr)                                        // (cleared under the barriers of the OR / AND reduction)
-    for (int i = threadIdx.x * 4; i < 32768; i += blockDim.x * 4) *reinterpret_cast<uint4*>(hist16 + i) = make_uint4(0u, 0u, 0u, 0u);
+  if (hist16 != nullptr)                   // cleared under the loads and the barriers of the OR / AND reduction (used or not:
+    for (int i = threadIdx.x * 4; i < 32768; i += blockDim.x * 4)      //  clearing it after the decision costs 0.8 us more)
+      *reinterpret_cast<uint4*>(hist16 + i) = make_uint4(0u, 0u, 0u, 0u);
   select_bits_begin(S);
   uint32_t o = 0u, an = 0xffffffffu;
 #pragma unroll
@@ -301,7 +303,11 @@ __device__ __forceinline__ void select_owned_threshold(const uint32_t (&key)[CH]
   const uint32_t varying = S.or_bits ^ all_and;
   uint32_t prefix = all_and;
   int kk = k;
-  if (hist16 != nullptr && varying != 0u && (varying & 0xffffu) == 0u && n < 65536 && blockDim.x == 1024) {
+  // (only when the 8-bit digits would need two passes or more: keys that differ in <= 8 bit positions - real page
+  //  scores are positive and sit in a narrow band of bf16 values - are settled by ONE 8-bit pass, 1.6 us, while their few
+  //  hundred distinct values would pile onto as many of the 65 536 bins: 3.0 us of atomics + the 1.5 us scan)
+  if (hist16 != nullptr && varying != 0u && (varying & 0xffffu) == 0u && n < 65536 && blockDim.x == 1024 &&
+      (31 - __builtin_clz(varying)) - __builtin_ctz(varying) >= 8) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = 16;
 #pragma unroll
     for (int j = 0; j < CH; ++j)

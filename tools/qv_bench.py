@@ -25,6 +25,18 @@ torch.manual_seed(0)
 scores = torch.randn(B, n_prev, device=d) * 3
 if mode == "bf16":
     scores = scores.bfloat16().float()
+elif mode == "pages":
+    # real page scores: svk_quest_score_pages over random min / max metadata (all positive, a narrow band of bf16 values)
+    Hq, Hkv, D = 28, 4, 128
+    pool = pages * B + 7
+    mx = (torch.randn(pool, Hkv, D, device=d) * 0.5 + 1).bfloat16()
+    mn = (torch.randn(pool, Hkv, D, device=d) * 0.5 - 1).bfloat16()
+    qq = (torch.randn(B, Hq, D, device=d) * 0.5).bfloat16()
+    pt = torch.stack([torch.randperm(pool, device=d)[:pages] for _ in range(B)]).to(torch.int32)
+    quest_ops.score_pages(qq, mx, mn, pt, torch.arange(B, dtype=torch.int32, device=d),
+                          torch.full((B,), ctx - 3, dtype=torch.int32, device=d), scores, page_size=ps, n_prev=n_prev)
+    torch.cuda.synchronize()
+    print("distinct values per row:", [int(torch.unique(scores[b]).numel()) for b in range(B)], "min/max", float(scores.min()), float(scores.max()))
 ptab = torch.stack([torch.randperm(pages * B, device=d)[:pages] for _ in range(B)]).to(torch.int32)
 ttab = torch.zeros(B, ctx, dtype=torch.int32, device=d)
 req = torch.arange(B, dtype=torch.int32, device=d)
