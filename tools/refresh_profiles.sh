@@ -36,7 +36,7 @@ timeout 300 python3 "$R/tools/kbench_kivi.py" --batches 1,4 --block-seqs 1024,23
 timeout 300 python3 "$R/tools/kbench_kivi.py" --batches 1,4 --block-seqs 1024,2304 --sink 0 --tail 0 < /dev/null 2>/dev/null | grep kivi > "$O/paths/kbench_kivi_no_raw.txt"
 timeout 300 python3 "$R/tools/kbench_quest.py" < /dev/null 2>/dev/null | grep quest > "$O/paths/kbench_quest.txt"
 timeout 300 python3 "$R/tools/kbench_quest.py" --batch 1 < /dev/null 2>/dev/null | grep quest >> "$O/paths/kbench_quest.txt"
-for v in "bf16 paged" "bf16" "normal paged"; do timeout 120 python3 "$R/tools/qv_bench.py" 131072 4 4672 $v < /dev/null 2>/dev/null | grep "per launch" >> "$O/paths/kbench_quest_view.txt"; done
+for v in "pages paged" "bf16 paged" "bf16" "normal paged"; do timeout 120 python3 "$R/tools/qv_bench.py" 131072 4 4672 $v < /dev/null 2>/dev/null | grep "per launch" >> "$O/paths/kbench_quest_view.txt"; done
 timeout 120 python3 "$R/tools/qv_bench.py" 131072 8 4672 bf16 paged < /dev/null 2>/dev/null | grep "per launch" >> "$O/paths/kbench_quest_view.txt"
 timeout 300 python3 "$R/tools/kbench.py" --graph-pair --batches 4,8 --len 4672 --block-seqs 64,96,128,160,256 --iters 40 < /dev/null 2>/dev/null | grep graph > "$O/paths/kbench_stage1_stage2_short_rows.txt"
 timeout 300 python3 "$R/tools/kbench_prefill.py" < /dev/null 2>/dev/null | grep prefill > "$O/paths/kbench_prefill.txt"
