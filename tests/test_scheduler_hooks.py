@@ -100,6 +100,9 @@ def test_mi355x_decode_launch_geometry():
     assert cfg(14, 2, 256, 4224) == 2112           # two waves per workgroup -> 512 workgroups
     assert cfg(7, 1, 256, 4224) == 1056            # one wave per workgroup -> 1024 workgroups
     assert cfg(7, 1, 64, 4224) == 272
+    assert cfg(28, 4, 4, 4672) == 96               # short blocks are whole 32-token tiles (Quest view: 73 -> 80 -> 96)
+    assert cfg(28, 4, 8, 4672) == 160
+    assert cfg(28, 4, 64, 1152) == 288
     for hkv in (1, 2, 4, 8):
         assert cfg(8 * hkv // hkv * hkv if hkv > 1 else 7, hkv, 16, 8192) % 16 == 0
     other = DeviceCaps(platform=PlatformEnum.ROCM, arch="gfx942", num_cus=304)
