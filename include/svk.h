@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 14
+#define SVK_ABI_VERSION 15
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -620,6 +620,15 @@ typedef struct SvkDeltakvReconstructArgs {
   const int32_t* father_table;     /* NULL or [latents, K]                                                       */
   const int32_t* father_index;     /* [N] latent slot per entry (may be -1)                                      */
   int64_t father_table_stride;
+  /* MI355X (dense bf16 delta, 16-byte form): when out_k_cache != NULL the reconstructed rows are written THERE instead
+   * of into k_cache / v_cache - entry n goes to row (n / out_entries_per_row) * out_view_width + out_view_offset +
+   * n % out_entries_per_row, i.e. straight into its place in the layer's attention view (the [sink | K selected |
+   * tail] layout of the static decode plan; svk_deltakv_materialize_sparse_view then skips those rows: skip_temp).
+   * out_slots[n] < 0 still marks an entry that reconstructs nothing. */
+  uint16_t* out_k_cache;           /* NULL or [rows, Hkv, D] bf16 (out_slot_stride / out_head_stride)            */
+  uint16_t* out_v_cache;
+  int64_t out_slot_stride, out_head_stride;
+  int32_t out_view_width, out_view_offset, out_entries_per_row, _pad1;
 } SvkDeltakvReconstructArgs;
 int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs* a, svk_stream_t stream);
 /* The dense-delta decode form for `n_batch` layers in one launch (same plan: out_slots / out_pos / father_index shared;
@@ -627,6 +636,7 @@ int svk_deltakv_reconstruct_writeback(const SvkDeltakvReconstructArgs* a, svk_st
 typedef struct SvkDeltakvReconstructBatch {
   int32_t n_batch;
   int64_t delta_stride_batch, father_table_stride_batch, kv_cache_stride_batch, k_norm_stride_batch;
+  int64_t out_cache_stride_batch;  /* elements between the layers' out_k_cache / out_v_cache                     */
 } SvkDeltakvReconstructBatch;
 int svk_deltakv_reconstruct_writeback_batched(const SvkDeltakvReconstructArgs* first, const SvkDeltakvReconstructBatch* b,
                                               svk_stream_t stream);
@@ -706,6 +716,9 @@ typedef struct SvkDeltakvMaterializeArgs {
   const uint16_t* new_v;
   const int32_t* new_slots;        /* NULL or [batch]                                         */
   int64_t new_token_stride, new_head_stride;
+  /* MI355X: 1 = the entries recognised as this step's reconstruct scratch (temp_slots) are NOT copied: the
+   * reconstruction wrote them into out_k / out_v itself (SvkDeltakvReconstructArgs.out_k_cache) */
+  int32_t skip_temp, _pad0;
 } SvkDeltakvMaterializeArgs;
 int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeArgs* a, svk_stream_t stream);
 

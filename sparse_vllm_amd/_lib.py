@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 14
+SVK_ABI_VERSION = 15
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -164,7 +164,7 @@ class SvkDequantLinearBatch(C.Structure):
 
 class SvkDeltakvReconstructBatch(C.Structure):
     _fields_ = [("n_batch", C.c_int32), ("delta_stride_batch", C.c_int64), ("father_table_stride_batch", C.c_int64),
-                ("kv_cache_stride_batch", C.c_int64), ("k_norm_stride_batch", C.c_int64)]
+                ("kv_cache_stride_batch", C.c_int64), ("k_norm_stride_batch", C.c_int64), ("out_cache_stride_batch", C.c_int64)]
 
 
 class SvkDeltakvDecodeAllocArgs(C.Structure):
@@ -193,7 +193,9 @@ class SvkDeltakvReconstructArgs(C.Structure):
                 ("k_norm_eps", _f32), ("n", _i32), ("k_fathers", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
                 ("delta_bits", _i32), ("group_size", _i32), ("delta_dtype", _i32), ("scale_dtype", _i32),
                 ("cos_dtype", _i32), ("raw_k_cache", _i32), ("store_raw_k", _i32),
-                ("father_table", _p), ("father_index", _p), ("father_table_stride", _i64)]
+                ("father_table", _p), ("father_index", _p), ("father_table_stride", _i64),
+                ("out_k_cache", _p), ("out_v_cache", _p), ("out_slot_stride", _i64), ("out_head_stride", _i64),
+                ("out_view_width", _i32), ("out_view_offset", _i32), ("out_entries_per_row", _i32), ("_pad1", _i32)]
 
 
 class SvkDequantGroupedArgs(C.Structure):
@@ -231,7 +233,8 @@ class SvkDeltakvMaterializeArgs(C.Structure):
                [("k_norm_eps", _f32)] + \
                [(n, _i32) for n in ("batch", "width", "num_slots", "num_kv_heads", "head_dim", "cos_dtype")] + \
                [("temp_slots", _p), ("temp_stride", _i64), ("temp_offset", _i32), ("temp_count", _i32)] + \
-               [("new_k", _p), ("new_v", _p), ("new_slots", _p), ("new_token_stride", _i64), ("new_head_stride", _i64)]
+               [("new_k", _p), ("new_v", _p), ("new_slots", _p), ("new_token_stride", _i64), ("new_head_stride", _i64)] + \
+               [("skip_temp", _i32), ("_pad0", _i32)]
 
 
 class SvkContextAttentionArgs(C.Structure):

@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(256) deltakv_reconstruct_vec_kernel(const SvkD
     a.k_cache += z * lb.kv_cache_stride_batch;
     a.v_cache += z * lb.kv_cache_stride_batch;
     if (a.k_norm_weight != nullptr) a.k_norm_weight += z * lb.k_norm_stride_batch;
+    if (a.out_k_cache != nullptr) { a.out_k_cache += z * lb.out_cache_stride_batch; a.out_v_cache += z * lb.out_cache_stride_batch; }
   }
   constexpr int HD2 = D / 2, LPH = HD2 / 8;
   const int H = a.num_kv_heads;
@@ -298,11 +299,19 @@ __global__ void __launch_bounds__(256) deltakv_reconstruct_vec_kernel(const SvkD
     return make_uint4(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16), f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16),
                       f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16), f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16));
   };
-  const int64_t ob = (int64_t)out_slot * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
-  *reinterpret_cast<uint4*>(a.k_cache + ob) = pk8(o1);
-  *reinterpret_cast<uint4*>(a.k_cache + ob + HD2) = pk8(o2);
-  *reinterpret_cast<uint4*>(a.v_cache + ob) = pk8(v1);
-  *reinterpret_cast<uint4*>(a.v_cache + ob + HD2) = pk8(v2);
+  uint16_t* ok = a.k_cache;
+  uint16_t* ov = a.v_cache;
+  int64_t ob = (int64_t)out_slot * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
+  if (a.out_k_cache != nullptr) {                       // straight into the entry's row of the attention view
+    const int64_t row = (int64_t)(n / a.out_entries_per_row) * a.out_view_width + a.out_view_offset + n % a.out_entries_per_row;
+    ok = a.out_k_cache;
+    ov = a.out_v_cache;
+    ob = row * a.out_slot_stride + (int64_t)h * a.out_head_stride + p;
+  }
+  *reinterpret_cast<uint4*>(ok + ob) = pk8(o1);
+  *reinterpret_cast<uint4*>(ok + ob + HD2) = pk8(o2);
+  *reinterpret_cast<uint4*>(ov + ob) = pk8(v1);
+  *reinterpret_cast<uint4*>(ov + ob + HD2) = pk8(v2);
 }
 
 // ------------------------------------------------------------------------------------
@@ -875,6 +884,15 @@ int launch_reconstruct(const SvkDeltakvReconstructArgs* a, const SvkDeltakvRecon
                 "svk_deltakv_reconstruct_writeback: packed residuals need latent_slots, scale and mn");
   }
   if (a->n <= 0) return SVK_OK;
+  if (a->out_k_cache != nullptr) {
+    SVK_REQUIRE(a->out_v_cache != nullptr && a->out_entries_per_row > 0 && a->out_view_width >= a->out_view_offset + a->out_entries_per_row &&
+                    a->out_view_offset >= 0 && a->out_slot_stride % 8 == 0 && a->out_head_stride % 8 == 0 &&
+                    reinterpret_cast<uintptr_t>(a->out_k_cache) % 16 == 0 && reinterpret_cast<uintptr_t>(a->out_v_cache) % 16 == 0,
+                SVK_ERR_LAYOUT, "svk_deltakv_reconstruct_writeback: bad view destination (width %d, offset %d, entries per row %d)",
+                a->out_view_width, a->out_view_offset, a->out_entries_per_row);
+    SVK_REQUIRE(lb.n_batch == 1 || lb.out_cache_stride_batch % 8 == 0, SVK_ERR_LAYOUT,
+                "svk_deltakv_reconstruct_writeback_batched: per-layer view stride must keep 16-byte alignment");
+  }
   // decode path: dense bf16 delta, fp32 cos|sin, 16-byte aligned rows -> 16-byte lanes
   if (a->delta_bits == 0 && a->delta_dtype == SVK_DTYPE_BF16 && a->cos_dtype == SVK_DTYPE_F32 && (a->head_dim == 64 || a->head_dim == 128) &&
       a->num_kv_heads <= 8 && a->delta_stride % 8 == 0 && a->kv_slot_stride % 8 == 0 && a->kv_head_stride % 8 == 0 && a->cos_stride % 4 == 0 &&
@@ -887,6 +905,7 @@ int launch_reconstruct(const SvkDeltakvReconstructArgs* a, const SvkDeltakvRecon
     return check_launch("svk_deltakv_reconstruct_writeback");
   }
   SVK_REQUIRE(lb.n_batch == 1, SVK_ERR_LAYOUT, "svk_deltakv_reconstruct_writeback_batched: only the dense bf16 16-byte form is batched");
+  SVK_REQUIRE(a->out_k_cache == nullptr, SVK_ERR_LAYOUT, "svk_deltakv_reconstruct_writeback: the view destination needs the dense bf16 16-byte form");
   int threads = per_entry;
   if (threads < 256) threads = (256 / per_entry) * per_entry;
   const int epb = threads / per_entry;

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
   float k1[8], k2[8];
   uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1, rk1 = v1, rk2 = v1;
   int pos = 0;
-  bool copy = false;
+  bool copy = false, skip = false;
   if (a.new_slots != nullptr && tl < tokens_per_block && n >= total && n - total < a.batch) {
     // the blocks behind the view: this step's raw rows into the cache (what store_kvcache did in a launch of its own)
     const int b = (int)(n - total);
@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
     if (a.temp_slots != nullptr) {
       const int j = w - a.temp_offset;
       copy = valid && j >= 0 && j < a.temp_count && a.temp_slots[(int64_t)b * a.temp_stride + j] == slot;
+      skip = copy && a.skip_temp != 0;          // the reconstruction wrote this row of the view itself
     }
     const uint16_t* ks = a.k_cache;
     const uint16_t* vs = a.v_cache;
@@ -79,10 +80,12 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
       vs = a.new_v;
       base = (int64_t)b * a.new_token_stride + (int64_t)h * a.new_head_stride + p;
     }
-    rk1 = *reinterpret_cast<const uint4*>(ks + base);
-    rk2 = *reinterpret_cast<const uint4*>(ks + base + HD2);
-    v1 = *reinterpret_cast<const uint4*>(vs + base);
-    v2 = *reinterpret_cast<const uint4*>(vs + base + HD2);
+    if (!skip) {
+      rk1 = *reinterpret_cast<const uint4*>(ks + base);
+      rk2 = *reinterpret_cast<const uint4*>(ks + base + HD2);
+      v1 = *reinterpret_cast<const uint4*>(vs + base);
+      v2 = *reinterpret_cast<const uint4*>(vs + base + HD2);
+    }
   }
   unpack8(rk1, k1);
   unpack8(rk2, k2);
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
       n2[e] = k2[e] * rstd * a.k_norm_weight[p + HD2 + e];
     }
   }
-  if (!live) return;
+  if (!live || skip) return;
   uint4 o1 = rk1, o2 = rk2;
   if (!copy) {
     float c[8], s[8], r1[8], r2[8];

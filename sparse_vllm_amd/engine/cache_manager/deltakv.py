@@ -225,6 +225,13 @@ class DeltaKVCacheManager(CacheManager):
         width = sink + keep + self._deltakv_decode_static_max_buffer()
         self.deltakv_materialized_compute_num_slots = rows * width
         self.deltakv_materialized_kv_cache = torch.zeros((2, rows * width, H, D), dtype=bf, device=d)
+        # MI355X: the static-decode reconstruction writes its rows straight into the layer's attention view (include/svk.h
+        # `out_k_cache`) - the view kernel then copies the ~150 raw rows only, not the 2048 reconstructed ones out of the
+        # scratch slots.  Every sparse layer owns a view for that (the look-ahead reconstruction of the layers behind
+        # runs while a layer attends): allocated on first use.  False = scratch slots + full copy (the reference's flow).
+        self.recon_into_view = bool(self._RECON_INTO_VIEW_DEFAULT)
+        self._layer_views: torch.Tensor | None = None
+        self._recon_view_layers: set[int] = set()      # sparse layers (l_idx) whose reconstructed rows of this plan are in their view
         self._deltakv_postrope_slot_mask = torch.zeros((Ls, n_sparse), dtype=torch.bool, device=d)
         bits = int(cfg.kv_quant_bits or 0)
         payload = self._sparse_payload_dim()
@@ -814,6 +821,32 @@ class DeltaKVCacheManager(CacheManager):
             residual = self.deltakv_latent_cache[l_idx, recon_latent.clamp_min(0).long()]
         return self.compress_up[l_idx](residual)
 
+    def _recon_view_geometry(self, active_slots: torch.Tensor, recon_latent: torch.Tensor):
+        """(view width, first column of the selected block, entries per batch row) when the reconstruction can write into
+        the views (int4 latents through the fused two-Linear compress_up: a dense bf16 delta), else None."""
+        if not self.recon_into_view or int(self.config.kv_quant_bits or 0) != 4 or active_slots.dim() != 2:
+            return None
+        ok = self.__dict__.get("_recon_view_ok")
+        if ok is None:
+            ok = self._recon_view_ok = all(
+                (p := self._fused_up_parts(self.compress_up[i], self.deltakv_latent_cache[i])) is not None and p[1].bias is not None
+                for i in range(len(self.compress_up)))
+        B = int(active_slots.shape[0])
+        if not ok or B <= 0 or int(recon_latent.numel()) % B != 0:
+            return None
+        return int(active_slots.shape[1]), int(self.config.num_sink_tokens), int(recon_latent.numel()) // B
+
+    def _recon_view_out(self, l0: int, l1: int, geom):
+        """(out_k [l1 - l0, rows, Hkv, D], out_v, width, offset, entries per row) of the sparse layers [l0, l1), or None."""
+        if not self.recon_into_view or geom is None:
+            return None
+        if self._layer_views is None:
+            Ls = len(self.deltakv_layer_ids)
+            self._layer_views = torch.zeros((2, Ls, int(self.deltakv_materialized_compute_num_slots), self.num_kv_heads,
+                                             self.head_dim), dtype=torch.bfloat16, device=self.device)
+        width, offset, per_row = geom
+        return self._layer_views[0, l0:l1], self._layer_views[1, l0:l1], width, offset, per_row
+
     def _recon_lookahead_buffers(self, l_idx: int, n: int):
         """Caller-owned (hidden, delta) buffers of one sparse layer for the look-ahead reconstruction, or None when the
         layer's compress_up is not the fused two-Linear form."""
@@ -831,10 +864,13 @@ class DeltaKVCacheManager(CacheManager):
             store[l_idx] = cur
         return cur[0][:n], cur[1][:n]
 
-    def _reconstruct_layer(self, l_idx: int, recon_pos, recon_latent, recon_out_slot, bufs=None):
+    def _reconstruct_layer(self, l_idx: int, recon_pos, recon_latent, recon_out_slot, bufs=None, view_geom=None):
         k_cache, v_cache = self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx]
         with profiler.record("deltakv_less_memory_reconstruct_load_residual"):
             kv_delta = self._load_residual(l_idx, recon_latent, bufs)
+        view = self._recon_view_out(l_idx, l_idx + 1, view_geom) if kv_delta.dtype == torch.bfloat16 else None
+        if view is not None:
+            self._recon_view_layers.add(int(l_idx))
         with profiler.record("deltakv_less_memory_reconstruct_writeback"):
             # fathers = latent_to_full_slots[l, recon_latent.clamp_min(0)].clamp_min(0), resolved in-kernel
             dk.deltakv_reconstruct_writeback_grouped_heads(
@@ -842,7 +878,8 @@ class DeltaKVCacheManager(CacheManager):
                 slot_to_pos=self.deltakv_slot_to_pos,
                 out_slots=recon_out_slot, out_pos=recon_pos, cos_sin=self.cos_sin_cache, k_cache=k_cache,
                 v_cache=v_cache, k_norm_weight=None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx],
-                k_norm_eps=float(self.deltakv_k_norm_eps), raw_k_cache=True, store_raw_k=False)
+                k_norm_eps=float(self.deltakv_k_norm_eps), raw_k_cache=True, store_raw_k=False,
+                view_out=None if view is None else (view[0][0], view[1][0], view[2], view[3], view[4]))
 
     @staticmethod
     def _recon_lookahead_enabled() -> bool:
@@ -858,7 +895,7 @@ class DeltaKVCacheManager(CacheManager):
             l += 1
         return out
 
-    def _reconstruct_group_ahead(self, layer_idx: int, recon_pos, recon_latent, recon_out_slot) -> bool:
+    def _reconstruct_group_ahead(self, layer_idx: int, recon_pos, recon_latent, recon_out_slot, view_geom=None) -> bool:
         """MI355X: the residual load and reconstruction of a sparse layer depend on the plan of its observation group and
         on the layer's own caches, not on the step's activations - so all layers of the group are issued NOW, back to
         back on a side stream (three launches, ~43 us per layer at 2048 tokens), while the main stream walks the layers
@@ -880,7 +917,8 @@ class DeltaKVCacheManager(CacheManager):
         with torch.cuda.stream(side):
             if stack is None or sub <= 1:
                 for l in layers:
-                    self._reconstruct_layer(self.deltakv_layer_to_idx[l], recon_pos, recon_latent, recon_out_slot, bufs[l])
+                    self._reconstruct_layer(self.deltakv_layer_to_idx[l], recon_pos, recon_latent, recon_out_slot, bufs[l],
+                                            view_geom=view_geom)
                     self._recon_event(l).record(side)
             else:
                 # sub-batches of `sub` consecutive layers: one dequant + Linear + GELU launch, one batched GEMM and one
@@ -892,7 +930,7 @@ class DeltaKVCacheManager(CacheManager):
                     chunk = layers[c0: c0 + n_c]
                     c0, ci = c0 + n_c, ci + 1
                     self._reconstruct_layers_batched([self.deltakv_layer_to_idx[l] for l in chunk], stack, recon_pos,
-                                                     recon_latent, recon_out_slot)
+                                                     recon_latent, recon_out_slot, view_geom=view_geom)
                     for l in chunk:
                         self._recon_event(l).record(side)
         self._recon_ahead = {l: True for l in layers}
@@ -905,6 +943,7 @@ class DeltaKVCacheManager(CacheManager):
         return ev
 
     _RECON_SUB_BATCHES = [2]
+    _RECON_INTO_VIEW_DEFAULT = True
 
     @classmethod
     def _recon_sub_batches(cls) -> list[int]:
@@ -943,7 +982,7 @@ class DeltaKVCacheManager(CacheManager):
     _RECON_PAD = 64
     _RECON_GEMM_ROWS = 4096
 
-    def _reconstruct_layers_batched(self, l_idxs, stack, recon_pos, recon_latent, recon_out_slot):
+    def _reconstruct_layers_batched(self, l_idxs, stack, recon_pos, recon_latent, recon_out_slot, view_geom=None):
         """Residual load + reconstruction of consecutive sparse layers `l_idxs` (same plan) in three launches."""
         w1, b1, w2, b2 = stack
         l0, l1 = int(l_idxs[0]), int(l_idxs[-1]) + 1
@@ -971,11 +1010,14 @@ class DeltaKVCacheManager(CacheManager):
             c1 = min(n, c0 + self._RECON_GEMM_ROWS)
             torch.bmm(hp[:, c0:c1], w2[l0:l1].transpose(1, 2), out=delta[:, c0:c1])
         knw = self.deltakv_k_norm_weight
+        view = self._recon_view_out(l0, l1, view_geom)
+        if view is not None:
+            self._recon_view_layers.update(range(l0, l1))
         dk.deltakv_reconstruct_writeback_layers(
             delta, self.deltakv_latent_to_full_slots[l0:l1], recon_latent, self.deltakv_slot_to_pos, recon_out_slot, recon_pos,
             self.cos_sin_cache, self.deltakv_full_kv_cache[0, l0:l1], self.deltakv_full_kv_cache[1, l0:l1],
             k_norm_weight=None if knw is None else knw[l0:l1].float().contiguous(), k_norm_eps=float(self.deltakv_k_norm_eps),
-            raw_k_cache=True, store_raw_k=False)
+            raw_k_cache=True, store_raw_k=False, view_out=view)
 
     @staticmethod
     def _fused_up_parts(up, cache):
@@ -1020,17 +1062,20 @@ class DeltaKVCacheManager(CacheManager):
                 self._deltakv_build_view_and_plan_reconstruct(layer_idx, active_compressed_indices, req_indices)
             fresh_plan = self._deltakv_view_cache_value is not plan_before
             l_idx = self.deltakv_layer_to_idx[layer_idx]
+            if fresh_plan:
+                self._recon_view_layers = set()
             if recon_latent.numel() > 0:
+                geom = self._recon_view_geometry(active_slots, recon_latent)
                 ahead = self.__dict__.get("_recon_ahead") or {}
                 if fresh_plan:
                     ahead = self._recon_ahead = {}
                     if self._recon_lookahead_enabled():
-                        self._reconstruct_group_ahead(layer_idx, recon_pos, recon_latent, recon_out_slot)
+                        self._reconstruct_group_ahead(layer_idx, recon_pos, recon_latent, recon_out_slot, view_geom=geom)
                         ahead = self._recon_ahead
                 if ahead.pop(int(layer_idx), False):
                     torch.cuda.current_stream().wait_event(self._recon_events[int(layer_idx)])
                 else:
-                    self._reconstruct_layer(l_idx, recon_pos, recon_latent, recon_out_slot)
+                    self._reconstruct_layer(l_idx, recon_pos, recon_latent, recon_out_slot, view_geom=geom)
             # static decode: the post-RoPE slots of this layer are exactly the reconstruct scratch slots the plan put
             # into the view, so the attention view identifies them positionally (no per-layer mask maintenance;
             # `_set_postrope_slots` remains for callers that want the reference's mask)
@@ -1060,10 +1105,14 @@ class DeltaKVCacheManager(CacheManager):
         B, W = int(active_slots.shape[0]), int(active_slots.shape[1])
         total = B * W
         local_active, local_req = self._ensure_materialized_sparse_view(B, W)
-        k_out, v_out = self.deltakv_materialized_kv_cache[0, :total], self.deltakv_materialized_kv_cache[1, :total]
+        l_idx = self.deltakv_layer_to_idx[layer_idx]
+        in_view = l_idx in self._recon_view_layers and self._layer_views is not None    # this plan's reconstruction is already there
+        if in_view:
+            k_out, v_out = self._layer_views[0, l_idx, :total], self._layer_views[1, l_idx, :total]
+        else:
+            k_out, v_out = self.deltakv_materialized_kv_cache[0, :total], self.deltakv_materialized_kv_cache[1, :total]
         if total == 0:
             return k_out, v_out, local_active, local_req, context_lens
-        l_idx = self.deltakv_layer_to_idx[layer_idx]
         new_k = new_v = new_slots = None
         pending = self._pending_raw_store.pop(layer_idx, None)
         if pending is not None:
@@ -1080,7 +1129,7 @@ class DeltaKVCacheManager(CacheManager):
                 k_norm_weight=None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx],
                 k_norm_eps=float(self.deltakv_k_norm_eps),
                 temp_slots=self._ensure_decode_static_temp_slots(B, k_max), temp_offset=int(self.config.num_sink_tokens),
-                new_k=new_k, new_v=new_v, new_slots=new_slots)
+                new_k=new_k, new_v=new_v, new_slots=new_slots, skip_temp=in_view)
         return k_out, v_out, local_active, local_req, context_lens
 
     def build_decode_compute_view(self, layer_idx: int, q: torch.Tensor, selection: SparseSelection, *, num_heads: int,

@@ -67,7 +67,8 @@ def deltakv_static_decode_plan(*, raw_slots_map, latent_slots_map, active_compre
 
 
 def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
-                 v_cache, bits, group_size, k_norm_weight, k_norm_eps, raw_k_cache, store_raw_k, father_index=None, batch=None):
+                 v_cache, bits, group_size, k_norm_weight, k_norm_eps, raw_k_cache, store_raw_k, father_index=None, batch=None,
+                 view_out=None):
     assert k_cache.dtype == torch.bfloat16 and k_cache.stride() == v_cache.stride() and k_cache.stride(-1) == 1
     assert father_slots.dim() == 2 and father_slots.dtype == torch.int32 and father_slots.stride(1) == 1
     if father_index is not None:      # father_slots is the [latents, K] table, indexed in-kernel
@@ -91,6 +92,14 @@ def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, o
         scale_dtype=0 if scale is None else _dt(scale), cos_dtype=_dt(cos_sin), raw_k_cache=int(bool(raw_k_cache)),
         store_raw_k=int(bool(store_raw_k)), father_table=_lib.ptr(father_slots) if father_index is not None else None,
         father_index=_lib.ptr(father_index), father_table_stride=father_slots.stride(0))
+    if view_out is not None:
+        # MI355X: the rows go straight into the attention view (include/svk.h `out_k_cache`): (out_k, out_v, view width,
+        # first column of the selected block, entries per batch row)
+        vk, vv, width, offset, per_row = view_out
+        assert vk.dtype == torch.bfloat16 and vk.dim() == 3 and vk.stride() == vv.stride() and vk.stride(2) == 1
+        a.out_k_cache, a.out_v_cache = _lib.ptr(vk), _lib.ptr(vv)
+        a.out_slot_stride, a.out_head_stride = vk.stride(0), vk.stride(1)
+        a.out_view_width, a.out_view_offset, a.out_entries_per_row = int(width), int(offset), int(per_row)
     if batch is not None:
         _lib.check(lib.svk_deltakv_reconstruct_writeback_batched(C.byref(a), C.byref(batch), _lib.current_stream_handle()), lib)
         return
@@ -100,10 +109,11 @@ def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, o
 @torch.no_grad()
 def deltakv_reconstruct_writeback_layers(kv_delta, father_table, father_index, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
                                          v_cache, *, k_norm_weight=None, k_norm_eps: float = 1e-6, raw_k_cache: bool = False,
-                                         store_raw_k: bool = False):
+                                         store_raw_k: bool = False, view_out=None):
     """`deltakv_reconstruct_writeback_grouped_heads` for several layers that share one plan, in ONE launch: kv_delta
     [n_layers, N, 2*Hkv*D] bf16, father_table [n_layers, latents, K], k_cache / v_cache [n_layers, slots, Hkv, D],
-    k_norm_weight None or [n_layers, D] f32; father_index / out_slots / out_pos / slot_to_pos are the plan's."""
+    k_norm_weight None or [n_layers, D] f32; father_index / out_slots / out_pos / slot_to_pos are the plan's.
+    `view_out` = (out_k [n_layers, rows, Hkv, D], out_v, width, offset, entries_per_row): write into the layers' views."""
     nl = int(kv_delta.shape[0])
     assert kv_delta.dim() == 3 and kv_delta.dtype == torch.bfloat16 and kv_delta.stride(2) == 1
     assert father_table.dim() == 3 and father_table.shape[0] == nl and k_cache.dim() == 4 and k_cache.shape[0] == nl
@@ -113,19 +123,29 @@ def deltakv_reconstruct_writeback_layers(kv_delta, father_table, father_index, s
     batch = _lib.SvkDeltakvReconstructBatch(
         n_batch=nl, delta_stride_batch=kv_delta.stride(0), father_table_stride_batch=father_table.stride(0),
         kv_cache_stride_batch=k_cache.stride(0), k_norm_stride_batch=0 if k_norm_weight is None else k_norm_weight.stride(0))
+    view0 = None
+    if view_out is not None:
+        vk, vv, width, offset, per_row = view_out
+        assert vk.dim() == 4 and vk.shape[0] == nl and vk.stride() == vv.stride()
+        batch.out_cache_stride_batch = vk.stride(0)
+        view0 = (vk[0], vv[0], width, offset, per_row)
     _reconstruct(delta=kv_delta[0], scale=None, mn=None, latent_slots=None, father_slots=father_table[0],
                  slot_to_pos=slot_to_pos, out_slots=out_slots, out_pos=out_pos, cos_sin=cos_sin, k_cache=k_cache[0],
                  v_cache=v_cache[0], bits=0, group_size=0, k_norm_weight=None if k_norm_weight is None else k_norm_weight[0],
-                 k_norm_eps=k_norm_eps, raw_k_cache=raw_k_cache, store_raw_k=store_raw_k, father_index=father_index, batch=batch)
+                 k_norm_eps=k_norm_eps, raw_k_cache=raw_k_cache, store_raw_k=store_raw_k, father_index=father_index, batch=batch,
+                 view_out=view0)
 
 
 @torch.no_grad()
 def deltakv_reconstruct_writeback_grouped_heads(kv_delta, father_slots, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
                                                 v_cache, *, heads_per_program: int = 4, pre_rope_k_cache=None,
                                                 ref_v_cache=None, k_norm_weight=None, k_norm_eps: float = 1e-6,
-                                                raw_k_cache: bool = False, store_raw_k: bool = False, father_index=None):
+                                                raw_k_cache: bool = False, store_raw_k: bool = False, father_index=None,
+                                                view_out=None):
     """`father_index` (extension): `father_slots` is then the whole `[latents, K]` father table and entry n uses row
-    max(father_index[n], 0) with negative fathers clamped to 0 (the static-decode gather fused into the kernel)."""
+    max(father_index[n], 0) with negative fathers clamped to 0 (the static-decode gather fused into the kernel).
+    `view_out` (extension) = (out_k [rows, Hkv, D], out_v, width, offset, entries_per_row): the rows are written into
+    the attention view instead of the cache (include/svk.h `out_k_cache`)."""
     if int(heads_per_program) <= 0:
         raise ValueError("heads_per_program must be a positive integer.")
     if pre_rope_k_cache is not None or ref_v_cache is not None:
@@ -134,7 +154,7 @@ def deltakv_reconstruct_writeback_grouped_heads(kv_delta, father_slots, slot_to_
     _reconstruct(delta=kv_delta, scale=None, mn=None, latent_slots=None, father_slots=father_slots,
                  slot_to_pos=slot_to_pos, out_slots=out_slots, out_pos=out_pos, cos_sin=cos_sin, k_cache=k_cache,
                  v_cache=v_cache, bits=0, group_size=0, k_norm_weight=k_norm_weight, k_norm_eps=k_norm_eps,
-                 raw_k_cache=raw_k_cache, store_raw_k=store_raw_k, father_index=father_index)
+                 raw_k_cache=raw_k_cache, store_raw_k=store_raw_k, father_index=father_index, view_out=view_out)
 
 
 @torch.no_grad()
@@ -345,13 +365,14 @@ def topk_sorted_desc(scores, k: int, *, valid_len=None, masked_value: float = -1
 @torch.no_grad()
 def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, postrope_mask, k_cache, v_cache, out_k, out_v,
                                     cos_sin, *, k_norm_weight=None, k_norm_eps: float = 1e-6, block_tokens: int = 16,
-                                    temp_slots=None, temp_offset: int = 0, new_k=None, new_v=None, new_slots=None):
+                                    temp_slots=None, temp_offset: int = 0, new_k=None, new_v=None, new_slots=None,
+                                    skip_temp: bool = False):
     """Reference wrapper deltakv_kernels.py:3489-3585 (same arguments; `block_tokens` is a Triton tile knob).
     Extensions: `temp_slots` [B, K] + `temp_offset` replace the mask in static decode (an entry in columns
     [temp_offset, temp_offset + K) is post-RoPE iff its slot is this step's reconstruct scratch slot);
     `new_k`/`new_v` [B, Hkv, D] + `new_slots` [B] carry this step's raw store in the same launch (row b's new token
     goes to cache slot new_slots[b]; the view reads it from new_k/new_v), equal to store_kvcache followed by the
-    plain call."""
+    plain call; `skip_temp`: the scratch entries are left alone (the reconstruction wrote them into out_k / out_v)."""
     for t in (active_slots, context_lens, slot_to_pos, k_cache, v_cache, out_k, out_v, cos_sin):
         assert t.is_cuda
     assert active_slots.dim() == 2
@@ -395,7 +416,7 @@ def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, pos
         k_norm_eps=float(k_norm_eps), batch=int(batch), width=int(width), num_slots=int(k_cache.shape[0]),
         num_kv_heads=num_kv_heads, head_dim=head_dim, cos_dtype=_dt(cos_sin), temp_slots=_lib.ptr(temp_slots),
         temp_stride=0 if temp_slots is None else temp_slots.stride(0), temp_offset=int(temp_offset),
-        temp_count=0 if temp_slots is None else int(temp_slots.shape[1]))
+        temp_count=0 if temp_slots is None else int(temp_slots.shape[1]), skip_temp=int(bool(skip_temp) and temp_slots is not None))
     if new_slots is not None:
         assert new_k is not None and new_v is not None and new_k.shape == new_v.shape and new_k.stride() == new_v.stride()
         assert new_k.dtype == torch.bfloat16 and new_v.dtype == torch.bfloat16 and new_k.stride(-1) == 1

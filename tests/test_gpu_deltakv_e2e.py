@@ -46,6 +46,9 @@ def linear_up(mod, x):
 @pytest.mark.parametrize("cfg", [
     dict(layers=5, full="0,3", kivi=True, up="linear", bits=4, lens=[148, 92, 61], Hq=8, Hkv=2, D=64),
     dict(layers=6, full="0,1,4", kivi=False, up="mlp_gelu", bits=0, lens=[116, 44], Hq=28, Hkv=4, D=128),
+    # the published form: int4 latents through the two-Linear GELU compress_up - the fused residual load, the look-ahead
+    # reconstruction in groups of two layers on the side stream and the reconstruction straight into the layers' views
+    dict(layers=8, full="0,4", kivi=True, up="mlp_gelu", bits=4, lens=[148, 92], Hq=8, Hkv=2, D=64),
 ])
 def test_deltakv_decode_steps_match_oracle(cfg):
     from sparse_vllm_amd.config import Config
@@ -223,3 +226,44 @@ def test_deltakv_free_seq_returns_every_slot():
     assert after["deltakv_full"] == before["deltakv_full"] - scratch
     with pytest.raises(ValueError, match="unknown seq_id"):
         cm.free_seq(seqs[0].seq_id)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_reconstruction_into_the_views_equals_scratch_slots_then_copy(graph):
+    """DeltaKVCacheManager.recon_into_view (SvkDeltakvReconstructArgs.out_k_cache + SvkDeltakvMaterializeArgs.skip_temp):
+    the reconstructed rows written straight into each layer's attention view, with the view kernel copying the raw rows
+    only, give the decode outputs of the reference's flow - scratch slots in the cache, then the whole view copied - bit
+    for bit, over compression events, eager and under hipGraph replay (look-ahead reconstruction on the side stream)."""
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    L, B, Hq, D = 8, 3, 8, 64
+
+    def run(into_view):
+        conf = Config.from_kwargs(
+            sparse_method="deltakv", num_hidden_layers=L, full_attention_layers="0,4", num_attention_heads=Hq,
+            num_key_value_heads=2, head_dim=D, max_model_len=256, max_num_seqs_in_gpu=B + 1, sink_keep_tokens=4,
+            recent_keep_tokens=8, decode_keep_tokens=12, deltakv_neighbor_count=2, deltakv_latent_dim=32,
+            deltakv_latent_quant_bits=4, deltakv_latent_quant_group_size=16, deltakv_center_ratio=0.25,
+            allow_missing_deltakv_path=True, compressor_up_type="mlp_gelu", compressor_intermediate_size=48,
+            full_layer_kv_quant_bits=4, full_layer_kivi_decode_block_seq=64, rope_theta=10000.0)
+        drv = SparseDecodeDriver(conf)
+        cm = drv.cache_manager
+        cm.recon_into_view = into_view
+        cm.permute_free_slots(7)
+        drv.admit_compressed_rows(B, [148, 92, 61], seed=3)
+        if graph:
+            drv.enable_decode_graph()
+        outs = torch.zeros((L, B, Hq, D), dtype=torch.bfloat16, device=drv.device)
+        got = []
+        for step in range(20):                        # two compression events per row
+            q, k, v = drv.random_step_inputs(seed=70 + step)
+            drv.step(q, k, v, outputs=outs)
+            torch.cuda.synchronize()
+            got.append(outs.view(torch.int16).cpu().numpy().copy())
+        used = cm._layer_views is not None
+        return np.stack(got), used
+
+    ref, used_ref = run(False)
+    new, used_new = run(True)
+    assert used_new and not used_ref                  # the run under test really took the view path
+    np.testing.assert_array_equal(new, ref)

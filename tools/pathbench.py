@@ -247,7 +247,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--recon-sub-batches", default="", help="developer: DeltaKV look-ahead layers per launch group, e.g. 1,2,3")
+    ap.add_argument("--no-recon-into-view", action="store_true", help="developer: DeltaKV reconstruction into scratch slots + full view copy")
     args = ap.parse_args()
+    if args.no_recon_into_view:
+        from sparse_vllm_amd.engine.cache_manager.deltakv import DeltaKVCacheManager
+        DeltaKVCacheManager._RECON_INTO_VIEW_DEFAULT = False
     if args.recon_sub_batches:
         from sparse_vllm_amd.engine.cache_manager.deltakv import DeltaKVCacheManager
         DeltaKVCacheManager._RECON_SUB_BATCHES = [int(x) for x in args.recon_sub_batches.split(",")]
