@@ -842,6 +842,10 @@ class DeltaKVCacheManager(CacheManager):
             return None
         if self._layer_views is None:
             Ls = len(self.deltakv_layer_ids)
+            nbytes = 2 * Ls * int(self.deltakv_materialized_compute_num_slots) * self.num_kv_heads * self.head_dim * 2
+            if nbytes > self._LAYER_VIEWS_MAX_BYTES:         # (a view per sparse layer; beyond the budget: scratch slots + copy)
+                self.recon_into_view = False
+                return None
             self._layer_views = torch.zeros((2, Ls, int(self.deltakv_materialized_compute_num_slots), self.num_kv_heads,
                                              self.head_dim), dtype=torch.bfloat16, device=self.device)
         width, offset, per_row = geom
@@ -944,6 +948,7 @@ class DeltaKVCacheManager(CacheManager):
 
     _RECON_SUB_BATCHES = [2]
     _RECON_INTO_VIEW_DEFAULT = True
+    _LAYER_VIEWS_MAX_BYTES = 16 << 30
 
     @classmethod
     def _recon_sub_batches(cls) -> list[int]:
