@@ -11,7 +11,6 @@ from __future__ import annotations
 import os
 from dataclasses import dataclass
 
-import numpy as np
 import torch
 
 from ..kernels import deltakv_kernels, h2o_ops

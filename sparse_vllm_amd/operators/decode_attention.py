@@ -5,7 +5,6 @@ sizes BLOCK_SEQ so that one launch fills 256 CUs: the HIP stage-1 kernel runs on
 
 from __future__ import annotations
 
-import os
 
 from dataclasses import dataclass
 
