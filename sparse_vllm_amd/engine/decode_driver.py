@@ -196,6 +196,7 @@ class SparseDecodeDriver:
         self._graph = None
         self._graph_key = None
         self._graph_steps_seen = 0
+        self.graph_stats = {"eager": 0, "captured": 0, "replayed": 0}     # steps by how they ran (measurement tools read it)
 
     @torch.no_grad()
     def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None, *,
@@ -229,6 +230,7 @@ class SparseDecodeDriver:
                 if self._graph_steps_seen == 0 or self._graph_key != key:
                     # first step with these buffers runs eagerly (allocates every scratch buffer)
                     body()
+                    self.graph_stats["eager"] += 1
                     self._graph_key = key
                     self._graph_steps_seen = 1
                     self._graph = None
@@ -239,10 +241,12 @@ class SparseDecodeDriver:
                         body()
                     self._graph = g
                     g.replay()
+                    self.graph_stats["captured"] += 1
             else:
                 if dev_active:
                     cm.device_step_mark_launched()   # the replayed graph carries the burst launches
                 self._graph.replay()
+                self.graph_stats["replayed"] += 1
         if after_layers is not None:
             after_layers()
         sc.post_forward(seqs, False)

@@ -215,18 +215,31 @@ def measure(name: str, *, steps: int = 32, warmup: int = 4, graph: bool = True, 
     for _ in range(max(warmup, 3 if graph else 0)):          # the graph is captured in the first steps
         drv.step(q, k, v)
     torch.cuda.synchronize()
-    lens = []
-    t1 = time.perf_counter()
-    for _ in range(steps):
-        drv.step(q, k, v)
-        lens.append(float(drv.row_len()[0]))
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t1) * 1e3 / steps
-    mean_len = sum(lens) / len(lens)
+    # two timed windows, the faster one reported: the GPU boxes are shared hosts, and a step of a small configuration is a
+    # few hundred microseconds of GPU time behind a Python loop - a stalled host core shows up as a 3-4x slower window now
+    # and then (all steps replayed, same kernels, same kernel times).  StreamingLLM's window is one whole cycle, so both
+    # windows see the same row lengths.
+    windows = []
+    for _ in range(2):
+        lens = []
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            drv.step(q, k, v)
+            lens.append(float(drv.row_len()[0]))
+        torch.cuda.synchronize()
+        windows.append(((time.perf_counter() - t1) * 1e3 / steps, sum(lens) / len(lens)))
+    ms, mean_len = min(windows)
     nbytes = algorithmic_bytes_per_step(name, info, mean_row_len=mean_len)
+    stats = dict(getattr(drv, "graph_stats", {}) or {})
     res = dict(config=name, ms_per_step=round(ms, 4), tokens_per_s=round(info["batch"] / ms * 1e3, 1),
                algorithmic_mb_per_step=round(nbytes / 1e6, 1), roofline_frac=round(nbytes / (ms * 1e-3) / 8.0e12, 4),
                mean_row_len=round(mean_len, 1), graph=bool(graph), steps=steps, setup_s=round(setup, 1), **info)
+    res["window_ms_per_step"] = [round(w[0], 4) for w in windows]
+    if graph and stats:
+        res["graph_steps"] = stats               # how the warm-up + timed steps ran: eager / captured / replayed
+        gen = getattr(drv.cache_manager, "device_step_generation", None)
+        if gen is not None:
+            res["device_step_generation"] = int(gen)
     if kernels:
         try:
             ks = kernel_timings(drv, q, k, v, name)
