@@ -159,3 +159,47 @@ def test_fuzz_prefill_score(seed):
         np.testing.assert_allclose(out[fin], ref[fin], rtol=1e-4, atol=2e-3)
     else:
         np.testing.assert_allclose(out, ref, rtol=2e-2, atol=2e-4)
+
+
+@pytest.mark.parametrize("seed", range(12 * _SCALE))
+def test_fuzz_decode_stage1_page_slot_addressing(seed):
+    """`slot_page_size`: over random head shapes, batch sizes, ragged lengths, block sizes, page sizes and score modes the
+    launch over a table of page slots equals the launch over the expanded token slots bit for bit."""
+    from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import _launch
+    rng = np.random.default_rng(5000 + seed)
+    Hq, Hkv, D = HEADS[seed % len(HEADS)]
+    B = int(rng.integers(1, 5))
+    page = int(rng.choice([4, 8, 16, 32]))
+    n_pages = int(rng.integers(2, 40))
+    L = n_pages * page
+    lens = np.array([int(rng.integers(1, L + 1)) for _ in range(B)], np.int32)
+    lens[int(rng.integers(0, B))] = L
+    block_seq = int(rng.choice([16, 32, 64, 96, 128, 256]))
+    mode = int(rng.choice([0, 2, 3]))
+    rows_n = B + 1
+    total_pages = rows_n * n_pages + 3
+    ptab = rng.permutation(total_pages)[: rows_n * n_pages].reshape(rows_n, n_pages).astype(np.int32)
+    ttab = (ptab[:, :, None].astype(np.int64) * page + np.arange(page)[None, None, :]).reshape(rows_n, -1).astype(np.int32)
+    rows = rng.permutation(rows_n)[:B].astype(np.int32)
+    slots = total_pages * page
+    q = tb((rng.standard_normal((B, Hq, D)) * 0.5).astype(np.float32))
+    k = tb((rng.standard_normal((slots, Hkv, D)) * 0.5).astype(np.float32))
+    v = tb((rng.standard_normal((slots, Hkv, D)) * 0.5).astype(np.float32))
+    nblk = (L + block_seq - 1) // block_seq
+    outs = []
+    for tab, sps in ((ttab, 0), (ptab, page)):
+        mid = torch.full((B, Hq, nblk, D), 7.0, dtype=torch.float32, device=dev())
+        lse = torch.full((B, Hq, nblk), 7.0, dtype=torch.float32, device=dev())
+        score = None
+        if mode == 2:
+            score = torch.full((B, L), -1e20, dtype=torch.float32, device=dev())
+        elif mode == 3:
+            score = torch.full((B, Hq, L), -1e20, dtype=torch.float32, device=dev())
+        _launch(q, k, v, ti(tab), ti(rows), ti(lens), L, mid, lse, score, block_seq, None, slot_page_size=sps)
+        torch.cuda.synchronize()
+        outs.append((mid.view(torch.int32).cpu().numpy(), lse.view(torch.int32).cpu().numpy(),
+                     None if score is None else score.view(torch.int32).cpu().numpy()))
+    np.testing.assert_array_equal(outs[1][0], outs[0][0])
+    np.testing.assert_array_equal(outs[1][1], outs[0][1])
+    if mode:
+        np.testing.assert_array_equal(outs[1][2], outs[0][2])
