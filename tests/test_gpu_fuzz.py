@@ -203,3 +203,56 @@ def test_fuzz_decode_stage1_page_slot_addressing(seed):
     np.testing.assert_array_equal(outs[1][1], outs[0][1])
     if mode:
         np.testing.assert_array_equal(outs[1][2], outs[0][2])
+
+
+@pytest.mark.parametrize("seed", range(16 * _SCALE))
+def test_fuzz_quest_build_view(seed):
+    """svk_quest_build_view over random row lengths, budgets, score distributions (fp32 / bf16-valued, one sign or both,
+    narrow bands, heavy ties, -inf tails), page-slot and token-slot views: the selected pages are the first prev_budget of
+    a stable descending argsort, written in ascending page order, followed by the last page."""
+    from sparse_vllm_amd.kernels.quest_ops import build_view
+    rng = np.random.default_rng(9000 + seed)
+    page = 16
+    n_prev = int(rng.choice([int(rng.integers(3, 300)), int(rng.integers(300, 5000)), int(rng.integers(5000, 40000))]))
+    kb = int(rng.integers(1, min(n_prev, 2000) + 1))
+    B = int(rng.integers(1, 4))
+    kind = seed % 8
+    sc = rng.standard_normal((B, n_prev)).astype(np.float32) * 3
+    if kind == 1:
+        sc = bf16_round(sc)
+    elif kind == 2:
+        sc = bf16_round(np.abs(sc) + 40.0)                       # positive narrow band: <= 8 varying key bits
+    elif kind == 3:
+        sc = bf16_round(-np.abs(sc) - 1.0)
+    elif kind == 4:
+        sc = rng.choice(np.array([0.5, -0.5, 2.0], dtype=np.float32), (B, n_prev))
+    elif kind == 5:
+        sc = bf16_round(sc)
+        sc[:, n_prev - n_prev // 4:] = -np.inf
+    elif kind == 6:
+        sc = (1.0 + rng.random((B, n_prev)) * 2.0 ** -12).astype(np.float32)
+    elif kind == 7:
+        sc = bf16_round(sc * 1e-3)
+    n_pages = n_prev + 1
+    ptab = np.stack([rng.permutation(n_pages * B + 5)[:n_pages] for _ in range(B)]).astype(np.int32)
+    lens = (n_pages * page - rng.integers(0, page, size=B)).astype(np.int32)
+    paged = bool(seed & 1)
+    keep = (kb + 1) * page
+    d = dev()
+    packed = torch.full((B, keep), -3, dtype=torch.int32, device=d)
+    ll = torch.zeros((B,), dtype=torch.int32, device=d)
+    lr = torch.zeros((B,), dtype=torch.int32, device=d)
+    ttab = torch.zeros((B, 16), dtype=torch.int32, device=d)
+    build_view(ti(sc), ti(ptab), ttab, torch.arange(B, dtype=torch.int32, device=d), ti(lens), packed, ll, lr, page_size=page,
+               n_prev=n_prev, prev_budget=kb, token_budget=keep, page_budget_base=kb + 1, max_keep=keep, is_long_text=True,
+               emit_page_slots=paged)
+    got = packed.cpu().numpy()
+    for b in range(B):
+        order = np.sort(np.argsort(-sc[b], kind="stable")[:kb])
+        exp_pages = np.concatenate((ptab[b, order], ptab[b, n_pages - 1:n_pages]))
+        if paged:
+            np.testing.assert_array_equal(got[b, : kb + 1], exp_pages)
+        else:
+            exp = (exp_pages[:, None].astype(np.int64) * page + np.arange(page)[None, :]).reshape(-1)
+            np.testing.assert_array_equal(got[b], exp)
+    np.testing.assert_array_equal(ll.cpu().numpy(), kb * page + (lens - n_prev * page))
