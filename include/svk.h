@@ -323,7 +323,8 @@ typedef struct SvkH2oDeviceStepArgs {
   int32_t select_mode;         /* SVK_DEVICE_SELECT_H2O (0) | _WINDOW (1) | _SNAPKV (2)       */
   int32_t prefix_count, _pad;  /* SNAPKV: sink tokens always kept                            */
   int32_t* tickets;            /* NULL (burst = three launches) or [L] int32, zero before the first launch: the burst runs as
-                                * ONE launch whose last workgroup per layer commits the layer and resets its ticket      */
+                                * ONE launch - the workgroups of the rows that fired take a ticket when they are done, the
+                                * last of them commits the layer and resets its ticket; all others return at once        */
 } SvkH2oDeviceStepArgs;
 int svk_h2o_device_step_begin(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);
 int svk_h2o_device_burst(const SvkH2oDeviceStepArgs* a, svk_stream_t stream);
