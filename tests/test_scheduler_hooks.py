@@ -153,3 +153,42 @@ def test_snapkv_streamingllm_quest_capacity_hooks_match_reference():
         assert [{k: int(v) for k, v in m.prompt_admission_costs(s).items()} for s in seqs] == c["prompt_admission_costs"]
         assert int(m.prefill_batched_tokens_margin()) == c["prefill_batched_tokens_margin"]
         assert m.prompt_admission_failure_action() == c["prompt_admission_failure_action"]
+
+
+def test_deltakv_first_prefill_staging_view_bookkeeping():
+    """Host side of the DeltaKV prompt attention view (deltakv_base.py:1852-1993, :1020-1037): a first-prefill step - every
+    row starts at length 0 - marks the sparse layers as staged with slots = the step's token order (-1 beyond a chunk);
+    the flag lives for that step; a continuation chunk has no view and `build_prefill_compute_view` refuses it."""
+    import pytest
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.cache_manager.base import CacheManager
+    from sparse_vllm_amd.engine.sequence import Sequence
+    conf = Config.from_kwargs(
+        sparse_method="deltakv", num_hidden_layers=4, full_attention_layers="0,2", num_attention_heads=8,
+        num_key_value_heads=2, head_dim=64, max_model_len=512, max_num_seqs_in_gpu=3, sink_keep_tokens=4,
+        recent_keep_tokens=8, decode_keep_tokens=12, deltakv_neighbor_count=2, deltakv_latent_dim=32,
+        deltakv_latent_quant_bits=4, deltakv_latent_quant_group_size=16, deltakv_center_ratio=0.25,
+        allow_missing_deltakv_path=True, compressor_up_type="linear", full_layer_kv_quant_bits=4,
+        full_layer_kivi_decode_block_seq=64, rope_theta=10000.0, engine_prefill_chunk_size=256, num_kvcache_slots=4096,
+        device="cpu")
+    cm = CacheManager.create(conf, None)
+    assert not cm.prefill_attention_view_supported
+    s1, s2 = Sequence(num_prompt_tokens=80), Sequence(num_prompt_tokens=17)
+    s1.current_chunk_size, s2.current_chunk_size = 40, 17
+    cu, total = cm._prepare_prefill([s1, s2])
+    assert cu.tolist() == [0, 40, 57] and total == 57
+    assert cm.prefill_attention_view_supported
+    assert [cm.has_prefill_staging_view(l) for l in range(4)] == [False, True, False, True]      # sparse layers only
+    slots, req, ctx, temp = cm.get_prefill_staging_view(1)
+    assert temp is None and req.tolist() == [0, 1] and ctx.tolist() == [40, 17] and tuple(slots.shape) == (2, 40)
+    assert slots[0].tolist() == list(range(40)) and slots[1, :17].tolist() == list(range(40, 57))
+    assert (slots[1, 17:] == -1).all()
+    with pytest.raises(NotImplementedError):
+        cm.get_prefill_staging_view(0)
+    cm.on_forward_end([s1, s2], True)
+    assert not cm.prefill_attention_view_supported and not cm.has_prefill_staging_view(1)
+    s1.num_prefilled_tokens, s1.current_chunk_size = 40, 40
+    cm._prepare_prefill([s1])                            # continuation chunk: the row holds 40 tokens
+    assert not cm.prefill_attention_view_supported
+    with pytest.raises(NotImplementedError, match="reconstructed prefill compute view"):
+        cm.build_prefill_compute_view(1, None, None, None)
