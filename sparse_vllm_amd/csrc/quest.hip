@@ -71,11 +71,18 @@ __global__ void __launch_bounds__(512) quest_score_pages_kernel(const SvkQuestSc
   const int p0 = blockIdx.x * kPagesPerBlock;
   const int n = lane & 15, jq = lane >> 4;
   const int SP = Hkv * JQ;
+  const int p1 = min(p0 + kPagesPerBlock, a.n_prev);
+  float* out = a.page_scores + (int64_t)b * a.score_stride;
+  // the block's page slots are requested before the row's length is looked at (index clamped to the scored columns, which
+  // the table row always has): the length's round trip then runs under this one instead of in front of it
+  const int32_t* ptab = a.page_table + (int64_t)a.req_indices[b] * a.page_table_stride;
+  constexpr int NGRP = kPagesPerBlock / 16;
+  int slot[NGRP];
+#pragma unroll
+  for (int g = 0; g < NGRP; ++g) slot[g] = ptab[min(p0 + g * 16 + n, a.n_prev - 1)];
   const int len = a.context_lens[b];
   const int num_pages = max(1, (len + a.page_size - 1) / a.page_size);
   const int n_valid = min(a.n_prev, num_pages - 1);        // previous pages that exist
-  const int p1 = min(p0 + kPagesPerBlock, a.n_prev);
-  float* out = a.page_scores + (int64_t)b * a.score_stride;
   if (p0 >= n_valid) {                                       // nothing valid in this block
     for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) out[p] = -INFINITY;
     return;
@@ -101,18 +108,13 @@ __global__ void __launch_bounds__(512) quest_score_pages_kernel(const SvkQuestSc
       qn[c] = __builtin_bit_cast(bf16x8_t, make_uint4(nn[0], nn[1], nn[2], nn[3]));
     }
   }
-  const int32_t* ptab = a.page_table + (int64_t)a.req_indices[b] * a.page_table_stride;
   const int64_t head_off = (int64_t)w * D + jq * 8;
   const int64_t row_elems = (int64_t)Hkv * D;
-  // all page slots of the block first, then every group's metadata loads before the first MFMA: the scan is
+  // all page slots of the block first (above), then every group's metadata loads before the first MFMA: the scan is
   // latency-bound (two dependent round trips per 16 pages), so keep the whole block's requests in flight together
-  constexpr int NGRP = kPagesPerBlock / 16;
-  int slot[NGRP];
 #pragma unroll
-  for (int g = 0; g < NGRP; ++g) {
-    const int p = p0 + g * 16 + n;
-    slot[g] = p < n_valid ? ptab[p] : 0;
-  }
+  for (int g = 0; g < NGRP; ++g)
+    if (p0 + g * 16 + n >= n_valid) slot[g] = 0;
   uint4 vmax[NGRP][NC], vmin[NGRP][NC];
 #pragma unroll
   for (int g = 0; g < NGRP; ++g) {
