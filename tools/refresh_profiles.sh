@@ -18,9 +18,19 @@ stats() {  # stats <name> <cmd...>: kernel-trace stats csv of one command
 timeout 600 python3 "$R/bench.py" < /dev/null > "$O/bench_stdout.log" 2> "$O/bench_stderr.log"; tail -1 "$O/bench_stdout.log" > "$O/bench_line.json"
 stats bench_kernel_stats.csv python3 "$R/bench.py" --steps 128 --warmup 8 --no-cpu-baseline --no-paths     # (the other configurations launch the same kernels at other shapes: they would pollute the per-kernel averages)
 grep '^{' "$O/_bench_kernel_stats.log" | tail -1 > "$O/bench_line_profiled.json"
-for b in 1 8 32; do timeout 300 python3 "$R/bench.py" --batch $b --no-cpu-baseline --no-kernel-events < /dev/null 2>/dev/null | tail -1 >> "$O/bench_small_batches.jsonl"; done
+json_line() {  # json_line <file> <cmd...>: the command's last stdout line appended to <file>, one retry if it printed none
+  local f=$1; shift
+  local out
+  for try in 1 2; do
+    out=$(timeout 400 "$@" < /dev/null 2>> "$O/_json_line_stderr.log" | tail -1)
+    [ -n "$out" ] && break
+    sleep 5
+  done
+  echo "$out" >> "$f"
+}
+for b in 1 8 32; do json_line "$O/bench_small_batches.jsonl" python3 "$R/bench.py" --batch $b --no-cpu-baseline --no-kernel-events; done
 # the roofline leg at the neighbouring batch sizes (the default is 256)
-for b in 64 128 512; do timeout 400 python3 "$R/bench.py" --batch $b --no-cpu-baseline < /dev/null 2>/dev/null | tail -1 >> "$O/bench_other_batches.jsonl"; done
+for b in 64 128 512; do json_line "$O/bench_other_batches.jsonl" python3 "$R/bench.py" --batch $b --no-cpu-baseline; done
 # other configurations
 timeout 600 python3 "$R/tools/pathbench.py" --graph < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_graph.jsonl"
 timeout 600 python3 "$R/tools/pathbench.py" < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_eager.jsonl"
