@@ -11,6 +11,9 @@ engine would run it.
 
 from __future__ import annotations
 
+import contextlib
+import gc
+
 import numpy as np
 import torch
 
@@ -23,6 +26,22 @@ from .cache_manager.base import CacheManager
 from .sequence import Sequence
 from .sparse_controller import SparseController
 
+
+
+@contextlib.contextmanager
+def capture_without_gc():
+    """Around a hipGraph capture: collect cyclic garbage first and keep the collector off until the capture has ended.
+    A captured graph that is only reachable from dead reference cycles (an old driver, say) is destroyed whenever the
+    collector happens to run; `hipGraphDestroy` inside another stream capture is "operation not permitted when stream is
+    capturing", raised from a destructor - the process aborts.  (torch.cuda.graph no longer collects on entry.)"""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 class SparseDecodeDriver:
     def __init__(self, config: Config, *, use_launch_provider: bool = True):
@@ -237,7 +256,7 @@ class SparseDecodeDriver:
                 else:
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with capture_without_gc(), torch.cuda.graph(g):
                         body()
                     self._graph = g
                     g.replay()

@@ -14,6 +14,7 @@ BASELINE.json "other configs" (SURVEY section 8(d)), Qwen2.5-7B shapes, syntheti
 One JSON line per configuration: ms per decode step of the sparse path (all layers, no dense model).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -23,7 +24,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from sparse_vllm_amd.config import Config
-from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver, capture_without_gc
 
 QWEN = dict(num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4, head_dim=128)
 
@@ -140,6 +141,23 @@ def _kernel_specs(name: str):
     return specs
 
 
+class _TimedGraph:
+    """Stand-in for the driver's captured graph with HIP events right around every replay.  (A top-level class on purpose:
+    a class defined inside `measure` closes over the graph and is cyclic garbage afterwards - the collector then destroys
+    the hipGraph at some later allocation, and when that falls inside the NEXT configuration's stream capture the process
+    dies with "operation not permitted when stream is capturing".)"""
+
+    def __init__(self, graph):
+        self.graph, self.pairs = graph, []
+
+    def replay(self):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.graph.replay()
+        e1.record()
+        self.pairs.append((e0, e1))
+
+
 def kernel_timings(drv, q, k, v, name: str, *, replays: int = 5) -> list[dict]:
     specs = _kernel_specs(name)
     calls: dict[str, list] = {}
@@ -166,7 +184,7 @@ def kernel_timings(drv, q, k, v, name: str, *, replays: int = 5) -> list[dict]:
                 orig(*a, **kw)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_without_gc(), torch.cuda.graph(g):
                 for orig, a, kw, _f in lst:
                     orig(*a, **kw)
             g.replay()
@@ -234,22 +252,16 @@ def measure(name: str, *, steps: int = 32, warmup: int = 4, graph: bool = True, 
     graph_ms = None
     real_graph = getattr(drv, "_graph", None) if graph else None
     if real_graph is not None and steps <= 64:
-        pairs = []
-
-        class _Timed:
-            def replay(self_inner):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                real_graph.replay()
-                e1.record()
-                pairs.append((e0, e1))
-        drv._graph = _Timed()
+        timed = _TimedGraph(real_graph)
+        drv._graph = timed
         for _ in range(steps):
             drv.step(q, k, v)
         torch.cuda.synchronize()
         drv._graph = real_graph
-        if pairs:
-            graph_ms = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+        if timed.pairs:
+            graph_ms = sum(a.elapsed_time(b) for a, b in timed.pairs) / len(timed.pairs)
+        timed.graph, timed.pairs = None, []
+    real_graph = None
     nbytes = algorithmic_bytes_per_step(name, info, mean_row_len=mean_len)
     stats = dict(getattr(drv, "graph_stats", {}) or {})
     res = dict(config=name, ms_per_step=round(ms, 4), tokens_per_s=round(info["batch"] / ms * 1e3, 1),
@@ -271,7 +283,9 @@ def measure(name: str, *, steps: int = 32, warmup: int = 4, graph: bool = True, 
                 res["dominant_kernel"], res["kernel_us"], res["kernel_frac"] = ks[0]["kernel"], ks[0]["kernel_us"], ks[0]["frac"]
         except Exception as e:      # a failing side leg must not lose the step timing
             res["kernels_error"] = f"{type(e).__name__}: {e}"
+    drv._graph = None                    # the configuration's graph dies here, not whenever the collector finds the driver
     del drv, q, k, v
+    gc.collect()
     torch.cuda.empty_cache()
     return res
 
