@@ -178,6 +178,33 @@ def cpu_baseline(seed: int = 20260625, steps: int = 4, workers: int | None = Non
     }
 
 
+def _paths_in_child(names, steps: int) -> list[dict]:
+    """tools/pathbench.py in a CHILD process (one per call, all configurations): whatever a side leg does - a Python
+    exception, an abort inside a library, a hang - the headline line of this process is already computed and still gets
+    printed.  Each configuration comes back as one JSON line; a configuration the child did not report is an error entry."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "pathbench.py"), "--graph", "--configs", ",".join(names),
+           "--steps", str(int(steps)), "--warmup", "4"]
+    got, note = {}, None
+    try:
+        r = subprocess.run(cmd, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, text=True)
+        for line in r.stdout.splitlines():
+            if line.startswith("{"):
+                try:
+                    d = json.loads(line)
+                    got[d.get("config")] = d
+                except ValueError:
+                    pass
+        if r.returncode != 0:
+            tail = [l for l in r.stderr.strip().splitlines() if l and "amdgpu.ids" not in l][-1:] or [""]
+            note = f"pathbench child exited with {r.returncode}: {tail[0][:200]}"
+    except subprocess.TimeoutExpired:
+        note = "pathbench child timed out"
+    except OSError as e:
+        note = f"pathbench child failed to start: {e}"
+    return [got.get(n) or {"config": n, "error": note or "not reported by the pathbench child"} for n in names]
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -381,15 +408,9 @@ def main():
         del drv, cm, q, k, v
         record["calls"].clear()
         torch.cuda.empty_cache()
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import pathbench
-        out["paths"] = []
-        for name in ("h2o_b64", "h2o_b8", "h2o_b1", "streamingllm", "streamingllm_b1", "quest", "quest_b8", "quest_b1", "deltakv",
-                     "deltakv_b4"):
-            try:
-                out["paths"].append(pathbench.measure(name, steps=args.path_steps, warmup=4, graph=True))
-            except Exception as e:      # a failing side leg must not lose the headline line
-                out["paths"].append({"config": name, "error": f"{type(e).__name__}: {e}"})
+        names = ("h2o_b64", "h2o_b8", "h2o_b1", "streamingllm", "streamingllm_b1", "quest", "quest_b8", "quest_b1", "deltakv",
+                 "deltakv_b4")
+        out["paths"] = _paths_in_child(names, args.path_steps)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -306,7 +306,11 @@ def main():
         from sparse_vllm_amd.engine.cache_manager.deltakv import DeltaKVCacheManager
         DeltaKVCacheManager._RECON_SUB_BATCHES = [int(x) for x in args.recon_sub_batches.split(",")]
     for name in args.configs.split(","):
-        print(json.dumps(measure(name, steps=args.steps, warmup=args.warmup, graph=args.graph)), flush=True)
+        try:
+            res = measure(name, steps=args.steps, warmup=args.warmup, graph=args.graph)
+        except Exception as e:          # one failing configuration must not take the others with it
+            res = {"config": name, "error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
