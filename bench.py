@@ -237,7 +237,12 @@ def main():
     n_gpus = world if use_dist else 1
     device = "cpu" if stub else f"cuda:{local_rank}"
     # the CPU leg forks one worker per host core, so it runs before this process creates a GPU context
-    cpu = cpu_baseline() if (rank == 0 and n_gpus == 1 and not args.no_cpu_baseline) else None
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:           # the CPU leg is a reported baseline: it must not take the measurement with it
+            cpu = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
 
     from sparse_vllm_amd.config import Config
     from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
