@@ -525,3 +525,53 @@ def test_layer_batched_residual_and_reconstruct_equal_per_layer_launches():
                                                        cos_sin=cos_sin, k_cache=kr, v_cache=vr, raw_k_cache=True, store_raw_k=False)
         assert torch.equal(kr.view(torch.int16), kb[l].view(torch.int16))
         assert torch.equal(vr.view(torch.int16), vb[l].view(torch.int16))
+
+
+@pytest.mark.parametrize("cfg", [dict(B=1, K=64, W=90, off=4, Hkv=4, D=128, nl=2), dict(B=3, K=40, W=61, off=8, Hkv=2, D=64, nl=3),
+                                 dict(B=2, K=16, W=16, off=0, Hkv=8, D=128, nl=1)])
+def test_reconstruct_into_view_rows_equals_reconstruct_into_cache_slots(cfg):
+    """`SvkDeltakvReconstructArgs.out_k_cache`: entry n of the plan lands in view row (n / K) * W + off + n % K with exactly
+    the bytes the plain launch writes into cache slot out_slots[n]; entries with out_slots[n] < 0 write nothing; no other
+    view row and no cache row is touched.  Per-layer and layer-batched launches."""
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    B, K, W, off, Hkv, D, nl = (cfg[k] for k in ("B", "K", "W", "off", "Hkv", "D", "nl"))
+    torch.manual_seed(B * 100 + K)
+    d = torch.device("cuda:0")
+    n, latents, kf, slots = B * K, 150, 4, 900
+    delta = (torch.randn(nl, n, 2 * Hkv * D, device=d) * 0.1).bfloat16()
+    table = torch.randint(-1, slots // 2, (nl, latents, kf), dtype=torch.int32, device=d)
+    row_index = torch.randint(0, latents, (n,), dtype=torch.int32, device=d)
+    slot_to_pos = torch.randint(0, 500, (slots,), dtype=torch.int32, device=d)
+    out_slots = (slots // 2 + torch.randperm(slots // 2, device=d)[:n]).to(torch.int32)
+    out_pos = torch.randint(0, 500, (n,), dtype=torch.int32, device=d)
+    dead = torch.rand(n, device=d) < 0.2                    # selected tokens that are raw centres: nothing to reconstruct
+    out_slots[dead], out_pos[dead], row_index[dead] = -1, -1, -1
+    cos_sin = torch.randn(512, D, device=d)
+    base_k = (torch.randn(nl, slots, Hkv, D, device=d) * 0.3).bfloat16()
+    base_v = (torch.randn(nl, slots, Hkv, D, device=d) * 0.3).bfloat16()
+    ref_k, ref_v = base_k.clone(), base_v.clone()
+    dk.deltakv_reconstruct_writeback_layers(delta, table, row_index, slot_to_pos, out_slots, out_pos, cos_sin, ref_k, ref_v,
+                                            raw_k_cache=True, store_raw_k=False)
+    rows = (torch.arange(n, device=d) // K) * W + off + torch.arange(n, device=d) % K
+    live = ~dead
+    for batched in (True, False):
+        ck, cv = base_k.clone(), base_v.clone()
+        view_k = torch.full((nl, B * W, Hkv, D), 7.0, dtype=torch.bfloat16, device=d)
+        view_v = torch.full((nl, B * W, Hkv, D), 9.0, dtype=torch.bfloat16, device=d)
+        if batched:
+            dk.deltakv_reconstruct_writeback_layers(delta, table, row_index, slot_to_pos, out_slots, out_pos, cos_sin, ck, cv,
+                                                    raw_k_cache=True, store_raw_k=False, view_out=(view_k, view_v, W, off, K))
+        else:
+            for l in range(nl):
+                dk.deltakv_reconstruct_writeback_grouped_heads(
+                    kv_delta=delta[l], father_slots=table[l], father_index=row_index, slot_to_pos=slot_to_pos, out_slots=out_slots,
+                    out_pos=out_pos, cos_sin=cos_sin, k_cache=ck[l], v_cache=cv[l], raw_k_cache=True, store_raw_k=False,
+                    view_out=(view_k[l], view_v[l], W, off, K))
+        torch.cuda.synchronize()
+        assert torch.equal(ck.view(torch.int16), base_k.view(torch.int16)) and torch.equal(cv.view(torch.int16), base_v.view(torch.int16))
+        for l in range(nl):
+            assert torch.equal(view_k[l, rows[live]].view(torch.int16), ref_k[l, out_slots[live].long()].view(torch.int16))
+            assert torch.equal(view_v[l, rows[live]].view(torch.int16), ref_v[l, out_slots[live].long()].view(torch.int16))
+            untouched = torch.ones(B * W, dtype=torch.bool, device=d)
+            untouched[rows[live]] = False
+            assert (view_k[l, untouched] == 7.0).all() and (view_v[l, untouched] == 9.0).all()
