@@ -192,3 +192,26 @@ def test_deltakv_first_prefill_staging_view_bookkeeping():
     assert not cm.prefill_attention_view_supported
     with pytest.raises(NotImplementedError, match="reconstructed prefill compute view"):
         cm.build_prefill_compute_view(1, None, None, None)
+
+
+def test_capture_without_gc_restores_the_collector():
+    """`capture_without_gc` (engine/decode_driver.py): the cycle collector is off inside the block - a captured hipGraph
+    reachable only from dead cycles must not be destroyed inside another capture - and back afterwards, also on errors."""
+    import gc
+    import pytest
+    from sparse_vllm_amd.engine.decode_driver import capture_without_gc
+    assert gc.isenabled()
+    with capture_without_gc():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    with pytest.raises(RuntimeError):
+        with capture_without_gc():
+            raise RuntimeError("capture failed")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with capture_without_gc():
+            assert not gc.isenabled()
+        assert not gc.isenabled()              # a caller that runs with the collector off keeps it off
+    finally:
+        gc.enable()
