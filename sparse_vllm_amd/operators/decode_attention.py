@@ -64,7 +64,8 @@ class Mi355xDecodeLaunchProvider(DecodeAttentionLaunchProvider):
     priority = 100
     RESIDENT_WORKGROUPS = 256       # one workgroup per CU
     RESIDENT_WAVES = 1024           # one wave per SIMD
-    MIN_BLOCK_SEQ = 64
+    MIN_BLOCK_SEQ = 32              # one tile (round 4; 64 before: B=1 H2O 0.378 -> 0.368 ms, StreamingLLM B=1 0.314 -> 0.277 ms,
+                                    # a 2184-token DeltaKV view 10.6 -> 9.8 us per stage 1 + merge)
     wants_kv_heads = True           # PreparedDecodeAttentionLaunchOp passes the spec's num_kv_heads
 
     def supports(self, spec, caps):

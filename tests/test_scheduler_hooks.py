@@ -95,7 +95,7 @@ def test_mi355x_decode_launch_geometry():
     assert cfg(28, 4, 256, 4224) == 4224           # one block per sequence: stage 1 writes the output itself
     assert cfg(28, 4, 128, 4224) == 2112
     assert cfg(28, 4, 64, 4224) == 1056
-    assert cfg(28, 4, 1, 4224) == 64               # floor: MIN_BLOCK_SEQ
+    assert cfg(28, 4, 1, 4224) == 32               # floor: MIN_BLOCK_SEQ (one 32-token tile)
     assert cfg(32, 8, 256, 4224) == 4224           # 8 waves per workgroup: still one workgroup per CU
     assert cfg(14, 2, 256, 4224) == 2112           # two waves per workgroup -> 512 workgroups
     assert cfg(7, 1, 256, 4224) == 1056            # one wave per workgroup -> 1024 workgroups
