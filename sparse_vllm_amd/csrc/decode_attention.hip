@@ -441,12 +441,37 @@ decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
     if (d == 0) s_l[g] = sum;
     *reinterpret_cast<float4*>(&s_acc[g][d]) = acc;
     __syncthreads();
-    if (g != 0) return;
-    const int used = min(nblk, GROUPS);
-    for (int j = 1; j < used; ++j) {
-      const float4 tv = *reinterpret_cast<const float4*>(&s_acc[j][d]);
-      acc.x += tv.x; acc.y += tv.y; acc.z += tv.z; acc.w += tv.w;
-      sum += s_l[j];
+    if constexpr (GROUPS > 8) {
+      // two levels (1024 threads, 32 lane groups): every eighth group adds up its seven followers, then group 0 the
+      // leaders - 7 + 3 dependent LDS reads instead of 31 (groups beyond the partial count hold zeros)
+      if ((g & 7) == 0) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+          const float4 tv = *reinterpret_cast<const float4*>(&s_acc[g + j][d]);
+          acc.x += tv.x; acc.y += tv.y; acc.z += tv.z; acc.w += tv.w;
+          sum += s_l[g + j];
+        }
+        if (g != 0) {
+          *reinterpret_cast<float4*>(&s_acc[g][d]) = acc;
+          if (d == 0) s_l[g] = sum;
+        }
+      }
+      __syncthreads();
+      if (g != 0) return;
+#pragma unroll
+      for (int j = 8; j < GROUPS; j += 8) {
+        const float4 tv = *reinterpret_cast<const float4*>(&s_acc[j][d]);
+        acc.x += tv.x; acc.y += tv.y; acc.z += tv.z; acc.w += tv.w;
+        sum += s_l[j];
+      }
+    } else {
+      if (g != 0) return;
+      const int used = min(nblk, GROUPS);
+      for (int j = 1; j < used; ++j) {
+        const float4 tv = *reinterpret_cast<const float4*>(&s_acc[j][d]);
+        acc.x += tv.x; acc.y += tv.y; acc.z += tv.z; acc.w += tv.w;
+        sum += s_l[j];
+      }
     }
   } else if (g != 0) {
     return;
