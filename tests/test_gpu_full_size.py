@@ -26,7 +26,7 @@ QWEN = dict(num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4,
 
 def _driver(B, layers=28, graph=True, seed=0):
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     kw = dict(QWEN)
     kw["num_hidden_layers"] = layers
     conf = Config.from_kwargs(sparse_method="h2o", h2o_decode_budget=4096, h2o_decode_eviction_interval=128,
@@ -167,7 +167,7 @@ def test_h2o_headline_batch_256_single_block_direct_out_matches_split_path():
     results = []
     for headline in (True, False):
         from sparse_vllm_amd.config import Config
-        from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+        from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
         kw = dict(QWEN)
         kw["num_hidden_layers"] = L
         conf = Config.from_kwargs(sparse_method="h2o", h2o_decode_budget=4096, h2o_decode_eviction_interval=128,

@@ -27,7 +27,7 @@ def _bf(t):
 def test_h2o_decode_steps_match_oracle(cfg):
     # the score epilogues of all layers of a step run in one launch after the layer loop
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     B, L, budget, interval = cfg["B"], cfg["L"], cfg["budget"], cfg["interval"]
     conf = Config.from_kwargs(sparse_method="h2o", num_hidden_layers=L, num_attention_heads=cfg["Hq"],
                               num_key_value_heads=cfg["Hkv"], head_dim=cfg["D"], max_model_len=256,
@@ -108,7 +108,7 @@ def test_h2o_decode_steps_match_oracle(cfg):
 
 def _run_h2o(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False, slots: int | None = None):
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     B, L, budget, interval = 4, 3, 48, 16
     conf = Config.from_kwargs(sparse_method="h2o", num_hidden_layers=L, max_model_len=128, max_num_seqs_in_gpu=B + 1,
                               num_kvcache_slots=slots or (B * (budget + interval) + 41), h2o_decode_budget=budget,

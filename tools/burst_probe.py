@@ -1,7 +1,7 @@
 import sys, time, torch, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparse_vllm_amd.config import Config
-from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
 from sparse_vllm_amd.utils.profiler import profiler
 B=64
 cfg = Config.from_kwargs(sparse_method="h2o", h2o_decode_budget=4096, h2o_decode_eviction_interval=128, h2o_prefill_budget=8192,

@@ -24,7 +24,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from sparse_vllm_amd.config import Config
-from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver, capture_without_gc
+from sparse_vllm_amd.engine.decode_driver import capture_without_gc
+from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
 
 QWEN = dict(num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4, head_dim=128)
 

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from sparse_vllm_amd.config import Config
-from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
 from sparse_vllm_amd.engine.sequence import Sequence
 
 
