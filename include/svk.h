@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 15
+#define SVK_ABI_VERSION 16
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -166,6 +166,9 @@ typedef struct SvkFlashDecodeStage2Args {
   int64_t o_stride_b, o_stride_h;
   int32_t batch, num_q_heads, head_dim, block_seq;
   int32_t extra_partials;        /* partials merged beyond ceil(len / block_seq) (svk_kivi_decode_stage1), normally 0 */
+  int32_t max_partials;          /* partials THIS launch may merge per row (ceil(max_len_in_batch / block_seq) +
+                                  * extra_partials); picks the merge's thread geometry.  0 = unknown: the lse row stride
+                                  * (the workspace's capacity, which a grow-only workspace inflates) decides instead. */
 } SvkFlashDecodeStage2Args;
 int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_stream_t stream);
 
@@ -291,7 +294,16 @@ int svk_compact_rows(const SvkCompactRowsArgs* a, svk_stream_t stream);
  *                              its cumulative score row and svk_compact_rows on its slot-table / score row (dropped
  *                              slots go to the free stack in lane order, exactly where the host-driven burst puts
  *                              them), then row_len = budget and free_ptr[l] += dropped; rows below the trigger return
- *                              at once (three launches, microseconds when nothing triggers).
+ *                              at once.  Without `tickets` the burst is three launches (select, compact, commit); with
+ *                              `tickets` it is ONE launch (see the field).
+ * Preconditions of svk_h2o_device_burst (the caller's, not checked on the device):
+ *   - `row_ids` are DISTINCT rows: a row listed twice would be counted twice in the layer's fired-row total and
+ *     compacted by two workgroups at once;
+ *   - with `tickets`: tickets[l] == 0 on entry for every layer.  The launch leaves them at 0 when it completes; a launch
+ *     that is aborted mid-burst (device fault, stream destroyed) can leave a non-zero ticket behind, and that layer would
+ *     then never commit again - re-zero the tickets whenever the device state is rebuilt after a failed step
+ *     (SnapKVCacheManager._device_state_upload does);
+ *   - recent_count >= 1 in every select mode (the kernels index the recent range's first position).
  * Rows are uniform across layers (H2O's invariant, h2o.py:256-271).
  * The same two calls serve StreamingLLM (round 4): select_mode SVK_DEVICE_SELECT_WINDOW keeps the sink
  * [0, budget - recent_count) and the recent_count newest positions of a row that reached trigger_len = 2 * (sink + recent)

@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 15
+SVK_ABI_VERSION = 16
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -63,7 +63,8 @@ class SvkFlashDecodeStage2Args(C.Structure):
     _fields_ = [("mid_o", _p), ("mid_lse", _p), ("b_seqlen", _p), ("o", _p),
                 ("mid_o_stride_b", _i64), ("mid_o_stride_h", _i64), ("mid_o_stride_s", _i64),
                 ("mid_lse_stride_b", _i64), ("mid_lse_stride_h", _i64), ("o_stride_b", _i64), ("o_stride_h", _i64),
-                ("batch", _i32), ("num_q_heads", _i32), ("head_dim", _i32), ("block_seq", _i32), ("extra_partials", _i32)]
+                ("batch", _i32), ("num_q_heads", _i32), ("head_dim", _i32), ("block_seq", _i32), ("extra_partials", _i32),
+                ("max_partials", _i32)]
 
 
 class SvkH2oDecodeScoreArgs(C.Structure):

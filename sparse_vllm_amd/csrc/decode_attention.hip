@@ -582,11 +582,14 @@ extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_st
   if (a->batch <= 0) return SVK_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(a->batch, a->num_q_heads);
-  // the lse row stride is the workspace's partial capacity: workspaces of more than 128 partials get 1024 threads per
-  // (b, head) - 32 lane groups x 8 prefetched rows = 256 partials in ONE round trip, where 256 threads (8 groups) walk
-  // what lies beyond their first 64 in further trips (B=1 rows in 32-token blocks have 132 partials: 0.368 -> 0.355 ms per
-  // step; at 69 partials the 1024-thread form is the slower one - its last lane group adds up 31 others)
-  const bool wide = a->mid_lse_stride_h > 128;
+  // launches that may merge more than 128 partials per row get 1024 threads per (b, head) - 32 lane groups x 8
+  // prefetched rows = 256 partials in ONE round trip, where 256 threads (8 groups) walk what lies beyond their first 64
+  // in further trips (B=1 rows in 32-token blocks have 132 partials: 0.368 -> 0.355 ms per step; at 69 partials the
+  // 1024-thread form is the slower one - its last lane group adds up 31 others).  The count is the LAUNCH's
+  // (max_partials), not the workspace's capacity: the two forms add in different orders, so the output bits of a step
+  // must not depend on what an earlier, longer launch grew the shared workspace to.
+  SVK_REQUIRE(a->max_partials >= 0, SVK_ERR_VALUE, "svk_flash_decode_stage2: max_partials %d must be >= 0", a->max_partials);
+  const bool wide = (a->max_partials > 0 ? (int64_t)a->max_partials : a->mid_lse_stride_h) > 128;
   if (a->head_dim == 128) {
     if (wide) hipLaunchKernelGGL((decode_stage2_kernel<128, 1024>), grid, dim3(1024), 0, s, *a);
     else hipLaunchKernelGGL((decode_stage2_kernel<128, 256>), grid, dim3(256), 0, s, *a);

@@ -14,6 +14,7 @@ from typing import Any
 
 import torch
 
+from ...utils.context import get_context
 from ...method_registry import NATIVE_SPARSE_METHODS, SUPPORTED_SPARSE_METHODS, normalize_sparse_method
 
 
@@ -173,10 +174,42 @@ class CacheManager(ABC):
         return int(default)
 
     def save_rope_kv_if_needed(self, layer_idx: int, k: torch.Tensor, v: torch.Tensor):
-        """base.py:629-694 (_store_layer_kv): scatter this step's K/V rows to their slots."""
+        """base.py:629-694 (_store_layer_kv): scatter this step's K/V rows to their slots.  The model calls this right
+        before the layer's `Attention.forward` (models/qwen2.py:126-131).  MI355X: in a decode step whose store may ride
+        in the stage-1 launch (`fused_decode_store_slots`) the rows are kept back until that launch takes them
+        (`take_deferred_decode_store`); whatever is still held when the next store arrives is written first."""
+        if not get_context().is_prefill:
+            slots = self.fused_decode_store_slots(layer_idx)
+            if slots is not None:
+                self.flush_deferred_decode_store()
+                self._deferred_decode_store = (int(layer_idx), k, v, slots)
+                return
+        self._store_rows_now(layer_idx, k, v, self.get_layer_batch_states(layer_idx).slot_mapping)
+
+    def _store_rows_now(self, layer_idx: int, k: torch.Tensor, v: torch.Tensor, slot_mapping: torch.Tensor):
         from ...kernels import store_kvcache
         k_cache, v_cache = self.get_layer_store_view(layer_idx)
-        store_kvcache(k, v, k_cache, v_cache, self.get_layer_batch_states(layer_idx).slot_mapping)
+        store_kvcache(k, v, k_cache, v_cache, slot_mapping)
+
+    def take_deferred_decode_store(self, layer_idx: int):
+        """-> (k, v, slot_mapping) kept back by `save_rope_kv_if_needed` for this layer, or None.  The caller stores them
+        (inside its stage-1 launch, or through `store_deferred_decode_rows`)."""
+        held = self.__dict__.get("_deferred_decode_store")
+        if held is None or held[0] != int(layer_idx):
+            return None
+        self._deferred_decode_store = None
+        return held[1:]
+
+    def store_deferred_decode_rows(self, layer_idx: int, new_kv) -> None:
+        k, v, slots = new_kv
+        self._store_rows_now(layer_idx, k, v, slots)
+
+    def flush_deferred_decode_store(self) -> None:
+        """Rows that no attention launch took (a layer left early): store them with a launch of their own."""
+        held = self.__dict__.get("_deferred_decode_store")
+        if held is not None:
+            self._deferred_decode_store = None
+            self._store_rows_now(held[0], held[1], held[2], held[3])
 
     # ------------------------------------------------------------------ scheduler capacity hooks (SURVEY 8(f).4)
     # base.py:1290-1393 of the reference: what the scheduler asks a cache manager before it admits a prompt or schedules a

@@ -412,6 +412,10 @@ class SnapKVCacheManager(CacheManager):
         budget, trigger = sink + keep + recent, int(2.0 * keep)
         if keep <= 0 or trigger <= budget or trigger > self.max_model_len:
             return None
+        if recent < 1:
+            # svk_h2o_device_burst needs a recent range of at least one token; the reference's selection handles an empty
+            # one (sparse_controller.py:1670-1747), so such a configuration takes the host-driven steps
+            return None
         width = max(trigger, int(self._decode_static_max_context_len or 0))
         buf = self.__dict__.get("snapkv_decode_score_tensor")
         if buf is None or buf.shape[1] < int(graph_batch_size) or buf.shape[2] < width:
@@ -471,6 +475,9 @@ class SnapKVCacheManager(CacheManager):
         self._dev_row_len.copy_(torch.from_numpy(self._row_seq_lens_all), non_blocking=False)
         self._dev_free_ptr.copy_(torch.tensor([int(self._num_free_slots[int(l)]) for l in self.kv_transformer_layer_indices()],
                                               dtype=torch.long))
+        # a burst that aborted mid-way (a failed step) would leave a layer's ticket non-zero and that layer would never
+        # commit again: every re-upload starts from zeroed tickets
+        self._dev_burst_tickets.zero_()
         self._dev_state_dirty = False
 
     def prepare_decode_static(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,

@@ -19,8 +19,7 @@ import torch
 
 from ..config import Config
 from ..layers.attention import Attention
-from ..operators.decode_attention import DecodeAttentionLaunchSpec, prepare_decode_launch_op
-from ..platforms import current_platform
+from ..operators.decode_attention import DecodeAttentionLaunchSpec, prepare_decode_attention_launch_op
 from ..utils.context import set_context
 from .cache_manager.base import CacheManager
 from .sequence import Sequence
@@ -52,9 +51,11 @@ class SparseDecodeDriver:
         cm = self.cache_manager
         launch_op = None
         if use_launch_provider:
-            launch_op = prepare_decode_launch_op(
-                DecodeAttentionLaunchSpec(cm.num_heads, cm.num_kv_heads, cm.head_dim, config.vllm_sparse_method),
-                current_platform.device_caps(self.device))
+            # models/minimax_m2.py:108 of the reference builds the op the same way, once per attention module
+            launch_op = prepare_decode_attention_launch_op(
+                DecodeAttentionLaunchSpec(cm.num_heads, cm.num_kv_heads, cm.head_dim, torch.bfloat16,
+                                          page_size=int(getattr(cm, "page_size", 1) or 1)),
+                device_index=self.device.index or 0)
         self.attn = Attention(cm.num_heads, cm.head_dim, cm.head_dim ** -0.5, cm.num_kv_heads,
                               decode_launch_op=launch_op)
         self.seqs: list[Sequence] = []
@@ -72,14 +73,17 @@ class SparseDecodeDriver:
             save_raw = getattr(cm, "save_raw_kv_if_needed", None)
             if save_raw is not None:          # DeltaKV sparse layers keep the pre-RoPE key (models/qwen2.py attention)
                 save_raw(layer_idx, k[layer_idx], v[layer_idx])
-            # Attention.forward(q, k, v) stores this step's K/V rows: as a launch of its own, or inside the
-            # stage-1 launch where the cache manager allows it (`fused_decode_store_slots`)
+            # models/qwen2.py:126-131: hand this step's post-RoPE K/V rows to the manager, then call the attention layer.
+            # (The manager stores them with a launch of its own, or keeps them back for the layer's stage-1 launch where
+            # the store may ride in it: `fused_decode_store_slots`.)
+            cm.save_rope_kv_if_needed(layer_idx, k[layer_idx], v[layer_idx])
             o = self.attn(q[layer_idx], k[layer_idx], v[layer_idx])
             on_layer_end = getattr(sc, "on_layer_end", None)
             if on_layer_end is not None:
                 on_layer_end(layer_idx, ctx)
             if outputs is not None:
                 outputs[layer_idx].copy_(o)
+        cm.flush_deferred_decode_store()
         join = getattr(sc, "join_side_streams", None)
         if join is not None:
             join()

@@ -22,11 +22,13 @@ from .cache_manager.base import SparseSelection
 
 @dataclass
 class LayerBatchSparseState:
-    """sparse_controller.py:36-53."""
-    context_lens: torch.Tensor | None = None
-    req_indices: torch.Tensor | None = None
-    max_context_len: int | None = None
+    """sparse_controller.py:36-53, field for field."""
     attn_score: torch.Tensor | None = None
+    active_indices: torch.Tensor | None = None        # logical indices [B, K]
+    active_slots: torch.Tensor | None = None          # physical slots [B, K]
+    req_indices: torch.Tensor | None = None
+    context_lens: torch.Tensor | None = None
+    max_context_len: int | None = None
     active_compressed_indices: torch.Tensor | None = None
     global_req_indices: torch.Tensor | None = None
     deltakv_free_temp_slots: bool = False

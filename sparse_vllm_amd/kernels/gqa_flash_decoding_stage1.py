@@ -130,9 +130,10 @@ def flash_decode_stage1(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_
 @torch.no_grad()
 def flash_decode_stage1_with_score(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
                                    mid_out_logsumexp, attn_score, block_seq, *, new_kv=None, direct_out=None,
-                                   score_overwrite=False):
-    """2-D `attn_score` [B, W]: head-max raw logits fused; 3-D [B, Hq, W]: per head.  `new_kv` / `direct_out`: as in
-    `flash_decode_stage1`.  `score_overwrite` (MI355X extension, 2-D scores): store instead of max-combine - the caller
-    skips the -1e20 pre-fill and masks positions beyond the lengths itself (include/svk.h)."""
+                                   score_overwrite=False, slot_page_size=0):
+    """2-D `attn_score` [B, W]: head-max raw logits fused; 3-D [B, Hq, W]: per head.  `new_kv` / `direct_out` /
+    `slot_page_size`: as in `flash_decode_stage1`.  `score_overwrite` (MI355X extension, 2-D scores): store instead of
+    max-combine - the caller skips the -1e20 pre-fill and masks positions beyond the lengths itself (include/svk.h)."""
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv, direct_out=direct_out, score_overwrite=score_overwrite)
+            attn_score, block_seq, new_kv, direct_out=direct_out, score_overwrite=score_overwrite,
+            slot_page_size=slot_page_size)

@@ -59,6 +59,17 @@ def _fake_prefill_attention_enabled() -> bool:
     return enabled
 
 
+def _fake_decode_attention_enabled() -> bool:
+    """layers/attention_backend.py:50-55: SPARSEVLLM_FAKE_{DECODE_,}ATTENTION, same refusal as the prefill switch."""
+    enabled = _env_truthy("SPARSEVLLM_FAKE_DECODE_ATTENTION") or _env_truthy("SPARSEVLLM_FAKE_ATTENTION")
+    if enabled and not _env_truthy("SPARSEVLLM_ALLOW_FAKE_ATTENTION"):
+        raise RuntimeError(
+            "Sparse-vLLM fake attention was requested, but it is disabled by default because it "
+            "invalidates correctness and benchmark results. Set SPARSEVLLM_ALLOW_FAKE_ATTENTION=1 "
+            "only for explicit fake-attention tests or profiling.")
+    return enabled
+
+
 def _fake_attention_output(q: torch.Tensor) -> torch.Tensor:
     """layers/attention_backend.py:58-69."""
     mode = os.environ.get("SPARSEVLLM_FAKE_ATTENTION_MODE", "zero").strip().lower()
@@ -158,13 +169,55 @@ class HipAttentionBackend:
             stats["written_for"] = (q.data_ptr(), q._version, tuple(q.shape))
         return o
 
+    def _debug_check_decode_bounds(self, view: DecodeComputeView) -> None:
+        """layers/attention_backend.py:397-439 (SVLLM_DEBUG_DECODE_BOUNDS=1, never under stream capture): request rows
+        inside the slot table, the longest context inside its width, every visible slot id inside the KV pool.  The HIP
+        kernels trust the slot table exactly as the reference's Triton kernels do; this host check is the reference's
+        debugging aid for a corrupted table, with its messages."""
+        if os.environ.get("SVLLM_DEBUG_DECODE_BOUNDS", "0") != "1":
+            return
+        payload = _require_explicit_payload(view, operation="Decode bounds check")
+        meta = view.meta
+        if payload.backend not in {"dense", "flash_attn_contiguous"}:
+            return
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+        if meta.active_slots.dim() != 2:
+            raise RuntimeError(f"debug slot bounds check expects 2D active_slots, got shape={tuple(meta.active_slots.shape)}")
+        rows = meta.req_indices.to(torch.long)
+        row_min = int(rows.min().item()) if rows.numel() > 0 else 0
+        row_max = int(rows.max().item()) if rows.numel() > 0 else -1
+        num_rows, width = int(meta.active_slots.shape[0]), int(meta.active_slots.shape[1])
+        if row_min < 0 or row_max >= num_rows:
+            raise RuntimeError(f"decode req row index out of bounds: row_min={row_min} row_max={row_max} num_rows={num_rows}")
+        visible_len = int(meta.context_lens.max().item()) if meta.context_lens.numel() > 0 else 0
+        if visible_len > width:
+            raise RuntimeError("decode visible length exceeds Req_to_tokens width: "
+                               f"visible_len={visible_len} req_to_tokens_width={width}")
+        page = int((payload.metadata or {}).get("slot_page_size", 0) or 0)
+        visible = meta.active_slots.index_select(0, rows)[:, : visible_len if page <= 1 else -(-visible_len // page)]
+        pos = torch.arange(visible.shape[1], device=visible.device)[None, :]
+        lens = meta.context_lens[:, None] if page <= 1 else (meta.context_lens[:, None] + page - 1) // page
+        slot_cap = int(payload.k_cache.shape[0]) if page <= 1 else int(payload.k_cache.shape[0]) // page
+        bad = ((visible < 0) | (visible >= slot_cap)) & (pos < lens)
+        if bool(bad.any().item()):
+            b, p_ = (int(x) for x in bad.nonzero(as_tuple=False)[0])
+            raise RuntimeError("decode physical slot out of bounds before attention: "
+                               f"batch={b} req_row={int(rows[b].item())} pos={p_} slot={int(visible[b, p_].item())} "
+                               f"slot_cap={slot_cap} context_len={int(meta.context_lens[b].item())}")
+
     def run_decode(self, q: torch.Tensor, view: DecodeComputeView, *, mid_o, mid_o_logexpsum, max_len_in_batch: int,
                    block_seq: int, num_heads: int, num_kv_heads: int, gqa_block_n: int = 16,
                    gqa_num_warps: int = 2, new_kv=None, score_overwrite: bool = False) -> torch.Tensor:
-        payload = view.payload
-        if not isinstance(payload, ExplicitKVPayload):
-            raise TypeError(f"HIP decode requires ExplicitKVPayload, got {type(payload).__name__}.")
+        """layers/attention_backend.py:217-349.  `new_kv` / `score_overwrite` are MI355X extras the attention layer
+        passes only when they apply (this step's K/V rows riding in the stage-1 launch; scores stored instead of
+        max-merged)."""
+        payload = _require_explicit_payload(view, operation="HIP decode")
         meta = view.meta
+        if _fake_decode_attention_enabled():
+            if meta.attn_score is not None:
+                meta.attn_score.zero_()
+            return _fake_attention_output(q)
         kind = "full" if int(max_len_in_batch) > 8192 else "sparse"
         if payload.backend == "full_layer_kivi":
             # layers/attention_backend.py:236-247, :351-395
@@ -186,6 +239,7 @@ class HipAttentionBackend:
             o = torch.empty_like(q)
             flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq, extra_partials=extra)
             return o
+        self._debug_check_decode_bounds(view)
         if new_kv is not None and payload.backend not in ("dense", "full_layer_kivi"):
             raise RuntimeError("the fused decode store is only wired into the dense stage-1 launch")
         # MI355X: when one block covers every row of the launch the split-KV merge has nothing to merge and stage 1
@@ -193,17 +247,18 @@ class HipAttentionBackend:
         direct = payload.backend == "dense" and direct_out_supported(max_len_in_batch, block_seq)
         o = torch.empty_like(q)
         direct_out = o if direct else None
+        slot_page_size = int((payload.metadata or {}).get("slot_page_size", 0))     # a page-slot table (Quest view), scored or not
         with profiler.record(f"decode_attention_stage1_{kind}"):
             if meta.attn_score is not None:
                 flash_decode_stage1_with_score(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                                meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum,
                                                meta.attn_score, block_seq, new_kv=new_kv, direct_out=direct_out,
-                                               score_overwrite=score_overwrite)
+                                               score_overwrite=score_overwrite, slot_page_size=slot_page_size)
             else:
                 flash_decode_stage1(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                     meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum, block_seq,
                                     gqa_block_n, gqa_num_warps, new_kv=new_kv, direct_out=direct_out,
-                                    slot_page_size=int((payload.metadata or {}).get("slot_page_size", 0)))
+                                    slot_page_size=slot_page_size)
         if not direct:
             with profiler.record(f"decode_attention_stage2_{kind}"):
                 flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)
@@ -224,23 +279,24 @@ class Attention(torch.nn.Module):
         layer_idx = context.now_layer_idx
         if context.is_prefill:
             return self._forward_prefill(context, cache_manager, sparse_controller, layer_idx, q, k, v)
+        return self._forward_decode(context, cache_manager, sparse_controller, layer_idx, q)
+
+    def _forward_decode(self, context, cache_manager, sparse_controller, layer_idx, q):
+        """layers/attention.py:162-250 hook for hook.  This step's K/V rows were handed to
+        `cache_manager.save_rope_kv_if_needed` by the caller (models/qwen2.py:126-131); a manager that lets the store ride
+        in the stage-1 launch kept them back and hands them over through `take_deferred_decode_store`."""
         temp_slots = None
-        # this step's K/V rows: stored here (explicit launch), or inside the stage-1 launch when the manager allows it
-        new_kv = None
-        if k is not None and v is not None:
-            fuse = getattr(cache_manager, "fused_decode_store_slots", None)
-            slots = fuse(layer_idx) if fuse is not None else None
-            if slots is None:
-                cache_manager.save_rope_kv_if_needed(layer_idx, k, v)
-            else:
-                new_kv = (k, v, slots)
         try:
             batch_size = q.shape[0]
             selection = sparse_controller.get_decode_selection(layer_idx, q)
             decode_view = cache_manager.build_decode_compute_view(
                 layer_idx, q, selection, num_heads=self.num_heads, num_kv_heads=self.num_kv_heads)
+            if not isinstance(decode_view.payload, ExplicitKVPayload):
+                raise TypeError("Attention decode requires ExplicitKVPayload, got "
+                                f"{type(decode_view.payload).__name__}.")
             decode_meta = decode_view.meta
             temp_slots = decode_meta.temp_slots
+
             max_context_len = decode_meta.max_context_len
             static_cap = getattr(cache_manager, "_decode_static_max_context_len", None)
             if static_cap is not None:
@@ -249,27 +305,49 @@ class Attention(torch.nn.Module):
                 raise RuntimeError(f"static decode requires max_context_len, got None at layer={layer_idx}")
             max_len_in_batch = int(max_context_len)
             if decode_meta.active_slots.dim() == 2:
-                max_len_in_batch = min(max_len_in_batch, int(decode_meta.active_slots.shape[1]))
+                slot_table_len = int(decode_meta.active_slots.shape[1])
+                if (os.environ.get("SVLLM_DEBUG_DECODE_BOUNDS", "0") == "1"
+                        and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())):
+                    actual_max_len = int(decode_meta.context_lens.max().item()) if decode_meta.context_lens.numel() > 0 else 0
+                    if actual_max_len > slot_table_len:
+                        raise RuntimeError("decode context length exceeds active slot table width: "
+                                           f"layer={layer_idx} context_lens_max={actual_max_len} "
+                                           f"slot_table_len={slot_table_len}")
+                if max_len_in_batch > slot_table_len:
+                    max_len_in_batch = slot_table_len
                 if max_len_in_batch <= 0:
                     raise RuntimeError(f"decode requires a positive context length, got {max_len_in_batch} at layer={layer_idx}")
             block_seq = cache_manager.get_decode_block_seq(layer_idx, 256)
-            if self.decode_launch_op is None or decode_view.payload.backend == "full_layer_kivi":
+            kivi = decode_view.payload.backend == "full_layer_kivi"
+            if self.decode_launch_op is None or kivi:
                 # KIVI layers keep the manager's full_layer_kivi_decode_block_seq (128-token tiles, >= 2 workgroups per CU)
                 gqa_block_n, gqa_num_warps = 16, 2
             else:
+                extra = {"batch_size": batch_size} if getattr(self.decode_launch_op, "accepts_batch_size", False) else {}
                 block_seq, gqa_block_n, gqa_num_warps = self.decode_launch_op.launch_config(
                     block_seq=block_seq, max_context_len=max_len_in_batch,
-                    requires_attention_scores=decode_meta.attn_score is not None, batch_size=batch_size)
+                    requires_attention_scores=decode_meta.attn_score is not None, **extra)
             num_seq_blocks = (max_len_in_batch + block_seq - 1) // block_seq
-            if decode_view.payload.backend == "full_layer_kivi":
+            if kivi:
                 num_seq_blocks += 3           # room for the wide KIVI launch's extra partials (raw / ragged pieces of a row)
             mid_o, mid_lse = get_decode_workspace(context, batch_size, self.num_heads, num_seq_blocks, self.head_dim,
                                                   q.device)
+            # MI355X extras, passed only when they apply (a backend with the reference's signature is called with the
+            # reference's arguments)
+            extras = {}
+            take = getattr(cache_manager, "take_deferred_decode_store", None)
+            new_kv = take(layer_idx) if take is not None else None
+            if new_kv is not None:
+                if decode_view.payload.backend in ("dense", "full_layer_kivi"):
+                    extras["new_kv"] = new_kv
+                else:
+                    cache_manager.store_deferred_decode_rows(layer_idx, new_kv)
+            if getattr(sparse_controller, "decode_scores_overwrite", False):
+                extras["score_overwrite"] = True
             o = self.attention_backend.run_decode(
                 q, decode_view, mid_o=mid_o, mid_o_logexpsum=mid_lse, max_len_in_batch=max_len_in_batch,
                 block_seq=block_seq, num_heads=self.num_heads, num_kv_heads=self.num_kv_heads,
-                gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps, new_kv=new_kv,
-                score_overwrite=bool(getattr(sparse_controller, "decode_scores_overwrite", False)))
+                gqa_block_n=gqa_block_n, gqa_num_warps=gqa_num_warps, **extras)
             cache_manager.record_decode_query(layer_idx, q)
             sparse_controller.on_layer_attention_end(layer_idx)
             cache_manager.on_layer_attention_end(layer_idx)

@@ -1,0 +1,3 @@
+from .registry import OpRegistry, OpResolver, SupportResult
+
+__all__ = ["OpRegistry", "OpResolver", "SupportResult"]

@@ -1450,7 +1450,8 @@ def gen_attention_hooks():
     from sparsevllm.utils.context import get_context, set_context
 
     types = SimpleNamespace(SparseSelection=rb.SparseSelection, AttentionViewMeta=rb.AttentionViewMeta,
-                            ExplicitKVPayload=rb.ExplicitKVPayload, PrefillComputeView=rb.PrefillComputeView)
+                            ExplicitKVPayload=rb.ExplicitKVPayload, PrefillComputeView=rb.PrefillComputeView,
+                            DecodeComputeView=rb.DecodeComputeView)
 
     def install(is_prefill, cu, cm, sc, layer, seqs=None):
         set_context(is_prefill, cu_seqlens_q=cu, cache_manager=cm, seqs=seqs)
@@ -1460,6 +1461,12 @@ def gen_attention_hooks():
 
     out = {"cases": {c["name"]: ht.run_case(c, attention_cls=Attention, types=types, install_context=install)
                      for c in ht.CASES}}
+    # (C) the decode branch (layers/attention.py:162-250) on recording stand-ins, and the backend's own slot check
+    # (layers/attention_backend.py:397-439) on hand-built views
+    out["decode_cases"] = {c["name"]: ht.run_decode_case(c, attention_cls=Attention, types=types, install_context=install)
+                           for c in ht.DECODE_CASES}
+    backend = Attention(4, 4, 0.5, 2).attention_backend
+    out["bounds_cases"] = {c["name"]: ht.run_bounds_case(c, backend=backend, types=types) for c in ht.BOUNDS_CASES}
 
     # ---- (B)
     F = ht.H2O_FLOW
@@ -1510,6 +1517,39 @@ def gen_attention_hooks():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+def _registry_namespace():
+    """The reference's operator-registry / platform modules as the namespace tests/registry_scenarios.py drives."""
+    import sparsevllm.operators.decode_attention as da
+    import sparsevllm.operators.registry as reg
+    import sparsevllm.platforms as platforms
+    from sparsevllm.platforms import interface as pi
+    return SimpleNamespace(
+        OpRegistry=reg.OpRegistry, OpResolver=reg.OpResolver, SupportResult=reg.SupportResult,
+        record_operator_binding=reg.record_operator_binding, operator_runtime_stats=reg.operator_runtime_stats,
+        runtime_version_at_least=reg.runtime_version_at_least, bindings=reg._OPERATOR_BINDINGS,
+        DeviceCaps=pi.DeviceCaps, PlatformEnum=pi.PlatformEnum, AllocatorStats=pi.AllocatorStats, Platform=pi.Platform,
+        platforms=platforms, DecodeAttentionLaunchSpec=da.DecodeAttentionLaunchSpec,
+        DecodeAttentionLaunchProvider=da.DecodeAttentionLaunchProvider,
+        DefaultGqaDecodeLaunchProvider=da.DefaultGqaDecodeLaunchProvider,
+        DECODE_ATTENTION_LAUNCH_REGISTRY=da.DECODE_ATTENTION_LAUNCH_REGISTRY,
+        PreparedDecodeAttentionLaunchOp=da.PreparedDecodeAttentionLaunchOp,
+        prepare_decode_attention_launch_op=da.prepare_decode_attention_launch_op)
+
+
+def gen_operator_registry():
+    """The reference's OpRegistry / OpResolver / SupportResult / DeviceCaps / Platform / decode-attention-launch family
+    answering tests/registry_scenarios.py (the cases of its own tests/test_operator_registry.py and tests/test_platforms.py,
+    plus field tables of the boundary dataclasses)."""
+    import json
+    sys.path.insert(0, os.path.dirname(HERE))
+    import registry_scenarios as rs
+    out = rs.run_all(_registry_namespace())
+    path = os.path.join(HERE, "operator_registry.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 GROUPS = {
     "decode_alloc": gen_decode_alloc,
     "decode": gen_decode,
@@ -1531,6 +1571,7 @@ GROUPS = {
     "method_surface": gen_method_surface,
     "capacity_others": gen_capacity_others,
     "attention_hooks": gen_attention_hooks,
+    "operator_registry": gen_operator_registry,
 }
 
 

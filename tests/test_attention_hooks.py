@@ -1,4 +1,5 @@
-"""CPU: the prefill branch of this build's `Attention.forward` against the REFERENCE's (layers/attention.py:88-161).
+"""CPU: both branches of this build's `Attention.forward` against the REFERENCE's (layers/attention.py:88-161 prefill,
+:162-250 decode) and the backend's decode slot check (layers/attention_backend.py:397-439).
 
 tests/golden/attention_hooks.json was produced by tests/golden/gen_fixtures.py (`attention_hooks`) running the
 reference's `Attention.forward` over the recording stand-ins of tests/hook_trace.py; the same stand-ins driven through
@@ -31,7 +32,8 @@ def fixture():
 def _types():
     from sparse_vllm_amd.engine.cache_manager import base as b
     return SimpleNamespace(SparseSelection=b.SparseSelection, AttentionViewMeta=b.AttentionViewMeta,
-                           ExplicitKVPayload=b.ExplicitKVPayload, PrefillComputeView=b.PrefillComputeView)
+                           ExplicitKVPayload=b.ExplicitKVPayload, PrefillComputeView=b.PrefillComputeView,
+                           DecodeComputeView=b.DecodeComputeView)
 
 
 def _install(is_prefill, cu, cm, sc, layer, seqs=None):
@@ -53,6 +55,30 @@ def test_prefill_hook_trace_equals_reference(fixture, case):
 
 def test_every_reference_case_is_replayed(fixture):
     assert sorted(fixture["cases"]) == sorted(c["name"] for c in ht.CASES)
+    assert sorted(fixture["decode_cases"]) == sorted(c["name"] for c in ht.DECODE_CASES)
+    assert sorted(fixture["bounds_cases"]) == sorted(c["name"] for c in ht.BOUNDS_CASES)
+
+
+@pytest.mark.parametrize("case", ht.DECODE_CASES, ids=[c["name"] for c in ht.DECODE_CASES])
+def test_decode_hook_trace_equals_reference(fixture, case):
+    """The DECODE branch (layers/attention.py:162-250): get_decode_selection -> build_decode_compute_view (TypeError for a
+    payload that is not explicit KV) -> static capacity / slot-table clamp / SVLLM_DEBUG_DECODE_BOUNDS -> get_decode_block_seq
+    -> the launch provider asked with exactly the reference's three keywords -> run_decode with exactly the reference's
+    keywords and workspace shapes -> record_decode_query -> the two on_layer_attention_end hooks; temp slots released in
+    `finally` on every path."""
+    from sparse_vllm_amd.layers.attention import Attention
+    got = ht.run_decode_case(case, attention_cls=Attention, types=_types(), install_context=_install)
+    ref = fixture["decode_cases"][case["name"]]
+    assert json.loads(json.dumps(got["trace"])) == ref["trace"]
+    assert json.loads(json.dumps(got["result"])) == ref["result"]
+
+
+@pytest.mark.parametrize("case", ht.BOUNDS_CASES, ids=[c["name"] for c in ht.BOUNDS_CASES])
+def test_decode_bounds_checker_equals_reference(fixture, case):
+    """`_debug_check_decode_bounds` (layers/attention_backend.py:397-439): same verdicts, same messages."""
+    from sparse_vllm_amd.layers.attention import HipAttentionBackend
+    got = ht.run_bounds_case(case, backend=HipAttentionBackend(), types=_types())
+    assert json.loads(json.dumps(got)) == fixture["bounds_cases"][case["name"]]
 
 
 def test_h2o_prefill_flow_through_attention_layer_equals_reference(fixture):

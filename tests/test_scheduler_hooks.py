@@ -83,14 +83,25 @@ def test_base_capacity_hooks_defaults():
 
 
 def test_mi355x_decode_launch_geometry():
-    """`Mi355xDecodeLaunchProvider` (the reference's DecodeAttentionLaunchProvider pattern, operators/decode_attention.py:
-    13-158): the largest 16-aligned BLOCK_SEQ that keeps one workgroup per CU and - for 1- and 2-KV-head tensor-parallel
-    ranks, whose workgroups are one or two waves - one wave per SIMD; the default provider keeps the caller's value."""
-    from sparse_vllm_amd.operators.decode_attention import DecodeAttentionLaunchSpec, prepare_decode_launch_op
-    from sparse_vllm_amd.operators.registry import DeviceCaps, PlatformEnum
-    caps = DeviceCaps(platform=PlatformEnum.ROCM, arch="gfx950", num_cus=256)
+    """`Mi355xDecodeLaunchProvider` (registered in the reference's decode-attention-launch family,
+    operators/decode_attention.py:13-158): the largest 16-aligned BLOCK_SEQ that keeps one workgroup per CU and - for 1- and
+    2-KV-head tensor-parallel ranks, whose workgroups are one or two waves - one wave per SIMD; on any other device the
+    reference's default provider answers and keeps the caller's value."""
+    import torch
+    from sparse_vllm_amd.operators.decode_attention import (DECODE_ATTENTION_LAUNCH_REGISTRY, DecodeAttentionLaunchSpec,
+                                                            PreparedDecodeAttentionLaunchOp)
+    from sparse_vllm_amd.operators.registry import OpResolver
+    from sparse_vllm_amd.platforms.interface import DeviceCaps, PlatformEnum
+    caps = DeviceCaps(platform=PlatformEnum.ROCM, device_type="cuda", device_index=0, device_name="AMD Instinct MI355X",
+                      arch="gfx950", num_cus=256)
+
+    def prepared(hq, hkv, caps_):
+        spec = DecodeAttentionLaunchSpec(hq, hkv, 128, torch.bfloat16)
+        return PreparedDecodeAttentionLaunchOp(spec, OpResolver(DECODE_ATTENTION_LAUNCH_REGISTRY).resolve(spec, caps_).provider)
+
     def cfg(hq, hkv, batch, length):
-        op = prepare_decode_launch_op(DecodeAttentionLaunchSpec(num_heads=hq, num_kv_heads=hkv, head_dim=128), caps)
+        op = prepared(hq, hkv, caps)
+        assert op.name == "mi355x_hip_gqa" and op.accepts_batch_size
         return op.launch_config(block_seq=256, max_context_len=length, requires_attention_scores=True, batch_size=batch)[0]
     assert cfg(28, 4, 256, 4224) == 4224           # one block per sequence: stage 1 writes the output itself
     assert cfg(28, 4, 128, 4224) == 2112
@@ -105,9 +116,11 @@ def test_mi355x_decode_launch_geometry():
     assert cfg(28, 4, 64, 1152) == 288
     for hkv in (1, 2, 4, 8):
         assert cfg(8 * hkv // hkv * hkv if hkv > 1 else 7, hkv, 16, 8192) % 16 == 0
-    other = DeviceCaps(platform=PlatformEnum.ROCM, arch="gfx942", num_cus=304)
-    op = prepare_decode_launch_op(DecodeAttentionLaunchSpec(num_heads=28, num_kv_heads=4, head_dim=128), other)
-    assert op.launch_config(block_seq=256, max_context_len=4224, requires_attention_scores=False, batch_size=256) == (256, 16, 2)
+    other = DeviceCaps(platform=PlatformEnum.ROCM, device_type="cuda", device_index=0, device_name="AMD Instinct MI300X",
+                       arch="gfx942", num_cus=304)
+    op = prepared(28, 4, other)
+    assert op.name == "default_gqa" and not op.accepts_batch_size
+    assert op.launch_config(block_seq=256, max_context_len=4224, requires_attention_scores=False) == (256, 16, 2)
 
 
 def test_snapkv_streamingllm_quest_capacity_hooks_match_reference():

@@ -52,7 +52,7 @@ class SyntheticDecodeDriver(SparseDecodeDriver):
                         cm.kv_cache[kv, layer_idx, s0:s1].copy_(blk.to(torch.bfloat16))
         if paged and fill_kv:
             # min/max metadata of every complete page, as prefill would have left it
-            from ..kernels import quest_ops
+            from sparse_vllm_amd.kernels import quest_ops
             pages = []
             for s in self.seqs:
                 row = cm.seq_id_to_row[s.seq_id]
