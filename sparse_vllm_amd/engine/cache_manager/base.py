@@ -227,6 +227,50 @@ class CacheManager(ABC):
         """base.py:1326-1329."""
         return 0
 
+    def prefill_execution_mode(self, seq) -> str:
+        """base.py:1255-1258: every method of this build prefills in chunks (full-prompt staging and RawKV offload belong
+        to PyramidKV / DeltaKV staging, outside SURVEY section 8)."""
+        return "chunked"
+
+    def prefill_batch_compatibility_key(self, seq) -> object:
+        """base.py:1285-1288."""
+        return None
+
+    def should_schedule_full_prefill(self, seq) -> bool:
+        """base.py:1309-1311."""
+        return False
+
+    def requires_full_prefill_step(self, seq) -> bool:
+        """base.py:1313-1315."""
+        return False
+
+    def requires_long_prefill_offload(self, seq) -> bool:
+        """base.py:1338-1340."""
+        return False
+
+    def reset_prefill_execution_state(self, seq_id: int) -> None:
+        """base.py:1277-1280 (nothing sticky without the RawKV offload mode)."""
+        return None
+
+    def complete_prefill_execution(self, seq) -> None:
+        """base.py:1282-1283."""
+        self.reset_prefill_execution_state(int(seq.seq_id))
+
+    def on_prompt_admitted(self, seq, costs: dict) -> None:
+        """base.py:1395-1397."""
+        return None
+
+    def refresh_prefix_cache_hit(self, seq) -> None:
+        """base.py:1399: no prefix cache in this build (SURVEY section 2 marks it out of scope)."""
+        return None
+
+    def clear_prefix_cache_hit(self, seq) -> None:
+        return None
+
+    def free_slot_stats(self) -> dict:
+        """base.py:1453-1455."""
+        return {"free_slots": int(self.num_free_slots)}
+
     def reserved_prefill_slots(self, waiting_seqs, chunk_prefill_size: int) -> int:
         """Slots still owed to prompts that are part-way through their prefill."""
         total = 0

@@ -1550,6 +1550,20 @@ def gen_operator_registry():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+def gen_step_planner():
+    """The reference's `Scheduler.schedule` (engine/scheduler.py:398-792) answering tests/planner_scenarios.py: scripted
+    MemoryOracle, plain sequences; per step which sequences run with which chunk sizes, the queue orders, exception texts."""
+    import json
+    sys.path.insert(0, os.path.dirname(HERE))
+    import planner_scenarios as ps
+    from sparsevllm.engine.scheduler import Scheduler
+    out = ps.run_all(SimpleNamespace(make=lambda cfg, oracle: Scheduler(cfg, oracle)))
+    path = os.path.join(HERE, "step_planner.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 GROUPS = {
     "decode_alloc": gen_decode_alloc,
     "decode": gen_decode,
@@ -1572,6 +1586,7 @@ GROUPS = {
     "capacity_others": gen_capacity_others,
     "attention_hooks": gen_attention_hooks,
     "operator_registry": gen_operator_registry,
+    "step_planner": gen_step_planner,
 }
 
 
