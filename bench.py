@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--max-model-len", type=int, default=131072, help="row stride of the slot table / score tensor")
     ap.add_argument("--no-paths", action="store_true", help="skip the other configurations' decode-step timings")
     ap.add_argument("--path-steps", type=int, default=24)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (tools/e2e_decoder.py in child processes)")
+    ap.add_argument("--e2e", action="store_true", help="run ONLY the end-to-end leg and print its lines (one per batch / mode)")
+    ap.add_argument("--tp", type=int, default=0, help="tensor-parallel degree of the end-to-end leg (0: 1 on one GPU, else "
+                    "the largest of 2 / 4 that divides the GPU count: Qwen2.5-7B has 4 KV heads)")
+    ap.add_argument("--e2e-batches", default="", help="comma list; default 1,64,256 on one GPU, 64 under tensor parallelism")
     ap.add_argument("--stub-driver", action="store_true",
                     help="tests only: a stand-in decode driver that never touches a GPU (gloo ranks, a step = a fixed sleep of "
                          "rank + 1 ms) so that the launch / rendezvous / aggregation plumbing of --gpus N runs on CPU")
@@ -213,6 +218,52 @@ def _paths_in_child(names, steps: int, timeout_s: int = 240) -> list[dict]:
     return [got.get(n) or {"config": n, "error": note or "not reported by the pathbench child"} for n in names]
 
 
+def _e2e_in_child(args, world: int, rank: int, local_rank: int, timeout_s: int = 200) -> list[dict]:
+    """The end-to-end leg (tools/e2e_decoder.py) in a CHILD process per rank, after this process has released its GPU
+    memory: a random-weight Qwen2.5-7B-shaped decoder (torch dense layers) around this build's attention path.  One GPU:
+    tp=1 at B in {1, 64, 256}.  N GPUs: tensor-parallel groups (RCCL all-reduce after o_proj / down_proj) x replicas, the
+    children rendezvous on their own port.  Bounded by `timeout_s`; whatever happens in there - an exception, a hang in a
+    collective - the headline measurement of this process is already taken and is printed afterwards.  -> parsed lines."""
+    import subprocess
+    tp = int(args.tp) or (1 if world == 1 else (4 if world % 4 == 0 else 2))
+    batches = args.e2e_batches or ("1,64,256" if tp == 1 else "64")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_decoder.py"), "--tp", str(tp), "--batches", batches,
+           "--steps", "24", "--warmup", "3", "--modes", "graph" if world == 1 else "eager,graph"]
+    env = dict(os.environ)
+    if world > 1:
+        env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23))
+    else:
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+    lines, note = [], None
+
+    def take(stdout):
+        for line in (stdout or "").splitlines():
+            if line.startswith("{"):
+                try:
+                    lines.append(json.loads(line))
+                except ValueError:
+                    pass
+
+    try:
+        r = subprocess.run(cmd, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True,
+                           env=env)
+        take(r.stdout)
+        if r.returncode != 0:
+            tail = [l for l in r.stderr.strip().splitlines() if l and "amdgpu.ids" not in l][-1:] or [""]
+            note = f"e2e child exited with {r.returncode}: {tail[0][:200]}"
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout
+        take(out.decode(errors="replace") if isinstance(out, bytes) else out)
+        note = f"e2e child timed out after {timeout_s} s"
+    except OSError as e:
+        note = f"e2e child failed to start: {e}"
+    if note:
+        lines.append({"e2e": True, "error": note})
+    return lines
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -232,6 +283,11 @@ def main():
     if args.gpus != world:
         print(f"[bench] --gpus {args.gpus} does not match WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    if args.e2e:
+        for line in _e2e_in_child(args, world, rank, local_rank, timeout_s=900):
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+        return
     stub = bool(args.stub_driver)
     if stub:
         args.no_cpu_baseline = args.no_kernel_events = args.no_paths = True
@@ -433,6 +489,22 @@ def main():
                 "ms_per_step": b64.get("ms_per_step"), "tokens_per_s": b64.get("tokens_per_s"),
                 "step_frac_of_hbm_peak": b64.get("roofline_frac"), "stage1_kernel_us": b64.get("kernel_us"),
                 "stage1_kernel_frac_of_hbm_peak": b64.get("kernel_frac")}
+    if not stub and not args.no_e2e:
+        # end-to-end decode tokens/s as BASELINE.json words the metric, beside the unchanged headline: dense
+        # layers are plain torch GEMMs (outside this build's scope), the attention is this build's path
+        drv = cm = q = k = v = None          # release this process's KV pool before the children start
+        record["calls"].clear()
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        if use_dist:
+            dist.barrier()
+        e2e = _e2e_in_child(args, n_gpus, rank, local_rank)
+        if use_dist:
+            dist.barrier()
+        out["e2e"] = {"note": "random-weight Qwen2.5-7B-shaped decoder, torch F.linear / rms_norm / RoPE around this build's "
+                              "attention path (tools/e2e_decoder.py); bound_ms = (14.1 GB + B x 0.243 GB) / tp / 8 TB/s "
+                              "(BASELINE.md section 2); the dense layers are not part of this build", "runs": e2e}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
