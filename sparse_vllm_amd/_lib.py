@@ -64,7 +64,7 @@ class SvkFlashDecodeStage2Args(C.Structure):
                 ("mid_o_stride_b", _i64), ("mid_o_stride_h", _i64), ("mid_o_stride_s", _i64),
                 ("mid_lse_stride_b", _i64), ("mid_lse_stride_h", _i64), ("o_stride_b", _i64), ("o_stride_h", _i64),
                 ("batch", _i32), ("num_q_heads", _i32), ("head_dim", _i32), ("block_seq", _i32), ("extra_partials", _i32),
-                ("max_partials", _i32)]
+                ("max_partials", _i32), ("split_ws", _p), ("split_ws_bytes", _i64)]
 
 
 class SvkH2oDecodeScoreArgs(C.Structure):
@@ -295,6 +295,7 @@ ENTRY_POINTS = {
     "svk_copy_slots": ([C.POINTER(SvkCopySlotsArgs), _p], C.c_int),
     "svk_flash_decode_stage1": ([C.POINTER(SvkFlashDecodeStage1Args), _p], C.c_int),
     "svk_flash_decode_stage2": ([C.POINTER(SvkFlashDecodeStage2Args), _p], C.c_int),
+    "svk_flash_decode_stage2_split_workspace_bytes": ([C.c_int32, C.c_int32, C.c_int32, C.c_int32], C.c_int64),
     "svk_kivi_decode_stage1_extra_partials": ([C.POINTER(SvkKiviDecodeStage1Args)], C.c_int32),
     "svk_fill_f32": ([_p, _i64, _f32, _p], C.c_int),
     "svk_h2o_decode_score_update": ([C.POINTER(SvkH2oDecodeScoreArgs), _p], C.c_int),

@@ -481,6 +481,113 @@ decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
   *reinterpret_cast<uint2*>(a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d) = make_uint2(w0, w1);
 }
 
+// ---- two-level merge (launches with many partials per row: KIVI full layers at 256 k tokens, one-row launches)
+// The one-level kernel above gives a (row, head) ONE workgroup: 259 partials x 516 B are 134 KB through one CU, 28
+// workgroups on a 256-CU chip - 29 us per KIVI layer at 1 x 256 k, 11 % of a DeltaKV decode step.  Here workgroup
+// (b, h, s) merges the kSplitPPW partials [s * kSplitPPW, ...) into a second-level partial of the same form (normalised
+// row + lse) in the caller's workspace, takes a ticket, and the LAST workgroup of the (b, h) to arrive merges the
+// second-level partials in index order - whoever that is, the sums are formed in the same order - and writes the output.
+// Tickets live in the workspace (zero before the first launch; the last arriver leaves its ticket at zero again).
+constexpr int kSplitPPW = 32;          // partials per first-level workgroup
+constexpr int kSplitMin = 128;         // launches that may merge more partials than this per row take the two-level form
+
+__host__ __device__ inline int64_t split_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
+__host__ __device__ inline int split_groups(int max_partials) { return (max_partials + kSplitPPW - 1) / kSplitPPW; }
+
+template <int D>
+__global__ void __launch_bounds__(256)
+decode_stage2_split_kernel(const SvkFlashDecodeStage2Args a) {
+  constexpr int THREADS = 256, LPR = D / 4, GROUPS = THREADS / LPR, WAVES = THREADS / 64, KPRE = kSplitPPW / GROUPS;
+  static_assert(kSplitPPW % GROUPS == 0, "a workgroup's partials are whole rounds of its lane groups");
+  __shared__ float s_red[WAVES], s_l[GROUPS];
+  __shared__ __attribute__((aligned(16))) float s_acc[GROUPS][D];
+  __shared__ int s_last;
+  const int b = blockIdx.x, h = blockIdx.y, s = blockIdx.z;
+  const int g = threadIdx.x / LPR, d = (threadIdx.x % LPR) * 4;
+  const int len = a.b_seqlen[b];
+  const int nblk = len <= 0 ? 0 : (len + a.block_seq - 1) / a.block_seq + a.extra_partials;
+  const int s_row = max(1, (nblk + kSplitPPW - 1) / kSplitPPW);       // first-level workgroups this row needs
+  if (s >= s_row) return;
+  const int smax = split_groups(a.max_partials);
+  const int64_t n_bh = (int64_t)gridDim.x * gridDim.y, bh = (int64_t)b * gridDim.y + h;
+  unsigned char* ws = static_cast<unsigned char*>(a.split_ws);
+  int* tickets = reinterpret_cast<int*>(ws);
+  float* ws_lse = reinterpret_cast<float*>(ws + split_align(n_bh * 4)) + bh * smax;
+  float* ws_o = reinterpret_cast<float*>(ws + split_align(n_bh * 4) + split_align(n_bh * smax * 4)) + bh * smax * D;
+  const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h + d;
+  const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
+  int64_t stride = a.mid_o_stride_s;
+  int first = s * kSplitPPW, count = min(nblk - first, kSplitPPW);
+  for (int level = 0; level < 2; ++level) {
+    // merge rows [first, first + count) of (mo, ml): all loads of the round in flight together, the maximum reduced under them
+    float4 tv[KPRE];
+    float lv[KPRE];
+#pragma unroll
+    for (int j = 0; j < KPRE; ++j) {
+      const int i = g + j * GROUPS;
+      tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      lv[j] = -INFINITY;
+      if (i < count) {
+        tv[j] = *reinterpret_cast<const float4*>(mo + (int64_t)(first + i) * stride);
+        lv[j] = ml[first + i];
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KPRE; ++j) mx = fmaxf(mx, lv[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) mx = fmaxf(mx, s_red[w]);
+    float sum = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < KPRE; ++j) {
+      if (g + j * GROUPS < count) {
+        const float e = __expf(lv[j] - mx);
+        acc.x += e * tv[j].x; acc.y += e * tv[j].y; acc.z += e * tv[j].z; acc.w += e * tv[j].w;
+        sum += e;
+      }
+    }
+    if (d == 0) s_l[g] = sum;
+    *reinterpret_cast<float4*>(&s_acc[g][d]) = acc;
+    __syncthreads();
+    if (g == 0) {
+      const int used = min(max(count, 1), GROUPS);
+      for (int j = 1; j < used; ++j) {
+        const float4 t2 = *reinterpret_cast<const float4*>(&s_acc[j][d]);
+        acc.x += t2.x; acc.y += t2.y; acc.z += t2.z; acc.w += t2.w;
+        sum += s_l[j];
+      }
+      if (level == 1 || s_row == 1) {
+        const uint32_t w0 = f32_to_bf16_bits(acc.x / sum) | (f32_to_bf16_bits(acc.y / sum) << 16);
+        const uint32_t w1 = f32_to_bf16_bits(acc.z / sum) | (f32_to_bf16_bits(acc.w / sum) << 16);
+        *reinterpret_cast<uint2*>(a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d) = make_uint2(w0, w1);
+      } else {
+        *reinterpret_cast<float4*>(ws_o + (int64_t)s * D + d) = make_float4(acc.x / sum, acc.y / sum, acc.z / sum, acc.w / sum);
+        if (d == 0) ws_lse[s] = mx + __logf(sum);
+      }
+    }
+    if (level == 1 || s_row == 1) return;
+    // hand-over: this workgroup's second-level partial is published (agent-scope release) before its ticket is taken; the
+    // last arriver acquires before it reads the others' partials (per-XCD L2s are not coherent: MI355X_MICROARCH.md)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[bh], 1) == s_row - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) tickets[bh] = 0;            // self-cleaning for the next launch
+    mo = ws_o + d;
+    ml = ws_lse;
+    stride = D;
+    first = 0;
+    count = s_row;                                     // <= kSplitPPW (checked by the launcher)
+  }
+}
+
 template <int D, int G>
 int launch_stage1(const SvkFlashDecodeStage1Args& a, hipStream_t stream) {
   using C = Stage1Cfg<D, G>;
@@ -569,6 +676,14 @@ extern "C" int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_st
   return a->head_dim == 128 ? dispatch_group<128>(*a, G, s) : dispatch_group<64>(*a, G, s);
 }
 
+extern "C" int64_t svk_flash_decode_stage2_split_workspace_bytes(int32_t batch, int32_t num_q_heads, int32_t head_dim,
+                                                                  int32_t max_partials) {
+  using namespace svk;
+  if (batch <= 0 || num_q_heads <= 0 || max_partials <= kSplitMin || max_partials > kSplitPPW * kSplitPPW) return 0;
+  const int64_t n_bh = (int64_t)batch * num_q_heads, smax = split_groups(max_partials);
+  return split_align(n_bh * 4) + split_align(n_bh * smax * 4) + split_align(n_bh * smax * head_dim * 4);
+}
+
 extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_stream_t stream) {
   using namespace svk;
   SVK_REQUIRE(a != nullptr, SVK_ERR_VALUE, "svk_flash_decode_stage2: null args");
@@ -589,6 +704,15 @@ extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_st
   // (max_partials), not the workspace's capacity: the two forms add in different orders, so the output bits of a step
   // must not depend on what an earlier, longer launch grew the shared workspace to.
   SVK_REQUIRE(a->max_partials >= 0, SVK_ERR_VALUE, "svk_flash_decode_stage2: max_partials %d must be >= 0", a->max_partials);
+  if (a->split_ws != nullptr && a->max_partials > kSplitMin && a->max_partials <= kSplitPPW * kSplitPPW &&
+      a->split_ws_bytes >= svk_flash_decode_stage2_split_workspace_bytes(a->batch, a->num_q_heads, a->head_dim, a->max_partials)) {
+    SVK_REQUIRE((reinterpret_cast<uintptr_t>(a->split_ws) % 256) == 0, SVK_ERR_LAYOUT,
+                "svk_flash_decode_stage2: split_ws must be 256-byte aligned");
+    dim3 grid3(a->batch, a->num_q_heads, split_groups(a->max_partials));
+    if (a->head_dim == 128) hipLaunchKernelGGL((decode_stage2_split_kernel<128>), grid3, dim3(256), 0, s, *a);
+    else hipLaunchKernelGGL((decode_stage2_split_kernel<64>), grid3, dim3(256), 0, s, *a);
+    return check_launch("svk_flash_decode_stage2");
+  }
   const bool wide = (a->max_partials > 0 ? (int64_t)a->max_partials : a->mid_lse_stride_h) > 128;
   if (a->head_dim == 128) {
     if (wide) hipLaunchKernelGGL((decode_stage2_kernel<128, 1024>), grid, dim3(1024), 0, s, *a);

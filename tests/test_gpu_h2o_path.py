@@ -530,3 +530,48 @@ def test_split_kv_merge_many_partials_vs_float64(case):
     flash_decode_stage2(mid.to(d), lse.to(d), lens.to(d), o1, block_seq)
     torch.cuda.synchronize()
     np.testing.assert_allclose(o1.float().cpu().numpy(), ref, rtol=2 ** -7, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", [dict(B=1, Hq=28, D=128, nblk=259, block_seq=1024, extra=3), dict(B=4, Hq=28, D=128, nblk=132, block_seq=32),
+                                  dict(B=2, Hq=14, D=64, nblk=1024, block_seq=16), dict(B=3, Hq=7, D=128, nblk=129, block_seq=64),
+                                  dict(B=2, Hq=28, D=128, nblk=520, block_seq=512, extra=3)])
+def test_two_level_split_kv_merge(case, monkeypatch):
+    """Launches with more than 128 partials per row: the two-level merge (32 partials per first-level workgroup, the last
+    arriver of a (row, head) merges the second level and resets the ticket) against the float64 merge and against the
+    one-level kernel (`SVK_STAGE2_SPLIT=0`); ragged rows (rows with 1, 31, 32, 33 partials beside full ones: some first-level
+    workgroups have nothing to do, single-group rows skip the second level), extra partials, three launches in a row on
+    the same workspace (tickets self-clean: identical bits every time)."""
+    from sparse_vllm_amd.kernels import flash_decode_stage2
+    B, Hq, D, nblk, block_seq = (case[k] for k in ("B", "Hq", "D", "nblk", "block_seq"))
+    extra = case.get("extra", 0)
+    d = dev()
+    g = torch.Generator(device="cpu").manual_seed(nblk + B)
+    reg = nblk - extra
+    lens = torch.tensor([reg * block_seq] + [int(x) for x in (torch.tensor([1, 31, 33, 32])[: B - 1] * block_seq - 3).clamp_min(1)],
+                        dtype=torch.int32)[:B]
+    mid = torch.randn(B, Hq, nblk, D, generator=g)
+    lse = torch.randn(B, Hq, nblk, generator=g) * 4
+    ref = np.zeros((B, Hq, D))
+    for b in range(B):
+        n = (int(lens[b]) + block_seq - 1) // block_seq + extra
+        w = np.exp(lse[b, :, :n].double().numpy() - lse[b, :, :n].double().numpy().max(axis=1, keepdims=True))
+        ref[b] = (w[:, :, None] * mid[b, :, :n].double().numpy()).sum(axis=1) / w.sum(axis=1, keepdims=True)
+    md, ld, nd = mid.to(d), lse.to(d), lens.to(d)
+    outs = []
+    for _ in range(3):
+        o = torch.full((B, Hq, D), 7.0, dtype=torch.bfloat16, device=d)
+        flash_decode_stage2(md, ld, nd, o, block_seq, extra_partials=extra)
+        torch.cuda.synchronize()
+        outs.append(o.view(torch.int16).cpu().numpy().copy())
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref, rtol=2 ** -7, atol=1e-3)
+    assert (outs[0] == outs[1]).all() and (outs[1] == outs[2]).all()
+    from sparse_vllm_amd.kernels import flash_decoding_stage2 as mod
+    assert mod._SPLIT_WS, "the two-level form was not taken"
+    monkeypatch.setenv("SVK_STAGE2_SPLIT", "0")
+    o1 = torch.empty((B, Hq, D), dtype=torch.bfloat16, device=d)
+    flash_decode_stage2(md, ld, nd, o1, block_seq, extra_partials=extra)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o1.float().cpu().numpy(), ref, rtol=2 ** -7, atol=1e-3)
+    # two summation orders of the same fp32 terms: bf16 outputs agree to an ulp
+    np.testing.assert_allclose(o1.float().cpu().numpy(), outs[0].view(np.int16).astype(np.int32).__lshift__(16).view(np.float32).reshape(B, Hq, D),
+                               rtol=2 ** -7, atol=1e-3)
