@@ -169,18 +169,20 @@ typedef struct SvkFlashDecodeStage2Args {
   int32_t max_partials;          /* partials THIS launch may merge per row (ceil(max_len_in_batch / block_seq) +
                                   * extra_partials); picks the merge's thread geometry.  0 = unknown: the lse row stride
                                   * (the workspace's capacity, which a grow-only workspace inflates) decides instead. */
-  /* Optional two-level merge for launches with many partials per row (max_partials > 128: KIVI full layers at 256 k
+  /* Optional two-level merge for launches with many partials per row (max_partials > 256: KIVI full layers at 256 k
    * tokens, one-row launches in 32-token blocks): with split_ws != NULL and split_ws_bytes >=
    * svk_flash_decode_stage2_split_workspace_bytes(batch, num_q_heads, head_dim, max_partials), workgroup (b, h, s) merges
    * 32 partials into a second-level partial in the workspace and the last workgroup of a (b, h) to arrive (a ticket in the
    * workspace) merges those in index order and writes O - ceil(max_partials / 32) workgroups per (row, head) instead of
-   * one.  The workspace must be 256-byte aligned and ZERO before its first use (the tickets); every launch leaves the
-   * tickets at zero again, the rest is scratch.  One launch at a time per workspace.  NULL / too small = one level. */
+   * one.  split_ws: scratch, 256-byte aligned, contents irrelevant.  split_tickets: [batch * num_q_heads] int32 that are
+   * ZERO before the first launch; every launch leaves them at zero again.  One launch at a time per workspace / ticket
+   * array.  Either pointer NULL, or the scratch too small = one level. */
   void* split_ws;
   int64_t split_ws_bytes;
+  int32_t* split_tickets;
 } SvkFlashDecodeStage2Args;
 int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_stream_t stream);
-/* bytes of split_ws for a launch shape; 0 when the two-level form does not apply (max_partials <= 128 or > 1024). */
+/* bytes of split_ws for a launch shape; 0 when the two-level form does not apply (max_partials <= 256 or > 1024). */
 int64_t svk_flash_decode_stage2_split_workspace_bytes(int32_t batch, int32_t num_q_heads, int32_t head_dim, int32_t max_partials);
 
 /* ------------------------------------------------------------------------------------

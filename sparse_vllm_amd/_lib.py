@@ -64,7 +64,7 @@ class SvkFlashDecodeStage2Args(C.Structure):
                 ("mid_o_stride_b", _i64), ("mid_o_stride_h", _i64), ("mid_o_stride_s", _i64),
                 ("mid_lse_stride_b", _i64), ("mid_lse_stride_h", _i64), ("o_stride_b", _i64), ("o_stride_h", _i64),
                 ("batch", _i32), ("num_q_heads", _i32), ("head_dim", _i32), ("block_seq", _i32), ("extra_partials", _i32),
-                ("max_partials", _i32), ("split_ws", _p), ("split_ws_bytes", _i64)]
+                ("max_partials", _i32), ("split_ws", _p), ("split_ws_bytes", _i64), ("split_tickets", _p)]
 
 
 class SvkH2oDecodeScoreArgs(C.Structure):

@@ -487,9 +487,10 @@ decode_stage2_kernel(const SvkFlashDecodeStage2Args a) {
 // (b, h, s) merges the kSplitPPW partials [s * kSplitPPW, ...) into a second-level partial of the same form (normalised
 // row + lse) in the caller's workspace, takes a ticket, and the LAST workgroup of the (b, h) to arrive merges the
 // second-level partials in index order - whoever that is, the sums are formed in the same order - and writes the output.
-// Tickets live in the workspace (zero before the first launch; the last arriver leaves its ticket at zero again).
+// Tickets are the caller's [batch * heads] int32 (zero before the first launch; the last arriver leaves its ticket at zero
+// again) - NOT part of the scratch, whose layout moves with the launch shape.
 constexpr int kSplitPPW = 32;          // partials per first-level workgroup
-constexpr int kSplitMin = 128;         // launches that may merge more partials than this per row take the two-level form
+constexpr int kSplitMin = 256;         // launches that may merge more partials than this per row take the two-level form
 
 __host__ __device__ inline int64_t split_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
 __host__ __device__ inline int split_groups(int max_partials) { return (max_partials + kSplitPPW - 1) / kSplitPPW; }
@@ -511,9 +512,9 @@ decode_stage2_split_kernel(const SvkFlashDecodeStage2Args a) {
   const int smax = split_groups(a.max_partials);
   const int64_t n_bh = (int64_t)gridDim.x * gridDim.y, bh = (int64_t)b * gridDim.y + h;
   unsigned char* ws = static_cast<unsigned char*>(a.split_ws);
-  int* tickets = reinterpret_cast<int*>(ws);
-  float* ws_lse = reinterpret_cast<float*>(ws + split_align(n_bh * 4)) + bh * smax;
-  float* ws_o = reinterpret_cast<float*>(ws + split_align(n_bh * 4) + split_align(n_bh * smax * 4)) + bh * smax * D;
+  int* tickets = a.split_tickets;
+  float* ws_lse = reinterpret_cast<float*>(ws) + bh * smax;
+  float* ws_o = reinterpret_cast<float*>(ws + split_align(n_bh * smax * 4)) + bh * smax * D;
   const float* mo = a.mid_o + (int64_t)b * a.mid_o_stride_b + (int64_t)h * a.mid_o_stride_h + d;
   const float* ml = a.mid_lse + (int64_t)b * a.mid_lse_stride_b + (int64_t)h * a.mid_lse_stride_h;
   int64_t stride = a.mid_o_stride_s;
@@ -528,8 +529,20 @@ decode_stage2_split_kernel(const SvkFlashDecodeStage2Args a) {
       tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       lv[j] = -INFINITY;
       if (i < count) {
-        tv[j] = *reinterpret_cast<const float4*>(mo + (int64_t)(first + i) * stride);
-        lv[j] = ml[first + i];
+        if (level == 0) {
+          tv[j] = *reinterpret_cast<const float4*>(mo + (int64_t)(first + i) * stride);
+          lv[j] = ml[first + i];
+        } else {
+          // other workgroups' second-level partials: agent-scope (sc1) loads - coherent across CUs and XCDs without an
+          // acquire fence (1.7 us) in front of them
+          uint64_t* p = reinterpret_cast<uint64_t*>(const_cast<float*>(mo) + (int64_t)(first + i) * stride);
+          const uint64_t x0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t x1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tv[j] = make_float4(__uint_as_float((uint32_t)x0), __uint_as_float((uint32_t)(x0 >> 32)),
+                              __uint_as_float((uint32_t)x1), __uint_as_float((uint32_t)(x1 >> 32)));
+          lv[j] = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(const_cast<float*>(ml)) + first + i,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
       }
     }
     float mx = -INFINITY;
@@ -566,20 +579,29 @@ decode_stage2_split_kernel(const SvkFlashDecodeStage2Args a) {
         const uint32_t w1 = f32_to_bf16_bits(acc.z / sum) | (f32_to_bf16_bits(acc.w / sum) << 16);
         *reinterpret_cast<uint2*>(a.o + (int64_t)b * a.o_stride_b + (int64_t)h * a.o_stride_h + d) = make_uint2(w0, w1);
       } else {
-        *reinterpret_cast<float4*>(ws_o + (int64_t)s * D + d) = make_float4(acc.x / sum, acc.y / sum, acc.z / sum, acc.w / sum);
-        if (d == 0) ws_lse[s] = mx + __logf(sum);
+        // write-through (sc1) stores: visible to every CU / XCD once they have completed - no release fence, whose L2
+        // write-back of everything stage 1 has just written cost 13 us per launch
+        uint64_t* p = reinterpret_cast<uint64_t*>(ws_o + (int64_t)s * D + d);
+        const float o0 = acc.x / sum, o1 = acc.y / sum, o2 = acc.z / sum, o3 = acc.w / sum;
+        __hip_atomic_store(p, (uint64_t)__float_as_uint(o0) | ((uint64_t)__float_as_uint(o1) << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, (uint64_t)__float_as_uint(o2) | ((uint64_t)__float_as_uint(o3) << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        if (d == 0)
+          __hip_atomic_store(reinterpret_cast<uint32_t*>(ws_lse) + s, __float_as_uint(mx + __logf(sum)), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (level == 1 || s_row == 1) return;
-    // hand-over: this workgroup's second-level partial is published (agent-scope release) before its ticket is taken; the
-    // last arriver acquires before it reads the others' partials (per-XCD L2s are not coherent: MI355X_MICROARCH.md)
-    __threadfence();
+    // hand-over (cdna_hip_programming.md, guideline 16, R1): every storing wave drains its stores, then ONE lane takes the
+    // ticket; the last arriver reads the others' partials with agent-scope loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[bh], 1) == s_row - 1;
+    if (threadIdx.x == 0)
+      s_last = __hip_atomic_fetch_add(&tickets[bh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s_row - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x == 0) tickets[bh] = 0;            // self-cleaning for the next launch
+    if (threadIdx.x == 0) __hip_atomic_store(&tickets[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning
     mo = ws_o + d;
     ml = ws_lse;
     stride = D;
@@ -681,7 +703,7 @@ extern "C" int64_t svk_flash_decode_stage2_split_workspace_bytes(int32_t batch, 
   using namespace svk;
   if (batch <= 0 || num_q_heads <= 0 || max_partials <= kSplitMin || max_partials > kSplitPPW * kSplitPPW) return 0;
   const int64_t n_bh = (int64_t)batch * num_q_heads, smax = split_groups(max_partials);
-  return split_align(n_bh * 4) + split_align(n_bh * smax * 4) + split_align(n_bh * smax * head_dim * 4);
+  return split_align(n_bh * smax * 4) + split_align(n_bh * smax * head_dim * 4);
 }
 
 extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_stream_t stream) {
@@ -704,7 +726,7 @@ extern "C" int svk_flash_decode_stage2(const SvkFlashDecodeStage2Args* a, svk_st
   // (max_partials), not the workspace's capacity: the two forms add in different orders, so the output bits of a step
   // must not depend on what an earlier, longer launch grew the shared workspace to.
   SVK_REQUIRE(a->max_partials >= 0, SVK_ERR_VALUE, "svk_flash_decode_stage2: max_partials %d must be >= 0", a->max_partials);
-  if (a->split_ws != nullptr && a->max_partials > kSplitMin && a->max_partials <= kSplitPPW * kSplitPPW &&
+  if (a->split_ws != nullptr && a->split_tickets != nullptr && a->max_partials > kSplitMin && a->max_partials <= kSplitPPW * kSplitPPW &&
       a->split_ws_bytes >= svk_flash_decode_stage2_split_workspace_bytes(a->batch, a->num_q_heads, a->head_dim, a->max_partials)) {
     SVK_REQUIRE((reinterpret_cast<uintptr_t>(a->split_ws) % 256) == 0, SVK_ERR_LAYOUT,
                 "svk_flash_decode_stage2: split_ws must be 256-byte aligned");

@@ -381,6 +381,145 @@ __global__ void __launch_bounds__(256) dequant_linear_act_k256_kernel(const SvkD
   sub_tile(3, wb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same tile for launches with many row tiles (B >= 2 DeltaKV batches: 8192 rows x 2 layers).  Above, every
+// workgroup fetches its 256 features' weights (128 KB) for ONE 64-row tile: 2048 workgroups x 128 KB = 268 MB of L2 reads
+// per launch against 67 MB of output - the launch ran at the L2's delivery rate (69 us at 2 x 8192 rows, 250 TFLOP/s).
+// Here a workgroup keeps the weights of all four sub-tiles in registers (128 VGPRs) and walks `tiles` row tiles
+// (blockIdx.y, + gridDim.y, ...), the codes / scales of the next tile in flight under the current one: weight traffic
+// divided by `tiles`, same arithmetic element for element (bit-identical outputs).
+// ------------------------------------------------------------------------------------------------
+template <bool GELU>
+__global__ void __launch_bounds__(256) dequant_linear_act_k256_rows_kernel(const SvkDequantLinearArgs a_in, const SvkDequantLinearBatch lb,
+                                                                           int row_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];      // [kM2][kLdx2] bf16 | 2 x [kM2][kLdy2] bf16
+  SvkDequantLinearArgs a = a_in;
+  if (gridDim.z > 1) {
+    const int64_t z = blockIdx.z;
+    a.packed += z * lb.packed_stride_batch;
+    a.scale = reinterpret_cast<const uint16_t*>(a.scale) + z * lb.scale_stride_batch;
+    a.mn = reinterpret_cast<const uint16_t*>(a.mn) + z * lb.scale_stride_batch;
+    a.weight += z * lb.weight_stride_batch;
+    if (a.bias != nullptr) a.bias += z * lb.bias_stride_batch;
+    a.out += z * lb.out_stride_batch;
+  }
+  constexpr int K = 256, KS = K / 32;
+  const int nb0 = blockIdx.x * (kSub * kNSub);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, kc = lane >> 4;
+  uint16_t* ys = xs + kM2 * kLdx2;
+  // weights of the workgroup's 256 features: lane (fr, kc) of wave w holds row nb0 + ns*64 + w*16 + fr, K chunks kc*8 + ks*32
+  uint4 wf[kNSub][KS];
+#pragma unroll
+  for (int ns = 0; ns < kNSub; ++ns) {
+    const int n = min(nb0 + ns * kSub + w * 16 + fr, a.n - 1);            // clamped: features past N are never stored
+    const uint16_t* wr = a.weight + (int64_t)n * a.weight_stride + kc * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[ns][ks] = *reinterpret_cast<const uint4*>(wr + ks * 32);
+  }
+  float bias[kNSub][4];
+#pragma unroll
+  for (int ns = 0; ns < kNSub; ++ns)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nb0 + ns * kSub + w * 16 + kc * 4 + r;
+      bias[ns][r] = (a.bias != nullptr && n < a.n) ? __builtin_bit_cast(float, (uint32_t)a.bias[n] << 16) : 0.f;
+    }
+  // codes / scales of one 64-row tile: four threads per row, 64 codes (two groups) each
+  const int r_own = tid >> 2, qd = tid & 3;
+  uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+  uint32_t sv = 0, mv = 0;
+  bool live = false;
+  auto fetch = [&](int tile) {
+    const int row = tile * kM2 + r_own;
+    live = tile < row_tiles && row < a.rows;
+    if (live) {
+      const int64_t src = a.row_index ? max(a.row_index[row], 0) : row;
+      const int32_t* pw = a.packed + src * a.packed_stride + qd * 8;
+      c0 = *reinterpret_cast<const uint4*>(pw);
+      c1 = *reinterpret_cast<const uint4*>(pw + 4);
+      sv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.scale) + src * a.scale_stride + qd * 2);
+      mv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.mn) + src * a.scale_stride + qd * 2);
+    }
+  };
+  const uint16_t* xrow = xs + fr * kLdx2 + kc * 8;
+  const bool vec_out = (a.out_stride % 8) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16) == 0;
+  fetch(blockIdx.y);
+  for (int tile = blockIdx.y; tile < row_tiles; tile += gridDim.y) {
+    const int m0 = tile * kM2;
+    __syncthreads();                                   // the previous tile's products have read xs, its stores have read ys
+    {
+      uint16_t* dst = xs + r_own * kLdx2 + qd * 64;
+      if (live) {
+        const float scs[2] = {bf16_lo(sv), bf16_hi(sv)}, mns[2] = {bf16_lo(mv), bf16_hi(mv)};
+        const uint32_t wd[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float sc = scs[u >> 2], mn = mns[u >> 2];
+          uint32_t p[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float q0 = (float)((wd[u] >> (8 * e)) & 15u), q1 = (float)((wd[u] >> (8 * e + 4)) & 15u);
+            p[e] = pack2_bf16(add_rn(mul_rn(q0, sc), mn), add_rn(mul_rn(q1, sc), mn));
+          }
+          *reinterpret_cast<uint4*>(dst + u * 8) = make_uint4(p[0], p[1], p[2], p[3]);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<uint4*>(dst + u * 8) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    __syncthreads();
+    fetch(tile + gridDim.y);                           // next tile's codes travel under this tile's products and epilogues
+#pragma unroll
+    for (int ns = 0; ns < kNSub; ++ns) {
+      const int n0 = nb0 + ns * kSub;
+      if (n0 >= a.n) break;                            // (uniform over the workgroup)
+      f32x4_t acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8_t bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xrow + j * 16 * kLdx2 + ks * 32));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[ns][ks]), bfr[j], acc[j], 0, 0, 0);
+      }
+      const int nl = w * 16 + kc * 4;
+      uint16_t* yb = ys + (ns & 1) * (kM2 * kLdy2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = bf16_round(acc[j][r] + bias[ns][r]);
+          if (GELU) v = mul_rn(mul_rn(v, 0.5f), add_rn(1.0f, erf_fast(mul_rn(v, 0.70710678118654752440f))));
+          y[r] = v;
+        }
+        *reinterpret_cast<uint2*>(yb + (j * 16 + fr) * kLdy2 + nl) = make_uint2(pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3]));
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = tid + u * 256;
+        const int r = c >> 3, seg = c & 7;
+        const int row = m0 + r, n = n0 + seg * 8;
+        if (row >= a.rows || n >= a.n) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(yb + r * kLdy2 + seg * 8);
+        uint16_t* o = a.out + (int64_t)row * a.out_stride + n;
+        if (vec_out && n + 8 <= a.n) {
+          *reinterpret_cast<uint4*>(o) = v;
+        } else {
+          const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 8 && n + e < a.n; ++e) o[e] = (uint16_t)(wd[e >> 1] >> ((e & 1) * 16));
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace svk
 
@@ -416,6 +555,16 @@ int launch_dequant_linear_act(const SvkDequantLinearArgs* a, const SvkDequantLin
       (lb.n_batch == 1 || lb.scale_stride_batch % 2 == 0)) {
     const dim3 grid2((a->n + kSub * kNSub - 1) / (kSub * kNSub), (a->rows + kM2 - 1) / kM2, lb.n_batch);
     const size_t shm2 = sizeof(uint16_t) * (kM2 * kLdx2 + 2 * kM2 * kLdy2);
+    // many row tiles: workgroups that keep their weights and walk several row tiles, two workgroups per CU
+    static const bool rows_form = getenv("SVK_DQL_ROWS") == nullptr || atoi(getenv("SVK_DQL_ROWS")) != 0;
+    const int row_tiles = (int)grid2.y;
+    const int groups = max(1, 512 / (int)(grid2.x * grid2.z));
+    if (rows_form && row_tiles >= 2 * groups) {
+      const dim3 grid3(grid2.x, groups, grid2.z);
+      if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_k256_rows_kernel<true>), grid3, block, shm2, s, *a, lb, row_tiles);
+      else hipLaunchKernelGGL((dequant_linear_act_k256_rows_kernel<false>), grid3, block, shm2, s, *a, lb, row_tiles);
+      return check_launch(who);
+    }
     if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_k256_kernel<true>), grid2, block, shm2, s, *a, lb);
     else hipLaunchKernelGGL((dequant_linear_act_k256_kernel<false>), grid2, block, shm2, s, *a, lb);
     return check_launch(who);

@@ -532,11 +532,11 @@ def test_split_kv_merge_many_partials_vs_float64(case):
     np.testing.assert_allclose(o1.float().cpu().numpy(), ref, rtol=2 ** -7, atol=1e-3)
 
 
-@pytest.mark.parametrize("case", [dict(B=1, Hq=28, D=128, nblk=259, block_seq=1024, extra=3), dict(B=4, Hq=28, D=128, nblk=132, block_seq=32),
-                                  dict(B=2, Hq=14, D=64, nblk=1024, block_seq=16), dict(B=3, Hq=7, D=128, nblk=129, block_seq=64),
+@pytest.mark.parametrize("case", [dict(B=1, Hq=28, D=128, nblk=260, block_seq=1024, extra=3), dict(B=4, Hq=28, D=128, nblk=300, block_seq=32),
+                                  dict(B=2, Hq=14, D=64, nblk=1024, block_seq=16), dict(B=3, Hq=7, D=128, nblk=257, block_seq=64),
                                   dict(B=2, Hq=28, D=128, nblk=520, block_seq=512, extra=3)])
 def test_two_level_split_kv_merge(case, monkeypatch):
-    """Launches with more than 128 partials per row: the two-level merge (32 partials per first-level workgroup, the last
+    """Launches with more than 256 partials per row: the two-level merge (32 partials per first-level workgroup, the last
     arriver of a (row, head) merges the second level and resets the ticket) against the float64 merge and against the
     one-level kernel (`SVK_STAGE2_SPLIT=0`); ragged rows (rows with 1, 31, 32, 33 partials beside full ones: some first-level
     workgroups have nothing to do, single-group rows skip the second level), extra partials, three launches in a row on
