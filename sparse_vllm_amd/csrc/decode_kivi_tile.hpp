@@ -770,6 +770,24 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       f32x4_t s[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      // the eight operand words and the per-channel parameters of a chunk are read from LDS together at the top of the
+      // chunk (written out word by word inside the dequantisation, hipcc waited for every ds_read four instructions after
+      // issuing it).  Reading chunk c + 1 under chunk c (software pipeline, with or without a scheduling barrier), in this
+      // build or in a 256-thread-bound one that has the whole register file of a SIMD for its single wave (487 registers, no
+      // spill), was measured and is not faster: 59-61 us against 57 us at 1 x 256 k, 174-184 against 165 us at 4 x
+      // (profiles/r05/kivi_pipe_ab.txt).
+      constexpr bool kPipe = false;
+      uint32_t kwq[2][8];
+      float4 kpq[2][4];
+      auto read_k_chunk = [&](int c, uint32_t (&kw)[8], float4 (&kp)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kw[e] = *reinterpret_cast<const uint32_t*>(kl + c * 512 + (8 * (e >> 2) + (e & 3)) * 16);
+        kp[0] = *reinterpret_cast<const float4*>(kpl + c * 128);
+        kp[1] = *reinterpret_cast<const float4*>(kpl + c * 128 + 16);
+        kp[2] = *reinterpret_cast<const float4*>(kpl + 4 * kKParStride + c * 128);
+        kp[3] = *reinterpret_cast<const float4*>(kpl + 4 * kKParStride + c * 128 + 16);
+      };
+      if constexpr (kPipe) read_k_chunk(0, kwq[0], kpq[0]);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         if (c == NC - 2) {
@@ -779,11 +797,14 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
           vsw[0] = s4.x; vsw[1] = s4.y; vsw[2] = s4.z; vsw[3] = s4.w; vmw[0] = m4.x; vmw[1] = m4.y; vmw[2] = m4.z; vmw[3] = m4.w;
         }
         if (c == NC - 1) mp2 = maps4(t0 + 2 * kT);
+        if constexpr (kPipe) {
+          if (c + 1 < NC) read_k_chunk(c + 1, kwq[(c + 1) & 1], kpq[(c + 1) & 1]);
+        } else {
+          read_k_chunk(c, kwq[c & 1], kpq[c & 1]);
+        }
         float sc[8], mn[8];
         {
-          const float4 s0 = *reinterpret_cast<const float4*>(kpl + c * 128), s1 = *reinterpret_cast<const float4*>(kpl + c * 128 + 16);
-          const float4 m0 = *reinterpret_cast<const float4*>(kpl + 4 * kKParStride + c * 128);
-          const float4 m1 = *reinterpret_cast<const float4*>(kpl + 4 * kKParStride + c * 128 + 16);
+          const float4 s0 = kpq[c & 1][0], s1 = kpq[c & 1][1], m0 = kpq[c & 1][2], m1 = kpq[c & 1][3];
           sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
           mn[0] = m0.x; mn[1] = m0.y; mn[2] = m0.z; mn[3] = m0.w; mn[4] = m1.x; mn[5] = m1.y; mn[6] = m1.z; mn[7] = m1.w;
         }
@@ -792,8 +813,8 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
           f32x2_t y0[4], y1[4];
-          nibbles_fp8(*reinterpret_cast<const uint32_t*>(kl + c * 512 + (8 * ((2 * e2) >> 2) + ((2 * e2) & 3)) * 16), y0);
-          nibbles_fp8(*reinterpret_cast<const uint32_t*>(kl + c * 512 + (8 * ((2 * e2 + 1) >> 2) + ((2 * e2 + 1) & 3)) * 16), y1);
+          nibbles_fp8(kwq[c & 1][2 * e2], y0);
+          nibbles_fp8(kwq[c & 1][2 * e2 + 1], y1);
           const float s0 = sc[2 * e2], s1 = sc[2 * e2 + 1];             // already x 2^9
           const f32x2_t sv0 = {s0, s0}, mv0 = {mn[2 * e2], mn[2 * e2]}, sv1 = {s1, s1}, mv1 = {mn[2 * e2 + 1], mn[2 * e2 + 1]};
 #pragma unroll
@@ -832,12 +853,25 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
       if (nxt.ok) issue_k(nxt);                                // next tile's K codes and parameters travel under P.V
       lds_sync();
       // ---------------- P.V: 4 blocks of 32 tokens, 8 MFMAs each (head dims dg*8 + i)
+      uint32_t vwq[2][8];
+      uint4 vpq[2][3];                                          // P fragment, V scales, V mins of a 32-token block
+      auto read_v_block = [&](int j, uint32_t (&vw)[8], uint4 (&vp)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vw[e] = *reinterpret_cast<const uint32_t*>(vl + j * kVBlkStride + e * 64);
+        vp[0] = *reinterpret_cast<const uint4*>(Pl + n * PST + 32 * j + kc * 8);
+        vp[1] = *reinterpret_cast<const uint4*>(Vs + (dg / 4) * kT + 32 * j + kc * 8);
+        vp[2] = *reinterpret_cast<const uint4*>(Vm + (dg / 4) * kT + 32 * j + kc * 8);
+      };
+      if constexpr (kPipe) read_v_block(0, vwq[0], vpq[0]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint4 pa = *reinterpret_cast<const uint4*>(Pl + n * PST + 32 * j + kc * 8);
-        const bf16x8_t pfrag = __builtin_bit_cast(bf16x8_t, pa);
-        const uint4 s8 = *reinterpret_cast<const uint4*>(Vs + (dg / 4) * kT + 32 * j + kc * 8);
-        const uint4 m8 = *reinterpret_cast<const uint4*>(Vm + (dg / 4) * kT + 32 * j + kc * 8);
+        if constexpr (kPipe) {
+          if (j + 1 < 4) read_v_block(j + 1, vwq[(j + 1) & 1], vpq[(j + 1) & 1]);
+        } else {
+          read_v_block(j, vwq[j & 1], vpq[j & 1]);
+        }
+        const bf16x8_t pfrag = __builtin_bit_cast(bf16x8_t, vpq[j & 1][0]);
+        const uint4 s8 = vpq[j & 1][1], m8 = vpq[j & 1][2];
         const uint32_t s8w[4] = {s8.x, s8.y, s8.z, s8.w}, m8w[4] = {m8.x, m8.y, m8.z, m8.w};
         // token pairs (2*e2, 2*e2+1) of the block's k-chunk: 16 codes -> the e2-th operand word of all 8 MFMAs (head dim
         // dg*8 + i takes nibble i).  bf16 scale x 4-bit code is exact in fp32, so the fused multiply-add equals the
@@ -846,8 +880,8 @@ __global__ void __launch_bounds__(512) kivi_stage1_tile128_kernel(const SvkKiviD
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
           f32x2_t y0[4], y1[4];
-          nibbles_fp8(*reinterpret_cast<const uint32_t*>(vl + j * kVBlkStride + (2 * e2) * 64), y0);
-          nibbles_fp8(*reinterpret_cast<const uint32_t*>(vl + j * kVBlkStride + (2 * e2 + 1) * 64), y1);
+          nibbles_fp8(vwq[j & 1][2 * e2], y0);
+          nibbles_fp8(vwq[j & 1][2 * e2 + 1], y1);
           const float s0 = bf16_lo(s8w[e2]) * 512.0f, s1 = bf16_hi(s8w[e2]) * 512.0f;
           const float m0 = bf16_lo(m8w[e2]), m1 = bf16_hi(m8w[e2]);
           const f32x2_t sv0 = {s0, s0}, mv0 = {m0, m0}, sv1 = {s1, s1}, mv1 = {m1, m1};
