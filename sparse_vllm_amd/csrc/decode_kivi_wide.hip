@@ -5,6 +5,7 @@
 // Developer build (make EXTRA=-DSVK_KV_TIMING, then tools/kv_timing.py): s_memrealtime stamps (100 MHz) of wave 0 of every
 // workgroup of the wide KIVI kernel: 0 entry, 1 range known, 2 before the tile loop, 3 first K tile in LDS, 4 first tile
 // done, 5 tile loop done, 6 partials written.
+#include "svk_common.hpp"
 #ifdef SVK_KV_TIMING
 __device__ unsigned long long g_kv_stamps[4096 * 8];
 #define SVK_KV_STAMP(i)                                                                                                \

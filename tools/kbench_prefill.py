@@ -8,6 +8,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+if os.environ.get("SVK_AB_LIB"):          # developer A/B: another build of the library (e.g. sparse_vllm_amd/libsvk_ab.so)
+    import sparse_vllm_amd._lib as _svk_lib
+    _svk_lib.LIB_PATH = os.path.abspath(os.environ["SVK_AB_LIB"])
 from sparse_vllm_amd.kernels.context_flashattention_nopad import context_attention_fwd
 
 

@@ -14,6 +14,8 @@ import numpy as np
 import torch
 
 from sparse_vllm_amd import _lib
+if os.environ.get("SVK_AB_LIB"):          # developer A/B: another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["SVK_AB_LIB"])
 from sparse_vllm_amd.kernels.deltakv_kernels import full_layer_kivi_flash_decode_stage1
 
 lib = _lib.load()
