@@ -16,7 +16,7 @@ stats() {  # stats <name> <cmd...>: kernel-trace stats csv of one command
 }
 # headline bench: plain run (the judged line) and the same command under the profiler
 timeout 600 python3 "$R/bench.py" < /dev/null > "$O/bench_stdout.log" 2> "$O/bench_stderr.log"; tail -1 "$O/bench_stdout.log" > "$O/bench_line.json"
-stats bench_kernel_stats.csv python3 "$R/bench.py" --steps 128 --warmup 8 --no-cpu-baseline --no-paths     # (the other configurations launch the same kernels at other shapes: they would pollute the per-kernel averages)
+stats bench_kernel_stats.csv python3 "$R/bench.py" --steps 128 --warmup 8 --no-cpu-baseline --no-paths --no-e2e     # (the other configurations launch the same kernels at other shapes: they would pollute the per-kernel averages)
 grep '^{' "$O/_bench_kernel_stats.log" | tail -1 > "$O/bench_line_profiled.json"
 json_line() {  # json_line <file> <cmd...>: the command's last stdout line appended to <file>, one retry if it printed none
   local f=$1; shift
@@ -28,9 +28,9 @@ json_line() {  # json_line <file> <cmd...>: the command's last stdout line appen
   done
   echo "$out" >> "$f"
 }
-for b in 1 8 32; do json_line "$O/bench_small_batches.jsonl" python3 "$R/bench.py" --batch $b --no-cpu-baseline --no-kernel-events; done
+for b in 1 8 32; do json_line "$O/bench_small_batches.jsonl" python3 "$R/bench.py" --batch $b --no-cpu-baseline --no-kernel-events --no-e2e; done
 # the roofline leg at the neighbouring batch sizes (the default is 256)
-for b in 64 128 512; do json_line "$O/bench_other_batches.jsonl" python3 "$R/bench.py" --batch $b --no-cpu-baseline; done
+for b in 64 128 512; do json_line "$O/bench_other_batches.jsonl" python3 "$R/bench.py" --batch $b --no-cpu-baseline --no-e2e --no-paths; done
 # other configurations
 timeout 600 python3 "$R/tools/pathbench.py" --graph < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_graph.jsonl"
 timeout 600 python3 "$R/tools/pathbench.py" < /dev/null 2>/dev/null | grep '^{' > "$O/paths/pathbench_eager.jsonl"
@@ -59,9 +59,13 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   f=$(find "$O/_pmc_$ctr" -type f -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$O/kbench_pmc_$ctr.csv"
 done
+# the end-to-end leg on its own (tp = 1: B = 1 / 64 / 256, hipGraph replay and eager)
+timeout 400 python3 "$R/tools/e2e_decoder.py" --batches 1,64,256 --steps 32 --modes graph,eager < /dev/null 2>/dev/null | grep '^{' > "$O/e2e_tp1.jsonl"
+timeout 300 python3 "$R/tools/dql_ab.py" < /dev/null 2>/dev/null > "$O/paths/kbench_dequant_linear.txt"
+# PMC passes over the KIVI stage-1 kernel, one launch shape per run (counters only)
+bash "$R/tools/pmc_kivi.sh" 1 1024 > /dev/null 2>&1; cp "$R/gpurun_out/pmc_kivi_b1_bs1024/summary.txt" "$O/pmc_kivi_b1.txt"
+bash "$R/tools/pmc_kivi.sh" 4 2304 > /dev/null 2>&1; cp "$R/gpurun_out/pmc_kivi_b4_bs2304/summary.txt" "$O/pmc_kivi_b4.txt"
 # bare access-pattern and instruction probes (built here by hipcc, see the header of each file)
-# PMC passes over the KIVI stage-1 kernel (counters only)
-bash "$R/tools/pmc_kivi.sh" 4 2304 > "$O/pmc_kivi.txt" 2>/dev/null
 for p in probe_gather probe_kdma probe_dma_offset mfma_valu_mix probe_fp8cvt probe_tr4; do
   [ -x "$R/tools/bin/$p" ] && timeout 120 "$R/tools/bin/$p" < /dev/null > "$O/$p.txt" 2>&1
 done
