@@ -53,8 +53,11 @@ def main():
                 def pair():
                     kc, vc = kcs[it[0] % args.layers], vcs[it[0] % args.layers]
                     it[0] += 1
-                    flash_decode_stage1(q, kc, vc, req, bidx, blen, L, mid, lse, bs)
-                    flash_decode_stage2(mid, lse, blen, o, bs)
+                    if bs >= L:          # one block per row: stage 1 writes the output itself, no merge launch (as the layer does)
+                        flash_decode_stage1(q, kc, vc, req, bidx, blen, L, mid, lse, bs, direct_out=o)
+                    else:
+                        flash_decode_stage1(q, kc, vc, req, bidx, blen, L, mid, lse, bs)
+                        flash_decode_stage2(mid, lse, blen, o, bs)
                 pair()
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
