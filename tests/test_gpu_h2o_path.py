@@ -542,6 +542,7 @@ def test_two_level_split_kv_merge(case, monkeypatch):
     workgroups have nothing to do, single-group rows skip the second level), extra partials, three launches in a row on
     the same workspace (tickets self-clean: identical bits every time)."""
     from sparse_vllm_amd.kernels import flash_decode_stage2
+    monkeypatch.setenv("SVK_STAGE2_SPLIT", "1")
     B, Hq, D, nblk, block_seq = (case[k] for k in ("B", "Hq", "D", "nblk", "block_seq"))
     extra = case.get("extra", 0)
     d = dev()

@@ -14,6 +14,8 @@
   `dynamic_topk_indices`, compared with `check_sorted_topk`.
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -59,7 +61,8 @@ def test_h2o_headline_config_chained_oracle_under_graph_replay():
                               h2o_decode_eviction_interval=interval, h2o_prefill_budget=2 * budget)
     drv = SparseDecodeDriver(conf)
     cm = drv.cache_manager
-    assert cm._device_step_enabled, "the headline path keeps its bookkeeping on the device"
+    device_state = os.environ.get("SVK_H2O_DEVICE_STATE", "1") != "0"          # (the opt-out knob: host-driven steps)
+    assert cm._device_step_enabled == device_state, "the headline path keeps its bookkeeping on the device"
     cm.permute_free_slots(20260625)
     seqs = drv.admit_resident_rows(B, budget, logical_len=131072, seed=5)
     # the last row is `behind` tokens behind the others: its burst falls on a later step of the interval
@@ -121,8 +124,9 @@ def test_h2o_headline_config_chained_oracle_under_graph_replay():
         # ---- compare the full state: host mirrors, device copies, tables, stacks, scores
         np.testing.assert_array_equal(np.stack(cm.row_seq_lens), st.row_len, err_msg=f"step {step}")
         np.testing.assert_array_equal(np.asarray(cm._num_free_slots), st.free_ptr, err_msg=f"step {step}")
-        np.testing.assert_array_equal(cm._dev_row_len.cpu().numpy(), st.row_len, err_msg=f"device row lengths, step {step}")
-        np.testing.assert_array_equal(cm._dev_free_ptr.cpu().numpy().reshape(-1), st.free_ptr)
+        if device_state:
+            np.testing.assert_array_equal(cm._dev_row_len.cpu().numpy(), st.row_len, err_msg=f"device row lengths, step {step}")
+            np.testing.assert_array_equal(cm._dev_free_ptr.cpu().numpy().reshape(-1), st.free_ptr)
         if True:
             for l in range(L):
                 p = int(st.free_ptr[l])
@@ -149,7 +153,8 @@ def test_h2o_headline_config_chained_oracle_under_graph_replay():
     # two rows burst when they reach budget + interval, the late row `behind` steps after them
     assert burst_steps == [interval - 1, interval - 1 + behind], burst_steps
     assert cm._h2o_counters["decode_eviction_bursts"] == B
-    assert drv.graph_stats["replayed"] >= steps - 8, drv.graph_stats       # the device-resident step is one graph throughout
+    if device_state:
+        assert drv.graph_stats["replayed"] >= steps - 8, drv.graph_stats   # the device-resident step is one graph throughout
     assert mismatches == 0
     print(f"headline H2O chain: {steps} steps, bursts at {burst_steps}, worst |score err| {worst_score_err:.3e}")
 

@@ -102,7 +102,8 @@ def test_store_riding_in_stage1_equals_store_then_launch(method, monkeypatch):
     assert res["1"][2] > 0
 
 
-def test_flush_of_rows_no_launch_took():
+def test_flush_of_rows_no_launch_took(monkeypatch):
+    monkeypatch.setenv("SVK_FUSE_DECODE_STORE", "1")
     drv = _drivers()["h2o"]
     cm = drv.cache_manager
     from sparse_vllm_amd.utils.context import set_context

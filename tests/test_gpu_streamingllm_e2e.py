@@ -4,6 +4,8 @@ driven step by step on the same inputs: attention outputs within tolerance, slot
 bit-exact across sink + recent compactions (sparse_controller.py:1558-1653, snapkv.py:1805-1896), eager and under
 hipGraph replay with the physical-peak context capacity of StreamingLLMCacheManager."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -85,9 +87,10 @@ def test_streamingllm_decode_steps_match_oracle(cfg, graph):
             np.testing.assert_array_equal(stack[l, :p], st.free_stack[l, :p])
     assert compactions >= 3
     # the steps ran from the device-resident bookkeeping, whose copies equal the host mirrors
-    assert cm._dev_step_cache is not None
-    np.testing.assert_array_equal(cm._dev_row_len.cpu().numpy(), np.stack(cm.row_seq_lens))
-    np.testing.assert_array_equal(cm._dev_free_ptr.cpu().numpy(), np.asarray(cm._num_free_slots))
+    if os.environ.get("SVK_H2O_DEVICE_STATE", "1") != "0":          # (the opt-out knob runs the host-driven steps)
+        assert cm._dev_step_cache is not None
+        np.testing.assert_array_equal(cm._dev_row_len.cpu().numpy(), np.stack(cm.row_seq_lens))
+        np.testing.assert_array_equal(cm._dev_free_ptr.cpu().numpy(), np.asarray(cm._num_free_slots))
 
 
 def _run_window(device_state: bool, graph: bool, steps: int, *, ragged: bool = False, sync_debug: bool = False):
