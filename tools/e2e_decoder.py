@@ -31,6 +31,14 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+# The dense layers are library GEMMs at M <= 256.  PyTorch's TunableOp picks the fastest hipBLASLt / rocBLAS solution per
+# GEMM shape on first use (< 10 s for the five shapes of a batch size; results cached in a file under /tmp) instead of the
+# library heuristic's default: 10.3 -> 8.9 ms per step at B=64.  No kernel of this build is involved; opt out with
+# PYTORCH_TUNABLEOP_ENABLED=0.  (Read by torch at its first GEMM: set before the import.)
+os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(os.environ.get("TMPDIR", "/tmp"), "svk_e2e_tunableop.csv"))
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -268,6 +276,7 @@ def main():
                     "tp": tp, "replica_groups": n_groups, "n_gpus": world, "launch": "hipGraph replay" if mode == "graph" else "eager",
                     "bound_ms": lb, "frac_of_bound": lb / step_ms, "layers": int(args.layers),
                     "weight_bytes_per_rank": model.weight_bytes(), "collectives": bool(model.collectives),
+                    "gemm_selection": "TunableOp" if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "library default",
                     "graph_steps": r["graph_steps"], "sample_tokens": r["sample_tokens"], "steps": args.steps}), flush=True)
     if use_dist:
         dist.destroy_process_group()
