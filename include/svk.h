@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 16
+#define SVK_ABI_VERSION 17
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -587,6 +587,33 @@ typedef struct SvkDeltakvDecodeAllocArgs {
   int32_t graph_batch;
 } SvkDeltakvDecodeAllocArgs;
 int svk_deltakv_decode_alloc(const SvkDeltakvDecodeAllocArgs* a, svk_stream_t stream);
+
+/* MI355X: the same step with the bookkeeping RESIDENT on the device: row lengths, compressed lengths and
+ * the two LIFO free stacks with their pointers live in HBM, and the step pops `batch` slots from each stack exactly as the
+ * host's `pop(batch)` does (lane b takes stack[ptr - batch + b]; the pointer drops by `batch`), writes the maps and the
+ * graph-stable buffers like svk_deltakv_decode_alloc and advances row_len of its rows.  No host data: the launch is a
+ * node of the step's hipGraph.  One workgroup; rows must be distinct.  The host keeps mirrors by the same arithmetic and
+ * re-uploads the state after anything else touched it (compression, admission, free_seq). */
+typedef struct SvkDeltakvDeviceStepArgs {
+  const int32_t* rows;            /* [batch] row of lane b                                        */
+  int32_t* row_len;               /* [rows] tokens held (read, then + 1 for the step's rows)      */
+  const int32_t* compressed_len;  /* [rows]                                                       */
+  const int32_t* full_stack;      /* full-layer free stack (entries [0, *full_ptr) are free)      */
+  int32_t* full_ptr;              /* [1]                                                          */
+  const int32_t* sparse_stack;    /* sparse-layer raw free stack                                  */
+  int32_t* sparse_ptr;            /* [1]                                                          */
+  int32_t* full_slots_map;  int64_t full_map_stride;
+  int32_t* full_slot_to_pos;
+  int32_t* sparse_raw_slots_map;  int64_t sparse_map_stride;
+  int32_t* sparse_slot_to_pos;
+  int32_t* context_lens;          /* [graph_batch] the five graph-stable buffers of svk_deltakv_decode_alloc */
+  int32_t* req_indices;
+  int32_t* slot_mapping;
+  int32_t* sparse_slot_mapping;
+  int32_t* compressed_lens;
+  int32_t batch, graph_batch;
+} SvkDeltakvDeviceStepArgs;
+int svk_deltakv_device_step_begin(const SvkDeltakvDeviceStepArgs* a, svk_stream_t stream);
 
 /* Sparse-layer view + reconstruct work list of one decode step:
  *   row b = [sink raw slots | for j < min(clen,K): temp slot if the selected compressed position has a

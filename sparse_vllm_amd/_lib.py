@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 16
+SVK_ABI_VERSION = 17
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -175,6 +175,14 @@ class SvkDeltakvDecodeAllocArgs(C.Structure):
                 ("sparse_slot_mapping", _p), ("compressed_lens", _p), ("batch", C.c_int32), ("graph_batch", C.c_int32)]
 
 
+class SvkDeltakvDeviceStepArgs(C.Structure):
+    _fields_ = [("rows", _p), ("row_len", _p), ("compressed_len", _p), ("full_stack", _p), ("full_ptr", _p),
+                ("sparse_stack", _p), ("sparse_ptr", _p), ("full_slots_map", _p), ("full_map_stride", C.c_int64),
+                ("full_slot_to_pos", _p), ("sparse_raw_slots_map", _p), ("sparse_map_stride", C.c_int64),
+                ("sparse_slot_to_pos", _p), ("context_lens", _p), ("req_indices", _p), ("slot_mapping", _p),
+                ("sparse_slot_mapping", _p), ("compressed_lens", _p), ("batch", C.c_int32), ("graph_batch", C.c_int32)]
+
+
 class SvkDeltakvPlanArgs(C.Structure):
     _fields_ = [("raw_slots_map", _p), ("latent_slots_map", _p), ("active_compressed", _p), ("req_indices", _p),
                 ("context_lens", _p), ("compressed_lens", _p), ("temp_slots", _p), ("active_slots_out", _p),
@@ -310,6 +318,7 @@ ENTRY_POINTS = {
     "svk_prefill_score_window_pad": ([_i32, _i32, _i32], C.c_int32),
     "svk_prefill_score": ([C.POINTER(SvkPrefillScoreArgs), _p], C.c_int),
     "svk_deltakv_decode_alloc": ([C.POINTER(SvkDeltakvDecodeAllocArgs), _p], C.c_int),
+    "svk_deltakv_device_step_begin": ([C.POINTER(SvkDeltakvDeviceStepArgs), _p], C.c_int),
     "svk_deltakv_static_decode_plan": ([C.POINTER(SvkDeltakvPlanArgs), _p], C.c_int),
     "svk_deltakv_reconstruct_writeback": ([C.POINTER(SvkDeltakvReconstructArgs), _p], C.c_int),
     "svk_deltakv_reconstruct_writeback_batched": ([C.POINTER(SvkDeltakvReconstructArgs), C.POINTER(SvkDeltakvReconstructBatch), _p], C.c_int),

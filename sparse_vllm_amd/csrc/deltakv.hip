@@ -825,8 +825,51 @@ __global__ void __launch_bounds__(256) deltakv_decode_alloc_kernel(const SvkDelt
   a.compressed_lens[b] = clen;
 }
 
+// The same step from device-resident state (one workgroup: the stack pointers move once, behind a barrier).
+__global__ void __launch_bounds__(256) deltakv_device_begin_kernel(const SvkDeltakvDeviceStepArgs a) {
+  const int fp = *a.full_ptr, sp = *a.sparse_ptr;
+  const int row0 = a.rows[0];
+  const int cur0 = a.row_len[row0], clen0 = a.compressed_len[row0];
+  __syncthreads();                                   // every lane has read lane 0's length before its row moves on
+  for (int b = threadIdx.x; b < a.graph_batch; b += blockDim.x) {
+    int row = row0, cur = cur0, clen = clen0, fs = -1, ss = -1;
+    if (b < a.batch) {
+      row = a.rows[b];
+      cur = a.row_len[row];
+      clen = a.compressed_len[row];
+      fs = a.full_stack[fp - a.batch + b];
+      ss = a.sparse_stack[sp - a.batch + b];
+      a.full_slots_map[(int64_t)row * a.full_map_stride + cur] = fs;
+      a.full_slot_to_pos[fs] = cur;
+      a.sparse_raw_slots_map[(int64_t)row * a.sparse_map_stride + cur] = ss;
+      a.sparse_slot_to_pos[ss] = cur;
+      a.row_len[row] = cur + 1;
+    }
+    a.context_lens[b] = cur + 1;
+    a.req_indices[b] = row;
+    a.slot_mapping[b] = fs;
+    a.sparse_slot_mapping[b] = ss;
+    a.compressed_lens[b] = clen;
+  }
+  if (threadIdx.x == 0) {
+    *a.full_ptr = fp - a.batch;
+    *a.sparse_ptr = sp - a.batch;
+  }
+}
+
 }  // namespace
 }  // namespace svk
+
+extern "C" int svk_deltakv_device_step_begin(const SvkDeltakvDeviceStepArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->rows != nullptr && a->row_len != nullptr && a->full_ptr != nullptr && a->sparse_ptr != nullptr,
+              SVK_ERR_VALUE, "svk_deltakv_device_step_begin: null args");
+  SVK_REQUIRE(a->batch > 0, SVK_ERR_VALUE, "Static DeltaKV decode requires a non-empty real decode batch.");
+  SVK_REQUIRE(a->graph_batch >= a->batch, SVK_ERR_VALUE,
+              "Static DeltaKV decode graph batch is smaller than the real decode batch: graph=%d, real=%d.", a->graph_batch, a->batch);
+  hipLaunchKernelGGL(deltakv_device_begin_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_deltakv_device_step_begin");
+}
 
 extern "C" int svk_deltakv_decode_alloc(const SvkDeltakvDecodeAllocArgs* a, svk_stream_t stream) {
   using namespace svk;

@@ -102,6 +102,7 @@ class _Pool:
         self.free = int(n)
         self.size = int(n)
         self.name = name
+        self.version = 0          # moves with every change (the device-resident decode step tells its own pops from others)
 
     def pop(self, n: int) -> np.ndarray:
         n = int(n)
@@ -109,16 +110,19 @@ class _Pool:
             raise RuntimeError(f"Out of {self.name} slots: need={n} free={self.free}.")
         out = self.stack[self.free - n: self.free].copy()
         self.free -= n
+        self.version += 1
         return out
 
     def push(self, slots: np.ndarray):
         slots = np.asarray(slots, dtype=np.int32).reshape(-1)
         self.stack[self.free: self.free + slots.size] = slots
         self.free += int(slots.size)
+        self.version += 1
 
     def permute(self, seed: int):
         assert self.free == self.size
         self.stack = np.random.default_rng(seed).permutation(self.size).astype(np.int32)
+        self.version += 1
 
 
 class DeltaKVCacheManager(CacheManager):
@@ -156,6 +160,15 @@ class DeltaKVCacheManager(CacheManager):
         self._deltakv_decode_static_active_pos = None
         self._pending_raw_store: dict[int, tuple] = {}   # layer -> (k, v) whose store rides in the materialise launch
         self._reset_prefill_staging()
+        # MI355X, SURVEY 8(f).2: device-resident decode bookkeeping (`_device_state_sync`); SVK_H2O_DEVICE_STATE=0: every
+        # step uploads its rows / lengths / slots (svk_deltakv_decode_alloc)
+        import os
+        self._device_step_enabled = os.environ.get("SVK_H2O_DEVICE_STATE", "1") == "1"
+        self.device_step_generation = 0
+        self._device_step = None                 # this step's [args, launched] while the device-resident step is active
+        self._dev_step_cache = None
+        self._dev_state = None                   # row lengths, the two free stacks and their pointers on the device
+        self._dev_stands_for = None              # (full pool version, sparse pool version, row lengths) of that copy
 
     # ------------------------------------------------------------------ configuration helpers
     def _reset_prefill_staging(self):
@@ -408,9 +421,9 @@ class DeltaKVCacheManager(CacheManager):
         exception between layers) are still in flight on the side stream: join it before anything mutates the caches
         it reads (`deltakv_evict`, the next step) - also what lets a hipGraph capture end with no unjoined branch."""
         ahead = self.__dict__.get("_recon_ahead")
-        side = self.__dict__.get("_recon_stream")
-        if ahead and side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+        if ahead:
+            for side in self.__dict__.get("_recon_streams") or ():
+                torch.cuda.current_stream().wait_stream(side)
         if ahead:
             self._recon_ahead = {}
 
@@ -633,8 +646,47 @@ class DeltaKVCacheManager(CacheManager):
 
     # ------------------------------------------------------------------ decode preparation
     @torch.no_grad()
+    def _device_state_sync(self):
+        """The device copy of the decode bookkeeping - row lengths, the full-layer and sparse-layer free stacks with their
+        pointers (compressed lengths already live in `row_deltakv_compressed_lens_gpu`) - is brought up to the host's
+        state when anything but the device-resident step itself has touched it since (compression, admission, free_seq,
+        scratch allocations): pool versions and row lengths say so.  Returns the state."""
+        st, d = self._dev_state, self.device
+        if st is None:
+            i32 = torch.int32
+            st = self._dev_state = dict(
+                row_len=torch.zeros((self.max_buffer_rows,), dtype=i32, device=d),
+                full_stack=torch.zeros((self._pool_full.size,), dtype=i32, device=d), full_ptr=torch.zeros((1,), dtype=i32, device=d),
+                sparse_stack=torch.zeros((self._pool_sparse.size,), dtype=i32, device=d), sparse_ptr=torch.zeros((1,), dtype=i32, device=d))
+            self._dev_step_cache, self._dev_stands_for = None, None
+        cur = self._dev_stands_for
+        if cur is None or cur[0] != self._pool_full.version or cur[1] != self._pool_sparse.version \
+                or not np.array_equal(cur[2], self.row_seq_lens):
+            st["row_len"].copy_(torch.from_numpy(self.row_seq_lens))
+            for name, pool in (("full", self._pool_full), ("sparse", self._pool_sparse)):
+                n = int(pool.free)
+                if n:
+                    st[name + "_stack"][:n].copy_(torch.from_numpy(pool.stack[:n]))
+                st[name + "_ptr"].fill_(n)
+            self._dev_stands_for = (self._pool_full.version, self._pool_sparse.version, self.row_seq_lens.copy())
+        return st
+
+    def device_step_begin(self):
+        """The step's allocation launch, for a caller that took `defer_device_launch` (inside its hipGraph)."""
+        if self._device_step is not None:
+            dk.deltakv_device_step_begin(self._device_step[0])
+            self._device_step[1] = True
+
+    def device_step_mark_launched(self):
+        """A replayed hipGraph carried this step's allocation launch."""
+        if self._device_step is not None:
+            self._device_step[1] = True
+
+    def device_step_burst(self):
+        """(protocol of the decode driver: DeltaKV's compression side stays with `deltakv_evict` after the forward)"""
+
     def prepare_decode_static(self, seqs, input_ids=None, positions=None, slot_mapping=None, context_lens=None,
-                              req_indices=None, *, graph_batch_size: int | None = None):
+                              req_indices=None, *, graph_batch_size: int | None = None, defer_device_launch: bool = False):
         """deltakv_base.py:2038-2154: one new raw slot per row in each pool, graph-stable metadata buffers."""
         with profiler.record("cache_prepare_decode"):
             self._deltakv_reset_view_cache()
@@ -656,8 +708,9 @@ class DeltaKVCacheManager(CacheManager):
                 raise RuntimeError("DeltaKV raw tail exceeds the static decode buffer; deltakv_evict (the compression "
                                    "side) must run after every forward (SparseController.post_forward): "
                                    f"tail={int(buf.max()) + 1} max_buffer={self._deltakv_decode_static_max_buffer()}.")
-            full_slots = self._pool_full.pop(B)
-            sparse_slots = self._pool_sparse.pop(B)
+            self._device_step = None
+            use_device = self._device_step_enabled and slot_mapping is None and context_lens is None and req_indices is None \
+                and len(set(rows.tolist())) == B and min(self._pool_full.free, self._pool_sparse.free) >= B
             key = (GB,)
             st = self._static.get(key)
             if st is None:
@@ -667,20 +720,46 @@ class DeltaKVCacheManager(CacheManager):
             slot_mapping = own_slot_mapping if slot_mapping is None else slot_mapping
             context_lens = own_ctx if context_lens is None else context_lens
             req_indices = own_req if req_indices is None else req_indices
+            if use_device:
+                # MI355X: the step pops its slots from the device copies of the free stacks, by the arithmetic of the two
+                # host pops below (SvkDeltakvDeviceStepArgs) - nothing is uploaded, the launch is a node of the step's graph
+                dev = self._device_state_sync()                  # BEFORE the host mirrors move
+                ckey = (tuple(int(r) for r in rows), GB)
+                cache = self._dev_step_cache
+                if cache is None or cache[0] != ckey:
+                    rows_gpu = torch.from_numpy(rows.astype(np.int32)).to(d)
+                    args = dk.deltakv_device_step_args(
+                        rows=rows_gpu, row_len=dev["row_len"], compressed_len=self.row_deltakv_compressed_lens_gpu,
+                        full_stack=dev["full_stack"], full_ptr=dev["full_ptr"], sparse_stack=dev["sparse_stack"],
+                        sparse_ptr=dev["sparse_ptr"], full_slots_map=self.full_layer_slots_map,
+                        full_slot_to_pos=self.full_layer_slot_to_pos, sparse_raw_slots_map=self.sparse_layer_raw_slots_map,
+                        sparse_slot_to_pos=self.deltakv_slot_to_pos, context_lens=context_lens, req_indices=req_indices,
+                        slot_mapping=slot_mapping, sparse_slot_mapping=sparse_mapping, compressed_lens=compressed, batch=B)
+                    cache = self._dev_step_cache = (ckey, args, rows_gpu)
+                    self.device_step_generation += 1
+                self._device_step = [cache[1], False]
+            full_slots = self._pool_full.pop(B)
+            sparse_slots = self._pool_sparse.pop(B)
             # the step's host data as ONE upload, the four map scatters and five buffer fills as ONE launch
             # (svk_deltakv_decode_alloc; the reference issues them one by one, each with its own small upload: ~0.45 ms
             # of host-driven copies per step in front of a 2.1 ms graph replay)
-            clens = self.row_deltakv_compressed_lens[rows]
-            meta = np.stack([rows, cur, full_slots, sparse_slots, clens]).astype(np.int32)
-            meta_gpu = torch.from_numpy(meta).to(d, non_blocking=True)
             self.row_seq_lens[rows] += 1
             real_lens = self.row_seq_lens[rows]
-            dk.deltakv_decode_alloc(meta_gpu, batch=B, full_slots_map=self.full_layer_slots_map,
-                                    full_slot_to_pos=self.full_layer_slot_to_pos,
-                                    sparse_raw_slots_map=self.sparse_layer_raw_slots_map,
-                                    sparse_slot_to_pos=self.deltakv_slot_to_pos, context_lens=context_lens,
-                                    req_indices=req_indices, slot_mapping=slot_mapping, sparse_slot_mapping=sparse_mapping,
-                                    compressed_lens=compressed)
+            if use_device:
+                # the device copy moves by exactly these pops and increments when the launch runs
+                self._dev_stands_for = (self._pool_full.version, self._pool_sparse.version, self.row_seq_lens.copy())
+                if not defer_device_launch:
+                    self.device_step_begin()
+            else:
+                clens = self.row_deltakv_compressed_lens[rows]
+                meta = np.stack([rows, cur, full_slots, sparse_slots, clens]).astype(np.int32)
+                meta_gpu = torch.from_numpy(meta).to(d, non_blocking=True)
+                dk.deltakv_decode_alloc(meta_gpu, batch=B, full_slots_map=self.full_layer_slots_map,
+                                        full_slot_to_pos=self.full_layer_slot_to_pos,
+                                        sparse_raw_slots_map=self.sparse_layer_raw_slots_map,
+                                        sparse_slot_to_pos=self.deltakv_slot_to_pos, context_lens=context_lens,
+                                        req_indices=req_indices, slot_mapping=slot_mapping, sparse_slot_mapping=sparse_mapping,
+                                        compressed_lens=compressed)
             self._deltakv_decode_static_slot_mapping = sparse_mapping
             self._deltakv_decode_static_compressed_lens = compressed
             cap = self._decode_static_max_context_len
@@ -910,33 +989,40 @@ class DeltaKVCacheManager(CacheManager):
         bufs = {l: self._recon_lookahead_buffers(self.deltakv_layer_to_idx[l], n) for l in layers}
         if len(layers) < 2 or any(b is None for b in bufs.values()):
             return False
-        side = self.__dict__.get("_recon_stream")
-        if side is None:
-            side = self._recon_stream = torch.cuda.Stream(device=self.device)
-            self._recon_events = {}
+        sides = self.__dict__.get("_recon_streams")
+        if sides is None or len(sides) != self._recon_stream_count():
+            sides = self._recon_streams = [torch.cuda.Stream(device=self.device) for _ in range(self._recon_stream_count())]
+            self._recon_events = self.__dict__.get("_recon_events") or {}
         main = torch.cuda.current_stream()
-        side.wait_stream(main)                       # the plan (and everything before it) is complete for the side stream
+        for side in sides:
+            side.wait_stream(main)                   # the plan (and everything before it) is complete for the side streams
         stack = self._stacked_up_weights()
         sub = self._recon_sub_batch()
-        with torch.cuda.stream(side):
-            if stack is None or sub <= 1:
-                for l in layers:
+        if stack is None or sub <= 1:
+            for i, l in enumerate(layers):
+                side = sides[i % len(sides)]
+                with torch.cuda.stream(side):
                     self._reconstruct_layer(self.deltakv_layer_to_idx[l], recon_pos, recon_latent, recon_out_slot, bufs[l],
                                             view_geom=view_geom)
                     self._recon_event(l).record(side)
-            else:
-                # sub-batches of `sub` consecutive layers: one dequant + Linear + GELU launch, one batched GEMM and one
-                # reconstruct launch per sub-batch instead of three launches per layer (48 -> ~28 us per layer), small
-                # enough that the main stream can start on the group's first layers while the rest is still in flight
-                sizes, c0, ci = self._recon_sub_batches(), 0, 0
-                while c0 < len(layers):
-                    n_c = sizes[min(ci, len(sizes) - 1)]
-                    chunk = layers[c0: c0 + n_c]
-                    c0, ci = c0 + n_c, ci + 1
+        else:
+            # sub-batches of `sub` consecutive layers: one dequant + Linear + GELU launch, one batched GEMM and one
+            # reconstruct launch per sub-batch instead of three launches per layer (48 -> ~28 us per layer), small
+            # enough that the main stream can start on the group's first layers while the rest is still in flight.
+            # The sub-batches alternate between the side streams: at one or a few rows none of the three launches
+            # fills the chip, and the chain of launches - not the CUs - is what the walk of the layers waits for.
+            sizes, c0, ci = self._recon_sub_batches(), 0, 0
+            while c0 < len(layers):
+                n_c = sizes[min(ci, len(sizes) - 1)]
+                chunk = layers[c0: c0 + n_c]
+                side = sides[ci % len(sides)]
+                with torch.cuda.stream(side):
                     self._reconstruct_layers_batched([self.deltakv_layer_to_idx[l] for l in chunk], stack, recon_pos,
-                                                     recon_latent, recon_out_slot, view_geom=view_geom)
+                                                     recon_latent, recon_out_slot, view_geom=view_geom,
+                                                     buf_key=ci % len(sides))
                     for l in chunk:
                         self._recon_event(l).record(side)
+                c0, ci = c0 + n_c, ci + 1
         self._recon_ahead = {l: True for l in layers}
         return True
 
@@ -947,6 +1033,12 @@ class DeltaKVCacheManager(CacheManager):
         return ev
 
     _RECON_SUB_BATCHES = [2]
+    _RECON_STREAMS = 1
+
+    @classmethod
+    def _recon_stream_count(cls) -> int:
+        import os
+        return max(1, int(os.environ.get("SVK_DELTAKV_RECON_STREAMS", cls._RECON_STREAMS)))
     _RECON_INTO_VIEW_DEFAULT = True
     _LAYER_VIEWS_MAX_BYTES = 16 << 30
 
@@ -987,24 +1079,24 @@ class DeltaKVCacheManager(CacheManager):
     _RECON_PAD = 64
     _RECON_GEMM_ROWS = 4096
 
-    def _reconstruct_layers_batched(self, l_idxs, stack, recon_pos, recon_latent, recon_out_slot, view_geom=None):
+    def _reconstruct_layers_batched(self, l_idxs, stack, recon_pos, recon_latent, recon_out_slot, view_geom=None, buf_key=0):
         """Residual load + reconstruction of consecutive sparse layers `l_idxs` (same plan) in three launches."""
         w1, b1, w2, b2 = stack
         l0, l1 = int(l_idxs[0]), int(l_idxs[-1]) + 1
         assert list(l_idxs) == list(range(l0, l1))
         k, n = l1 - l0, int(recon_latent.numel())
         store = self.__dict__.setdefault("_recon_batch_bufs", {})
-        cur = store.get(n)                     # one buffer pair per token count, never freed while the side stream may use it
+        cur = store.get((n, buf_key))          # one buffer pair per (token count, side stream), never freed while in use
         hid = int(w1.shape[1])
         if cur is None or cur[0].shape[0] < k:
-            if len(store) >= 4:                   # a handful of token counts at most (batch compositions come and go)
-                torch.cuda.current_stream().synchronize()
+            if len(store) >= 4 * self._recon_stream_count():     # a handful of token counts at most (batch compositions come and go)
+                torch.cuda.synchronize(self.device)
                 store.clear()
             kb = max(k, self._recon_sub_batch())
             hbuf = torch.zeros((kb, n, hid + self._RECON_PAD), dtype=torch.bfloat16, device=self.device)
             hbuf[:, :, hid] = 1.0                                   # the bias feature; the kernel below writes [:, :, :hid] only
             cur = (hbuf, torch.empty((kb, n, int(w2.shape[1])), dtype=torch.bfloat16, device=self.device))
-            store[n] = cur
+            store[(n, buf_key)] = cur
         hp, delta = cur[0][:k], cur[1][:k]
         dk.dequant_linear_act(self.deltakv_latent_cache[l0:l1], self.deltakv_latent_scales[l0:l1], self.deltakv_latent_mins[l0:l1],
                               self._quant_group_size(), w1[l0:l1], b1[l0:l1], activation="gelu", row_index=recon_latent,

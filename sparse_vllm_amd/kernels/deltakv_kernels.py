@@ -258,6 +258,34 @@ def deltakv_decode_alloc(meta, *, batch: int, full_slots_map, full_slot_to_pos, 
     _lib.check(lib.svk_deltakv_decode_alloc(C.byref(a), _lib.current_stream_handle()), lib)
 
 
+def deltakv_device_step_args(*, rows, row_len, compressed_len, full_stack, full_ptr, sparse_stack, sparse_ptr, full_slots_map,
+                             full_slot_to_pos, sparse_raw_slots_map, sparse_slot_to_pos, context_lens, req_indices,
+                             slot_mapping, sparse_slot_mapping, compressed_lens, batch: int):
+    """Arguments of the device-resident DeltaKV decode step (`svk_deltakv_device_step_begin`), built once per batch
+    composition: every pointer is a persistent tensor of the manager (the caller keeps them alive)."""
+    gb = int(context_lens.numel())
+    for t in (rows, row_len, compressed_len, full_stack, full_ptr, sparse_stack, sparse_ptr, full_slots_map, full_slot_to_pos,
+              sparse_raw_slots_map, sparse_slot_to_pos, context_lens, req_indices, slot_mapping, sparse_slot_mapping, compressed_lens):
+        assert t.dtype == torch.int32 and t.stride(-1) == 1 and t.is_cuda
+    assert int(rows.numel()) >= batch and 0 < batch <= gb
+    for t in (req_indices, slot_mapping, sparse_slot_mapping, compressed_lens):
+        assert int(t.numel()) >= gb
+    return _lib.SvkDeltakvDeviceStepArgs(
+        rows=_lib.ptr(rows), row_len=_lib.ptr(row_len), compressed_len=_lib.ptr(compressed_len),
+        full_stack=_lib.ptr(full_stack), full_ptr=_lib.ptr(full_ptr), sparse_stack=_lib.ptr(sparse_stack),
+        sparse_ptr=_lib.ptr(sparse_ptr), full_slots_map=_lib.ptr(full_slots_map), full_map_stride=full_slots_map.stride(0),
+        full_slot_to_pos=_lib.ptr(full_slot_to_pos), sparse_raw_slots_map=_lib.ptr(sparse_raw_slots_map),
+        sparse_map_stride=sparse_raw_slots_map.stride(0), sparse_slot_to_pos=_lib.ptr(sparse_slot_to_pos),
+        context_lens=_lib.ptr(context_lens), req_indices=_lib.ptr(req_indices), slot_mapping=_lib.ptr(slot_mapping),
+        sparse_slot_mapping=_lib.ptr(sparse_slot_mapping), compressed_lens=_lib.ptr(compressed_lens), batch=int(batch),
+        graph_batch=gb)
+
+
+def deltakv_device_step_begin(args):
+    lib = _lib.load()
+    _lib.check(lib.svk_deltakv_device_step_begin(C.byref(args), _lib.current_stream_handle()), lib)
+
+
 def dequant_linear_act(packed, scale, mn, group_size: int, weight, bias=None, *, activation: str = "gelu", row_index=None,
                        out=None, layers: bool = False):
     """`act(F.linear(dequant_int4(packed[row_index]), weight, bias))` as one MFMA launch (MI355X fusion of the residual

@@ -267,3 +267,79 @@ def test_reconstruction_into_the_views_equals_scratch_slots_then_copy(graph):
     new, used_new = run(True)
     assert used_new and not used_ref                  # the run under test really took the view path
     np.testing.assert_array_equal(new, ref)
+
+
+def _run_bookkeeping(device_state: bool, graph: bool, steps: int, *, sync_debug_from: int | None = None, recent: int = 8,
+                     kivi: bool = True):
+    from sparse_vllm_amd.config import Config
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
+    L, B, Hq, D = 6, 3, 8, 64
+    conf = Config.from_kwargs(
+        sparse_method="deltakv", num_hidden_layers=L, full_attention_layers="0,3", num_attention_heads=Hq,
+        num_key_value_heads=2, head_dim=D, max_model_len=256, max_num_seqs_in_gpu=B + 1, sink_keep_tokens=4,
+        recent_keep_tokens=recent, decode_keep_tokens=12, deltakv_neighbor_count=2, deltakv_latent_dim=32,
+        deltakv_latent_quant_bits=4, deltakv_latent_quant_group_size=16, deltakv_center_ratio=0.25,
+        allow_missing_deltakv_path=True, compressor_up_type="mlp_gelu", compressor_intermediate_size=48,
+        full_layer_kv_quant_bits=4 if kivi else 0, full_layer_kivi_decode_block_seq=64, rope_theta=10000.0)
+    drv = SparseDecodeDriver(conf)
+    cm = drv.cache_manager
+    cm._device_step_enabled = device_state
+    cm.permute_free_slots(11)
+    drv.admit_compressed_rows(B, [148, 92, 61], seed=5)
+    if graph:
+        drv.enable_decode_graph()
+    outs = torch.zeros((L, B, Hq, D), dtype=torch.bfloat16, device=drv.device)
+    got, used_device, compared = [], 0, 0
+    for step in range(steps):
+        q, k, v = drv.random_step_inputs(seed=40 + step)
+        if sync_debug_from is not None and step >= sync_debug_from:
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            drv.step(q, k, v, outputs=outs)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+        got.append(outs.view(torch.int16).cpu().numpy().copy())
+        if cm._device_step is not None:
+            used_device += 1
+            stands = cm._dev_stands_for
+            if stands[0] == cm._pool_full.version and stands[1] == cm._pool_sparse.version:
+                # nothing but the step touched the bookkeeping: the device copies ARE the host mirrors
+                dev = cm._dev_state
+                np.testing.assert_array_equal(dev["row_len"].cpu().numpy(), cm.row_seq_lens)
+                for name, pool in (("full", cm._pool_full), ("sparse", cm._pool_sparse)):
+                    assert int(dev[name + "_ptr"].item()) == pool.free
+                    np.testing.assert_array_equal(dev[name + "_stack"][: pool.free].cpu().numpy(), pool.stack[: pool.free])
+                compared += 1
+    n = int(cm.row_seq_lens.max())
+    return dict(o=np.stack(got), full_map=cm.full_layer_slots_map[:, :n].cpu().numpy().copy(),
+                sparse_map=cm.sparse_layer_raw_slots_map[:, :n].cpu().numpy().copy(),
+                full_pos=cm.full_layer_slot_to_pos.cpu().numpy().copy(), sparse_pos=cm.deltakv_slot_to_pos.cpu().numpy().copy(),
+                lens=cm.row_seq_lens.copy(), clens=cm.row_deltakv_compressed_lens.copy(),
+                full_free=cm._pool_full.stack[: cm._pool_full.free].copy(),
+                sparse_free=cm._pool_sparse.stack[: cm._pool_sparse.free].copy(), used_device=used_device, compared=compared)
+
+
+def test_deltakv_device_resident_steps_equal_host_driven_steps():
+    """SURVEY 8(f).2 for DeltaKV: row lengths and the two raw-slot free stacks on the device, the step's allocation
+    (`svk_deltakv_device_step_begin`) a launch of the step instead of an upload + `svk_deltakv_decode_alloc`.  Against the
+    host-driven steps (deltakv_base.py:2038-2154) over several compression events per row: outputs, slot maps, position
+    maps, free stacks (content and order), lengths bit-identical, eager and under hipGraph replay; whenever only the step
+    touched the bookkeeping the device copies equal the host mirrors."""
+    steps = 26
+    ref = _run_bookkeeping(False, False, steps)
+    assert ref["used_device"] == 0
+    assert int(ref["clens"].max()) > 148 - 4 - 8               # compression did happen during the run
+    for graph in (False, True):
+        got = _run_bookkeeping(True, graph, steps)
+        assert got["used_device"] == steps and got["compared"] >= steps // 3
+        for key in ("o", "full_map", "sparse_map", "full_pos", "sparse_pos", "lens", "clens", "full_free", "sparse_free"):
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} graph={graph}")
+
+
+def test_deltakv_device_resident_step_uploads_nothing():
+    """Between compression events (the sparse layers' `deltakv_evict`, the full layers' KIVI block quantisation every
+    group of tokens - both host-driven) a replayed DeltaKV step is a graph launch plus numpy arithmetic on the host
+    mirrors: torch's sync debug mode "error" around the steps of a window long enough not to compress, raw full layers."""
+    got = _run_bookkeeping(True, True, 20, sync_debug_from=4, recent=64, kivi=False)
+    assert got["used_device"] == 20 and got["compared"] >= 16
