@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 17
+#define SVK_ABI_VERSION 18
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -693,6 +693,23 @@ typedef struct SvkDeltakvReconstructBatch {
 } SvkDeltakvReconstructBatch;
 int svk_deltakv_reconstruct_writeback_batched(const SvkDeltakvReconstructArgs* first, const SvkDeltakvReconstructBatch* b,
                                               svk_stream_t stream);
+
+/* MI355X: the second Linear of compress_up and the reconstruction above in ONE launch for `b->n_batch` layers that share a
+ * plan - delta[n, :] = bf16(hidden[n, :] . weight^T + bias) (utils/compressor.py:69-73, the reference's F.linear) never
+ * leaves the chip: a workgroup multiplies 128 tokens x one head of K or V on the matrix cores and finishes those rows as
+ * svk_deltakv_reconstruct_writeback_batched does (same element arithmetic; `first->delta*` are ignored).  Static decode
+ * form only: head_dim 128, un-rotated father keys (raw_k_cache), rotated output, fp32 cos|sin, 1..4 fathers per token.
+ * Against the library GEMM + svk_deltakv_reconstruct_writeback_batched the results differ by the fp32 summation order
+ * of the product only. */
+typedef struct SvkDeltakvUpReconArgs {
+  const uint16_t* hidden;   /* [n_batch][N][hidden_stride] bf16: act(Linear1) rows (svk_dequant_linear_act_batched)   */
+  const uint16_t* weight;   /* [n_batch][2*Hkv*D][weight_stride] bf16, input features contiguous                     */
+  const uint16_t* bias;     /* NULL or [n_batch][2*Hkv*D] bf16                                                      */
+  int64_t hidden_stride, hidden_stride_batch, weight_stride, weight_stride_batch, bias_stride_batch;   /* elements   */
+  int32_t k, _pad0;         /* input features of the Linear: a multiple of 64                                       */
+} SvkDeltakvUpReconArgs;
+int svk_deltakv_up_reconstruct(const SvkDeltakvUpReconArgs* u, const SvkDeltakvReconstructArgs* first,
+                               const SvkDeltakvReconstructBatch* b, svk_stream_t stream);
 
 /* out[r, f] = code(r, f) * scale[r, f/group] + mn[r, f/group]; codes are `bits`-wide fields packed
  * LSB-first into int32.  Replaces triton_dequantize_2d_int4_grouped (kernels/triton/quant.py:160-216) and

@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 17
+SVK_ABI_VERSION = 18
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -166,6 +166,12 @@ class SvkDequantLinearBatch(C.Structure):
 class SvkDeltakvReconstructBatch(C.Structure):
     _fields_ = [("n_batch", C.c_int32), ("delta_stride_batch", C.c_int64), ("father_table_stride_batch", C.c_int64),
                 ("kv_cache_stride_batch", C.c_int64), ("k_norm_stride_batch", C.c_int64), ("out_cache_stride_batch", C.c_int64)]
+
+
+class SvkDeltakvUpReconArgs(C.Structure):
+    _fields_ = [("hidden", _p), ("weight", _p), ("bias", _p), ("hidden_stride", C.c_int64), ("hidden_stride_batch", C.c_int64),
+                ("weight_stride", C.c_int64), ("weight_stride_batch", C.c_int64), ("bias_stride_batch", C.c_int64),
+                ("k", C.c_int32), ("_pad0", C.c_int32)]
 
 
 class SvkDeltakvDecodeAllocArgs(C.Structure):
@@ -322,6 +328,8 @@ ENTRY_POINTS = {
     "svk_deltakv_static_decode_plan": ([C.POINTER(SvkDeltakvPlanArgs), _p], C.c_int),
     "svk_deltakv_reconstruct_writeback": ([C.POINTER(SvkDeltakvReconstructArgs), _p], C.c_int),
     "svk_deltakv_reconstruct_writeback_batched": ([C.POINTER(SvkDeltakvReconstructArgs), C.POINTER(SvkDeltakvReconstructBatch), _p], C.c_int),
+    "svk_deltakv_up_reconstruct": ([C.POINTER(SvkDeltakvUpReconArgs), C.POINTER(SvkDeltakvReconstructArgs),
+                                    C.POINTER(SvkDeltakvReconstructBatch), _p], C.c_int),
     "svk_dequantize_grouped": ([C.POINTER(SvkDequantGroupedArgs), _p], C.c_int),
     "svk_dequant_linear_act": ([C.POINTER(SvkDequantLinearArgs), _p], C.c_int),
     "svk_dequant_linear_act_batched": ([C.POINTER(SvkDequantLinearArgs), C.POINTER(SvkDequantLinearBatch), _p], C.c_int),

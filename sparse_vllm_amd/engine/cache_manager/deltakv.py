@@ -965,6 +965,11 @@ class DeltaKVCacheManager(CacheManager):
                 view_out=None if view is None else (view[0][0], view[1][0], view[2], view[3], view[4]))
 
     @staticmethod
+    def _fused_up_recon_mode() -> str:
+        import os
+        return os.environ.get("SVK_DELTAKV_FUSED_UP", "1")
+
+    @staticmethod
     def _recon_lookahead_enabled() -> bool:
         import os
         return os.environ.get("SVK_DELTAKV_RECON_AHEAD", "1") == "1"
@@ -1101,15 +1106,32 @@ class DeltaKVCacheManager(CacheManager):
         dk.dequant_linear_act(self.deltakv_latent_cache[l0:l1], self.deltakv_latent_scales[l0:l1], self.deltakv_latent_mins[l0:l1],
                               self._quant_group_size(), w1[l0:l1], b1[l0:l1], activation="gelu", row_index=recon_latent,
                               out=hp[:, :, :hid], layers=True)
+        knw = self.deltakv_k_norm_weight
+        view = self._recon_view_out(l0, l1, view_geom)
+        if view is not None:
+            self._recon_view_layers.update(range(l0, l1))
+        fused = self._fused_up_recon_mode()
+        if fused != "0" and dk.deltakv_up_reconstruct_supported(
+                head_dim=self.head_dim, num_kv_heads=self.num_kv_heads,
+                k_fathers=int(self.deltakv_latent_to_full_slots.shape[-1]), hidden_features=hid) \
+                and (fused == "always" or -(-n // 128) * 2 * self.num_kv_heads * k > 256):
+            # MI355X: second Linear + reconstruction in one launch, the delta rows stay in LDS (include/svk.h
+            # SvkDeltakvUpReconArgs).  Taken once the launch is more than one round of 128-token tiles (two or more rows
+            # at 2048 selected tokens): alone the fused launch also wins at one row (31 against 35 us per two layers),
+            # but there it holds every CU's LDS for itself while the walk of the layers wants them for its small
+            # launches - measured 1.50-1.52 against 1.49 ms per step; 4 rows: 3.56-3.59 against 3.68 ms.
+            # `SVK_DELTAKV_FUSED_UP=0`: always the library GEMM and the reconstruct launch below; `=always`: always fused
+            dk.deltakv_up_reconstruct_layers(
+                hp[:, :, :hid], w2[l0:l1, :, :hid], b2[l0:l1], self.deltakv_latent_to_full_slots[l0:l1], recon_latent,
+                self.deltakv_slot_to_pos, recon_out_slot, recon_pos, self.cos_sin_cache, self.deltakv_full_kv_cache[0, l0:l1],
+                self.deltakv_full_kv_cache[1, l0:l1], k_norm_weight=None if knw is None else knw[l0:l1].float().contiguous(),
+                k_norm_eps=float(self.deltakv_k_norm_eps), view_out=view)
+            return
         # (row chunks: this image's hipBLASLt faults inside the batched bf16 GEMM at 8192 rows - plain
         #  torch.bmm([2, 8192, 2112] x [2, 2112, 1024]), tools/probe_bmm2.py; 4096 rows and the per-layer mm are fine)
         for c0 in range(0, n, self._RECON_GEMM_ROWS):
             c1 = min(n, c0 + self._RECON_GEMM_ROWS)
             torch.bmm(hp[:, c0:c1], w2[l0:l1].transpose(1, 2), out=delta[:, c0:c1])
-        knw = self.deltakv_k_norm_weight
-        view = self._recon_view_out(l0, l1, view_geom)
-        if view is not None:
-            self._recon_view_layers.update(range(l0, l1))
         dk.deltakv_reconstruct_writeback_layers(
             delta, self.deltakv_latent_to_full_slots[l0:l1], recon_latent, self.deltakv_slot_to_pos, recon_out_slot, recon_pos,
             self.cos_sin_cache, self.deltakv_full_kv_cache[0, l0:l1], self.deltakv_full_kv_cache[1, l0:l1],

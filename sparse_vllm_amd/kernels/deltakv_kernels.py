@@ -68,7 +68,7 @@ def deltakv_static_decode_plan(*, raw_slots_map, latent_slots_map, active_compre
 
 def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, out_slots, out_pos, cos_sin, k_cache,
                  v_cache, bits, group_size, k_norm_weight, k_norm_eps, raw_k_cache, store_raw_k, father_index=None, batch=None,
-                 view_out=None):
+                 view_out=None, up=None):
     assert k_cache.dtype == torch.bfloat16 and k_cache.stride() == v_cache.stride() and k_cache.stride(-1) == 1
     assert father_slots.dim() == 2 and father_slots.dtype == torch.int32 and father_slots.stride(1) == 1
     if father_index is not None:      # father_slots is the [latents, K] table, indexed in-kernel
@@ -100,6 +100,9 @@ def _reconstruct(*, delta, scale, mn, latent_slots, father_slots, slot_to_pos, o
         a.out_k_cache, a.out_v_cache = _lib.ptr(vk), _lib.ptr(vv)
         a.out_slot_stride, a.out_head_stride = vk.stride(0), vk.stride(1)
         a.out_view_width, a.out_view_offset, a.out_entries_per_row = int(width), int(offset), int(per_row)
+    if up is not None:
+        _lib.check(lib.svk_deltakv_up_reconstruct(C.byref(up), C.byref(a), C.byref(batch), _lib.current_stream_handle()), lib)
+        return
     if batch is not None:
         _lib.check(lib.svk_deltakv_reconstruct_writeback_batched(C.byref(a), C.byref(batch), _lib.current_stream_handle()), lib)
         return
@@ -134,6 +137,50 @@ def deltakv_reconstruct_writeback_layers(kv_delta, father_table, father_index, s
                  v_cache=v_cache[0], bits=0, group_size=0, k_norm_weight=None if k_norm_weight is None else k_norm_weight[0],
                  k_norm_eps=k_norm_eps, raw_k_cache=raw_k_cache, store_raw_k=store_raw_k, father_index=father_index, batch=batch,
                  view_out=view0)
+
+
+def deltakv_up_reconstruct_supported(*, head_dim: int, num_kv_heads: int, k_fathers: int, hidden_features: int) -> bool:
+    """Shapes `svk_deltakv_up_reconstruct` serves (the caller keeps the library GEMM + reconstruct pair otherwise)."""
+    return int(head_dim) == 128 and 1 <= int(num_kv_heads) <= 8 and 1 <= int(k_fathers) <= 4 and int(hidden_features) >= 64 \
+        and int(hidden_features) % 64 == 0
+
+
+@torch.no_grad()
+def deltakv_up_reconstruct_layers(hidden, weight, bias, father_table, father_index, slot_to_pos, out_slots, out_pos, cos_sin,
+                                  k_cache, v_cache, *, k_norm_weight=None, k_norm_eps: float = 1e-6, view_out=None):
+    """MI355X: `F.linear(hidden, weight, bias)` (the second Linear of compress_up, utils/compressor.py:69-73) and
+    `deltakv_reconstruct_writeback_layers` of its output in ONE launch for the layers of a look-ahead sub-batch: hidden
+    [n_layers, N, K] bf16 (rows may be strided), weight [n_layers, 2*Hkv*D, K] bf16 (rows may be strided), bias None or
+    [n_layers, 2*Hkv*D] bf16; the rest as `deltakv_reconstruct_writeback_layers` (un-rotated father keys, rotated
+    output).  The delta rows stay in LDS (include/svk.h SvkDeltakvUpReconArgs)."""
+    nl = int(hidden.shape[0])
+    assert hidden.dim() == 3 and hidden.dtype == torch.bfloat16 and hidden.stride(2) == 1
+    assert weight.dim() == 3 and weight.dtype == torch.bfloat16 and weight.stride(2) == 1 and weight.shape[0] == nl
+    assert weight.shape[2] == hidden.shape[2] and int(weight.shape[1]) == 2 * int(k_cache.shape[2]) * int(k_cache.shape[3])
+    assert father_table.dim() == 3 and father_table.shape[0] == nl and k_cache.dim() == 4 and k_cache.shape[0] == nl
+    assert k_cache.stride() == v_cache.stride() and int(father_index.numel()) == int(hidden.shape[1])
+    if bias is not None:
+        assert bias.dim() == 2 and bias.dtype == torch.bfloat16 and bias.shape[0] == nl and bias.stride(1) == 1
+    if k_norm_weight is not None:
+        assert k_norm_weight.dim() == 2 and k_norm_weight.shape[0] == nl and k_norm_weight.dtype == torch.float32 and k_norm_weight.is_contiguous()
+    up = _lib.SvkDeltakvUpReconArgs(
+        hidden=_lib.ptr(hidden), weight=_lib.ptr(weight), bias=_lib.ptr(bias), hidden_stride=hidden.stride(1),
+        hidden_stride_batch=hidden.stride(0), weight_stride=weight.stride(1), weight_stride_batch=weight.stride(0),
+        bias_stride_batch=0 if bias is None else bias.stride(0), k=int(hidden.shape[2]))
+    batch = _lib.SvkDeltakvReconstructBatch(
+        n_batch=nl, delta_stride_batch=0, father_table_stride_batch=father_table.stride(0),
+        kv_cache_stride_batch=k_cache.stride(0), k_norm_stride_batch=0 if k_norm_weight is None else k_norm_weight.stride(0))
+    view0 = None
+    if view_out is not None:
+        vk, vv, width, offset, per_row = view_out
+        assert vk.dim() == 4 and vk.shape[0] == nl and vk.stride() == vv.stride()
+        batch.out_cache_stride_batch = vk.stride(0)
+        view0 = (vk[0], vv[0], width, offset, per_row)
+    _reconstruct(delta=hidden[0], scale=None, mn=None, latent_slots=None, father_slots=father_table[0],
+                 slot_to_pos=slot_to_pos, out_slots=out_slots, out_pos=out_pos, cos_sin=cos_sin, k_cache=k_cache[0],
+                 v_cache=v_cache[0], bits=0, group_size=0, k_norm_weight=None if k_norm_weight is None else k_norm_weight[0],
+                 k_norm_eps=k_norm_eps, raw_k_cache=True, store_raw_k=False, father_index=father_index, batch=batch,
+                 view_out=view0, up=up)
 
 
 @torch.no_grad()

@@ -343,3 +343,49 @@ def test_deltakv_device_resident_step_uploads_nothing():
     mirrors: torch's sync debug mode "error" around the steps of a window long enough not to compress, raw full layers."""
     got = _run_bookkeeping(True, True, 20, sync_debug_from=4, recent=64, kivi=False)
     assert got["used_device"] == 20 and got["compared"] >= 16
+
+
+def test_fused_second_linear_and_reconstruction_in_the_decode_steps(monkeypatch):
+    """`svk_deltakv_up_reconstruct` inside the manager's look-ahead (SVK_DELTAKV_FUSED_UP=always) against the library GEMM +
+    reconstruct launches (=0) over decode steps with compression events, head_dim 128: the delta rows differ by the fp32
+    summation order of the second Linear only, the attention outputs agree within the bf16 tolerance of the path and
+    nearly all of them exactly; the fused launch really ran."""
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
+    L, B, Hq, Hkv, D = 6, 2, 8, 4, 128
+    calls = {"n": 0}
+    orig = dk.deltakv_up_reconstruct_layers
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(dk, "deltakv_up_reconstruct_layers", counted)
+
+    def run(mode):
+        monkeypatch.setenv("SVK_DELTAKV_FUSED_UP", mode)
+        conf = Config.from_kwargs(
+            sparse_method="deltakv", num_hidden_layers=L, full_attention_layers="0,3", num_attention_heads=Hq,
+            num_key_value_heads=Hkv, head_dim=D, max_model_len=512, max_num_seqs_in_gpu=B + 1, sink_keep_tokens=4,
+            recent_keep_tokens=16, decode_keep_tokens=160, deltakv_neighbor_count=4, deltakv_latent_dim=64,
+            deltakv_latent_quant_bits=4, deltakv_latent_quant_group_size=32, deltakv_center_ratio=0.1,
+            allow_missing_deltakv_path=True, compressor_up_type="mlp_gelu", compressor_intermediate_size=128,
+            full_layer_kv_quant_bits=0, rope_theta=10000.0)
+        drv = SparseDecodeDriver(conf)
+        drv.cache_manager.permute_free_slots(5)
+        drv.admit_compressed_rows(B, [300, 211], seed=2)
+        outs = torch.zeros((L, B, Hq, D), dtype=torch.bfloat16, device=drv.device)
+        got = []
+        for step in range(20):
+            q, k, v = drv.random_step_inputs(seed=90 + step)
+            drv.step(q, k, v, outputs=outs)
+            torch.cuda.synchronize()
+            got.append(outs.float().cpu().numpy().copy())
+        return np.stack(got)
+
+    ref = run("0")
+    assert calls["n"] == 0
+    new = run("always")
+    assert calls["n"] >= 20                      # two sparse groups of two layers per step
+    np.testing.assert_allclose(new, ref, rtol=2e-2, atol=2e-2)
+    assert float((new == ref).mean()) > 0.9
