@@ -62,23 +62,34 @@ __device__ __forceinline__ void ur_dma2x16_off32(uint32_t v0, uint32_t v1, const
                : "=&s"(keep) : "v"(v0), "v"(v1), "s"(base), "s"(lds_addr) : "memory");
 }
 
-// TM = tokens per workgroup: 128 (4 waves, ring of 4 stages of 32 KiB) or 256 (8 waves = two per SIMD, ring of 3 stages of
-// 48 KiB: a quarter less operand traffic per product, and a partner wave for the epilogue's vector work).
+// TM = tokens per workgroup, WAVES = its waves:
+//   (128, 4)  a wave = 64 tokens x 64 features; ring of 4 stages of 32 KiB
+//   (256, 8)  the same wave tile, two waves per SIMD; ring of 3 stages of 48 KiB, a quarter less operand traffic per product
+//   (256, 4)  a wave = 64 tokens x all 128 features (128 accumulator registers): 6 operand reads per 8 MFMAs instead of
+//             4 per 4.  Measured equal per step to (256, 8) (1.18 us per 64-deep step of a 256 x 128 tile) and slower in
+//             the epilogue (one wave per SIMD): 110 against 107 us at 2 x 8192 tokens - developer form only
 // KF = fathers per token held in registers (k_fathers <= KF).
-template <int TM, int KF>
-__global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P) {
+template <int TM, int WAVES, int KF>
+__global__ void __launch_bounds__(WAVES * 64) up_recon_kernel(const UpReconParams P) {
   constexpr int D = 128, HD2 = 64;
-  constexpr int NT = TM * 2;                           // threads
+  constexpr int NT = WAVES * 64;                       // threads
   constexpr int STAGES = TM == 128 ? 4 : 3;
   constexpr int H_TILE = TM * 128;                     // bytes of the hidden tile of a stage
   constexpr int STAGE = H_TILE + kUrWTileBytes;
-  constexpr int PER_TILE = TM == 128 ? 8 : 6;          // DMA instructions of one wave per stage
+  constexpr int TOKB = 2;                              // 32-token MFMA blocks of a wave
+  constexpr int FEATB = (TM / 64) * 4 / WAVES;         // 32-feature MFMA blocks of a wave: 2, or 4 (all features)
+  constexpr int HG = (TM / 32) / WAVES;                // hidden DMA groups (32 rows, 4 instructions) of a wave per stage
+  constexpr int WI = 16 / WAVES;                       // weight DMA instructions (8 rows each) of a wave per stage
+  constexpr int PER_TILE = 4 * HG + WI;                // DMA instructions of one wave per stage
   constexpr int AHEAD = STAGES - 3;                    // tiles still in flight behind the one a step waits for
-  constexpr int RPP = NT / 8;                          // token rows per epilogue pass (8 lanes per token), 4 passes
+  constexpr int RPP = NT / 8;                          // token rows per epilogue pass (8 lanes per token)
+  constexpr int NP = TM / RPP;                         // epilogue passes
+  static_assert(FEATB == 2 || FEATB == 4, "wave tile");
+  static_assert(2 * PER_TILE <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = FEATB == 4 ? w : w >> 1, wn = FEATB == 4 ? 0 : w & 1;
   // workgroup -> (m tile, n tile, layer).  Workgroups are dealt to the 8 XCDs round-robin: the n tiles of one m tile (they
   // read the same hidden rows) stay on one XCD's L2.
   const int n_tiles = 2 * P.r.num_kv_heads;
@@ -101,17 +112,18 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw);
   const char* hbase = reinterpret_cast<const char*>(P.u.hidden + z * P.u.hidden_stride_batch) - 3072;
   const char* wbase = reinterpret_cast<const char*>(P.u.weight + z * P.u.weight_stride_batch + (int64_t)n_tile * 128 * P.u.weight_stride) - 3072;
-  constexpr int WI = TM == 128 ? 4 : 2;                // weight DMA instructions of a wave per stage
-  uint32_t hoff[4], woff[WI];
+  uint32_t hoff[HG][4], woff[WI];
   {
     const uint32_t lrow = lane >> 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = w * 32 + i * 8 + (int)lrow;
-      const uint32_t chunk = (lane & 7) ^ (((uint32_t)row >> 1) & 7u);      // position p of row r holds chunk p ^ ((r >> 1) & 7)
-      const int tok = min(m0 + row, a.n - 1);
-      hoff[i] = (uint32_t)tok * (uint32_t)(P.u.hidden_stride * 2) + (chunk << 4) + 3072u - 1024u * i;
-    }
+    for (int g = 0; g < HG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (w * HG + g) * 32 + i * 8 + (int)lrow;
+        const uint32_t chunk = (lane & 7) ^ (((uint32_t)row >> 1) & 7u);      // position p of row r holds chunk p ^ ((r >> 1) & 7)
+        const int tok = min(m0 + row, a.n - 1);
+        hoff[g][i] = (uint32_t)tok * (uint32_t)(P.u.hidden_stride * 2) + (chunk << 4) + 3072u - 1024u * i;
+      }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int row = w * (8 * WI) + i * 8 + (int)lrow;
@@ -121,10 +133,13 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
   }
   auto issue = [&](int t) {
     const uint32_t sb = lds0 + (uint32_t)(t % STAGES) * STAGE;
-    uint32_t hv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) hv[i] = hoff[i] + (uint32_t)t * 128u;
-    pa_dma4x16_off32(hv, hbase, sb + (uint32_t)w * 4096u);
+    for (int g = 0; g < HG; ++g) {
+      uint32_t hv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hv[i] = hoff[g][i] + (uint32_t)t * 128u;
+      pa_dma4x16_off32(hv, hbase, sb + (uint32_t)(w * HG + g) * 4096u);
+    }
     if constexpr (WI == 4) {
       uint32_t wv[4];
 #pragma unroll
@@ -143,11 +158,11 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
   //      values, requested behind the first tiles' DMA and in rounds (entry -> father row): all loads of a round go out
   //      together, the compiler's wait for them is pinned behind the round, not at their first use
   const int tq = threadIdx.x >> 3, p = (threadIdx.x & 7) * 8;
-  int out_slot[4], out_pos[4], fidx[4], fs[4][KF];
-  bool active[4];
-  int nc[4];
+  int out_slot[NP], out_pos[NP], fidx[NP], fs[NP][KF];
+  bool active[NP];
+  int nc[NP];
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NP; ++ps) {
     const int n = m0 + ps * RPP + tq;
     active[ps] = n < a.n;
     nc[ps] = min(n, a.n - 1);
@@ -157,29 +172,29 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
   }
   if (a.father_table != nullptr) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) fidx[ps] = a.father_index[nc[ps]];
+    for (int ps = 0; ps < NP; ++ps) fidx[ps] = a.father_index[nc[ps]];
   }
-  uint2 bw[2][4];
+  uint2 bw[FEATB][4];
 #pragma unroll
-  for (int fi = 0; fi < 2; ++fi)
+  for (int fi = 0; fi < FEATB; ++fi)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) bw[fi][rq] = make_uint2(0u, 0u);
   if (P.u.bias != nullptr) {
-    const uint16_t* bias = P.u.bias + z * P.u.bias_stride_batch + n_tile * 128 + wn * 64 + (lane >> 5) * 4;
+    const uint16_t* bias = P.u.bias + z * P.u.bias_stride_batch + n_tile * 128 + wn * (FEATB * 32) + (lane >> 5) * 4;
 #pragma unroll
-    for (int fi = 0; fi < 2; ++fi)
+    for (int fi = 0; fi < FEATB; ++fi)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) bw[fi][rq] = *reinterpret_cast<const uint2*>(bias + fi * 32 + rq * 8);
   }
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) asm volatile("" : "+v"(out_slot[ps]), "+v"(out_pos[ps]), "+v"(fidx[ps]));
+  for (int ps = 0; ps < NP; ++ps) asm volatile("" : "+v"(out_slot[ps]), "+v"(out_pos[ps]), "+v"(fidx[ps]));
 #pragma unroll
-  for (int fi = 0; fi < 2; ++fi)
+  for (int fi = 0; fi < FEATB; ++fi)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) asm volatile("" : "+v"(bw[fi][rq].x), "+v"(bw[fi][rq].y));
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NP; ++ps) {
     if (!active[ps]) { out_slot[ps] = -1; out_pos[ps] = -1; }
   }
   {
@@ -187,21 +202,21 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
     const int32_t* fbase = tab ? a.father_table : a.father_slots;
     const int64_t fstride = tab ? a.father_table_stride : a.father_stride;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < NP; ++ps) {
       const int32_t* fathers = fbase + (int64_t)max(fidx[ps], 0) * fstride;
 #pragma unroll
       for (int kk = 0; kk < KF; ++kk) fs[ps][kk] = fathers[min(kk, a.k_fathers - 1)];
     }
     if (tab) {
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps)
+      for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
         for (int kk = 0; kk < KF; ++kk) fs[ps][kk] = max(fs[ps][kk], 0);
     }
   }
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps)
+  for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
     for (int kk = 0; kk < KF; ++kk) asm volatile("" : "+v"(fs[ps][kk]));
 
@@ -209,12 +224,12 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
   uint32_t fa[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) fa[s] = (uint32_t)(lane & 31) * 128u + ((uint32_t)((2 * s + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
-  const uint32_t h_rows = (uint32_t)wm * 64u * 128u, w_rows = H_TILE + (uint32_t)wn * 64u * 128u;
-  f32x16_t acc[2][2];
+  const uint32_t h_rows = (uint32_t)wm * 64u * 128u, w_rows = H_TILE + (uint32_t)wn * (FEATB * 32u) * 128u;
+  f32x16_t acc[FEATB][TOKB];
 #pragma unroll
-  for (int fi = 0; fi < 2; ++fi)
+  for (int fi = 0; fi < FEATB; ++fi)
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TOKB; ++ti)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[fi][ti][r] = 0.f;
 
@@ -222,19 +237,21 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
   //      of tile t are in registers when the step starts; their MFMAs cover the reads of substeps 2, 3; then tile t + 1 is
   //      waited for, the barrier retires tile t - 1's ring slot for the DMA of tile t + STAGES - 1, and the MFMAs of
   //      substeps 2, 3 cover the reads of tile t + 1's substeps 0, 1.
-  auto read4 = [&](uint32_t sb, int s, bf16x8_t (&f)[4]) {
-    f[0] = lds_frag(sb + w_rows + fa[s]);
-    f[1] = lds_frag(sb + w_rows + 32 * 128 + fa[s]);
-    f[2] = lds_frag(sb + h_rows + fa[s]);
-    f[3] = lds_frag(sb + h_rows + 32 * 128 + fa[s]);
+  constexpr int NF = FEATB + TOKB;                     // operand fragments of a k-substep: features first, then tokens
+  auto read4 = [&](uint32_t sb, int s, bf16x8_t (&f)[NF]) {
+#pragma unroll
+    for (int i = 0; i < FEATB; ++i) f[i] = lds_frag(sb + w_rows + i * (32 * 128) + fa[s]);
+#pragma unroll
+    for (int i = 0; i < TOKB; ++i) f[FEATB + i] = lds_frag(sb + h_rows + i * (32 * 128) + fa[s]);
   };
-  auto mfma4 = [&](const bf16x8_t (&f)[4]) {
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], f[2], acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], f[3], acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], f[2], acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], f[3], acc[1][1], 0, 0, 0);
+  auto mfma4 = [&](const bf16x8_t (&f)[NF]) {
+#pragma unroll
+    for (int fi = 0; fi < FEATB; ++fi)
+#pragma unroll
+      for (int ti = 0; ti < TOKB; ++ti)
+        acc[fi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[fi], f[FEATB + ti], acc[fi][ti], 0, 0, 0);
   };
-  bf16x8_t f0[4], f1[4], g0[4], g1[4];
+  bf16x8_t f0[NF], f1[NF], g0[NF], g1[NF];
   // tile 0 has landed: the prologue put STAGES - 1 tiles in flight
   if (KT >= STAGES - 1 && STAGES == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
   else if (KT >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
@@ -273,9 +290,9 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
   };
   const uint16_t* cache = is_v ? a.v_cache : a.k_cache;
   const float* cs_tab = reinterpret_cast<const float*>(a.cos_sin);
-  bool act[4];
+  bool act[NP];
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) act[ps] = active[ps] && out_slot[ps] >= 0 && out_pos[ps] >= 0;
+  for (int ps = 0; ps < NP; ++ps) act[ps] = active[ps] && out_slot[ps] >= 0 && out_pos[ps] >= 0;
   auto gather = [&](int ps, uint4 (&y1)[KF], uint4 (&y2)[KF], float4 (&cs)[4]) {
 #pragma unroll
     for (int kk = 0; kk < KF; ++kk) {
@@ -297,13 +314,13 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
 
   // ---- delta tile: C^T[feature][token] -> bf16(acc + bias) at [token][feature]
 #pragma unroll
-  for (int fi = 0; fi < 2; ++fi)
+  for (int fi = 0; fi < FEATB; ++fi)
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < TOKB; ++ti) {
       const int tok = wm * 64 + ti * 32 + (lane & 31);
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const int f0c = wn * 64 + fi * 32 + rq * 8 + (lane >> 5) * 4;
+        const int f0c = wn * (FEATB * 32) + fi * 32 + rq * 8 + (lane >> 5) * 4;
         const float b0 = bf16_lo(bw[fi][rq].x), b1 = bf16_hi(bw[fi][rq].x), b2 = bf16_lo(bw[fi][rq].y), b3 = bf16_hi(bw[fi][rq].y);
         const uint2 o = make_uint2(pack2_bf16(acc[fi][ti][rq * 4] + b0, acc[fi][ti][rq * 4 + 1] + b1),
                                    pack2_bf16(acc[fi][ti][rq * 4 + 2] + b2, acc[fi][ti][rq * 4 + 3] + b3));
@@ -370,12 +387,13 @@ __global__ void __launch_bounds__(TM * 2) up_recon_kernel(const UpReconParams P)
     *reinterpret_cast<uint4*>(dst + ob) = pk8(o1);
     *reinterpret_cast<uint4*>(dst + ob + HD2) = pk8(o2);
   };
-  finish(0, ya1, ya2, csa);
-  gather(2, ya1, ya2, csa);
-  finish(1, yb1, yb2, csb);
-  gather(3, yb1, yb2, csb);
-  finish(2, ya1, ya2, csa);
-  finish(3, yb1, yb2, csb);
+#pragma unroll
+  for (int ps = 0; ps < NP; ps += 2) {
+    finish(ps, ya1, ya2, csa);
+    if (ps + 2 < NP) gather(ps + 2, ya1, ya2, csa);
+    finish(ps + 1, yb1, yb2, csb);
+    if (ps + 3 < NP) gather(ps + 3, yb1, yb2, csb);
+  }
 }
 
 }  // namespace
@@ -416,27 +434,26 @@ extern "C" int svk_deltakv_up_reconstruct(const SvkDeltakvUpReconArgs* u, const 
   p.lb = *b;
   const int n_tiles = 2 * first->num_kv_heads;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // token tile: 256 once 128-token tiles would not fit the chip in one round (SVK_UP_RECON_TM=128 / 256 forces one)
+  // token tile: 256 once 128-token tiles would not fit the chip in one round (SVK_UP_RECON_TM = 128 / 256 / 2564 forces
+  // the (128, 4) / (256, 8) / (256, 4) form)
   const char* env = getenv("SVK_UP_RECON_TM");
   const int forced = env ? atoi(env) : 0;
   const int tiles128 = ((first->n + 127) / 128) * n_tiles * b->n_batch;
-  const bool tall = forced == 256 || (forced != 128 && tiles128 > 256);
-  if (tall) {
-    p.m_tiles = (first->n + 255) / 256;
-    const dim3 grid(8u * (unsigned)n_tiles * (unsigned)((p.m_tiles + 7) / 8), (unsigned)b->n_batch), block(512);
-    const size_t shm = (size_t)3 * (256 * 128 + kUrWTileBytes);
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_recon_kernel<256, 4>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;
-    (void)attr_ok;
-    hipLaunchKernelGGL((up_recon_kernel<256, 4>), grid, block, shm, s, p);
-  } else {
-    p.m_tiles = (first->n + 127) / 128;
-    const dim3 grid(8u * (unsigned)n_tiles * (unsigned)((p.m_tiles + 7) / 8), (unsigned)b->n_batch), block(256);
-    const size_t shm = (size_t)4 * (128 * 128 + kUrWTileBytes);
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_recon_kernel<128, 4>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;
-    (void)attr_ok;
-    hipLaunchKernelGGL((up_recon_kernel<128, 4>), grid, block, shm, s, p);
-  }
+  const int form = forced ? forced : (tiles128 > 256 ? 256 : 128);
+  const int tm = form == 128 ? 128 : 256;
+  p.m_tiles = (first->n + tm - 1) / tm;
+  const dim3 grid(8u * (unsigned)n_tiles * (unsigned)((p.m_tiles + 7) / 8), (unsigned)b->n_batch);
+  const size_t shm = form == 128 ? (size_t)4 * (128 * 128 + kUrWTileBytes) : (size_t)3 * (256 * 128 + kUrWTileBytes);
+#define SVK_UR_LAUNCH(TM_, W_)                                                                                         \
+  do {                                                                                                                 \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_recon_kernel<TM_, W_, 4>),       \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess; \
+    (void)attr_ok;                                                                                                     \
+    hipLaunchKernelGGL((up_recon_kernel<TM_, W_, 4>), grid, dim3(W_ * 64), shm, s, p);                                 \
+  } while (0)
+  if (form == 128) SVK_UR_LAUNCH(128, 4);
+  else if (form == 256) SVK_UR_LAUNCH(256, 8);
+  else SVK_UR_LAUNCH(256, 4);
+#undef SVK_UR_LAUNCH
   return check_launch("svk_deltakv_up_reconstruct");
 }
