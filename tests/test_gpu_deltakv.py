@@ -581,13 +581,17 @@ def test_reconstruct_into_view_rows_equals_reconstruct_into_cache_slots(cfg):
                                  dict(B=3, K=40, W=61, off=4, Hkv=2, nl=3, hid=320, kf=2, norm=True, view=True),
                                  dict(B=2, K=129, W=129, off=0, Hkv=8, nl=1, hid=64, kf=1, norm=False, view=False),
                                  dict(B=4, K=2048, W=2184, off=8, Hkv=4, nl=2, hid=2048, kf=4, norm=False, view=True)])
-def test_up_reconstruct_equals_linear_then_reconstruct(cfg):
+@pytest.mark.parametrize("form", ["", "128", "256", "2564", "512"])
+def test_up_reconstruct_equals_linear_then_reconstruct(cfg, form, monkeypatch):
     """svk_deltakv_up_reconstruct (second Linear of compress_up + reconstruction in one launch, delta in LDS) against
     torch's F.linear (bf16 output) followed by svk_deltakv_reconstruct_writeback_batched: the two differ by the fp32
     summation order of the product only, i.e. an occasional delta element one bf16 ulp apart - the reconstructed rows agree
     within that, nearly all of them exactly; dead entries and rows outside the plan are not touched; strided hidden and
-    weight rows (the manager's padded buffers)."""
+    weight rows (the manager's padded buffers).  `form`: the launch's own choice, or one of the tile forms forced
+    (SVK_UP_RECON_TM: 128 tokens x 1 head, 256 x 1 head with 8 or 4 waves, 256 x 2 heads)."""
     from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    if form:
+        monkeypatch.setenv("SVK_UP_RECON_TM", form)
     B, K, W, off, Hkv, nl, hid, kf = (cfg[k] for k in ("B", "K", "W", "off", "Hkv", "nl", "hid", "kf"))
     D = 128
     torch.manual_seed(B * 1000 + K)
