@@ -26,6 +26,23 @@
 #include "lds_dma.hpp"
 #include "svk_common.hpp"
 
+// Developer build (make EXTRA=-DSVK_UR_TIMING, tools/ur_timing.py): s_memtime stamps of every wave of the first 64
+// workgroups inside main-loop steps 8..15 of up_recon_kernel: 0 step start, 1 reads + MFMAs of k-substeps 0, 1 issued,
+// 2 tile t+1 waited for, 3 behind the barrier, 4 DMA issued, 5 step end.
+#ifdef SVK_UR_TIMING
+__device__ unsigned long long g_ur_stamps[64 * 8 * 8 * 6];
+#define SVK_UR_STAMP(t_, i_)                                                                                           \
+  do {                                                                                                                 \
+    if ((t_) >= 8 && (t_) < 16 && blockIdx.x < 64u && blockIdx.y == 0u && (threadIdx.x & 63) == 0)                      \
+      g_ur_stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + ((t_) - 8)) * 6 + (i_)] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
+extern "C" int svk_debug_up_recon_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ur_stamps), sizeof(g_ur_stamps));
+}
+#else
+#define SVK_UR_STAMP(t_, i_)
+#endif
+
 namespace svk {
 namespace {
 
@@ -264,21 +281,29 @@ __global__ void __launch_bounds__(WAVES * 64) up_recon_kernel(const UpReconParam
   for (int t = 0; t < KT; ++t) {
     const uint32_t sb = lds0 + (uint32_t)(t % STAGES) * STAGE;
     const uint32_t sbn = lds0 + (uint32_t)((t + 1) % STAGES) * STAGE;
+    SVK_UR_STAMP(t, 0);
     read4(sb, 2, g0);
     mfma4(f0);
     read4(sb, 3, g1);
     mfma4(f1);
+    SVK_UR_STAMP(t, 1);
     if (t + 1 < KT) {
       // tile t + 1 has landed; still in flight behind it: AHEAD tiles
       if (AHEAD == 1 && t + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    SVK_UR_STAMP(t, 2);
     __syncthreads();                                  // everyone's tile t + 1 is in LDS, everyone has read all of tile t
+    SVK_UR_STAMP(t, 3);
+    // (dealing these 8 instructions over the step, two at a time between the MFMA groups, moves their 400-550 cycles
+    //  from here into the MFMA phases and leaves the step as long: tools/ur_timing.py, 1716 -> 1700 cycles)
     if (t + STAGES - 1 < KT) issue(t + STAGES - 1);
+    SVK_UR_STAMP(t, 4);
     if (t + 1 < KT) read4(sbn, 0, f0);
     mfma4(g0);
     if (t + 1 < KT) read4(sbn, 1, f1);
     mfma4(g1);
+    SVK_UR_STAMP(t, 5);
   }
   // (the barrier of the last step is behind every operand read: the ring becomes the delta tile)
 

@@ -32,5 +32,8 @@ extern "C" int svk_build_flags(void) {
 #ifdef SVK_KV_TIMING
   f |= 4;
 #endif
+#ifdef SVK_UR_TIMING
+  f |= 8;
+#endif
   return f;
 }
