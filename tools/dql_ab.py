@@ -1,5 +1,8 @@
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+if os.environ.get("SVK_AB_LIB"):          # developer A/B: another build of the library
+    from sparse_vllm_amd import _lib as _svk_lib
+    _svk_lib.LIB_PATH = os.path.abspath(os.environ["SVK_AB_LIB"])
 from sparse_vllm_amd.kernels import deltakv_kernels as dk
 d = torch.device("cuda:0"); g = torch.Generator(device=d).manual_seed(0)
 def t(fn, iters=40):
