@@ -258,7 +258,12 @@ __global__ void __launch_bounds__(256) dequant_linear_act_kernel(const SvkDequan
 // 64-feature sub-tile are fetched under the MFMAs / GELU epilogue of the current one, and the 768 workgroups of that
 // launch are resident together (43 KiB of LDS, three per CU).
 // ------------------------------------------------------------------------------------------------
-constexpr int kM2 = 64, kSub = 64, kNSub = 4, kLdx2 = 256 + 8, kLdy2 = kSub + 8;
+// A tile in LDS: rows of 512 + 32 bytes.  The 16 lanes of every `ds_read_b128` lane group of an operand read ({0-3, 12-15,
+// 20-27}, ...: row fr = lane & 15, 16-byte column kc = lane >> 4) then sit on 16 different bank quads; at 512 + 16 bytes
+// one pair of every group shared a quad, which doubles the cycles of the read (54 % of this kernel's LDS cycles were
+// conflict cycles; 19 % now, what is left are the 16-byte stores of the dequantisation).  53 248 B per workgroup: still
+// three per CU, which is what keeps the 768 workgroups of a 2048-row launch resident together.
+constexpr int kM2 = 64, kSub = 64, kNSub = 4, kLdx2 = 256 + 16, kLdy2 = kSub + 8;
 
 template <bool GELU>
 __global__ void __launch_bounds__(256) dequant_linear_act_k256_kernel(const SvkDequantLinearArgs a_in, const SvkDequantLinearBatch lb) {
