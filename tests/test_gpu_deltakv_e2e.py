@@ -364,6 +364,7 @@ def test_fused_second_linear_and_reconstruction_in_the_decode_steps(monkeypatch)
 
     def run(mode):
         monkeypatch.setenv("SVK_DELTAKV_FUSED_UP", mode)
+        monkeypatch.setenv("SVK_DELTAKV_RECON_AHEAD", "1")        # the fused launch lives in the look-ahead's layer batches
         conf = Config.from_kwargs(
             sparse_method="deltakv", num_hidden_layers=L, full_attention_layers="0,3", num_attention_heads=Hq,
             num_key_value_heads=Hkv, head_dim=D, max_model_len=512, max_num_seqs_in_gpu=B + 1, sink_keep_tokens=4,
