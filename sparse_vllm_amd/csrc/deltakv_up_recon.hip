@@ -87,11 +87,14 @@ __device__ __forceinline__ void ur_dma2x16_off32(uint32_t v0, uint32_t v1, const
 //             4 per 4.  Measured equal per step to (256, 8) (1.18 us per 64-deep step of a 256 x 128 tile) and slower in
 //             the epilogue (one wave per SIMD): 110 against 107 us at 2 x 8192 tokens - developer form only
 // KF = fathers per token held in registers (k_fathers <= KF).
-template <int TM, int WAVES, int KF>
-__global__ void __launch_bounds__(WAVES * 64) up_recon_kernel(const UpReconParams P) {
+// SLOTS = ring slots of a stage each; the DMA runs DIST = SLOTS - 1 tiles ahead (SLOTS 2: also 2 - tile t + 2 goes into tile
+// t's own slot behind the mid-step barrier, when every wave holds the rest of tile t in registers).
+template <int TM, int WAVES, int KF, int SLOTS = (TM == 128 ? 4 : 3)>
+__global__ void __launch_bounds__(WAVES * 64, SLOTS == 2 ? 2 : 1) up_recon_kernel(const UpReconParams P) {
   constexpr int D = 128, HD2 = 64;
   constexpr int NT = WAVES * 64;                       // threads
-  constexpr int STAGES = TM == 128 ? 4 : 3;
+  constexpr int STAGES = SLOTS;
+  constexpr int DIST = SLOTS == 2 ? 2 : SLOTS - 1;
   constexpr int H_TILE = TM * 128;                     // bytes of the hidden tile of a stage
   constexpr int STAGE = H_TILE + kUrWTileBytes;
   constexpr int TOKB = 2;                              // 32-token MFMA blocks of a wave
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(WAVES * 64) up_recon_kernel(const UpReconParam
   constexpr int HG = (TM / 32) / WAVES;                // hidden DMA groups (32 rows, 4 instructions) of a wave per stage
   constexpr int WI = 16 / WAVES;                       // weight DMA instructions (8 rows each) of a wave per stage
   constexpr int PER_TILE = 4 * HG + WI;                // DMA instructions of one wave per stage
-  constexpr int AHEAD = STAGES - 3;                    // tiles still in flight behind the one a step waits for
+  constexpr int AHEAD = DIST - 2;                      // tiles still in flight behind the one a step waits for
   constexpr int RPP = NT / 8;                          // token rows per epilogue pass (8 lanes per token)
   constexpr int NP = TM / RPP;                         // epilogue passes
   static_assert(FEATB == 2 || FEATB == 4, "wave tile");
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(WAVES * 64) up_recon_kernel(const UpReconParam
   };
   const int KT = P.u.k / 64;
 #pragma unroll
-  for (int t = 0; t < STAGES - 1; ++t)
+  for (int t = 0; t < DIST; ++t)
     if (t < KT) issue(t);
 
   // ---- the plan's per-token indices of the epilogue (4 passes of RPP tokens, 8 lanes per token) and the lane's bias
@@ -272,7 +275,7 @@ __global__ void __launch_bounds__(WAVES * 64) up_recon_kernel(const UpReconParam
   };
   bf16x8_t f0[NF], f1[NF], g0[NF], g1[NF];
   // tile 0 has landed: the prologue put STAGES - 1 tiles in flight
-  if (KT >= STAGES - 1 && STAGES == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
+  if (DIST == 3 && KT >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
   else if (KT >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(WAVES * 64) up_recon_kernel(const UpReconParam
     SVK_UR_STAMP(t, 3);
     // (dealing these 8 instructions over the step, two at a time between the MFMA groups, moves their 400-550 cycles
     //  from here into the MFMA phases and leaves the step as long: tools/ur_timing.py, 1716 -> 1700 cycles)
-    if (t + STAGES - 1 < KT) issue(t + STAGES - 1);
+    if (t + DIST < KT) issue(t + DIST);
     SVK_UR_STAMP(t, 4);
     if (t + 1 < KT) read4(sbn, 0, f0);
     mfma4(g0);
@@ -742,14 +745,14 @@ extern "C" int svk_deltakv_up_reconstruct(const SvkDeltakvUpReconArgs* u, const 
   p.debug_same_k = getenv("SVK_UP_RECON_SAME_K") != nullptr && atoi(getenv("SVK_UP_RECON_SAME_K")) != 0;
   const int n_tiles = 2 * first->num_kv_heads;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // token tile: 256 once 128-token tiles would not fit the chip in one round (SVK_UP_RECON_TM = 128 / 256 / 2564 / 512
-  // forces the (128, 4) / (256, 8) / (256, 4) form / the two-head 256 x 256 tile)
+  // more than one round of 128-token tiles: the two-slot form, two workgroups per CU (SVK_UP_RECON_TM = 128 / 1282 / 256 /
+  // 2564 / 512 forces the (128, 4) form with four / two ring slots, the (256, 8) / (256, 4) form, the two-head 256 x 256 tile)
   const char* env = getenv("SVK_UP_RECON_TM");
   const int forced = env ? atoi(env) : 0;
   const int tiles128 = ((first->n + 127) / 128) * n_tiles * b->n_batch;
-  int form = forced ? forced : (tiles128 > 256 ? 256 : 128);
+  int form = forced ? forced : (tiles128 > 256 ? 1282 : 128);
   if (form == 512 && first->num_kv_heads % 2 != 0) form = 256;       // the two-head tile pairs heads
-  const int tm = form == 128 ? 128 : 256;
+  const int tm = (form == 128 || form == 1282) ? 128 : 256;
   p.m_tiles = (first->n + tm - 1) / tm;
   if (form == 512) {
     const dim3 grid2(8u * (unsigned)first->num_kv_heads * (unsigned)((p.m_tiles + 7) / 8), (unsigned)b->n_batch);
@@ -760,17 +763,19 @@ extern "C" int svk_deltakv_up_reconstruct(const SvkDeltakvUpReconArgs* u, const 
     return check_launch("svk_deltakv_up_reconstruct");
   }
   const dim3 grid(8u * (unsigned)n_tiles * (unsigned)((p.m_tiles + 7) / 8), (unsigned)b->n_batch);
-  const size_t shm = form == 128 ? (size_t)4 * (128 * 128 + kUrWTileBytes) : (size_t)3 * (256 * 128 + kUrWTileBytes);
-#define SVK_UR_LAUNCH(TM_, W_)                                                                                         \
+  const size_t shm = form == 128 ? (size_t)4 * (128 * 128 + kUrWTileBytes)
+                                 : (form == 1282 ? (size_t)2 * (128 * 128 + kUrWTileBytes) : (size_t)3 * (256 * 128 + kUrWTileBytes));
+#define SVK_UR_LAUNCH(TM_, W_, S_)                                                                                     \
   do {                                                                                                                 \
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_recon_kernel<TM_, W_, 4>),       \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_recon_kernel<TM_, W_, 4, S_>),   \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess; \
     (void)attr_ok;                                                                                                     \
-    hipLaunchKernelGGL((up_recon_kernel<TM_, W_, 4>), grid, dim3(W_ * 64), shm, s, p);                                 \
+    hipLaunchKernelGGL((up_recon_kernel<TM_, W_, 4, S_>), grid, dim3(W_ * 64), shm, s, p);                             \
   } while (0)
-  if (form == 128) SVK_UR_LAUNCH(128, 4);
-  else if (form == 256) SVK_UR_LAUNCH(256, 8);
-  else SVK_UR_LAUNCH(256, 4);
+  if (form == 128) SVK_UR_LAUNCH(128, 4, 4);
+  else if (form == 1282) SVK_UR_LAUNCH(128, 4, 2);
+  else if (form == 256) SVK_UR_LAUNCH(256, 8, 3);
+  else SVK_UR_LAUNCH(256, 4, 3);
 #undef SVK_UR_LAUNCH
   return check_launch("svk_deltakv_up_reconstruct");
 }

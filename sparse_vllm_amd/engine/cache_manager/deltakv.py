@@ -1100,9 +1100,9 @@ class DeltaKVCacheManager(CacheManager):
             kb = max(k, self._recon_sub_batch())
             hbuf = torch.zeros((kb, n, hid + self._RECON_PAD), dtype=torch.bfloat16, device=self.device)
             hbuf[:, :, hid] = 1.0                                   # the bias feature; the kernel below writes [:, :, :hid] only
-            cur = (hbuf, torch.empty((kb, n, int(w2.shape[1])), dtype=torch.bfloat16, device=self.device))
+            cur = [hbuf, None]                                      # (the delta buffer only if the library GEMM runs)
             store[(n, buf_key)] = cur
-        hp, delta = cur[0][:k], cur[1][:k]
+        hp = cur[0][:k]
         dk.dequant_linear_act(self.deltakv_latent_cache[l0:l1], self.deltakv_latent_scales[l0:l1], self.deltakv_latent_mins[l0:l1],
                               self._quant_group_size(), w1[l0:l1], b1[l0:l1], activation="gelu", row_index=recon_latent,
                               out=hp[:, :, :hid], layers=True)
@@ -1110,17 +1110,15 @@ class DeltaKVCacheManager(CacheManager):
         view = self._recon_view_out(l0, l1, view_geom)
         if view is not None:
             self._recon_view_layers.update(range(l0, l1))
-        fused = self._fused_up_recon_mode()
-        if fused != "0" and dk.deltakv_up_reconstruct_supported(
+        if self._fused_up_recon_mode() != "0" and dk.deltakv_up_reconstruct_supported(
                 head_dim=self.head_dim, num_kv_heads=self.num_kv_heads,
-                k_fathers=int(self.deltakv_latent_to_full_slots.shape[-1]), hidden_features=hid) \
-                and (fused == "always" or -(-n // 128) * 2 * self.num_kv_heads * k > 256):
-            # MI355X: second Linear + reconstruction in one launch, the delta rows stay in LDS (include/svk.h
-            # SvkDeltakvUpReconArgs).  Taken once the launch is more than one round of 128-token tiles (two or more rows
-            # at 2048 selected tokens): alone the fused launch also wins at one row (31 against 35 us per two layers),
-            # but there it holds every CU's LDS for itself while the walk of the layers wants them for its small
-            # launches - measured 1.50-1.52 against 1.49 ms per step; 4 rows: 3.56-3.59 against 3.68 ms.
-            # `SVK_DELTAKV_FUSED_UP=0`: always the library GEMM and the reconstruct launch below; `=always`: always fused
+                k_fathers=int(self.deltakv_latent_to_full_slots.shape[-1]), hidden_features=hid):
+            # MI355X: second Linear + reconstruction in one hand-written MFMA launch, the delta rows stay in LDS
+            # (include/svk.h SvkDeltakvUpReconArgs).  Per two layers alone: 30 against 35 us at 2048
+            # selected tokens, 98 against 110 us at 4 x 2048; in the step 1.496 against 1.501 ms at one row (inside the
+            # noise) and 3.48-3.51 against 3.58-3.59 ms at four.  `SVK_DELTAKV_FUSED_UP=0`: the library GEMM and the
+            # reconstruct launch below (what shapes the fused launch does not serve - head_dim 64, more than four
+            # fathers - always take)
             dk.deltakv_up_reconstruct_layers(
                 hp[:, :, :hid], w2[l0:l1, :, :hid], b2[l0:l1], self.deltakv_latent_to_full_slots[l0:l1], recon_latent,
                 self.deltakv_slot_to_pos, recon_out_slot, recon_pos, self.cos_sin_cache, self.deltakv_full_kv_cache[0, l0:l1],
@@ -1129,6 +1127,9 @@ class DeltaKVCacheManager(CacheManager):
             return
         # (row chunks: this image's hipBLASLt faults inside the batched bf16 GEMM at 8192 rows - plain
         #  torch.bmm([2, 8192, 2112] x [2, 2112, 1024]), tools/probe_bmm2.py; 4096 rows and the per-layer mm are fine)
+        if cur[1] is None:
+            cur[1] = torch.empty((cur[0].shape[0], n, int(w2.shape[1])), dtype=torch.bfloat16, device=self.device)
+        delta = cur[1][:k]
         for c0 in range(0, n, self._RECON_GEMM_ROWS):
             c1 = min(n, c0 + self._RECON_GEMM_ROWS)
             torch.bmm(hp[:, c0:c1], w2[l0:l1].transpose(1, 2), out=delta[:, c0:c1])

@@ -581,7 +581,7 @@ def test_reconstruct_into_view_rows_equals_reconstruct_into_cache_slots(cfg):
                                  dict(B=3, K=40, W=61, off=4, Hkv=2, nl=3, hid=320, kf=2, norm=True, view=True),
                                  dict(B=2, K=129, W=129, off=0, Hkv=8, nl=1, hid=64, kf=1, norm=False, view=False),
                                  dict(B=4, K=2048, W=2184, off=8, Hkv=4, nl=2, hid=2048, kf=4, norm=False, view=True)])
-@pytest.mark.parametrize("form", ["", "128", "256", "2564", "512"])
+@pytest.mark.parametrize("form", ["", "128", "1282", "256", "2564", "512"])
 def test_up_reconstruct_equals_linear_then_reconstruct(cfg, form, monkeypatch):
     """svk_deltakv_up_reconstruct (second Linear of compress_up + reconstruction in one launch, delta in LDS) against
     torch's F.linear (bf16 output) followed by svk_deltakv_reconstruct_writeback_batched: the two differ by the fp32
