@@ -592,8 +592,10 @@ int svk_deltakv_decode_alloc(const SvkDeltakvDecodeAllocArgs* a, svk_stream_t st
  * the two LIFO free stacks with their pointers live in HBM, and the step pops `batch` slots from each stack exactly as the
  * host's `pop(batch)` does (lane b takes stack[ptr - batch + b]; the pointer drops by `batch`), writes the maps and the
  * graph-stable buffers like svk_deltakv_decode_alloc and advances row_len of its rows.  No host data: the launch is a
- * node of the step's hipGraph.  One workgroup; rows must be distinct.  The host keeps mirrors by the same arithmetic and
- * re-uploads the state after anything else touched it (compression, admission, free_seq). */
+ * node of the step's hipGraph.  One workgroup; rows must be distinct and both stacks must hold at least `batch` entries
+ * (the host, which keeps mirrors by the same arithmetic, checks that before it takes this form of the step) - the
+ * launch itself does not test the pointers.  The host re-uploads the state after anything else touched it (compression,
+ * admission, free_seq). */
 typedef struct SvkDeltakvDeviceStepArgs {
   const int32_t* rows;            /* [batch] row of lane b                                        */
   int32_t* row_len;               /* [rows] tokens held (read, then + 1 for the step's rows)      */
