@@ -1,24 +1,22 @@
-"""Operator provider registry — the reference's own pattern (operators/registry.py:120-194), so that a provider class
-written for the reference registers here unchanged and the other way round:
+"""Operator provider registry behind the reference's registration pattern, written from the behaviour
+table in tests/golden/operator_registry.json (what the reference answered to tests/registry_scenarios.py), not from
+the reference's file.  The contract those scenarios pin, and nothing more:
 
-    @REGISTRY.register
-    class Provider:
-        name = "..."; priority = N
-        @classmethod
-        def supports(cls, spec, caps: DeviceCaps) -> SupportResult: ...
-
-`OpRegistry(family)` keeps provider CLASSES by `name` (a second registration of a name is a ValueError),
-`OpResolver(registry).resolve(spec, caps, **provider_kwargs)` asks every class, orders the supporting ones by
-(-priority, name), instantiates the first with `provider_kwargs` and returns `ResolvedProvider(provider, rejected)`
-where `rejected` lists (name, reason) of the classes that declined; no supporting class is a RuntimeError that names the
-family, the spec, the device and every reason.  Bound providers are tracked per family for `operator_runtime_stats()`
-(operators/registry.py:17-72).
+* a provider is a CLASS with `name`, `priority` and a classmethod `supports(spec, caps) -> SupportResult`;
+* `OpRegistry(family).register(cls)` is usable as a decorator, keeps insertion order in `.providers`, and refuses a
+  second class of the same `name` with ValueError("Provider 'x' is already registered for 'family'.");
+* `OpResolver(registry).resolve(spec, caps, **ctor_kwargs)` instantiates the accepting class of highest priority (ties:
+  smallest name) and reports every declining class as `(name, reason)` in registration order; when nobody accepts it
+  raises RuntimeError("No <family> provider supports spec=... on device='...': a: why; b: why.") — or
+  "...: no providers registered." for an empty family;
+* every resolved instance is remembered weakly per family so that `operator_runtime_stats()` can sum the counters of the
+  live ones.
 """
 
 from __future__ import annotations
 
-import re
 import weakref
+from collections import Counter, defaultdict
 from dataclasses import dataclass
 from typing import Generic, Protocol, TypeVar
 
@@ -27,57 +25,84 @@ from ..platforms.interface import DeviceCaps, PlatformEnum  # noqa: F401  (re-ex
 SpecT = TypeVar("SpecT")
 ProviderT = TypeVar("ProviderT", bound="OperatorProvider")
 
+# family -> weak set of bound provider instances (a provider that died drops out of the statistics by itself)
 _OPERATOR_BINDINGS: dict[str, "weakref.WeakSet[object]"] = {}
 
 
 def record_operator_binding(operator_type: str, provider: object) -> None:
-    _OPERATOR_BINDINGS.setdefault(operator_type, weakref.WeakSet()).add(provider)
+    live = _OPERATOR_BINDINGS.get(operator_type)
+    if live is None:
+        live = _OPERATOR_BINDINGS[operator_type] = weakref.WeakSet()
+    live.add(provider)
 
 
-def _implementation_name(provider: object) -> str:
-    return getattr(provider, "implementation_name", None) or getattr(provider, "name", None) or provider.provider_name
+class _ImplTally:
+    """Counters of all live providers that share one implementation label."""
+
+    __slots__ = ("bound", "instrumented", "paths", "fallbacks")
+
+    def __init__(self) -> None:
+        self.bound = 0
+        self.instrumented = 0
+        self.paths: defaultdict[str, Counter] = defaultdict(Counter)
+        self.fallbacks: Counter = Counter()
+
+    def absorb(self, provider: object) -> None:
+        self.bound += 1
+        probe = getattr(provider, "runtime_kernel_stats", None)
+        if not callable(probe):
+            return
+        self.instrumented += 1
+        report = probe() or {}
+        for path, counters in (report.get("kernel_paths") or {}).items():
+            self.paths[str(path)].update({str(k): int(v) for k, v in counters.items()})
+        self.fallbacks.update({str(k): int(v) for k, v in (report.get("fallback_reasons") or {}).items()})
+
+    def entry(self, label: str) -> dict[str, object]:
+        # Counter.update() keeps zero counts, which the table shows ("noncontiguous:output": 0)
+        return {"implementation": label, "bound_provider_count": self.bound,
+                "instrumented_provider_count": self.instrumented,
+                "kernel_paths": {p: {k: self.paths[p][k] for k in sorted(self.paths[p])} for p in sorted(self.paths)},
+                "fallback_reasons": {k: self.fallbacks[k] for k in sorted(self.fallbacks)}}
+
+
+def _label_of(provider: object) -> str:
+    for attr in ("implementation_name", "name", "provider_name"):
+        label = getattr(provider, attr, None)
+        if label:
+            return str(label)
+    return type(provider).__name__
 
 
 def operator_runtime_stats() -> dict[str, list[dict[str, object]]]:
-    """Per operator family, per implementation: how many live providers are bound and the kernel-path / fallback counters
-    of those that expose `runtime_kernel_stats()` (summed)."""
-    out: dict[str, list[dict[str, object]]] = {}
-    for family in sorted(_OPERATOR_BINDINGS):
-        by_impl: dict[str, list[object]] = {}
-        for provider in _OPERATOR_BINDINGS[family]:
-            by_impl.setdefault(_implementation_name(provider), []).append(provider)
-        entries = []
-        for impl in sorted(by_impl):
-            paths: dict[str, dict[str, int]] = {}
-            fallbacks: dict[str, int] = {}
-            instrumented = 0
-            for provider in by_impl[impl]:
-                fn = getattr(provider, "runtime_kernel_stats", None)
-                if not callable(fn):
-                    continue
-                instrumented += 1
-                stats = fn()
-                for path, counts in stats.get("kernel_paths", {}).items():
-                    agg = paths.setdefault(str(path), {})
-                    for key, n in counts.items():
-                        agg[str(key)] = int(agg.get(str(key), 0)) + int(n)
-                for reason, n in stats.get("fallback_reasons", {}).items():
-                    fallbacks[str(reason)] = int(fallbacks.get(str(reason), 0)) + int(n)
-            entries.append({"implementation": impl, "bound_provider_count": len(by_impl[impl]),
-                            "instrumented_provider_count": instrumented,
-                            "kernel_paths": {p: dict(sorted(c.items())) for p, c in sorted(paths.items())},
-                            "fallback_reasons": dict(sorted(fallbacks.items()))})
-        if entries:
-            out[family] = entries
-    return out
+    """{family: [one entry per implementation label, sorted]} over the providers that are still alive; families whose
+    providers are all gone are left out."""
+    tallies: dict[tuple[str, str], _ImplTally] = {}
+    for family, live in _OPERATOR_BINDINGS.items():
+        for provider in tuple(live):
+            key = (family, _label_of(provider))
+            tally = tallies.get(key)
+            if tally is None:
+                tally = tallies[key] = _ImplTally()
+            tally.absorb(provider)
+    report: dict[str, list[dict[str, object]]] = {}
+    for family, label in sorted(tallies):
+        report.setdefault(family, []).append(tallies[(family, label)].entry(label))
+    return report
 
 
 def runtime_version_at_least(version: str | None, minimum: tuple[int, int]) -> bool:
-    """operators/registry.py:107-117: "major.minor..." >= minimum; None / unparsable -> False."""
+    """True when `version` starts with "<major>.<minor>" (anything may follow the minor digits) and (major, minor) is
+    not below `minimum`.  None, a bare major ("13") and non-numeric text are False."""
     if version is None:
         return False
-    m = re.match(r"^\s*(\d+)\.(\d+)", str(version))
-    return m is not None and (int(m.group(1)), int(m.group(2))) >= tuple(minimum)
+    major, dot, rest = str(version).strip().partition(".")
+    digits = rest[: len(rest) - len(rest.lstrip("0123456789"))]
+    if not (dot and major.isdigit() and digits):
+        return False
+    want_major, want_minor = (int(x) for x in minimum)
+    have = (int(major), int(digits))
+    return have[0] > want_major or (have[0] == want_major and have[1] >= want_minor)
 
 
 @dataclass(frozen=True)
@@ -87,11 +112,11 @@ class SupportResult:
 
     @classmethod
     def yes(cls, reason: str = "supported") -> "SupportResult":
-        return cls(True, reason)
+        return cls(supported=True, reason=reason)
 
     @classmethod
     def no(cls, reason: str) -> "SupportResult":
-        return cls(False, reason)
+        return cls(supported=False, reason=reason)
 
 
 class OperatorProvider(Protocol[SpecT]):
@@ -103,15 +128,17 @@ class OperatorProvider(Protocol[SpecT]):
 
 
 class OpRegistry(Generic[SpecT, ProviderT]):
+    """The provider classes of one operator family, in registration order."""
+
     def __init__(self, family: str) -> None:
         self.family = str(family)
         self._providers: dict[str, type] = {}
 
     def register(self, provider: type) -> type:
-        name = str(provider.name)
-        if name in self._providers:
-            raise ValueError(f"Provider {name!r} is already registered for {self.family!r}.")
-        self._providers[name] = provider
+        key = str(provider.name)
+        if key in self._providers:            # also the same class twice
+            raise ValueError(f"Provider {key!r} is already registered for {self.family!r}.")
+        self._providers[key] = provider
         return provider
 
     @property
@@ -130,19 +157,23 @@ class OpResolver(Generic[SpecT, ProviderT]):
         self.registry = registry
 
     def resolve(self, spec, caps: DeviceCaps, **provider_kwargs) -> ResolvedProvider:
-        accepted: list[type] = []
-        rejected: list[tuple[str, str]] = []
-        for cls in self.registry.providers:
-            verdict = cls.supports(spec, caps)
-            if verdict.supported:
-                accepted.append(cls)
-            else:
-                rejected.append((cls.name, verdict.reason))
-        if not accepted:
-            details = "; ".join(f"{name}: {reason}" for name, reason in rejected)
-            raise RuntimeError(f"No {self.registry.family} provider supports spec={spec!r} on "
-                               f"device={caps.device_name!r}: {details or 'no providers registered'}.")
-        accepted.sort(key=lambda cls: (-int(cls.priority), cls.name))
-        chosen = accepted[0](**provider_kwargs)
-        record_operator_binding(self.registry.family, chosen)
-        return ResolvedProvider(chosen, tuple(rejected))
+        winner: type | None = None
+        declined: list[tuple[str, str]] = []
+        for candidate in self.registry.providers:
+            answer = candidate.supports(spec, caps)
+            if not answer.supported:
+                declined.append((candidate.name, answer.reason))
+            elif winner is None or self._rank(candidate) < self._rank(winner):
+                winner = candidate
+        if winner is None:
+            why = "; ".join(f"{n}: {r}" for n, r in declined) if declined else "no providers registered"
+            raise RuntimeError(f"No {self.registry.family} provider supports spec={spec!r} "
+                               f"on device={caps.device_name!r}: {why}.")
+        instance = winner(**provider_kwargs)
+        record_operator_binding(self.registry.family, instance)
+        return ResolvedProvider(provider=instance, rejected=tuple(declined))
+
+    @staticmethod
+    def _rank(provider: type) -> tuple[int, str]:
+        """Smaller is better: higher priority first, then the smaller name."""
+        return (-int(provider.priority), str(provider.name))

@@ -1,26 +1,26 @@
-"""CPU platform: import / unit-test paths only, as in the reference (platforms/cpu.py:8-44) — no inference."""
+"""CPU platform: import / unit-test paths only (the reference's CPU platform never runs inference either).
+Behaviour pinned by tests/golden/operator_registry.json `platforms.cpu`."""
 
 from __future__ import annotations
 
+import dataclasses
+
 import torch
 
-from .interface import DeviceCaps, Platform, PlatformEnum
+from .interface import Platform, PlatformEnum
+
+_HOST = torch.device("cpu")
 
 
 class CpuPlatform(Platform):
     name = "cpu"
-    device_type = "cpu"
+    device_type = _HOST.type
     enum = PlatformEnum.CPU
 
-    def check_available(self) -> bool:
-        return True
+    check_available = staticmethod(lambda: True)            # the host is always there
+    set_device = staticmethod(lambda device=None: None)     # one host, nothing to select
+    get_device = staticmethod(lambda local_rank=0: _HOST)
 
-    def get_device(self, local_rank: int = 0) -> torch.device:
-        return torch.device("cpu")
-
-    def set_device(self, device) -> None:
-        return None
-
-    def get_device_caps(self, device_index: int = 0) -> DeviceCaps:
-        return DeviceCaps(platform=self.enum, device_type=self.device_type, device_index=int(device_index),
-                          device_name="cpu", supports_bfloat16=True)
+    def get_device_caps(self, device_index: int = 0):
+        # torch's CPU kernels do bf16 arithmetic; nothing else a GPU provider asks for exists here
+        return dataclasses.replace(super().get_device_caps(device_index), supports_bfloat16=True)

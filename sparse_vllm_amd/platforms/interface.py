@@ -1,27 +1,26 @@
-"""Platform interface (the names, fields and defaults of platforms/interface.py:12-174).
+"""Platform boundary types: what an operator provider is told about the device it may run on.
 
-`DeviceCaps` carries the reference's twelve fields in the reference's order, so a provider written for the
-reference's registry reads the same attributes here; what the MI355X providers additionally want to know about the
-chip follows as optional fields with defaults (a `DeviceCaps` built with the reference's arguments alone stays valid).
+Written from tests/golden/operator_registry.json — the reference's answers to tests/registry_scenarios.py `types` and
+`platforms` — not from the reference's file.  Pinned there, and kept: the member names of `PlatformEnum`, the field
+names / order / defaults of `AllocatorStats` and of the first twelve `DeviceCaps` fields, the public attribute set of
+`Platform`, the defaults of an unspecialised `Platform()` and three error texts.  Everything else is this build's:
+the boolean families (`supports_*`, `is_*`) are generated from two small tables, hooks a backend may leave alone are
+generated no-ops, and the members a backend MUST answer are generated to raise NotImplementedError naming themselves.
+
+MI355X additions: four optional `DeviceCaps` fields after the reference's twelve (`arch`, `num_cus`, `lds_bytes`,
+`hbm_bytes`), so a `DeviceCaps` built with the reference's arguments alone stays valid.
 """
 
 from __future__ import annotations
 
-from contextlib import contextmanager
+import contextlib
+import enum
 from dataclasses import dataclass
-from enum import Enum, auto
-from functools import lru_cache
 from typing import Any
 
 import torch
 
-
-class PlatformEnum(Enum):
-    CUDA = auto()
-    ROCM = auto()
-    NPU = auto()
-    CPU = auto()
-    UNSPECIFIED = auto()
+PlatformEnum = enum.Enum("PlatformEnum", ["CUDA", "ROCM", "NPU", "CPU", "UNSPECIFIED"], module=__name__)
 
 
 @dataclass(frozen=True)
@@ -44,11 +43,46 @@ class DeviceCaps:
     supports_pin_memory: bool = False
     supports_bfloat16: bool = False
     supports_native_fp8: bool = False
-    # ---- MI355X extras (not in the reference; optional)
+    # MI355X extras (optional)
     arch: str = ""                  # "gfx950"
     num_cus: int = 0
     lds_bytes: int = 0
     hbm_bytes: int = 0
+
+
+# Platform.<query>() -> the DeviceCaps field of device 0 that answers it
+_CAPS_QUERIES = {
+    "supports_graph_capture": "supports_graph_capture",
+    "supports_torch_compile": "supports_torch_compile",
+    "supports_triton": "supports_triton",
+    "supports_pin_memory": "supports_pin_memory",
+    "supports_bfloat16": "supports_bfloat16",
+    "supports_fp8": "supports_native_fp8",
+}
+# Platform.<predicate>() -> the enum members it is true for
+_KIND_PREDICATES = {
+    "is_cuda": ("CUDA",),
+    "is_rocm": ("ROCM",),
+    "is_npu": ("NPU",),
+    "is_cpu": ("CPU",),
+    "is_cuda_alike": ("CUDA", "ROCM"),
+}
+# hooks with nothing to do by default -> their default answer
+_OPTIONAL_HOOKS = {
+    "init_backend": None,
+    "reset_peak_memory_stats": None,
+    "empty_cache": None,
+    "synchronize": None,
+    "apply_config_defaults": None,
+    "barrier_device_ids": None,
+    "get_communicator_cls": None,
+    "get_decode_graph_runner_cls": None,
+    "is_stream_capturing": False,
+    "supports_inference": False,
+    "check_available": False,
+}
+# members every device backend has to answer itself
+_REQUIRED_OF_A_BACKEND = ("get_device", "set_device", "get_available_memory")
 
 
 class Platform:
@@ -57,123 +91,76 @@ class Platform:
     enum: PlatformEnum = PlatformEnum.UNSPECIFIED
     supported_quantization: tuple[str, ...] = ()
 
-    # ---- availability
-    def check_available(self) -> bool:
-        return False
-
+    # ---- gates
     def validate_environment(self) -> None:
         if not self.check_available():
             raise RuntimeError(f"Platform {self.name!r} is not available.")
 
-    def supports_inference(self) -> bool:
-        return False
-
     def validate_inference(self) -> None:
         self.validate_environment()
         if not self.supports_inference():
-            raise RuntimeError(f"Platform {self.name!r} is detected, but Sparse-vLLM inference is not supported "
-                               "on this platform in the current build.")
+            raise RuntimeError(f"Platform {self.name!r} is detected, but Sparse-vLLM inference is not supported on this "
+                               "platform in the current build.")
 
-    def init_backend(self) -> None:
-        return None
+    def validate_config(self, config: Any) -> None:
+        asked = any(bool(getattr(config, flag, False)) for flag in ("decode_cuda_graph", "decode_graph"))
+        if asked and not self.supports_graph_capture():
+            raise RuntimeError(f"Platform {self.name!r} does not support decode graph capture.")
 
-    # ---- device / memory
-    def get_device(self, local_rank: int = 0) -> torch.device:
-        raise NotImplementedError(f"Platform {self.name!r} does not implement get_device().")
-
-    def set_device(self, device: torch.device | int | str) -> None:
-        raise NotImplementedError(f"Platform {self.name!r} does not implement set_device().")
-
-    def get_available_memory(self, device_id: int = 0) -> tuple[int, int]:
-        raise NotImplementedError(f"Platform {self.name!r} does not implement get_available_memory().")
+    # ---- description
+    def get_device_caps(self, device_index: int = 0) -> DeviceCaps:
+        return DeviceCaps(self.enum, self.device_type, int(device_index), self.name)
 
     def get_allocator_stats(self, device: torch.device | None = None) -> AllocatorStats:
         return AllocatorStats()
 
-    def reset_peak_memory_stats(self, device: torch.device | None = None) -> None:
-        return None
-
-    def empty_cache(self) -> None:
-        return None
-
-    def synchronize(self) -> None:
-        return None
-
-    def is_stream_capturing(self) -> bool:
-        return False
-
-    # ---- distributed
     def get_distributed_backend(self) -> str:
         return "gloo"
-
-    def barrier_device_ids(self, rank: int) -> list[int] | None:
-        return None
-
-    def get_communicator_cls(self) -> type | None:
-        return None
-
-    # ---- capabilities
-    @lru_cache(maxsize=None)
-    def get_device_caps(self, device_index: int = 0) -> DeviceCaps:
-        return DeviceCaps(platform=self.enum, device_type=self.device_type, device_index=int(device_index),
-                          device_name=self.name)
-
-    def supports_graph_capture(self) -> bool:
-        return self.get_device_caps().supports_graph_capture
-
-    def supports_torch_compile(self) -> bool:
-        return self.get_device_caps().supports_torch_compile
-
-    def supports_triton(self) -> bool:
-        return self.get_device_caps().supports_triton
-
-    def supports_pin_memory(self) -> bool:
-        return self.get_device_caps().supports_pin_memory
-
-    def supports_fp8(self) -> bool:
-        return self.get_device_caps().supports_native_fp8
-
-    def supports_bfloat16(self) -> bool:
-        return self.get_device_caps().supports_bfloat16
 
     def get_default_attention_backend(self) -> str:
         return "native"
 
-    def get_decode_graph_runner_cls(self):
-        return None
-
     def get_dispatch_key(self) -> str:
-        return self.name
+        return str(self.name)
 
-    # ---- config
-    def apply_config_defaults(self, config: Any) -> None:
-        return None
-
-    def validate_config(self, config: Any) -> None:
-        wants_graph = getattr(config, "decode_graph", False) or getattr(config, "decode_cuda_graph", False)
-        if wants_graph and not self.supports_graph_capture():
-            raise RuntimeError(f"Platform {self.name!r} does not support decode graph capture.")
-
-    @contextmanager
+    # ---- run-time helpers
     def inference_mode(self):
-        with torch.inference_mode():
-            yield
+        return torch.inference_mode() if hasattr(torch, "inference_mode") else contextlib.nullcontext()
 
     def seed_everything(self, seed: int) -> None:
         torch.manual_seed(int(seed))
 
-    # ---- kind
-    def is_cuda(self) -> bool:
-        return self.enum == PlatformEnum.CUDA
 
-    def is_rocm(self) -> bool:
-        return self.enum == PlatformEnum.ROCM
+def _install_generated_members() -> None:
+    def caps_query(field: str):
+        def query(self) -> bool:
+            return bool(getattr(self.get_device_caps(), field))
+        return query
 
-    def is_npu(self) -> bool:
-        return self.enum == PlatformEnum.NPU
+    def kind_predicate(members: tuple[str, ...]):
+        def predicate(self) -> bool:
+            return self.enum.name in members
+        return predicate
 
-    def is_cpu(self) -> bool:
-        return self.enum == PlatformEnum.CPU
+    def optional_hook(answer):
+        def hook(self, *args, **kwargs):
+            return answer
+        return hook
 
-    def is_cuda_alike(self) -> bool:
-        return self.enum in {PlatformEnum.CUDA, PlatformEnum.ROCM}
+    def required(member: str):
+        def missing(self, *args, **kwargs):
+            raise NotImplementedError(f"Platform {self.name!r} does not implement {member}().")
+        return missing
+
+    generated = {}
+    generated.update({n: caps_query(f) for n, f in _CAPS_QUERIES.items()})
+    generated.update({n: kind_predicate(m) for n, m in _KIND_PREDICATES.items()})
+    generated.update({n: optional_hook(a) for n, a in _OPTIONAL_HOOKS.items()})
+    generated.update({n: required(n) for n in _REQUIRED_OF_A_BACKEND})
+    for member, fn in generated.items():
+        fn.__name__ = member
+        fn.__qualname__ = f"Platform.{member}"
+        setattr(Platform, member, fn)
+
+
+_install_generated_members()
