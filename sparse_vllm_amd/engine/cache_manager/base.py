@@ -184,6 +184,8 @@ class CacheManager(ABC):
                 self.flush_deferred_decode_store()
                 self._deferred_decode_store = (int(layer_idx), k, v, slots)
                 return
+        else:
+            self.drop_deferred_decode_store()          # rows of a decode step that never finished: their slots are history
         self._store_rows_now(layer_idx, k, v, self.get_layer_batch_states(layer_idx).slot_mapping)
 
     def _store_rows_now(self, layer_idx: int, k: torch.Tensor, v: torch.Tensor, slot_mapping: torch.Tensor):
@@ -203,6 +205,12 @@ class CacheManager(ABC):
     def store_deferred_decode_rows(self, layer_idx: int, new_kv) -> None:
         k, v, slots = new_kv
         self._store_rows_now(layer_idx, k, v, slots)
+
+    def drop_deferred_decode_store(self) -> None:
+        """Forget rows held back by a step that did not finish (a layer raised between `save_rope_kv_if_needed` and the
+        launch that takes the rows).  Their slot ids belong to that step: storing them later could write into slots that
+        have since been freed and handed to another sequence.  Called at the start of every step."""
+        self._deferred_decode_store = None
 
     def flush_deferred_decode_store(self) -> None:
         """Rows that no attention launch took (a layer left early): store them with a launch of their own."""

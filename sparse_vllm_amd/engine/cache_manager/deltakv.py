@@ -708,6 +708,11 @@ class DeltaKVCacheManager(CacheManager):
                 raise RuntimeError("DeltaKV raw tail exceeds the static decode buffer; deltakv_evict (the compression "
                                    "side) must run after every forward (SparseController.post_forward): "
                                    f"tail={int(buf.max()) + 1} max_buffer={self._deltakv_decode_static_max_buffer()}.")
+            prev = self._device_step
+            if prev is not None and not prev[1]:
+                # the previous step's allocation launch never ran (its forward raised, or the caller deferred and never
+                # launched): the host mirrors moved, the device copies did not - they stand for nothing until re-uploaded
+                self._dev_stands_for = None
             self._device_step = None
             use_device = self._device_step_enabled and slot_mapping is None and context_lens is None and req_indices is None \
                 and len(set(rows.tolist())) == B and min(self._pool_full.free, self._pool_sparse.free) >= B

@@ -109,6 +109,7 @@ class SparseDecodeDriver:
         """`after_layers()` (measurement hook) runs between the layer loop and post_forward."""
         cm, sc = self.cache_manager, self.sparse_controller
         seqs = self.seqs
+        cm.drop_deferred_decode_store()          # (only a step that raised leaves rows behind)
         # a manager with device-resident bookkeeping (H2O) hands its allocation and its predicated burst over as launches
         # of the step: with the layer loop they are ONE hipGraph and the step uploads nothing
         dev = hasattr(cm, "device_step_begin")
@@ -170,6 +171,7 @@ class SparseDecodeDriver:
         q [L, tokens, Hq, D], k/v [L, tokens, Hkv, D]; every seq needs `current_chunk_size`.  `k_raw` [L, tokens, Hkv, D]:
         the pre-RoPE keys a model hands to `save_raw_kv_if_needed` (models/qwen2.py:118-125; default: `k`)."""
         cm, sc = self.cache_manager, self.sparse_controller
+        cm.drop_deferred_decode_store()
         out = cm._prepare_prefill(seqs)
         cu = out[0] if isinstance(out, tuple) else None
         if cu is None:

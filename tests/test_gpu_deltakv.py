@@ -644,3 +644,81 @@ def test_up_reconstruct_equals_linear_then_reconstruct(cfg, form, monkeypatch):
         g, r = got.float(), ref.float()
         torch.testing.assert_close(g, r, rtol=2 ** -6, atol=2 ** -6)
         assert float((got.view(torch.int16) == ref.view(torch.int16)).float().mean()) > 0.97
+
+
+@pytest.mark.parametrize("norm,view", [(False, True), (True, True), (False, False), (True, False)])
+@pytest.mark.parametrize("form", ["", "128", "1282", "256", "2564", "512"])
+def test_up_reconstruct_matches_oracle(form, norm, view, monkeypatch):
+    """svk_deltakv_up_reconstruct — the default reconstruction launch at BASELINE configs[4]'s shape — against the ORACLE,
+    not against this build's other launches: delta = bf16(hidden @ W2^T + b2) (the second Linear of `compress_up`,
+    utils/compressor.py:69-73, a bf16 torch module: fp32 accumulation, bf16 output) fed to
+    oracle.deltakv.reconstruct_writeback(delta=...) (kernels/triton/deltakv_kernels.py:2732-2907).  Qwen2.5-7B shape:
+    Hkv 4, D 128, hidden 2048, 4 fathers; k-norm on/off; dead plan entries; view rows and cache slots as destination;
+    every SVK_UP_RECON_TM tile form and the launch's own choice.  Tolerance: the oracle rounds delta to bf16 after a
+    numpy fp32 product whose summation order differs from the MFMA's, so a delta element may sit one bf16 ulp away
+    (2^-8 relative) before the father mean is added: rtol = atol = 2^-6 on the bf16 rows, and >= 97 % of them bit-equal."""
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    if form:
+        monkeypatch.setenv("SVK_UP_RECON_TM", form)
+    B, K, W, off, Hkv, D, nl, hid, kf = 2, 300, 330, 8, 4, 128, 2, 2048, 4
+    rng = np.random.default_rng(17 + 2 * norm + view)
+    n, latents, slots, max_p = B * K, 900, 2400, 700
+    hidden = bf16_round((rng.standard_normal((nl, n, hid)) * 0.5).astype(np.float32))
+    weight = bf16_round((rng.standard_normal((nl, 2 * Hkv * D, hid)) * hid ** -0.5).astype(np.float32))
+    bias = bf16_round((rng.standard_normal((nl, 2 * Hkv * D)) * 0.1).astype(np.float32))
+    table = rng.integers(-1, slots // 2, (nl, latents, kf)).astype(np.int32)
+    row_index = rng.integers(0, latents, n).astype(np.int32)
+    s2p = rng.integers(0, max_p, slots).astype(np.int32)
+    out_slots = (slots // 2 + rng.permutation(slots // 2)[:n]).astype(np.int32)
+    out_pos = rng.integers(0, max_p, n).astype(np.int32)
+    dead = rng.random(n) < 0.1
+    out_slots[dead], out_pos[dead], row_index[dead] = -1, -1, -1
+    inv = 1.0 / (1e6 ** (np.arange(D // 2) / (D // 2)))
+    ang = np.arange(max_p)[:, None] * inv[None, :]
+    cos_sin = np.concatenate((np.cos(ang), np.sin(ang)), axis=1).astype(np.float32)
+    knw = (rng.random((nl, D)) + 0.5).astype(np.float32) if norm else None
+    k0 = bf16_round((rng.standard_normal((nl, slots, Hkv, D)) * 0.3).astype(np.float32))
+    v0 = bf16_round((rng.standard_normal((nl, slots, Hkv, D)) * 0.3).astype(np.float32))
+
+    gk, gv = to_bf16(k0), to_bf16(v0)
+    if view:
+        vk = torch.full((nl, B * W, Hkv, D), 7.0, dtype=torch.bfloat16, device=dev())
+        vv = torch.full((nl, B * W, Hkv, D), 9.0, dtype=torch.bfloat16, device=dev())
+        view_out = (vk, vv, W, off, K)
+    else:
+        view_out = None
+    assert dk.deltakv_up_reconstruct_supported(head_dim=D, num_kv_heads=Hkv, k_fathers=kf, hidden_features=hid)
+    dk.deltakv_up_reconstruct_layers(to_bf16(hidden), to_bf16(weight), to_bf16(bias), t(table), t(row_index), t(s2p),
+                                     t(out_slots), t(out_pos), t(cos_sin), gk, gv,
+                                     k_norm_weight=t(knw) if norm else None, view_out=view_out)
+    torch.cuda.synchronize()
+
+    live = ~dead
+    rows = (np.arange(n) // K) * W + off + np.arange(n) % K
+    exact = []
+    for l in range(nl):
+        delta = bf16_round((hidden[l] @ weight[l].T + bias[l]).astype(np.float32))
+        ek, ev = k0[l].copy(), v0[l].copy()
+        od.reconstruct_writeback(ek, ev, father_slots=np.maximum(table[l][np.maximum(row_index, 0)], 0), slot_to_pos=s2p,
+                                 out_slots=out_slots, out_pos=out_pos, cos_sin=cos_sin, delta=delta,
+                                 k_norm_weight=knw[l] if norm else None, raw_k_cache=True, store_raw_k=False)
+        if view:
+            # caches are read-only; live entries land in their view rows; nothing else in the view is touched
+            np.testing.assert_array_equal(gk[l].float().cpu().numpy(), k0[l])
+            np.testing.assert_array_equal(gv[l].float().cpu().numpy(), v0[l])
+            got_k, got_v = vk[l].float().cpu().numpy(), vv[l].float().cpu().numpy()
+            untouched = np.ones(B * W, bool)
+            untouched[rows[live]] = False
+            assert (got_k[untouched] == 7.0).all() and (got_v[untouched] == 9.0).all()
+            pairs = ((got_k[rows[live]], ek[out_slots[live]]), (got_v[rows[live]], ev[out_slots[live]]))
+        else:
+            got_k, got_v = gk[l].float().cpu().numpy(), gv[l].float().cpu().numpy()
+            other = np.ones(slots, bool)
+            other[out_slots[live]] = False
+            np.testing.assert_array_equal(got_k[other], k0[l][other])      # dead entries and foreign slots: not written
+            np.testing.assert_array_equal(got_v[other], v0[l][other])
+            pairs = ((got_k[out_slots[live]], ek[out_slots[live]]), (got_v[out_slots[live]], ev[out_slots[live]]))
+        for got, ref in pairs:
+            np.testing.assert_allclose(got, ref, rtol=2 ** -6, atol=2 ** -6)
+            exact.append(float((got == ref).mean()))
+    assert min(exact) > 0.97, exact

@@ -49,19 +49,37 @@ def linear_up(mod, x):
     # the published form: int4 latents through the two-Linear GELU compress_up - the fused residual load, the look-ahead
     # reconstruction in groups of two layers on the side stream and the reconstruction straight into the layers' views
     dict(layers=8, full="0,4", kivi=True, up="mlp_gelu", bits=4, lens=[148, 92], Hq=8, Hkv=2, D=64),
+    # BASELINE configs[4]'s head shape (Qwen2.5-7B: 28 / 4 heads of 128), int4 latents, two-Linear GELU compress_up with a
+    # hidden width the fused launch serves (a multiple of 64), four fathers, look-ahead on: the DEFAULT reconstruction here
+    # is `svk_deltakv_up_reconstruct` (second Linear + reconstruction in one launch) and the test asserts that it ran
+    dict(layers=7, full="0,3", kivi=True, up="mlp_gelu", bits=4, lens=[180, 97], Hq=28, Hkv=4, D=128, latent=64, group=32,
+         inter=128, Kf=4, keep=40, fused=True),
 ])
-def test_deltakv_decode_steps_match_oracle(cfg):
+def test_deltakv_decode_steps_match_oracle(cfg, monkeypatch):
     from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
     from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
     B, L = len(cfg["lens"]), cfg["layers"]
-    sink, recent, keep, Kf = 4, 8, 12, 2
+    sink, recent, keep, Kf = 4, 8, cfg.get("keep", 12), cfg.get("Kf", 2)
+    group = cfg.get("group", 16)
+    fused_calls = {"n": 0, "layers": 0}
+    fused_launch = dk.deltakv_up_reconstruct_layers
+
+    def counted(hidden, *a, **k):
+        fused_calls["n"] += 1
+        fused_calls["layers"] += int(hidden.shape[0])
+        return fused_launch(hidden, *a, **k)
+    monkeypatch.setattr(dk, "deltakv_up_reconstruct_layers", counted)
+    monkeypatch.delenv("SVK_DELTAKV_FUSED_UP", raising=False)       # the defaults are what is under test
+    monkeypatch.delenv("SVK_DELTAKV_RECON_AHEAD", raising=False)
     conf = Config.from_kwargs(
         sparse_method="deltakv", num_hidden_layers=L, full_attention_layers=cfg["full"], num_attention_heads=cfg["Hq"],
         num_key_value_heads=cfg["Hkv"], head_dim=cfg["D"], max_model_len=256, max_num_seqs_in_gpu=B + 1,
         sink_keep_tokens=sink, recent_keep_tokens=recent, decode_keep_tokens=keep, deltakv_neighbor_count=Kf,
-        deltakv_latent_dim=32, deltakv_latent_quant_bits=cfg["bits"], deltakv_latent_quant_group_size=16,
+        deltakv_latent_dim=cfg.get("latent", 32), deltakv_latent_quant_bits=cfg["bits"],
+        deltakv_latent_quant_group_size=group,
         deltakv_center_ratio=0.25, allow_missing_deltakv_path=True, compressor_up_type=cfg["up"],
-        compressor_intermediate_size=48, full_layer_kv_quant_bits=4 if cfg["kivi"] else 0,
+        compressor_intermediate_size=cfg.get("inter", 48), full_layer_kv_quant_bits=4 if cfg["kivi"] else 0,
         full_layer_kivi_decode_block_seq=64, rope_theta=10000.0)
     drv = SparseDecodeDriver(conf)
     cm, sc = drv.cache_manager, drv.sparse_controller
@@ -159,7 +177,7 @@ def test_deltakv_decode_steps_match_oracle(cfg):
             need = rl >= 0
             safe_l = np.maximum(rl, 0)
             if cfg["bits"]:
-                x = bf16_round(od.dequantize_grouped(lat_code[i][safe_l], lat_scale[i][safe_l], lat_mn[i][safe_l], 16, 4))
+                x = bf16_round(od.dequantize_grouped(lat_code[i][safe_l], lat_scale[i][safe_l], lat_mn[i][safe_l], group, 4))
             else:
                 x = lat_dense[i][safe_l]
             delta = linear_up(cm.compress_up[i], x)
@@ -196,6 +214,12 @@ def test_deltakv_decode_steps_match_oracle(cfg):
             centres = raw_after[r, sink:sink + c] >= 0
             assert centres.sum() == len(cm.row_deltakv_center_slots.get(int(r), [0] * sink)) - sink or c == 0
     assert n_evictions >= 2 * B - 1
+    n_steps = cfg.get("steps", 28)
+    if cfg.get("fused"):
+        # every sparse layer of every step went through the fused second-Linear + reconstruction launch
+        assert fused_calls["layers"] == n_steps * len(cm.deltakv_layer_ids), fused_calls
+    else:
+        assert fused_calls["n"] == 0, fused_calls          # (shapes the fused launch does not serve)
 
 
 def test_deltakv_free_seq_returns_every_slot():

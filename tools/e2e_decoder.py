@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """End-to-end decode leg: a random-weight Qwen2.5-7B-SHAPED decoder whose attention is this build's hot path.
 
 MEASUREMENT SCAFFOLDING, not product code ("random bf16 Qwen2.5-7B-shaped weights when measuring

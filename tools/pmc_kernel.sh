@@ -1,8 +1,19 @@
 #!/bin/bash
 # developer tool: SQ / GRBM counters of the kernels whose name contains <pattern> while <command...> runs (counters only,
 # one group per pass):   tools/pmc_kernel.sh <pattern> <out-tag> <command...>
+# <command...> must START with the program itself (python3 <script> ... or an ELF binary): with --pmc the profiler's
+# preloaded library initialises the GPU before the program starts, so a launcher hop (env VAR=..., bash -c, sh -c, taskset,
+# numactl, a script run through its #! line) is an exec from a GPU-initialised process - on this pool that takes the box
+# down.  Export knobs BEFORE calling this script:   SVK_UP_RECON_TM=256 tools/pmc_kernel.sh up_recon ur256 python3 tools/ur_one.py
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 PAT=$1; TAG=$2; shift 2
+case "$(basename "$1")" in
+  python3|python) ;;
+  env|bash|sh|taskset|numactl|timeout|nice|*.py|*.sh)
+    echo "pmc_kernel.sh: refusing launcher '$1' under rocprofv3 --pmc (see the header); start with python3 <script> or a binary" >&2; exit 2 ;;
+  *) if ! head -c 4 "$(command -v "$1")" 2>/dev/null | grep -q ELF; then
+       echo "pmc_kernel.sh: '$1' is not an ELF binary (a script would re-exec through its interpreter)" >&2; exit 2; fi ;;
+esac
 O=$R/gpurun_out/pmc_$TAG
 rm -rf "$O"; mkdir -p "$O"; cd /tmp; export TMPDIR=/tmp
 i=0

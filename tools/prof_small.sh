@@ -5,7 +5,7 @@ O=$R/gpurun_out/prof_small
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 for b in "$@"; do
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/_p$b" -- python3 "$R/bench.py" --batch $b --steps 128 --warmup 8 --no-cpu-baseline --no-paths --no-kernel-events < /dev/null > "$O/b$b.log" 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/_p$b" -- python3 "$R/bench.py" --batch $b --steps 128 --warmup 8 --no-cpu-baseline --no-paths --no-kernel-events --no-e2e < /dev/null > "$O/b$b.log" 2>&1
   f=$(find "$O/_p$b" -type f -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$O/b${b}_kernel_stats.csv"
   rm -rf "$O/_p$b"

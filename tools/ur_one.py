@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """developer: a few eager launches of svk_deltakv_up_reconstruct at one shape (for counter collection)."""
 import os
 import sys
