@@ -62,11 +62,14 @@ class SparseDecodeDriver:
         # lanes of the step's static buffers (>= len(seqs)); the extra lanes are the padded lanes of a hipGraph
         # captured for a larger batch (decode_cuda_graph.py:266-303)
         self.graph_batch_size: int | None = None
+        # decode batches are all-long or all-short (the scheduler partitions them, model_runner.py:1135-1150); synthetic
+        # drivers leave the flag off, `run()` sets it per step
+        self.is_long_text = False
 
     # ------------------------------------------------------------------ one decode step
     def _forward_layers(self, q, k, v, outputs):
         cm, sc = self.cache_manager, self.sparse_controller
-        ctx = set_context(False, cache_manager=cm, sparse_controller=sc)
+        ctx = set_context(False, cache_manager=cm, sparse_controller=sc, is_long_text=bool(self.is_long_text))
         sc.prepare_forward(self.seqs, False)
         for layer_idx in range(cm.num_layers):
             ctx.now_layer_idx = layer_idx
@@ -105,8 +108,9 @@ class SparseDecodeDriver:
 
     @torch.no_grad()
     def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None, *,
-             after_layers=None):
-        """`after_layers()` (measurement hook) runs between the layer loop and post_forward."""
+             after_layers=None, append: bool = True):
+        """`after_layers()` (measurement hook) runs between the layer loop and post_forward.  `append=False`: the rows'
+        sampled tokens are the scheduler's to append (`StepPlanner.postprocess`)."""
         cm, sc = self.cache_manager, self.sparse_controller
         seqs = self.seqs
         cm.drop_deferred_decode_store()          # (only a step that raised leaves rows behind)
@@ -131,7 +135,8 @@ class SparseDecodeDriver:
             body()
         else:
             key = (q.data_ptr(), k.data_ptr(), v.data_ptr(), None if outputs is None else outputs.data_ptr(),
-                   tuple(s.seq_id for s in seqs), int(cm.device_step_generation) if dev_active else None)
+                   tuple(s.seq_id for s in seqs), int(cm.device_step_generation) if dev_active else None,
+                   bool(self.is_long_text))
             if self._graph is None or self._graph_key != key:
                 if self._graph_steps_seen == 0 or self._graph_key != key:
                     # first step with these buffers runs eagerly (allocates every scratch buffer)
@@ -157,19 +162,21 @@ class SparseDecodeDriver:
             after_layers()
         sc.post_forward(seqs, False)
         cm.on_forward_end(seqs, False)
-        for s in seqs:
-            s.append_token(0)
+        if append:
+            for s in seqs:
+                s.append_token(0)
 
     # ------------------------------------------------------------------ one prefill chunk
     @torch.no_grad()
     def prefill_chunk(self, seqs, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, outputs: torch.Tensor | None = None,
-                      *, k_raw: torch.Tensor | None = None):
+                      *, k_raw: torch.Tensor | None = None, advance: bool = True):
         """The sparse side of one chunked-prefill step (ModelRunner.run prefill branch,
         model_runner.py:1447-1481): allocate the chunk, per layer store its K/V and run `Attention.forward`
         (causal attention of the chunk + the manager's prefill hooks, which collect the method's token scores),
         then the post-forward eviction.  `outputs` [L, tokens, Hq, D] receives the attention outputs.
         q [L, tokens, Hq, D], k/v [L, tokens, Hkv, D]; every seq needs `current_chunk_size`.  `k_raw` [L, tokens, Hkv, D]:
-        the pre-RoPE keys a model hands to `save_raw_kv_if_needed` (models/qwen2.py:118-125; default: `k`)."""
+        the pre-RoPE keys a model hands to `save_raw_kv_if_needed` (models/qwen2.py:118-125; default: `k`).  `advance=False`:
+        the prompts' progress is the scheduler's to move (`StepPlanner.postprocess`, as in the reference)."""
         cm, sc = self.cache_manager, self.sparse_controller
         cm.drop_deferred_decode_store()
         out = cm._prepare_prefill(seqs)
@@ -198,9 +205,48 @@ class SparseDecodeDriver:
                     outputs[layer_idx].copy_(o)
         sc.post_forward(seqs, True)
         cm.on_forward_end(seqs, True)
-        for s in seqs:
-            s.num_prefilled_tokens += int(s.current_chunk_size)
+        if advance:
+            for s in seqs:
+                s.num_prefilled_tokens += int(s.current_chunk_size)
         set_context(False, cache_manager=cm, sparse_controller=sc)
+
+    # ------------------------------------------------------------------ the engine loop over a step planner
+    def run(self, planner, prompts, step_inputs, *, on_step=None, max_steps: int = 100000) -> list[dict]:
+        """Waiting prompts -> planned prefill chunks -> decode, until every sequence has used its generation budget: the
+        reference's loop `schedule -> prepare_step -> forward -> post_forward -> postprocess -> free finished`
+        (llm_engine.py:1187-1300, model_runner.py:1447-1481, scheduler.py:398-870) over `StepPlanner`, this build's cache
+        manager as its memory oracle and this driver's two step forms.  No model: `step_inputs(is_prefill, seqs, n)` ->
+        (q [L, n, Hq, D], k, v [L, n, Hkv, D], outputs or None) stands in for the layers around the attention path
+        (n = chunk tokens of the step, or decode rows).  `on_step(record)` sees every executed step before the next one
+        is planned.  -> the plan: one record per step."""
+        cm = self.cache_manager
+        for seq in prompts:
+            planner.add(seq)
+        plan = []
+        while not planner.is_finished():
+            if len(plan) >= max_steps:
+                raise RuntimeError(f"run() did not finish within {max_steps} steps")
+            seqs, is_prefill, _ = planner.schedule()
+            if not seqs:
+                raise RuntimeError("the planner scheduled nothing although sequences are queued")
+            n = sum(int(s.current_chunk_size) for s in seqs) if is_prefill else len(seqs)
+            q, k, v, outputs = step_inputs(is_prefill, seqs, n)
+            if is_prefill:
+                self.prefill_chunk(seqs, q, k, v, outputs=outputs, advance=False)
+            else:
+                self.seqs = list(seqs)
+                self.is_long_text = planner._is_long_decode(seqs[0])
+                self.step(q, k, v, outputs=outputs, append=False)
+            record = dict(prefill=bool(is_prefill), seqs=list(seqs), q=q, k=k, v=v, outputs=outputs,
+                          chunks=[int(s.current_chunk_size) if is_prefill else 1 for s in seqs])
+            record["finished"] = finished = planner.postprocess(seqs, [0] * len(seqs), is_prefill)
+            if on_step is not None:
+                on_step(record)                        # (before the finished rows are released: their state is still there)
+            for seq in finished:
+                cm.free_seq(seq.seq_id)
+            plan.append(record)
+        self.seqs = []
+        return plan
 
     def row_len(self) -> np.ndarray:
         cm = self.cache_manager

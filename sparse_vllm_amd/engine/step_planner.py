@@ -84,6 +84,29 @@ class StepPlanner:
                 self.memory_oracle.complete_prefill_execution(seq)
                 self.decoding.append(seq)
 
+    def postprocess(self, seqs, token_ids, is_prefill: bool) -> list:
+        """`Scheduler.postprocess` (scheduler.py:794-870) for sequences of this build, without EOS / log-probs / replay:
+        prefill - progress and queues as `after_prefill`, a prompt that finished its last chunk takes its first sampled
+        token; decode - every row takes its token.  A row whose generation budget is used up leaves `decoding`.
+        -> the finished sequences (the engine frees their cache rows, llm_engine.py:1282-1300)."""
+        finished = []
+        if is_prefill:
+            self.after_prefill(seqs)
+            for seq, tok in zip(seqs, token_ids):
+                if seq.num_prefilled_tokens >= seq.num_prompt_tokens:
+                    seq.append_token(tok)
+                    if seq.is_finished:
+                        self.decoding.remove(seq)
+                        finished.append(seq)
+            return finished
+        for seq, tok in zip(seqs, token_ids):
+            seq.append_token(tok)
+            if seq.is_finished:
+                if seq in self.decoding:
+                    self.decoding.remove(seq)
+                finished.append(seq)
+        return finished
+
     @staticmethod
     def _take(queue: deque, idx: int):
         queue.rotate(-idx)

@@ -1564,6 +1564,159 @@ def gen_step_planner():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+# ----------------------------------------------------------------------------------
+# planned run: the reference's Scheduler over its own cache managers through the engine's step order (capacity only)
+# ----------------------------------------------------------------------------------
+def _planned_run_loop(sc, sch, m, seqs, *, prepare_prefill, prepare_decode, after_prefill, after_decode, snapshot):
+    base = seqs[0].seq_id
+    trace = []
+    for s in seqs:
+        sch.add(s)
+    while not sch.is_finished():
+        assert len(trace) < 2000
+        chosen, is_prefill, preempted = sch.schedule()
+        assert chosen and not preempted
+        rec = dict(prefill=bool(is_prefill), seqs=[[s.seq_id - base, int(s.current_chunk_size) if is_prefill else 1] for s in chosen])
+        if is_prefill:
+            prepare_prefill(chosen)
+            after_prefill(chosen)
+        else:
+            prepare_decode(chosen)
+            after_decode(chosen)
+        sch.postprocess(chosen, [0] * len(chosen), is_prefill)
+        rec.update(snapshot(base))                    # before the finished rows are released
+        rec["finished"] = [s.seq_id - base for s in chosen if s.is_finished]
+        for s in chosen:
+            if s.is_finished:
+                m.free_seq(s.seq_id)
+        rec["waiting"] = [s.seq_id - base for s in sch.waiting]
+        rec["decoding"] = [s.seq_id - base for s in sch.decoding]
+        rec["deferred"] = sorted(int(x) - base for x in sch._admission_defer_warned_seq_ids)
+        trace.append(rec)
+    return trace
+
+
+def gen_planned_run():
+    """tests/planned_run_scenarios.py through the reference: `Scheduler.schedule / postprocess` over the reference's
+    H2OCacheManager (`_prepare_prefill`, `evict_after_prefill`, `_prepare_decode`, `evict_after_decode`, `free_seq`;
+    arbitrary scores - counts do not depend on them) and QuestCacheManager (`_prepare_prefill`, `_prepare_decode`,
+    `free_seq`; page tables recorded) on CPU."""
+    import json
+    from collections import deque
+    sys.path.insert(0, os.path.dirname(HERE))
+    import planned_run_scenarios as prs
+    from sparsevllm.engine.cache_manager.base import LayerBatchStates
+    from sparsevllm.engine.cache_manager.h2o import H2OCacheManager
+    from sparsevllm.engine.cache_manager.quest import QuestCacheManager
+    from sparsevllm.engine.scheduler import Scheduler
+    from sparsevllm.engine.sequence import Sequence
+    from sparsevllm.sampling_params import SamplingParams
+    out = {}
+
+    def sched_cfg(sc):
+        return SimpleNamespace(prefill_schedule_policy="all_chunked", eos=-1, eos_token_ids=(), num_sink_tokens=sc["sink"],
+                               num_recent_tokens=sc["recent"], decode_keep_tokens=sc["keep"], snapkv_window_size=4,
+                               vllm_sparse_method=sc["method"], **sc["planner"])
+
+    def mkseqs(sc):
+        return [Sequence(list(range(n)), SamplingParams(max_tokens=g, ignore_eos=True)) for n, g in zip(sc["prompts"], sc["gens"])]
+
+    # ---- H2O
+    sc = prs.H2O
+    L = sc["layers"]
+    m = _make_manager([[0] * sc["rows"]] * L, cap=sc["max_model_len"], nslots=sc["slots"], budget=sc["budget"],
+                      interval=sc["interval"], prefill_budget=sc["prefill_budget"])
+    m.seq_id_to_row = [dict() for _ in range(L)]
+    m.free_rows = [deque(range(sc["rows"])) for _ in range(L)]
+    m.config.chunk_prefill_size = sc["planner"]["chunk_prefill_size"]
+    m.config.h2o_recent_ratio = sc["recent_ratio"]
+    m.layer_batch_states = [SimpleNamespace(slot_mapping=None, context_lens=None, req_indices=None, max_context_len=0) for _ in range(L)]
+    # what `free_seq` touches besides the slot bookkeeping (snapkv.py:1489-1514): none of it exists without PyramidKV staging
+    m._prefill_attn_score_accumulators = {}
+    m._pyramidkv_clear_long_prefill_offload_prefetch = lambda: None
+    m._pyramidkv_long_prefill_offload_kind = lambda: "none"
+    m.raw_kv_offload_buffer = SimpleNamespace(release_layer=lambda **k: None)
+    seqs = mkseqs(sc)
+
+    def fake_scores(chosen):
+        for l in m.kv_transformer_layer_indices():
+            for s in chosen:
+                n = int(m.row_seq_lens[l][m.seq_id_to_row[l][s.seq_id]])
+                g = torch.Generator().manual_seed(1000 * l + 7 * s.seq_id + n)
+                m._h2o_scores[m._score_key(l, s.seq_id)] = torch.rand(n, generator=g)
+
+    def snap_h2o(base):
+        lens = {}
+        for s in seqs:
+            if s.seq_id in m.seq_id_to_row[0]:
+                per_layer = [int(m.row_seq_lens[l][m.seq_id_to_row[l][s.seq_id]]) for l in range(L)]
+                assert len(set(per_layer)) == 1
+                lens[str(s.seq_id - base)] = per_layer[0]
+        return dict(free=[int(x) for x in m._num_free_slots], lens=lens, counters={k: int(v) for k, v in m._h2o_counters.items()})
+
+    trace = _planned_run_loop(
+        sc, Scheduler(sched_cfg(sc), m), m, seqs,
+        prepare_prefill=lambda ch: m._prepare_prefill(ch),
+        prepare_decode=lambda ch: H2OCacheManager._prepare_decode(m, ch),
+        after_prefill=lambda ch: (fake_scores(ch), m.evict_after_prefill(ch)),
+        after_decode=lambda ch: (fake_scores(ch), m.evict_after_decode(ch)), snapshot=snap_h2o)
+    out["h2o"] = dict(trace=trace)
+
+    # ---- Quest
+    sc = prs.QUEST
+    page, rows, n_pages = sc["page"], sc["rows"], sc["pages"]
+    q = object.__new__(QuestCacheManager)
+    q.device = torch.device("cpu")
+    q.page_size, q.max_model_len = page, sc["max_model_len"]
+    q.max_pages_per_row = sc["max_model_len"] // page
+    q.num_pages = n_pages
+    q.num_layers = q.num_kv_layers = sc["layers"]
+    q.buffer_req_to_token_slots = torch.zeros(rows, sc["max_model_len"], dtype=torch.int32)
+    q.buffer_req_to_page_slots = torch.full((rows, q.max_pages_per_row), -1, dtype=torch.int32)
+    q.buffer_req_to_page_slots_cpu = np.full((rows, q.max_pages_per_row), -1, dtype=np.int32)
+    perm = torch.randperm(n_pages, generator=torch.Generator().manual_seed(5)).to(torch.int32)
+    q.free_pages_stack = perm.clone()
+    q.free_pages_cpu_stack = perm.numpy().copy()
+    q._num_free_pages = n_pages
+    q.page_offsets_i32 = torch.arange(page, dtype=torch.int32)
+    q.page_offsets_i64 = q.page_offsets_i32.to(torch.int64)
+    q.enable_prefix_caching, q.prefix_cache, q.prefix_offload_controller = False, None, None
+    q.seq_id_to_row, q.free_rows = {}, deque(range(rows))
+    q.row_seq_lens = np.zeros((rows,), dtype=np.int32)
+    q.layer_batch_state = LayerBatchStates()
+    q.seq_id_to_cached_pages, q.seq_id_to_prefix_blocks, q.seq_id_to_materialized_blocks = {}, {}, {}
+    q.prefix_runtime_states, q.pending_prefix_blocks = {}, {}
+    q.config = SimpleNamespace(vllm_sparse_method="quest", quest_skip_layers=sc["skip_layers"], quest_token_budget=sc["token_budget"])
+    for name in ("_poll_prefix_offload", "_attach_prefix_cache_if_needed", "_record_prefix_materialization",
+                 "_release_prefix_blocks", "_schedule_write_through_prefix_blocks", "_evict_prefix_cache_until_free"):
+        setattr(q, name, lambda *a, **k: None)
+    qseqs = mkseqs(sc)
+
+    def snap_quest(base):
+        lens, tables = {}, {}
+        for s in qseqs:
+            r = q.seq_id_to_row.get(s.seq_id)
+            if r is not None:
+                n = int(q.row_seq_lens[r])
+                lens[str(s.seq_id - base)] = n
+                tables[str(s.seq_id - base)] = [int(x) for x in q.buffer_req_to_page_slots_cpu[r, : (n + page - 1) // page]]
+        return dict(free_pages=int(q._num_free_pages), free_slots=int(q.num_free_slots), lens=lens, page_tables=tables)
+
+    trace = _planned_run_loop(
+        sc, Scheduler(sched_cfg(sc), q), q, qseqs,
+        prepare_prefill=lambda ch: q._prepare_prefill(ch), prepare_decode=lambda ch: q._prepare_decode(ch),
+        after_prefill=lambda ch: None, after_decode=lambda ch: None, snapshot=snap_quest)
+    out["quest"] = dict(trace=trace, free_pages_stack=[int(x) for x in perm])
+
+    for name, t in out.items():
+        kinds = [r["prefill"] for r in t["trace"]]
+        print(name, "steps", len(kinds), "prefill", sum(kinds), "deferred steps", sum(1 for r in t["trace"] if r["deferred"]))
+    path = os.path.join(HERE, "planned_run.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=None, sort_keys=True, separators=(",", ":"))
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 GROUPS = {
     "decode_alloc": gen_decode_alloc,
     "decode": gen_decode,
@@ -1587,6 +1740,7 @@ GROUPS = {
     "attention_hooks": gen_attention_hooks,
     "operator_registry": gen_operator_registry,
     "step_planner": gen_step_planner,
+    "planned_run": gen_planned_run,
 }
 
 

@@ -101,3 +101,58 @@ def test_planner_over_a_real_cache_manager():
     assert plan[0] == (True, [(0, 32), (1, 20)])            # 64-token step: a 32-token chunk + the whole short prompt
     assert plan[1] == (True, [(0, 32)]) and plan[2] == (True, [(0, 6)])
     assert plan[3][0] is False and sorted(i for i, _ in plan[3][1]) == [0, 1]
+
+
+def test_planner_over_a_quest_manager_reproduces_the_reference_plan():
+    """tests/golden/planned_run.json `quest` (the reference's Scheduler over the reference's QuestCacheManager,
+    tests/planned_run_scenarios.py) against `StepPlanner` over this build's QuestCacheManager, host side only (paging is host
+    arithmetic; the GPU twin, tests/test_gpu_planned_run.py, also executes every step): per step the same sequences and
+    chunk sizes, queues, deferred prompts, finished rows, free pages and - bit for bit - the same page tables."""
+    import numpy as np
+    import planned_run_scenarios as prs
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.cache_manager.base import CacheManager
+    from sparse_vllm_amd.engine.sequence import Sequence
+    from sparse_vllm_amd.engine.step_planner import StepPlanner
+    with open(os.path.join(HERE, "golden", "planned_run.json")) as f:
+        want = json.load(f)["quest"]
+    sc = prs.QUEST
+    conf = Config.from_kwargs(sparse_method="quest", num_hidden_layers=sc["layers"], max_model_len=sc["max_model_len"],
+                              max_num_seqs_in_gpu=sc["rows"], num_kvcache_slots=sc["pages"] * sc["page"],
+                              sink_keep_tokens=sc["sink"], recent_keep_tokens=sc["recent"], decode_keep_tokens=sc["keep"],
+                              quest_skip_layers=sc["skip_layers"], num_attention_heads=4, num_key_value_heads=2, head_dim=4,
+                              engine_prefill_chunk_size=sc["planner"]["chunk_prefill_size"], device="cpu")
+    cm = CacheManager.create(conf)
+    cm.free_pages_cpu_stack = np.asarray(want["free_pages_stack"], dtype=np.int32)
+    cfg = SimpleNamespace(num_sink_tokens=sc["sink"], num_recent_tokens=sc["recent"], decode_keep_tokens=sc["keep"],
+                          vllm_sparse_method="quest", **sc["planner"])
+    p = StepPlanner(cfg, cm)
+    seqs = [Sequence(num_prompt_tokens=n, max_tokens=g) for n, g in zip(sc["prompts"], sc["gens"])]
+    base = seqs[0].seq_id
+    for s in seqs:
+        p.add(s)
+    step, page = 0, sc["page"]
+    while not p.is_finished():
+        chosen, is_prefill, _ = p.schedule()
+        w = want["trace"][step]
+        assert is_prefill == w["prefill"]
+        assert [[s.seq_id - base, int(s.current_chunk_size) if is_prefill else 1] for s in chosen] == w["seqs"], step
+        if is_prefill:
+            cm._prepare_prefill(chosen)
+        else:
+            for s in chosen:
+                cm._allocate(s.seq_id, 1)
+        finished = p.postprocess(chosen, [0] * len(chosen), is_prefill)
+        tables = {str(s.seq_id - base): [int(x) for x in cm.buffer_req_to_page_slots_cpu[
+            cm.seq_id_to_row[s.seq_id], : (int(cm.row_seq_lens[cm.seq_id_to_row[s.seq_id]]) + page - 1) // page]]
+                  for s in seqs if s.seq_id in cm.seq_id_to_row}
+        assert tables == w["page_tables"], step
+        assert int(cm._num_free_pages) == w["free_pages"] and int(cm.num_free_slots) == w["free_slots"]
+        assert sorted(s.seq_id - base for s in finished) == w["finished"]
+        for s in finished:
+            cm.free_seq(s.seq_id)
+        assert [s.seq_id - base for s in p.waiting] == w["waiting"] and [s.seq_id - base for s in p.decoding] == w["decoding"]
+        assert sorted(x - base for x in p._defer_noted) == w["deferred"], step
+        step += 1
+    assert step == len(want["trace"]) and any(r["deferred"] for r in want["trace"])
+    assert cm._num_free_pages == cm.num_pages
