@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 18
+#define SVK_ABI_VERSION 19
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -898,6 +898,32 @@ typedef struct SvkClusterTopkArgs {
   int32_t rows, m, m0, k, row_offset, score_dtype;
 } SvkClusterTopkArgs;
 int svk_cluster_topk(const SvkClusterTopkArgs* a, svk_stream_t stream);
+
+/* MI355X: the ranking product, the causal mask and the top-k of `_cluster_compress` in one MFMA launch that never
+ * materialises the [rows, m] score matrix - what `_deltakv_l2_topk_block_kernel` + `deltakv_l2_topk_blockwise`
+ * (kernels/triton/deltakv_kernels.py:3945-4134) and the candidate merge (deltakv_base.py:3352-3358) do for the
+ * reference, with the runtime's bf16 rounding points (`_metric_l2`, deltakv_base.py:2168-2190):
+ *   score[r, c] = bf16(2 * bf16(sum_d token[r, d] * centre[c, d]) - bf16(sum_d bf16(centre[c, d]^2)))
+ * centre c = concat(K[center_slots[c]], V[center_slots[c]]) read from the layer caches (slot rows contiguous: Hkv*D
+ * values), masked to -inf when c >= m0 and new_center_rel[c - m0] > row_offset + r; topk[r, :k] = columns by (score
+ * descending, column ascending) - the order of svk_cluster_topk, which this launch replaces together with the library
+ * GEMM in front of it.  Hkv*D a multiple of 32, at most 512 (SVK_ERR_LAYOUT beyond: the caller keeps the GEMM).
+ * `workspace`: svk_cluster_l2_topk_workspace_bytes(rows, m, k) bytes, 16-byte aligned (centre norms + per-split
+ * candidates); not retained after the launch has run. */
+typedef struct SvkClusterL2TopkArgs {
+  const uint16_t* tokens;         /* [rows, 2*Hkv*D] bf16 (token_stride)     */
+  const uint16_t* k_cache;        /* [slots, Hkv*D] bf16 (kv_slot_stride)    */
+  const uint16_t* v_cache;
+  const int32_t* center_slots;    /* [m]                                     */
+  const int32_t* new_center_rel;  /* [m - m0]                                */
+  int32_t* topk;                  /* [rows, k] (topk_stride)                 */
+  void* workspace;
+  int64_t workspace_bytes;
+  int64_t token_stride, kv_slot_stride, topk_stride;
+  int32_t rows, m, m0, k, row_offset, half_dim;   /* half_dim = Hkv*D */
+} SvkClusterL2TopkArgs;
+int64_t svk_cluster_l2_topk_workspace_bytes(int32_t rows, int32_t m, int32_t k);
+int svk_cluster_l2_topk(const SvkClusterL2TopkArgs* a, svk_stream_t stream);
 
 /* base[r] = mean over the k father rows of concat(K[slot], V[slot]) (fp32 accumulate, bf16 out): the
  * `all_centers.gather(...).mean(dim=2)` of _cluster_compress (:2788-2789) / batch_gather_mean

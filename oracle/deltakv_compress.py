@@ -87,7 +87,9 @@ def kivi_quantize_blocks(k: np.ndarray, v: np.ndarray, value_group: int, rnd):
 def l2_scores(kv: np.ndarray, centers: np.ndarray, rnd) -> np.ndarray:
     """deltakv_base.py:2168-2190: 2*dot(a, b) - ||b||^2 with the [N, M] matrix kept in the storage dtype."""
     dot = rnd(kv.astype(np.float32) @ centers.astype(np.float32).T)
-    b_norm = rnd((centers.astype(np.float32) ** 2).sum(axis=1, dtype=np.float32))
+    # `(b * b).sum(dim=1, dtype=torch.float32)`: the product is a tensor of the storage dtype (each square rounded),
+    # the sum runs in fp32, `.to(dot.dtype)` rounds it once more
+    b_norm = rnd(rnd(centers.astype(np.float32) ** 2).sum(axis=1, dtype=np.float32))
     return rnd(dot * np.float32(2.0) - b_norm[None, :])
 
 

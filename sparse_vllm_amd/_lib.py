@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 18
+SVK_ABI_VERSION = 19
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -282,6 +282,12 @@ class SvkClusterTopkArgs(C.Structure):
                [(n, _i32) for n in ("rows", "m", "m0", "k", "row_offset", "score_dtype")]
 
 
+class SvkClusterL2TopkArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("tokens", "k_cache", "v_cache", "center_slots", "new_center_rel", "topk", "workspace")] + \
+               [(n, _i64) for n in ("workspace_bytes", "token_stride", "kv_slot_stride", "topk_stride")] + \
+               [(n, _i32) for n in ("rows", "m", "m0", "k", "row_offset", "half_dim")]
+
+
 class SvkGatherMeanArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("k_cache", "v_cache", "center_slots", "topk", "base", "father_slots")] + \
                [(n, _i64) for n in ("kv_slot_stride", "kv_head_stride", "topk_stride", "base_stride", "father_stride")] + \
@@ -343,6 +349,8 @@ ENTRY_POINTS = {
     "svk_quantize_pack_grouped": ([C.POINTER(SvkQuantPackArgs), _p], C.c_int),
     "svk_kivi_store_blocks": ([C.POINTER(SvkKiviStoreArgs), _p], C.c_int),
     "svk_cluster_topk": ([C.POINTER(SvkClusterTopkArgs), _p], C.c_int),
+    "svk_cluster_l2_topk": ([C.POINTER(SvkClusterL2TopkArgs), _p], C.c_int),
+    "svk_cluster_l2_topk_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),
     "svk_gather_mean_fathers": ([C.POINTER(SvkGatherMeanArgs), _p], C.c_int),
     "svk_kivi_decode_stage1": ([C.POINTER(SvkKiviDecodeStage1Args), _p], C.c_int),
     "svk_quest_page_minmax": ([C.POINTER(SvkQuestPageMinmaxArgs), _p], C.c_int),

@@ -1315,6 +1315,11 @@ class DeltaKVCacheManager(CacheManager):
         b_norm = (all_centers * all_centers).sum(dim=1, dtype=torch.float32).to(dot.dtype)
         return dot.mul(2.0).sub_(b_norm.unsqueeze(0))
 
+    @staticmethod
+    def _fused_cluster_enabled() -> bool:
+        import os
+        return os.environ.get("SVK_DELTAKV_FUSED_CLUSTER", "1") != "0"
+
     def _gather_raw_kv_rows(self, l_idx: int, slots: torch.Tensor) -> torch.Tensor:
         """[n] slots -> [n, 2*Hkv*D] concat(K_raw, V) rows of sparse layer l_idx (deltakv_less_memory.py:2708-2717)."""
         half = self.num_kv_heads * self.head_dim
@@ -1332,9 +1337,16 @@ class DeltaKVCacheManager(CacheManager):
         if m == 0:
             raise RuntimeError("DeltaKV less-memory: no available reference centers.")
         k_eff = min(k_neighbors, m)
-        centers = self._gather_raw_kv_rows(l_idx, all_center_slots)
-        scores = self._metric_l2(kv_block, centers)
-        topk = dk.cluster_topk(scores, m0=m0, new_center_rel=new_center_rel, k=k_eff)
+        if self._fused_cluster_enabled() and kv_block.is_cuda and dk.cluster_l2_topk_supported(
+                num_kv_heads=self.num_kv_heads, head_dim=self.head_dim, dtype=kv_block.dtype):
+            # MI355X: ranking product + mask + top-k in one MFMA launch over the layer caches; neither the gathered centre
+            # matrix nor the [n, m] scores exist (`SVK_DELTAKV_FUSED_CLUSTER=0`: the library GEMM + svk_cluster_topk below)
+            topk = dk.cluster_l2_topk(kv_block, self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx],
+                                      all_center_slots, m0=m0, new_center_rel=new_center_rel, k=k_eff)
+        else:
+            centers = self._gather_raw_kv_rows(l_idx, all_center_slots)
+            scores = self._metric_l2(kv_block, centers)
+            topk = dk.cluster_topk(scores, m0=m0, new_center_rel=new_center_rel, k=k_eff)
         base, fathers = dk.gather_mean_fathers(self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx],
                                                all_center_slots, topk, k_out=k_neighbors)
         return fathers, base

@@ -708,6 +708,47 @@ def cluster_topk(scores, *, m0: int, new_center_rel, k: int, row_offset: int = 0
     return out
 
 
+def cluster_l2_topk_supported(*, num_kv_heads: int, head_dim: int, dtype) -> bool:
+    """Shapes `svk_cluster_l2_topk` serves (wider rows keep the library product + `cluster_topk`)."""
+    half = int(num_kv_heads) * int(head_dim)
+    return dtype == torch.bfloat16 and half % 32 == 0 and 0 < half <= 512
+
+
+_CLUSTER_WS: dict = {}
+
+
+@torch.no_grad()
+def cluster_l2_topk(tokens, k_cache, v_cache, center_slots, *, m0: int, new_center_rel, k: int, row_offset: int = 0):
+    """MI355X: `_metric_l2` (deltakv_base.py:2168-2190) + causal mask + top-k (deltakv_less_memory.py:2766-2787) of
+    `_cluster_compress` in one MFMA launch over the layer caches - the [rows, m] score matrix is never written (the
+    reference's fused form: `deltakv_l2_topk_blockwise`, kernels/triton/deltakv_kernels.py:3945-4134).  tokens [rows,
+    2*Hkv*D] bf16; k_cache / v_cache [slots, Hkv, D] bf16; center_slots [m] int32 (every centre column's slot, the
+    block's own centres last); returns int32 [rows, k] column indices, best first, lower column on ties."""
+    assert tokens.dim() == 2 and tokens.dtype == torch.bfloat16 and tokens.stride(1) == 1
+    assert k_cache.dtype == torch.bfloat16 and k_cache.dim() == 3 and k_cache.stride() == v_cache.stride()
+    H, D = int(k_cache.shape[1]), int(k_cache.shape[2])
+    assert k_cache.stride(2) == 1 and k_cache.stride(1) == D and int(tokens.shape[1]) == 2 * H * D
+    assert center_slots.dtype == torch.int32 and center_slots.is_contiguous()
+    rows, m = int(tokens.shape[0]), int(center_slots.numel())
+    if new_center_rel is not None:
+        assert new_center_rel.dtype == torch.int32 and new_center_rel.is_contiguous() and new_center_rel.numel() == m - int(m0)
+    else:
+        assert int(m0) == m
+    out = torch.empty((rows, int(k)), dtype=torch.int32, device=tokens.device)
+    lib = _lib.load()
+    need = int(lib.svk_cluster_l2_topk_workspace_bytes(rows, m, int(k)))
+    ws = _CLUSTER_WS.get(tokens.device.index)          # grow-only scratch; eviction runs outside graph capture
+    if ws is None or ws.numel() < need:
+        ws = _CLUSTER_WS[tokens.device.index] = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, device=tokens.device)
+    a = _lib.SvkClusterL2TopkArgs(
+        tokens=_lib.ptr(tokens), k_cache=_lib.ptr(k_cache), v_cache=_lib.ptr(v_cache), center_slots=_lib.ptr(center_slots),
+        new_center_rel=_lib.ptr(new_center_rel), topk=_lib.ptr(out), workspace=_lib.ptr(ws), workspace_bytes=int(ws.numel()),
+        token_stride=tokens.stride(0), kv_slot_stride=k_cache.stride(0), topk_stride=out.stride(0), rows=rows, m=m,
+        m0=int(m0), k=int(k), row_offset=int(row_offset), half_dim=H * D)
+    _lib.check(lib.svk_cluster_l2_topk(C.byref(a), _lib.current_stream_handle()), lib)
+    return out
+
+
 @torch.no_grad()
 def gather_mean_fathers(k_cache, v_cache, center_slots, topk, *, k_out: int | None = None):
     """base = mean over fathers of concat(K[slot], V[slot]) (deltakv_less_memory.py:2788-2789, batch_gather_mean
