@@ -218,6 +218,49 @@ def _paths_in_child(names, steps: int, timeout_s: int = 240) -> list[dict]:
     return [got.get(n) or {"config": n, "error": note or "not reported by the pathbench child"} for n in names]
 
 
+def _traffic_in_child(batch: int, timeout_s: int = 150) -> dict:
+    """HBM bytes of one stage-1 launch from the PMC counters, measured in this run: `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` as two separate passes (counters only, the program itself after `--`) over tools/kbench.py at the
+    headline batch and row length 4224, with the micro-architecture guide's gfx950 correction (FETCH_SIZE counts 128-byte
+    requests as 64: read bytes = 2 x FETCH_SIZE x 1024).  -> per-launch figures, or {"error": ...} (then the committed
+    profiles/stage1_traffic.json stays the source)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return {"error": "rocprofv3 not on PATH"}
+    L = 4224
+    per_launch = {}
+    tmp = tempfile.mkdtemp(prefix="svk_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, ctr)
+            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", out_dir, "--", sys.executable,
+                   os.path.join(ROOT, "tools", "kbench.py"), "--batches", str(batch), "--block-seqs", str(L), "--modes", "2", "--iters", "3"]
+            try:
+                subprocess.run(cmd, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            except (subprocess.TimeoutExpired, OSError) as e:
+                return {"error": f"{ctr} pass: {type(e).__name__}"}
+            vals = []
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    vals += [float(r["Counter_Value"]) for r in csv.DictReader(fh)
+                             if r["Counter_Name"] == ctr and "decode_stage1_kernel" in r["Kernel_Name"]]
+            if not vals:
+                return {"error": f"{ctr} pass: no stage-1 rows in the counter output"}
+            per_launch[ctr] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd, wr = 2.0 * per_launch["FETCH_SIZE"][0] * 1024.0, per_launch["WRITE_SIZE"][0] * 1024.0
+    return {"hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "row_len": L,
+            "batch": batch, "launches": per_launch["FETCH_SIZE"][1], "algorithmic_bytes_per_launch": batch * L * (2 * 4 * 128 * 2 + 4 + 4),
+            "measured_in": "children of this bench.py run"}
+
+
 def _e2e_in_child(args, world: int, rank: int, local_rank: int, timeout_s: int = 200) -> list[dict]:
     """The end-to-end leg (tools/e2e_decoder.py) in a CHILD process per rank, after this process has released its GPU
     memory: a random-weight Qwen2.5-7B-shaped decoder (torch dense layers) around this build's attention path.  One GPU:
@@ -413,7 +456,8 @@ def main():
         for _ in range(args.event_steps):
             record["on"] = True
             drv.step(q, k, v, after_layers=after_layers)
-    from sparse_vllm_amd.replicas import aggregate_throughput
+    from sparse_vllm_amd.replicas import aggregate_throughput, gather_per_rank
+    per_rank_s = gather_per_rank(elapsed, device=device)          # every replica's own clock (N = 1: one entry)
     tokens, elapsed = aggregate_throughput(B * args.steps, elapsed, device=device)
     out = {
         "metric": "decode tokens/s at 128k ctx, H2O budget=4k, Qwen2.5-7B (sparse attention hot path)",
@@ -429,6 +473,10 @@ def main():
             "max_model_len": int(args.max_model_len), "logical_context": 131072,
             "bursts_in_timed_window": int(bursts_in_window),
         },
+        # replicas: what every rank measured on its own clock (value uses the slowest one)
+        "ranks_seen": len(per_rank_s),
+        "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank_s],
+        "per_gpu_tokens_per_s": {"min": B * args.steps / max(per_rank_s), "max": B * args.steps / min(per_rank_s)},
     }
     if burst is not None:
         # what the timed window would read with exactly one burst per `interval` steps, whatever K the driver chose
@@ -484,11 +532,23 @@ def main():
         # parser keeps it (same workload and build as the headline, tools/pathbench.py `h2o_b64`)
         b64 = next((p for p in out["paths"] if p.get("config") == "h2o_b64" and "error" not in p), None)
         if b64 is not None:
-            out["config"]["secondary"] = {
-                "workload": "same as the headline at seqs_per_gpu=64 (SURVEY 8(d) batch)", "seqs_per_gpu": 64,
-                "ms_per_step": b64.get("ms_per_step"), "tokens_per_s": b64.get("tokens_per_s"),
-                "step_frac_of_hbm_peak": b64.get("roofline_frac"), "stage1_kernel_us": b64.get("kernel_us"),
-                "stage1_kernel_frac_of_hbm_peak": b64.get("kernel_frac")}
+            # flat scalar keys: the driver's parser keeps scalars of `config` and drops nested objects
+            out["config"].update({
+                "b64_ms_per_step": b64.get("ms_per_step"), "b64_tokens_per_s": b64.get("tokens_per_s"),
+                "b64_step_frac_of_hbm_peak": b64.get("roofline_frac"), "b64_stage1_kernel_us": b64.get("kernel_us"),
+                "b64_stage1_frac_of_hbm_peak": b64.get("kernel_frac")})
+        if "roofline" in out:
+            # HBM traffic of the stage-1 launch measured NOW, in children of this process (two counter passes)
+            meas = _traffic_in_child(B)
+            if meas.get("hbm_bytes_per_launch"):
+                rf = out["roofline"]
+                rf["traffic"] = float(meas["hbm_bytes_per_launch"]) * rf["mean_row_len"] / float(meas["row_len"])
+                rf["traffic_measured"] = meas
+                rf["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/kbench.py at "
+                                        "this batch, run as children of this bench process; read bytes = 2 x FETCH_SIZE x 1024 "
+                                        "(the guide's gfx950 correction), scaled by mean_row_len / row_len")
+            else:
+                out["roofline"]["traffic_in_process"] = meas
     if not stub and not args.no_e2e:
         # end-to-end decode tokens/s as BASELINE.json words the metric, beside the unchanged headline: dense
         # layers are plain torch GEMMs (outside this build's scope), the attention is this build's path

@@ -29,3 +29,14 @@ def aggregate_throughput(local_tokens: int, local_seconds: float, *, device="cpu
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
     return int(n.item()), float(t.item())
+
+
+def gather_per_rank(local_value: float, *, device="cpu", group=None) -> list[float]:
+    """-> every rank's value, rank order, on every rank (one all-gather of a float64).  Single process: [value].  The
+    length of the list is the number of ranks that really took part - bench.py reports it as `ranks_seen`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [float(local_value)]
+    mine = torch.tensor([float(local_value)], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, mine, group=group)
+    return [float(p.item()) for p in parts]

@@ -78,6 +78,11 @@ def test_bench_spawn_path_two_ranks_on_cpu():
     assert out["ms_per_step"] >= 2.0
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 * steps - 2 * batch * steps) < 1e-6 * 2 * batch * steps
     assert "roofline" not in out and "cpu_baseline" not in out  # N > 1: neither leg runs
+    # what every replica measured on its own clock: both ranks reported, rank 1 (2 ms sleeps) is the slower one
+    assert out["ranks_seen"] == 2 and len(out["per_rank_ms_per_step"]) == 2
+    assert out["per_rank_ms_per_step"][1] >= 2.0 > 0.0 and out["per_rank_ms_per_step"][0] >= 1.0
+    assert abs(max(out["per_rank_ms_per_step"]) - out["ms_per_step"]) < 0.5
+    assert out["per_gpu_tokens_per_s"]["min"] <= out["per_gpu_tokens_per_s"]["max"]
 
 
 def test_bench_refuses_mismatched_world_size():

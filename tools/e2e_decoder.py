@@ -188,6 +188,47 @@ def _build_sparse_driver(B: int, model: QwenShapedDecoder, device: str, rank: in
     return drv
 
 
+def rccl_sanity(world: int, rank: int, device: str, group, tp: int, batches) -> dict:
+    """One record about the collective the model's tensor parallelism uses (layers/linear.py:588): how many ranks the job
+    really has (all-reduce SUM of ones over the world) and what one all-reduce of a decode step's activations - [B, 3584]
+    bf16 = 7 KB x B - costs inside the TP group, eager and as nodes of a replayed hipGraph (56 per step in the model)."""
+    ones = torch.ones(1, device=device)
+    dist.all_reduce(ones)
+    rec = {"rccl_sanity": True, "ranks_seen": int(ones.item()), "world_size": world, "tp": tp, "backend": dist.get_backend(),
+           "allreduce": []}
+    for B in batches:
+        x = torch.randn(B, QWEN25_7B["hidden"], device=device).to(torch.bfloat16)
+        n = 56
+        for _ in range(5):
+            dist.all_reduce(x, group=group)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            dist.all_reduce(x, group=group)
+        torch.cuda.synchronize()
+        eager_us = (time.perf_counter() - t0) / n * 1e6
+        graph_us = None
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n):
+                    dist.all_reduce(x, group=group)
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                g.replay()
+            torch.cuda.synchronize()
+            graph_us = (time.perf_counter() - t0) / (4 * n) * 1e6
+        except Exception as e:                   # capture support is a property of the RCCL build: report, do not fail the leg
+            graph_us = f"{type(e).__name__}: {e}"[:160]
+        rec["allreduce"].append({"batch": B, "bytes": int(x.numel() * 2), "eager_us": eager_us, "graph_replay_us": graph_us})
+    worst = torch.tensor([max(a["eager_us"] for a in rec["allreduce"])], dtype=torch.float64, device=device)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    rec["slowest_rank_eager_us"] = float(worst.item())
+    return rec
+
+
 def bound_ms(batch: int, tp: int, weight_bytes: int | None = None) -> float:
     w = 14.1e9 / tp if weight_bytes is None else float(weight_bytes)
     return (w + batch * 0.243e9 / tp) / HBM_PEAK * 1e3
@@ -253,6 +294,13 @@ def main():
             torch.cuda.synchronize()
 
     n_groups = world // tp
+    if use_dist:
+        try:
+            rec = rccl_sanity(world, rank, device, group, tp, [int(x) for x in args.batches.split(",") if x])
+        except Exception as e:
+            rec = {"rccl_sanity": True, "error": f"{type(e).__name__}: {e}"[:300]}
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
     for B in [int(x) for x in args.batches.split(",") if x]:
         for mode in [m for m in args.modes.split(",") if m]:
             try:
