@@ -1015,7 +1015,10 @@ int svk_deltakv_token_scores_chunks(int32_t length);
  * sparse_controller.py:1797-1811).  Entries at index >= valid_len[r] compare as `masked_value`.
  * Replaces the DeltaKV branch of _update_dynamic_omnikv_indices, sparse_controller.py:1790-1822. k <= 4096.
  * Long rows are split over several workgroups through `workspace` (svk_topk_sorted_workspace_bytes(); may be NULL
- * when that returns 0, and a NULL workspace always selects the single-workgroup path). */
+ * when that returns 0, and a NULL workspace always selects the single-workgroup path).  ABI 19: the first
+ * rows x 16 KiB of a non-NULL workspace (the level-1 histograms of the two-level plan) must be ZERO when the launch
+ * starts and are zero again when it has run - zero-fill a workspace once and reuse it call after call (one launch
+ * at a time per workspace); the rest of the workspace needs no initialisation. */
 typedef struct SvkTopkSortedArgs {
   const float* scores;        /* [rows, score_stride]            */
   const int32_t* valid_len;   /* NULL or [rows]                  */

@@ -5,6 +5,7 @@
 #include "svk_common.hpp"
 #include "svk_select.hpp"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace svk {
@@ -559,6 +560,8 @@ struct TopkHistWs {
   uint32_t* counts;
   uint32_t* bits;
   unsigned long long* cand;
+  const unsigned long long* flat = nullptr;    // two-level plan: the candidates once more as one contiguous list,
+  const uint32_t* flat_count = nullptr;        // and how many were appended (may exceed the list's capacity)
 };
 __host__ __device__ __forceinline__ int64_t topk_hist_bytes(int rows, int nwg) {
   return (int64_t)rows * ((int64_t)sizeof(uint32_t) * (kTopkHistBins + ((nwg + 3) & ~3) + ((2 * nwg + 3) & ~3)) +
@@ -573,6 +576,48 @@ __device__ __forceinline__ TopkHistWs topk_hist_ws(void* workspace, int rows, in
   w.bits = base + (int64_t)rows * (kTopkHistBins + cpad) + (int64_t)r * bpad;
   w.cand = reinterpret_cast<unsigned long long*>(base + (int64_t)rows * (kTopkHistBins + cpad + bpad)) + (int64_t)r * nwg * kTopkHistChunk;
   return w;
+}
+
+// workspace of the two-level plan (see topk2_* below)
+struct Topk2Ws {
+  uint32_t* hist1;
+  uint32_t* hist2;
+  uint32_t* counts;      // [nwg] final candidates per region (what topk_rank_kernel reads)
+  uint32_t* kept;        // [nwg] keys of the threshold bin kept aside
+  uint32_t* meta;        // [4]: T1, keys in bins below T1, entries appended to `flat`
+  unsigned long long* flat;   // [kTopk2Flat] the same candidates as the regions' fronts, unordered, contiguous (rank launch)
+  unsigned long long* cand;
+};
+constexpr int kTopk2Flat = 4096;          // = kTopkRankCap: what the rank launch can take
+__host__ __device__ __forceinline__ int64_t topk2_bytes(int rows, int nwg) {
+  const int cpad = (nwg + 3) & ~3;
+  return (int64_t)rows * ((int64_t)sizeof(uint32_t) * (2 * kTopkHistBins + 2 * cpad + 4) +
+                          (int64_t)sizeof(unsigned long long) * ((int64_t)nwg * kTopkHistChunk + kTopk2Flat));
+}
+__device__ __forceinline__ Topk2Ws topk2_ws(void* workspace, int rows, int r, int nwg) {
+  uint32_t* base = static_cast<uint32_t*>(workspace);
+  const int cpad = (nwg + 3) & ~3;
+  Topk2Ws w;
+  w.hist1 = base + (int64_t)r * kTopkHistBins;                                  // (all rows' level-1 histograms first: the zero contract)
+  w.hist2 = base + (int64_t)rows * kTopkHistBins + (int64_t)r * kTopkHistBins;
+  w.counts = base + (int64_t)rows * 2 * kTopkHistBins + (int64_t)r * cpad;
+  w.kept = base + (int64_t)rows * (2 * kTopkHistBins + cpad) + (int64_t)r * cpad;
+  w.meta = base + (int64_t)rows * (2 * kTopkHistBins + 2 * cpad) + (int64_t)r * 4;
+  unsigned long long* wide = reinterpret_cast<unsigned long long*>(base + (int64_t)rows * (2 * kTopkHistBins + 2 * cpad + 4));
+  w.flat = wide + (int64_t)r * kTopk2Flat;
+  w.cand = wide + (int64_t)rows * kTopk2Flat + (int64_t)r * nwg * kTopkHistChunk;
+  return w;
+}
+// the same regions / counts seen through the one-level layout's accessor names, for topk_rank_kernel and the fallback
+__device__ __forceinline__ TopkHistWs topk2_as_hist_ws(const Topk2Ws& w) {
+  TopkHistWs h;
+  h.hist = w.hist1; h.counts = w.counts; h.bits = w.meta; h.cand = w.cand;
+  h.flat = w.flat; h.flat_count = w.meta + 2;
+  return h;
+}
+
+__device__ __forceinline__ TopkHistWs topk_any_ws(void* workspace, int rows, int r, int nwg, int two_level) {
+  return two_level ? topk2_as_hist_ws(topk2_ws(workspace, rows, r, nwg)) : topk_hist_ws(workspace, rows, r, nwg);
 }
 
 // the bin window of a row: bin(key) for keys whose bits above the window equal `hi`
@@ -734,14 +779,14 @@ __global__ void __launch_bounds__(1024) topk_collect_kernel(const SvkTopkSortedA
 }
 
 // one workgroup per row; `lds_cap` = candidates whose keys fit the dynamic LDS next to the sort buffer and the prefix table
-__global__ void __launch_bounds__(1024) topk_final_kernel(const SvkTopkSortedArgs a, int kpad, void* workspace, int nwg, int lds_cap) {
-  __shared__ SelectScratch scratch;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+// (any block size of 64..1024 threads; `dyn` = the kernel's dynamic LDS, `rows` = rows of the launch)
+__device__ __forceinline__ void topk_final_select_sort(const SvkTopkSortedArgs& a, int r, int rows, int kpad, void* workspace, int nwg,
+                                                       int lds_cap, SelectScratch& scratch, unsigned char* dyn, int two_level) {
   unsigned long long* sorted = reinterpret_cast<unsigned long long*>(dyn);                    // [kpad]
   int* prefix = reinterpret_cast<int*>(dyn + sizeof(unsigned long long) * kpad);               // [nwg + 1] exclusive
   uint32_t* keys = reinterpret_cast<uint32_t*>(prefix + ((nwg + 2) & ~1));                     // [lds_cap]
-  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const TopkHistWs ws = topk_hist_ws(workspace, (int)gridDim.x, r, nwg);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const TopkHistWs ws = topk_any_ws(workspace, rows, r, nwg, two_level);
   // exclusive prefix of the region counts: one coalesced load into LDS (a thread summing straight from memory chains
   // a round trip per region: 20 us at 64 regions), then every thread adds up what is in front of its regions
   int* cnt = reinterpret_cast<int*>(keys);           // the key stage is not in use yet
@@ -797,6 +842,300 @@ __global__ void __launch_bounds__(1024) topk_final_kernel(const SvkTopkSortedArg
   __syncthreads();
   bitonic_sort_keys(sorted, kpad);
   for (int i = tid; i < a.k; i += nt) a.indices[(int64_t)r * a.index_stride + i] = (int32_t)(sorted[i] & 0xffffffffull);
+}
+
+__global__ void __launch_bounds__(1024) topk_final_kernel(const SvkTopkSortedArgs a, int kpad, void* workspace, int nwg, int lds_cap) {
+  __shared__ SelectScratch scratch;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  topk_final_select_sort(a, (int)blockIdx.x, (int)gridDim.x, kpad, workspace, nwg, lds_cap, scratch, dyn, 0);
+}
+
+// The final stage as a RANK launch (round 6; `SVK_TOPK_FINAL=select` keeps the single-workgroup select + bitonic sort
+// above: 25 us at 262 k scores, k = 2048).  The candidates of a row - every key of the bins <= T, k <= m < k + |bin T| -
+// are few: each of them can simply COUNT the candidates in front of it in the (score desc, index asc) order.  That count is
+// its output position; the candidates with a count below k are the result, already in order - exact selection and sort in
+// one barrier-free sweep.  The sweep is m^2 compare-and-count operations: spread thin - a workgroup of 256 threads stages
+// all m candidates in LDS (all of a thread's loads in flight at once) and ranks SIXTEEN of them, sixteen lanes per candidate
+// each over every sixteenth entry of the list - it is ~130 LDS reads per lane on ~130 CUs (the first form, 128 candidates
+// per workgroup and two lanes per candidate, kept 68 SIMDs busy for 10 us).  Rows with more than kTopkRankCap candidates (a huge tie group at the
+// threshold) take the select + sort above inside the row's first workgroup.
+constexpr int kTopkRankCap = 4096, kTopkRankPerWg = 16;
+
+__global__ void __launch_bounds__(256) topk_rank_kernel(const SvkTopkSortedArgs a, int kpad, void* workspace, int nwg, int lds_cap,
+                                                        int two_level) {
+  __shared__ SelectScratch scratch;
+  __shared__ int s_prefix[260];
+  __shared__ int wtot[4];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  const int r = blockIdx.y, tid = threadIdx.x;
+  const TopkHistWs ws = topk_any_ws(workspace, (int)gridDim.y, r, nwg, two_level);
+  int m = -1;
+  const bool flat = ws.flat != nullptr;
+  if (flat) {
+    m = (int)*ws.flat_count;                    // (one scalar load: no prefix over the regions on this path)
+  } else if (nwg <= 256) {
+    // exclusive prefix of the region counts (one thread per region, wave scans)
+    const int cnt = tid < nwg ? (int)ws.counts[tid] : 0;
+    const int incl = wave_incl_scan_add(cnt);
+    if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int j = 0; j < (tid >> 6); ++j) base += wtot[j];
+    if (tid < nwg) s_prefix[tid] = base + incl - cnt;
+    if (tid == 255) s_prefix[256] = base + incl;
+    __syncthreads();
+    m = s_prefix[256];
+    __syncthreads();
+    if (tid == 0) s_prefix[nwg] = m;
+    __syncthreads();
+  }
+  if (m < 0 || m > kTopkRankCap) {
+    if (blockIdx.x == 0) topk_final_select_sort(a, r, (int)gridDim.y, kpad, workspace, nwg, lds_cap, scratch, dyn, two_level);
+    return;
+  }
+  if ((int)blockIdx.x * kTopkRankPerWg >= m) return;
+  // all m candidates -> LDS as (key, index) pairs of 32-bit words (every load of the sweep in flight at once)
+  uint2* cand = reinterpret_cast<uint2*>(dyn);                  // [m] (<= 32 KB)
+  {
+    unsigned long long c16[kTopkRankCap / 256];
+#pragma unroll
+    for (int u = 0; u < kTopkRankCap / 256; ++u) {
+      const int i = u * 256 + tid;
+      c16[u] = 0ull;
+      if (i < m) {
+        if (flat) {
+          c16[u] = ws.flat[i];
+        } else {
+          int lo = 0, hi = nwg;                 // largest c with prefix[c] <= i
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_prefix[mid] <= i) lo = mid; else hi = mid;
+          }
+          c16[u] = ws.cand[(int64_t)lo * kTopkHistChunk + (i - s_prefix[lo])];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kTopkRankCap / 256; ++u) {
+      const int i = u * 256 + tid;
+      if (i < m) cand[i] = make_uint2((uint32_t)(c16[u] >> 32), (uint32_t)c16[u]);
+    }
+  }
+  __syncthreads();
+  // sixteen lanes per candidate, each over every sixteenth candidate of the list
+  const int mine_i = (int)blockIdx.x * kTopkRankPerWg + (tid >> 4), part = tid & 15;
+  const uint2 mine = cand[mine_i < m ? mine_i : 0];
+  int rank = 0;
+#pragma unroll 4
+  for (int j = part; j < m; j += 16) {
+    const uint2 c = cand[j];
+    rank += (int)(c.x < mine.x) + (int)((c.x == mine.x) & (c.y < mine.y));
+  }
+  rank += __shfl_xor(rank, 8, 64);
+  rank += __shfl_xor(rank, 4, 64);
+  rank += __shfl_xor(rank, 2, 64);
+  rank += __shfl_xor(rank, 1, 64);
+  if (part == 0 && mine_i < m && rank < a.k) a.indices[(int64_t)r * a.index_stride + rank] = (int32_t)mine.y;
+}
+
+// ------------------------------------------------------------------------------------
+// long rows, TWO-LEVEL plan (round 6, default; `SVK_TOPK_PLAN=hist` keeps the one-level plan above).  The one-level
+// threshold bin still holds 5-12 k keys of a 262 k row (fp32 scores spread over ~60 of the 4096 bins), which the final
+// workgroup then had to radix-select and sort: 22-25 us.  Two fixed 12-bit levels - key bits [31:20], then [19:8] inside the
+// threshold bin - leave k + a handful of candidates, few enough for every candidate to rank itself (topk_rank_kernel):
+//   topk2_hist1_kernel    4096 keys per workgroup -> level-1 histogram (LDS, then global atomics); zeroes level 2
+//   topk2_split_kernel    threshold bin T1 from level 1; keys below T1 are winners (front of the chunk's region, ascending
+//                         index), keys IN T1 are kept aside (back of the region) and counted into the level-2 histogram
+//   topk2_refine_kernel   threshold sub-bin T2 from level 2; the kept keys with sub-bin <= T2 join the region's front
+//                         (still ascending index among themselves); zeroes level 1 for the next launch
+//   topk_rank_kernel      every candidate counts the candidates in front of it = its output position
+// Candidates that tie on all 24 bits beyond kTopkRankCap (rows of equal scores) fall back to the ordered select + sort in
+// the rank launch's first workgroup; equal keys lie in ascending index order in the concatenated regions, which is what
+// that select needs.  The level-1 histogram must be ZERO when the launch starts and is zero again when it ends.
+// ------------------------------------------------------------------------------------
+// thread t owns bins 4t .. 4t+3 of a 4096-bin histogram (1024 threads): the bin that holds the `want`-th key (1-based)
+// and the number of keys in the bins before it.  All threads call; `wsum` = 16 ints, `res` = 2 ints of LDS.
+__device__ __forceinline__ void topk2_find_bin(const uint32_t* hist, int want, int* wsum, int* res) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint4 h = *reinterpret_cast<const uint4*>(hist + tid * 4);
+  const int cb[4] = {(int)h.x, (int)h.y, (int)h.z, (int)h.w};
+  const int local = cb[0] + cb[1] + cb[2] + cb[3];
+  const int incl_w = wave_incl_scan_add(local);
+  if (lane == 63) wsum[w] = incl_w;
+  __syncthreads();
+  int base = 0;
+  for (int j = 0; j < w; ++j) base += wsum[j];
+  const int incl = base + incl_w, excl = incl - local;
+  if (want > excl && want <= incl) {
+    int run = excl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (want > run && want <= run + cb[j]) { res[0] = tid * 4 + j; res[1] = run; }
+      run += cb[j];
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) topk2_hist1_kernel(const SvkTopkSortedArgs a, void* workspace, int nwg) {
+  __shared__ int hist[kTopkHistBins];
+  const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  const Topk2Ws ws = topk2_ws(workspace, (int)gridDim.y, r, nwg);
+  const int per = (kTopkHistBins + nwg - 1) / nwg;               // this workgroup's slice of the level-2 histogram to zero
+  for (int j = tid; j < per; j += 1024)
+    if (c * per + j < kTopkHistBins) ws.hist2[c * per + j] = 0u;
+  if (c == 0 && tid == 0) ws.meta[2] = 0u;
+  int vlen;
+  const int ne = topk_effective_n(a, r, vlen);
+  const int i0 = c * kTopkHistChunk;
+  if (i0 >= ne) return;
+  uint32_t key[4];
+  topk_load4(a, r, i0, vlen, key);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) hist[u * 1024 + tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) hist_add_aggregated(hist, key[u] >> 20, i0 + u * 1024 + tid < ne);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int n = hist[u * 1024 + tid];
+    if (n != 0) atomicAdd(&ws.hist1[u * 1024 + tid], (uint32_t)n);
+  }
+}
+
+__global__ void __launch_bounds__(1024) topk2_split_kernel(const SvkTopkSortedArgs a, void* workspace, int nwg) {
+  __shared__ int hist[kTopkHistBins];
+  __shared__ int wsum[16], res[2];
+  __shared__ int cnt[4][16];
+  const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int vlen;
+  const int ne = topk_effective_n(a, r, vlen);
+  const Topk2Ws ws = topk2_ws(workspace, (int)gridDim.y, r, nwg);
+  const int i0 = c * kTopkHistChunk;
+  if (i0 >= ne) {
+    if (tid == 0) { ws.counts[c] = 0u; ws.kept[c] = 0u; }
+    return;
+  }
+  uint32_t key[4];
+  topk_load4(a, r, i0, vlen, key);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) hist[u * 1024 + tid] = 0;
+  topk2_find_bin(ws.hist1, a.k, wsum, res);                      // (its barriers also publish the zeroed bins)
+  const uint32_t T1 = (uint32_t)res[0];
+  if (c == 0 && tid == 0) { ws.meta[0] = T1; ws.meta[1] = (uint32_t)res[1]; }
+  // winners (bins below T1) to the front of the region, the threshold bin's keys to its back, both in ascending index
+  // order: four ballots per wave, ONE barrier
+  bool win[4], keep[4];
+  unsigned long long bw[4], bk[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const bool in = i0 + u * 1024 + tid < ne;
+    const uint32_t b1 = key[u] >> 20;
+    win[u] = in && b1 < T1;
+    keep[u] = in && b1 == T1;
+    bw[u] = __ballot(win[u]);
+    bk[u] = __ballot(keep[u]);
+    if (lane == 0) cnt[u][w] = __popcll(bw[u]) | (__popcll(bk[u]) << 16);
+    hist_add_aggregated(hist, (key[u] >> 8) & (kTopkHistBins - 1), keep[u]);
+  }
+  __syncthreads();
+  __shared__ int s_flat_base;
+  if (tid == 0) {
+    int total = 0;
+    for (int u = 0; u < 4; ++u)
+      for (int j = 0; j < 16; ++j) total += cnt[u][j] & 0xffff;
+    s_flat_base = total ? (int)atomicAdd(&ws.meta[2], (uint32_t)total) : 0;
+  }
+  __syncthreads();
+  const int flat_base = s_flat_base;
+  unsigned long long* out = ws.cand + (int64_t)c * kTopkHistChunk;
+  int nwin = 0, nkeep = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    int bw_base = 0, bk_base = 0, tw = 0, tk = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int v = cnt[u][j];
+      if (j < w) { bw_base += v & 0xffff; bk_base += v >> 16; }
+      tw += v & 0xffff;
+      tk += v >> 16;
+    }
+    const unsigned long long item = ((unsigned long long)key[u] << 32) | (unsigned)(i0 + u * 1024 + tid);
+    if (win[u]) {
+      const int pos = nwin + bw_base + __popcll(bw[u] & below);
+      out[pos] = item;
+      if (flat_base + pos < kTopk2Flat) ws.flat[flat_base + pos] = item;
+    }
+    if (keep[u]) out[kTopkHistChunk - 1 - (nkeep + bk_base + __popcll(bk[u] & below))] = item;
+    nwin += tw;
+    nkeep += tk;
+  }
+  if (tid == 0) { ws.counts[c] = (uint32_t)nwin; ws.kept[c] = (uint32_t)nkeep; }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int n = hist[u * 1024 + tid];
+    if (n != 0) atomicAdd(&ws.hist2[u * 1024 + tid], (uint32_t)n);
+  }
+}
+
+__global__ void __launch_bounds__(1024) topk2_refine_kernel(const SvkTopkSortedArgs a, void* workspace, int nwg) {
+  __shared__ int wsum[16], res[2];
+  __shared__ int cnt[4][16];
+  const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const Topk2Ws ws = topk2_ws(workspace, (int)gridDim.y, r, nwg);
+  const int per = (kTopkHistBins + nwg - 1) / nwg;               // level 1 is not read any more: zero it for the next launch
+  for (int j = tid; j < per; j += 1024)
+    if (c * per + j < kTopkHistBins) ws.hist1[c * per + j] = 0u;
+  const int nkeep = (int)ws.kept[c];
+  if (nkeep == 0) return;                                        // (uniform: nothing of this chunk lies in the threshold bin)
+  const int need = a.k - (int)ws.meta[1];                        // keys still wanted from the threshold bin (>= 1)
+  topk2_find_bin(ws.hist2, need, wsum, res);
+  const uint32_t T2 = (uint32_t)res[0];
+  unsigned long long* out = ws.cand + (int64_t)c * kTopkHistChunk;
+  int nwin = (int)ws.counts[c];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int j0 = 0; j0 < nkeep; j0 += 4 * 1024) {
+    unsigned long long item[4], bal[4];
+    bool take[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 1024 + tid;
+      item[u] = j < nkeep ? out[kTopkHistChunk - 1 - j] : ~0ull;
+      take[u] = j < nkeep && (((uint32_t)(item[u] >> 32) >> 8) & (kTopkHistBins - 1)) <= T2;
+      bal[u] = __ballot(take[u]);
+      if (lane == 0) cnt[u][w] = __popcll(bal[u]);
+    }
+    __syncthreads();                                             // (also: every kept item of this trip is in registers)
+    __shared__ int s_flat_base;
+    if (tid == 0) {
+      int total = 0;
+      for (int u = 0; u < 4; ++u)
+        for (int j = 0; j < 16; ++j) total += cnt[u][j];
+      s_flat_base = total ? (int)atomicAdd(&ws.meta[2], (uint32_t)total) : 0;
+    }
+    __syncthreads();
+    int flat_pos = s_flat_base;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int base = 0, tot = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < w) base += cnt[u][j];
+        tot += cnt[u][j];
+      }
+      if (take[u]) {
+        const int pos = base + __popcll(bal[u] & below);
+        out[nwin + pos] = item[u];
+        if (flat_pos + pos < kTopk2Flat) ws.flat[flat_pos + pos] = item[u];
+      }
+      nwin += tot;
+      flat_pos += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) ws.counts[c] = (uint32_t)nwin;
 }
 
 // fallback for shapes whose candidates do not fit one LDS stage: single workgroup, keys re-read from memory
@@ -1013,7 +1352,8 @@ extern "C" int64_t svk_topk_sorted_workspace_bytes(int32_t rows, int32_t n, int3
   (void)k;
   if (n <= svk::kTopkStage) return 0;
   const int nwg = (n + svk::kTopkHistChunk - 1) / svk::kTopkHistChunk;
-  return svk::topk_hist_bytes(rows, nwg);
+  const int64_t one = svk::topk_hist_bytes(rows, nwg), two = svk::topk2_bytes(rows, nwg);
+  return one > two ? one : two;
 }
 
 extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, void* workspace, svk_stream_t stream) {
@@ -1035,16 +1375,39 @@ extern "C" int svk_topk_sorted_desc(const SvkTopkSortedArgs* a, void* workspace,
     static bool final_attr = false;
     if (!final_attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       final_attr = true;
     }
-    hipLaunchKernelGGL(topk_prep_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
-    hipLaunchKernelGGL(topk_hist_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
-    hipLaunchKernelGGL(topk_collect_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
     const int prefix_ints = (nwg + 2) & ~1;
     const int cap = kTopkStage;
-    hipLaunchKernelGGL(topk_final_kernel, dim3(a->rows), dim3(1024),
-                       sizeof(unsigned long long) * kpad + sizeof(int) * (size_t)prefix_ints + sizeof(uint32_t) * (size_t)cap, s, *a,
-                       kpad, workspace, nwg, cap);
+    const size_t final_lds = sizeof(unsigned long long) * kpad + sizeof(int) * (size_t)prefix_ints + sizeof(uint32_t) * (size_t)cap;
+    // the rank launch keeps its LDS small (four workgroups per CU: 256 short workgroups per row): its fallback - more than
+    // kTopkRankCap candidates, i.e. thousands of keys that tie on 24 bits - selects with the keys re-read from memory
+    // (lds_cap = 0) instead of staged
+    const size_t rank_sort = sizeof(unsigned long long) * kpad + sizeof(int) * (size_t)(prefix_ints + nwg + 2);   // (+ the count stage)
+    const size_t rank_lds = rank_sort > sizeof(unsigned long long) * (kTopkRankCap + 2) ? rank_sort : sizeof(unsigned long long) * (kTopkRankCap + 2);
+    const int plan = [] {                              // 2: two-level + rank (default); 1: one-level + rank; 0: one-level + select
+      const char* e = getenv("SVK_TOPK_PLAN");
+      const char* f = getenv("SVK_TOPK_FINAL");
+      if (f != nullptr && strcmp(f, "select") == 0) return 0;
+      return (e != nullptr && strcmp(e, "hist") == 0) ? 1 : 2;
+    }();
+    if (plan == 2) {
+      // (the level-1 histograms - the first rows x 16 KB of the workspace - are zero on entry and zero again on exit)
+      hipLaunchKernelGGL(topk2_hist1_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
+      hipLaunchKernelGGL(topk2_split_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
+      hipLaunchKernelGGL(topk2_refine_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
+      hipLaunchKernelGGL(topk_rank_kernel, dim3(kTopkRankCap / kTopkRankPerWg, a->rows), dim3(256), rank_lds, s, *a, kpad, workspace, nwg, 0, 1);
+    } else {
+      hipLaunchKernelGGL(topk_prep_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
+      hipLaunchKernelGGL(topk_hist_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
+      hipLaunchKernelGGL(topk_collect_kernel, dim3(nwg, a->rows), dim3(1024), 0, s, *a, workspace, nwg);
+      if (plan == 0) {
+        hipLaunchKernelGGL(topk_final_kernel, dim3(a->rows), dim3(1024), final_lds, s, *a, kpad, workspace, nwg, cap);
+      } else {
+        hipLaunchKernelGGL(topk_rank_kernel, dim3(kTopkRankCap / kTopkRankPerWg, a->rows), dim3(256), rank_lds, s, *a, kpad, workspace, nwg, 0, 0);
+      }
+    }
   } else if (a->n <= kTopkStage) {
     hipLaunchKernelGGL(topk_stage_kernel, dim3(1, a->rows), dim3(a->n > 2048 ? 1024 : 256),
                        sizeof(unsigned long long) * kpad + sizeof(uint32_t) * (size_t)a->n, s, *a, kpad, a->n, 1,

@@ -422,6 +422,9 @@ def decode_softmax_token_scores(scores, *, candidate_start: int, candidate_lens,
     return out
 
 
+_TOPK_WS: dict = {}
+
+
 def topk_sorted_desc(scores, k: int, *, valid_len=None, masked_value: float = -1e10):
     """`scores.topk(k, sorted=True).indices` (int32) with ties broken by the lower index."""
     assert scores.dim() == 2 and scores.dtype == torch.float32 and scores.stride(1) == 1
@@ -429,7 +432,20 @@ def topk_sorted_desc(scores, k: int, *, valid_len=None, masked_value: float = -1
     out = torch.empty((rows, int(k)), dtype=torch.int32, device=scores.device)
     lib = _lib.load()
     ws_bytes = int(lib.svk_topk_sorted_workspace_bytes(rows, n, int(k)))
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=scores.device) if ws_bytes > 0 else None
+    ws = None
+    if ws_bytes > 0:
+        # include/svk.h: the workspace's first rows x 16 KiB (level-1 histograms) are zero on entry and zero again on exit,
+        # so ONE zero-filled buffer per (device, launch shape) serves every call (launches on a device are ordered; a
+        # captured step keeps pointing at it: the buffer is never released)
+        import os
+        if os.environ.get("SVK_TOPK_PLAN") or os.environ.get("SVK_TOPK_FINAL"):
+            # the A/B plans (one histogram level) do not keep the contract: a buffer of their own per call
+            ws = torch.zeros((ws_bytes,), dtype=torch.uint8, device=scores.device)
+        else:
+            key = (scores.device.index, rows, n)
+            ws = _TOPK_WS.get(key)
+            if ws is None or ws.numel() < ws_bytes:
+                ws = _TOPK_WS[key] = torch.zeros((ws_bytes,), dtype=torch.uint8, device=scores.device)
     a = _lib.SvkTopkSortedArgs(scores=_lib.ptr(scores), valid_len=_lib.ptr(valid_len), indices=_lib.ptr(out),
                                score_stride=scores.stride(0), index_stride=out.stride(0), masked_value=float(masked_value),
                                rows=rows, n=n, k=int(k))

@@ -186,13 +186,19 @@ def test_token_scores_and_sorted_topk():
         np.testing.assert_array_equal(idx[b], exp)
 
 
+TOPK_PLANS = [dict(), dict(SVK_TOPK_PLAN="hist"), dict(SVK_TOPK_FINAL="select")]      # two-level + rank (default), one-level + rank, one-level + select
+
+
+@pytest.mark.parametrize("plan", TOPK_PLANS, ids=["two_level", "one_level_rank", "one_level_select"])
 @pytest.mark.parametrize("n,k,rows", [(262144, 2048, 2), (70000, 4096, 1), (40000, 300, 3), (24576, 4096, 2),
                                        (9000, 291, 4), (1_100_000, 2048, 1), (50, 50, 2)])
-def test_sorted_topk_long_rows(n, k, rows):
+def test_sorted_topk_long_rows(n, k, rows, plan, monkeypatch):
     """Rows longer than one LDS stage take the histogram plan (12-bit histogram -> candidates of the bins up to the
     threshold bin -> one select + sort); without a workspace the single-workgroup fallback.  bf16-valued probabilities => massive ties; result must equal the stable
     descending argsort (score desc, index asc) bit for bit, including masked tails shorter than k."""
     from sparse_vllm_amd.kernels.deltakv_kernels import topk_sorted_desc
+    for name, value in plan.items():
+        monkeypatch.setenv(name, value)
     rng = np.random.default_rng(n + k)
     x = bf16_round((rng.random((rows, n)) ** 8).astype(np.float32))
     x[0, : min(n, 5000)] = 0.25                                   # one huge tie group
@@ -203,13 +209,16 @@ def test_sorted_topk_long_rows(n, k, rows):
         np.testing.assert_array_equal(idx[r], np.argsort(-s, kind="stable")[:k])
 
 
+@pytest.mark.parametrize("plan", TOPK_PLANS, ids=["two_level", "one_level_rank", "one_level_select"])
 @pytest.mark.parametrize("seed", range(12))
-def test_sorted_topk_histogram_plan_fuzz(seed):
+def test_sorted_topk_histogram_plan_fuzz(seed, plan, monkeypatch):
     """Seeded random shapes of the histogram plan (rows longer than one LDS stage): value kinds that stress the bin window -
     a narrow band of bf16 probabilities (all keys share their leading bits), wide-range fp32 with both signs, signed
     zeros and infinities, a constant row (every key in one bin: the memory fallback), a few distinct values - with random
     valid lengths (shorter than k included) and masked values above and below the data.  Must equal the stable argsort."""
     from sparse_vllm_amd.kernels.deltakv_kernels import topk_sorted_desc
+    for name, value in plan.items():
+        monkeypatch.setenv(name, value)
     rng = np.random.default_rng(1000 + seed)
     rows = int(rng.integers(1, 4))
     n = int(rng.integers(24577, 300001))
