@@ -68,6 +68,27 @@ typedef struct SvkStoreKvcacheArgs {
 } SvkStoreKvcacheArgs;
 int svk_store_kvcache(const SvkStoreKvcacheArgs* a, svk_stream_t stream);
 
+/* Device-side guard for a decode step's slot table (MI355X addition): the attention launches trust the table exactly as
+ * the reference's Triton kernels do, and the reference's debugging aid for a corrupted table
+ * (layers/attention_backend.py:397-439, SVLLM_DEBUG_DECODE_BOUNDS) is a HOST check that synchronises and cannot run
+ * under stream capture.  This launch checks the same three things on the device - request rows inside the table, visible
+ * length inside its width, every visible slot (or page slot) inside the KV pool - never synchronises, may be captured
+ * into the step's graph, and records the FIRST violation of any launch since `status` was last cleared:
+ *   status[0] = 0 (clean) or SVK_SLOT_CHECK_*, status[1..5] = batch lane, table row, position, slot, context length.
+ * The caller reads `status` whenever it next synchronises anyway (the reference's `torch._assert_async` discipline). */
+enum { SVK_SLOT_CHECK_ROW = 1, SVK_SLOT_CHECK_WIDTH = 2, SVK_SLOT_CHECK_SLOT = 3 };
+typedef struct SvkCheckSlotTableArgs {
+  const int32_t* slot_table;    /* [num_rows, width] (table_stride): token slots, or page slots when slot_page_size > 1 */
+  const int32_t* req_indices;   /* [batch] */
+  const int32_t* context_lens;  /* [batch] */
+  int32_t* status;              /* [8] int32, caller-owned, zero = clean */
+  int64_t table_stride;
+  int32_t batch, num_rows, width;
+  int32_t slot_cap;             /* slots (or pages) of the KV pool */
+  int32_t slot_page_size;       /* 0 / 1: token slots */
+} SvkCheckSlotTableArgs;
+int svk_check_slot_table(const SvkCheckSlotTableArgs* a, svk_stream_t stream);
+
 /* copy_slots: cache[dst[i]] = cache[src[i]] for K and V through a caller-owned
  * workspace (gather all, then scatter all => safe when src and dst sets overlap).
  * Replaces the K/V move of H2OCacheManager._compact_final_prefill_dense_batch,

@@ -282,6 +282,11 @@ class SvkClusterTopkArgs(C.Structure):
                [(n, _i32) for n in ("rows", "m", "m0", "k", "row_offset", "score_dtype")]
 
 
+class SvkCheckSlotTableArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("slot_table", "req_indices", "context_lens", "status")] + [("table_stride", _i64)] + \
+               [(n, _i32) for n in ("batch", "num_rows", "width", "slot_cap", "slot_page_size")]
+
+
 class SvkClusterL2TopkArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("tokens", "k_cache", "v_cache", "center_slots", "new_center_rel", "topk", "workspace")] + \
                [(n, _i64) for n in ("workspace_bytes", "token_stride", "kv_slot_stride", "topk_stride")] + \
@@ -349,6 +354,7 @@ ENTRY_POINTS = {
     "svk_quantize_pack_grouped": ([C.POINTER(SvkQuantPackArgs), _p], C.c_int),
     "svk_kivi_store_blocks": ([C.POINTER(SvkKiviStoreArgs), _p], C.c_int),
     "svk_cluster_topk": ([C.POINTER(SvkClusterTopkArgs), _p], C.c_int),
+    "svk_check_slot_table": ([C.POINTER(SvkCheckSlotTableArgs), _p], C.c_int),
     "svk_cluster_l2_topk": ([C.POINTER(SvkClusterL2TopkArgs), _p], C.c_int),
     "svk_cluster_l2_topk_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),
     "svk_gather_mean_fathers": ([C.POINTER(SvkGatherMeanArgs), _p], C.c_int),

@@ -42,8 +42,43 @@ copy_slots_kernel(const SvkCopySlotsArgs a, int chunks_per_row, int phase) {
   }
 }
 
+// one workgroup per decode lane: the first violation found anywhere in the launch is recorded (atomicCAS on status[0])
+__global__ void __launch_bounds__(256) check_slot_table_kernel(const SvkCheckSlotTableArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int row = a.req_indices[b], len = a.context_lens[b];
+  auto report = [&](int kind, int pos, int slot) {
+    if (atomicCAS(&a.status[0], 0, kind) == 0) {
+      a.status[1] = b; a.status[2] = row; a.status[3] = pos; a.status[4] = slot; a.status[5] = len;
+    }
+  };
+  if (row < 0 || row >= a.num_rows) {
+    if (tid == 0) report(SVK_SLOT_CHECK_ROW, -1, -1);
+    return;
+  }
+  if (len > a.width * (a.slot_page_size > 1 ? a.slot_page_size : 1)) {
+    if (tid == 0) report(SVK_SLOT_CHECK_WIDTH, -1, -1);
+    return;
+  }
+  const int n = a.slot_page_size > 1 ? (len + a.slot_page_size - 1) / a.slot_page_size : len;
+  const int32_t* tab = a.slot_table + (int64_t)row * a.table_stride;
+  for (int p = tid; p < n; p += 256) {
+    const int s = tab[p];
+    if (s < 0 || s >= a.slot_cap) { report(SVK_SLOT_CHECK_SLOT, p, s); break; }
+  }
+}
+
 }  // namespace
 }  // namespace svk
+
+extern "C" int svk_check_slot_table(const SvkCheckSlotTableArgs* a, svk_stream_t stream) {
+  using namespace svk;
+  SVK_REQUIRE(a != nullptr && a->slot_table != nullptr && a->req_indices != nullptr && a->context_lens != nullptr && a->status != nullptr,
+              SVK_ERR_VALUE, "svk_check_slot_table: null args");
+  SVK_REQUIRE(a->slot_cap > 0 && a->num_rows > 0 && a->width > 0, SVK_ERR_VALUE, "svk_check_slot_table: empty table / pool");
+  if (a->batch <= 0) return SVK_OK;
+  hipLaunchKernelGGL(check_slot_table_kernel, dim3(a->batch), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("svk_check_slot_table");
+}
 
 extern "C" int svk_store_kvcache(const SvkStoreKvcacheArgs* a, svk_stream_t stream) {
   using namespace svk;

@@ -174,7 +174,19 @@ class HipAttentionBackend:
         inside the slot table, the longest context inside its width, every visible slot id inside the KV pool.  The HIP
         kernels trust the slot table exactly as the reference's Triton kernels do; this host check is the reference's
         debugging aid for a corrupted table, with its messages."""
-        if os.environ.get("SVLLM_DEBUG_DECODE_BOUNDS", "0") != "1":
+        mode = os.environ.get("SVLLM_DEBUG_DECODE_BOUNDS", "0")
+        if mode == "device":
+            # MI355X: the same three checks as a launch of the step (no synchronisation, capture-safe); the record is read
+            # by `raise_if_slot_check_failed` wherever the caller synchronises anyway (SparseDecodeDriver: after the step)
+            payload = _require_explicit_payload(view, operation="Decode bounds check")
+            meta = view.meta
+            if payload.backend in {"dense", "flash_attn_contiguous"} and meta.active_slots.dim() == 2 and meta.active_slots.is_cuda:
+                from ..kernels.store_kvcache import check_slot_table_async
+                page = int((payload.metadata or {}).get("slot_page_size", 0) or 0)
+                cap = int(payload.k_cache.shape[0]) if page <= 1 else int(payload.k_cache.shape[0]) // page
+                check_slot_table_async(meta.active_slots, meta.req_indices, meta.context_lens, slot_cap=cap, slot_page_size=page)
+            return
+        if mode != "1":
             return
         payload = _require_explicit_payload(view, operation="Decode bounds check")
         meta = view.meta

@@ -76,6 +76,74 @@ def test_debug_decode_bounds_catches_a_corrupted_slot_table(monkeypatch):
     monkeypatch.setenv("SVLLM_DEBUG_DECODE_BOUNDS", "0")                # unchecked, the kernels would have trusted it
 
 
+@pytest.mark.parametrize("method", ["h2o", "quest", "streamingllm", "deltakv"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_device_side_slot_guard_on_real_managers(method, graph, monkeypatch):
+    """`SVLLM_DEBUG_DECODE_BOUNDS=device` (svk_check_slot_table): the reference's bounds check as a launch of the step - no
+    synchronisation, captured into the step's hipGraph.  Clean steps of every method leave the record clean and the outputs
+    bit-identical to the unchecked run; a slot table corrupted behind the captured graph's back is reported with the
+    reference's message and coordinates by `raise_if_slot_check_failed` (the read is where the caller synchronises anyway)."""
+    from sparse_vllm_amd.kernels.store_kvcache import raise_if_slot_check_failed, slot_check_status
+    outs = {}
+    for mode in ("0", "device"):
+        monkeypatch.setenv("SVLLM_DEBUG_DECODE_BOUNDS", mode)
+        drv = _drivers()[method]
+        cm = drv.cache_manager
+        if graph:
+            drv.enable_decode_graph()
+        o = torch.zeros((cm.num_layers, len(drv.seqs), 28, 128), dtype=torch.bfloat16, device=drv.device)
+        q, k, v = drv.random_step_inputs(seed=20)
+        for step in range(4):
+            drv.step(q, k, v, outputs=o)
+        torch.cuda.synchronize()
+        outs[mode] = o.view(torch.int16).cpu().numpy().copy()
+        if mode == "device":
+            raise_if_slot_check_failed(drv.device)                                 # clean
+            assert int(slot_check_status(drv.device)[0]) == 0
+            if method == "h2o":
+                row = cm.seq_id_to_row[1][drv.seqs[1].seq_id]
+                wild = int(cm.kv_cache.shape[2]) + 3                               # just past the pool: recorded, and harmless to read
+                saved = int(cm.buffer_req_to_token_slots_tensor[1, row, 17])
+                cm.buffer_req_to_token_slots_tensor[1, row, 17] = wild
+                drv.step(q, k, v, outputs=o)                                       # (a replayed graph when `graph`)
+                cm.buffer_req_to_token_slots_tensor[1, row, 17] = saved
+                with pytest.raises(RuntimeError, match=rf"decode physical slot out of bounds before attention: batch=1 req_row={row} pos=17 slot={wild}"):
+                    raise_if_slot_check_failed(drv.device)
+                raise_if_slot_check_failed(drv.device)                             # the record was cleared
+        del drv
+    np.testing.assert_array_equal(outs["0"], outs["device"])
+
+
+def test_slot_guard_kinds_and_page_slots():
+    """svk_check_slot_table at kernel level: a request row outside the table, a visible length beyond the table's width, a
+    negative slot, page-slot tables (Quest's view: ids are PAGE slots, lengths in tokens); the first violation stays."""
+    from sparse_vllm_amd.kernels.store_kvcache import check_slot_table_async
+    d = torch.device("cuda:0")
+    tab = torch.arange(4 * 64, dtype=torch.int32, device=d).reshape(4, 64) % 100
+    i32 = lambda *x: torch.tensor(x, dtype=torch.int32, device=d)
+
+    def run(tab, req, lens, cap, page=0):
+        st = torch.zeros(8, dtype=torch.int32, device=d)
+        check_slot_table_async(tab, req, lens, slot_cap=cap, slot_page_size=page, status=st)
+        return st.cpu().tolist()[:6]
+
+    assert run(tab, i32(0, 3), i32(64, 10), 100)[0] == 0
+    assert run(tab, i32(0, 4), i32(64, 10), 100)[:3] == [1, 1, 4]                          # row 4 of a 4-row table
+    assert run(tab, i32(0, 3), i32(64, 65), 100)[:3] == [2, 1, 3] and run(tab, i32(0, 3), i32(64, 65), 100)[5] == 65
+    bad = tab.clone(); bad[2, 5] = -1
+    assert run(bad, i32(2), i32(6), 100) == [3, 0, 2, 5, -1, 6]
+    assert run(bad, i32(2), i32(5), 100)[0] == 0                                           # position 5 is not visible at length 5
+    bad = tab.clone(); bad[1, 9] = 100
+    assert run(bad, i32(1), i32(64), 100)[:5] == [3, 0, 1, 9, 100]
+    # page slots: 16-token pages, 10 pages visible at length 150; the table's width is in pages
+    pages = (torch.arange(4 * 16, dtype=torch.int32, device=d).reshape(4, 16)) % 30
+    assert run(pages, i32(0, 1), i32(150, 256), 30, page=16)[0] == 0
+    assert run(pages, i32(0, 1), i32(150, 257), 30, page=16)[:3] == [2, 1, 1]              # 17 pages > width 16
+    bad = pages.clone(); bad[0, 9] = 30
+    assert run(bad, i32(0), i32(150), 30, page=16)[:5] == [3, 0, 0, 9, 30]
+    assert run(bad, i32(0), i32(144), 30, page=16)[0] == 0                                 # 9 pages visible
+
+
 @pytest.mark.parametrize("method", ["h2o", "quest", "deltakv"])
 def test_store_riding_in_stage1_equals_store_then_launch(method, monkeypatch):
     res = {}

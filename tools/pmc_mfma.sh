@@ -16,7 +16,7 @@ def load(path, match):
         if match in r["Kernel_Name"]:
             rows[(r["Kernel_Name"].replace("void ", "").replace("svk::(anonymous namespace)::", "").split("(")[0], r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
     return rows
-out = ["# MFMA-busy of the two MFMA-bound kernels (PMC, round 3)", "",
+out = ["# MFMA-busy of the two MFMA-bound kernels (PMC, re-measured on the current kernels)", "",
        "`tools/pmc_mfma.sh`: `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` (counters only) over",
        "`tools/kbench_prefill.py --iters 2` and `tools/kbench_prefill_score.py --iters 2 --keys 16384`.  MFMA-busy =",
        "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) (the busy counter is summed over the SIMDs, GUI_ACTIVE over",
