@@ -63,6 +63,8 @@ done
 timeout 400 python3 "$R/tools/e2e_decoder.py" --batches 1,64,256 --steps 32 --modes graph,eager < /dev/null 2>/dev/null | grep '^{' > "$O/e2e_tp1.jsonl"
 timeout 300 python3 "$R/tools/dql_ab.py" < /dev/null 2>/dev/null > "$O/paths/kbench_dequant_linear.txt"
 timeout 300 python3 "$R/tools/kbench_up_recon.py" --rows 2048,4096,8192,16384 --hidden 2048 < /dev/null 2>/dev/null | grep layers > "$O/paths/kbench_up_recon.txt"
+timeout 300 python3 "$R/tools/kbench_cluster.py" < /dev/null 2>/dev/null | grep rows > "$O/paths/kbench_cluster.txt"
+timeout 300 python3 "$R/tools/kbench_topk.py" < /dev/null 2>/dev/null | grep rows > "$O/paths/kbench_topk.txt"
 # per-node timelines of the replayed steps (kernel trace only)
 bash "$R/tools/timeline.sh" h2o_b1 h2o_b8 quest streamingllm deltakv deltakv_b4 > /dev/null 2>&1
 for f in "$R"/gpurun_out/timeline/*.txt; do cp "$f" "$O/paths/timeline_$(basename "$f")"; done
