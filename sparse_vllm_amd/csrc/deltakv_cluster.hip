@@ -17,6 +17,8 @@
 // sum of the bf16-rounded squares (`(b * b).sum(dim=1, dtype=float32)`).  Order: score descending, lower centre column on
 // ties - `svk_cluster_topk`'s order, which this launch replaces together with the library GEMM in front of it.
 
+#include <stdlib.h>
+
 #include "svk_common.hpp"
 
 namespace svk {
@@ -161,25 +163,51 @@ __global__ void __launch_bounds__(64) cluster_l2_topk_kernel(const SvkClusterL2T
   }
 }
 
+// one wave per token row: lanes take the (token, split) candidates 64 apart into sorted local lists, then k rounds of a wave
+// arg-max pop the winners in order (a thread per token walking its splits x K candidates one dependent load at a time took
+// 100 us at 125 splits)
 template <int K>
 __global__ void __launch_bounds__(256) cluster_merge_kernel(const SvkClusterL2TopkArgs a, const uint64_t* __restrict__ partial, int splits) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   uint64_t best[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) best[j] = 0;
   const uint64_t* src = partial + (int64_t)row * splits * K;
-  for (int i = 0; i < splits * K; ++i) insert<K>(best, src[i]);
+  const int n = splits * K;
+  for (int i0 = 0; i0 < n; i0 += 4 * 64) {
+    uint64_t c[4];
 #pragma unroll
-  for (int j = 0; j < K; ++j)
-    if (j < a.k) a.topk[(int64_t)row * a.topk_stride + j] = key_col(best[j]);
+    for (int u = 0; u < 4; ++u) c[u] = i0 + u * 64 + lane < n ? src[i0 + u * 64 + lane] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) insert<K>(best, c[u]);
+  }
+  for (int j = 0; j < a.k; ++j) {
+    uint64_t top = best[0];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(top >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)top, off, 64);
+      top = o > top ? o : top;
+    }
+    if (lane == 0) a.topk[(int64_t)row * a.topk_stride + j] = key_col(top);
+    if (best[0] == top) {                      // (keys are unique: exactly one lane pops)
+#pragma unroll
+      for (int q = 0; q + 1 < K; ++q) best[q] = best[q + 1];
+      best[K - 1] = 0;
+    }
+  }
 }
 
-// centre-range splits: enough single-wave workgroups for two waves per SIMD, at least four tiles per split
+// centre-range splits: about one single-wave workgroup per SIMD, at least two tiles per split
 int choose_splits(int rows, int m) {
   const int groups = (rows + kTokTile - 1) / kTokTile, tiles = (m + 15) / 16;
-  int s = (2048 + groups - 1) / groups;
-  if (s > tiles / 4) s = tiles / 4;
+  // measured (tools/kbench_cluster.py, 128 rows x 8000 centres): >= 2 tiles per split and ~1024 waves: 44 us; 4 tiles / 2048
+  // waves 43; 1 tile / 4096 waves 72 (the 16 token rows are re-read by every split); 8 tiles 52
+  static const int min_tiles = [] { const char* e = getenv("SVK_CLUSTER_SPLIT_TILES"); return e ? atoi(e) : 2; }();   // developer knobs
+  static const int waves = [] { const char* e = getenv("SVK_CLUSTER_WAVES"); return e ? atoi(e) : 1024; }();
+  int s = (waves + groups - 1) / groups;
+  if (s > tiles / min_tiles) s = tiles / min_tiles;
   return s < 1 ? 1 : s;
 }
 
@@ -218,8 +246,8 @@ extern "C" int svk_cluster_l2_topk(const SvkClusterL2TopkArgs* in, svk_stream_t 
   if (kernel_k(a.k) == 4) hipLaunchKernelGGL(cluster_l2_topk_kernel<4>, grid, dim3(64), 0, s, a, norms, partial);
   else hipLaunchKernelGGL(cluster_l2_topk_kernel<8>, grid, dim3(64), 0, s, a, norms, partial);
   if (splits > 1) {
-    if (kernel_k(a.k) == 4) hipLaunchKernelGGL(cluster_merge_kernel<4>, dim3((a.rows + 255) / 256), dim3(256), 0, s, a, partial, splits);
-    else hipLaunchKernelGGL(cluster_merge_kernel<8>, dim3((a.rows + 255) / 256), dim3(256), 0, s, a, partial, splits);
+    if (kernel_k(a.k) == 4) hipLaunchKernelGGL(cluster_merge_kernel<4>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a, partial, splits);
+    else hipLaunchKernelGGL(cluster_merge_kernel<8>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a, partial, splits);
   }
   return check_launch("svk_cluster_l2_topk");
 }

@@ -1001,7 +1001,8 @@ class DeltaKVCacheManager(CacheManager):
             return False
         sides = self.__dict__.get("_recon_streams")
         if sides is None or len(sides) != self._recon_stream_count():
-            sides = self._recon_streams = [torch.cuda.Stream(device=self.device) for _ in range(self._recon_stream_count())]
+            sides = self._recon_streams = [torch.cuda.Stream(device=self.device, priority=self._recon_stream_priority())
+                                           for _ in range(self._recon_stream_count())]
             self._recon_events = self.__dict__.get("_recon_events") or {}
         main = torch.cuda.current_stream()
         for side in sides:
@@ -1049,6 +1050,11 @@ class DeltaKVCacheManager(CacheManager):
     def _recon_stream_count(cls) -> int:
         import os
         return max(1, int(os.environ.get("SVK_DELTAKV_RECON_STREAMS", cls._RECON_STREAMS)))
+    @staticmethod
+    def _recon_stream_priority() -> int:
+        """Priority of the look-ahead streams (developer knob `SVK_DELTAKV_RECON_PRIORITY`; default: torch's default)."""
+        import os
+        return int(os.environ.get("SVK_DELTAKV_RECON_PRIORITY", "0"))
     _RECON_INTO_VIEW_DEFAULT = True
     _LAYER_VIEWS_MAX_BYTES = 16 << 30
 
@@ -1338,7 +1344,7 @@ class DeltaKVCacheManager(CacheManager):
             raise RuntimeError("DeltaKV less-memory: no available reference centers.")
         k_eff = min(k_neighbors, m)
         if self._fused_cluster_enabled() and kv_block.is_cuda and dk.cluster_l2_topk_supported(
-                num_kv_heads=self.num_kv_heads, head_dim=self.head_dim, dtype=kv_block.dtype):
+                num_kv_heads=self.num_kv_heads, head_dim=self.head_dim, dtype=kv_block.dtype, rows=int(kv_block.shape[0])):
             # MI355X: ranking product + mask + top-k in one MFMA launch over the layer caches; neither the gathered centre
             # matrix nor the [n, m] scores exist (`SVK_DELTAKV_FUSED_CLUSTER=0`: the library GEMM + svk_cluster_topk below)
             topk = dk.cluster_l2_topk(kv_block, self.deltakv_full_kv_cache[0, l_idx], self.deltakv_full_kv_cache[1, l_idx],
