@@ -1001,8 +1001,7 @@ class DeltaKVCacheManager(CacheManager):
             return False
         sides = self.__dict__.get("_recon_streams")
         if sides is None or len(sides) != self._recon_stream_count():
-            sides = self._recon_streams = [torch.cuda.Stream(device=self.device, priority=self._recon_stream_priority())
-                                           for _ in range(self._recon_stream_count())]
+            sides = self._recon_streams = [torch.cuda.Stream(device=self.device) for _ in range(self._recon_stream_count())]
             self._recon_events = self.__dict__.get("_recon_events") or {}
         main = torch.cuda.current_stream()
         for side in sides:
@@ -1050,11 +1049,6 @@ class DeltaKVCacheManager(CacheManager):
     def _recon_stream_count(cls) -> int:
         import os
         return max(1, int(os.environ.get("SVK_DELTAKV_RECON_STREAMS", cls._RECON_STREAMS)))
-    @staticmethod
-    def _recon_stream_priority() -> int:
-        """Priority of the look-ahead streams (developer knob `SVK_DELTAKV_RECON_PRIORITY`; default: torch's default)."""
-        import os
-        return int(os.environ.get("SVK_DELTAKV_RECON_PRIORITY", "0"))
     _RECON_INTO_VIEW_DEFAULT = True
     _LAYER_VIEWS_MAX_BYTES = 16 << 30
 

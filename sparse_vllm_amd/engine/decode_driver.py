@@ -93,18 +93,6 @@ class SparseDecodeDriver:
         if join is not None:
             join()
 
-    def _capture_stream(self):
-        """Stream the step is captured on: torch's own by default; `SVK_GRAPH_CAPTURE_PRIORITY=p` (developer knob) captures on
-        a stream of that priority, which the kernel nodes of the step's main branch then carry (a manager's side-stream
-        branches keep theirs): -1 lets the walk's short launches overtake a look-ahead branch that fills the chip."""
-        prio = os.environ.get("SVK_GRAPH_CAPTURE_PRIORITY")
-        if not prio:
-            return None
-        st = self.__dict__.get("_capture_stream_obj")
-        if st is None:
-            st = self._capture_stream_obj = torch.cuda.Stream(device=self.device, priority=int(prio))
-        return st
-
     def enable_decode_graph(self):
         """hipGraph replay of the per-step layer loop (the reference's DecodeCudaGraphRunner,
         engine/decode_cuda_graph.py:403-566): lengths/slots are read from device buffers with
@@ -162,7 +150,7 @@ class SparseDecodeDriver:
                 else:
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    with capture_without_gc(), torch.cuda.graph(g, stream=self._capture_stream()):
+                    with capture_without_gc(), torch.cuda.graph(g):
                         body()
                     self._graph = g
                     g.replay()
