@@ -1708,6 +1708,63 @@ def gen_planned_run():
         after_prefill=lambda ch: None, after_decode=lambda ch: None, snapshot=snap_quest)
     out["quest"] = dict(trace=trace, free_pages_stack=[int(x) for x in perm])
 
+    # ---- StreamingLLM (sink + recent window): the controller's eviction functions over the SnapKV-family manager
+    from sparsevllm.engine.cache_manager.snapkv import SnapKVCacheManager
+    from sparsevllm.engine.cache_manager.streamingllm import StreamingLLMCacheManager
+    from sparsevllm.utils.context import set_context
+    sc = prs.STREAMINGLLM
+    L = sc["layers"]
+    sm = _make_snapkv_manager([[0] * sc["rows"]] * L, cap=sc["max_model_len"], nslots=sc["slots"], sink=sc["sink"],
+                              recent=sc["recent"], keep=sc["keep"], window=4, heads=2, dim=4)
+    sm.__class__ = StreamingLLMCacheManager
+    sm.config.vllm_sparse_method = "streamingllm"
+    sm.config.chunk_prefill_size = sc["planner"]["chunk_prefill_size"]
+    sm.seq_id_to_row = [dict() for _ in range(L)]
+    sm.free_rows = [deque(range(sc["rows"])) for _ in range(L)]
+    sm.layer_batch_states = [SimpleNamespace(slot_mapping=None, context_lens=None, req_indices=None, max_context_len=0) for _ in range(L)]
+    sm._pyramidkv_clear_long_prefill_offload_prefetch = lambda: None
+    sm._pyramidkv_long_prefill_offload_kind = lambda: "none"
+    sm.raw_kv_offload_buffer = SimpleNamespace(release_layer=lambda **k: None)
+    ctl = _make_controller(sink=sc["sink"], recent=sc["recent"], keep=sc["keep"], method="streamingllm", cache_manager=sm, num_layers=L)
+    sseqs = mkseqs(sc)
+    initial_stack = sm.free_slots_stack_tensor.numpy().copy()
+
+    def sync_states(is_prefill):                                  # what SparseController.prepare_forward does for these fields
+        for l in range(L):
+            st, bs = ctl.layer_batch_sparse_states[l], sm.layer_batch_states[l]
+            st.context_lens = bs.context_lens.clone() if is_prefill else bs.context_lens
+            st.max_context_len, st.req_indices = bs.max_context_len, bs.req_indices
+
+    def s_prefill(ch):
+        set_context(True, seqs=ch)
+        sm._prepare_prefill(ch)
+        sync_states(True)
+
+    def s_decode(ch):
+        set_context(False, seqs=ch)
+        SnapKVCacheManager._prepare_decode(sm, ch)
+        sync_states(False)
+
+    def snap_sllm(base):
+        lens, tables = {}, {}
+        for s_ in sseqs:
+            if s_.seq_id in sm.seq_id_to_row[0]:
+                rows_l = [sm.seq_id_to_row[l][s_.seq_id] for l in range(L)]
+                n = int(sm.row_seq_lens[0][rows_l[0]])
+                assert all(int(sm.row_seq_lens[l][rows_l[l]]) == n for l in range(L))
+                lens[str(s_.seq_id - base)] = n
+                tables[str(s_.seq_id - base)] = [[int(x) for x in sm.buffer_req_to_token_slots[l][rows_l[l], :n]] for l in range(L)]
+        import zlib
+        return dict(free=[int(x) for x in sm._num_free_slots], lens=lens, slot_tables=tables,
+                    free_stack_crc=[int(zlib.crc32(sm.free_slots_stack[l][: int(sm._num_free_slots[l])].numpy().astype(np.int32).tobytes()))
+                                    for l in range(L)])
+
+    trace = _planned_run_loop(
+        sc, Scheduler(sched_cfg(sc), sm), sm, sseqs, prepare_prefill=s_prefill, prepare_decode=s_decode,
+        after_prefill=lambda ch: ctl._streamingllm_prefill_eviction(ch), after_decode=lambda ch: ctl._streamingllm_decode_eviction(ch),
+        snapshot=snap_sllm)
+    out["streamingllm"] = dict(trace=trace, initial_free_stack=[[int(x) for x in initial_stack[l]] for l in range(L)])
+
     for name, t in out.items():
         kinds = [r["prefill"] for r in t["trace"]]
         print(name, "steps", len(kinds), "prefill", sum(kinds), "deferred steps", sum(1 for r in t["trace"] if r["deferred"]))

@@ -31,4 +31,14 @@ QUEST = dict(
     planner=dict(max_num_seqs_in_batch=3, max_num_batched_tokens=160, max_decoding_seqs=4, chunk_prefill_size=64),
 )
 
-SCENARIOS = {"h2o": H2O, "quest": QUEST}
+# StreamingLLM: nothing depends on scores - which slots survive is arithmetic (sink + recent), so the reference run's slot
+# tables and free stacks are recorded too and the GPU run must reproduce them bit for bit from the same initial stack
+STREAMINGLLM = dict(
+    method="streamingllm", layers=2, rows=6, slots=190, max_model_len=512,
+    sink=4, recent=24, keep=0,                       # budget 28 tokens, decode re-eviction at 56
+    prompts=[100, 20, 61, 45, 130, 28],
+    gens=[40, 50, 12, 60, 9, 33],
+    planner=dict(max_num_seqs_in_batch=3, max_num_batched_tokens=64, max_decoding_seqs=4, chunk_prefill_size=32),
+)
+
+SCENARIOS = {"h2o": H2O, "quest": QUEST, "streamingllm": STREAMINGLLM}

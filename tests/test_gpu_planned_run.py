@@ -1,6 +1,7 @@
 """SURVEY 8(f).4 with a consumer: waiting prompts -> `StepPlanner` -> planned prefill chunks -> decode, executed on the GPU
-by `SparseDecodeDriver.run` (engine/decode_driver.py) under a KV pool small enough that admission defers, for H2O and
-Quest.  Two independent checks of every step:
+by `SparseDecodeDriver.run` (engine/decode_driver.py) under a KV pool small enough that admission defers, for H2O, Quest
+and StreamingLLM (whose slot tables and free stacks, having no scores in them, must equal the REFERENCE run's bit for bit).
+Two independent checks of every step:
 
 * the PLAN (which sequences ran, chunk sizes, queue orders, deferred prompts, finished rows, every row's physical length,
   free capacity, H2O eviction counters, Quest page tables) equals tests/golden/planned_run.json - what the REFERENCE's
@@ -333,3 +334,83 @@ def test_quest_planned_run_matches_reference_plan_and_oracle(ref_plan):
     assert seen["sparse_views"] > 0 and seen["dense_views"] > 0             # long rows attended through a query-aware view
     assert drv.graph_stats["replayed"] >= 10, drv.graph_stats
     assert cm._num_free_pages == cm.num_pages and not cm.seq_id_to_row
+
+
+# ------------------------------------------------------------------------------------------------------------ StreamingLLM
+def test_streamingllm_planned_run_reproduces_the_reference_bit_for_bit(ref_plan):
+    """Sink + recent window eviction has no scores in it: from the reference run's initial free stack the GPU run must
+    reproduce the reference's plan AND its slot tables, free-stack contents (crc of the live part, order included) and row
+    lengths after every step - prefill chunks, final-chunk eviction, decode re-eviction at twice the budget, rows released -
+    while the attention outputs are checked against the oracle over those tables."""
+    import zlib
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    sc = prs.STREAMINGLLM
+    L = sc["layers"]
+    conf = Config.from_kwargs(sparse_method="streamingllm", num_hidden_layers=L, max_model_len=sc["max_model_len"],
+                              max_num_seqs_in_gpu=sc["rows"], num_kvcache_slots=sc["slots"], sink_keep_tokens=sc["sink"],
+                              recent_keep_tokens=sc["recent"], engine_prefill_chunk_size=sc["planner"]["chunk_prefill_size"])
+    drv = SparseDecodeDriver(conf)
+    cm = drv.cache_manager
+    ref = ref_plan["streamingllm"]
+    cm.free_slots_stack_tensor.copy_(torch.tensor(ref["initial_free_stack"], dtype=torch.int32))
+    cm._dev_state_dirty = True
+    drv.enable_decode_graph()
+    planner = _planner(sc, cm)
+    seqs = _prompts(sc)
+    base = seqs[0].seq_id
+    want = ref["trace"]
+    kc, vc = _f(cm.kv_cache[0]).copy(), _f(cm.kv_cache[1]).copy()
+    prev_tables: dict[int, list] = {}                 # seq index -> per-layer slot lists after its last step (the reference's)
+    seen = dict(steps=0, evicting_decode_steps=0)
+
+    def on_step(rec):
+        torch.cuda.synchronize()
+        step, w = seen["steps"], want[seen["steps"]]
+        qn, kn, vn, got_o = _f(rec["q"]), _f(rec["k"]), _f(rec["v"]), _f(rec["outputs"])
+        ids = [s.seq_id - base for s in rec["seqs"]]
+        chunk = np.array(rec["chunks"], np.int32)
+        starts = np.concatenate(([0], np.cumsum(chunk)[:-1])).astype(np.int32)
+        # ---- the rows as the attention saw them: the reference's table of the previous step + this step's new slots
+        for l in range(L):
+            new_slots = cm.layer_batch_states[l].slot_mapping.cpu().numpy()[: int(chunk.sum())]
+            width = max(len(prev_tables.get(i, [[]] * L)[l]) + int(c) for i, c in zip(ids, chunk))
+            table = np.zeros((len(ids), width), np.int32)
+            lens = np.zeros(len(ids), np.int32)
+            for b, (i, c) in enumerate(zip(ids, chunk)):
+                old = prev_tables.get(i, [[]] * L)[l]
+                row = list(old) + [int(x) for x in new_slots[starts[b]: starts[b] + c]]
+                table[b, : len(row)], lens[b] = row, len(row)
+                kc[l][row[len(old):]] = kn[l][starts[b]: starts[b] + c]
+                vc[l][row[len(old):]] = vn[l][starts[b]: starts[b] + c]
+            req = np.arange(len(ids), dtype=np.int32)
+            if rec["prefill"]:
+                ref_o = opa.context_attention_fwd(qn[l], kc[l], vc[l], req, starts, lens, lens - chunk, table)
+            else:
+                mid, lse = oda.flash_decode_stage1(qn[l], kc[l], vc[l], table, req, lens, int(lens.max()), 64)
+                ref_o = oda.flash_decode_stage2(mid, lse, lens, 64)
+            np.testing.assert_allclose(got_o[l], bf16_round(ref_o), rtol=TOL, atol=TOL, err_msg=f"layer {l} step {step}")
+        # ---- plan, lengths, slot tables and free stacks == the reference run
+        live = {s.seq_id - base: s for s in seqs if s.seq_id in cm.seq_id_to_row[0]}
+        lens_now = {i: int(cm.row_seq_lens[0][cm.seq_id_to_row[0][s.seq_id]]) for i, s in live.items()}
+        tab = cm.buffer_req_to_token_slots_tensor.cpu().numpy()
+        stack = cm.free_slots_stack_tensor.cpu().numpy()
+        tables = {str(i): [[int(x) for x in tab[l, cm.seq_id_to_row[l][s.seq_id], : lens_now[i]]] for l in range(L)] for i, s in live.items()}
+        crc = [int(zlib.crc32(stack[l, : int(cm._num_free_slots[l])].astype(np.int32).tobytes())) for l in range(L)]
+        _check_plan_record(step, rec, w, planner, base, lens_now,
+                           dict(free=[int(x) for x in cm._num_free_slots], slot_tables=tables, free_stack_crc=crc))
+        if not rec["prefill"] and any(w["lens"][str(i)] < (prev_tables.get(i) and len(prev_tables[i][0]) or 0) for i in ids):
+            seen["evicting_decode_steps"] += 1
+        for i in live:
+            prev_tables[i] = w["slot_tables"][str(i)]
+        for s in rec["finished"]:
+            prev_tables.pop(s.seq_id - base, None)
+        np.testing.assert_array_equal(_f(cm.kv_cache[0]), kc)
+        np.testing.assert_array_equal(_f(cm.kv_cache[1]), vc)
+        seen["steps"] += 1
+
+    plan = drv.run(planner, seqs, StepInputs(L, drv.device), on_step=on_step)
+    assert len(plan) == len(want) == seen["steps"]
+    assert any(r["deferred"] for r in want) and seen["evicting_decode_steps"] >= 3
+    assert drv.graph_stats["replayed"] >= 10, drv.graph_stats
+    assert all(n == cm.num_slots for n in cm._num_free_slots) and not cm.seq_id_to_row[0]
