@@ -156,3 +156,33 @@ def test_planner_over_a_quest_manager_reproduces_the_reference_plan():
         step += 1
     assert step == len(want["trace"]) and any(r["deferred"] for r in want["trace"])
     assert cm._num_free_pages == cm.num_pages
+
+
+def test_postprocess_moves_progress_tokens_and_finished_rows():
+    """`StepPlanner.postprocess` = the queue effects of `Scheduler.postprocess` (scheduler.py:794-870) for this build's
+    sequences: a prompt that finishes its last chunk takes its first token and joins `decoding`; an unfinished one returns to
+    the head of `waiting`; a row whose generation budget is used up leaves `decoding` and is returned for release - also when
+    the budget is one token (finished by the prefill step itself)."""
+    from sparse_vllm_amd.engine.sequence import Sequence
+    from sparse_vllm_amd.engine.step_planner import StepPlanner
+    oracle = ps.ScriptedOracle()
+    p = StepPlanner(ps._cfg(None, chunk=4, max_tokens=16), oracle)
+    a, b, c = Sequence(num_prompt_tokens=6, max_tokens=2), Sequence(num_prompt_tokens=3, max_tokens=1), Sequence(num_prompt_tokens=4, max_tokens=3)
+    for s in (a, b, c):
+        p.add(s)
+    chosen, is_prefill, _ = p.schedule()
+    assert is_prefill and [(s.seq_id, s.current_chunk_size) for s in chosen] == [(a.seq_id, 4), (b.seq_id, 3), (c.seq_id, 4)]
+    finished = p.postprocess(chosen, [7, 8, 9], True)
+    assert finished == [b] and b.num_completion_tokens == 1 and b.last_token == 8 and b.num_tokens == 4     # budget of one token
+    assert list(p.waiting) == [a] and a.num_prefilled_tokens == 4 and a.num_completion_tokens == 0
+    assert list(p.decoding) == [c] and c.num_completion_tokens == 1 and c.num_tokens == 5
+    assert oracle.completed == [b.seq_id, c.seq_id]
+    chosen, is_prefill, _ = p.schedule()                       # the rest of `a`
+    assert is_prefill and chosen == [a] and a.current_chunk_size == 2
+    assert p.postprocess(chosen, [1], True) == [] and list(p.decoding) == [c, a] and not p.waiting
+    chosen, is_prefill, _ = p.schedule()
+    assert not is_prefill and sorted(s.seq_id for s in chosen) == sorted((a.seq_id, c.seq_id))
+    finished = p.postprocess(chosen, [0] * len(chosen), False)
+    assert finished == [a] and list(p.decoding) == [c] and c.num_completion_tokens == 2      # a: 2 of 2, c: 2 of 3
+    chosen, _, _ = p.schedule()
+    assert p.postprocess(chosen, [0], False) == [c] and p.is_finished()
