@@ -180,9 +180,12 @@ def test_postprocess_moves_progress_tokens_and_finished_rows():
     chosen, is_prefill, _ = p.schedule()                       # the rest of `a`
     assert is_prefill and chosen == [a] and a.current_chunk_size == 2
     assert p.postprocess(chosen, [1], True) == [] and list(p.decoding) == [c, a] and not p.waiting
+    # decode: short rows first (a holds 7 tokens > sink + keep + recent = 6, c holds 5), so c decodes alone until it is done
     chosen, is_prefill, _ = p.schedule()
-    assert not is_prefill and sorted(s.seq_id for s in chosen) == sorted((a.seq_id, c.seq_id))
-    finished = p.postprocess(chosen, [0] * len(chosen), False)
-    assert finished == [a] and list(p.decoding) == [c] and c.num_completion_tokens == 2      # a: 2 of 2, c: 2 of 3
+    assert not is_prefill and chosen == [c]
+    assert p.postprocess(chosen, [0], False) == [] and c.num_completion_tokens == 2
     chosen, _, _ = p.schedule()
-    assert p.postprocess(chosen, [0], False) == [c] and p.is_finished()
+    assert chosen == [c] and p.postprocess(chosen, [0], False) == [c] and list(p.decoding) == [a]      # 3 of 3
+    chosen, is_prefill, _ = p.schedule()
+    assert not is_prefill and chosen == [a]
+    assert p.postprocess(chosen, [0], False) == [a] and p.is_finished()                                 # 2 of 2
