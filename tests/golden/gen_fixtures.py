@@ -1615,7 +1615,7 @@ def gen_planned_run():
 
     def sched_cfg(sc):
         return SimpleNamespace(prefill_schedule_policy="all_chunked", eos=-1, eos_token_ids=(), num_sink_tokens=sc["sink"],
-                               num_recent_tokens=sc["recent"], decode_keep_tokens=sc["keep"], snapkv_window_size=4,
+                               num_recent_tokens=sc["recent"], decode_keep_tokens=sc["keep"], snapkv_window_size=sc.get("window", 4),
                                vllm_sparse_method=sc["method"], **sc["planner"])
 
     def mkseqs(sc):
@@ -1764,6 +1764,67 @@ def gen_planned_run():
         after_prefill=lambda ch: ctl._streamingllm_prefill_eviction(ch), after_decode=lambda ch: ctl._streamingllm_decode_eviction(ch),
         snapshot=snap_sllm)
     out["streamingllm"] = dict(trace=trace, initial_free_stack=[[int(x) for x in initial_stack[l]] for l in range(L)])
+
+    # ---- SnapKV: final-chunk selection and decode re-eviction through the controller, arbitrary scores (counts only)
+    sc = prs.SNAPKV
+    L = sc["layers"]
+    km = _make_snapkv_manager([[0] * sc["rows"]] * L, cap=sc["max_model_len"], nslots=sc["slots"], sink=sc["sink"],
+                              recent=sc["recent"], keep=sc["keep"], window=sc["window"], heads=2, dim=4)
+    km.config.chunk_prefill_size = sc["planner"]["chunk_prefill_size"]
+    km.seq_id_to_row = [dict() for _ in range(L)]
+    km.free_rows = [deque(range(sc["rows"])) for _ in range(L)]
+    km.layer_batch_states = [SimpleNamespace(slot_mapping=None, context_lens=None, req_indices=None, max_context_len=0) for _ in range(L)]
+    km._pyramidkv_clear_long_prefill_offload_prefetch = lambda: None
+    km._pyramidkv_long_prefill_offload_kind = lambda: "none"
+    km.raw_kv_offload_buffer = SimpleNamespace(release_layer=lambda **k: None)
+    km.decode_kv_lens_for_layer = lambda layer_idx, seqs_, _m=km: [int(_m.row_seq_lens[layer_idx][_m.seq_id_to_row[layer_idx][s_.seq_id]])
+                                                                  for s_ in seqs_]
+    kctl = _make_controller(sink=sc["sink"], recent=sc["recent"], keep=sc["keep"], method="snapkv", cache_manager=km, num_layers=L)
+    kseqs = mkseqs(sc)
+    kg = torch.Generator().manual_seed(5)
+
+    def k_sync(is_prefill):
+        for l in range(L):
+            st, bs = kctl.layer_batch_sparse_states[l], km.layer_batch_states[l]
+            st.context_lens = bs.context_lens.clone() if is_prefill else bs.context_lens
+            st.max_context_len, st.req_indices = bs.max_context_len, bs.req_indices
+
+    def k_prefill(ch):
+        set_context(True, seqs=ch)
+        km._prepare_prefill(ch)
+        k_sync(True)
+
+    def k_decode(ch):
+        set_context(False, seqs=ch)
+        SnapKVCacheManager._prepare_decode(km, ch)
+        k_sync(False)
+
+    def k_after_prefill(ch):
+        for l in range(L):
+            for s_ in ch:
+                if s_.is_last_chunk_prefill:
+                    n = int(s_.num_prefilled_tokens) + int(s_.current_chunk_size)
+                    km._prefill_attn_score_accumulators[(l, s_.seq_id)] = torch.rand(n, generator=kg)
+        kctl._snapkv_prefill_eviction(ch)
+
+    def k_after_decode(ch):
+        for l in range(L):
+            st = kctl.layer_batch_sparse_states[l]
+            st.attn_score = torch.rand(len(ch), int(st.max_context_len), generator=kg)
+        kctl._snapkv_decode_eviction(ch)
+
+    def snap_snapkv(base):
+        lens = {}
+        for s_ in kseqs:
+            if s_.seq_id in km.seq_id_to_row[0]:
+                per_layer = [int(km.row_seq_lens[l][km.seq_id_to_row[l][s_.seq_id]]) for l in range(L)]
+                assert len(set(per_layer)) == 1
+                lens[str(s_.seq_id - base)] = per_layer[0]
+        return dict(free=[int(x) for x in km._num_free_slots], lens=lens)
+
+    trace = _planned_run_loop(sc, Scheduler(sched_cfg(sc), km), km, kseqs, prepare_prefill=k_prefill, prepare_decode=k_decode,
+                              after_prefill=k_after_prefill, after_decode=k_after_decode, snapshot=snap_snapkv)
+    out["snapkv"] = dict(trace=trace)
 
     for name, t in out.items():
         kinds = [r["prefill"] for r in t["trace"]]

@@ -41,4 +41,14 @@ STREAMINGLLM = dict(
     planner=dict(max_num_seqs_in_batch=3, max_num_batched_tokens=64, max_decoding_seqs=4, chunk_prefill_size=32),
 )
 
-SCENARIOS = {"h2o": H2O, "quest": QUEST, "streamingllm": STREAMINGLLM}
+# SnapKV: the whole prompt stays resident until its final chunk (selection from the last `window` queries' scores), decode
+# re-evicts at twice the top budget; counts only in the reference run (which tokens survive needs scores)
+SNAPKV = dict(
+    method="snapkv", layers=2, rows=6, slots=200, max_model_len=512,
+    sink=4, recent=8, keep=20, window=8,             # budget 32 tokens, decode re-eviction at 40
+    prompts=[100, 20, 61, 45, 130, 33],
+    gens=[40, 50, 12, 60, 9, 21],
+    planner=dict(max_num_seqs_in_batch=3, max_num_batched_tokens=64, max_decoding_seqs=4, chunk_prefill_size=32),
+)
+
+SCENARIOS = {"h2o": H2O, "quest": QUEST, "streamingllm": STREAMINGLLM, "snapkv": SNAPKV}

@@ -1,6 +1,6 @@
 """SURVEY 8(f).4 with a consumer: waiting prompts -> `StepPlanner` -> planned prefill chunks -> decode, executed on the GPU
-by `SparseDecodeDriver.run` (engine/decode_driver.py) under a KV pool small enough that admission defers, for H2O, Quest
-and StreamingLLM (whose slot tables and free stacks, having no scores in them, must equal the REFERENCE run's bit for bit).
+by `SparseDecodeDriver.run` (engine/decode_driver.py) under a KV pool small enough that admission defers, for H2O, Quest,
+SnapKV and StreamingLLM (whose slot tables and free stacks, having no scores in them, must equal the REFERENCE run's bit for bit).
 Two independent checks of every step:
 
 * the PLAN (which sequences ran, chunk sizes, queue orders, deferred prompts, finished rows, every row's physical length,
@@ -414,3 +414,113 @@ def test_streamingllm_planned_run_reproduces_the_reference_bit_for_bit(ref_plan)
     assert any(r["deferred"] for r in want) and seen["evicting_decode_steps"] >= 3
     assert drv.graph_stats["replayed"] >= 10, drv.graph_stats
     assert all(n == cm.num_slots for n in cm._num_free_slots) and not cm.seq_id_to_row[0]
+
+
+# ------------------------------------------------------------------------------------------------------------ SnapKV
+def test_snapkv_planned_run_matches_reference_plan_and_oracle(ref_plan):
+    """SnapKV through the engine loop: whole prompts resident until their final chunk (which must hold the score window:
+    `min_final_prefill_chunk_size`), final-chunk selection sink + top-k of the window's scores + recent, decode re-eviction at
+    twice the top budget from the step's head-max raw scores.  Plan, queues, deferred prompts, lengths and free counts equal
+    the reference run's; slot tables, free stacks and outputs equal the chained oracle's (`oracle/snapkv.py`)."""
+    from oracle import snapkv as osk
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.decode_driver import SparseDecodeDriver
+    sc = prs.SNAPKV
+    L, sink, recent, keep, window = sc["layers"], sc["sink"], sc["recent"], sc["keep"], sc["window"]
+    budget = sink + keep + recent
+    conf = Config.from_kwargs(sparse_method="snapkv", num_hidden_layers=L, max_model_len=sc["max_model_len"],
+                              max_num_seqs_in_gpu=sc["rows"], num_kvcache_slots=sc["slots"], sink_keep_tokens=sink,
+                              recent_keep_tokens=recent, decode_keep_tokens=keep, snapkv_window_size=window,
+                              engine_prefill_chunk_size=sc["planner"]["chunk_prefill_size"])
+    drv = SparseDecodeDriver(conf)
+    cm = drv.cache_manager
+    cm.permute_free_slots(6)
+    drv.enable_decode_graph()
+    planner = _planner(sc, cm)
+    seqs = _prompts(sc)
+    base = seqs[0].seq_id
+    want = ref_plan["snapkv"]["trace"]
+    st = oh.SlotState(cm.buffer_req_to_token_slots_tensor.cpu().numpy().copy(), cm.free_slots_stack_tensor.cpu().numpy().copy(),
+                      np.asarray(cm._num_free_slots, dtype=np.int64), np.stack(cm.row_seq_lens).astype(np.int32))
+    kc, vc = _f(cm.kv_cache[0]).copy(), _f(cm.kv_cache[1]).copy()
+    acc: dict = {}                                   # (layer, row) -> element-wise max of the window scores
+    seen = dict(steps=0, decode_evictions=0, prefill_evictions=0)
+
+    def row_of(s):
+        return cm.seq_id_to_row[0][s.seq_id]
+
+    def on_step(rec):
+        torch.cuda.synchronize()
+        step = seen["steps"]
+        active, chunk = rec["seqs"], np.array(rec["chunks"], np.int32)
+        rows = [row_of(s) for s in active]
+        qn, kn, vn, got_o = _f(rec["q"]), _f(rec["k"]), _f(rec["v"]), _f(rec["outputs"])
+        req = np.array(rows, np.int32)
+        if rec["prefill"]:
+            starts = np.concatenate(([0], np.cumsum(chunk)[:-1])).astype(np.int32)
+            finals = [s.num_prefilled_tokens >= s.num_prompt_tokens for s in active]         # (postprocess has run)
+            done = [s.num_prefilled_tokens - int(c) for s, c in zip(active, chunk)]
+            scored = osk.prefill_score_rows([s.num_prompt_tokens for s in active], done, chunk, budget=budget, window=window)
+            for l in range(L):
+                ctx = []
+                for b, (r, n) in enumerate(zip(rows, chunk)):
+                    new = oh.allocate(st, l, r, int(n))
+                    kc[l][new], vc[l][new] = kn[l][starts[b]: starts[b] + n], vn[l][starts[b]: starts[b] + n]
+                    ctx.append(int(st.row_len[l, r]))
+                ctx = np.array(ctx, np.int32)
+                ref_o = opa.context_attention_fwd(qn[l], kc[l], vc[l], req, starts, ctx, ctx - chunk, st.slot_table[l])
+                np.testing.assert_allclose(got_o[l], bf16_round(ref_o), rtol=TOL, atol=TOL, err_msg=f"prefill layer {l} step {step}")
+                if scored:
+                    sb = [b for b, _, _ in scored]
+                    qs = np.array([s0 for _, s0, _ in scored], np.int32)
+                    qe = np.array([e0 for _, _, e0 in scored], np.int32)
+                    scs = np.empty((len(sb), int(ctx[sb].max())), np.float32)
+                    ops.prefill_score_fwd(qn[l], kc[l], scs, req[sb], starts[sb], ctx[sb], (ctx - chunk)[sb], int((qe - qs).max()),
+                                          st.slot_table[l], qs, qe, candidate_start=sink, num_recent_tokens=recent)
+                    for j, b in enumerate(sb):
+                        acc[(l, rows[b])] = osk.accumulate_prefill_score(acc.get((l, rows[b])), scs[j, : ctx[b]], mode="probability")
+            before = int(st.free_ptr[0])
+            osk.snapkv_prefill_eviction(st, range(L), rows, [int(st.row_len[0, r]) for r in rows], finals, acc, sink=sink,
+                                        recent=recent, keep=keep)
+            seen["prefill_evictions"] += int(int(st.free_ptr[0]) != before)
+            for r, fin in zip(rows, finals):
+                if fin:
+                    for l in range(L):
+                        acc.pop((l, r), None)
+        else:
+            new_slots = oh.decode_allocate_batch_layers(st, range(L), rows)
+            lens = np.array([st.row_len[0, r] for r in rows], dtype=np.int32)
+            raws = {}
+            for l in range(L):
+                kc[l][new_slots[l]], vc[l][new_slots[l]] = kn[l], vn[l]
+                raw = np.full((len(rows), int(lens.max())), -1e20, dtype=np.float32)
+                mid, lse = oda.flash_decode_stage1(qn[l], kc[l], vc[l], st.slot_table[l], req, lens, int(lens.max()), 64, attn_score=raw)
+                o = oda.flash_decode_stage2(mid, lse, lens, 64)
+                np.testing.assert_allclose(got_o[l], bf16_round(o), rtol=TOL, atol=TOL, err_msg=f"decode layer {l} step {step}")
+                raws[l] = raw
+            before = int(st.free_ptr[0])
+            osk.snapkv_decode_eviction(st, range(L), rows, raws, sink=sink, recent=recent, keep=keep)
+            seen["decode_evictions"] += int(int(st.free_ptr[0]) != before)
+        # ---- device state == oracle mirror, plan == reference
+        np.testing.assert_array_equal(np.stack(cm.row_seq_lens), st.row_len)
+        np.testing.assert_array_equal(np.asarray(cm._num_free_slots), st.free_ptr)
+        tab, stack = cm.buffer_req_to_token_slots_tensor.cpu().numpy(), cm.free_slots_stack_tensor.cpu().numpy()
+        for l in range(L):
+            for r in sorted(set(cm.seq_id_to_row[0].values())):
+                n = int(st.row_len[l, r])
+                np.testing.assert_array_equal(tab[l, r, :n], st.slot_table[l, r, :n], err_msg=f"slot table step {step} layer {l} row {r}")
+            p = int(st.free_ptr[l])
+            np.testing.assert_array_equal(stack[l, :p], st.free_stack[l, :p])
+        lens_now = {s.seq_id - base: int(cm.row_seq_lens[0][row_of(s)]) for s in seqs if s.seq_id in cm.seq_id_to_row[0]}
+        _check_plan_record(step, rec, want[step], planner, base, lens_now, dict(free=[int(x) for x in cm._num_free_slots]))
+        for s in rec["finished"]:
+            oh.free_seq(st, range(L), row_of(s))
+        seen["steps"] += 1
+
+    plan = drv.run(planner, seqs, StepInputs(L, drv.device), on_step=on_step)
+    assert len(plan) == len(want) == seen["steps"]
+    assert any(r["deferred"] for r in want) and seen["prefill_evictions"] >= 4 and seen["decode_evictions"] >= 6
+    assert drv.graph_stats["replayed"] >= 10, drv.graph_stats
+    assert all(n == cm.num_slots for n in cm._num_free_slots) and not cm.seq_id_to_row[0]
+    np.testing.assert_array_equal(_f(cm.kv_cache[0]), kc)
+    np.testing.assert_array_equal(_f(cm.kv_cache[1]), vc)
