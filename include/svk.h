@@ -1020,7 +1020,8 @@ typedef struct SvkDeltakvTokenScoresArgs {
   const float* raw_scores;        /* [B, H, L] f32 (3-D output of stage 1)        */
   const int32_t* candidate_lens;  /* [B]                                          */
   float* token_scores;            /* [B, L] f32 out                               */
-  float* workspace;               /* [B, H, svk_deltakv_token_scores_chunks(L), 2] f32 partial max / sum */
+  float* workspace;               /* [B, H, svk_deltakv_token_scores_chunks(L), 2] f32 partial max / sum + a ticket word per
+                                     (row, head): ZERO before the first launch, zero again after every launch (ABI 19) */
   int64_t raw_stride_b, raw_stride_h, out_stride;
   float scale, fill_value;
   int32_t batch, num_heads, length, candidate_start;
@@ -1028,7 +1029,7 @@ typedef struct SvkDeltakvTokenScoresArgs {
 } SvkDeltakvTokenScoresArgs;
 int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_stream_t stream);
 /* statistics slots per (row, head) the workspace must hold for score rows of `length` elements: one per 4096-element
- * chunk plus one for their combination */
+ * chunk, one for their combination and one for the ticket of the chunk that combines them (the last to arrive) */
 int svk_deltakv_token_scores_chunks(int32_t length);
 
 /* idx[r, :k] = indices of the k largest of scores[r, :n] ordered by (score desc, index asc) -

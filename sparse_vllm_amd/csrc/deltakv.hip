@@ -356,29 +356,35 @@ __global__ void __launch_bounds__(256) token_score_stats_kernel(const SvkDeltakv
     for (int j = 0; j < kTokenScoreChunk / 256; ++j) sum += expf(v[j] - mx);     // exp(-inf) == 0 for the padding
   }
   sum = block_allsum(sum, red);
+  float* row_ws = a.workspace + ((int64_t)b * a.num_heads + h) * (nchunk + 2) * 2;
+  __shared__ int s_last;
   if (threadIdx.x == 0) {
-    float* ws = a.workspace + (((int64_t)b * a.num_heads + h) * (nchunk + 1) + c) * 2;
-    ws[0] = mx;
-    ws[1] = sum;
+    // write-through (agent-scope) stores + a ticket: the LAST chunk of a (row, head) to arrive combines the row's chunk
+    // statistics itself (round 6; a launch of its own before: 5.3 us per observation layer).  No release fence - it would
+    // write back everything stage 1 has just left dirty in this XCD's L2 (docs/KERNELS.md 4.2).
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(row_ws) + 2 * c, __float_as_uint(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(row_ws) + 2 * c + 1, __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int* ticket = reinterpret_cast<int*>(row_ws + 2 * (nchunk + 1));
+    s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunk - 1;
+    if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // self-cleaning
   }
-}
-
-// the chunk statistics of one (row, head) -> its global (max, sum) in slot `nchunk` of the same workspace row; one wave.
-// (Round 2 combined them at the top of every workgroup of the final kernel: 1024 workgroups each re-did 28 two-pass
-// wave reductions - most of that kernel's 19 us at 262 k tokens.)
-__global__ void __launch_bounds__(64) token_score_combine_kernel(const SvkDeltakvTokenScoresArgs a, int nchunk) {
-  const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  float* ws = a.workspace + ((int64_t)b * a.num_heads + h) * (nchunk + 1) * 2;
-  float mx = -INFINITY;
-  for (int c = lane; c < nchunk; c += 64) mx = fmaxf(mx, ws[2 * c]);
-  mx = wave_allmax(mx);
-  float sum = 0.f;
-  for (int c = lane; c < nchunk; c += 64) {
-    const float m = ws[2 * c];
-    if (m > -INFINITY) sum += ws[2 * c + 1] * expf(m - mx);
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64) return;
+  // combine (one wave): the order of the sums is fixed by the chunk index, whoever arrives last
+  const int lane = threadIdx.x;
+  float gm = -INFINITY;
+  for (int cc = lane; cc < nchunk; cc += 64)
+    gm = fmaxf(gm, __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(row_ws) + 2 * cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+  gm = wave_allmax(gm);
+  float gs = 0.f;
+  for (int cc = lane; cc < nchunk; cc += 64) {
+    const float m = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(row_ws) + 2 * cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float sv = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(row_ws) + 2 * cc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (m > -INFINITY) gs += sv * expf(m - gm);
   }
-  sum = wave_allsum(sum);
-  if (lane == 0) { ws[2 * nchunk] = mx; ws[2 * nchunk + 1] = sum; }
+  gs = wave_allsum(gs);
+  if (lane == 0) { row_ws[2 * nchunk] = gm; row_ws[2 * nchunk + 1] = gs; }
 }
 
 // two tokens per thread (256 apart), 16 heads per trip: the kernel is a latency chain per trip (loads -> exp / divide), so
@@ -389,7 +395,7 @@ __global__ void __launch_bounds__(256) token_score_final_kernel(const SvkDeltakv
   extern __shared__ float stats[];      // [H][2] global max / sum per head
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < 2 * a.num_heads; i += 256)
-    stats[i] = a.workspace[(((int64_t)b * a.num_heads + (i >> 1)) * (nchunk + 1) + nchunk) * 2 + (i & 1)];
+    stats[i] = a.workspace[(((int64_t)b * a.num_heads + (i >> 1)) * (nchunk + 2) + nchunk) * 2 + (i & 1)];
   __syncthreads();
   const int len = min(max(a.candidate_lens[b], 0), a.length - a.candidate_start);
   const int t0 = blockIdx.x * 512 + threadIdx.x;
@@ -1328,9 +1334,10 @@ extern "C" int svk_deltakv_reconstruct_writeback_batched(const SvkDeltakvReconst
   return launch_reconstruct(first, *b, stream);
 }
 
-// statistics slots per (row, head) of the workspace: one per 4096-element chunk + one for the combined (max, sum)
+// statistics slots per (row, head) of the workspace: one per 4096-element chunk + one for the combined (max, sum) + one
+// whose first word is the (row, head)'s ticket (zero before the first launch, zero again after every launch)
 extern "C" int svk_deltakv_token_scores_chunks(int32_t length) {
-  return (length <= 0 ? 1 : (length + svk::kTokenScoreChunk - 1) / svk::kTokenScoreChunk) + 1;
+  return (length <= 0 ? 1 : (length + svk::kTokenScoreChunk - 1) / svk::kTokenScoreChunk) + 2;
 }
 
 extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_stream_t stream) {
@@ -1340,9 +1347,8 @@ extern "C" int svk_deltakv_token_scores(const SvkDeltakvTokenScoresArgs* a, svk_
               "candidate_start must be within score length; got %d for L=%d.", a->candidate_start, a->length);
   if (a->batch <= 0 || a->length <= 0) return SVK_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int nchunk = svk_deltakv_token_scores_chunks(a->length) - 1;
+  const int nchunk = svk_deltakv_token_scores_chunks(a->length) - 2;
   hipLaunchKernelGGL(token_score_stats_kernel, dim3(a->batch, a->num_heads, nchunk), dim3(256), 0, s, *a, nchunk);
-  hipLaunchKernelGGL(token_score_combine_kernel, dim3(a->batch, a->num_heads), dim3(64), 0, s, *a, nchunk);
   hipLaunchKernelGGL(token_score_final_kernel, dim3((a->length + 511) / 512, a->batch), dim3(256),
                      sizeof(float) * 2 * a->num_heads, s, *a, nchunk);
   return check_launch("svk_deltakv_token_scores");

@@ -397,6 +397,9 @@ def triton_dequantize_2d_int4_grouped(packed, scale, mn, group_size: int, output
     return dequantize_grouped(packed, scale, mn, group_size, output_dim, 4)
 
 
+_TOKEN_SCORE_WS: dict = {}
+
+
 def decode_softmax_token_scores(scores, *, candidate_start: int, candidate_lens, scale: float, round_dtype=None,
                                 fill_value: float | None = None):
     """SparseController._decode_softmax_token_scores (sparse_controller.py:255-299)."""
@@ -412,7 +415,12 @@ def decode_softmax_token_scores(scores, *, candidate_start: int, candidate_lens,
         fill_value = torch.finfo(rd).min
     out = torch.empty((B, L), dtype=torch.float32, device=scores.device)
     lib = _lib.load()
-    ws = torch.empty((B, H, int(lib.svk_deltakv_token_scores_chunks(L)), 2), dtype=torch.float32, device=scores.device)
+    # statistics + tickets: zero-filled once, self-cleaning afterwards (include/svk.h), one buffer per launch shape
+    key = (scores.device.index, B, H, L)
+    ws = _TOKEN_SCORE_WS.get(key)
+    if ws is None:
+        ws = _TOKEN_SCORE_WS[key] = torch.zeros((B, H, int(lib.svk_deltakv_token_scores_chunks(L)), 2), dtype=torch.float32,
+                                                device=scores.device)
     a = _lib.SvkDeltakvTokenScoresArgs(
         raw_scores=_lib.ptr(scores), candidate_lens=_lib.ptr(candidate_lens.to(torch.int32)), token_scores=_lib.ptr(out),
         workspace=_lib.ptr(ws), raw_stride_b=scores.stride(0), raw_stride_h=scores.stride(1), out_stride=out.stride(0),
