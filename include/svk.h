@@ -40,7 +40,7 @@ typedef enum SvkStatus {
   SVK_ERR_LAUNCH = -4   /* HIP launch failure                  -> RuntimeError   */
 } SvkStatus;
 
-#define SVK_ABI_VERSION 19
+#define SVK_ABI_VERSION 20
 
 int svk_abi_version(void);
 const char* svk_last_error(void);
@@ -172,6 +172,30 @@ typedef struct SvkFlashDecodeStage1Args {
    * page_slot * page_size + offset, e.g. Quest: the decode view is then 1 / page_size of the entries).  0 = token slots,
    * the reference's contract.  Must be a power of two. */
   int32_t slot_page_size;
+  /* MI355X (ABI 20), unscored launches only: the ROTATED form of the fused store, for an attention view that is a rotated
+   * copy of a pre-RoPE cache (DeltaKV sparse layers: the newest row of deltakv_materialize_sparse_view,
+   * kernels/triton/deltakv_kernels.py:3588-3693, and the raw store of save_raw_kv_if_needed,
+   * deltakv_less_memory.py:1269-1281, riding in the attention launch).  With new_cos_sin != NULL (and new_k, new_v,
+   * slot_mapping as above) the workgroup that owns position b_seqlen[b]-1 writes
+   *   raw_k_cache / raw_v_cache[slot_mapping[b]]            = new_k[b], new_v[b]        (the pre-RoPE rows), and
+   *   k_cache[req_to_tokens[row, b_seqlen[b]-1]]            = bf16(RoPE(k_norm(new_k[b]))) at position
+   *                                                           max(new_slot_to_pos[slot_mapping[b]], 0),
+   *   v_cache[same slot]                                    = new_v[b]
+   * before it reads the view's row; slot_mapping[b] < 0 or >= raw_num_slots writes nothing.  Same bits as the view launch
+   * with new_k / new_v / new_slots.  slot_page_size must be 0. */
+  const void* new_cos_sin;         /* NULL = plain fused store; [max_pos, D] cos | sin halves (new_cos_dtype) */
+  const int32_t* new_slot_to_pos;  /* [raw_num_slots]                                       */
+  const int32_t* new_row_lens;     /* NULL, or [B]: the absolute length of lane b's row INCLUDING the new token - the
+                                    * position is then max(new_row_lens[b] - 1, 0), which is what
+                                    * new_slot_to_pos[slot_mapping[b]] holds once the step's allocation has recorded the
+                                    * token, read without the dependent trip through slot_mapping                        */
+  const float* new_k_norm_weight;  /* NULL or [D] f32                                       */
+  uint16_t* raw_k_cache;           /* [raw_num_slots, Hkv, D] bf16 (raw_slot_stride / raw_head_stride) */
+  uint16_t* raw_v_cache;
+  int64_t raw_slot_stride, raw_head_stride, new_cos_stride;
+  int32_t raw_num_slots, new_cos_dtype;
+  float new_k_norm_eps;
+  int32_t _pad_rot;
 } SvkFlashDecodeStage1Args;
 int svk_flash_decode_stage1(const SvkFlashDecodeStage1Args* a, svk_stream_t stream);
 
@@ -811,7 +835,15 @@ typedef struct SvkDeltakvMaterializeArgs {
   int64_t new_token_stride, new_head_stride;
   /* MI355X: 1 = the entries recognised as this step's reconstruct scratch (temp_slots) are NOT copied: the
    * reconstruction wrote them into out_k / out_v itself (SvkDeltakvReconstructArgs.out_k_cache) */
-  int32_t skip_temp, _pad0;
+  int32_t skip_temp;
+  /* MI355X (ABI 20): 1 = the entry whose slot equals new_slots[b] is NOT written either (new_slots != NULL, new_k / new_v
+   * NULL): the layer's attention launch stores that row itself, rotated (SvkFlashDecodeStage1Args.new_cos_sin). */
+  int32_t skip_new;
+  /* MI355X (ABI 20): layer_count > 1 = the same slot table materialised for layer_count consecutive layers in one
+   * launch: layer i reads k_cache / v_cache + i * kv_layer_stride, writes out_k / out_v + i * out_layer_stride and
+   * normalises with k_norm_weight + i * k_norm_layer_stride (elements).  Carries no store (new_k NULL).  0 / 1 = one layer. */
+  int64_t kv_layer_stride, out_layer_stride, k_norm_layer_stride;
+  int32_t layer_count, _pad0;
 } SvkDeltakvMaterializeArgs;
 int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeArgs* a, svk_stream_t stream);
 

@@ -23,7 +23,7 @@ SVK_SCORE_NONE = 0
 SVK_SCORE_HEADMAX = 2
 SVK_SCORE_PERHEAD = 3
 
-SVK_ABI_VERSION = 19
+SVK_ABI_VERSION = 20
 
 SVK_PREFILL_SCORE_PROBABILITY = 0
 SVK_PREFILL_SCORE_LOGITS = 1
@@ -56,7 +56,10 @@ class SvkFlashDecodeStage1Args(C.Structure):
                 ("batch", _i32), ("num_q_heads", _i32), ("num_kv_heads", _i32), ("head_dim", _i32),
                 ("max_len_in_batch", _i32), ("block_seq", _i32), ("score_mode", _i32),
                 ("new_k", _p), ("new_v", _p), ("slot_mapping", _p), ("new_stride_b", _i64), ("new_stride_h", _i64),
-                ("direct_o", _p), ("direct_stride_b", _i64), ("direct_stride_h", _i64), ("score_overwrite", _i32), ("slot_page_size", _i32)]
+                ("direct_o", _p), ("direct_stride_b", _i64), ("direct_stride_h", _i64), ("score_overwrite", _i32), ("slot_page_size", _i32),
+                ("new_cos_sin", _p), ("new_slot_to_pos", _p), ("new_row_lens", _p), ("new_k_norm_weight", _p), ("raw_k_cache", _p), ("raw_v_cache", _p),
+                ("raw_slot_stride", _i64), ("raw_head_stride", _i64), ("new_cos_stride", _i64),
+                ("raw_num_slots", _i32), ("new_cos_dtype", _i32), ("new_k_norm_eps", _f32), ("_pad_rot", _i32)]
 
 
 class SvkFlashDecodeStage2Args(C.Structure):
@@ -249,7 +252,8 @@ class SvkDeltakvMaterializeArgs(C.Structure):
                [(n, _i32) for n in ("batch", "width", "num_slots", "num_kv_heads", "head_dim", "cos_dtype")] + \
                [("temp_slots", _p), ("temp_stride", _i64), ("temp_offset", _i32), ("temp_count", _i32)] + \
                [("new_k", _p), ("new_v", _p), ("new_slots", _p), ("new_token_stride", _i64), ("new_head_stride", _i64)] + \
-               [("skip_temp", _i32), ("_pad0", _i32)]
+               [("skip_temp", _i32), ("skip_new", _i32), ("kv_layer_stride", _i64), ("out_layer_stride", _i64),
+                ("k_norm_layer_stride", _i64), ("layer_count", _i32), ("_pad0", _i32)]
 
 
 class SvkContextAttentionArgs(C.Structure):

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "svk_common.hpp"
+#include "rope_row.hpp"
 #include "svk_select.hpp"
 
 namespace svk {
@@ -89,6 +90,26 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
   constexpr int score_mode = MODE;
 
   const int len = a.b_seqlen[b];
+  // rotated form of the fused store (unscored launches): what it needs and what depends on nothing but (b, w, lane) is
+  // requested here, beside the row length - the owner of the newest token then has one round trip (cos | sin and its
+  // view slot) between the length and its stores instead of four
+  bool rotated = false;
+  int rot_ns = -1, rot_pos = 0;
+  uint4 rot_k1 = make_uint4(0, 0, 0, 0), rot_k2 = rot_k1, rot_v1 = rot_k1, rot_v2 = rot_k1;
+  if constexpr (MODE == SVK_SCORE_NONE) {
+    rotated = a.new_cos_sin != nullptr;
+    if (rotated) {
+      rot_ns = a.slot_mapping[b];
+      if (a.new_row_lens != nullptr) rot_pos = a.new_row_lens[b];
+      if (lane < D / 16) {
+        const int64_t src = (int64_t)b * a.new_stride_b + (int64_t)w * a.new_stride_h + lane * 8;
+        rot_k1 = *reinterpret_cast<const uint4*>(a.new_k + src);
+        rot_k2 = *reinterpret_cast<const uint4*>(a.new_k + src + D / 2);
+        rot_v1 = *reinterpret_cast<const uint4*>(a.new_v + src);
+        rot_v2 = *reinterpret_cast<const uint4*>(a.new_v + src + D / 2);
+      }
+    }
+  }
   const int start = blk * a.block_seq;
   const int end = min(len, start + a.block_seq);
 
@@ -123,14 +144,43 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
     // launch and the CU cannot hold a stale line of it (L1 is write-through, invalidated at kernel start), so a
     // workgroup-scope fence pair (= the store has completed) is enough; agent scope would write back the XCD's L2
     // (+10 us per launch measured).
-    const int ns = a.slot_mapping[b];
-    if (ns >= 0 && lane < 2 * DW) {
-      const bool is_v = lane >= DW;
-      const int seg = lane % DW;
-      const uint16_t* src = (is_v ? a.new_v : a.new_k) + (int64_t)b * a.new_stride_b + (int64_t)w * a.new_stride_h + seg * 8;
-      uint16_t* dst = const_cast<uint16_t*>(is_v ? a.v_cache : a.k_cache) + (int64_t)ns * a.kv_slot_stride +
-                      (int64_t)w * a.kv_head_stride + seg * 8;
-      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    if (rotated) {
+      if constexpr (MODE == SVK_SCORE_NONE) {
+        // rotated store (include/svk.h): the raw rows go to the pre-RoPE cache, the view's row of position len-1 gets
+        // the k-normed, rotated key - lane j < D/16 owns elements 8j.. and their rotate-half partners, exactly as in
+        // the view launch (rope_row.hpp), V rides with the same lanes.  Rows, slot and position were requested
+        // above, beside the row length.
+        constexpr int HD2 = D / 2, LPH = HD2 / 8;
+        if (rot_ns >= 0 && rot_ns < a.raw_num_slots && lane < LPH) {
+          const int p = lane * 8;
+          const int vslot = a.req_to_tokens[(int64_t)a.b_req_idx[b] * a.req_stride + (len - 1)];
+          const int pos = max(a.new_row_lens != nullptr ? rot_pos - 1 : a.new_slot_to_pos[rot_ns], 0);
+          float n1[8], n2[8];
+          rope_row_norm<D>(rot_k1, rot_k2, a.new_k_norm_weight, a.new_k_norm_eps, p, n1, n2);
+          uint4 o1, o2;
+          rope_row_rotate<D>(n1, n2, a.new_cos_sin, (int64_t)pos * a.new_cos_stride, a.new_cos_dtype, p, o1, o2);
+          const int64_t rd = (int64_t)rot_ns * a.raw_slot_stride + (int64_t)w * a.raw_head_stride + p;
+          *reinterpret_cast<uint4*>(a.raw_k_cache + rd) = rot_k1;
+          *reinterpret_cast<uint4*>(a.raw_k_cache + rd + HD2) = rot_k2;
+          *reinterpret_cast<uint4*>(a.raw_v_cache + rd) = rot_v1;
+          *reinterpret_cast<uint4*>(a.raw_v_cache + rd + HD2) = rot_v2;
+          const int64_t vd = (int64_t)vslot * a.kv_slot_stride + (int64_t)w * a.kv_head_stride + p;
+          *reinterpret_cast<uint4*>(const_cast<uint16_t*>(a.k_cache) + vd) = o1;
+          *reinterpret_cast<uint4*>(const_cast<uint16_t*>(a.k_cache) + vd + HD2) = o2;
+          *reinterpret_cast<uint4*>(const_cast<uint16_t*>(a.v_cache) + vd) = rot_v1;
+          *reinterpret_cast<uint4*>(const_cast<uint16_t*>(a.v_cache) + vd + HD2) = rot_v2;
+        }
+      }
+    } else {
+      const int ns = a.slot_mapping[b];
+      if (ns >= 0 && lane < 2 * DW) {
+        const bool is_v = lane >= DW;
+        const int seg = lane % DW;
+        const uint16_t* src = (is_v ? a.new_v : a.new_k) + (int64_t)b * a.new_stride_b + (int64_t)w * a.new_stride_h + seg * 8;
+        uint16_t* dst = const_cast<uint16_t*>(is_v ? a.v_cache : a.k_cache) + (int64_t)ns * a.kv_slot_stride +
+                        (int64_t)w * a.kv_head_stride + seg * 8;
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -678,6 +728,16 @@ static int validate_stage1(const SvkFlashDecodeStage1Args* a, const char* who) {
     SVK_REQUIRE((a->new_stride_b % 8) == 0 && (a->new_stride_h % 8) == 0 && (reinterpret_cast<uintptr_t>(a->new_k) % 16) == 0 &&
                     (reinterpret_cast<uintptr_t>(a->new_v) % 16) == 0,
                 SVK_ERR_LAYOUT, "%s: new_k/new_v rows must be 16-byte aligned", who);
+  }
+  if (a->new_cos_sin != nullptr) {
+    SVK_REQUIRE(a->score_mode == SVK_SCORE_NONE && a->slot_page_size == 0, SVK_ERR_VALUE,
+                "%s: the rotated store rides in unscored launches over token slots only", who);
+    SVK_REQUIRE(a->new_k != nullptr && a->raw_k_cache != nullptr && a->raw_v_cache != nullptr && a->new_slot_to_pos != nullptr,
+                SVK_ERR_VALUE, "%s: the rotated store needs new_k / new_v / slot_mapping, raw_k_cache, raw_v_cache and new_slot_to_pos", who);
+    SVK_REQUIRE((a->raw_slot_stride % 8) == 0 && (a->raw_head_stride % 8) == 0 && a->raw_num_slots > 0, SVK_ERR_LAYOUT,
+                "%s: raw cache rows must be 16-byte aligned", who);
+    SVK_REQUIRE(a->new_cos_dtype == SVK_DTYPE_F32 || a->new_cos_dtype == SVK_DTYPE_BF16 || a->new_cos_dtype == SVK_DTYPE_F16,
+                SVK_ERR_VALUE, "%s: new_cos_dtype %d", who, a->new_cos_dtype);
   }
   if (a->direct_o != nullptr) {
     SVK_REQUIRE(a->max_len_in_batch <= a->block_seq, SVK_ERR_VALUE,

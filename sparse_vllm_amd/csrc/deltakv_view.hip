@@ -3,34 +3,10 @@
 // partner (elements p..p+7 and p+D/2..), D/16 lanes per (token, head), so each K/V row is read and
 // written as full 2*D-byte runs; k-norm statistics are reduced over those D/16 lanes with DPP-free shuffles.
 
-#include "svk_common.hpp"
+#include "rope_row.hpp"
 
 namespace svk {
 namespace {
-
-__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
-  f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
-  f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z); f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
-}
-
-__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
-  return make_uint4(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16), f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16),
-                    f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16), f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16));
-}
-
-__device__ __forceinline__ void load8(const void* base, int64_t off, int dtype, float (&f)[8]) {
-  if (dtype == SVK_DTYPE_F32) {
-    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
-    const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off + 4);
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-  } else if (dtype == SVK_DTYPE_BF16) {
-    unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + off), f);
-  } else {
-    const _Float16* h = reinterpret_cast<const _Float16*>(base) + off;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
-  }
-}
 
 template <int D>
 __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMaterializeArgs a) {
@@ -43,21 +19,28 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
   const int64_t total = (int64_t)a.batch * a.width;
   const int64_t n = (int64_t)blockIdx.x * tokens_per_block + tl;
   const bool live = tl < tokens_per_block && n < total;
-  float k1[8], k2[8];
+  // blockIdx.y: one of layer_count consecutive layers that share the slot table (caches, views and k-norm weights at
+  // their layer strides)
+  const int64_t ly = blockIdx.y;
+  uint16_t* const k_cache = a.k_cache + ly * a.kv_layer_stride;
+  uint16_t* const v_cache = a.v_cache + ly * a.kv_layer_stride;
+  uint16_t* const out_k = a.out_k + ly * a.out_layer_stride;
+  uint16_t* const out_v = a.out_v + ly * a.out_layer_stride;
+  const float* const k_norm_weight = a.k_norm_weight == nullptr ? nullptr : a.k_norm_weight + ly * a.k_norm_layer_stride;
   uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1, rk1 = v1, rk2 = v1;
   int pos = 0;
   bool copy = false, skip = false;
-  if (a.new_slots != nullptr && tl < tokens_per_block && n >= total && n - total < a.batch) {
+  if (a.new_k != nullptr && tl < tokens_per_block && n >= total && n - total < a.batch) {
     // the blocks behind the view: this step's raw rows into the cache (what store_kvcache did in a launch of its own)
     const int b = (int)(n - total);
     const int slot = a.new_slots[b];
     if (slot >= 0 && slot < a.num_slots) {
       const int64_t src = (int64_t)b * a.new_token_stride + (int64_t)h * a.new_head_stride + p;
       const int64_t dst = (int64_t)slot * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
-      *reinterpret_cast<uint4*>(a.k_cache + dst) = *reinterpret_cast<const uint4*>(a.new_k + src);
-      *reinterpret_cast<uint4*>(a.k_cache + dst + HD2) = *reinterpret_cast<const uint4*>(a.new_k + src + HD2);
-      *reinterpret_cast<uint4*>(a.v_cache + dst) = *reinterpret_cast<const uint4*>(a.new_v + src);
-      *reinterpret_cast<uint4*>(a.v_cache + dst + HD2) = *reinterpret_cast<const uint4*>(a.new_v + src + HD2);
+      *reinterpret_cast<uint4*>(k_cache + dst) = *reinterpret_cast<const uint4*>(a.new_k + src);
+      *reinterpret_cast<uint4*>(k_cache + dst + HD2) = *reinterpret_cast<const uint4*>(a.new_k + src + HD2);
+      *reinterpret_cast<uint4*>(v_cache + dst) = *reinterpret_cast<const uint4*>(a.new_v + src);
+      *reinterpret_cast<uint4*>(v_cache + dst + HD2) = *reinterpret_cast<const uint4*>(a.new_v + src + HD2);
     }
   }
   if (live) {
@@ -72,13 +55,17 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
       copy = valid && j >= 0 && j < a.temp_count && a.temp_slots[(int64_t)b * a.temp_stride + j] == slot;
       skip = copy && a.skip_temp != 0;          // the reconstruction wrote this row of the view itself
     }
-    const uint16_t* ks = a.k_cache;
-    const uint16_t* vs = a.v_cache;
+    const uint16_t* ks = k_cache;
+    const uint16_t* vs = v_cache;
     int64_t base = (int64_t)safe * a.kv_slot_stride + (int64_t)h * a.kv_head_stride + p;
     if (a.new_slots != nullptr && valid && slot == a.new_slots[b]) {   // the row the store blocks are writing right now
-      ks = a.new_k;
-      vs = a.new_v;
-      base = (int64_t)b * a.new_token_stride + (int64_t)h * a.new_head_stride + p;
+      if (a.skip_new != 0) {
+        skip = true;                            // the attention launch of the layer writes this row (rotated store)
+      } else {
+        ks = a.new_k;
+        vs = a.new_v;
+        base = (int64_t)b * a.new_token_stride + (int64_t)h * a.new_head_stride + p;
+      }
     }
     if (!skip) {
       rk1 = *reinterpret_cast<const uint4*>(ks + base);
@@ -87,43 +74,16 @@ __global__ void __launch_bounds__(256) materialize_kernel(const SvkDeltakvMateri
       v2 = *reinterpret_cast<const uint4*>(vs + base + HD2);
     }
   }
-  unpack8(rk1, k1);
-  unpack8(rk2, k2);
   float n1[8], n2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { n1[e] = k1[e]; n2[e] = k2[e]; }
-  if (a.k_norm_weight != nullptr) {
-    float ss = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ss += k1[e] * k1[e] + k2[e] * k2[e];
-#pragma unroll
-    for (int off = 1; off < LPH; off <<= 1) ss += __shfl_xor(ss, off, 64);
-    const float rstd = rsqrtf(ss / (float)D + a.k_norm_eps);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      n1[e] = k1[e] * rstd * a.k_norm_weight[p + e];
-      n2[e] = k2[e] * rstd * a.k_norm_weight[p + HD2 + e];
-    }
-  }
+  rope_row_norm<D>(rk1, rk2, k_norm_weight, a.k_norm_eps, p, n1, n2);
   if (!live || skip) return;
   uint4 o1 = rk1, o2 = rk2;
-  if (!copy) {
-    float c[8], s[8], r1[8], r2[8];
-    load8(a.cos_sin, (int64_t)pos * a.cos_stride + p, a.cos_dtype, c);
-    load8(a.cos_sin, (int64_t)pos * a.cos_stride + p + HD2, a.cos_dtype, s);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      r1[e] = n1[e] * c[e] - n2[e] * s[e];
-      r2[e] = n2[e] * c[e] + n1[e] * s[e];
-    }
-    o1 = pack8(r1);
-    o2 = pack8(r2);
-  }
+  if (!copy) rope_row_rotate<D>(n1, n2, a.cos_sin, (int64_t)pos * a.cos_stride, a.cos_dtype, p, o1, o2);
   const int64_t ob = n * a.out_slot_stride + (int64_t)h * a.out_head_stride + p;
-  *reinterpret_cast<uint4*>(a.out_k + ob) = o1;
-  *reinterpret_cast<uint4*>(a.out_k + ob + HD2) = o2;
-  *reinterpret_cast<uint4*>(a.out_v + ob) = v1;
-  *reinterpret_cast<uint4*>(a.out_v + ob + HD2) = v2;
+  *reinterpret_cast<uint4*>(out_k + ob) = o1;
+  *reinterpret_cast<uint4*>(out_k + ob + HD2) = o2;
+  *reinterpret_cast<uint4*>(out_v + ob) = v1;
+  *reinterpret_cast<uint4*>(out_v + ob + HD2) = v2;
 }
 
 }  // namespace
@@ -139,7 +99,12 @@ extern "C" int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeAr
   SVK_REQUIRE(a->kv_slot_stride % 8 == 0 && a->kv_head_stride % 8 == 0 && a->out_slot_stride % 8 == 0 && a->out_head_stride % 8 == 0,
               SVK_ERR_LAYOUT, "svk_deltakv_materialize_sparse_view: K/V strides must keep 16-byte alignment");
   const int64_t total = (int64_t)a->batch * a->width;
-  const bool store = a->new_slots != nullptr;
+  const int layers = a->layer_count > 1 ? a->layer_count : 1;
+  SVK_REQUIRE(a->skip_new == 0 || (a->new_slots != nullptr && a->new_k == nullptr && a->new_v == nullptr), SVK_ERR_VALUE,
+              "svk_deltakv_materialize_sparse_view: skip_new needs new_slots and no new_k / new_v (the attention launch stores the row)");
+  SVK_REQUIRE(layers == 1 || (a->new_k == nullptr && a->kv_layer_stride % 8 == 0 && a->out_layer_stride % 8 == 0), SVK_ERR_LAYOUT,
+              "svk_deltakv_materialize_sparse_view: a multi-layer launch carries no store and needs 16-byte aligned layer strides");
+  const bool store = a->new_slots != nullptr && a->skip_new == 0;
   if (store) {
     SVK_REQUIRE(a->new_k != nullptr && a->new_v != nullptr, SVK_ERR_VALUE,
                 "svk_deltakv_materialize_sparse_view: new_slots needs new_k and new_v");
@@ -152,7 +117,9 @@ extern "C" int svk_deltakv_materialize_sparse_view(const SvkDeltakvMaterializeAr
   const int tpb = 256 / lpt;
   const unsigned grid = (unsigned)((entries + tpb - 1) / tpb);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (a->head_dim == 128) hipLaunchKernelGGL(materialize_kernel<128>, dim3(grid), dim3(256), 0, s, *a);
-  else hipLaunchKernelGGL(materialize_kernel<64>, dim3(grid), dim3(256), 0, s, *a);
+  SvkDeltakvMaterializeArgs k = *a;
+  if (layers == 1) k.kv_layer_stride = k.out_layer_stride = k.k_norm_layer_stride = 0;
+  if (a->head_dim == 128) hipLaunchKernelGGL(materialize_kernel<128>, dim3(grid, layers), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL(materialize_kernel<64>, dim3(grid, layers), dim3(256), 0, s, k);
   return check_launch("svk_deltakv_materialize_sparse_view");
 }

@@ -245,6 +245,8 @@ class DeltaKVCacheManager(CacheManager):
         self.recon_into_view = bool(self._RECON_INTO_VIEW_DEFAULT)
         self._layer_views: torch.Tensor | None = None
         self._recon_view_layers: set[int] = set()      # sparse layers (l_idx) whose reconstructed rows of this plan are in their view
+        self._view_rest_layers: set[int] = set()       # ... whose raw rows (all but the step's newest) are in their view as well
+        self._rotated_store_for: dict[int, dict] = {}  # layer -> the newest row's rotated store for the attention launch
         self._deltakv_postrope_slot_mask = torch.zeros((Ls, n_sparse), dtype=torch.bool, device=d)
         bits = int(cfg.kv_quant_bits or 0)
         payload = self._sparse_payload_dim()
@@ -988,7 +990,8 @@ class DeltaKVCacheManager(CacheManager):
             l += 1
         return out
 
-    def _reconstruct_group_ahead(self, layer_idx: int, recon_pos, recon_latent, recon_out_slot, view_geom=None) -> bool:
+    def _reconstruct_group_ahead(self, layer_idx: int, recon_pos, recon_latent, recon_out_slot, view_geom=None,
+                                 view_table=None) -> bool:
         """MI355X: the residual load and reconstruction of a sparse layer depend on the plan of its observation group and
         on the layer's own caches, not on the step's activations - so all layers of the group are issued NOW, back to
         back on a side stream (three launches, ~43 us per layer at 2048 tokens), while the main stream walks the layers
@@ -1008,6 +1011,8 @@ class DeltaKVCacheManager(CacheManager):
             side.wait_stream(main)                   # the plan (and everything before it) is complete for the side streams
         stack = self._stacked_up_weights()
         sub = self._recon_sub_batch()
+        if stack is not None and sub > 1 and view_table is not None:
+            self._views_rest_ahead(layers, view_table, view_geom, sides)
         if stack is None or sub <= 1:
             for i, l in enumerate(layers):
                 side = sides[i % len(sides)]
@@ -1036,6 +1041,64 @@ class DeltaKVCacheManager(CacheManager):
         self._recon_ahead = {l: True for l in layers}
         return True
 
+    @staticmethod
+    def _rotated_store_enabled() -> bool:
+        """`SVK_DELTAKV_ROTATED_STORE=0`: the per-layer view launch on the walk (the A/B reference)."""
+        return os.environ.get("SVK_DELTAKV_ROTATED_STORE", "1") != "0"
+
+    def _rotated_store_row_lens(self, batch: int):
+        lens = self.deltakv_layer_batch_states.context_lens
+        if (lens is None or lens.dtype != torch.int32 or not lens.is_contiguous() or int(lens.numel()) < batch
+                or os.environ.get("SVK_DELTAKV_ROTATED_POS", "lens") != "lens"):
+            return None
+        return lens
+
+    def _views_rest_ahead(self, layers, view_table, view_geom, sides) -> None:
+        """MI355X: a sparse layer's view launch on the walk (`get_layer_compute_view`: 7 us at one row, 20 us at four beside
+        the look-ahead - a chain of dependent loads for a few hundred rows) has nothing left to do once (a) the raw rows of
+        the view that exist BEFORE the step - sink + buffered tail - are written for every layer of the group by ONE launch
+        on the look-ahead stream, in front of the group's reconstructions, and (b) the step's newest row rides in the
+        layer's attention launch (`rotated_store`).  Here: (a)."""
+        if not self._rotated_store_enabled() or not self.recon_into_view or view_geom is None:
+            return
+        active_slots, view_lens = view_table
+        new_slots = self.deltakv_layer_batch_states.slot_mapping
+        B = int(active_slots.shape[0])
+        if (new_slots is None or new_slots is not self._deltakv_decode_static_slot_mapping or new_slots.dtype != torch.int32
+                or int(new_slots.numel()) != B or get_context().is_prefill):
+            return
+        l_idxs = [self.deltakv_layer_to_idx[l] for l in layers]
+        l0, l1 = int(l_idxs[0]), int(l_idxs[-1]) + 1
+        view = self._recon_view_out(l0, l1, view_geom)
+        if view is None or l_idxs != list(range(l0, l1)):
+            return
+        W = int(active_slots.shape[1])
+        total = B * W
+        k_max = W - int(self.config.num_sink_tokens) - self._deltakv_decode_static_max_buffer()
+        knw = self.deltakv_k_norm_weight
+        if knw is not None and (knw.dtype != torch.float32 or knw.stride(-1) != 1):
+            knw = self.__dict__.get("_k_norm_weight_f32")
+            if knw is None or knw[1] != (self.deltakv_k_norm_weight.data_ptr(), self.deltakv_k_norm_weight._version):
+                knw = self._k_norm_weight_f32 = (self.deltakv_k_norm_weight.float().contiguous(),
+                                                 (self.deltakv_k_norm_weight.data_ptr(), self.deltakv_k_norm_weight._version))
+            knw = knw[0]
+        with torch.cuda.stream(sides[0]):
+            dk.deltakv_materialize_sparse_view(
+                active_slots, view_lens, self.deltakv_slot_to_pos, None,
+                self.deltakv_full_kv_cache[0, l0:l1], self.deltakv_full_kv_cache[1, l0:l1],
+                view[0][:, :total], view[1][:, :total], self.cos_sin_cache,
+                k_norm_weight=None if knw is None else knw[l0:l1], k_norm_eps=float(self.deltakv_k_norm_eps),
+                temp_slots=self._ensure_decode_static_temp_slots(B, k_max), temp_offset=int(self.config.num_sink_tokens),
+                new_slots=new_slots, skip_temp=True, skip_new=True)
+            if len(sides) > 1:
+                ev = self.__dict__.get("_view_rest_event")
+                if ev is None:
+                    ev = self._view_rest_event = torch.cuda.Event()
+                ev.record(sides[0])
+        for side in sides[1:]:
+            side.wait_event(self._view_rest_event)
+        self._view_rest_layers = set(range(l0, l1))
+
     def _recon_event(self, layer_idx: int):
         ev = self._recon_events.get(layer_idx)
         if ev is None:
@@ -1056,6 +1119,9 @@ class DeltaKVCacheManager(CacheManager):
     def _recon_sub_batches(cls) -> list[int]:
         """Layers per look-ahead launch group (the last value repeats).  Two balances the side stream against the main
         stream's per-layer chain (measured 1 / 2 / 3 / 4 layers -> 1.88 / 1.62 / 1.66 / 1.73 ms per 256 k step)."""
+        env = os.environ.get("SVK_DELTAKV_RECON_SUB")          # developer knob: "1,2" = a first launch group of one layer, then twos
+        if env:
+            return [max(1, int(x)) for x in env.split(",") if x.strip()]
         return list(cls._RECON_SUB_BATCHES)
 
     @classmethod
@@ -1189,13 +1255,15 @@ class DeltaKVCacheManager(CacheManager):
             l_idx = self.deltakv_layer_to_idx[layer_idx]
             if fresh_plan:
                 self._recon_view_layers = set()
+                self._view_rest_layers = set()
             if recon_latent.numel() > 0:
                 geom = self._recon_view_geometry(active_slots, recon_latent)
                 ahead = self.__dict__.get("_recon_ahead") or {}
                 if fresh_plan:
                     ahead = self._recon_ahead = {}
                     if self._recon_lookahead_enabled():
-                        self._reconstruct_group_ahead(layer_idx, recon_pos, recon_latent, recon_out_slot, view_geom=geom)
+                        self._reconstruct_group_ahead(layer_idx, recon_pos, recon_latent, recon_out_slot, view_geom=geom,
+                                                      view_table=(active_slots, new_context_lens))
                         ahead = self._recon_ahead
                 if ahead.pop(int(layer_idx), False):
                     torch.cuda.current_stream().wait_event(self._recon_events[int(layer_idx)])
@@ -1245,6 +1313,21 @@ class DeltaKVCacheManager(CacheManager):
             new_slots = self.deltakv_layer_batch_states.slot_mapping
             if int(new_slots.numel()) != B:
                 raise RuntimeError(f"DeltaKV fused raw store: {int(new_slots.numel())} slots for a view of {B} rows")
+        self._rotated_store_for.pop(layer_idx, None)
+        if in_view and new_slots is not None and l_idx in self._view_rest_layers and l_idx in self._recon_view_layers:
+            # every row of this view but the step's newest is (being) written on the look-ahead stream, whose event the
+            # caller has waited for; the newest row rides in the attention launch: no launch here
+            knw = None if self.deltakv_k_norm_weight is None else self.deltakv_k_norm_weight[l_idx]
+            if knw is not None and knw.dtype != torch.float32:
+                knw = self._k_norm_weight_f32[0][l_idx]
+            self._rotated_store_for[layer_idx] = dict(
+                new_kv=(new_k, new_v, new_slots),
+                args=dict(raw_k=self.deltakv_full_kv_cache[0, l_idx], raw_v=self.deltakv_full_kv_cache[1, l_idx],
+                          slot_to_pos=self.deltakv_slot_to_pos, cos_sin=self.cos_sin_cache, k_norm_weight=knw,
+                          k_norm_eps=float(self.deltakv_k_norm_eps),
+                          # the step's allocation wrote slot_to_pos[new slot] = row length - 1 (deltakv_base.py:2098-2113)
+                          row_lens=self._rotated_store_row_lens(B)))
+            return k_out, v_out, local_active, local_req, context_lens
         with profiler.record("deltakv_materialize_sparse_view"):
             k_max = W - int(self.config.num_sink_tokens) - self._deltakv_decode_static_max_buffer()
             dk.deltakv_materialize_sparse_view(
@@ -1290,11 +1373,13 @@ class DeltaKVCacheManager(CacheManager):
             return_reconstruct_temp_slots=selection.release_temp_slots)
         k_cache, v_cache, active_slots, req_indices, context_lens = self.get_layer_compute_view(
             layer_idx, active_slots, local_req, context_lens, selection)
+        rotated = self._rotated_store_for.pop(layer_idx, None)
         return DecodeComputeView(
             meta=AttentionViewMeta(active_slots=active_slots, req_indices=req_indices, context_lens=context_lens,
                                    attn_score=selection.attn_score, max_context_len=selection.max_context_len,
                                    temp_slots=temp_slots),
-            payload=ExplicitKVPayload(k_cache=k_cache, v_cache=v_cache))
+            payload=ExplicitKVPayload(k_cache=k_cache, v_cache=v_cache,
+                                      **({} if rotated is None else {"metadata": {"rotated_store": rotated}})))
 
     def release_layer_temp_slots(self, layer_idx: int, temp_slots):
         """Static decode keeps its reconstruct scratch for the life of the graph (deltakv_less_memory.py:449-470)."""

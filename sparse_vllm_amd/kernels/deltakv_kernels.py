@@ -465,17 +465,34 @@ def topk_sorted_desc(scores, k: int, *, valid_len=None, masked_value: float = -1
 def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, postrope_mask, k_cache, v_cache, out_k, out_v,
                                     cos_sin, *, k_norm_weight=None, k_norm_eps: float = 1e-6, block_tokens: int = 16,
                                     temp_slots=None, temp_offset: int = 0, new_k=None, new_v=None, new_slots=None,
-                                    skip_temp: bool = False):
+                                    skip_temp: bool = False, skip_new: bool = False):
     """Reference wrapper deltakv_kernels.py:3489-3585 (same arguments; `block_tokens` is a Triton tile knob).
     Extensions: `temp_slots` [B, K] + `temp_offset` replace the mask in static decode (an entry in columns
     [temp_offset, temp_offset + K) is post-RoPE iff its slot is this step's reconstruct scratch slot);
     `new_k`/`new_v` [B, Hkv, D] + `new_slots` [B] carry this step's raw store in the same launch (row b's new token
     goes to cache slot new_slots[b]; the view reads it from new_k/new_v), equal to store_kvcache followed by the
-    plain call; `skip_temp`: the scratch entries are left alone (the reconstruction wrote them into out_k / out_v)."""
+    plain call; `skip_temp`: the scratch entries are left alone (the reconstruction wrote them into out_k / out_v);
+    `skip_new` (with `new_slots`, without `new_k`): the entry of row b's newest token is left alone too - the layer's
+    attention launch stores it rotated (`flash_decode_stage1(rotated_store=...)`).  k_cache / v_cache / out_k / out_v may
+    carry a leading LAYER dimension ([n, slots, Hkv, D], `k_norm_weight` [n, D]): the same slot table materialised for n
+    consecutive layers in one launch (no store)."""
     for t in (active_slots, context_lens, slot_to_pos, k_cache, v_cache, out_k, out_v, cos_sin):
         assert t.is_cuda
     assert active_slots.dim() == 2
     assert context_lens.dim() == 1 and context_lens.shape[0] == active_slots.shape[0]
+    layers = 1
+    kv_ls = out_ls = kn_ls = 0
+    if k_cache.dim() == 4:
+        layers = int(k_cache.shape[0])
+        assert v_cache.shape == k_cache.shape and out_k.dim() == 4 and out_k.shape[0] == layers and out_v.shape == out_k.shape
+        assert new_k is None and k_cache.stride() == v_cache.stride() and out_k.stride() == out_v.stride()
+        kv_ls, out_ls = k_cache.stride(0), out_k.stride(0)
+        if k_norm_weight is not None:
+            assert k_norm_weight.dim() == 2 and k_norm_weight.shape[0] == layers and k_norm_weight.dtype == torch.float32
+            assert k_norm_weight.stride(1) == 1
+            kn_ls = k_norm_weight.stride(0)
+            k_norm_weight = k_norm_weight[0]
+        k_cache, v_cache, out_k, out_v = k_cache[0], v_cache[0], out_k[0], out_v[0]
     assert k_cache.dim() == 3 and v_cache.shape == k_cache.shape
     assert out_k.dim() == 3 and out_v.shape == out_k.shape
     batch, width = active_slots.shape
@@ -493,7 +510,8 @@ def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, pos
     assert cos_sin.dim() == 2 and cos_sin.shape[1] == head_dim and cos_sin.stride(1) == 1
     if k_norm_weight is not None:
         assert k_norm_weight.is_cuda and k_norm_weight.dim() == 1 and k_norm_weight.shape[0] == head_dim
-        k_norm_weight = k_norm_weight.to(torch.float32).contiguous()
+        if layers == 1:
+            k_norm_weight = k_norm_weight.to(torch.float32).contiguous()
     if postrope_mask is not None:
         assert postrope_mask.is_cuda and postrope_mask.dim() == 1 and postrope_mask.shape[0] >= k_cache.shape[0]
         assert postrope_mask.dtype in (torch.bool, torch.uint8) and postrope_mask.is_contiguous()
@@ -515,8 +533,13 @@ def deltakv_materialize_sparse_view(active_slots, context_lens, slot_to_pos, pos
         k_norm_eps=float(k_norm_eps), batch=int(batch), width=int(width), num_slots=int(k_cache.shape[0]),
         num_kv_heads=num_kv_heads, head_dim=head_dim, cos_dtype=_dt(cos_sin), temp_slots=_lib.ptr(temp_slots),
         temp_stride=0 if temp_slots is None else temp_slots.stride(0), temp_offset=int(temp_offset),
-        temp_count=0 if temp_slots is None else int(temp_slots.shape[1]), skip_temp=int(bool(skip_temp) and temp_slots is not None))
-    if new_slots is not None:
+        temp_count=0 if temp_slots is None else int(temp_slots.shape[1]), skip_temp=int(bool(skip_temp) and temp_slots is not None),
+        layer_count=layers, kv_layer_stride=kv_ls, out_layer_stride=out_ls, k_norm_layer_stride=kn_ls)
+    if skip_new:
+        assert new_slots is not None and new_k is None and new_v is None
+        assert new_slots.dtype == torch.int32 and new_slots.is_contiguous() and new_slots.numel() == batch
+        a.new_slots, a.skip_new = _lib.ptr(new_slots), 1
+    elif new_slots is not None:
         assert new_k is not None and new_v is not None and new_k.shape == new_v.shape and new_k.stride() == new_v.stride()
         assert new_k.dtype == torch.bfloat16 and new_v.dtype == torch.bfloat16 and new_k.stride(-1) == 1
         assert tuple(new_k.shape) == (batch, num_kv_heads, head_dim)

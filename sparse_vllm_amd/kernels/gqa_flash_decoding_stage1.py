@@ -39,7 +39,8 @@ def direct_out_supported(max_len_in_batch, block_seq) -> bool:
 
 
 def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                 attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False, slot_page_size=0):
+                 attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False, slot_page_size=0,
+                 rotated_store=None):
     Lq, Lk = q.shape[-1], k.shape[-1]
     assert Lq == Lk
     assert Lk in {16, 32, 64, 128, 256}
@@ -72,6 +73,31 @@ def _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, 
         assert slot_mapping.dtype == torch.int32 and slot_mapping.is_contiguous() and slot_mapping.numel() >= batch
         store = dict(new_k=_lib.ptr(new_k), new_v=_lib.ptr(new_v), slot_mapping=_lib.ptr(slot_mapping),
                      new_stride_b=new_k.stride(0), new_stride_h=new_k.stride(1))
+    if rotated_store is not None:
+        # MI355X: the fused store in its rotated form (include/svk.h): k / v are an attention VIEW (rotated copy), the raw
+        # rows go to the pre-RoPE cache `raw_k` / `raw_v` at slot_mapping[b], the view's newest row is written rotated
+        assert new_kv is not None and attn_score is None and int(slot_page_size) == 0
+        rs = rotated_store
+        raw_k, raw_v, cos_sin = rs["raw_k"], rs["raw_v"], rs["cos_sin"]
+        assert raw_k.dtype == torch.bfloat16 and raw_v.dtype == torch.bfloat16 and raw_k.stride() == raw_v.stride()
+        assert raw_k.dim() == 3 and raw_k.shape[1] == kv_head_num and raw_k.shape[2] == Lk and raw_k.stride(2) == 1
+        if cos_sin.dim() == 3:
+            cos_sin = cos_sin[:, 0, :]
+        assert cos_sin.dim() == 2 and cos_sin.shape[1] == Lk and cos_sin.stride(1) == 1
+        pos = rs["slot_to_pos"]
+        assert pos.dtype == torch.int32 and pos.is_contiguous() and pos.numel() >= raw_k.shape[0]
+        kw = rs.get("k_norm_weight")
+        if kw is not None:
+            assert kw.dtype == torch.float32 and kw.is_contiguous() and kw.numel() == Lk
+        row_lens = rs.get("row_lens")
+        if row_lens is not None:
+            assert row_lens.dtype == torch.int32 and row_lens.is_contiguous() and row_lens.numel() >= batch
+            store.update(new_row_lens=_lib.ptr(row_lens))
+        cos_dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[cos_sin.dtype]
+        store.update(new_cos_sin=_lib.ptr(cos_sin), new_slot_to_pos=_lib.ptr(pos), new_k_norm_weight=_lib.ptr(kw),
+                     raw_k_cache=_lib.ptr(raw_k), raw_v_cache=_lib.ptr(raw_v), raw_slot_stride=raw_k.stride(0),
+                     raw_head_stride=raw_k.stride(1), new_cos_stride=cos_sin.stride(0), raw_num_slots=int(raw_k.shape[0]),
+                     new_cos_dtype=cos_dt, new_k_norm_eps=float(rs.get("k_norm_eps", 1e-6)))
     if direct_out is not None:
         # MI355X: a single-block launch writes bf16(acc / l) itself; the stage-2 launch disappears (include/svk.h)
         assert direct_out.dtype == torch.bfloat16 and direct_out.shape == q.shape and direct_out.stride(-1) == 1
@@ -108,9 +134,9 @@ def h2o_score_args(attn_score, scale, *, cum_score=None, b_req_idx=None, b_seqle
 
 
 def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-            attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False, slot_page_size=0):
+            attn_score, block_seq, new_kv=None, direct_out=None, score_overwrite=False, slot_page_size=0, rotated_store=None):
     a = _stage1_args(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp,
-                     attn_score, block_seq, new_kv, direct_out, score_overwrite, slot_page_size)
+                     attn_score, block_seq, new_kv, direct_out, score_overwrite, slot_page_size, rotated_store)
     lib = _lib.load()
     _lib.check(lib.svk_flash_decode_stage1(C.byref(a), _lib.current_stream_handle()), lib)
 
@@ -118,13 +144,15 @@ def _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_o
 @torch.no_grad()
 def flash_decode_stage1(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out,
                         mid_out_logsumexp, block_seq, block_n=16, num_warps=2, num_stages=2, *, new_kv=None, direct_out=None,
-                        slot_page_size=0):
+                        slot_page_size=0, rotated_store=None):
     """`new_kv=(new_k, new_v, slot_mapping)` (MI355X extension): store this step's K/V rows inside the launch.
     `direct_out` [B, Hq, D] bf16 (MI355X extension, see `direct_out_supported`): the launch writes the attention output
     itself and no stage 2 is needed.  `slot_page_size` (MI355X extension): Req_to_tokens holds page slots of that many
-    tokens (include/svk.h)."""
+    tokens (include/svk.h).  `rotated_store` (MI355X extension, with `new_kv`): dict(raw_k, raw_v, slot_to_pos, cos_sin,
+    k_norm_weight=None, k_norm_eps=1e-6, row_lens=None) - k / v are a rotated VIEW of the pre-RoPE cache raw_k / raw_v: the raw rows go to
+    raw slot slot_mapping[b], the view's row of the newest position gets the k-normed, rotated key (include/svk.h)."""
     _launch(q, k, v, Req_to_tokens, B_req_idx, B_Seqlen, max_len_in_batch, mid_out, mid_out_logsumexp, None,
-            block_seq, new_kv, direct_out=direct_out, slot_page_size=slot_page_size)
+            block_seq, new_kv, direct_out=direct_out, slot_page_size=slot_page_size, rotated_store=rotated_store)
 
 
 @torch.no_grad()

@@ -260,6 +260,14 @@ class HipAttentionBackend:
         o = torch.empty_like(q)
         direct_out = o if direct else None
         slot_page_size = int((payload.metadata or {}).get("slot_page_size", 0))     # a page-slot table (Quest view), scored or not
+        # MI355X: a view whose newest row the manager left to this launch (DeltaKV sparse layers: raw rows to the pre-RoPE
+        # cache, the rotated row into the view; include/svk.h `new_cos_sin`)
+        rotated = (payload.metadata or {}).get("rotated_store")
+        rotated_args = None
+        if rotated is not None:
+            if new_kv is not None or meta.attn_score is not None:
+                raise RuntimeError("a rotated store rides in an unscored launch that carries no other store")
+            new_kv, rotated_args = rotated["new_kv"], rotated["args"]
         with profiler.record(f"decode_attention_stage1_{kind}"):
             if meta.attn_score is not None:
                 flash_decode_stage1_with_score(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
@@ -270,7 +278,7 @@ class HipAttentionBackend:
                 flash_decode_stage1(q, payload.k_cache, payload.v_cache, meta.active_slots, meta.req_indices,
                                     meta.context_lens, max_len_in_batch, mid_o, mid_o_logexpsum, block_seq,
                                     gqa_block_n, gqa_num_warps, new_kv=new_kv, direct_out=direct_out,
-                                    slot_page_size=slot_page_size)
+                                    slot_page_size=slot_page_size, rotated_store=rotated_args)
         if not direct:
             with profiler.record(f"decode_attention_stage2_{kind}"):
                 flash_decode_stage2(mid_o, mid_o_logexpsum, meta.context_lens, o, block_seq)

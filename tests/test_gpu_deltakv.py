@@ -399,6 +399,96 @@ def test_materialize_with_riding_raw_store_equals_store_then_materialize(cfg):
     assert not torch.equal(res[1][2], kc)
 
 
+@pytest.mark.parametrize("cfg", [dict(B=3, Hq=28, Hkv=4, D=128, W=300, knorm=False, layers=3, block_seq=32, row_lens=True),
+                                 dict(B=5, Hq=8, Hkv=1, D=128, W=77, knorm=True, layers=2, block_seq=64),
+                                 dict(B=2, Hq=8, Hkv=2, D=64, W=133, knorm=True, layers=1, block_seq=256, row_lens=True),
+                                 dict(B=2, Hq=8, Hkv=2, D=64, W=40, knorm=False, layers=4, block_seq=32, cos="bf16")])
+def test_rest_rows_ahead_plus_rotated_store_equal_the_view_launch(cfg):
+    """The sparse layers' view without a launch on the walk: (a) ONE `skip_new` launch over `layers` consecutive layers
+    writes every raw row of the views but the step's newest, (b) the attention launch stores the newest row itself -
+    raw into the layer's pre-RoPE cache, k-normed + rotated into the view (`rotated_store`).  Against the reference flow
+    (the view launch with the riding store, then the plain attention launch): views, raw caches, partials bit-identical;
+    rows of different lengths, a padded lane (slot -1), reconstruct-scratch columns left alone by both."""
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    from sparse_vllm_amd.kernels.gqa_flash_decoding_stage1 import flash_decode_stage1
+    B, Hq, Hkv, D, W, NL, bs = (cfg[k] for k in ("B", "Hq", "Hkv", "D", "W", "layers", "block_seq"))
+    S, P = 900, 1200
+    g = torch.Generator().manual_seed(B * 17 + W)
+    rng = np.random.default_rng(B * 3 + W)
+    kc = torch.randn((NL, S, Hkv, D), generator=g).to(torch.bfloat16).to(dev())
+    vc = torch.randn((NL, S, Hkv, D), generator=g).to(torch.bfloat16).to(dev())
+    s2p = torch.from_numpy(rng.integers(0, P, S).astype(np.int32)).to(dev())
+    inv = 1.0 / (1e6 ** (np.arange(D // 2) / (D // 2)))
+    ang = np.arange(P)[:, None] * inv[None, :]
+    cos_sin = t(np.concatenate((np.cos(ang), np.sin(ang)), axis=1).astype(np.float32))
+    if cfg.get("cos") == "bf16":
+        cos_sin = cos_sin.to(torch.bfloat16)
+    lens = rng.integers(max(8, W // 2), W + 1, B).astype(np.int32)
+    lens[0] = W
+    new_slots = rng.choice(np.arange(600, S), B, replace=False).astype(np.int32)
+    active = rng.integers(0, 600, (B, W)).astype(np.int32)
+    for b in range(B):
+        active[b, lens[b] - 1] = new_slots[b]              # the new token closes the row's raw tail
+        active[b, lens[b]:] = -1
+    abs_lens = rng.integers(1, P, B).astype(np.int32)      # absolute row lengths: the new token sits at position length - 1
+    s2p[torch.from_numpy(new_slots).long().to(dev())] = t(abs_lens - 1)
+    if B > 2:
+        new_slots[2] = -1                                   # a padded lane: nothing stored, its last column is a plain raw row
+    temp = torch.from_numpy(active[:, 2:6].copy()).to(dev())   # columns 2..5 are this step's reconstruct scratch
+    knw = torch.rand((NL, D), generator=g).add(0.5).to(dev()) if cfg["knorm"] else None
+    nk = torch.randn((NL, B, Hkv, D), generator=g).to(torch.bfloat16).to(dev())
+    nv = torch.randn((NL, B, Hkv, D), generator=g).to(torch.bfloat16).to(dev())
+    q = torch.randn((B, Hq, D), generator=g).to(torch.bfloat16).to(dev())
+    table = torch.arange(B * W, dtype=torch.int32, device=dev()).view(B, W)
+    rows = torch.arange(B, dtype=torch.int32, device=dev())
+    nblk = -(-W // bs)
+    lens_t, act_t, ns_t = t(lens), t(active), t(new_slots)
+
+    def attention(view_k, view_v, **extra):
+        mo = torch.zeros((B, Hq, nblk, D), dtype=torch.float32, device=dev())
+        ml = torch.zeros((B, Hq, nblk), dtype=torch.float32, device=dev())
+        flash_decode_stage1(q, view_k, view_v, table, rows, lens_t, W, mo, ml, bs, **extra)
+        return mo, ml
+
+    seeded = torch.randn((NL, B * W, Hkv, D), generator=g).to(torch.bfloat16).to(dev())   # what the scratch columns hold
+    # reference flow, layer by layer
+    ref = []
+    k_ref, v_ref = kc.clone(), vc.clone()
+    for l in range(NL):
+        ok, ov = seeded[l].clone(), seeded[l].flip(0).clone()
+        dk.deltakv_materialize_sparse_view(act_t, lens_t, s2p, None, k_ref[l], v_ref[l], ok, ov, cos_sin,
+                                           k_norm_weight=None if knw is None else knw[l], temp_slots=temp, temp_offset=2,
+                                           new_k=nk[l], new_v=nv[l], new_slots=ns_t, skip_temp=True)
+        ref.append((ok, ov) + attention(ok, ov))
+    # the split flow
+    k_new, v_new = kc.clone(), vc.clone()
+    views_k = seeded.clone()
+    views_v = torch.stack([seeded[l].flip(0) for l in range(NL)]).contiguous()
+    multi = NL > 1
+    dk.deltakv_materialize_sparse_view(act_t, lens_t, s2p, None, k_new if multi else k_new[0], v_new if multi else v_new[0],
+                                       views_k if multi else views_k[0], views_v if multi else views_v[0], cos_sin,
+                                       k_norm_weight=None if knw is None else (knw if multi else knw[0]), temp_slots=temp,
+                                       temp_offset=2, new_slots=ns_t, skip_temp=True, skip_new=True)
+    torch.cuda.synchronize()
+    for l in range(NL):
+        rot = dict(raw_k=k_new[l], raw_v=v_new[l], slot_to_pos=s2p, cos_sin=cos_sin,
+                   k_norm_weight=None if knw is None else knw[l], k_norm_eps=1e-6,
+                   row_lens=t(abs_lens) if cfg.get("row_lens") else None)      # (position by length instead of by slot)
+        mo, ml = attention(views_k[l], views_v[l], new_kv=(nk[l], nv[l], ns_t), rotated_store=rot)
+        torch.cuda.synchronize()
+        ok, ov, mo_ref, ml_ref = ref[l]
+        live = torch.zeros(B * W, dtype=torch.bool)
+        for b in range(B):
+            live[b * W: b * W + int(lens[b])] = True            # (both flows write the columns beyond a row's length too,
+        if B > 2:                                               #  except the split one for the padded lane's "newest" row)
+            live[2 * W + int(lens[2]) - 1] = True
+        live = live.to(dev())
+        assert torch.equal(views_k[l][live], ok[live]) and torch.equal(views_v[l][live], ov[live]), f"layer {l}"
+        assert torch.equal(mo, mo_ref) and torch.equal(ml, ml_ref), f"layer {l}"
+    assert torch.equal(k_new, k_ref) and torch.equal(v_new, v_ref)
+    assert not torch.equal(k_new, kc)
+
+
 @pytest.mark.parametrize("shape", [dict(rows=300, src=157, K=256, N=2048), dict(rows=129, src=129, K=64, N=200),
                                    dict(rows=5, src=9, K=512, N=136), dict(rows=260, src=33, K=32, N=128),
                                    dict(rows=70, src=50, K=256, N=204), dict(rows=64, src=64, K=256, N=520)])

@@ -414,3 +414,68 @@ def test_fused_second_linear_and_reconstruction_in_the_decode_steps(monkeypatch)
     assert calls["n"] >= 20                      # two sparse groups of two layers per step
     np.testing.assert_allclose(new, ref, rtol=2e-2, atol=2e-2)
     assert float((new == ref).mean()) > 0.9
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("shape", [dict(Hq=8, Hkv=2, D=64, inter=48, latent=32, group=16, lens=[148, 92, 61], keep=12, knorm=False),
+                                   dict(Hq=28, Hkv=4, D=128, inter=128, latent=64, group=32, lens=[300, 211, 97], keep=160, knorm=True)])
+def test_views_without_a_launch_on_the_walk_equal_the_view_launch_per_layer(shape, graph, monkeypatch):
+    """`SVK_DELTAKV_ROTATED_STORE` (default on): a sparse layer's view is complete without a launch of its own on the walk -
+    its raw rows are written for the whole layer group by one launch in front of the look-ahead reconstructions, the
+    step's newest row (raw into the layer cache, k-normed + rotated into the view) rides in the attention launch.  Against
+    the per-layer view launch (=0, deltakv_less_memory.py:1344-1402 with the riding store): outputs of every layer and the
+    sparse layers' raw caches bit-identical over steps with compression events, eager and replayed; the view launches per
+    step drop from one per sparse layer to one per layer group."""
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.kernels import deltakv_kernels as dk
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
+    L, B = 8, 3
+    Hq, Hkv, D = shape["Hq"], shape["Hkv"], shape["D"]
+    calls = {"n": 0}
+    orig = dk.deltakv_materialize_sparse_view
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(dk, "deltakv_materialize_sparse_view", counted)
+
+    def run(mode):
+        monkeypatch.setenv("SVK_DELTAKV_ROTATED_STORE", mode)
+        conf = Config.from_kwargs(
+            sparse_method="deltakv", num_hidden_layers=L, full_attention_layers="0,4", num_attention_heads=Hq,
+            num_key_value_heads=Hkv, head_dim=D, max_model_len=512, max_num_seqs_in_gpu=B + 1, sink_keep_tokens=4,
+            recent_keep_tokens=8, decode_keep_tokens=shape["keep"], deltakv_neighbor_count=2, deltakv_latent_dim=shape["latent"],
+            deltakv_latent_quant_bits=4, deltakv_latent_quant_group_size=shape["group"], deltakv_center_ratio=0.25,
+            allow_missing_deltakv_path=True, compressor_up_type="mlp_gelu", compressor_intermediate_size=shape["inter"],
+            full_layer_kv_quant_bits=4, full_layer_kivi_decode_block_seq=64, rope_theta=10000.0)
+        drv = SparseDecodeDriver(conf)
+        cm = drv.cache_manager
+        if shape["knorm"]:
+            gen = torch.Generator().manual_seed(4)
+            cm.deltakv_k_norm_weight = torch.rand((len(cm.deltakv_layer_ids), D), generator=gen).add(0.5).to(drv.device)
+        cm.permute_free_slots(7)
+        drv.admit_compressed_rows(B, shape["lens"], seed=3)
+        if graph:
+            drv.enable_decode_graph()
+        outs = torch.zeros((L, B, Hq, D), dtype=torch.bfloat16, device=drv.device)
+        got = []
+        calls["n"] = 0
+        for step in range(20):                        # two compression events per row
+            q, k, v = drv.random_step_inputs(seed=70 + step)
+            drv.step(q, k, v, outputs=outs)
+            torch.cuda.synchronize()
+            got.append(outs.view(torch.int16).cpu().numpy().copy())
+        raw = cm.deltakv_full_kv_cache.view(torch.int16).cpu().numpy().copy()
+        n_sparse, groups = len(cm.deltakv_layer_ids), 2
+        return np.stack(got), raw, calls["n"], n_sparse, groups
+
+    ref, raw_ref, n_ref, n_sparse, groups = run("0")
+    new, raw_new, n_new, _, _ = run("1")
+    np.testing.assert_array_equal(new, ref)
+    # the reconstruct-scratch slots of the raw caches are written by neither flow when the views take the reconstruction;
+    # everything the steps stored must agree
+    np.testing.assert_array_equal(raw_new, raw_ref)
+    if not graph:
+        assert n_ref == 20 * n_sparse and n_new == 20 * groups, (n_ref, n_new)
+    else:
+        assert n_new < n_ref
