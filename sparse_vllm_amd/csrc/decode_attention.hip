@@ -94,13 +94,13 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
   // requested here, beside the row length - the owner of the newest token then has one round trip (cos | sin and its
   // view slot) between the length and its stores instead of four
   bool rotated = false;
-  int rot_ns = -1, rot_pos = 0;
+  int rot_ns = -1, rot_len = 0;
   uint4 rot_k1 = make_uint4(0, 0, 0, 0), rot_k2 = rot_k1, rot_v1 = rot_k1, rot_v2 = rot_k1;
   if constexpr (MODE == SVK_SCORE_NONE) {
     rotated = a.new_cos_sin != nullptr;
     if (rotated) {
       rot_ns = a.slot_mapping[b];
-      if (a.new_row_lens != nullptr) rot_pos = a.new_row_lens[b];
+      if (a.new_row_lens != nullptr) rot_len = a.new_row_lens[b];
       if (lane < D / 16) {
         const int64_t src = (int64_t)b * a.new_stride_b + (int64_t)w * a.new_stride_h + lane * 8;
         rot_k1 = *reinterpret_cast<const uint4*>(a.new_k + src);
@@ -154,7 +154,7 @@ decode_stage1_kernel_v3(const SvkFlashDecodeStage1Args a) {
         if (rot_ns >= 0 && rot_ns < a.raw_num_slots && lane < LPH) {
           const int p = lane * 8;
           const int vslot = a.req_to_tokens[(int64_t)a.b_req_idx[b] * a.req_stride + (len - 1)];
-          const int pos = max(a.new_row_lens != nullptr ? rot_pos - 1 : a.new_slot_to_pos[rot_ns], 0);
+          const int pos = max(a.new_row_lens != nullptr ? rot_len - 1 : a.new_slot_to_pos[rot_ns], 0);
           float n1[8], n2[8];
           rope_row_norm<D>(rot_k1, rot_k2, a.new_k_norm_weight, a.new_k_norm_eps, p, n1, n2);
           uint4 o1, o2;

@@ -1057,7 +1057,7 @@ class DeltaKVCacheManager(CacheManager):
         """MI355X: a sparse layer's view launch on the walk (`get_layer_compute_view`: 7 us at one row, 20 us at four beside
         the look-ahead - a chain of dependent loads for a few hundred rows) has nothing left to do once (a) the raw rows of
         the view that exist BEFORE the step - sink + buffered tail - are written for every layer of the group by ONE launch
-        on the look-ahead stream, in front of the group's reconstructions, and (b) the step's newest row rides in the
+        at the head of the group (while the walk waits for the first reconstruction anyway), and (b) the step's newest row rides in the
         layer's attention launch (`rotated_store`).  Here: (a)."""
         if not self._rotated_store_enabled() or not self.recon_into_view or view_geom is None:
             return
@@ -1082,21 +1082,15 @@ class DeltaKVCacheManager(CacheManager):
                 knw = self._k_norm_weight_f32 = (self.deltakv_k_norm_weight.float().contiguous(),
                                                  (self.deltakv_k_norm_weight.data_ptr(), self.deltakv_k_norm_weight._version))
             knw = knw[0]
-        with torch.cuda.stream(sides[0]):
-            dk.deltakv_materialize_sparse_view(
-                active_slots, view_lens, self.deltakv_slot_to_pos, None,
-                self.deltakv_full_kv_cache[0, l0:l1], self.deltakv_full_kv_cache[1, l0:l1],
-                view[0][:, :total], view[1][:, :total], self.cos_sin_cache,
-                k_norm_weight=None if knw is None else knw[l0:l1], k_norm_eps=float(self.deltakv_k_norm_eps),
-                temp_slots=self._ensure_decode_static_temp_slots(B, k_max), temp_offset=int(self.config.num_sink_tokens),
-                new_slots=new_slots, skip_temp=True, skip_new=True)
-            if len(sides) > 1:
-                ev = self.__dict__.get("_view_rest_event")
-                if ev is None:
-                    ev = self._view_rest_event = torch.cuda.Event()
-                ev.record(sides[0])
-        for side in sides[1:]:
-            side.wait_event(self._view_rest_event)
+        # on the walk's OWN stream: it has nothing to do until the group's first reconstruction lands (one launch group,
+        # ~50 us), and in front of the reconstructions on the look-ahead stream the launch would delay all of them
+        dk.deltakv_materialize_sparse_view(
+            active_slots, view_lens, self.deltakv_slot_to_pos, None,
+            self.deltakv_full_kv_cache[0, l0:l1], self.deltakv_full_kv_cache[1, l0:l1],
+            view[0][:, :total], view[1][:, :total], self.cos_sin_cache,
+            k_norm_weight=None if knw is None else knw[l0:l1], k_norm_eps=float(self.deltakv_k_norm_eps),
+            temp_slots=self._ensure_decode_static_temp_slots(B, k_max), temp_offset=int(self.config.num_sink_tokens),
+            new_slots=new_slots, skip_temp=True, skip_new=True)
         self._view_rest_layers = set(range(l0, l1))
 
     def _recon_event(self, layer_idx: int):

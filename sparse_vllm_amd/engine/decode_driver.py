@@ -158,6 +158,11 @@ class SparseDecodeDriver:
             else:
                 if dev_active:
                     cm.device_step_mark_launched()   # the replayed graph carries the burst launches
+                else:
+                    # host-driven bookkeeping: post_forward reads the step's score buffers through the controller's layer
+                    # states, which a prefill step in between has reset - bind them again (the reference's runner calls
+                    # prepare_forward in front of every replay, model_runner.py:1447-1481; same persistent buffers)
+                    self._bind_states_for_replay()
                 self._graph.replay()
                 self.graph_stats["replayed"] += 1
         if after_layers is not None:
@@ -167,6 +172,11 @@ class SparseDecodeDriver:
         if append:
             for s in seqs:
                 s.append_token(0)
+
+    def _bind_states_for_replay(self):
+        cm, sc = self.cache_manager, self.sparse_controller
+        set_context(False, cache_manager=cm, sparse_controller=sc, is_long_text=bool(self.is_long_text))
+        sc.prepare_forward(self.seqs, False)
 
     # ------------------------------------------------------------------ one prefill chunk
     @torch.no_grad()

@@ -103,6 +103,19 @@ class SparseController:
             if budget is None:
                 return False
             trigger_len = self._snapkv_decode_trigger_len(budget)
+            if bool(getattr(self.config, "decode_cuda_graph", False)) and getattr(self.cache_manager, "_device_step", None) is None:
+                # host-driven steps under graph replay (:1977-1996): a replayed graph cannot start to collect scores on the
+                # step that evicts, so every graph family whose capacity reaches the trigger collects them on every step
+                # (the device-resident step does the same for another reason: prepare_forward)
+                state = self.layer_batch_sparse_states[layer_idx]
+                cap = getattr(self.cache_manager, "_decode_static_max_context_len", None)
+                cur = state.max_context_len
+                if cap is None or (cur is not None and int(cap) < int(cur)):
+                    raise RuntimeError("SnapKV decode CUDA graph requires a score capacity covering the "
+                                       f"current context: graph_capacity={cap} current={cur}.")
+                # (the reference also clamps a short-text family's capacity to the budget, i.e. collects nothing there;
+                #  collecting is a superset that changes no result, and synthetic drivers do not classify their batches)
+                return int(cap) >= trigger_len and int(cap) > int(budget)
             # eager decode only collects scores on the step that is about to evict (:2003-2007)
             kv_lens = self.cache_manager.decode_kv_lens_for_layer(layer_idx, seqs)
             return any(int(n) >= trigger_len and int(n) > budget for n in kv_lens)

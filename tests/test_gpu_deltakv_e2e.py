@@ -441,6 +441,8 @@ def test_views_without_a_launch_on_the_walk_equal_the_view_launch_per_layer(shap
 
     def run(mode):
         monkeypatch.setenv("SVK_DELTAKV_ROTATED_STORE", mode)
+        monkeypatch.setenv("SVK_DELTAKV_RECON_AHEAD", "1")        # the path under test lives behind the look-ahead ...
+        monkeypatch.setenv("SVK_DELTAKV_FUSE_RAW_STORE", "1")     # ... and the riding raw store
         conf = Config.from_kwargs(
             sparse_method="deltakv", num_hidden_layers=L, full_attention_layers="0,4", num_attention_heads=Hq,
             num_key_value_heads=Hkv, head_dim=D, max_model_len=512, max_num_seqs_in_gpu=B + 1, sink_keep_tokens=4,
