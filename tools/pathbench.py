@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from sparse_vllm_amd.config import Config
+if os.environ.get("SVK_AB_LIB"):          # developer A/B: another build of the library (e.g. sparse_vllm_amd/libsvk_ab.so)
+    from sparse_vllm_amd import _lib as _svk_lib
+    _svk_lib.LIB_PATH = os.path.abspath(os.environ["SVK_AB_LIB"])
 from sparse_vllm_amd.engine.decode_driver import capture_without_gc
 from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
 
