@@ -56,6 +56,40 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(1.0f - ec, x);
 }
 
+// The GELU of a bf16-rounded Linear output is a function of 16 bits.  Kernels whose threads each evaluate a few hundred
+// elements build a table of it in LDS once - with the very formula above, so every output is bit-identical to the
+// arithmetic form - for the exponents 2^-16 .. 2^4 of both signs (5120 entries, 10 KB) and gather from it: ~6 integer
+// instructions and one ds_read_u16 per element instead of ~22 vector instructions with two transcendentals.  Values outside
+// the table (|x| < 2^-16, |x| >= 16, inf / nan) take the arithmetic form on the spot.
+constexpr int kGeluE0 = 111, kGeluE1 = 131;                     // exponent fields [E0, E1): 2^-16 .. 2^4
+constexpr int kGeluHalf = (kGeluE1 - kGeluE0) * 128, kGeluN = 2 * kGeluHalf;
+
+__device__ __forceinline__ float gelu_erf(float y) {
+  return mul_rn(mul_rn(y, 0.5f), add_rn(1.0f, erf_fast(mul_rn(y, 0.70710678118654752440f))));
+}
+
+__device__ __forceinline__ void gelu_table_build(uint16_t* tab, int tid, int nt) {
+  for (int i = tid; i < kGeluN; i += nt) {
+    const uint32_t neg = i >= kGeluHalf;
+    const uint32_t bits = (uint32_t)(i - (int)neg * kGeluHalf + (kGeluE0 << 7)) | (neg << 15);
+    tab[i] = (uint16_t)pack2_bf16(gelu_erf(__builtin_bit_cast(float, bits << 16)), 0.f);
+  }
+}
+
+// bf16 pair (low | high << 16) -> bf16 pair of their GELUs
+__device__ __forceinline__ uint32_t gelu_table_pair(const uint16_t* tab, uint32_t pair) {
+  const uint32_t u0 = pair & 0xffffu, u1 = pair >> 16;
+  const uint32_t i0 = (u0 & 0x7fffu) - (uint32_t)(kGeluE0 << 7), i1 = (u1 & 0x7fffu) - (uint32_t)(kGeluE0 << 7);
+  const bool in0 = i0 < (uint32_t)kGeluHalf, in1 = i1 < (uint32_t)kGeluHalf;
+  uint32_t g0 = tab[in0 ? i0 + (u0 >> 15) * kGeluHalf : 0u];
+  uint32_t g1 = tab[in1 ? i1 + (u1 >> 15) * kGeluHalf : 0u];
+  if (__builtin_expect(!(in0 && in1), 0)) {
+    if (!in0) g0 = pack2_bf16(gelu_erf(__builtin_bit_cast(float, u0 << 16)), 0.f) & 0xffffu;
+    if (!in1) g1 = pack2_bf16(gelu_erf(__builtin_bit_cast(float, u1 << 16)), 0.f) & 0xffffu;
+  }
+  return g0 | (g1 << 16);
+}
+
 template <bool GELU, int KT>
 __global__ void __launch_bounds__(256) dequant_linear_act_kernel(const SvkDequantLinearArgs a_in, const SvkDequantLinearBatch lb) {
   extern __shared__ __attribute__((aligned(16))) uint16_t xs[];      // [kBM][K + 8] bf16
@@ -265,9 +299,9 @@ __global__ void __launch_bounds__(256) dequant_linear_act_kernel(const SvkDequan
 // three per CU, which is what keeps the 768 workgroups of a 2048-row launch resident together.
 constexpr int kM2 = 64, kSub = 64, kNSub = 4, kLdx2 = 256 + 16, kLdy2 = kSub + 8;
 
-template <bool GELU>
+template <bool GELU, bool TABLE>
 __global__ void __launch_bounds__(256) dequant_linear_act_k256_kernel(const SvkDequantLinearArgs a_in, const SvkDequantLinearBatch lb) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];      // [kM2][kLdx2] bf16 | 2 x [kM2][kLdy2] bf16
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];      // [kM2][kLdx2] bf16 | 2 x [kM2][kLdy2] bf16 | GELU table
   SvkDequantLinearArgs a = a_in;
   if (gridDim.z > 1) {
     const int64_t z = blockIdx.z;
@@ -283,6 +317,7 @@ __global__ void __launch_bounds__(256) dequant_linear_act_k256_kernel(const SvkD
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, kc = lane >> 4;
   uint16_t* ys = xs + kM2 * kLdx2;
+  [[maybe_unused]] uint16_t* gtab = ys + 2 * kM2 * kLdy2;
   auto load_w = [&](int ns, uint4 (&wf)[KS]) {
     const int n = min(nb0 + ns * kSub + w * 16 + fr, a.n - 1);            // clamped: features past N are never stored
     const uint16_t* wr = a.weight + (int64_t)n * a.weight_stride + kc * 8;
@@ -296,12 +331,19 @@ __global__ void __launch_bounds__(256) dequant_linear_act_k256_kernel(const SvkD
     const int r = tid >> 2, qd = tid & 3;
     const int row = m0 + r;
     uint16_t* dst = xs + r * kLdx2 + qd * 64;
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+    uint32_t sv = 0, mv = 0;
     if (row < a.rows) {
       const int64_t src = a.row_index ? max(a.row_index[row], 0) : row;
       const int32_t* pw = a.packed + src * a.packed_stride + qd * 8;
-      const uint4 c0 = *reinterpret_cast<const uint4*>(pw), c1 = *reinterpret_cast<const uint4*>(pw + 4);
-      const uint32_t sv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.scale) + src * a.scale_stride + qd * 2);
-      const uint32_t mv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.mn) + src * a.scale_stride + qd * 2);
+      c0 = *reinterpret_cast<const uint4*>(pw);
+      c1 = *reinterpret_cast<const uint4*>(pw + 4);
+      sv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.scale) + src * a.scale_stride + qd * 2);
+      mv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.mn) + src * a.scale_stride + qd * 2);
+    }
+    // the GELU table is built while the row index -> codes round trips are in flight
+    if constexpr (GELU && TABLE) gelu_table_build(gtab, tid, 256);
+    if (row < a.rows) {
       const float scs[2] = {bf16_lo(sv), bf16_hi(sv)}, mns[2] = {bf16_lo(mv), bf16_hi(mv)};
       const uint32_t wd[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
@@ -352,12 +394,16 @@ __global__ void __launch_bounds__(256) dequant_linear_act_k256_kernel(const SvkD
       // (bf16 rounding of the Linear output by v_cvt_pk_bf16_f32 and a shift back: see the row-walking kernel below)
       const uint32_t r01 = pack2_bf16(acc[j][0] + bias[0], acc[j][1] + bias[1]);
       const uint32_t r23 = pack2_bf16(acc[j][2] + bias[2], acc[j][3] + bias[3]);
-      float y[4] = {bf16_lo(r01), bf16_hi(r01), bf16_lo(r23), bf16_hi(r23)};
-      if (GELU) {
+      if constexpr (GELU && TABLE) {
+        *reinterpret_cast<uint2*>(yb + (j * 16 + fr) * kLdy2 + nl) = make_uint2(gelu_table_pair(gtab, r01), gelu_table_pair(gtab, r23));
+      } else {
+        float y[4] = {bf16_lo(r01), bf16_hi(r01), bf16_lo(r23), bf16_hi(r23)};
+        if (GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = mul_rn(mul_rn(y[r], 0.5f), add_rn(1.0f, erf_fast(mul_rn(y[r], 0.70710678118654752440f))));
+          for (int r = 0; r < 4; ++r) y[r] = gelu_erf(y[r]);
+        }
+        *reinterpret_cast<uint2*>(yb + (j * 16 + fr) * kLdy2 + nl) = make_uint2(pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3]));
       }
-      *reinterpret_cast<uint2*>(yb + (j * 16 + fr) * kLdy2 + nl) = make_uint2(pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3]));
     }
     __syncthreads();
     // 64 rows x 128 B: two 16-byte segments per thread
@@ -395,10 +441,10 @@ __global__ void __launch_bounds__(256) dequant_linear_act_k256_kernel(const SvkD
 // (blockIdx.y, + gridDim.y, ...), the codes / scales of the next tile in flight under the current one: weight traffic
 // divided by `tiles`, same arithmetic element for element (bit-identical outputs).
 // ------------------------------------------------------------------------------------------------
-template <bool GELU>
+template <bool GELU, bool TABLE>
 __global__ void __launch_bounds__(256) dequant_linear_act_k256_rows_kernel(const SvkDequantLinearArgs a_in, const SvkDequantLinearBatch lb,
                                                                            int row_tiles) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];      // [kM2][kLdx2] bf16 | 2 x [kM2][kLdy2] bf16
+  extern __shared__ __attribute__((aligned(16))) uint16_t xs[];      // [kM2][kLdx2] bf16 | 2 x [kM2][kLdy2] bf16 | GELU table
   SvkDequantLinearArgs a = a_in;
   if (gridDim.z > 1) {
     const int64_t z = blockIdx.z;
@@ -414,6 +460,8 @@ __global__ void __launch_bounds__(256) dequant_linear_act_k256_rows_kernel(const
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, kc = lane >> 4;
   uint16_t* ys = xs + kM2 * kLdx2;
+  [[maybe_unused]] uint16_t* gtab = ys + 2 * kM2 * kLdy2;
+  if constexpr (GELU && TABLE) gelu_table_build(gtab, threadIdx.x, 256);       // (the first tile's barrier publishes it)
   // weights of the workgroup's 256 features: lane (fr, kc) of wave w holds row nb0 + ns*64 + w*16 + fr, K chunks kc*8 + ks*32
   uint4 wf[kNSub][KS];
 #pragma unroll
@@ -501,12 +549,16 @@ __global__ void __launch_bounds__(256) dequant_linear_act_k256_rows_kernel(const
         // instead of the integer form of bf16_round (eight instructions per value; same bits for finite values)
         const uint32_t r01 = pack2_bf16(acc[j][0] + bias[ns][0], acc[j][1] + bias[ns][1]);
         const uint32_t r23 = pack2_bf16(acc[j][2] + bias[ns][2], acc[j][3] + bias[ns][3]);
-        float y[4] = {bf16_lo(r01), bf16_hi(r01), bf16_lo(r23), bf16_hi(r23)};
-        if (GELU) {
+        if constexpr (GELU && TABLE) {
+          *reinterpret_cast<uint2*>(yb + (j * 16 + fr) * kLdy2 + nl) = make_uint2(gelu_table_pair(gtab, r01), gelu_table_pair(gtab, r23));
+        } else {
+          float y[4] = {bf16_lo(r01), bf16_hi(r01), bf16_lo(r23), bf16_hi(r23)};
+          if (GELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) y[r] = mul_rn(mul_rn(y[r], 0.5f), add_rn(1.0f, erf_fast(mul_rn(y[r], 0.70710678118654752440f))));
+            for (int r = 0; r < 4; ++r) y[r] = gelu_erf(y[r]);
+          }
+          *reinterpret_cast<uint2*>(yb + (j * 16 + fr) * kLdy2 + nl) = make_uint2(pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3]));
         }
-        *reinterpret_cast<uint2*>(yb + (j * 16 + fr) * kLdy2 + nl) = make_uint2(pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3]));
       }
       __syncthreads();
 #pragma unroll
@@ -569,12 +621,18 @@ int launch_dequant_linear_act(const SvkDequantLinearArgs* a, const SvkDequantLin
     const int groups = max(1, 512 / (int)(grid2.x * grid2.z));
     if (rows_form && row_tiles >= 2 * groups) {
       const dim3 grid3(grid2.x, groups, grid2.z);
-      if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_k256_rows_kernel<true>), grid3, block, shm2, s, *a, lb, row_tiles);
-      else hipLaunchKernelGGL((dequant_linear_act_k256_rows_kernel<false>), grid3, block, shm2, s, *a, lb, row_tiles);
+      // (SVK_DQL_GELU_TABLE=0: the arithmetic GELU, the A/B reference of the table form - same bits)
+      static const bool gelu_table = getenv("SVK_DQL_GELU_TABLE") == nullptr || atoi(getenv("SVK_DQL_GELU_TABLE")) != 0;
+      if (a->activation == 1 && gelu_table)
+        hipLaunchKernelGGL((dequant_linear_act_k256_rows_kernel<true, true>), grid3, block, shm2 + sizeof(uint16_t) * kGeluN, s, *a, lb, row_tiles);
+      else if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_k256_rows_kernel<true, false>), grid3, block, shm2, s, *a, lb, row_tiles);
+      else hipLaunchKernelGGL((dequant_linear_act_k256_rows_kernel<false, false>), grid3, block, shm2, s, *a, lb, row_tiles);
       return check_launch(who);
     }
-    if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_k256_kernel<true>), grid2, block, shm2, s, *a, lb);
-    else hipLaunchKernelGGL((dequant_linear_act_k256_kernel<false>), grid2, block, shm2, s, *a, lb);
+    // (one row tile per workgroup = 64 elements per thread: the table form - built under the code loads' round trips,
+    //  TABLE = true - measures 20.9 against 20.5 us at 2 x 2048 rows; the arithmetic form stays)
+    if (a->activation == 1) hipLaunchKernelGGL((dequant_linear_act_k256_kernel<true, false>), grid2, block, shm2, s, *a, lb);
+    else hipLaunchKernelGGL((dequant_linear_act_k256_kernel<false, false>), grid2, block, shm2, s, *a, lb);
     return check_launch(who);
   }
   if (a->k == 256 && (a->packed_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(a->packed) % 16) == 0) {
