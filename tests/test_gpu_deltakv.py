@@ -525,6 +525,52 @@ def test_dequant_linear_act_matches_separate_ops(shape, act):
                                rtol=2e-2, atol=2e-2)
 
 
+def test_dequant_linear_act_row_walking_form_and_its_gelu_table():
+    """Launches with many row tiles (2 layers x 8192 rows: a four-row DeltaKV step) take the row-walking kernel, whose GELU is
+    gathered from an LDS table built with the kernel's own formula for |x| in [2^-16, 16) and evaluated arithmetically
+    outside.  Against the numpy restatement (same rounding points as `test_dequant_linear_act_matches_separate_ops`), with
+    bias columns that push whole features out of the table's range on both sides (|x| >= 16, |x| tiny), and bit for bit
+    against the one-tile-per-workgroup kernel (arithmetic GELU) on the same rows, 64 at a time."""
+    import math
+    from scipy.special import erf
+    from sparse_vllm_amd.kernels.deltakv_kernels import dequant_linear_act, dequantize_grouped
+    L, rows, src, K, N = 2, 8192, 9000, 256, 2048
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((L, src, K)).astype(np.float32)
+    packs = [od.quantize_pack_grouped(x[l], 32, 4) for l in range(L)]
+    code = np.stack([p[0] for p in packs])
+    scale = bf16_round(np.stack([p[1] for p in packs]))
+    mn = bf16_round(np.stack([p[2] for p in packs]))
+    W = bf16_round((rng.standard_normal((L, N, K)) / math.sqrt(K)).astype(np.float32))
+    b = (rng.standard_normal((L, N)) * 0.1).astype(np.float32)
+    W[:, 0:8] = 0.0                                           # features whose pre-activation is the bias alone:
+    b[:, 0:8] = [30.0, -30.0, 16.0, -16.0, 1e-6, -1e-6, 0.0, 15.9375]       # beyond the table on both sides, inside at its edge
+    b[:, 8:12] = [15.5, -15.5, 16.5, -16.5]                   # and features that straddle +-16 row by row
+    b = bf16_round(b)
+    ridx = rng.integers(0, src, size=rows).astype(np.int32)
+    out = torch.empty((L, rows, N), dtype=torch.bfloat16, device=dev())
+    dequant_linear_act(t(code), to_bf16(scale), to_bf16(mn), 32, to_bf16(W), to_bf16(b), activation="gelu", row_index=t(ridx),
+                       out=out, layers=True)
+    got = out.float().cpu().numpy()
+    for l in range(L):
+        # (the dequantised operand: the stand-alone kernel's bf16 output, pinned against the oracle by its own tests)
+        xd = dequantize_grouped(t(code[l]), to_bf16(scale[l]), to_bf16(mn[l]), 32, K, 4, row_index=t(ridx)).float().cpu().numpy()
+        y = bf16_round((xd.astype(np.float64) @ W[l].astype(np.float64).T + b[l].astype(np.float64)).astype(np.float32)).astype(np.float64)
+        ref = bf16_round((y * 0.5 * (1.0 + erf(y * math.sqrt(0.5)))).astype(np.float32))
+        np.testing.assert_allclose(got[l], ref, rtol=2e-2, atol=2e-2)
+        assert np.mean(got[l] == ref) > 0.97
+        np.testing.assert_array_equal(got[l][:, 0], np.full(rows, 30.0, np.float32))       # gelu(x) = x far right
+        assert np.all(np.abs(got[l][:, 1]) < 1e-30)                                         # ... and (-)0 far left
+        assert np.any(got[l][:, 8] > 16.0) and np.any(got[l][:, 8] < 16.0) and np.any(got[l][:, 10] < 16.0)
+    # the one-tile kernel (launches below the row-walking threshold) on the same rows: the same bits
+    for r0 in (0, 4096, rows - 64):
+        sl = slice(r0, r0 + 64)
+        small = torch.empty((L, 64, N), dtype=torch.bfloat16, device=dev())
+        dequant_linear_act(t(code), to_bf16(scale), to_bf16(mn), 32, to_bf16(W), to_bf16(b), activation="gelu",
+                           row_index=t(ridx[sl].copy()), out=small, layers=True)
+        assert torch.equal(small, out[:, sl])
+
+
 @pytest.mark.parametrize("n,k", [(262144, 2048), (5000, 2048), (3000, 1000), (70000, 4096), (300, 7), (24576, 64)])
 @pytest.mark.parametrize("kind", ["f32", "bf16", "ties"])
 def test_topk_sorted_desc_equals_stable_argsort(n, k, kind):
