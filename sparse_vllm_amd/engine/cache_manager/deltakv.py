@@ -1010,7 +1010,7 @@ class DeltaKVCacheManager(CacheManager):
         for side in sides:
             side.wait_stream(main)                   # the plan (and everything before it) is complete for the side streams
         stack = self._stacked_up_weights()
-        sub = self._recon_sub_batch()
+        sub = self._recon_sub_batch(n)
         if stack is not None and sub > 1 and view_table is not None:
             self._views_rest_ahead(layers, view_table, view_geom, sides)
         if stack is None or sub <= 1:
@@ -1026,7 +1026,7 @@ class DeltaKVCacheManager(CacheManager):
             # enough that the main stream can start on the group's first layers while the rest is still in flight.
             # The sub-batches alternate between the side streams: at one or a few rows none of the three launches
             # fills the chip, and the chain of launches - not the CUs - is what the walk of the layers waits for.
-            sizes, c0, ci = self._recon_sub_batches(), 0, 0
+            sizes, c0, ci = self._recon_sub_batches(n), 0, 0
             while c0 < len(layers):
                 n_c = sizes[min(ci, len(sizes) - 1)]
                 chunk = layers[c0: c0 + n_c]
@@ -1100,6 +1100,8 @@ class DeltaKVCacheManager(CacheManager):
         return ev
 
     _RECON_SUB_BATCHES = [2]
+    _RECON_SUB_BATCHES_WIDE = [4]           # ... for launches of at least _RECON_WIDE_TOKENS selected tokens (rows x keep)
+    _RECON_WIDE_TOKENS = 4096
     _RECON_STREAMS = 1
 
     @classmethod
@@ -1110,17 +1112,19 @@ class DeltaKVCacheManager(CacheManager):
     _LAYER_VIEWS_MAX_BYTES = 16 << 30
 
     @classmethod
-    def _recon_sub_batches(cls) -> list[int]:
-        """Layers per look-ahead launch group (the last value repeats).  Two balances the side stream against the main
-        stream's per-layer chain (measured 1 / 2 / 3 / 4 layers -> 1.88 / 1.62 / 1.66 / 1.73 ms per 256 k step)."""
+    def _recon_sub_batches(cls, n_tokens: int = 0) -> list[int]:
+        """Layers per look-ahead launch group (the last value repeats).  At one row (2048 selected tokens) two balances the
+        side stream against the main stream's per-layer chain (1 / 2 / 3 / 4 layers -> 1.40 / 1.35 / 1.41-1.48 / 1.42 ms per
+        256 k step); at four rows (8192 tokens) the launches fill the chip several times over and fewer, larger ones win
+        (2 / 3 / 4 / 5 / 6 layers -> 3.36-3.38 / 3.29-3.32 / 3.24-3.32 / 3.26 / 3.26 ms; at two rows 2 / 4 layers -> 2.04 / 2.00 ms)."""
         env = os.environ.get("SVK_DELTAKV_RECON_SUB")          # developer knob: "1,2" = a first launch group of one layer, then twos
         if env:
             return [max(1, int(x)) for x in env.split(",") if x.strip()]
-        return list(cls._RECON_SUB_BATCHES)
+        return list(cls._RECON_SUB_BATCHES_WIDE if int(n_tokens) >= cls._RECON_WIDE_TOKENS else cls._RECON_SUB_BATCHES)
 
     @classmethod
-    def _recon_sub_batch(cls) -> int:
-        return max(cls._recon_sub_batches())
+    def _recon_sub_batch(cls, n_tokens: int = 0) -> int:
+        return max(cls._recon_sub_batches(n_tokens))
 
     def _stacked_up_weights(self):
         """(W1 [Ls, hid, K], b1 [Ls, hid], W2 [Ls, out, hid], b2 [Ls, out]) of the sparse layers' compress_up modules as
@@ -1162,7 +1166,7 @@ class DeltaKVCacheManager(CacheManager):
             if len(store) >= 4 * self._recon_stream_count():     # a handful of token counts at most (batch compositions come and go)
                 torch.cuda.synchronize(self.device)
                 store.clear()
-            kb = max(k, self._recon_sub_batch())
+            kb = max(k, self._recon_sub_batch(n))
             hbuf = torch.zeros((kb, n, hid + self._RECON_PAD), dtype=torch.bfloat16, device=self.device)
             hbuf[:, :, hid] = 1.0                                   # the bias feature; the kernel below writes [:, :, :hid] only
             cur = [hbuf, None]                                      # (the delta buffer only if the library GEMM runs)

@@ -481,3 +481,48 @@ def test_views_without_a_launch_on_the_walk_equal_the_view_launch_per_layer(shap
         assert n_ref == 20 * n_sparse and n_new == 20 * groups, (n_ref, n_new)
     else:
         assert n_new < n_ref
+
+
+def test_lookahead_launch_group_sizes_do_not_change_the_steps(monkeypatch):
+    """The look-ahead reconstructs the sparse layers of a layer group in launch groups of 2 layers (4 from 4096 selected
+    tokens on: `_recon_sub_batches`).  Whatever the grouping - one layer per launch, twos, a whole group at once, mixed - the
+    decode steps are the same bit for bit (groups of 5 and 3 sparse layers, compression events, replayed)."""
+    from sparse_vllm_amd.config import Config
+    from sparse_vllm_amd.engine.cache_manager.deltakv import DeltaKVCacheManager
+    from tools.synthetic import SyntheticDecodeDriver as SparseDecodeDriver
+    L, B, Hq, Hkv, D = 10, 2, 8, 4, 128
+
+    def run(sizes, wide_from):
+        monkeypatch.setenv("SVK_DELTAKV_RECON_AHEAD", "1")
+        monkeypatch.delenv("SVK_DELTAKV_RECON_SUB", raising=False)
+        monkeypatch.setattr(DeltaKVCacheManager, "_RECON_SUB_BATCHES", list(sizes))
+        monkeypatch.setattr(DeltaKVCacheManager, "_RECON_SUB_BATCHES_WIDE", [4])
+        monkeypatch.setattr(DeltaKVCacheManager, "_RECON_WIDE_TOKENS", wide_from)
+        conf = Config.from_kwargs(
+            sparse_method="deltakv", num_hidden_layers=L, full_attention_layers="0,6", num_attention_heads=Hq,
+            num_key_value_heads=Hkv, head_dim=D, max_model_len=512, max_num_seqs_in_gpu=B + 1, sink_keep_tokens=4,
+            recent_keep_tokens=16, decode_keep_tokens=160, deltakv_neighbor_count=4, deltakv_latent_dim=64,
+            deltakv_latent_quant_bits=4, deltakv_latent_quant_group_size=32, deltakv_center_ratio=0.1,
+            allow_missing_deltakv_path=True, compressor_up_type="mlp_gelu", compressor_intermediate_size=128,
+            full_layer_kv_quant_bits=0, rope_theta=10000.0)
+        drv = SparseDecodeDriver(conf)
+        drv.cache_manager.permute_free_slots(5)
+        drv.admit_compressed_rows(B, [300, 211], seed=2)
+        drv.enable_decode_graph()
+        outs = torch.zeros((L, B, Hq, D), dtype=torch.bfloat16, device=drv.device)
+        got = []
+        for step in range(20):
+            q, k, v = drv.random_step_inputs(seed=90 + step)
+            drv.step(q, k, v, outputs=outs)
+            torch.cuda.synchronize()
+            got.append(outs.view(torch.int16).cpu().numpy().copy())
+        return np.stack(got)
+
+    ref = run([2], 1 << 30)
+    for sizes, wide_from in (([2], 0), ([8], 1 << 30), ([3, 2], 1 << 30), ([1, 4], 1 << 30)):
+        np.testing.assert_array_equal(run(sizes, wide_from), ref, err_msg=f"sizes={sizes} wide_from={wide_from}")
+    # one layer per launch everywhere is the per-layer path (library GEMMs for compress_up): the second Linear's fp32
+    # summation order differs, a handful of outputs land on the neighbouring bf16 value
+    one = run([1], 1 << 30)
+    assert float((one == ref).mean()) > 0.999
+    assert int(np.abs(one.astype(np.int32) - ref.astype(np.int32)).max()) <= 1          # (bf16 bit patterns: neighbours)

@@ -50,9 +50,9 @@ def build(name: str):
         drv.cache_manager.permute_free_pages(1)
         drv.admit_resident_rows(B, ctx, seed=0, device_rng=True)
         return drv, dict(batch=B, context=ctx, token_budget=cfg.quest_token_budget)
-    if name in ("deltakv", "deltakv_raw", "deltakv_b4"):
+    if name in ("deltakv", "deltakv_raw") or name.startswith("deltakv_b"):
         kivi = name != "deltakv_raw"
-        B, ctx = (4 if name == "deltakv_b4" else 1), 8 + 128 * (2048 if kivi else 512)     # tail == recent: room for `recent` decode steps
+        B, ctx = (int(name.split("_b")[1]) if name.startswith("deltakv_b") else 1), 8 + 128 * (2048 if kivi else 512)     # tail == recent: room for `recent` decode steps
         cfg = Config.from_kwargs(sparse_method="deltakv", full_attention_layers="0,1,2,8,18,27" if kivi else "0,1,2,8,18",
                                  sink_keep_tokens=8, recent_keep_tokens=128, decode_keep_tokens=2048, deltakv_neighbor_count=4,
                                  deltakv_latent_dim=256, deltakv_latent_quant_bits=4, deltakv_latent_quant_group_size=32,
@@ -89,7 +89,7 @@ def algorithmic_bytes_per_step(name: str, info: dict, mean_row_len: float | None
     if name.startswith("quest"):
         ctx, budget = info["context"], info["token_budget"]
         return B * ((L - 2) * (ctx * 128 + budget * 2056) + 2 * ctx * 2052)
-    if name in ("deltakv", "deltakv_raw", "deltakv_b4"):
+    if name in ("deltakv", "deltakv_raw") or name.startswith("deltakv_b"):
         ctx, nfull = info["context"], info["full_layers"]
         keep, K, view = 2048, 4, 8 + 2048 + 256
         sparse = keep * (K * 2048 + 160 + 2048) + view * 2052
@@ -309,6 +309,7 @@ def main():
     if args.recon_sub_batches:
         from sparse_vllm_amd.engine.cache_manager.deltakv import DeltaKVCacheManager
         DeltaKVCacheManager._RECON_SUB_BATCHES = [int(x) for x in args.recon_sub_batches.split(",")]
+        DeltaKVCacheManager._RECON_SUB_BATCHES_WIDE = list(DeltaKVCacheManager._RECON_SUB_BATCHES)
     for name in args.configs.split(","):
         try:
             res = measure(name, steps=args.steps, warmup=args.warmup, graph=args.graph)
