@@ -1009,6 +1009,10 @@ class DeltaKVCacheManager(CacheManager):
         main = torch.cuda.current_stream()
         for side in sides:
             side.wait_stream(main)                   # the plan (and everything before it) is complete for the side streams
+        # one event per launch group: the walk joins it at the group's first layer, the other layers of the launch group
+        # find it joined (every join of a replayed graph is a cross-queue dependency of 6-12 us, trace_step.py)
+        self._recon_event_of = {}
+        self._recon_joined = set()
         stack = self._stacked_up_weights()
         sub = self._recon_sub_batch(n)
         if stack is not None and sub > 1 and view_table is not None:
@@ -1020,6 +1024,7 @@ class DeltaKVCacheManager(CacheManager):
                     self._reconstruct_layer(self.deltakv_layer_to_idx[l], recon_pos, recon_latent, recon_out_slot, bufs[l],
                                             view_geom=view_geom)
                     self._recon_event(l).record(side)
+                self._recon_event_of[l] = l
         else:
             # sub-batches of `sub` consecutive layers: one dequant + Linear + GELU launch, one batched GEMM and one
             # reconstruct launch per sub-batch instead of three launches per layer (48 -> ~28 us per layer), small
@@ -1027,6 +1032,27 @@ class DeltaKVCacheManager(CacheManager):
             # The sub-batches alternate between the side streams: at one or a few rows none of the three launches
             # fills the chip, and the chain of launches - not the CUs - is what the walk of the layers waits for.
             sizes, c0, ci = self._recon_sub_batches(n), 0, 0
+            # few selected tokens (one row): the residual loads of the WHOLE layer group as one launch in front of the
+            # reconstructions - at 2048 tokens a two-layer load is one latency-bound round of workgroups (21 us) and nine
+            # layers of it cost little more than two
+            load_first = (n < self._RECON_WIDE_TOKENS and len(sides) == 1 and len(layers) > sizes[0]
+                          and os.environ.get("SVK_DELTAKV_RECON_LOAD_FIRST", "1") != "0")
+            g_idx = [self.deltakv_layer_to_idx[l] for l in layers]
+            if load_first:
+                with torch.cuda.stream(sides[0]):
+                    self._reconstruct_layers_batched(g_idx, stack, recon_pos, recon_latent, recon_out_slot, view_geom=view_geom,
+                                                     buf_key="group", phase="load", buf_l0=g_idx[0], buf_layers=len(g_idx))
+            while load_first and c0 < len(layers):
+                n_c = sizes[min(ci, len(sizes) - 1)]
+                chunk = layers[c0: c0 + n_c]
+                with torch.cuda.stream(sides[0]):
+                    self._reconstruct_layers_batched([self.deltakv_layer_to_idx[l] for l in chunk], stack, recon_pos,
+                                                     recon_latent, recon_out_slot, view_geom=view_geom, buf_key="group",
+                                                     phase="recon", buf_l0=g_idx[0], buf_layers=len(g_idx))
+                    self._recon_event(chunk[0]).record(sides[0])
+                for l in chunk:
+                    self._recon_event_of[l] = chunk[0]
+                c0, ci = c0 + n_c, ci + 1
             while c0 < len(layers):
                 n_c = sizes[min(ci, len(sizes) - 1)]
                 chunk = layers[c0: c0 + n_c]
@@ -1035,8 +1061,9 @@ class DeltaKVCacheManager(CacheManager):
                     self._reconstruct_layers_batched([self.deltakv_layer_to_idx[l] for l in chunk], stack, recon_pos,
                                                      recon_latent, recon_out_slot, view_geom=view_geom,
                                                      buf_key=ci % len(sides))
-                    for l in chunk:
-                        self._recon_event(l).record(side)
+                    self._recon_event(chunk[0]).record(side)
+                for l in chunk:
+                    self._recon_event_of[l] = chunk[0]
                 c0, ci = c0 + n_c, ci + 1
         self._recon_ahead = {l: True for l in layers}
         return True
@@ -1153,8 +1180,11 @@ class DeltaKVCacheManager(CacheManager):
     _RECON_PAD = 64
     _RECON_GEMM_ROWS = 4096
 
-    def _reconstruct_layers_batched(self, l_idxs, stack, recon_pos, recon_latent, recon_out_slot, view_geom=None, buf_key=0):
-        """Residual load + reconstruction of consecutive sparse layers `l_idxs` (same plan) in three launches."""
+    def _reconstruct_layers_batched(self, l_idxs, stack, recon_pos, recon_latent, recon_out_slot, view_geom=None, buf_key=0,
+                                    phase=None, buf_l0=None, buf_layers=0):
+        """Residual load + reconstruction of consecutive sparse layers `l_idxs` (same plan) in three launches.
+        `phase`: "load" = the residual load only (hidden rows stay in the buffer, layer `buf_l0` at its row 0, room for
+        `buf_layers` layers), "recon" = what follows it for layers whose load an earlier call did; None = both."""
         w1, b1, w2, b2 = stack
         l0, l1 = int(l_idxs[0]), int(l_idxs[-1]) + 1
         assert list(l_idxs) == list(range(l0, l1))
@@ -1162,19 +1192,24 @@ class DeltaKVCacheManager(CacheManager):
         store = self.__dict__.setdefault("_recon_batch_bufs", {})
         cur = store.get((n, buf_key))          # one buffer pair per (token count, side stream), never freed while in use
         hid = int(w1.shape[1])
-        if cur is None or cur[0].shape[0] < k:
-            if len(store) >= 4 * self._recon_stream_count():     # a handful of token counts at most (batch compositions come and go)
+        off = 0 if buf_l0 is None else l0 - int(buf_l0)
+        need = max(k + off, int(buf_layers))
+        if cur is None or cur[0].shape[0] < need:
+            if len(store) >= 4 * (self._recon_stream_count() + 1):     # a handful of token counts at most (batch compositions come and go)
                 torch.cuda.synchronize(self.device)
                 store.clear()
-            kb = max(k, self._recon_sub_batch(n))
+            kb = max(need, self._recon_sub_batch(n))
             hbuf = torch.zeros((kb, n, hid + self._RECON_PAD), dtype=torch.bfloat16, device=self.device)
             hbuf[:, :, hid] = 1.0                                   # the bias feature; the kernel below writes [:, :, :hid] only
             cur = [hbuf, None]                                      # (the delta buffer only if the library GEMM runs)
             store[(n, buf_key)] = cur
-        hp = cur[0][:k]
-        dk.dequant_linear_act(self.deltakv_latent_cache[l0:l1], self.deltakv_latent_scales[l0:l1], self.deltakv_latent_mins[l0:l1],
-                              self._quant_group_size(), w1[l0:l1], b1[l0:l1], activation="gelu", row_index=recon_latent,
-                              out=hp[:, :, :hid], layers=True)
+        hp = cur[0][off: off + k]
+        if phase != "recon":
+            dk.dequant_linear_act(self.deltakv_latent_cache[l0:l1], self.deltakv_latent_scales[l0:l1], self.deltakv_latent_mins[l0:l1],
+                                  self._quant_group_size(), w1[l0:l1], b1[l0:l1], activation="gelu", row_index=recon_latent,
+                                  out=hp[:, :, :hid], layers=True)
+        if phase == "load":
+            return
         knw = self.deltakv_k_norm_weight
         view = self._recon_view_out(l0, l1, view_geom)
         if view is not None:
@@ -1264,7 +1299,10 @@ class DeltaKVCacheManager(CacheManager):
                                                       view_table=(active_slots, new_context_lens))
                         ahead = self._recon_ahead
                 if ahead.pop(int(layer_idx), False):
-                    torch.cuda.current_stream().wait_event(self._recon_events[int(layer_idx)])
+                    owner = self.__dict__.get("_recon_event_of", {}).get(int(layer_idx), int(layer_idx))
+                    if owner not in self._recon_joined:
+                        torch.cuda.current_stream().wait_event(self._recon_events[owner])
+                        self._recon_joined.add(owner)
                 else:
                     self._reconstruct_layer(l_idx, recon_pos, recon_latent, recon_out_slot, view_geom=geom)
             # static decode: the post-RoPE slots of this layer are exactly the reconstruct scratch slots the plan put
